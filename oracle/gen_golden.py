@@ -1,0 +1,466 @@
+"""Generate tests/golden/*.npz from the REAL reference imported on CPU.
+
+Run in the build container only:  python -m oracle.gen_golden
+(needs /root/reference; see oracle/ref_import.py).  The fixtures are data:
+seeded inputs and the outputs the reference code produced for them, plus the
+vectors held by the reference's own tests (captured by executing those tests
+with the function under test wrapped, or by reading the literals with `ast`).
+
+The reference's CUDA op `nms_gpu` cannot run here; wherever a fixture's
+outputs depend on it the C restatement (oracle/ivx_oracle.c) is injected and
+the fixture says so in `nms_source`.
+"""
+import ast
+import hashlib
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import ref_import, imvoxel_oracle as orc  # noqa: E402
+
+warnings.filterwarnings('ignore')
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(GOLD, exist_ok=True)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def sd_to_np(sd, prefix='sd::'):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items() if 'num_batches_tracked' not in k}
+
+
+def randomize_bn(module, gen):
+    for m in module.modules():
+        if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.BatchNorm2d)):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+
+
+# ------------------------------------------------------------------ cameras
+def look_at(eye, target, up=(0, 0, 1)):
+    """world->camera 4x4 (camera looks along +z, x right, y down)."""
+    eye, target, up = (np.asarray(v, np.float64) for v in (eye, target, up))
+    f = target - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(f, up)
+    r /= np.linalg.norm(r)
+    d = np.cross(f, r)
+    R = np.stack([r, d, f])
+    E = np.eye(4)
+    E[:3, :3] = R
+    E[:3, 3] = -R @ eye
+    return E.astype(np.float32)
+
+
+def kitti_like_meta(img_shape, ori_shape, t=(0.05, 0.1, 0.27)):
+    K = np.array([[721.5377, 0, 609.5593, 0], [0, 721.5377, 172.854, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    E = np.array([[0, -1, 0, t[0]], [0, 0, -1, t[1]], [1, 0, 0, t[2]], [0, 0, 0, 1]], np.float32)
+    return dict(img_shape=img_shape, ori_shape=ori_shape,
+                lidar2img=dict(intrinsic=K, extrinsic=[E], origin=np.array([34.56, 0, -1], np.float32)))
+
+
+def backproject_cases():
+    cases = {}
+    # A: KITTI-like single view, padded crop (img_shape < feature map), real-image ratio
+    K = np.array([[60., 0, 15.5, 0], [0, 60., 11.2, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    E = np.array([[0, -1, 0, 0.02], [0, 0, -1, 0.4], [1, 0, 0, 0.3], [0, 0, 0, 1]], np.float32)
+    cases['A'] = dict(meta=dict(img_shape=(88, 120, 3), ori_shape=(44, 60, 3),
+                                lidar2img=dict(intrinsic=K, extrinsic=[E], origin=np.array([3.0, 0, 0.2], np.float32))),
+                      feat_hw=(24, 32), C=8, n_voxels=(16, 12, 6), voxel_size=(.4, .4, .4), seed=0)
+    # B: two indoor views, one camera inside the grid (points behind the camera, w<=0)
+    Kb = np.array([[28.9, 0, 15.5, 0], [0, 28.9, 11.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    Eb = [look_at((2.0, 0.1, 0.6), (0, 0, 0.5)), look_at((0.2, 0.3, 0.5), (-2, 0.5, 0.4))]
+    cases['B'] = dict(meta=dict(img_shape=(96, 128, 3), ori_shape=(96, 128, 3),
+                                lidar2img=dict(intrinsic=Kb, extrinsic=Eb, origin=np.array([0, 0, .5], np.float32))),
+                      feat_hw=(24, 32), C=8, n_voxels=(12, 12, 6), voxel_size=(.25, .25, .25), seed=1)
+    # C: six cameras on a ring looking outwards (nuScenes-like; intrinsic=eye, K folded into extrinsic)
+    Kc = np.array([[20., 0, 16, 0], [0, 20., 12, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    Ec = []
+    for yaw in np.deg2rad([0, 55, 110, 180, -110, -55]):
+        eye = np.array([0.3 * np.cos(yaw), 0.3 * np.sin(yaw), 0.5])
+        Ec.append((Kc.astype(np.float64) @ look_at(eye, eye + np.array([np.cos(yaw), np.sin(yaw), -0.05])).astype(np.float64)).astype(np.float32))
+    cases['C'] = dict(meta=dict(img_shape=(96, 128, 3), ori_shape=(96, 128, 3),
+                                lidar2img=dict(intrinsic=np.eye(4, dtype=np.float32), extrinsic=Ec,
+                                               origin=np.array([0, 0, -.2], np.float32))),
+                      feat_hw=(24, 32), C=8, n_voxels=(14, 14, 4), voxel_size=(.5, .5, .5), seed=2)
+    # D: dyadic intrinsics / exact .5 pixel ties -> round-half-even, bit-exact projection
+    Kd = np.array([[8., 0, 8.5, 0], [0, 8., 6.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    Ed = np.array([[0, -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float32)
+    cases['D'] = dict(meta=dict(img_shape=(48, 64, 3), ori_shape=(48, 64, 3),
+                                lidar2img=dict(intrinsic=Kd, extrinsic=[Ed], origin=np.array([2.0, 0, 0], np.float32))),
+                      feat_hw=(12, 16), C=4, n_voxels=(8, 16, 8), voxel_size=(.5, .25, .25), seed=3)
+    # E: camera plane passes exactly through voxel corners (w == 0 -> inf / nan), 3 views, C=5 (odd)
+    Ke = np.array([[16., 0, 8, 0], [0, 16., 6, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    Ee = [np.array([[0, -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float32),
+          np.array([[0, -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, -0.5], [0, 0, 0, 1]], np.float32),
+          np.array([[1, 0, 0, 0], [0, 0, -1, 0], [0, 1, 0, 1.0], [0, 0, 0, 1]], np.float32)]
+    cases['E'] = dict(meta=dict(img_shape=(48, 64, 3), ori_shape=(48, 64, 3),
+                                lidar2img=dict(intrinsic=Ke, extrinsic=Ee, origin=np.array([0, 0, 0], np.float32))),
+                      feat_hw=(12, 16), C=5, n_voxels=(8, 8, 4), voxel_size=(.5, .5, .5), seed=4)
+    return cases
+
+
+def gen_backproject(ns):
+    det = ns.detector
+    out = {}
+    for name, c in backproject_cases().items():
+        meta = c['meta']
+        V = len(meta['lidar2img']['extrinsic'])
+        g = torch.Generator().manual_seed(c['seed'])
+        feat = torch.randn((V, c['C']) + c['feat_hw'], generator=g)
+        P = det.ImVoxelNet._compute_projection(meta, 4, None)
+        pts = det.get_points(torch.tensor(c['n_voxels']), torch.tensor(c['voxel_size']),
+                             torch.tensor(meta['lidar2img']['origin']))
+        h, w = meta['img_shape'][0] // 4, meta['img_shape'][1] // 4
+        vol, valid = det.backproject(feat[:, :, :h, :w], pts, P)
+        # index maps exactly as the reference computes them (:148-153)
+        p = pts.view(1, 3, -1).expand(V, 3, -1)
+        p = torch.cat((p, torch.ones_like(p[:, :1])), dim=1)
+        p23 = torch.bmm(P, p)
+        xi = (p23[:, 0] / p23[:, 2]).round().long()
+        yi = (p23[:, 1] / p23[:, 2]).round().long()
+        # view mean (:70-74)
+        vs = vol.sum(dim=0)
+        cnt = valid.sum(dim=0)
+        mean = vs / cnt
+        ok = cnt > 0
+        mean[:, ~ok[0]] = .0
+        pre = f'{name}::'
+        out.update({pre + 'feat': feat.numpy(), pre + 'intrinsic': meta['lidar2img']['intrinsic'],
+                    pre + 'extrinsic': np.stack(meta['lidar2img']['extrinsic']),
+                    pre + 'origin': meta['lidar2img']['origin'],
+                    pre + 'img_shape': np.array(meta['img_shape']), pre + 'ori_shape': np.array(meta['ori_shape']),
+                    pre + 'n_voxels': np.array(c['n_voxels']), pre + 'voxel_size': np.array(c['voxel_size'], np.float32),
+                    pre + 'projection': P.numpy(), pre + 'points': pts.numpy(),
+                    pre + 'xi': xi.numpy(), pre + 'yi': yi.numpy(), pre + 'valid': valid.numpy(),
+                    pre + 'volume': vol.numpy(), pre + 'mean': mean.numpy(), pre + 'mean_valid': ok.numpy()})
+        print('backproject', name, 'V', V, 'valid frac', float(valid.float().mean()), 'novalid', int((~ok).sum()))
+    np.savez_compressed(os.path.join(GOLD, 'backproject_cases.npz'), **out)
+
+
+def gen_fullsize_kitti(ns):
+    """Full-size KITTI unprojection: only hashes / sums are stored."""
+    det = ns.detector
+    meta = kitti_like_meta((384, 1280, 3), (384, 1280, 3), t=(0.0, 0.0, 0.0))
+    g = torch.Generator().manual_seed(1234)
+    feat = torch.randn((1, 64, 96, 320), generator=g)
+    P = det.ImVoxelNet._compute_projection(meta, 4, None)
+    pts = det.get_points(torch.tensor((216, 248, 12)), torch.tensor((.32, .32, .32)),
+                         torch.tensor(meta['lidar2img']['origin']))
+    vol, valid = det.backproject(feat, pts, P)
+    vs = vol.sum(0)
+    cnt = valid.sum(0)
+    mean = vs / cnt
+    ok = cnt > 0
+    mean[:, ~ok[0]] = .0
+    info = dict(seed=1234, feat_shape=[1, 64, 96, 320], n_voxels=[216, 248, 12], voxel_size=[.32, .32, .32],
+                intrinsic=meta['lidar2img']['intrinsic'].tolist(), extrinsic=[meta['lidar2img']['extrinsic'][0].tolist()],
+                origin=[34.56, 0, -1], valid_frac=float(ok.float().mean()), valid_sha256=sha(ok.numpy()),
+                mean_sha256=sha(mean.numpy()), mean_sum=float(mean.double().sum()), mean_absmax=float(mean.abs().max()),
+                projection=P.numpy().tolist(), feat_sha256=sha(feat.numpy()))
+    with open(os.path.join(GOLD, 'kitti_fullsize_backproject.json'), 'w') as f:
+        json.dump(info, f, indent=1)
+    print('fullsize kitti valid frac', info['valid_frac'])
+
+
+def gen_necks(ns):
+    nk = ns.necks
+    out = {}
+    g = torch.Generator().manual_seed(10)
+
+    def run(name, module, x):
+        torch.manual_seed(hash(name) % 1000)
+        randomize_bn(module, g)
+        # un-zero the zero-initialised residual BN gammas of the Atlas net so the test has signal
+        module.eval()
+        with torch.no_grad():
+            ys = module(x)
+        out.update(sd_to_np(module.state_dict(), f'{name}::sd::'))
+        out[f'{name}::x'] = x.numpy()
+        for i, y in enumerate(ys):
+            out[f'{name}::y{i}'] = y.numpy()
+        print('neck', name, [tuple(y.shape) for y in ys], 'absmax', [float(y.abs().max()) for y in ys])
+
+    torch.manual_seed(11)
+    run('kitti', nk.KittiImVoxelNeck(4, 8), torch.randn(2, 4, 7, 9, 12, generator=g))
+    torch.manual_seed(12)
+    run('nuscenes', nk.NuScenesImVoxelNeck(4, 8), torch.randn(1, 4, 10, 12, 12, generator=g))
+    torch.manual_seed(13)
+    run('fast', nk.FastIndoorImVoxelNeck(4, [1, 1, 1], 8), torch.randn(1, 4, 8, 8, 4, generator=g))
+    torch.manual_seed(14)
+    run('atlas', nk.ImVoxelNeck([4, 8, 16], 4, [1, 2, 2], [2, 1], False), torch.randn(1, 4, 8, 8, 8, generator=g))
+    np.savez_compressed(os.path.join(GOLD, 'necks.npz'), **out)
+
+
+def gen_anchor_head(ns):
+    ah = ns.anchor_head
+    from types import SimpleNamespace
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+
+    ns.nms.nms_gpu = orc.nms_gpu            # CUDA op replaced by the C restatement
+    ns.nms.nms_normal_gpu = orc.nms_normal_gpu
+    out = {}
+    for name, (H, W, ncls, ranges, sizes, test_cfg) in {
+        'kitti': (10, 12, 1, [[0, -39.68, -1.78, 69.12 - .32, 39.68 - .32, -1.78]], [[1.6, 3.9, 1.56]],
+                  dict(use_rotate_nms=True, nms_across_levels=False, nms_thr=0.01, score_thr=0.1, min_bbox_size=0,
+                       nms_pre=100, max_num=50)),
+        'nus': (9, 9, 1, [[-49.92, -49.92, -1.8, 49.92 - .64, 49.92 - .64, -1.8]], [[1.95, 4.60, 1.73]],
+                dict(use_rotate_nms=True, nms_across_levels=False, nms_thr=0.2, score_thr=0.05, min_bbox_size=0,
+                     nms_pre=60, max_num=20)),
+    }.items():
+        torch.manual_seed(20 if name == 'kitti' else 21)
+        head = ah.Anchor3DHead(num_classes=ncls, in_channels=16, train_cfg=None, test_cfg=Cfg(test_cfg),
+                               feat_channels=16, use_direction_classifier=True,
+                               anchor_generator=dict(type='Anchor3DRangeGenerator', ranges=ranges, sizes=sizes,
+                                                     rotations=[0, 1.57], reshape_out=True),
+                               diff_rad_by_sin=True, bbox_coder=dict(type='DeltaXYZWLHRBBoxCoder'),
+                               loss_cls=dict(type='FocalLoss', use_sigmoid=True))
+        with torch.no_grad():
+            head.conv_cls.weight.normal_(0, 0.5)
+            head.conv_cls.bias.fill_(-1.0)
+            head.conv_reg.weight.normal_(0, 0.05)
+            head.conv_dir_cls.weight.normal_(0, 0.3)
+        x = torch.randn(2, 16, H, W)
+        with torch.no_grad():
+            cls, reg, dr = head([x])
+        metas = [dict(box_type_3d=ns.lidar.LiDARInstance3DBoxes)] * 2
+        with torch.no_grad():
+            res = head.get_bboxes(cls, reg, dr, None, metas)
+        anchors = head.anchor_generator.grid_anchors([cls[0].shape[-2:]], device='cpu')[0]
+        pre = f'{name}::'
+        out.update(sd_to_np(head.state_dict(), pre + 'sd::'))
+        out.update({pre + 'x': x.numpy(), pre + 'cls': cls[0].numpy(), pre + 'reg': reg[0].numpy(),
+                    pre + 'dir': dr[0].numpy(), pre + 'anchors': anchors.numpy(),
+                    pre + 'ranges': np.array(ranges, np.float64), pre + 'sizes': np.array(sizes, np.float64),
+                    pre + 'test_cfg': np.array(json.dumps(test_cfg))})
+        for b, (boxes, scores, labels) in enumerate(res):
+            out[pre + f'boxes{b}'] = boxes.tensor.numpy()
+            out[pre + f'scores{b}'] = scores.numpy()
+            out[pre + f'labels{b}'] = labels.numpy()
+            print('anchor head', name, b, 'kept', len(scores))
+        out[pre + 'nms_source'] = np.array('oracle/ivx_oracle.c (reference CUDA op iou3d_cuda cannot run here)')
+    np.savez_compressed(os.path.join(GOLD, 'anchor_head.npz'), **out)
+
+    # full-size KITTI / nuScenes anchor grids: hashes + strided samples
+    info = {}
+    for name, (fm, ranges, sizes) in {
+        'kitti': ((246, 214), [[0, -39.68, -1.78, 69.12 - .32, 39.68 - .32, -1.78]], [[1.6, 3.9, 1.56]]),
+        'nuscenes': ((156, 156), [[-49.92, -49.92, -1.8, 49.92 - .64, 49.92 - .64, -1.8]], [[1.95, 4.60, 1.73]]),
+    }.items():
+        gen = ns.anchor.Anchor3DRangeGenerator(ranges=ranges, sizes=sizes, rotations=[0, 1.57], reshape_out=True)
+        a = gen.grid_anchors([fm], device='cpu')[0].numpy()
+        info[name] = dict(featmap=list(fm), ranges=ranges, sizes=sizes, rotations=[0, 1.57], shape=list(a.shape),
+                          sha256=sha(a), first=a[0].tolist(), last=a[-1].tolist(),
+                          strided=a[::9973].tolist())
+    with open(os.path.join(GOLD, 'anchors_fullsize.json'), 'w') as f:
+        json.dump(info, f, indent=1)
+
+
+def gen_box_utils(ns):
+    g = torch.Generator().manual_seed(30)
+    out = {}
+    val = torch.randn(64, generator=g) * 6
+    out['limit_period::val'] = val.numpy()
+    out['limit_period::o0.5'] = ns.utils.limit_period(val, 0.5, np.pi).numpy()
+    out['limit_period::o1'] = ns.utils.limit_period(val, 1, np.pi).numpy()
+    out['limit_period::o0'] = ns.utils.limit_period(val, 0, 2 * np.pi).numpy()
+    b = torch.randn(32, 5, generator=g)
+    out['xywhr::in'] = b.numpy()
+    out['xywhr::out'] = ns.utils.xywhr2xyxyr(b).numpy()
+    pts = torch.randn(16, 5, 3, generator=g)
+    ang = torch.randn(16, generator=g) * 2
+    out['rot::points'] = pts.numpy()
+    out['rot::angles'] = ang.numpy()
+    out['rot::axis2'] = ns.utils.rotation_3d_in_axis(pts, ang, axis=2).numpy()
+    anchors = torch.rand(40, 7, generator=g) * 3 + 0.5
+    deltas = torch.randn(40, 7, generator=g) * 0.3
+    out['coder::anchors'] = anchors.numpy()
+    out['coder::deltas'] = deltas.numpy()
+    out['coder::decoded'] = ns.coder.DeltaXYZWLHRBBoxCoder.decode(anchors, deltas).numpy()
+    # box ctor origin shift (base_box3d.py:63-66) + gravity centre
+    t = torch.rand(12, 7, generator=g) * 4
+    out['boxes::in'] = t.numpy()
+    out['boxes::depth_origin_555'] = ns.depth.DepthInstance3DBoxes(t, origin=(.5, .5, .5)).tensor.numpy()
+    out['boxes::lidar_bev'] = ns.lidar.LiDARInstance3DBoxes(t).bev.numpy()
+    out['boxes::lidar_gravity'] = ns.lidar.LiDARInstance3DBoxes(t).gravity_center.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'box_utils.npz'), **out)
+
+
+def gen_nms_vectors(ns):
+    """Vectors held by the reference's own tests: tests/test_nms.py (aligned_3d_nms,
+    captured by running the test with the function wrapped) and
+    tests/test_box3d.py::test_boxes3d_overlaps (literals read with ast; CUDA-only test)."""
+    out = {}
+    cap = {}
+    real = ns.nms.aligned_3d_nms
+
+    def spy(boxes, scores, classes, thresh):
+        r = real(boxes, scores, classes, thresh)
+        cap.update(boxes=boxes.numpy(), scores=scores.numpy(), classes=classes.numpy(), thresh=thresh, pick=r.numpy())
+        return r
+
+    sys.modules['mmdet3d.core.post_processing'].aligned_3d_nms = spy
+    src = open(os.path.join(ref_import.REF, 'tests/test_nms.py')).read()
+    scope = {}
+    exec(compile(src, 'test_nms.py', 'exec'), scope)
+    scope['test_aligned_3d_nms']()      # asserts pick == expected inside
+    sys.modules['mmdet3d.core.post_processing'].aligned_3d_nms = real
+    for k, v in cap.items():
+        out['aligned::' + k] = np.asarray(v)
+
+    tree = ast.parse(open(os.path.join(ref_import.REF, 'tests/test_box3d.py')).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'test_boxes3d_overlaps'][0]
+    want = {'boxes1_tensor', 'boxes2_tensor', 'expected_iou_tensor', 'expected_iof_tensor'}
+    for node in ast.walk(fn):
+        if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name) and node.targets[0].id in want:
+            name = node.targets[0].id
+            if name in out:
+                continue
+            lit = node.value.args[0]
+            out['overlaps::' + name] = np.array(ast.literal_eval(lit), np.float32)
+            if len([k for k in out if k.startswith('overlaps::')]) == 4:
+                break
+    # extra: random aligned-nms sets with distinct scores through the real reference
+    g = torch.Generator().manual_seed(40)
+    for i, n in enumerate([1, 7, 64, 300]):
+        c = torch.rand(n, 3, generator=g) * 4
+        s = torch.rand(n, 3, generator=g) * 1.5 + 0.1
+        boxes = torch.cat([c - s / 2, c + s / 2], 1)
+        scores = torch.rand(n, generator=g)
+        cls = torch.randint(0, 3, (n,), generator=g)
+        out[f'aligned_rand{i}::boxes'] = boxes.numpy()
+        out[f'aligned_rand{i}::scores'] = scores.numpy()
+        out[f'aligned_rand{i}::classes'] = cls.numpy()
+        out[f'aligned_rand{i}::pick'] = real(boxes, scores, cls, 0.25).numpy()
+    np.savez_compressed(os.path.join(GOLD, 'nms_vectors.npz'), **out)
+    print('nms vectors', sorted(out))
+
+
+def gen_e2e_small(ns):
+    """Reference ImVoxelNet.simple_test end to end (orchestration pin): a toy stride-4
+    backbone/FPN stand-in feeds the REAL extract_feat -> KittiImVoxelNeck -> Anchor3DHead
+    -> get_bboxes -> bbox3d2result.  The toy trunk's level-0 output is stored as an input."""
+    from torch import nn
+    R = ns.registries
+
+    class ToyBackbone(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = nn.Conv2d(3, 8, 4, 4)
+
+        def forward(self, x):
+            y = self.c(x)
+            return (y, y[..., ::2, ::2], y[..., ::4, ::4], y[..., ::8, ::8])
+
+        def init_weights(self, pretrained=None):
+            pass
+
+    class ToyFPN(nn.Module):
+        def forward(self, xs):
+            return [torch.tanh(x) for x in xs]
+
+        def init_weights(self):
+            pass
+
+    R['DET'].module_dict  # noqa
+    sys.modules['mmdet.models'].BACKBONES.register_module()(ToyBackbone)
+    R['NECKS'].register_module()(ToyFPN)
+    ns.nms.nms_gpu = orc.nms_gpu
+    ns.nms.nms_normal_gpu = orc.nms_normal_gpu
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+
+    test_cfg = dict(use_rotate_nms=True, nms_across_levels=False, nms_thr=0.01, score_thr=0.1, min_bbox_size=0,
+                    nms_pre=100, max_num=50)
+    n_voxels, vs = (20, 24, 12), (.32, .32, .32)
+    # anchor ranges follow the kitti config rule: grid extent shrunk by one voxel (imvoxelnet_kitti.py:30)
+    ox, oy = 3.2 + 0.5, 0.0
+    ranges = [[ox - 3.2, oy - 3.84, -1.78, ox + 3.2 - .32, oy + 3.84 - .32, -1.78]]
+    torch.manual_seed(50)
+
+    def super_init(self, pretrained=None):
+        return None
+    nn.Module.init_weights = super_init  # BaseDetector.init_weights stand-in (mmdet, logging only)
+    model = ns.detector.ImVoxelNet(
+        backbone=dict(type='ToyBackbone'), neck=dict(type='ToyFPN'),
+        neck_3d=dict(type='KittiImVoxelNeck', in_channels=8, out_channels=16),
+        bbox_head=dict(type='Anchor3DHead', num_classes=1, in_channels=16, feat_channels=16,
+                       use_direction_classifier=True,
+                       anchor_generator=dict(type='Anchor3DRangeGenerator', ranges=ranges, sizes=[[1.6, 3.9, 1.56]],
+                                             rotations=[0, 1.57], reshape_out=True),
+                       diff_rad_by_sin=True, bbox_coder=dict(type='DeltaXYZWLHRBBoxCoder'),
+                       loss_cls=dict(type='FocalLoss', use_sigmoid=True)),
+        n_voxels=n_voxels, voxel_size=vs, train_cfg=None, test_cfg=Cfg(test_cfg))
+    del nn.Module.init_weights
+    g = torch.Generator().manual_seed(51)
+    randomize_bn(model, g)
+    with torch.no_grad():
+        model.bbox_head.conv_cls.weight.normal_(0, 0.3)
+        model.bbox_head.conv_cls.bias.fill_(-0.5)
+        model.bbox_head.conv_reg.weight.normal_(0, 0.05)
+        model.bbox_head.conv_dir_cls.weight.normal_(0, 0.3)
+    model.eval()
+    B, H, W = 2, 96, 160
+    img = torch.randn(B, 1, 3, H, W, generator=g)
+    K = np.array([[36., 0, 40, 0], [0, 36., 22, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    metas = []
+    for b in range(B):
+        E = np.array([[0, -1, 0, 0.03 * b], [0, 0, -1, 0.2], [1, 0, 0, 0.1], [0, 0, 0, 1]], np.float32)
+        metas.append(dict(img_shape=(H - 8 * b, W - 12 * b, 3), ori_shape=((H - 8 * b) // 2, (W - 12 * b) // 2, 3),
+                          box_type_3d=ns.lidar.LiDARInstance3DBoxes,
+                          lidar2img=dict(intrinsic=K, extrinsic=[E], origin=np.array([ox, oy, -1.0], np.float32))))
+    with torch.no_grad():
+        x, valids, _ = model.extract_feat(img, metas, 'test')
+        res = model.simple_test(img, metas)
+        f = model.backbone(img.reshape(-1, 3, H, W))
+        fpn0 = model.neck(f)[0]
+    out = {}
+    out.update(sd_to_np(model.state_dict(), 'sd::'))
+    out.update({'fpn0': fpn0.numpy(), 'neck_out': x[0].numpy(), 'valids': valids.numpy(),
+                'n_voxels': np.array(n_voxels), 'voxel_size': np.array(vs, np.float32),
+                'ranges': np.array(ranges), 'test_cfg': np.array(json.dumps(test_cfg)),
+                'nms_source': np.array('oracle/ivx_oracle.c')})
+    for b in range(B):
+        m = metas[b]
+        out[f'meta{b}::img_shape'] = np.array(m['img_shape'])
+        out[f'meta{b}::ori_shape'] = np.array(m['ori_shape'])
+        out[f'meta{b}::intrinsic'] = m['lidar2img']['intrinsic']
+        out[f'meta{b}::extrinsic'] = np.stack(m['lidar2img']['extrinsic'])
+        out[f'meta{b}::origin'] = m['lidar2img']['origin']
+        out[f'res{b}::boxes'] = res[b]['boxes_3d'].tensor.numpy()
+        out[f'res{b}::scores'] = res[b]['scores_3d'].numpy()
+        out[f'res{b}::labels'] = res[b]['labels_3d'].numpy()
+        print('e2e sample', b, 'valid frac', float(valids[b].float().mean()), 'dets', len(res[b]['scores_3d']))
+    np.savez_compressed(os.path.join(GOLD, 'e2e_small.npz'), **out)
+
+
+def main():
+    ns = ref_import.load()
+    gen_backproject(ns)
+    gen_fullsize_kitti(ns)
+    gen_necks(ns)
+    gen_box_utils(ns)
+    gen_nms_vectors(ns)
+    gen_anchor_head(ns)
+    gen_e2e_small(ns)
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)))
+
+
+if __name__ == '__main__':
+    main()
