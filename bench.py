@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""bench.py -- ImVoxelNet inference throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL; weak scaling, per-GPU batch fixed)
+
+A step = one pass of the hot path (ImVoxelNet.simple_test: ResNet-50 + FPN -> unprojection -> KittiImVoxelNeck
+-> Anchor3DHead -> decode + rotated NMS -> D2H of detections [-> all-gather of detections when N > 1]) over one
+batch of synthetic KITTI-shaped input already resident in HBM.  Workload = BASELINE.json configs[1]:
+1 view 3x384x1280, 216x248x12 voxels, batch 4 per GPU, fp32 (the reference's arithmetic type).
+
+Prints ONE JSON line (rank 0) with `roofline` (the conv kernel on the 3-D neck, measured live with HIP events
+on the launch stream inside the timed region) and, at N == 1, `cpu_baseline` (the oracle's torch-fp32/C port of
+the same path timed on this box's host cores on one image).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BATCH_PER_GPU = 4
+
+
+def neck_flops_per_sample(nv, c_in, c_out):
+    """Algorithmic FLOPs (2 x MAC) of KittiImVoxelNeck for one sample (2603.4 GFLOP at KITTI)."""
+    X, Y, Z = nv
+    c1, c2, c4 = c_in, c_in * 2, c_in * 4
+    z2, z3 = (Z + 2 - 3) // 2 + 1, ((Z + 2 - 3) // 2 + 1 + 2 - 3) // 2 + 1
+    macs = 2 * X * Y * Z * c1 * c1 * 27
+    macs += X * Y * z2 * c2 * c1 * 27 + 2 * X * Y * z2 * c2 * c2 * 27
+    macs += X * Y * z3 * c4 * c2 * 27 + 2 * X * Y * z3 * c4 * c4 * 27
+    macs += (X - 2) * (Y - 2) * (z3 - 2) * c_out * c4 * 27
+    return 2.0 * macs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='samples per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0:
+        print(f'# note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE', file=sys.stderr)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    import imvoxelnet_amd as ia
+    from imvoxelnet_amd import dist as ivx_dist
+    from kitti_cfg import kitti_model_cfg, KITTI_TEST_CFG, kitti_meta
+
+    model = ia.build_detector(kitti_model_cfg(), test_cfg=KITTI_TEST_CFG)
+    ia.randomize_(model, 0)
+    with torch.no_grad():   # trained-net-like head statistics so the NMS tail has real work
+        model.bbox_head.conv_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(5))
+        model.bbox_head.conv_cls.bias.fill_(-2.0)
+        model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
+        model.bbox_head.conv_dir_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(7))
+    model.prepare(dev)
+
+    B = args.batch
+    g = torch.Generator().manual_seed(1000 + rank)
+    img_host = torch.randn(B, 1, 3, 384, 1280, generator=g)
+    img = img_host.to(dev)
+    metas = [kitti_meta(t=(0.01 * b, 0.0, 0.0), box_type=ia.LiDARInstance3DBoxes) for b in range(B)]
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps + args.warmup)]
+
+    def step(i):
+        p0 = model.features_2d_cl(img)
+        vol, _ = model.lift_cl(p0, metas)
+        ev[i][0].record()                                   # HIP events on the stream the kernels launch on
+        y = model.neck_3d.forward_cl(vol)
+        ev[i][1].record()
+        h = model.bbox_head.forward_cl(y)
+        boxes, scores, labels, count = model.bbox_head.get_bboxes_cl(h, y.shape[2], y.shape[1], metas, hw_transposed=True)
+        if world > 1:
+            boxes, scores, labels, count = ivx_dist.all_gather_detections(boxes, scores, labels, count)
+        # D2H of the results (bbox3d2result in the reference): one packed copy
+        return ivx_dist.pack_detections(boxes, scores, labels, count).cpu()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    neck_ms = [ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][1]) for i in range(args.steps)]
+    neck_ms_avg = sum(neck_ms) / len(neck_ms)
+    n_launch = 11
+    flops_step = neck_flops_per_sample((216, 248, 12), 64, 256) * B
+    achieved = flops_step / (neck_ms_avg * 1e-3) / 1e12
+
+    if rank == 0:
+        total_images = B * world * args.steps
+        rec = {
+            'metric': 'images/sec/node (KITTI 3x384x1280, 216x248x12 vox)',
+            'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'kitti_mono_1x3x384x1280_vox216x248x12_resnet50_fpn64_kittineck_anchor3dhead',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'detections_last_step': int(last[:, -1].sum().item())},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_f32_kernel (3-D neck, 11 launches/step)',
+                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'algorithmic_gflop_per_launch': round(flops_step / n_launch / 1e9, 2),
+                         'avg_launch_ms': round(neck_ms_avg / n_launch, 4), 'neck_ms_per_step': round(neck_ms_avg, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import imvoxel_oracle as orc
+            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            cfg = dict(n_voxels=(216, 248, 12), voxel_size=(.32, .32, .32), neck='kitti', num_classes=1, test_cfg=KITTI_TEST_CFG,
+                       anchor=dict(ranges=[[0, -39.68, -1.78, 69.12 - .32, 39.68 - .32, -1.78]], sizes=[[1.6, 3.9, 1.56]],
+                                   rotations=[0, 1.57]))
+            tc = time.perf_counter()
+            orc.simple_test_anchor(img_host[:1], metas[:1], sd, cfg)
+            tc = time.perf_counter() - tc
+            rec['cpu_baseline'] = {'value': round(1.0 / tc, 4), 'unit': 'images/s', 'cores': torch.get_num_threads(),
+                                   'kind': 'port', 'host_cpus': os.cpu_count(),
+                                   'sample': '1 image (1x3x384x1280 -> 216x248x12) through the oracle port '
+                                             '(torch-CPU fp32 convs + C unprojection/NMS), %.1f s' % tc}
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

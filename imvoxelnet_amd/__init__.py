@@ -1,0 +1,18 @@
+"""imvoxelnet_amd -- MI355X-native ImVoxelNet forward path (hand-written HIP for gfx950 behind a C-ABI).
+
+Importing the package registers the modules under the reference's registry names; it does NOT load the
+HIP library (that happens on first use and fails loudly if libimvoxel_hip.so is missing).
+"""
+from .registry import (BACKBONES, NECKS, HEADS, DETECTORS, ANCHOR_GENERATORS, BBOX_CODERS, ConfigDict,  # noqa: F401
+                       build_backbone, build_neck, build_head, build_detector)
+from .backbones import ResNet, FPN                                           # noqa: F401
+from .necks3d import KittiImVoxelNeck, NuScenesImVoxelNeck, BasicBlock3d    # noqa: F401
+from .anchor import Anchor3DRangeGenerator, DeltaXYZWLHRBBoxCoder          # noqa: F401
+from .heads import Anchor3DHead                                            # noqa: F401
+from .detector import ImVoxelNet, get_points                               # noqa: F401
+from .boxes import (LiDARInstance3DBoxes, DepthInstance3DBoxes, limit_period, xywhr2xyxyr,  # noqa: F401
+                    rotation_3d_in_axis, bbox3d2result)
+from .nms import nms_gpu, nms_normal_gpu, box3d_multiclass_nms, aligned_3d_nms, boxes_iou_bev  # noqa: F401
+from .params import randomize_                                              # noqa: F401
+
+__version__ = '0.1.0'

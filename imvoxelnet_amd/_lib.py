@@ -1,0 +1,77 @@
+"""ctypes binding of libimvoxel_hip.so (the C-ABI declared in include/imvoxel.h).
+
+The product path fails loudly when the library is missing or a call fails: there is no CPU
+fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libimvoxel_hip.so')
+_lib = None
+
+
+class IvxError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ('B', 'D', 'H', 'W', 'Cin', 'Cout', 'KD', 'KH', 'KW', 'sd', 'sh', 'sw', 'pd', 'ph', 'pw',
+                 'relu', 'res_mode', 'res_h', 'res_w')]
+
+
+class AnchorHeadDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ('B', 'H', 'W', 'CH', 'num_anchors', 'num_classes', 'cls_off', 'reg_off', 'dir_off',
+                 'nms_pre', 'max_num', 'use_rotate_nms', 'hw_transposed')] + \
+               [(n, C.c_float) for n in ('score_thr', 'nms_thr', 'dir_offset', 'dir_limit_offset')]
+
+
+EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive',
+           'ivx_maxpool2d_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
+           'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_nms_workspace_bytes',
+           'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms']
+
+
+def lib():
+    """Load (once) and return the library.  Raises IvxError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IvxError(f'{LIB_PATH} is missing: build it with `python -m imvoxelnet_amd._build` '
+                       '(or __graft_entry__.build()).  There is no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.ivx_version.restype = C.c_int
+    L.ivx_last_error.restype = C.c_char_p
+    L.ivx_conv_out_dims.argtypes = [C.POINTER(ConvDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    for name in ('ivx_conv_fwd', 'ivx_conv_fwd_naive'):
+        getattr(L, name).argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
+    L.ivx_maxpool2d_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ivx_nchw_to_nhwc.argtypes = [vp, i32, i32, i64, i32, vp, vp]
+    L.ivx_nhwc_to_nchw.argtypes = [vp, i32, i64, i32, vp, vp]
+    L.ivx_backproject_mean_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(f32), i32, i32, i32,
+                                           vp, vp, vp]
+    L.ivx_anchor_head_workspace_bytes.argtypes = [C.POINTER(AnchorHeadDesc)]
+    L.ivx_anchor_head_workspace_bytes.restype = i64
+    L.ivx_anchor_head_get_bboxes.argtypes = [C.POINTER(AnchorHeadDesc), vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ivx_nms_workspace_bytes.argtypes = [i32]
+    L.ivx_nms_workspace_bytes.restype = i64
+    L.ivx_nms_bev.argtypes = [vp, i32, f32, i32, vp, i64, vp, vp, vp]
+    L.ivx_boxes_overlap_bev.argtypes = [vp, i32, vp, i32, i32, vp, vp]
+    L.ivx_aligned_3d_nms.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
+    for name in EXPORTS:
+        if name not in ('ivx_last_error', 'ivx_anchor_head_workspace_bytes', 'ivx_nms_workspace_bytes'):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().ivx_last_error().decode('utf-8', 'replace')
+        if rc == -1:
+            raise ValueError(f'{what}: {msg}')
+        raise IvxError(f'{what}: status {rc}: {msg}')

@@ -1,0 +1,154 @@
+"""2-D trunk on the MI355X conv kernel: ResNet (depth 50, style='pytorch', eval BN) and FPN.
+
+Replaces the mmdet 2.10.0 modules the reference builds at mmdet3d/models/detectors/imvoxelnet.py:22-23
+and calls at :48,:50 (configs/imvoxelnet/imvoxelnet_kitti.py:4-17).  Parameter names follow
+torchvision / mmdet so `torchvision://resnet50` and released ImVoxelNet checkpoints load.
+Parity status: UNPINNED (mmdet/torchvision sources are not in the reference tree); checked against the
+torch-CPU restatement in oracle/imvoxel_oracle.py.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .conv import FusedConv
+from .params import ConvParams, BNParams
+from .registry import BACKBONES, NECKS
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, planes, stride, downsample):
+        super().__init__()
+        self.stride = stride
+        self.conv1 = ConvParams(cin, planes, 1, dims=2)
+        self.bn1 = BNParams(planes)
+        self.conv2 = ConvParams(planes, planes, 3, dims=2)
+        self.bn2 = BNParams(planes)
+        self.conv3 = ConvParams(planes, planes * 4, 1, dims=2)
+        self.bn3 = BNParams(planes * 4)
+        if downsample:
+            self.downsample = nn.Sequential(ConvParams(cin, planes * 4, 1, dims=2), BNParams(planes * 4))
+        else:
+            self.downsample = None
+
+    def prepare(self, device):
+        # style='pytorch': the stride sits on the 3x3 conv
+        self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2).to(device)
+        self.f2 = FusedConv(self.conv2.weight, bn=self.bn2.tensors(), stride=self.stride, padding=1, relu=True, dims=2).to(device)
+        self.f3 = FusedConv(self.conv3.weight, bn=self.bn3.tensors(), relu=True, dims=2).to(device)  # relu after the add
+        self.fd = None
+        if self.downsample is not None:
+            self.fd = FusedConv(self.downsample[0].weight, bn=self.downsample[1].tensors(), stride=self.stride, dims=2).to(device)
+
+    def forward_cl(self, x):
+        idt = x if self.fd is None else self.fd(x)
+        return self.f3(self.f2(self.f1(x)), res=idt)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_cfg=None, norm_eval=True,
+                 style='pytorch', in_channels=3, **kwargs):
+        super().__init__()
+        if depth not in self.arch:
+            raise KeyError(f'ResNet depth {depth} is not built (bottleneck depths: {sorted(self.arch)})')
+        if style != 'pytorch':
+            raise NotImplementedError("only style='pytorch' (stride on the 3x3 conv) is built")
+        if kwargs.get('dcn') is not None:
+            raise NotImplementedError('DCNv2 stages (nuScenes reference config) are not built; see DESIGN.md')
+        self.out_indices = tuple(out_indices)
+        self.conv1 = ConvParams(in_channels, 64, 7, dims=2)
+        self.bn1 = BNParams(64)
+        cin = 64
+        blocks = self.arch[depth][:num_stages]
+        for i, nb in enumerate(blocks):
+            planes = 64 * 2 ** i
+            layer = []
+            for j in range(nb):
+                layer.append(_Bottleneck(cin, planes, (2 if i > 0 else 1) if j == 0 else 1, downsample=(j == 0)))
+                cin = planes * 4
+            setattr(self, f'layer{i + 1}', nn.Sequential(*layer))
+        self.num_stages = len(blocks)
+        self._device = None
+
+    def init_weights(self, pretrained=None):
+        if pretrained is not None and not str(pretrained).startswith('torchvision://'):
+            sd = torch.load(pretrained, map_location='cpu')
+            self.load_state_dict(sd.get('state_dict', sd), strict=False)
+
+    def prepare(self, device):
+        self.stem = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), stride=2, padding=3, relu=True, dims=2).to(device)
+        for i in range(self.num_stages):
+            for blk in getattr(self, f'layer{i + 1}'):
+                blk.prepare(device)
+        self._device = device
+        return self
+
+    def forward_cl(self, x):
+        """x [N,1,H,W,4] channels-last image (3 channels zero-padded to 4) -> tuple of stage outputs."""
+        if self._device is None:
+            self.prepare(x.device)
+        x = ops.maxpool2d(self.stem(x), 3, 2, 1)
+        outs = []
+        for i in range(self.num_stages):
+            for blk in getattr(self, f'layer{i + 1}'):
+                x = blk.forward_cl(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def forward(self, img):
+        """img [N,3,H,W] -> tuple of [N,C,h,w] (reference layout)."""
+        outs = self.forward_cl(ops.to_channels_last(img.contiguous(), pad_to=4))
+        return tuple(ops.from_channels_last(o, 2) for o in outs)
+
+
+@NECKS.register_module()
+class FPN(nn.Module):
+    """mmdet FPN restated: lateral 1x1 (bias) -> top-down nearest x2 add -> 3x3 (bias); no norm, no
+    activation.  Only level 0 is consumed by ImVoxelNet (detectors/imvoxelnet.py:50), so levels 1..3 are
+    computed only on request; their parameters are still held so checkpoints load strictly."""
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False, **kwargs):
+        super().__init__()
+        if start_level != 0 or end_level != -1 or add_extra_convs:
+            raise NotImplementedError('only the plain FPN used by the ImVoxelNet configs is built')
+        self.in_channels = list(in_channels)
+        self.out_channels = out_channels
+        self.num_outs = num_outs
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for c in self.in_channels:
+            lat, out = nn.Module(), nn.Module()
+            lat.conv = ConvParams(c, out_channels, 1, bias=True, dims=2)
+            out.conv = ConvParams(out_channels, out_channels, 3, bias=True, dims=2)
+            self.lateral_convs.append(lat)
+            self.fpn_convs.append(out)
+        self._device = None
+
+    def init_weights(self):
+        pass
+
+    def prepare(self, device):
+        self.flat = [FusedConv(m.conv.weight, m.conv.bias, dims=2).to(device) for m in self.lateral_convs]
+        self.fout = [FusedConv(m.conv.weight, m.conv.bias, padding=1, dims=2).to(device) for m in self.fpn_convs]
+        self._device = device
+        return self
+
+    def forward_cl(self, feats, all_levels=False):
+        if self._device is None:
+            self.prepare(feats[0].device)
+        n = len(feats)
+        lat = [None] * n
+        lat[n - 1] = self.flat[n - 1](feats[n - 1])
+        for i in range(n - 2, -1, -1):   # lateral conv + nearest-upsampled coarser level, fused in the epilogue
+            lat[i] = self.flat[i](feats[i], res=lat[i + 1], res_mode=2)
+        outs = [self.fout[0](lat[0])]
+        if all_levels:
+            outs += [self.fout[i](lat[i]) for i in range(1, n)]
+        return outs
+
+    def forward(self, inputs, all_levels=True):
+        outs = self.forward_cl([ops.to_channels_last(t.contiguous()) for t in inputs], all_levels)
+        return tuple(ops.from_channels_last(o, 2) for o in outs)

@@ -1,0 +1,69 @@
+"""Host side of the fused convolution: packs reference-format parameters for ivx_conv_fwd.
+
+A `FusedConv` is the deploy form of  Conv{2,3}d [+bias] -> [eval BatchNorm] -> [+residual] -> [ReLU]:
+  weights  [Cout,Cin,(kd,)kh,kw] (torch layout)  ->  [Cout,kd,kh,kw,Cin_pad4]  (K contiguous per filter)
+  epilogue y = acc*scale + shift  with  scale = gamma/sqrt(var+eps),  shift = beta + (bias - mean)*scale
+The reference never fuses Conv3d+BN (tools/fuse_conv_bn.py handles Conv2d only); applying the BN affine
+in the epilogue instead of folding it into the weights keeps the accumulate identical to conv-then-BN.
+"""
+import torch
+
+from . import ops
+
+
+def _spatial3(v, dims, fill):
+    """int / 2-tuple / 3-tuple -> (d, h, w); a 2-D op gets `fill` on the depth axis."""
+    if isinstance(v, int):
+        return (fill, v, v) if dims == 2 else (v, v, v)
+    v = tuple(int(i) for i in v)
+    if len(v) == 2:
+        return (fill,) + v
+    if len(v) != 3:
+        raise ValueError(f'expected an int, 2-tuple or 3-tuple, got {v}')
+    return v
+
+
+class FusedConv:
+    def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, relu=False, dims=3, eps=1e-5):
+        """weight: [Cout,Cin,kh,kw] (dims=2) or [Cout,Cin,kd,kh,kw] (dims=3) tensor (any device).
+        bn: None or (gamma, beta, running_mean, running_var)."""
+        w = weight.detach().to(torch.float32)
+        if dims == 2:
+            w = w.unsqueeze(2)
+        self.stride = _spatial3(stride, dims, 1)
+        self.padding = _spatial3(padding, dims, 0)
+        self.cout, self.cin = w.shape[0], w.shape[1]
+        self.kernel = tuple(w.shape[2:])
+        self.cin_pad = (self.cin + 3) // 4 * 4
+        wp = w.permute(0, 2, 3, 4, 1).contiguous()
+        if self.cin_pad != self.cin:
+            wp = torch.nn.functional.pad(wp, (0, self.cin_pad - self.cin))
+        self._w_host = wp.contiguous()
+        scale = torch.ones(self.cout)
+        shift = torch.zeros(self.cout)
+        if bias is not None:
+            shift = bias.detach().to(torch.float32).cpu().clone()
+        if bn is not None:
+            g, b, m, v = (t.detach().to(torch.float32).cpu() for t in bn)
+            scale = g / torch.sqrt(v + eps)
+            shift = b + (shift - m) * scale
+        self._identity_epilogue = bias is None and bn is None
+        self._scale_host, self._shift_host = scale.contiguous(), shift.contiguous()
+        self.relu = relu
+        self.w = self.scale = self.shift = None
+
+    def to(self, device):
+        self.w = self._w_host.to(device)
+        if not self._identity_epilogue:
+            self.scale = self._scale_host.to(device)
+            self.shift = self._shift_host.to(device)
+        return self
+
+    def __call__(self, x, res=None, res_mode=0, relu=None, naive=False):
+        if self.w is None:
+            raise RuntimeError('FusedConv.to(device) must be called before use')
+        return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,
+                            self.relu if relu is None else relu, res, res_mode, naive=naive)
+
+    def flops(self, out_positions):
+        return 2.0 * out_positions * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]

@@ -1,0 +1,663 @@
+// Detection tail on the device: Anchor3DHead.get_bboxes_single (sigmoid + top-k + decode + BEV NMS +
+// yaw fix-up), the stand-alone BEV NMS (iou3d_cuda.nms_gpu / nms_normal_gpu without the host round
+// trip), pairwise rotated overlap, and aligned_3d_nms.  See include/imvoxel.h for the reference
+// lines each entry point replaces.  Latency-bound code: a handful of small launches per batch.
+// Compiled with -ffp-contract=off so the box arithmetic is the reference's operation order.
+#include "ivx_common.h"
+
+#include <math.h>
+
+#define IVX_PI_F 3.14159274101257324f /* float(np.pi) */
+#define IVX_NMS_EPS 1e-8f
+
+// ------------------------------------------------------------------------------------------------
+// Rotated-rectangle geometry: mmdet3d/ops/iou3d/src/iou3d_kernel.cu:16-251 restated for wave64.
+struct Pt { float x, y; };
+__device__ inline float cross2(Pt a, Pt b) { return a.x * b.y - a.y * b.x; }
+__device__ inline float cross3(Pt p1, Pt p2, Pt p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+
+__device__ inline int rect_cross(Pt p1, Pt p2, Pt q1, Pt q2) {
+  return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
+         fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
+}
+
+__device__ inline int in_box2d(const float *box, Pt p) {
+  const float MARGIN = 1e-5f;
+  float cx = (box[0] + box[2]) / 2, cy = (box[1] + box[3]) / 2;
+  float ac = cosf(-box[4]), as = sinf(-box[4]);
+  float rx = (p.x - cx) * ac + (p.y - cy) * as + cx;
+  float ry = -(p.x - cx) * as + (p.y - cy) * ac + cy;
+  return (rx > box[0] - MARGIN && rx < box[2] + MARGIN && ry > box[1] - MARGIN && ry < box[3] + MARGIN);
+}
+
+__device__ inline int seg_isect(Pt p1, Pt p0, Pt q1, Pt q0, Pt *ans) {
+  if (rect_cross(p0, p1, q0, q1) == 0) return 0;
+  float s1 = cross3(q0, p1, p0), s2 = cross3(p1, q1, p0), s3 = cross3(p0, q1, q0), s4 = cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+  float s5 = cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > IVX_NMS_EPS) {
+    ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    float D = a0 * b1 - a1 * b0;
+    ans->x = (b0 * c1 - b1 * c0) / D;
+    ans->y = (a1 * c0 - a0 * c1) / D;
+  }
+  return 1;
+}
+
+__device__ inline void rot_center(Pt c, float ac, float as, Pt *p) {
+  float nx = (p->x - c.x) * ac + (p->y - c.y) * as + c.x;
+  float ny = -(p->x - c.x) * as + (p->y - c.y) * ac + c.y;
+  p->x = nx;
+  p->y = ny;
+}
+
+__device__ float box_overlap_dev(const float *ba, const float *bb) {
+  float a_x1 = ba[0], a_y1 = ba[1], a_x2 = ba[2], a_y2 = ba[3], a_ang = ba[4];
+  float b_x1 = bb[0], b_y1 = bb[1], b_x2 = bb[2], b_y2 = bb[3], b_ang = bb[4];
+  Pt ca = {(a_x1 + a_x2) / 2, (a_y1 + a_y2) / 2};
+  Pt cb = {(b_x1 + b_x2) / 2, (b_y1 + b_y2) / 2};
+  Pt A[5] = {{a_x1, a_y1}, {a_x2, a_y1}, {a_x2, a_y2}, {a_x1, a_y2}, {0, 0}};
+  Pt Bc[5] = {{b_x1, b_y1}, {b_x2, b_y1}, {b_x2, b_y2}, {b_x1, b_y2}, {0, 0}};
+  float a_cos = cosf(a_ang), a_sin = sinf(a_ang), b_cos = cosf(b_ang), b_sin = sinf(b_ang);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    rot_center(ca, a_cos, a_sin, &A[k]);
+    rot_center(cb, b_cos, b_sin, &Bc[k]);
+  }
+  A[4] = A[0];
+  Bc[4] = Bc[0];
+  Pt cp[16];
+  Pt pc = {0.f, 0.f};
+  int cnt = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      Pt t;
+      if (seg_isect(A[i + 1], A[i], Bc[j + 1], Bc[j], &t)) {
+        cp[cnt] = t;
+        pc.x = pc.x + t.x;
+        pc.y = pc.y + t.y;
+        cnt++;
+      }
+    }
+  for (int k = 0; k < 4; ++k) {
+    if (in_box2d(ba, Bc[k])) {
+      pc.x = pc.x + Bc[k].x;
+      pc.y = pc.y + Bc[k].y;
+      cp[cnt++] = Bc[k];
+    }
+    if (in_box2d(bb, A[k])) {
+      pc.x = pc.x + A[k].x;
+      pc.y = pc.y + A[k].y;
+      cp[cnt++] = A[k];
+    }
+  }
+  pc.x /= cnt;
+  pc.y /= cnt;
+  for (int j = 0; j < cnt - 1; ++j)
+    for (int i = 0; i < cnt - j - 1; ++i) {
+      const bool gt = atan2f(cp[i].y - pc.y, cp[i].x - pc.x) > atan2f(cp[i + 1].y - pc.y, cp[i + 1].x - pc.x);
+      if (gt) {
+        Pt t = cp[i];
+        cp[i] = cp[i + 1];
+        cp[i + 1] = t;
+      }
+    }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; ++k) {
+    Pt u = {cp[k].x - cp[0].x, cp[k].y - cp[0].y};
+    Pt v = {cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+    area += cross2(u, v);
+  }
+  return fabsf(area) / 2.0f;
+}
+
+__device__ inline float iou_bev_dev(const float *a, const float *b) {
+  float sa = (a[2] - a[0]) * (a[3] - a[1]);
+  float sb = (b[2] - b[0]) * (b[3] - b[1]);
+  float so = box_overlap_dev(a, b);
+  return so / fmaxf(sa + sb - so, IVX_NMS_EPS);
+}
+
+__device__ inline float iou_normal_dev(const float *a, const float *b) {
+  float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+  float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+  float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+  float interS = width * height;
+  float Sa = (a[2] - a[0]) * (a[3] - a[1]);
+  float Sb = (b[2] - b[0]) * (b[3] - b[1]);
+  return interS / fmaxf(Sa + Sb - interS, IVX_NMS_EPS);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Suppression mask: one wave64 per (row block, col block) tile; each lane builds one 64-bit word
+// (iou3d_kernel.cu:284-333 / :345-396).  Only col >= row blocks are built: the greedy scan
+// (iou3d.cpp:127-143) never reads the others.  boxes [nb][stride_boxes][5], n1 per batch item.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float *boxes, const int *n_arr, int n_fixed, int box_stride,
+                                                      int cb_stride, float thr, int rotated, unsigned long long *mask) {
+  const int bz = blockIdx.z;
+  const int n = n_arr ? n_arr[bz] : n_fixed;
+  const int row_start = blockIdx.y, col_start = blockIdx.x;
+  if (col_start < row_start) return;
+  if (row_start * 64 >= n || col_start * 64 >= n) return;
+  const float *bx = boxes + (size_t)bz * box_stride * 5;
+  const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
+  __shared__ float blk[64 * 5];
+  const int t = threadIdx.x;
+  if (t < col_size) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) blk[t * 5 + q] = bx[(size_t)(64 * col_start + t) * 5 + q];
+  }
+  __syncthreads();
+  if (t < row_size) {
+    const int cur = 64 * row_start + t;
+    float cb_[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) cb_[q] = bx[(size_t)cur * 5 + q];
+    unsigned long long w = 0;
+    const int start = (row_start == col_start) ? t + 1 : 0;
+    for (int i = start; i < col_size; ++i) {
+      const float v = rotated ? iou_bev_dev(cb_, blk + i * 5) : iou_normal_dev(cb_, blk + i * 5);
+      if (v > thr) w |= 1ULL << i;
+    }
+    mask[((size_t)bz * box_stride + cur) * cb_stride + col_start] = w;
+  }
+}
+
+// Greedy scan by one wave: lane w owns removal word w (n <= 4096).  Returns the number kept (all lanes)
+// and writes kept indices (ascending == descending score) to keep_s (LDS or global), at most max_keep.
+__device__ int greedy_scan_wave(const unsigned long long *mask, int n, int cb_stride, int max_keep, int *keep_out) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long remv = 0;
+  int nk = 0;
+  for (int i = 0; i < n && nk < max_keep; ++i) {
+    const int word = i >> 6, bit = i & 63;
+    const unsigned long long rw = __shfl(remv, word, 64);
+    if (!((rw >> bit) & 1ULL)) {
+      if (lane == 0) keep_out[nk] = i;
+      ++nk;
+      if (lane >= word && lane * 64 < n) remv |= mask[(size_t)i * cb_stride + lane];
+    }
+  }
+  return nk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Anchor head: scores
+struct HeadP {
+  const float *head_out;  // [B, HW, CH]
+  const float *anchors;   // [HW*A, 7]
+  int B, HW, CH, A, ncls, cls_off, reg_off, dir_off;
+  int Hh, Ww, transposed;
+  int n;                  // HW * A
+  int nms_pre, max_num, kpad, cb;
+  float score_thr, nms_thr, dir_offset, dir_limit_offset;
+  int rotated;
+};
+
+// memory position of logical location hw = y*W + x
+__device__ inline int hw_mem(const HeadP &p, int hw) {
+  if (!p.transposed) return hw;
+  const int y = hw / p.Ww, x = hw - y * p.Ww;
+  return x * p.Hh + y;
+}
+
+__device__ inline float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void anchor_scores_kernel(const HeadP p, float *keys) {
+  const size_t total = (size_t)p.B * p.n;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / p.n);
+    const int i = (int)(idx % p.n);
+    const int hw = i / p.A, a = i % p.A;
+    const float *src = p.head_out + ((size_t)b * p.HW + hw_mem(p, hw)) * p.CH + p.cls_off + a * p.ncls;
+    float m = sigmoid_ref(src[0]);
+    for (int c = 1; c < p.ncls; ++c) {
+      const float s = sigmoid_ref(src[c]);
+      m = s > m ? s : m;
+    }
+    keys[idx] = m;
+  }
+}
+
+__device__ inline unsigned int f2key(float f) {
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float key2f(unsigned int k) {
+  unsigned int u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// Bitonic sort of `len` (power of two) 64-bit keys in LDS, descending.
+__device__ void bitonic_sort_desc(unsigned long long *s, int len) {
+  for (int k = 2; k <= len; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = s[i], b = s[ixj];
+          const bool up = ((i & k) == 0);  // descending blocks first
+          if (up ? (a < b) : (a > b)) {
+            s[i] = b;
+            s[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// top-k (torch.topk semantics: k largest, sorted descending; ties -> lower index first) of keys[b][0..n)
+// by an 8-bit radix select on the composite key (score bits << 32 | ~index), then an LDS bitonic sort.
+// One workgroup of 1024 threads per batch item.  kk = min(nms_pre, n) candidates are produced (when
+// n <= nms_pre the reference keeps all of them unsorted; sorting them changes nothing downstream because
+// nms_gpu sorts by score itself).  Writes topk_idx[b][0..kpad) (-1 padded), cnt[b] = kk and
+// n1[b] = #(score > score_thr) (a prefix of the sorted candidates).
+__global__ __launch_bounds__(1024) void topk_select_kernel(const HeadP p, const float *keys, int *topk_idx, int *cnt_out,
+                                                           int *n1_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];  // kpad entries
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned long long s_prefix, s_mask;
+  __shared__ int s_remaining, s_done, s_cnt, s_n1;
+  const int b = blockIdx.x;
+  const float *kb = keys + (size_t)b * p.n;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int k = (p.nms_pre > 0 && p.nms_pre < p.n) ? p.nms_pre : p.n;
+  int *out_idx = topk_idx + (size_t)b * p.kpad;
+
+  if (tid == 0) {
+    s_prefix = 0;
+    s_mask = 0;
+    s_remaining = k;
+    s_done = (k >= p.n) ? 1 : 0;  // everything selected: threshold key 0
+    s_cnt = 0;
+    s_n1 = 0;
+  }
+  __syncthreads();
+  if (!s_done) {
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+      for (int i = tid; i < 256; i += nt) hist[i] = 0;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix, msk = s_mask;
+      for (int i = tid; i < p.n; i += nt) {
+        const unsigned long long key = ((unsigned long long)f2key(kb[i]) << 32) | (unsigned int)(~(unsigned int)i);
+        if ((key & msk) == prefix) atomicAdd(&hist[(unsigned int)(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int rem = s_remaining;
+        int cum = 0, chosen = 0;
+        for (int bin = 255; bin >= 0; --bin) {
+          const int h = (int)hist[bin];
+          if (cum + h >= rem) {
+            chosen = bin;
+            break;
+          }
+          cum += h;
+        }
+        rem -= cum;
+        s_prefix = prefix | ((unsigned long long)chosen << shift);
+        s_mask = msk | (0xffULL << shift);
+        s_remaining = rem;
+        if ((int)hist[chosen] == rem) s_done = 1;  // the whole bucket is taken: lower bits are irrelevant
+      }
+      __syncthreads();
+      if (s_done) break;
+    }
+  }
+  const unsigned long long thr_key = s_prefix;  // every key >= thr_key is selected: exactly k of them
+  for (int i = tid; i < p.kpad; i += nt) sk[i] = 0ULL;
+  __syncthreads();
+  for (int i = tid; i < p.n; i += nt) {
+    const unsigned long long key = ((unsigned long long)f2key(kb[i]) << 32) | (unsigned int)(~(unsigned int)i);
+    if (key >= thr_key) {
+      const int pos = atomicAdd(&s_cnt, 1);
+      if (pos < p.kpad) sk[pos] = key;
+    }
+  }
+  __syncthreads();
+  bitonic_sort_desc(sk, p.kpad);
+  int local = 0;
+  for (int i = tid; i < p.kpad; i += nt) {
+    if (i < k) {
+      const unsigned long long key = sk[i];
+      out_idx[i] = (int)(~(unsigned int)(key & 0xffffffffULL));
+      if (key2f((unsigned int)(key >> 32)) > p.score_thr) ++local;
+    } else {
+      out_idx[i] = -1;
+    }
+  }
+  atomicAdd(&s_n1, local);
+  __syncthreads();
+  if (tid == 0) {
+    cnt_out[b] = k;
+    n1_out[b] = s_n1;
+  }
+}
+
+// Decode the selected candidates (DeltaXYZWLHRBBoxCoder.decode, coders/delta_xyzwhlr_bbox_coder.py:56-90),
+// direction argmax (anchor3d_head.py:465-466), BEV xyxyr boxes (lidar_box3d.py:86-90, utils.py:64-82).
+__global__ __launch_bounds__(64) void decode_kernel(const HeadP p, const float *keys, const int *topk_idx,
+                                                    float *cand_boxes, float *cand_scores, int *cand_dir, float *cand_bev) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= p.kpad) return;
+  const int idx = topk_idx[(size_t)b * p.kpad + j];
+  float *ob = cand_boxes + ((size_t)b * p.kpad + j) * 7;
+  float *bev = cand_bev + ((size_t)b * p.kpad + j) * 5;
+  if (idx < 0) {
+#pragma unroll
+    for (int q = 0; q < 7; ++q) ob[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bev[q] = 0.f;
+    cand_scores[(size_t)b * p.kpad + j] = 0.f;
+    cand_dir[(size_t)b * p.kpad + j] = 0;
+    return;
+  }
+  const int hw = idx / p.A, a = idx % p.A;
+  const float *row = p.head_out + ((size_t)b * p.HW + hw_mem(p, hw)) * p.CH;
+  const float *an = p.anchors + (size_t)idx * 7;
+  const float *dl = row + p.reg_off + a * 7;
+  const float xa = an[0], ya = an[1], wa = an[3], la = an[4], ha = an[5], ra = an[6];
+  float za = an[2];
+  const float xt = dl[0], yt = dl[1], zt = dl[2], wt = dl[3], lt = dl[4], ht = dl[5], rt = dl[6];
+  za = za + ha / 2;
+  const float diag = sqrtf(la * la + wa * wa);
+  const float xg = xt * diag + xa;
+  const float yg = yt * diag + ya;
+  float zg = zt * ha + za;
+  const float lg = expf(lt) * la;
+  const float wg = expf(wt) * wa;
+  const float hg = expf(ht) * ha;
+  const float rg = rt + ra;
+  zg = zg - hg / 2;
+  ob[0] = xg; ob[1] = yg; ob[2] = zg; ob[3] = wg; ob[4] = lg; ob[5] = hg; ob[6] = rg;
+  const float hwid = wg / 2, hlen = lg / 2;
+  bev[0] = xg - hwid; bev[1] = yg - hlen; bev[2] = xg + hwid; bev[3] = yg + hlen; bev[4] = rg;
+  const float d0 = row[p.dir_off + a * 2], d1 = row[p.dir_off + a * 2 + 1];
+  cand_dir[(size_t)b * p.kpad + j] = d1 > d0 ? 1 : 0;
+  cand_scores[(size_t)b * p.kpad + j] = keys[(size_t)b * p.n + idx];
+}
+
+// Greedy scan + gather of the kept boxes (first max_num in descending score) + yaw fix-up
+// (anchor3d_head.py:510-515 with limit_period, structures/utils.py:5-18).  One workgroup per batch item.
+__global__ __launch_bounds__(256) void nms_finalize_kernel(const HeadP p, const int *n1_arr, const unsigned long long *mask,
+                                                           const float *cand_boxes, const float *cand_scores,
+                                                           const int *cand_dir, float *out_boxes, float *out_scores,
+                                                           long long *out_labels, int *out_count) {
+  __shared__ int keep_s[4096];
+  __shared__ int s_nk;
+  const int b = blockIdx.x;
+  const int n1 = n1_arr[b];
+  if (threadIdx.x < 64) {
+    const int nk = greedy_scan_wave(mask + (size_t)b * p.kpad * p.cb, n1, p.cb, p.max_num, keep_s);
+    if (threadIdx.x == 0) s_nk = nk;
+  }
+  __syncthreads();
+  const int nk = s_nk;
+  for (int j = threadIdx.x; j < p.max_num; j += blockDim.x) {
+    float *ob = out_boxes + ((size_t)b * p.max_num + j) * 7;
+    if (j < nk) {
+      const int i = keep_s[j];
+      const float *cb_ = cand_boxes + ((size_t)b * p.kpad + i) * 7;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) ob[q] = cb_[q];
+      const float val = cb_[6] - p.dir_offset;
+      const float t = floorf(val / IVX_PI_F + p.dir_limit_offset);
+      const float dir_rot = val - t * IVX_PI_F;
+      ob[6] = (dir_rot + p.dir_offset) + IVX_PI_F * (float)cand_dir[(size_t)b * p.kpad + i];
+      out_scores[(size_t)b * p.max_num + j] = cand_scores[(size_t)b * p.kpad + i];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 7; ++q) ob[q] = 0.f;
+      out_scores[(size_t)b * p.max_num + j] = 0.f;
+    }
+    out_labels[(size_t)b * p.max_num + j] = 0;
+  }
+  if (threadIdx.x == 0) out_count[b] = nk;
+}
+
+__global__ void export_cands_kernel(const HeadP p, const int *topk_idx, const float *cand_boxes, const float *cand_scores,
+                                    long long *o_idx, float *o_boxes, float *o_scores) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p.nms_pre) return;
+  const bool in = j < p.kpad;
+  const int idx = in ? topk_idx[(size_t)b * p.kpad + j] : -1;
+  if (o_idx) o_idx[(size_t)b * p.nms_pre + j] = idx;
+  if (o_boxes)
+    for (int q = 0; q < 7; ++q) o_boxes[((size_t)b * p.nms_pre + j) * 7 + q] = (in && idx >= 0) ? cand_boxes[((size_t)b * p.kpad + j) * 7 + q] : 0.f;
+  if (o_scores) o_scores[(size_t)b * p.nms_pre + j] = (in && idx >= 0) ? cand_scores[(size_t)b * p.kpad + j] : 0.f;
+}
+
+static int next_pow2(int v) {
+  int r = 1;
+  while (r < v) r <<= 1;
+  return r;
+}
+
+struct HeadWs {
+  int64_t keys, topk, cnt, n1, boxes, scores, dir, bev, mask, total;
+};
+
+static int head_layout(const ivx_anchor_head_desc *d, HeadP *p, HeadWs *w) {
+  IVX_REQUIRE(d, "ivx_anchor_head: null desc");
+  IVX_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->CH > 0 && d->num_anchors > 0, "ivx_anchor_head: non-positive dims");
+  IVX_REQUIRE(d->num_classes == 1, "ivx_anchor_head: only num_classes == 1 (the KITTI / nuScenes ImVoxelNet configs) is built; got %d",
+              d->num_classes);
+  IVX_REQUIRE(d->cls_off >= 0 && d->reg_off >= 0 && d->dir_off >= 0 &&
+                  d->cls_off + d->num_anchors * d->num_classes <= d->CH && d->reg_off + d->num_anchors * 7 <= d->CH &&
+                  d->dir_off + d->num_anchors * 2 <= d->CH,
+              "ivx_anchor_head: channel blocks exceed CH");
+  const int64_t n64 = (int64_t)d->H * d->W * d->num_anchors;
+  IVX_REQUIRE(n64 < (1LL << 31) && (int64_t)d->B * n64 < (1LL << 40), "ivx_anchor_head: too many anchors");
+  const int n = (int)n64;
+  const int k = (d->nms_pre > 0 && d->nms_pre < n) ? d->nms_pre : n;
+  IVX_REQUIRE(k <= 4096, "ivx_anchor_head: at most 4096 NMS candidates per sample (nms_pre=%d, anchors=%d)", d->nms_pre, n);
+  IVX_REQUIRE(d->max_num > 0 && d->max_num <= 4096, "ivx_anchor_head: max_num must be in 1..4096");
+  IVX_REQUIRE(d->nms_pre > 0, "ivx_anchor_head: nms_pre must be positive (size of the candidate outputs)");
+  p->Hh = d->H; p->Ww = d->W; p->transposed = d->hw_transposed ? 1 : 0;
+  p->B = d->B; p->HW = d->H * d->W; p->CH = d->CH; p->A = d->num_anchors; p->ncls = d->num_classes;
+  p->cls_off = d->cls_off; p->reg_off = d->reg_off; p->dir_off = d->dir_off; p->n = n;
+  p->nms_pre = d->nms_pre; p->max_num = d->max_num; p->kpad = next_pow2(k < 64 ? 64 : k); p->cb = p->kpad / 64;
+  p->score_thr = d->score_thr; p->nms_thr = d->nms_thr; p->dir_offset = d->dir_offset; p->dir_limit_offset = d->dir_limit_offset;
+  p->rotated = d->use_rotate_nms;
+  int64_t o = 0;
+  w->keys = o; o = ivx_align_up(o + (int64_t)d->B * n * 4, 256);
+  w->topk = o; o = ivx_align_up(o + (int64_t)d->B * p->kpad * 4, 256);
+  w->cnt = o; o = ivx_align_up(o + (int64_t)d->B * 4, 256);
+  w->n1 = o; o = ivx_align_up(o + (int64_t)d->B * 4, 256);
+  w->boxes = o; o = ivx_align_up(o + (int64_t)d->B * p->kpad * 7 * 4, 256);
+  w->scores = o; o = ivx_align_up(o + (int64_t)d->B * p->kpad * 4, 256);
+  w->dir = o; o = ivx_align_up(o + (int64_t)d->B * p->kpad * 4, 256);
+  w->bev = o; o = ivx_align_up(o + (int64_t)d->B * p->kpad * 5 * 4, 256);
+  w->mask = o; o = ivx_align_up(o + (int64_t)d->B * p->kpad * p->cb * 8, 256);
+  w->total = o;
+  return IVX_OK;
+}
+
+extern "C" int64_t ivx_anchor_head_workspace_bytes(const ivx_anchor_head_desc *d) {
+  HeadP p;
+  HeadWs w;
+  if (head_layout(d, &p, &w) != IVX_OK) return -1;
+  return w.total;
+}
+
+extern "C" int ivx_anchor_head_get_bboxes(const ivx_anchor_head_desc *d, const float *head_out, const float *anchors,
+                                          void *workspace, int64_t workspace_bytes, float *out_boxes, float *out_scores,
+                                          int64_t *out_labels, int32_t *out_count, int64_t *cand_idx, float *cand_boxes,
+                                          float *cand_scores, ivx_stream_t stream) {
+  HeadP p;
+  HeadWs w;
+  int rc = head_layout(d, &p, &w);
+  if (rc != IVX_OK) return rc;
+  IVX_REQUIRE(head_out && anchors && workspace && out_boxes && out_scores && out_labels && out_count, "ivx_anchor_head_get_bboxes: null argument");
+  if (workspace_bytes < w.total) {
+    ivx_set_error("ivx_anchor_head_get_bboxes: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)w.total);
+    return IVX_ERR_WORKSPACE;
+  }
+  IVX_REQUIRE(((uintptr_t)workspace & 255) == 0, "ivx_anchor_head_get_bboxes: workspace must be 256-byte aligned");
+  p.head_out = head_out;
+  p.anchors = anchors;
+  hipStream_t st = (hipStream_t)stream;
+  char *ws = (char *)workspace;
+  float *keys = (float *)(ws + w.keys);
+  int *topk = (int *)(ws + w.topk);
+  int *cnt = (int *)(ws + w.cnt);
+  int *n1 = (int *)(ws + w.n1);
+  float *cboxes = (float *)(ws + w.boxes);
+  float *cscores = (float *)(ws + w.scores);
+  int *cdir = (int *)(ws + w.dir);
+  float *cbev = (float *)(ws + w.bev);
+  unsigned long long *mask = (unsigned long long *)(ws + w.mask);
+
+  const size_t total = (size_t)p.B * p.n;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(anchor_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, keys);
+  hipLaunchKernelGGL(topk_select_kernel, dim3(p.B), dim3(1024), (size_t)p.kpad * 8, st, p, keys, topk, cnt, n1);
+  hipLaunchKernelGGL(decode_kernel, dim3(p.kpad / 64, p.B), dim3(64), 0, st, p, keys, topk, cboxes, cscores, cdir, cbev);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(p.cb, p.cb, p.B), dim3(64), 0, st, cbev, n1, 0, p.kpad, p.cb, p.nms_thr, p.rotated, mask);
+  hipLaunchKernelGGL(nms_finalize_kernel, dim3(p.B), dim3(256), 0, st, p, n1, mask, cboxes, cscores, cdir, out_boxes, out_scores,
+                     (long long *)out_labels, out_count);
+  if (cand_idx || cand_boxes || cand_scores)
+    hipLaunchKernelGGL(export_cands_kernel, dim3((p.nms_pre + 63) / 64, p.B), dim3(64), 0, st, p, topk, cboxes, cscores,
+                       (long long *)cand_idx, cand_boxes, cand_scores);
+  IVX_CHECK_LAUNCH("ivx_anchor_head_get_bboxes");
+  return IVX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone BEV NMS
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long *mask, int n, int cb, long long *keep, int *num_out) {
+  __shared__ int keep_s[4096];
+  const int nk = greedy_scan_wave(mask, n, cb, n, keep_s);
+  __syncthreads();
+  for (int j = threadIdx.x; j < nk; j += 64) keep[j] = keep_s[j];
+  if (threadIdx.x == 0) *num_out = nk;
+}
+
+extern "C" int64_t ivx_nms_workspace_bytes(int32_t n) {
+  if (n < 0) return -1;
+  const int64_t cb = (n + 63) / 64;
+  return ivx_align_up((int64_t)(n > 0 ? n : 1) * (cb > 0 ? cb : 1) * 8, 256);
+}
+
+extern "C" int ivx_nms_bev(const float *boxes_sorted, int32_t n, float thresh, int32_t rotated, void *workspace,
+                           int64_t workspace_bytes, int64_t *keep, int32_t *num_out, ivx_stream_t stream) {
+  IVX_REQUIRE(n >= 0 && n <= 4096, "ivx_nms_bev: n must be in 0..4096 (got %d)", n);
+  IVX_REQUIRE(keep && num_out, "ivx_nms_bev: null output");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(num_out, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) {
+      ivx_set_error("ivx_nms_bev: memset failed: %s", hipGetErrorString(e));
+      return IVX_ERR_HIP;
+    }
+    return IVX_OK;
+  }
+  IVX_REQUIRE(boxes_sorted && workspace, "ivx_nms_bev: null argument");
+  if (workspace_bytes < ivx_nms_workspace_bytes(n)) {
+    ivx_set_error("ivx_nms_bev: workspace too small");
+    return IVX_ERR_WORKSPACE;
+  }
+  const int cb = (n + 63) / 64;
+  unsigned long long *mask = (unsigned long long *)workspace;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, 1), dim3(64), 0, st, boxes_sorted, (const int *)nullptr, n, n, cb, thresh, rotated, mask);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, mask, n, cb, (long long *)keep, num_out);
+  IVX_CHECK_LAUNCH("ivx_nms_bev");
+  return IVX_OK;
+}
+
+__global__ void overlap_pairs_kernel(const float *a, int na, const float *b, int nb, int iou, float *out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= nb || i >= na) return;
+  float ba[5], bb[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    ba[q] = a[(size_t)i * 5 + q];
+    bb[q] = b[(size_t)j * 5 + q];
+  }
+  out[(size_t)i * nb + j] = iou ? iou_bev_dev(ba, bb) : box_overlap_dev(ba, bb);
+}
+
+extern "C" int ivx_boxes_overlap_bev(const float *a, int32_t na, const float *b, int32_t nb, int32_t iou, float *out,
+                                     ivx_stream_t stream) {
+  IVX_REQUIRE(na >= 0 && nb >= 0 && na <= 65535, "ivx_boxes_overlap_bev: bad sizes");
+  if (na == 0 || nb == 0) return IVX_OK;
+  IVX_REQUIRE(a && b && out, "ivx_boxes_overlap_bev: null argument");
+  hipLaunchKernelGGL(overlap_pairs_kernel, dim3((nb + 63) / 64, na), dim3(64), 0, (hipStream_t)stream, a, na, b, nb, iou, out);
+  IVX_CHECK_LAUNCH("ivx_boxes_overlap_bev");
+  return IVX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// aligned_3d_nms (box3d_nms.py:91-138): boxes in descending score order; a box is picked iff no earlier
+// picked box of the same class has IoU > thresh with it (NaN IoU suppresses, as `iou <= thresh` is false).
+__global__ __launch_bounds__(1024) void aligned_nms_kernel(const float *boxes, const float *scores, const long long *classes,
+                                                           int n, int npad, float thresh, long long *pick, int *num_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];  // npad keys, then npad flag bytes
+  unsigned char *supp = reinterpret_cast<unsigned char *>(sk + npad);
+  __shared__ int s_np;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < npad; i += nt) {
+    sk[i] = i < n ? (((unsigned long long)f2key(scores[i]) << 32) | (unsigned int)(~(unsigned int)i)) : 0ULL;
+    supp[i] = 0;
+  }
+  if (tid == 0) s_np = 0;
+  __syncthreads();
+  bitonic_sort_desc(sk, npad);
+  for (int i = 0; i < n; ++i) {
+    if (supp[i]) continue;  // uniform: LDS value, synchronised by the barrier below
+    const int bi = (int)(~(unsigned int)(sk[i] & 0xffffffffULL));
+    if (tid == 0) pick[s_np++] = bi;
+    const float *B1 = boxes + (size_t)bi * 6;
+    const float x1 = B1[0], y1 = B1[1], z1 = B1[2], x2 = B1[3], y2 = B1[4], z2 = B1[5];
+    const float ai = (x2 - x1) * (y2 - y1) * (z2 - z1);
+    const long long ci = classes[bi];
+    for (int j = i + 1 + tid; j < n; j += nt) {
+      if (supp[j]) continue;
+      const int bj = (int)(~(unsigned int)(sk[j] & 0xffffffffULL));
+      const float *B2 = boxes + (size_t)bj * 6;
+      const float xx1 = fmaxf(x1, B2[0]), yy1 = fmaxf(y1, B2[1]), zz1 = fmaxf(z1, B2[2]);
+      const float xx2 = fminf(x2, B2[3]), yy2 = fminf(y2, B2[4]), zz2 = fminf(z2, B2[5]);
+      const float il = fmaxf(0.f, xx2 - xx1), iw = fmaxf(0.f, yy2 - yy1), ih = fmaxf(0.f, zz2 - zz1);
+      const float inter = il * iw * ih;
+      const float aj = (B2[3] - B2[0]) * (B2[4] - B2[1]) * (B2[5] - B2[2]);
+      float iou = inter / (ai + aj - inter);
+      iou = iou * (ci == classes[bj] ? 1.0f : 0.0f);
+      if (!(iou <= thresh)) supp[j] = 1;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) *num_out = s_np;
+}
+
+extern "C" int ivx_aligned_3d_nms(const float *boxes, const float *scores, const int64_t *classes, int32_t n, float thresh,
+                                  int64_t *pick, int32_t *num_out, ivx_stream_t stream) {
+  IVX_REQUIRE(n >= 0 && n <= 4096, "ivx_aligned_3d_nms: n must be in 0..4096 (got %d)", n);
+  IVX_REQUIRE(pick && num_out, "ivx_aligned_3d_nms: null output");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(num_out, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) {
+      ivx_set_error("ivx_aligned_3d_nms: memset failed: %s", hipGetErrorString(e));
+      return IVX_ERR_HIP;
+    }
+    return IVX_OK;
+  }
+  IVX_REQUIRE(boxes && scores && classes, "ivx_aligned_3d_nms: null argument");
+  const int npad = next_pow2(n < 64 ? 64 : n);
+  hipLaunchKernelGGL(aligned_nms_kernel, dim3(1), dim3(1024), (size_t)npad * 9, st, boxes, scores, (const long long *)classes, n, npad,
+                     thresh, (long long *)pick, num_out);
+  IVX_CHECK_LAUNCH("ivx_aligned_3d_nms");
+  return IVX_OK;
+}

@@ -1,0 +1,17 @@
+// Error reporting + version for libimvoxel_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/imvoxel.h"
+
+static thread_local char g_err[512] = "";
+
+void ivx_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int ivx_version(void) { return 100; /* 0.1.0 */ }
+extern "C" const char *ivx_last_error(void) { return g_err; }

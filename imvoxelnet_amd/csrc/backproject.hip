@@ -1,0 +1,167 @@
+// Fused image-to-voxel unprojection (projection + nearest gather + view mean + zero fill + valid
+// mask) for a whole batch in one launch.  Replaces mmdet3d/models/detectors/imvoxelnet.py:58-76,
+// :132-141 (get_points) and :145-160 (backproject); see include/imvoxel.h.
+//
+// HBM-bound: the volume [B,X,Y,Z,C] is written exactly once (coalesced: a voxel's C channels are
+// contiguous and consecutive voxels are consecutive in memory), the feature maps are read through
+// L2 / Infinity Cache (neighbouring voxels hit neighbouring pixels), nothing else is materialised
+// (the reference materialises [V,C,N] and makes four more passes over it).
+//
+// Work split: a group of LPV lanes (power of two, >= ceil(C/VEC) up to 64) owns one voxel; each
+// lane owns VEC consecutive channels (float4 when C % 4 == 0).  The per-view projection is spread
+// over the group's lanes -- lane g projects view (chunk*LPV + g) -- and the resulting pixel
+// offsets are broadcast with wavefront shuffles, so a 50-view scene costs one projection per
+// lane per LPV views instead of one per lane per view.
+//
+// Arithmetic parity (measured against the imported reference, tests/golden/backproject_cases.npz):
+//   point   = float(idx) * voxel_size + new_origin                (fp32 mul, fp32 add, no FMA)
+//   (u,v,w) = fma(P3,1, fma(P2,z, fma(P1,y, P0*x)))               (what torch.bmm does on CPU)
+//   x = rint(u / w), y = rint(v / w)                               (IEEE divide, round-half-even)
+//   valid   = 0 <= x < w_crop  &&  0 <= y < h_crop  &&  w > 0      (tested on the rounded floats:
+//             NaN/inf fail, as do the INT64_MIN values the reference's .long() produces for them)
+//   mean    = (sum over valid views in view order) / float(count)  (IEEE divide), 0 if count == 0
+// This file is compiled with -ffp-contract=off.
+#include "ivx_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct BpParams {
+  const float *feat;        // [B*V, FH, FW, C]
+  const float *proj;        // [B, V, 12]
+  const float *new_origin;  // [B, 3]
+  const int *crop_hw;       // [B, 2]
+  float *volume;            // [B, N, C]
+  uint8_t *valid;           // [B, N]
+  float vs0, vs1, vs2;
+  int V, FH, FW, C;
+  int X, Y, Z;
+  int N;        // X*Y*Z
+  int nchunk;   // ceil(C / VEC)
+  int lpv_log2; // lanes per voxel = 1 << lpv_log2
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void backproject_mean_kernel(const BpParams p) {
+  const int b = blockIdx.y;
+  const int lpv = 1 << p.lpv_log2;
+  const int lane = threadIdx.x & 63;
+  const int g = lane & (lpv - 1);        // lane inside the voxel group
+  const int gbase = lane & ~(lpv - 1);   // first lane of the group inside the wave
+  const int vox_per_block = 256 >> p.lpv_log2;
+  const int n = blockIdx.x * vox_per_block + (threadIdx.x >> p.lpv_log2);
+  const bool active = n < p.N;
+  const int nn = active ? n : p.N - 1;
+
+  // voxel coordinates: n = (i*Y + j)*Z + k
+  const int k = nn % p.Z;
+  const int t = nn / p.Z;
+  const int j = t % p.Y;
+  const int i = t / p.Y;
+  const float *no = p.new_origin + b * 3;
+  const float px = __fadd_rn(__fmul_rn((float)i, p.vs0), no[0]);
+  const float py = __fadd_rn(__fmul_rn((float)j, p.vs1), no[1]);
+  const float pz = __fadd_rn(__fmul_rn((float)k, p.vs2), no[2]);
+  const int hc = p.crop_hw[b * 2 + 0], wc = p.crop_hw[b * 2 + 1];
+
+  constexpr int MAXCH = 4;  // channel chunks per lane when ceil(C/VEC) > 64 lanes (C up to 1024 for VEC 4)
+  float acc[MAXCH][VEC];
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[q][e] = 0.f;
+  int cnt = 0;
+
+  for (int v0 = 0; v0 < p.V; v0 += lpv) {
+    // lane g projects view v0 + g
+    const int v = v0 + g;
+    int off = -1;
+    if (v < p.V) {
+      const float *P = p.proj + ((size_t)b * p.V + v) * 12;
+      float u = __fmul_rn(P[0], px);
+      u = __fmaf_rn(P[1], py, u);
+      u = __fmaf_rn(P[2], pz, u);
+      u = __fmaf_rn(P[3], 1.0f, u);
+      float w_ = __fmul_rn(P[4], px);
+      w_ = __fmaf_rn(P[5], py, w_);
+      w_ = __fmaf_rn(P[6], pz, w_);
+      w_ = __fmaf_rn(P[7], 1.0f, w_);
+      float d = __fmul_rn(P[8], px);
+      d = __fmaf_rn(P[9], py, d);
+      d = __fmaf_rn(P[10], pz, d);
+      d = __fmaf_rn(P[11], 1.0f, d);
+      const float xr = rintf(__fdiv_rn(u, d));
+      const float yr = rintf(__fdiv_rn(w_, d));
+      const bool ok = (xr >= 0.f) && (yr >= 0.f) && (xr < (float)wc) && (yr < (float)hc) && (d > 0.f);
+      if (ok) off = (((b * p.V + v) * p.FH + (int)yr) * p.FW + (int)xr);
+    }
+    const int nv = (p.V - v0) < lpv ? (p.V - v0) : lpv;
+    for (int s = 0; s < nv; ++s) {
+      const int o = __shfl(off, gbase + s, 64);
+      if (o >= 0) {
+        ++cnt;
+        const float *src = p.feat + (size_t)o * p.C;
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+          const int ch = g + q * lpv;
+          if (ch < p.nchunk) {
+            if constexpr (VEC == 4) {
+              const f32x4 x = *reinterpret_cast<const f32x4 *>(src + ch * 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[q][e] = __fadd_rn(acc[q][e], x[e]);
+            } else {
+              acc[q][0] = __fadd_rn(acc[q][0], src[ch]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (!active) return;
+  const float dn = (float)cnt;
+  float *dst = p.volume + ((size_t)b * p.N + n) * p.C;
+#pragma unroll
+  for (int q = 0; q < MAXCH; ++q) {
+    const int ch = g + q * lpv;
+    if (ch < p.nchunk) {
+      if constexpr (VEC == 4) {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = cnt ? __fdiv_rn(acc[q][e], dn) : 0.f;
+        *reinterpret_cast<f32x4 *>(dst + ch * 4) = y;
+      } else {
+        dst[ch] = cnt ? __fdiv_rn(acc[q][0], dn) : 0.f;
+      }
+    }
+  }
+  if (g == 0) p.valid[(size_t)b * p.N + n] = cnt > 0 ? 1 : 0;
+}
+
+extern "C" int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,
+                                        const float *proj, const float *new_origin, const int32_t *crop_hw,
+                                        const float *voxel_size, int32_t X, int32_t Y, int32_t Z, float *volume,
+                                        uint8_t *valid, ivx_stream_t stream) {
+  IVX_REQUIRE(feat && proj && new_origin && crop_hw && voxel_size && volume && valid, "ivx_backproject_mean_fwd: null argument");
+  IVX_REQUIRE(B > 0 && V > 0 && FH > 0 && FW > 0 && C > 0 && X > 0 && Y > 0 && Z > 0, "ivx_backproject_mean_fwd: non-positive dims");
+  IVX_REQUIRE((int64_t)X * Y * Z < (1LL << 31), "ivx_backproject_mean_fwd: voxel grid too large");
+  IVX_REQUIRE((int64_t)B * V * FH * FW < (1LL << 31), "ivx_backproject_mean_fwd: feature maps too large");
+  IVX_REQUIRE(B <= 65535, "ivx_backproject_mean_fwd: batch too large");
+  BpParams p;
+  p.feat = feat; p.proj = proj; p.new_origin = new_origin; p.crop_hw = crop_hw; p.volume = volume; p.valid = valid;
+  p.vs0 = voxel_size[0]; p.vs1 = voxel_size[1]; p.vs2 = voxel_size[2];
+  p.V = V; p.FH = FH; p.FW = FW; p.C = C; p.X = X; p.Y = Y; p.Z = Z; p.N = X * Y * Z;
+  const int vec = (C % 4 == 0) ? 4 : 1;
+  p.nchunk = (C + vec - 1) / vec;
+  IVX_REQUIRE(p.nchunk <= 64 * 4, "ivx_backproject_mean_fwd: C=%d too large (max %d)", C, 256 * vec);
+  int lg = 0;
+  while ((1 << lg) < p.nchunk && lg < 6) ++lg;
+  p.lpv_log2 = lg;
+  const int vox_per_block = 256 >> lg;
+  dim3 grid((p.N + vox_per_block - 1) / vox_per_block, B);
+  if (vec == 4)
+    hipLaunchKernelGGL(backproject_mean_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(backproject_mean_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  IVX_CHECK_LAUNCH("ivx_backproject_mean_fwd");
+  return IVX_OK;
+}

@@ -1,0 +1,347 @@
+// Channels-last implicit-GEMM convolution on the CDNA4 matrix cores, exact fp32.
+//
+//   GEMM view:  M = B*Do*Ho*Wo output positions, N = Cout, K = KD*KH*KW*Cin (k = tap*Cin + ci)
+//   MFMA:       v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate == an fmaf chain, 64 cyc/SIMD)
+//   Workgroup:  256 threads = 4 wave64, block tile BM x BN = (WR*TM*32) x (WC*TN*32),
+//               each wave owns TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each).
+//   K loop:     slabs of BK = 32 floats.  The im2col gather is done on the fly: a thread owns
+//               one 16-byte chunk column (4 consecutive ci of one tap) of BM/32 A rows and BN/32
+//               B rows, loads them with global_load_dwordx4 one slab ahead (register prefetch),
+//               and stages them in double-buffered LDS with ds_write_b128.
+//   LDS:        row stride 36 floats (144 B = 9 sixteen-byte slots, odd) so the ds_read_b128 of a
+//               fragment (32 rows x 16 B per half-wave) is bank-conflict free.
+//   Fragments:  lane l reads 4 consecutive k (16 B) of row (l & 31); half-wave h = l>>5 takes the
+//               k-group 4h..4h+3 of every 8, so one ds_read_b128 per operand feeds 4 MFMAs.  The
+//               k permutation is the same for A and B, so the sum over k is unchanged.
+//   Epilogue:   y = acc*scale[n] + shift[n] (+ residual, same-shape or nearest-upsampled) (ReLU),
+//               stored with 32 consecutive lanes on 32 consecutive channels (128-byte rows).
+//   Grid:       x = M tiles with an XCD-aware bijective remap (block b runs on XCD b % 8; give every
+//               XCD a contiguous range of M tiles so halo re-reads hit its own L2), y = N tiles.
+//
+// Reference call sites replaced: see include/imvoxel.h (ivx_conv_fwd).
+#include "ivx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+  const float *in, *wgt, *scale, *shift, *res;
+  float *out;
+  int B, D, H, W, Cin;
+  int Cout, KD, KH, KW;
+  int sd, sh, sw, pd, ph, pw;
+  int Do, Ho, Wo;
+  int M, K;
+  int relu, res_mode, rH, rW;
+};
+
+#define IVX_BK 32
+#define IVX_LDK 36
+
+// Row base (in floats) of the nearest-upsampled residual for output row m (res_mode 2; FPN top-down,
+// F.interpolate(mode='nearest', size=...): src = min(floor(dst * in/out), in-1), identity / >>1 when exact).
+__device__ __noinline__ size_t res2_row_base(int m, int Ho, int Wo, int rH, int rW, int Cout) {
+  const int ow = m % Wo;
+  const int t = m / Wo;
+  const int oh = t % Ho;
+  const int b = t / Ho;  // Do == 1 for this mode
+  int sh_ = (Ho == rH) ? oh : (Ho == 2 * rH ? (oh >> 1) : (int)floorf(oh * ((float)rH / Ho)));
+  int sw_ = (Wo == rW) ? ow : (Wo == 2 * rW ? (ow >> 1) : (int)floorf(ow * ((float)rW / Wo)));
+  sh_ = sh_ < rH - 1 ? sh_ : rH - 1;
+  sw_ = sw_ < rW - 1 ? sw_ : rW - 1;
+  return (((size_t)b * rH + sh_) * rW + sw_) * Cout;
+}
+
+template <int TM, int TN, int WR, int WC>
+__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p) {
+  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  constexpr int AR = BM / 32, BR = BN / 32;
+  static_assert(WR * WC == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * IVX_LDK];
+  float *As = smem;
+  float *Bs = smem + 2 * BM * IVX_LDK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid / WC, wc = wid % WC;
+
+  // XCD-aware bijective remap of the M-tile index.
+  int bid = blockIdx.x;
+  {
+    const int nb = gridDim.x;
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = bid * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- loader state -------------------------------------------------------------------------
+  const int cc = tid & 7;   // 16-byte chunk column inside the slab
+  const int lr = tid >> 3;  // 0..31
+  int a_bd[AR], a_id[AR], a_ih[AR], a_iw[AR];
+#pragma unroll
+  for (int j = 0; j < AR; ++j) {
+    const int m = m0 + lr + 32 * j;
+    if (m < p.M) {
+      const int ow = m % p.Wo;
+      int t = m / p.Wo;
+      const int oh = t % p.Ho;
+      t /= p.Ho;
+      const int od = t % p.Do;
+      const int b = t / p.Do;
+      a_bd[j] = b * p.D;
+      a_id[j] = od * p.sd - p.pd;
+      a_ih[j] = oh * p.sh - p.ph;
+      a_iw[j] = ow * p.sw - p.pw;
+    } else {
+      a_bd[j] = 0;
+      a_id[j] = -(1 << 28);  // fails the bounds test for every tap
+      a_ih[j] = 0;
+      a_iw[j] = 0;
+    }
+  }
+  // per-thread k cursor: k4 = slab*32 + cc*4 = tap*Cin + kc
+  int k4 = cc * 4;
+  int kc, ka, ke, kf;
+  {
+    const int tap = k4 / p.Cin;
+    kc = k4 - tap * p.Cin;
+    kf = tap % p.KW;
+    const int t2 = tap / p.KW;
+    ke = t2 % p.KH;
+    ka = t2 / p.KH;
+  }
+  const int S = (p.K + IVX_BK - 1) / IVX_BK;
+
+  f32x4 ra[AR], rb[BR];
+  auto load_slab = [&]() {
+    const bool kok = k4 < p.K;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+      const int id = a_id[j] + ka, ih = a_ih[j] + ke, iw = a_iw[j] + kf;
+      const bool ok = kok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H &&
+                      (unsigned)iw < (unsigned)p.W;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const size_t off = (((size_t)(a_bd[j] + id) * p.H + ih) * p.W + iw) * (size_t)p.Cin + kc;
+        v = *reinterpret_cast<const f32x4 *>(p.in + off);
+      }
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const int n = n0 + lr + 32 * j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (kok && n < p.Cout) v = *reinterpret_cast<const f32x4 *>(p.wgt + (size_t)n * p.K + k4);
+      rb[j] = v;
+    }
+  };
+  auto advance_k = [&]() {
+    k4 += IVX_BK;
+    kc += IVX_BK;
+    while (kc >= p.Cin) {
+      kc -= p.Cin;
+      if (++kf == p.KW) {
+        kf = 0;
+        if (++ke == p.KH) {
+          ke = 0;
+          ++ka;
+        }
+      }
+    }
+  };
+  auto store_slab = [&](int buf) {
+    float *Ab = As + buf * BM * IVX_LDK + lr * IVX_LDK + cc * 4;
+    float *Bb = Bs + buf * BN * IVX_LDK + lr * IVX_LDK + cc * 4;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) *reinterpret_cast<f32x4 *>(Ab + 32 * j * IVX_LDK) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4 *>(Bb + 32 * j * IVX_LDK) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_slab();
+  store_slab(0);
+  __syncthreads();
+
+  const int frag_off = (lane & 31) * IVX_LDK + 4 * (lane >> 5);
+  for (int s = 0; s < S; ++s) {
+    const int cur = s & 1;
+    const bool more = (s + 1) < S;
+    if (more) {
+      advance_k();
+      load_slab();
+    }
+    const float *Ac = As + cur * BM * IVX_LDK + wr * TM * 32 * IVX_LDK + frag_off;
+    const float *Bc = Bs + cur * BN * IVX_LDK + wc * TN * 32 * IVX_LDK + frag_off;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_LDK + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * IVX_LDK + kk * 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_slab(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------
+  const int col_l = lane & 31, hh = lane >> 5;
+  float sc[TN], sf[TN];
+  int nn[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    nn[j] = n0 + (wc * TN + j) * 32 + col_l;
+    const bool nok = nn[j] < p.Cout;
+    sc[j] = (nok && p.scale) ? p.scale[nn[j]] : 1.0f;
+    sf[j] = (nok && p.shift) ? p.shift[nn[j]] : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (m >= p.M) continue;
+      size_t rbase = (size_t)m * p.Cout;
+      if (p.res_mode == 2) rbase = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (nn[j] >= p.Cout) continue;
+        float v = acc[i][j][r] * sc[j] + sf[j];
+        if (p.res_mode) v += p.res[rbase + nn[j]];
+        if (p.relu) v = v > 0.f ? v : 0.f;
+        p.out[(size_t)m * p.Cout + nn[j]] = v;
+      }
+    }
+  }
+}
+
+// Validation kernel: one thread per output element, sequential fmaf over (kd,kh,kw,ci).
+__global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p) {
+  const size_t total = (size_t)p.M * p.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % p.Cout);
+    const int m = (int)(idx / p.Cout);
+    const int ow = m % p.Wo;
+    int t = m / p.Wo;
+    const int oh = t % p.Ho;
+    t /= p.Ho;
+    const int od = t % p.Do;
+    const int b = t / p.Do;
+    float acc = 0.f;
+    for (int a = 0; a < p.KD; ++a) {
+      const int id = od * p.sd - p.pd + a;
+      if ((unsigned)id >= (unsigned)p.D) continue;
+      for (int e = 0; e < p.KH; ++e) {
+        const int ih = oh * p.sh - p.ph + e;
+        if ((unsigned)ih >= (unsigned)p.H) continue;
+        for (int f = 0; f < p.KW; ++f) {
+          const int iw = ow * p.sw - p.pw + f;
+          if ((unsigned)iw >= (unsigned)p.W) continue;
+          const float *x = p.in + ((((size_t)b * p.D + id) * p.H + ih) * p.W + iw) * p.Cin;
+          const float *w = p.wgt + (size_t)n * p.K + ((a * p.KH + e) * p.KW + f) * p.Cin;
+          for (int c = 0; c < p.Cin; ++c) acc = fmaf(x[c], w[c], acc);
+        }
+      }
+    }
+    float v = acc * (p.scale ? p.scale[n] : 1.0f) + (p.shift ? p.shift[n] : 0.0f);
+    if (p.res_mode == 1) {
+      v += p.res[(size_t)m * p.Cout + n];
+    } else if (p.res_mode == 2) {
+      v += p.res[res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + n];
+    }
+    if (p.relu) v = v > 0.f ? v : 0.f;
+    p.out[idx] = v;
+  }
+}
+
+static int fill_params(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
+                       const float *shift, const float *res, float *out, ConvParams *p) {
+  IVX_REQUIRE(d && in && wgt && out, "ivx_conv_fwd: null argument");
+  IVX_REQUIRE(d->B > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "ivx_conv_fwd: non-positive dims");
+  IVX_REQUIRE(d->Cin % 4 == 0, "ivx_conv_fwd: Cin (%d) must be a multiple of 4 (pad the input channels)", d->Cin);
+  IVX_REQUIRE(d->KD > 0 && d->KH > 0 && d->KW > 0 && d->sd > 0 && d->sh > 0 && d->sw > 0, "ivx_conv_fwd: bad kernel/stride");
+  IVX_REQUIRE(d->pd >= 0 && d->ph >= 0 && d->pw >= 0, "ivx_conv_fwd: negative padding");
+  int32_t Do, Ho, Wo;
+  if (ivx_conv_out_dims(d, &Do, &Ho, &Wo) != IVX_OK) return IVX_ERR_INVALID_ARG;
+  const int64_t M = (int64_t)d->B * Do * Ho * Wo;
+  const int64_t K = (int64_t)d->KD * d->KH * d->KW * d->Cin;
+  IVX_REQUIRE(M < (1LL << 31) - 512 && K < (1LL << 30), "ivx_conv_fwd: problem too large for 32-bit row index");
+  IVX_REQUIRE((int64_t)d->B * d->D * d->H * d->W < (1LL << 31), "ivx_conv_fwd: input voxel count exceeds 2^31");
+  IVX_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2, "ivx_conv_fwd: bad res_mode");
+  IVX_REQUIRE(d->res_mode == 0 || res, "ivx_conv_fwd: res_mode set but res is NULL");
+  if (d->res_mode == 2) {
+    IVX_REQUIRE(Do == 1 && d->res_h > 0 && d->res_w > 0, "ivx_conv_fwd: res_mode 2 needs a 2-D output and res dims");
+  }
+  p->in = in; p->wgt = wgt; p->scale = scale; p->shift = shift; p->res = d->res_mode ? res : nullptr; p->out = out;
+  p->B = d->B; p->D = d->D; p->H = d->H; p->W = d->W; p->Cin = d->Cin;
+  p->Cout = d->Cout; p->KD = d->KD; p->KH = d->KH; p->KW = d->KW;
+  p->sd = d->sd; p->sh = d->sh; p->sw = d->sw; p->pd = d->pd; p->ph = d->ph; p->pw = d->pw;
+  p->Do = Do; p->Ho = Ho; p->Wo = Wo; p->M = (int)M; p->K = (int)K;
+  p->relu = d->relu; p->res_mode = d->res_mode; p->rH = d->res_h; p->rW = d->res_w;
+  return IVX_OK;
+}
+
+extern "C" int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *Ho, int32_t *Wo) {
+  IVX_REQUIRE(d && Do && Ho && Wo, "ivx_conv_out_dims: null argument");
+  const int od = (d->D + 2 * d->pd - d->KD) / d->sd + 1;
+  const int oh = (d->H + 2 * d->ph - d->KH) / d->sh + 1;
+  const int ow = (d->W + 2 * d->pw - d->KW) / d->sw + 1;
+  IVX_REQUIRE(d->D + 2 * d->pd >= d->KD && d->H + 2 * d->ph >= d->KH && d->W + 2 * d->pw >= d->KW && od > 0 && oh > 0 && ow > 0,
+              "ivx_conv_out_dims: kernel larger than padded input");
+  *Do = od; *Ho = oh; *Wo = ow;
+  return IVX_OK;
+}
+
+template <int TM, int TN, int WR, int WC>
+static void launch_cfg(const ConvParams &p, hipStream_t st) {
+  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
+}
+
+extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
+                            const float *shift, const float *res, float *out, ivx_stream_t stream) {
+  ConvParams p;
+  int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
+  if (rc != IVX_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (p.Cout > 64)
+    launch_cfg<2, 2, 2, 2>(p, st);  // 128 x 128
+  else if (p.Cout > 32)
+    launch_cfg<2, 2, 4, 1>(p, st);  // 256 x 64
+  else
+    launch_cfg<1, 1, 4, 1>(p, st);  // 128 x 32
+  IVX_CHECK_LAUNCH("ivx_conv_fwd");
+  return IVX_OK;
+}
+
+extern "C" int ivx_conv_fwd_naive(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
+                                  const float *shift, const float *res, float *out, ivx_stream_t stream) {
+  ConvParams p;
+  int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
+  if (rc != IVX_OK) return rc;
+  const size_t total = (size_t)p.M * p.Cout;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 65536 * 8) blocks = 65536 * 8;
+  hipLaunchKernelGGL(conv_naive_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  IVX_CHECK_LAUNCH("ivx_conv_fwd_naive");
+  return IVX_OK;
+}

@@ -1,0 +1,144 @@
+"""ImVoxelNet detector (inference) under the reference's registry name, constructor kwargs and method
+surface (mmdet3d/models/detectors/imvoxelnet.py:8-187): extract_feat / simple_test / forward_test.
+
+Differences in HOW, not WHAT:
+  * the whole path runs channels-last on the device through libimvoxel_hip.so; tensors are converted to
+    the reference layout only where the public methods hand them to the caller;
+  * the per-sample Python loop (:58-76) is one fused launch for the batch; only the tiny per-sample
+    camera set-up (:114-129, :139) stays on the host, using the same torch CPU ops as the reference, and is
+    uploaded once per batch;
+  * FPN levels 1..3 are not computed (only level 0 is consumed, :50).
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .boxes import bbox3d2result
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+
+
+@torch.no_grad()
+def get_points(n_voxels, voxel_size, origin):
+    """detectors/imvoxelnet.py:132-141 (host helper kept for API parity; the kernel computes the same
+    idx * voxel_size + new_origin in registers)."""
+    points = torch.stack(torch.meshgrid([torch.arange(n_voxels[0]), torch.arange(n_voxels[1]),
+                                         torch.arange(n_voxels[2])], indexing='ij'))
+    new_origin = origin - n_voxels / 2. * voxel_size
+    return points * voxel_size.view(3, 1, 1, 1) + new_origin.view(3, 1, 1, 1)
+
+
+@DETECTORS.register_module()
+class ImVoxelNet(nn.Module):
+    def __init__(self, backbone, neck, neck_3d, bbox_head, n_voxels, voxel_size, head_2d=None, train_cfg=None,
+                 test_cfg=None, pretrained=None):
+        super().__init__()
+        if head_2d is not None:
+            raise NotImplementedError('head_2d (LayoutHead, SUN RGB-D Total configs) is outside the built path')
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck)
+        self.neck_3d = build_neck(neck_3d)
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = build_head(bbox_head)
+        self.bbox_head.voxel_size = voxel_size
+        self.head_2d = None
+        self.n_voxels = tuple(int(v) for v in n_voxels)
+        self.voxel_size = tuple(float(v) for v in voxel_size)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_weights(pretrained=pretrained)
+
+    def init_weights(self, pretrained=None):
+        self.backbone.init_weights(pretrained=pretrained)
+        self.neck.init_weights()
+        self.neck_3d.init_weights()
+        self.bbox_head.init_weights()
+
+    def prepare(self, device):
+        """Pack every layer's parameters for the device kernels (call again after changing weights)."""
+        for m in (self.backbone, self.neck, self.neck_3d, self.bbox_head):
+            m.prepare(device)
+        return self
+
+    # ------------------------------------------------------------------ host-side camera set-up
+    @staticmethod
+    def _compute_projection(img_meta, stride, angles=None):
+        """detectors/imvoxelnet.py:114-129 with the same torch CPU ops (angles: SUN RGB-D Total only)."""
+        if angles is not None:
+            raise NotImplementedError('predicted-angle extrinsics (head_2d) are outside the built path')
+        intrinsic = torch.tensor(img_meta['lidar2img']['intrinsic'][:3, :3])
+        ratio = img_meta['ori_shape'][0] / (img_meta['img_shape'][0] / stride)
+        intrinsic[:2] /= ratio
+        return torch.stack([intrinsic @ torch.tensor(e)[:3] for e in img_meta['lidar2img']['extrinsic']])
+
+    def _camera_setup(self, img_metas, stride, device):
+        proj, orig, crop = [], [], []
+        nv = torch.tensor(self.n_voxels)
+        vs = torch.tensor(self.voxel_size)
+        for meta in img_metas:
+            p = self._compute_projection(meta, stride, None)
+            if p.dtype != torch.float32:
+                raise TypeError('lidar2img intrinsic/extrinsic must be float32 (as the reference datasets produce)')
+            proj.append(p)
+            origin = torch.tensor(meta['lidar2img']['origin'])
+            if origin.dtype != torch.float32:
+                origin = origin.float()
+            orig.append(origin - nv / 2. * vs)                      # :139
+            crop.append([meta['img_shape'][0] // stride, meta['img_shape'][1] // stride])   # :67-68
+        V = proj[0].shape[0]
+        if any(p.shape[0] != V for p in proj):
+            raise ValueError('all samples of a batch must have the same number of views')
+        return (torch.stack(proj).contiguous().to(device), torch.stack(orig).contiguous().to(device),
+                torch.tensor(crop, dtype=torch.int32).to(device))
+
+    # ------------------------------------------------------------------ channels-last fast path
+    def features_2d_cl(self, img):
+        """img [B,V,3,H,W] -> FPN level 0, channels-last [B*V,1,H/4,W/4,Cf]."""
+        B = img.shape[0]
+        x = img.reshape([-1] + list(img.shape)[2:]).contiguous()
+        feats = self.backbone.forward_cl(ops.to_channels_last(x, pad_to=4))
+        p0 = self.neck.forward_cl(list(feats))[0]
+        stride = x.shape[-1] / p0.shape[3]
+        assert stride == 4, 'stride of FPN level 0 must be 4 (detectors/imvoxelnet.py:53-54)'
+        return p0
+
+    def lift_cl(self, p0, img_metas):
+        """FPN level 0 [B*V,1,h,w,C] + metas -> (volume [B,X,Y,Z,C], valid [B,X,Y,Z] bool)."""
+        proj, new_origin, crop = self._camera_setup(img_metas, 4, p0.device)
+        return ops.backproject_mean(p0, proj, new_origin, crop, self.voxel_size, self.n_voxels)
+
+    def detect_cl(self, volume, img_metas, want_candidates=False):
+        y = self.neck_3d.forward_cl(volume)                      # [B,X',Y',1,C]
+        h = self.bbox_head.forward_cl(y)                         # [B,X',Y',1,CH]
+        # the reference transposes to [B,C,Y',X'] (necks/imvoxelnet.py:120): H = Y', W = X'
+        return self.bbox_head.get_bboxes_cl(h, y.shape[2], y.shape[1], img_metas, hw_transposed=True,
+                                            want_candidates=want_candidates)
+
+    # ------------------------------------------------------------------ reference surface
+    def extract_feat(self, img, img_metas, mode='test'):
+        """-> (list of neck outputs in the reference layout, valids [B,1,X,Y,Z] bool, None)."""
+        p0 = self.features_2d_cl(img)
+        volume, valid = self.lift_cl(p0, img_metas)
+        y = self.neck_3d.forward_cl(volume)
+        out = ops.from_channels_last(y, 3)
+        return [out[..., 0].transpose(-1, -2)], valid.unsqueeze(1), None
+
+    def simple_test(self, img, img_metas):
+        p0 = self.features_2d_cl(img)
+        volume, _ = self.lift_cl(p0, img_metas)
+        boxes, scores, labels, count = self.detect_cl(volume, img_metas)
+        dets = self.bbox_head._wrap(boxes, scores, labels, count, img_metas)
+        return [bbox3d2result(b, s, l) for b, s, l in dets]
+
+    def forward_test(self, img, img_metas, **kwargs):
+        return self.simple_test(img, img_metas)
+
+    def forward(self, img, img_metas, return_loss=False, **kwargs):
+        if return_loss:
+            raise NotImplementedError('training (forward_train / losses) is outside the built path')
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def aug_test(self, imgs, img_metas):
+        pass
+
+    def show_results(self, *args, **kwargs):
+        pass

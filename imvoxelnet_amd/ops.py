@@ -1,0 +1,206 @@
+"""Tensor-level wrappers over the C-ABI.  torch tensors are containers only: every wrapper
+checks device / dtype / contiguity (as CHECK_INPUT does for the reference's native op,
+mmdet3d/ops/iou3d/src/iou3d.cpp:17-23), allocates the output with torch.empty and passes raw
+pointers plus the current HIP stream to libimvoxel_hip.so.
+
+Internal activation layout is channels-last: 5-D [B, D, H, W, C] (a 2-D map has D == 1).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, AnchorHeadDesc, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name} must be a torch.Tensor')
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a device (HIP) tensor; the MI355X path has no CPU fallback')
+    if t.dtype != dtype:
+        raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ------------------------------------------------------------------ layout
+def to_channels_last(x, pad_to=None):
+    """[B,C,*spatial] (reference layout) -> [B,D,H,W,Cpad] channels-last (D=1 for 2-D input)."""
+    _chk(x, 'x')
+    B, Cn = x.shape[0], x.shape[1]
+    sp = list(x.shape[2:])
+    if len(sp) == 2:
+        sp = [1] + sp
+    S = sp[0] * sp[1] * sp[2]
+    Cp = Cn if pad_to is None else ((Cn + pad_to - 1) // pad_to) * pad_to
+    out = torch.empty([B] + sp + [Cp], device=x.device, dtype=torch.float32)
+    check(_lib.lib().ivx_nchw_to_nhwc(_ptr(x), B, Cn, S, Cp, _ptr(out), _stream()), 'ivx_nchw_to_nhwc')
+    return out
+
+
+def from_channels_last(x, ndim_spatial=3):
+    """[B,D,H,W,C] -> [B,C,D,H,W] (or [B,C,H,W] when ndim_spatial == 2)."""
+    _chk(x, 'x')
+    B, D, H, W, Cn = x.shape
+    S = D * H * W
+    shape = [B, Cn, D, H, W] if ndim_spatial == 3 else [B, Cn, H, W]
+    if ndim_spatial == 2 and D != 1:
+        raise ValueError('2-D output requested but D != 1')
+    out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    check(_lib.lib().ivx_nhwc_to_nchw(_ptr(x), B, S, Cn, _ptr(out), _stream()), 'ivx_nhwc_to_nchw')
+    return out
+
+
+# ------------------------------------------------------------------ conv
+def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0), relu=False,
+             res=None, res_mode=0, naive=False, out=None):
+    """x [B,D,H,W,Cin], wgt [Cout,KD,KH,KW,Cin] (packed), scale/shift [Cout] -> [B,Do,Ho,Wo,Cout]."""
+    _chk(x, 'x')
+    _chk(wgt, 'wgt')
+    B, D, H, W, Cin = x.shape
+    Cout = wgt.shape[0]
+    if tuple(wgt.shape[1:]) != (kernel[0], kernel[1], kernel[2], Cin):
+        raise ValueError(f'weight shape {tuple(wgt.shape)} does not match kernel {kernel} / Cin {Cin}')
+    d = ConvDesc(B, D, H, W, Cin, Cout, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
+                 padding[0], padding[1], padding[2], int(bool(relu)), 0, 0, 0)
+    do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
+    L = _lib.lib()
+    check(L.ivx_conv_out_dims(C.byref(d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')
+    if res is not None:
+        _chk(res, 'res')
+        if res_mode == 0:
+            res_mode = 1
+        if res_mode == 1 and tuple(res.shape) != (B, do.value, ho.value, wo.value, Cout):
+            raise ValueError(f'residual shape {tuple(res.shape)} != output shape')
+        if res_mode == 2:
+            if res.shape[0] != B or res.shape[1] != 1 or res.shape[4] != Cout:
+                raise ValueError('res_mode 2 residual must be [B,1,h,w,Cout]')
+            d.res_h, d.res_w = res.shape[2], res.shape[3]
+        d.res_mode = res_mode
+    for t, n in ((scale, 'scale'), (shift, 'shift')):
+        if t is not None:
+            _chk(t, n)
+            if t.numel() != Cout:
+                raise ValueError(f'{n} must have Cout elements')
+    if out is None:
+        out = torch.empty((B, do.value, ho.value, wo.value, Cout), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, 'out')
+    fn = L.ivx_conv_fwd_naive if naive else L.ivx_conv_fwd
+    check(fn(C.byref(d), _ptr(x), _ptr(wgt), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _stream()), 'ivx_conv_fwd')
+    return out
+
+
+def maxpool2d(x, k=3, s=2, p=1):
+    _chk(x, 'x')
+    B, D, H, W, Cn = x.shape
+    if D != 1:
+        raise ValueError('maxpool2d expects a 2-D map (D == 1)')
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    out = torch.empty((B, 1, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
+    check(_lib.lib().ivx_maxpool2d_fwd(_ptr(x), B, H, W, Cn, k, s, p, _ptr(out), _stream()), 'ivx_maxpool2d_fwd')
+    return out
+
+
+# ------------------------------------------------------------------ unprojection
+def backproject_mean(feat, proj, new_origin, crop_hw, voxel_size, n_voxels):
+    """feat [B*V,1,FH,FW,C] channels-last, proj [B,V,3,4], new_origin [B,3], crop_hw [B,2] int32 (device)
+    -> volume [B,X,Y,Z,C] fp32, valid [B,X,Y,Z] bool."""
+    _chk(feat, 'feat')
+    _chk(proj, 'proj')
+    _chk(new_origin, 'new_origin')
+    _chk(crop_hw, 'crop_hw', torch.int32)
+    B, V = proj.shape[0], proj.shape[1]
+    BV, D, FH, FW, Cn = feat.shape
+    if BV != B * V or D != 1 or tuple(proj.shape[2:]) != (3, 4):
+        raise ValueError('feat / proj shapes do not agree')
+    X, Y, Z = (int(v) for v in n_voxels)
+    vol = torch.empty((B, X, Y, Z, Cn), device=feat.device, dtype=torch.float32)
+    valid = torch.empty((B, X, Y, Z), device=feat.device, dtype=torch.uint8)
+    vs = (C.c_float * 3)(*[float(v) for v in voxel_size])
+    check(_lib.lib().ivx_backproject_mean_fwd(_ptr(feat), B, V, FH, FW, Cn, _ptr(proj), _ptr(new_origin), _ptr(crop_hw),
+                                              vs, X, Y, Z, _ptr(vol), _ptr(valid), _stream()), 'ivx_backproject_mean_fwd')
+    return vol, valid.view(torch.bool)
+
+
+# ------------------------------------------------------------------ detection tail
+def anchor_head_get_bboxes(head_out, anchors, H, W, num_anchors, num_classes, offs, cfg, dir_offset=0.0,
+                           dir_limit_offset=1.0, hw_transposed=False, want_candidates=False):
+    """head_out [B,*,*,CH] channels-last map of the fused head conv; anchors [H*W*A,7].
+    Returns (boxes [B,max_num,7], scores [B,max_num], labels [B,max_num] int64, count [B] int32[, cands])."""
+    _chk(head_out, 'head_out')
+    _chk(anchors, 'anchors')
+    B, CH = head_out.shape[0], head_out.shape[-1]
+    if head_out.numel() != B * H * W * CH:
+        raise ValueError('head_out does not hold B*H*W*CH values')
+    if anchors.shape[0] != H * W * num_anchors or anchors.shape[1] != 7:
+        raise ValueError('anchors must be [H*W*A, 7]')
+    nms_pre, max_num = int(cfg['nms_pre']), int(cfg['max_num'])
+    d = AnchorHeadDesc(B, H, W, CH, num_anchors, num_classes, offs[0], offs[1], offs[2], nms_pre, max_num,
+                       int(bool(cfg['use_rotate_nms'])), int(bool(hw_transposed)), float(cfg.get('score_thr', 0)),
+                       float(cfg['nms_thr']), float(dir_offset), float(dir_limit_offset))
+    L = _lib.lib()
+    ws_bytes = L.ivx_anchor_head_workspace_bytes(C.byref(d))
+    if ws_bytes < 0:
+        check(-1, 'ivx_anchor_head_workspace_bytes')
+    ws = torch.empty((ws_bytes,), device=head_out.device, dtype=torch.uint8)
+    boxes = torch.empty((B, max_num, 7), device=head_out.device, dtype=torch.float32)
+    scores = torch.empty((B, max_num), device=head_out.device, dtype=torch.float32)
+    labels = torch.empty((B, max_num), device=head_out.device, dtype=torch.int64)
+    count = torch.empty((B,), device=head_out.device, dtype=torch.int32)
+    ci = cb = cs = None
+    if want_candidates:
+        ci = torch.empty((B, nms_pre), device=head_out.device, dtype=torch.int64)
+        cb = torch.empty((B, nms_pre, 7), device=head_out.device, dtype=torch.float32)
+        cs = torch.empty((B, nms_pre), device=head_out.device, dtype=torch.float32)
+    check(L.ivx_anchor_head_get_bboxes(C.byref(d), _ptr(head_out), _ptr(anchors), _ptr(ws), ws_bytes, _ptr(boxes),
+                                       _ptr(scores), _ptr(labels), _ptr(count), _ptr(ci), _ptr(cb), _ptr(cs), _stream()),
+          'ivx_anchor_head_get_bboxes')
+    if want_candidates:
+        return boxes, scores, labels, count, (ci, cb, cs)
+    return boxes, scores, labels, count
+
+
+def nms_bev_sorted(boxes_sorted, thresh, rotated=True):
+    """boxes [n,5] sorted by descending score -> (keep [n] int64, num [1] int32) device tensors."""
+    _chk(boxes_sorted, 'boxes')
+    n = boxes_sorted.shape[0]
+    L = _lib.lib()
+    ws_bytes = L.ivx_nms_workspace_bytes(n)
+    ws = torch.empty((max(int(ws_bytes), 256),), device=boxes_sorted.device, dtype=torch.uint8)
+    keep = torch.empty((max(n, 1),), device=boxes_sorted.device, dtype=torch.int64)
+    num = torch.empty((1,), device=boxes_sorted.device, dtype=torch.int32)
+    check(L.ivx_nms_bev(_ptr(boxes_sorted), n, float(thresh), int(bool(rotated)), _ptr(ws), ws.numel(), _ptr(keep),
+                        _ptr(num), _stream()), 'ivx_nms_bev')
+    return keep, num
+
+
+def boxes_overlap_bev(a, b, iou=False):
+    _chk(a, 'a')
+    _chk(b, 'b')
+    out = torch.zeros((a.shape[0], b.shape[0]), device=a.device, dtype=torch.float32)
+    check(_lib.lib().ivx_boxes_overlap_bev(_ptr(a), a.shape[0], _ptr(b), b.shape[0], int(bool(iou)), _ptr(out), _stream()),
+          'ivx_boxes_overlap_bev')
+    return out
+
+
+def aligned_3d_nms_dev(boxes, scores, classes, thresh):
+    _chk(boxes, 'boxes')
+    _chk(scores, 'scores')
+    _chk(classes, 'classes', torch.int64)
+    n = boxes.shape[0]
+    pick = torch.empty((max(n, 1),), device=boxes.device, dtype=torch.int64)
+    num = torch.empty((1,), device=boxes.device, dtype=torch.int32)
+    check(_lib.lib().ivx_aligned_3d_nms(_ptr(boxes), _ptr(scores), _ptr(classes), n, float(thresh), _ptr(pick), _ptr(num),
+                                        _stream()), 'ivx_aligned_3d_nms')
+    return pick, num

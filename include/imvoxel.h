@@ -1,0 +1,169 @@
+/*
+ * imvoxel.h -- C-ABI of libimvoxel_hip.so, the MI355X (gfx950) implementation of the
+ * ImVoxelNet forward hot path.
+ *
+ * Boundary convention.  The reference reaches native code on this
+ * path in exactly two ways:
+ *   (1) torch.nn ops (Conv2d/Conv3d/BatchNorm/ReLU/max_pool/interpolate/bmm/index/topk)
+ *       that dispatch into cuDNN/cuBLAS, and
+ *   (2) its own pybind module iou3d_cuda:  int nms_gpu(Tensor boxes, Tensor keep,
+ *       float thr, int device_id)   (mmdet3d/ops/iou3d/src/iou3d.cpp:95-147,203-208).
+ * Every entry point below replaces one of those call sites and keeps convention (2):
+ * plain pointers + sizes, caller-owned buffers, int status return (0 = ok, <0 = error;
+ * the library never exit()s, unlike gpuAssert at iou3d.cpp:27-36), no torch types, no
+ * hidden allocation, asynchronous on the HIP stream handed in (hipStream_t as void*;
+ * NULL = the default stream).  All pointers are DEVICE pointers unless marked "host".
+ *
+ * Layouts: activations are channels-last fp32 -- NHWC for 2-D, NDHWC for 3-D (a 2-D
+ * tensor is the D == 1 case).  For the feature volume the reference's (X, Y, Z) axes are
+ * (D, H, W), so a voxel's C channels are contiguous and z is the fastest spatial axis,
+ * matching the reference's flat voxel index n = (i*Y + j)*Z + k
+ * (mmdet3d/models/detectors/imvoxelnet.py:148).
+ */
+#ifndef IMVOXEL_H_
+#define IMVOXEL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVX_OK 0
+#define IVX_ERR_INVALID_ARG (-1)
+#define IVX_ERR_HIP (-2)
+#define IVX_ERR_UNSUPPORTED (-3)
+#define IVX_ERR_WORKSPACE (-4)
+
+typedef void *ivx_stream_t; /* hipStream_t */
+
+/* Library version (major*10000 + minor*100 + patch) and the message of the last failing
+ * call on this thread (never NULL). */
+int ivx_version(void);
+const char *ivx_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Channels-last convolution with fused epilogue -- replaces nn.Conv2d / nn.Conv3d followed
+ * by eval-mode BatchNorm, residual add and ReLU:
+ *   ResNet-50 / FPN call sites  mmdet3d/models/detectors/imvoxelnet.py:48,50
+ *   3-D necks                   mmdet3d/models/necks/imvoxelnet.py:46-60,99-113,181-230
+ *   head convs                  mmdet3d/models/dense_heads/anchor3d_head.py:122-153
+ *
+ *   out[b,do,ho,wo,co] = act( (sum_{kd,kh,kw,ci} in[b, do*sd-pd+kd, ho*sh-ph+kh, wo*sw-pw+kw, ci]
+ *                              * wgt[co,kd,kh,kw,ci]) * scale[co] + shift[co] + res[...] )
+ *
+ * in    [B,D,H,W,Cin]   Cin % 4 == 0 (pad the image to 4 channels with ivx_nchw_to_nhwc)
+ * wgt   [Cout,KD,KH,KW,Cin]
+ * scale,shift [Cout] or NULL (1 / 0).  Conv bias and BN fold into them on the host.
+ * res   NULL, or res_mode 1: same shape as out; res_mode 2: [B,1,res_h,res_w,Cout] read with
+ *       nearest-neighbour up-sampling to (Ho,Wo) (FPN top-down path, F.interpolate 'nearest').
+ * Arithmetic: fp32 inputs, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.            */
+typedef struct ivx_conv_desc {
+  int32_t B, D, H, W, Cin;
+  int32_t Cout, KD, KH, KW;
+  int32_t sd, sh, sw;
+  int32_t pd, ph, pw;
+  int32_t relu;
+  int32_t res_mode, res_h, res_w;
+} ivx_conv_desc;
+
+int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *Ho, int32_t *Wo);
+int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
+                 const float *shift, const float *res, float *out, ivx_stream_t stream);
+/* Validation kernel: same contract, one thread per output element, plain FMA loop. Used by the
+ * GPU tests to cross-check the MFMA kernel at full size; never called by the product path.   */
+int ivx_conv_fwd_naive(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
+                       const float *shift, const float *res, float *out, ivx_stream_t stream);
+
+/* nn.MaxPool2d(kernel, stride, padding) on NHWC (ResNet stem: 3, 2, 1). */
+int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                      int32_t s, int32_t p, float *out, ivx_stream_t stream);
+
+/* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] (channels >= C zero filled), and NHWC/NDHWC -> NCHW/NCDHW
+ * ([B,S,C] -> [B,C,S] with S = product of the spatial dims). */
+int ivx_nchw_to_nhwc(const float *in, int32_t B, int32_t C, int64_t S, int32_t Cpad, float *out,
+                     ivx_stream_t stream);
+int ivx_nhwc_to_nchw(const float *in, int32_t B, int64_t S, int32_t C, float *out, ivx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused image-to-voxel unprojection -- replaces the per-sample Python loop
+ * mmdet3d/models/detectors/imvoxelnet.py:58-76 (get_points :132-141, backproject :145-160,
+ * view sum / count / divide / zero-fill :70-74) for a whole batch in one launch.
+ *
+ * feat        [B*V, FH, FW, C]  FPN level-0 features, NHWC
+ * proj        [B, V, 3, 4]      per-view K' @ E[:3] (built on the host exactly as :114-129)
+ * new_origin  [B, 3]            origin - n_voxels/2 * voxel_size (fp32, :139)
+ * crop_hw     [B, 2] int32      img_shape // stride (h, w): the crop at :67-69
+ * voxel_size  host float[3]
+ * volume      [B, X, Y, Z, C]   mean over valid views, 0 where no view sees the voxel
+ * valid       [B, X, Y, Z] u8   1 where >= 1 view sees the voxel (the reference's `valids`)
+ * Projection arithmetic is the reference's bit for bit: fp32 FMA chain in k order (what
+ * torch.bmm does), IEEE division, round-half-even, nearest-pixel gather.                    */
+int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,
+                             const float *proj, const float *new_origin, const int32_t *crop_hw,
+                             const float *voxel_size /*host*/, int32_t X, int32_t Y, int32_t Z,
+                             float *volume, uint8_t *valid, ivx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Anchor3DHead tail -- replaces Anchor3DHead.get_bboxes_single
+ * (mmdet3d/models/dense_heads/anchor3d_head.py:428-517) for a batch, single feature level,
+ * sigmoid classification: permute to HWC, sigmoid, direction argmax, top-k(nms_pre),
+ * DeltaXYZWLHRBBoxCoder.decode (coders/delta_xyzwhlr_bbox_coder.py:56-90), BEV boxes
+ * (lidar_box3d.py:86-90 + structures/utils.py:64-82), box3d_multiclass_nms
+ * (post_processing/box3d_nms.py:8-88) with rotated (iou3d_kernel.cu:284-333) or axis-aligned
+ * (:345-396) NMS and the greedy scan of iou3d.cpp:127-143 done on the device, top max_num,
+ * yaw fix-up with limit_period (anchor3d_head.py:510-515).
+ *
+ * head_out   [B, H, W, CH]  NHWC output of the fused 1x1 head conv; channel blocks
+ *                           [cls: A*ncls | reg: A*7 | dir: A*2] starting at cls_off/reg_off/dir_off
+ * anchors    [H*W*A, 7]     Anchor3DRangeGenerator.grid_anchors output (flat order y, x, size, rot)
+ * workspace  ivx_anchor_head_workspace_bytes() bytes, 256-byte aligned
+ * out_boxes  [B, max_num, 7], out_scores [B, max_num], out_labels [B, max_num] int64,
+ * out_count  [B] int32.  Rows >= count are zero.
+ * Optional debug outputs (NULL to skip): cand_idx [B,nms_pre] int64 top-k anchor indices in
+ * descending-score order (-1 padded), cand_boxes [B,nms_pre,7], cand_scores [B,nms_pre].     */
+typedef struct ivx_anchor_head_desc {
+  int32_t B, H, W, CH;
+  int32_t num_anchors; /* A: base anchors per location (sizes * rotations) */
+  int32_t num_classes;
+  int32_t cls_off, reg_off, dir_off;
+  int32_t nms_pre, max_num;
+  int32_t use_rotate_nms;
+  int32_t hw_transposed; /* 1: head_out is stored [B, W, H, CH] (x-major), as the Kitti/NuScenes neck
+                            leaves it before its .transpose(-1, -2) (necks/imvoxelnet.py:120) */
+  float score_thr, nms_thr;
+  float dir_offset, dir_limit_offset;
+} ivx_anchor_head_desc;
+
+int64_t ivx_anchor_head_workspace_bytes(const ivx_anchor_head_desc *d);
+int ivx_anchor_head_get_bboxes(const ivx_anchor_head_desc *d, const float *head_out, const float *anchors,
+                               void *workspace, int64_t workspace_bytes, float *out_boxes,
+                               float *out_scores, int64_t *out_labels, int32_t *out_count,
+                               int64_t *cand_idx, float *cand_boxes, float *cand_scores,
+                               ivx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * BEV NMS -- device-side replacement of iou3d_cuda.nms_gpu / nms_normal_gpu
+ * (mmdet3d/ops/iou3d/src/iou3d.cpp:95-201, iou3d_kernel.cu:284-396).  Same contract as the
+ * reference op except that nothing is copied to the host: boxes [n,5] (x1,y1,x2,y2,ry) must
+ * already be sorted by descending score (as iou3d_utils.py:39-47 does before the call);
+ * keep [n] int64 receives indices into that order, num_out [1] int32 their count.
+ * workspace >= ivx_nms_workspace_bytes(n).                                                   */
+int64_t ivx_nms_workspace_bytes(int32_t n);
+int ivx_nms_bev(const float *boxes_sorted, int32_t n, float thresh, int32_t rotated, void *workspace,
+                int64_t workspace_bytes, int64_t *keep, int32_t *num_out, ivx_stream_t stream);
+/* Pairwise rotated BEV overlap area / IoU (boxes_overlap_bev_gpu / boxes_iou_bev_gpu,
+ * iou3d.cpp:38-93): a [na,5], b [nb,5] -> out [na,nb]. */
+int ivx_boxes_overlap_bev(const float *a, int32_t na, const float *b, int32_t nb, int32_t iou, float *out,
+                          ivx_stream_t stream);
+
+/* aligned_3d_nms (mmdet3d/core/post_processing/box3d_nms.py:91-138) on the device.
+ * boxes [n,6] corners, scores [n], classes [n] int64; pick [n] int64 receives the kept box
+ * indices in descending score order, num_out [1] int32.  One workgroup; n <= 16384.           */
+int ivx_aligned_3d_nms(const float *boxes, const float *scores, const int64_t *classes, int32_t n,
+                       float thresh, int64_t *pick, int32_t *num_out, ivx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMVOXEL_H_ */

@@ -1,0 +1,347 @@
+"""-m gpu: the HIP kernels through the C-ABI against the oracle / golden vectors.  Runs on the MI355X box."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load_npz, load_json, sub, sd_from, meta_from_case
+from gpu_util import assert_close, cl, uncl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ia():
+    import imvoxelnet_amd
+    from imvoxelnet_amd import _lib
+    _lib.lib()            # fails loudly if the HIP library is missing
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    return imvoxelnet_amd
+
+
+CONV_CASES = [
+    # name, B, Cin, D,H,W, Cout, k, stride, pad, bias, bn, res, relu
+    ('k3_c64_s1', 1, 64, 10, 12, 12, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, True, True, True),
+    ('k3_c64_128_s112', 2, 64, 9, 11, 12, 128, (3, 3, 3), (1, 1, 2), (1, 1, 1), True, True, False, True),
+    ('k3_c128_256_s2', 1, 128, 8, 8, 6, 256, (3, 3, 3), (2, 2, 2), (1, 1, 1), True, True, False, True),
+    ('k3_c32_p0', 1, 32, 7, 9, 3, 48, (3, 3, 3), (1, 1, 1), (0, 0, 0), True, False, False, False),
+    ('k3_c16_p110', 1, 16, 6, 6, 3, 24, (3, 3, 3), (1, 1, 1), (1, 1, 0), False, True, False, True),
+    ('k3_c4_tiny', 2, 4, 7, 9, 12, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, True, True, True),
+    ('k3_c8_cout20', 1, 8, 5, 6, 7, 20, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, False, False, False),
+    ('k1_c256_64', 2, 256, 1, 24, 40, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), True, False, False, False),
+    ('k1_s2_c64_256', 1, 64, 1, 23, 31, 256, (1, 1, 1), (1, 2, 2), (0, 0, 0), False, True, False, False),
+    ('k3_2d_c64_s2', 1, 64, 1, 30, 44, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1), False, True, False, True),
+    ('stem7x7', 1, 4, 1, 64, 96, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), False, True, False, True),
+    ('k3_c256_big_k', 1, 256, 6, 6, 3, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, True, True, True),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_vs_torch_fp32(ia, case):
+    from imvoxelnet_amd.conv import FusedConv
+    name, B, Cin, D, H, W, Cout, k, s, p, bias, bn, res, relu = case
+    g = torch.Generator().manual_seed(abs(hash(name)) % 10000)
+    x = torch.randn(B, Cin, D, H, W, generator=g)
+    w = torch.randn((Cout, Cin) + k, generator=g) * (2.0 / (Cin * k[0] * k[1] * k[2])) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+    bnp = None
+    if bn:
+        bnp = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1,
+               torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5)
+    ref = F.conv3d(x, w, b, s, p)
+    if bn:
+        ref = F.batch_norm(ref, bnp[2], bnp[3], bnp[0], bnp[1], False, 0.0, 1e-5)
+    r = torch.randn(ref.shape, generator=g) if res else None
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    fc = FusedConv(w, b, bnp, stride=s, padding=p, relu=relu).to('cuda')
+    xc = cl(x)
+    rc = cl(r) if res else None
+    y = fc(xc, res=rc)
+    yn = fc(xc, res=rc, naive=True)
+    torch.cuda.synchronize()
+    assert_close(name + ' naive-vs-torch', uncl(yn), ref, 1e-4, 1e-4)
+    assert_close(name + ' mfma-vs-torch', uncl(y), ref, 1e-4, 1e-4)
+    assert_close(name + ' mfma-vs-naive', uncl(y), uncl(yn), 1e-4, 5e-5)
+
+
+def test_conv_config_variants(ia):
+    """Every tile configuration of the MFMA kernel on the same problem (Cout picks the config)."""
+    from imvoxelnet_amd.conv import FusedConv
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 32, 6, 9, 7, generator=g)
+    xc = cl(x)
+    for cout in (8, 32, 33, 64, 65, 128, 160):
+        w = torch.randn(cout, 32, 3, 3, 3, generator=g) * 0.05
+        ref = F.conv3d(x, w, None, 1, 1)
+        y = FusedConv(w, padding=1).to('cuda')(xc)
+        assert_close(f'cout{cout}', uncl(y), ref, 1e-4, 1e-4)
+
+
+def test_conv_fpn_upsample_residual(ia):
+    """res_mode 2: lateral 1x1 conv + nearest-upsampled coarser level (exact x2 and non-integer ratio)."""
+    from imvoxelnet_amd.conv import FusedConv
+    g = torch.Generator().manual_seed(8)
+    for (h, w_, rh, rw) in [(12, 20, 6, 10), (13, 21, 7, 11), (12, 20, 12, 20)]:
+        x = torch.randn(2, 32, h, w_, generator=g)
+        wt = torch.randn(16, 32, 1, 1, generator=g) * 0.2
+        b = torch.randn(16, generator=g)
+        coarse = torch.randn(2, 16, rh, rw, generator=g)
+        ref = F.conv2d(x, wt, b) + F.interpolate(coarse, size=(h, w_), mode='nearest')
+        y = FusedConv(wt, b, dims=2).to('cuda')(cl(x), res=cl(coarse), res_mode=2)
+        assert_close(f'fpn_{h}x{w_}_from_{rh}x{rw}', uncl(y)[:, :, 0], ref, 1e-4, 1e-4)
+
+
+def test_conv_linearity_fullsize_layer(ia):
+    """Size-independent property at a full KITTI neck layer shape: conv(a) + conv(b) == conv(a+b) (no bias),
+    and the MFMA kernel agrees with the validation kernel on a strided sample of outputs."""
+    from imvoxelnet_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(9)
+    a = torch.randn(1, 216, 248, 12, 64, device='cuda', generator=g)
+    b = torch.randn(1, 216, 248, 12, 64, device='cuda', generator=g)
+    w = torch.randn(64, 3, 3, 3, 64, device='cuda', generator=g) * 0.03
+    ya = ops.conv_fwd(a, w, None, None, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    yb = ops.conv_fwd(b, w, None, None, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    yab = ops.conv_fwd(a + b, w, None, None, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    err = (ya + yb - yab).abs().max().item()
+    print('linearity max err', err, 'max|y|', yab.abs().max().item())
+    assert err < 2e-4
+    yn = ops.conv_fwd(a, w, None, None, (3, 3, 3), (1, 1, 1), (1, 1, 1), naive=True)
+    err2 = (ya - yn).abs().max().item()
+    print('mfma vs naive full size max err', err2)
+    assert err2 < 2e-4
+
+
+def test_maxpool_and_layout(ia):
+    from imvoxelnet_amd import ops
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 64, 37, 53, generator=g)
+    y = ops.maxpool2d(cl(x), 3, 2, 1)
+    assert_close('maxpool', uncl(y)[:, :, 0], F.max_pool2d(x, 3, 2, 1), 0, 0)
+    img = torch.randn(3, 3, 20, 33, generator=g).cuda()
+    c = ops.to_channels_last(img, pad_to=4)
+    assert c.shape == (3, 1, 20, 33, 4)
+    assert torch.equal(c[..., :3].permute(0, 4, 1, 2, 3)[:, :, 0], img) and float(c[..., 3].abs().max()) == 0.0
+    v = torch.randn(2, 5, 3, 4, 6, generator=g).cuda()
+    assert torch.equal(ops.from_channels_last(ops.to_channels_last(v), 3), v)
+
+
+@pytest.mark.parametrize('case', list('ABCDE'))
+def test_unprojection_golden_bit_exact(ia, case):
+    """HIP unprojection == imported reference, bit for bit (volume) and exactly (valid mask)."""
+    from imvoxelnet_amd import ops
+    from oracle import imvoxel_oracle as orc
+    c = sub(load_npz('backproject_cases.npz'), case + '::')
+    meta = meta_from_case(c)
+    P = torch.from_numpy(c['projection'])[None].cuda()
+    nv, vs = c['n_voxels'], c['voxel_size']
+    new_origin = (torch.from_numpy(c['origin']) - torch.tensor(nv) / 2. * torch.from_numpy(vs))[None].cuda()
+    crop = torch.tensor([[meta['img_shape'][0] // 4, meta['img_shape'][1] // 4]], dtype=torch.int32).cuda()
+    vol, valid = ops.backproject_mean(cl(c['feat']), P.contiguous(), new_origin.contiguous(), crop, vs, nv)
+    got = vol[0].permute(3, 0, 1, 2).cpu().numpy()
+    assert np.array_equal(valid[0].cpu().numpy(), c['mean_valid'][0])
+    assert np.array_equal(got, c['mean']), f'{(got != c["mean"]).sum()} voxels-channels differ'
+
+
+def test_unprojection_fullsize_kitti(ia):
+    """Full KITTI shape, batch 2 (two different cameras): HIP == C oracle bit for bit; sample 0 also matches
+    the SHA-256 of the imported reference's output."""
+    from imvoxelnet_amd import ops
+    from oracle import imvoxel_oracle as orc
+    info = load_json('kitti_fullsize_backproject.json')
+    g = torch.Generator().manual_seed(info['seed'])
+    feat0 = torch.randn(tuple(info['feat_shape']), generator=g)
+    feat1 = torch.randn(tuple(info['feat_shape']), generator=g)
+    metas = []
+    for t in (0.0, 0.07):
+        E = np.array(info['extrinsic'][0], np.float32)
+        E[:3, 3] += t
+        metas.append(dict(img_shape=(384, 1280 - int(t * 400) * 4, 3), ori_shape=(384, 1280, 3),
+                          lidar2img=dict(intrinsic=np.array(info['intrinsic'], np.float32), extrinsic=[E],
+                                         origin=np.array(info['origin'], np.float32))))
+    nv, vs = info['n_voxels'], info['voxel_size']
+    P = torch.from_numpy(np.stack([orc.compute_projection(m, 4) for m in metas])).cuda()
+    no = torch.stack([torch.tensor(m['lidar2img']['origin']) - torch.tensor(nv) / 2. * torch.tensor(vs) for m in metas]).cuda()
+    crop = torch.tensor([[m['img_shape'][0] // 4, m['img_shape'][1] // 4] for m in metas], dtype=torch.int32).cuda()
+    feats = torch.cat([feat0, feat1])
+    vol, valid = ops.backproject_mean(cl(feats), P.contiguous(), no.contiguous(), crop, vs, nv)
+    torch.cuda.synchronize()
+    for b, f in enumerate((feat0, feat1)):
+        ref, ok = orc.extract_volume(f.numpy(), metas[b], nv, vs)
+        got = vol[b].permute(3, 0, 1, 2).cpu().numpy()
+        assert np.array_equal(valid[b].cpu().numpy(), ok[0]), f'sample {b}: valid mask differs'
+        assert np.array_equal(got, ref), f'sample {b}: {(got != ref).sum()} values differ'
+        if b == 0:
+            assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == info['mean_sha256']
+    # property: an all-ones feature map unprojects to exactly the valid mask
+    ones = torch.ones(2, 1, 96, 320, 64, device='cuda')
+    v1, m1 = ops.backproject_mean(ones, P.contiguous(), no.contiguous(), crop, vs, nv)
+    assert torch.equal(v1, m1.unsqueeze(-1).float().expand_as(v1))
+
+
+def test_unprojection_multiview_indoor(ia):
+    """20 views, C=256 (ScanNet-fast shape, smaller grid): the wave-shuffle view distribution path."""
+    from imvoxelnet_amd import ops
+    from oracle import c_oracle as co
+    rng = np.random.RandomState(3)
+    V, Cn, FH, FW = 20, 256, 30, 40
+    feat = torch.randn(V, Cn, FH, FW, generator=torch.Generator().manual_seed(5))
+    K = np.array([[577.87 / 16, 0, 319.5 / 16, 0], [0, 577.87 / 16, 239.5 / 16, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    Es = []
+    for i in range(V):
+        a = 2 * np.pi * i / V
+        eye = np.array([2.5 * np.cos(a), 2.5 * np.sin(a), 1.2])
+        f = -eye / np.linalg.norm(eye)
+        r = np.cross(f, [0, 0, 1.0]); r /= np.linalg.norm(r)
+        d = np.cross(f, r)
+        R = np.stack([r, d, f])
+        E = np.eye(4); E[:3, :3] = R; E[:3, 3] = -R @ eye
+        Es.append(E.astype(np.float32))
+    P = co.compute_projection(K, Es, 1.0)
+    nv, vs, origin = (24, 24, 10), (.16, .16, .16), np.array([0, 0, .5], np.float32)
+    pts = co.get_points(nv, vs, origin)
+    ref, ok = co.backproject_mean(feat.numpy(), pts, P, FH - 1, FW - 2)
+    no = (torch.from_numpy(origin) - torch.tensor(nv) / 2. * torch.tensor(vs))[None].cuda()
+    crop = torch.tensor([[FH - 1, FW - 2]], dtype=torch.int32).cuda()
+    vol, valid = ops.backproject_mean(cl(feat), torch.from_numpy(P)[None].cuda().contiguous(), no.contiguous(), crop, vs, nv)
+    got = vol[0].permute(3, 0, 1, 2).cpu().numpy()
+    assert np.array_equal(valid[0].cpu().numpy(), ok[0])
+    assert np.array_equal(got, ref), f'{(got != ref).sum()} values differ (max {np.abs(got - ref).max()})'
+
+
+@pytest.mark.parametrize('name', ['kitti', 'nuscenes'])
+def test_neck_golden(ia, name):
+    """HIP 3-D neck vs the imported reference module's output (golden)."""
+    g = load_npz('necks.npz')
+    sd = sd_from(g, name + '::sd::')
+    cls = ia.KittiImVoxelNeck if name == 'kitti' else ia.NuScenesImVoxelNeck
+    neck = cls(4, 8)
+    missing = neck.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all('num_batches_tracked' in k for k in missing.missing_keys), missing
+    x = torch.from_numpy(g[name + '::x']).cuda()
+    y = neck(x)[0]
+    assert_close(name + ' neck', y, g[name + '::y0'], 1e-3, 1e-4)
+
+
+def _head_from_golden(ia, g, p, cfg):
+    ranges, sizes = g[p + 'ranges'].tolist(), g[p + 'sizes'].tolist()
+    head = ia.Anchor3DHead(num_classes=1, in_channels=16, feat_channels=16, test_cfg=cfg,
+                           anchor_generator=dict(type='Anchor3DRangeGenerator', ranges=ranges, sizes=sizes,
+                                                 rotations=[0, 1.57], reshape_out=True),
+                           bbox_coder=dict(type='DeltaXYZWLHRBBoxCoder'), loss_cls=dict(type='FocalLoss', use_sigmoid=True))
+    head.load_state_dict(sd_from(g, p + 'sd::'))
+    return head
+
+
+@pytest.mark.parametrize('name', ['kitti', 'nus'])
+def test_anchor_head_golden(ia, name):
+    """Fused head conv + device tail (top-k, decode, rotated NMS, yaw fix-up) vs the reference's
+    Anchor3DHead.get_bboxes: identical kept anchors / order, values within fp32 noise."""
+    g = load_npz('anchor_head.npz')
+    p = name + '::'
+    cfg = json.loads(str(g[p + 'test_cfg']))
+    head = _head_from_golden(ia, g, p, cfg)
+    x = torch.from_numpy(g[p + 'x']).cuda()
+    cls, reg, dr = head([x])
+    assert_close('cls', cls[0], g[p + 'cls'], 1e-4, 1e-5)
+    assert_close('reg', reg[0], g[p + 'reg'], 1e-4, 1e-5)
+    assert_close('dir', dr[0], g[p + 'dir'], 1e-4, 1e-5)
+    # feed the reference's own raw head outputs so the tail is compared in isolation
+    metas = [dict(box_type_3d=ia.LiDARInstance3DBoxes)] * 2
+    res = head.get_bboxes([torch.from_numpy(g[p + 'cls']).cuda()], [torch.from_numpy(g[p + 'reg']).cuda()],
+                          [torch.from_numpy(g[p + 'dir']).cuda()], None, metas)
+    for b, (boxes, scores, labels) in enumerate(res):
+        assert len(scores) == len(g[p + f'scores{b}']), f'kept {len(scores)} vs reference {len(g[p + f"scores{b}"])}'
+        assert_close(f'scores{b}', scores, g[p + f'scores{b}'], 1e-5, 1e-6)
+        assert_close(f'boxes{b}', boxes.tensor, g[p + f'boxes{b}'], 1e-4, 1e-4)
+        assert np.array_equal(labels.cpu().numpy(), g[p + f'labels{b}'])
+
+
+def test_e2e_small_golden(ia):
+    """Reference ImVoxelNet.simple_test (toy trunk) from FPN level-0 features on: unprojection ->
+    KittiImVoxelNeck -> Anchor3DHead -> boxes; valid mask exact, detections identical."""
+    g = load_npz('e2e_small.npz')
+    cfg = json.loads(str(g['test_cfg']))
+    sd = sd_from(g, 'sd::')
+    model = ia.ImVoxelNet(
+        backbone=dict(type='ResNet', depth=50), neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=8, num_outs=4),
+        neck_3d=dict(type='KittiImVoxelNeck', in_channels=8, out_channels=16),
+        bbox_head=dict(type='Anchor3DHead', num_classes=1, in_channels=16, feat_channels=16,
+                       anchor_generator=dict(type='Anchor3DRangeGenerator', ranges=g['ranges'].tolist(), sizes=[[1.6, 3.9, 1.56]],
+                                             rotations=[0, 1.57], reshape_out=True),
+                       bbox_coder=dict(type='DeltaXYZWLHRBBoxCoder'), loss_cls=dict(type='FocalLoss', use_sigmoid=True)),
+        n_voxels=tuple(g['n_voxels'].tolist()), voxel_size=tuple(g['voxel_size'].tolist()), test_cfg=cfg)
+    model.neck_3d.load_state_dict({k[len('neck_3d.'):]: v for k, v in sd.items() if k.startswith('neck_3d.')}, strict=False)
+    model.bbox_head.load_state_dict({k[len('bbox_head.'):]: v for k, v in sd.items() if k.startswith('bbox_head.')})
+    metas = []
+    for b in range(2):
+        m = meta_from_case(sub(g, f'meta{b}::'))
+        m['box_type_3d'] = ia.LiDARInstance3DBoxes
+        metas.append(m)
+    p0 = cl(g['fpn0'])
+    volume, valid = model.lift_cl(p0, metas)
+    assert np.array_equal(valid.cpu().numpy(), g['valids'][:, 0])
+    y = model.neck_3d.forward_cl(volume)
+    ref_neck = g['neck_out']                                  # [B,C,Y',X']
+    assert_close('neck_out', y[:, :, :, 0].permute(0, 3, 2, 1), ref_neck, 1e-3, 1e-4)
+    boxes, scores, labels, count = model.detect_cl(volume, metas)
+    for b in range(2):
+        n = int(count[b])
+        assert n == len(g[f'res{b}::scores']), f'sample {b}: kept {n} vs {len(g[f"res{b}::scores"])}'
+        assert_close(f'scores{b}', scores[b, :n], g[f'res{b}::scores'], 1e-4, 1e-5)
+        assert_close(f'boxes{b}', boxes[b, :n], g[f'res{b}::boxes'], 1e-3, 1e-3)
+
+
+def test_nms_ops(ia):
+    """nms_gpu / nms_normal_gpu / aligned_3d_nms / pairwise overlap on the device vs the C oracle and
+    the reference's own test vectors."""
+    from oracle import c_oracle as co
+    g = torch.Generator().manual_seed(11)
+    for n in (1, 5, 64, 65, 300, 1000):
+        ctr = torch.rand(n, 2, generator=g) * 30
+        wh = torch.rand(n, 2, generator=g) * 3 + 0.5
+        ang = (torch.rand(n, 1, generator=g) - 0.5) * 6
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2, ang], 1)
+        scores = torch.rand(n, generator=g)
+        for rot in (True, False):
+            keep = (ia.nms_gpu if rot else ia.nms_normal_gpu)(boxes.cuda(), scores.cuda(), 0.1)
+            order = scores.sort(0, descending=True)[1]
+            ref = order[torch.from_numpy(co.nms_sorted(boxes[order].numpy(), 0.1, rot))]
+            assert torch.equal(keep.cpu(), ref), f'n={n} rotated={rot}: {keep.cpu().tolist()[:10]} vs {ref.tolist()[:10]}'
+    a = boxes[:40]
+    ov = ia.nms.boxes_overlap_bev(a.cuda(), a.cuda()).cpu().numpy()
+    assert_close('overlap', ov, co.boxes_overlap_bev(a.numpy(), a.numpy()), 1e-4, 1e-5)
+    v = load_npz('nms_vectors.npz')
+    pick = ia.aligned_3d_nms(torch.from_numpy(v['aligned::boxes']).cuda(), torch.from_numpy(v['aligned::scores']).cuda(),
+                             torch.from_numpy(v['aligned::classes']).cuda(), float(v['aligned::thresh']))
+    assert np.array_equal(pick.cpu().numpy(), v['aligned::pick'])          # reference tests/test_nms.py
+    for i in range(4):
+        q = f'aligned_rand{i}::'
+        pick = ia.aligned_3d_nms(torch.from_numpy(v[q + 'boxes']).cuda(), torch.from_numpy(v[q + 'scores']).cuda(),
+                                 torch.from_numpy(v[q + 'classes']).cuda(), 0.25)
+        assert np.array_equal(pick.cpu().numpy(), v[q + 'pick'])
+    # reference known answers for the rotated overlap (tests/test_box3d.py::test_boxes3d_overlaps)
+    b1, b2 = torch.from_numpy(v['overlaps::boxes1_tensor']), torch.from_numpy(v['overlaps::boxes2_tensor'])
+    bev = lambda b: ia.xywhr2xyxyr(b[:, [0, 1, 3, 4, 6]])
+    ovb = ia.nms.boxes_overlap_bev(bev(b1).cuda(), bev(b2).cuda()).cpu()
+    oh = torch.clamp(torch.min((b1[:, 2] + b1[:, 5]).view(-1, 1), (b2[:, 2] + b2[:, 5]).view(1, -1)) -
+                     torch.max(b1[:, 2].view(-1, 1), b2[:, 2].view(1, -1)), min=0)
+    o3 = ovb * oh
+    v1, v2 = (b1[:, 3] * b1[:, 4] * b1[:, 5]).view(-1, 1), (b2[:, 3] * b2[:, 4] * b2[:, 5]).view(1, -1)
+    assert torch.allclose(torch.from_numpy(v['overlaps::expected_iou_tensor']), o3 / torch.clamp(v1 + v2 - o3, min=1e-8),
+                          rtol=1e-4, atol=1e-7)
+
+
+def test_errors_are_loud(ia):
+    from imvoxelnet_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.conv_fwd(torch.zeros(1, 1, 4, 4, 4), torch.zeros(4, 1, 1, 1, 4))      # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        ops.conv_fwd(torch.zeros(1, 1, 4, 4, 6, device='cuda'), torch.zeros(4, 1, 1, 1, 6, device='cuda'))  # Cin % 4
+    with pytest.raises(ValueError):
+        ops.conv_fwd(torch.zeros(1, 1, 2, 2, 4, device='cuda'), torch.zeros(4, 1, 3, 3, 4, device='cuda'), kernel=(1, 3, 3))
