@@ -64,10 +64,18 @@ class ScaleParams(nn.Module):
         self.scale = nn.Parameter(torch.tensor(float(scale)), requires_grad=False)
 
 
-def randomize_(module, seed=0):
+def randomize_(module, seed=0, residual_gain=0.2):
     """Synthetic weights for benchmarks/tests: Kaiming-normal convs, BN gamma~U(.5,1.5),
-    beta~N(0,.1), mean~N(0,.1), var~U(.5,1.5).  Deterministic in `seed`."""
+    beta~N(0,.1), mean~N(0,.1), var~U(.5,1.5).  The last BN of every residual branch (bn3 of a bottleneck,
+    bn2 / norm2 of a 3-D basic block) gets its gamma scaled by `residual_gain`, as trained residual nets
+    have, so activations stay O(1) through ~30 residual blocks instead of growing ~2x per block.
+    Deterministic in `seed`."""
     g = torch.Generator().manual_seed(seed)
+    for name, m in module.named_modules():
+        last = name.rsplit('.', 1)[-1]
+        if isinstance(m, BNParams) and last in ('bn3', 'norm2') or (isinstance(m, BNParams) and last == 'bn2' and
+                                                                   not hasattr(_parent(module, name), 'conv3')):
+            m._residual_tail = True
     for m in module.modules():
         if isinstance(m, (ConvParams, ConvTransposeParams)):
             w = m.weight
@@ -77,7 +85,16 @@ def randomize_(module, seed=0):
                 m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.05)
         elif isinstance(m, BNParams):
             m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+            if getattr(m, '_residual_tail', False):
+                m.weight.mul_(residual_gain)
             m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
             m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
             m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
     return module
+
+
+def _parent(root, name):
+    mod = root
+    for part in name.split('.')[:-1]:
+        mod = getattr(mod, part)
+    return mod
