@@ -28,7 +28,7 @@ class AnchorHeadDesc(C.Structure):
                [(n, C.c_float) for n in ('score_thr', 'nms_thr', 'dir_offset', 'dir_limit_offset')]
 
 
-EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive',
+EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override',
            'ivx_maxpool2d_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
            'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_nms_workspace_bytes',
            'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms']
@@ -49,6 +49,7 @@ def lib():
     L.ivx_conv_out_dims.argtypes = [C.POINTER(ConvDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     for name in ('ivx_conv_fwd', 'ivx_conv_fwd_naive'):
         getattr(L, name).argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
+    L.ivx_conv_set_tile_override.argtypes = [C.c_int]
     L.ivx_maxpool2d_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ivx_nchw_to_nhwc.argtypes = [vp, i32, i32, i64, i32, vp, vp]
     L.ivx_nhwc_to_nchw.argtypes = [vp, i32, i64, i32, vp, vp]

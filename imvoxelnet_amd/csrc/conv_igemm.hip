@@ -33,6 +33,7 @@ struct ConvParams {
   int Do, Ho, Wo;
   int M, K;
   int relu, res_mode, rH, rW;
+  int prio_mode;
 };
 
 #define IVX_BK 32
@@ -50,6 +51,40 @@ __device__ __noinline__ size_t res2_row_base(int m, int Ho, int Wo, int rH, int 
   sh_ = sh_ < rH - 1 ? sh_ : rH - 1;
   sw_ = sw_ < rW - 1 ? sw_ : rW - 1;
   return (((size_t)b * rH + sh_) * rW + sw_) * Cout;
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
+                                              int lane) {
+  // ---- epilogue -------------------------------------------------------------------------------
+  const int col_l = lane & 31, hh = lane >> 5;
+  float sc[TN], sf[TN];
+  int nn[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    nn[j] = n0 + (wc * TN + j) * 32 + col_l;
+    const bool nok = nn[j] < p.Cout;
+    sc[j] = (nok && p.scale) ? p.scale[nn[j]] : 1.0f;
+    sf[j] = (nok && p.shift) ? p.shift[nn[j]] : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (m >= p.M) continue;
+      size_t rbase = (size_t)m * p.Cout;
+      if (p.res_mode == 2) rbase = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (nn[j] >= p.Cout) continue;
+        float v = acc[i][j][r] * sc[j] + sf[j];
+        if (p.res_mode) v += p.res[rbase + nn[j]];
+        if (p.relu) v = v > 0.f ? v : 0.f;
+        p.out[(size_t)m * p.Cout + nn[j]] = v;
+      }
+    }
+  }
 }
 
 template <int TM, int TN, int WR, int WC>
@@ -202,35 +237,205 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     __syncthreads();
   }
 
-  // ---- epilogue -------------------------------------------------------------------------------
-  const int col_l = lane & 31, hh = lane >> 5;
-  float sc[TN], sf[TN];
-  int nn[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    nn[j] = n0 + (wc * TN + j) * 32 + col_l;
-    const bool nok = nn[j] < p.Cout;
-    sc[j] = (nok && p.scale) ? p.scale[nn[j]] : 1.0f;
-    sf[j] = (nok && p.shift) ? p.shift[nn[j]] : 0.0f;
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v2: same tiling, cheaper slab loop.
+//   * operands are fetched with raw buffer loads (buffer_load_dwordx4 ... offen): an out-of-image tap, a
+//     row past M or a k past K gets the out-of-range offset 0x80000000 and the hardware returns zeros --
+//     no exec-mask branches, no 64-bit address arithmetic in the loop (needs the tensor < 2 GiB);
+//   * per-row tap validity is a precomputed bit mask (kernel extents <= 8), per-slab work per load is
+//     one AND/compare, one add, one select;
+//   * MFMA fragments are double-buffered in registers: the ds_read_b128 of k-group kk+1 is issued before
+//     the 16 MFMAs of group kk.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int TM, int TN, int WR, int WC>
+__global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams p, const unsigned in_bytes,
+                                                                  const unsigned w_bytes) {
+  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  constexpr int AR = BM / 32, BR = BN / 32;
+  static_assert(WR * WC == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * IVX_LDK];
+  float *As = smem;
+  float *Bs = smem + 2 * BM * IVX_LDK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid / WC, wc = wid % WC;
+
+  int bid = blockIdx.x;
+  {
+    const int nb = gridDim.x;
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int m0 = bid * BM;
+  const int n0 = blockIdx.y * BN;
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, w_bytes, 0x00020000);
+
+  // Two workgroups share a CU (one wave of each per SIMD).  Launched together and running identical code they stay
+  // in lockstep, so their load/ds_write/barrier phases coincide and the matrix pipe idles.  Raising the priority of
+  // the wave in the odd hardware wave slot makes the pair alternate instead: one streams MFMAs while the other
+  // refills LDS.  (HW_REG_HW_ID[3:0] = wave slot inside the SIMD; speed only, never correctness.)
+  if (p.prio_mode == 1) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    if (slot & 1) __builtin_amdgcn_s_setprio(1);
+  } else if (p.prio_mode == 2) {
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+  } else if (p.prio_mode == 3) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    if (slot & 1) __builtin_amdgcn_s_setprio(3);
+  }
+
+  const int cc = tid & 7;
+  const int lr = tid >> 3;
+  int a_off[AR];
+  unsigned a_msk[AR];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (m >= p.M) continue;
-      size_t rbase = (size_t)m * p.Cout;
-      if (p.res_mode == 2) rbase = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (nn[j] >= p.Cout) continue;
-        float v = acc[i][j][r] * sc[j] + sf[j];
-        if (p.res_mode) v += p.res[rbase + nn[j]];
-        if (p.relu) v = v > 0.f ? v : 0.f;
-        p.out[(size_t)m * p.Cout + nn[j]] = v;
-      }
+  for (int j = 0; j < AR; ++j) {
+    const int m = m0 + lr + 32 * j;
+    a_off[j] = 0;
+    a_msk[j] = 0;
+    if (m < p.M) {
+      const int ow = m % p.Wo;
+      int t = m / p.Wo;
+      const int oh = t % p.Ho;
+      t /= p.Ho;
+      const int od = t % p.Do;
+      const int b = t / p.Do;
+      const int id0 = od * p.sd - p.pd, ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
+      a_off[j] = (((b * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin;
+      unsigned md = 0, mh = 0, mw = 0;
+      for (int a = 0; a < p.KD; ++a) md |= ((unsigned)(id0 + a) < (unsigned)p.D) ? (1u << a) : 0u;
+      for (int e = 0; e < p.KH; ++e) mh |= ((unsigned)(ih0 + e) < (unsigned)p.H) ? (1u << e) : 0u;
+      for (int f = 0; f < p.KW; ++f) mw |= ((unsigned)(iw0 + f) < (unsigned)p.W) ? (1u << f) : 0u;
+      a_msk[j] = md | (mh << 8) | (mw << 16);
     }
   }
+  int b_off[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int n = n0 + lr + 32 * j;
+    b_off[j] = n < p.Cout ? n * p.K : -1;
+  }
+  int k4 = cc * 4;
+  int kc, ka, ke, kf;
+  {
+    const int tap = k4 / p.Cin;
+    kc = k4 - tap * p.Cin;
+    kf = tap % p.KW;
+    const int t2 = tap / p.KW;
+    ke = t2 % p.KH;
+    ka = t2 / p.KH;
+  }
+  const int S = (p.K + IVX_BK - 1) / IVX_BK;
+  const unsigned OOB = 0x80000000u;
+
+  u32x4 ra[AR], rb[BR];
+  auto load_slab = [&]() {
+    // branch-free: a k past K turns the tap mask into all-ones, which no row mask can satisfy
+    const unsigned kbad = (k4 < p.K) ? 0u : 0xffffffffu;
+    const int delta = ((ka * p.H + ke) * p.W + kf) * p.Cin + kc;
+    const unsigned tap = ((1u << ka) | (1u << (8 + ke)) | (1u << (16 + kf))) | kbad;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+      const unsigned good = ((a_msk[j] & tap) == tap) ? 0xffffffffu : 0u;
+      const unsigned vo = (((unsigned)(a_off[j] + delta) << 2) & good) | (OOB & ~good);
+      ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const unsigned good = (b_off[j] >= 0 ? 0xffffffffu : 0u) & ~kbad;
+      const unsigned vo = (((unsigned)(b_off[j] + k4) << 2) & good) | (OOB & ~good);
+      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo, 0, 0);
+    }
+  };
+  auto advance_k = [&]() {
+    k4 += IVX_BK;
+    kc += IVX_BK;
+    while (kc >= p.Cin) {
+      kc -= p.Cin;
+      if (++kf == p.KW) {
+        kf = 0;
+        if (++ke == p.KH) {
+          ke = 0;
+          ++ka;
+        }
+      }
+    }
+  };
+  auto store_slab = [&](int buf) {
+    float *Ab = As + buf * BM * IVX_LDK + lr * IVX_LDK + cc * 4;
+    float *Bb = Bs + buf * BN * IVX_LDK + lr * IVX_LDK + cc * 4;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4 *>(Ab + 32 * j * IVX_LDK) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4 *>(Bb + 32 * j * IVX_LDK) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_slab();
+  store_slab(0);
+  __syncthreads();
+
+  const int abl = p.prio_mode;  // >= 10: timing ablations (tools/conv_bench.py), results invalid
+  const int frag_off = (lane & 31) * IVX_LDK + 4 * (lane >> 5);
+  for (int s = 0; s < S; ++s) {
+    const int cur = s & 1;
+    const bool more = (s + 1) < S;
+    if (more && abl != 10 && abl != 11 && abl != 13 && abl != 14) {
+      advance_k();
+      load_slab();
+    }
+    const float *Ac = As + cur * BM * IVX_LDK + wr * TM * 32 * IVX_LDK + frag_off;
+    const float *Bc = Bs + cur * BN * IVX_LDK + wc * TN * 32 * IVX_LDK + frag_off;
+    f32x4 fa[2][TM], fb[2][TN];
+    if (abl == 14) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[0][i] = fa[1][i] = f32x4{1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[0][j] = fb[1][j] = f32x4{1.f, 2.f, 3.f, 4.f};
+    }
+    if (abl != 14) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_LDK);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * IVX_LDK);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (kk < 3 && abl != 14) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_LDK + (kk + 1) * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * IVX_LDK + (kk + 1) * 8);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][i][q], fb[cb][j][q], acc[i][j], 0, 0, 0);
+    }
+    if (more && abl != 10 && abl != 11 && abl != 13 && abl != 14) store_slab(cur ^ 1);
+    if (abl != 11 && abl != 12 && abl != 13 && abl != 14) __syncthreads();
+  }
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
 
 // Validation kernel: one thread per output element, sequential fmaf over (kd,kh,kw,ci).
@@ -295,7 +500,7 @@ static int fill_params(const ivx_conv_desc *d, const float *in, const float *wgt
   p->Cout = d->Cout; p->KD = d->KD; p->KH = d->KH; p->KW = d->KW;
   p->sd = d->sd; p->sh = d->sh; p->sw = d->sw; p->pd = d->pd; p->ph = d->ph; p->pw = d->pw;
   p->Do = Do; p->Ho = Ho; p->Wo = Wo; p->M = (int)M; p->K = (int)K;
-  p->relu = d->relu; p->res_mode = d->res_mode; p->rH = d->res_h; p->rW = d->res_w;
+  p->relu = d->relu; p->res_mode = d->res_mode; p->rH = d->res_h; p->rW = d->res_w; p->prio_mode = 0;
   return IVX_OK;
 }
 
@@ -311,10 +516,26 @@ extern "C" int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *H
 }
 
 template <int TM, int TN, int WR, int WC>
-static void launch_cfg(const ConvParams &p, hipStream_t st) {
+static void launch_cfg(const ConvParams &p, hipStream_t st, bool v2) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
+  const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4;
+  const int64_t w_bytes = (int64_t)p.Cout * p.K * 4;
+  // v2 needs 31-bit byte offsets and kernel extents that fit the 8-bit tap masks; otherwise the generic kernel
+  v2 = v2 && in_bytes < (1LL << 31) && w_bytes < (1LL << 31) && p.KD <= 8 && p.KH <= 8 && p.KW <= 8;
+  if (v2)
+    hipLaunchKernelGGL((conv_igemm_f32_v2_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
+  else
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
+}
+
+static int g_tile_override = 0;
+static int g_prio_mode = 0;
+// Tuning knob (A/B experiments, tools/conv_bench.py): 0 = automatic choice by Cout, 1..N = force a tile config.
+extern "C" int ivx_conv_set_tile_override(int cfg) {
+  g_prio_mode = cfg / 1000;
+  g_tile_override = cfg % 1000;
+  return IVX_OK;
 }
 
 extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
@@ -323,12 +544,38 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float
   int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
   if (rc != IVX_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (p.Cout > 64)
-    launch_cfg<2, 2, 2, 2>(p, st);  // 128 x 128
-  else if (p.Cout > 32)
-    launch_cfg<2, 2, 4, 1>(p, st);  // 256 x 64
-  else
-    launch_cfg<1, 1, 4, 1>(p, st);  // 128 x 32
+  int cfg = g_tile_override;
+  p.prio_mode = g_prio_mode;
+  bool v2 = true;
+  if (cfg >= 100) {  // 100 + c: force the generic (v1) kernel with tile config c
+    v2 = false;
+    cfg -= 100;
+  }
+  if (cfg == 0) {
+    // Tile choice (measured per layer on MI355X, tools/conv_bench.py): big problems want the 128-row tiles with the
+    // best MFMA : staging ratio; when 128 x 128 tiles would not fill the 512 workgroup slots (2 per CU) several
+    // times over -- every ResNet/FPN layer at KITTI resolution -- 64 x 64 tiles win by occupancy.
+    const long long nblk = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    if (p.Cout <= 32)
+      cfg = 4;
+    else if (nblk >= 4096)
+      cfg = p.Cout > 64 ? 1 : 3;
+    else
+      cfg = 6;
+  }
+  switch (cfg) {
+    case 1: launch_cfg<2, 2, 2, 2>(p, st, v2); break;  // 128 x 128, 2 blocks/CU
+    case 2: launch_cfg<2, 2, 4, 1>(p, st, v2); break;  // 256 x 64, 1 block/CU
+    case 3: launch_cfg<2, 1, 2, 2>(p, st, v2); break;  // 128 x 64, 2 blocks/CU
+    case 4: launch_cfg<1, 1, 4, 1>(p, st, v2); break;  // 128 x 32
+    case 5: launch_cfg<1, 2, 4, 1>(p, st, v2); break;  // 128 x 64 (wave 32 x 64)
+    case 6: launch_cfg<1, 1, 2, 2>(p, st, v2); break;  // 64 x 64
+    case 7: launch_cfg<1, 2, 2, 2>(p, st, v2); break;  // 64 x 128
+
+    default:
+      ivx_set_error("ivx_conv_fwd: unknown tile override %d", cfg);
+      return IVX_ERR_INVALID_ARG;
+  }
   IVX_CHECK_LAUNCH("ivx_conv_fwd");
   return IVX_OK;
 }

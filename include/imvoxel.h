@@ -75,6 +75,9 @@ int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float *wgt, cons
 int ivx_conv_fwd_naive(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
                        const float *shift, const float *res, float *out, ivx_stream_t stream);
 
+/* Tuning knob for A/B experiments only: 0 = automatic tile choice (default), 1..6 = force a tile config. */
+int ivx_conv_set_tile_override(int cfg);
+
 /* nn.MaxPool2d(kernel, stride, padding) on NHWC (ResNet stem: 3, 2, 1). */
 int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
                       int32_t s, int32_t p, float *out, ivx_stream_t stream);
