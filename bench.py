@@ -126,6 +126,19 @@ def main():
     flops_step = neck_flops_per_sample((216, 248, 12), 64, 256) * B
     achieved = flops_step / (neck_ms_avg * 1e-3) / 1e12
 
+    # HBM traffic of the neck conv launches: PMC counters cannot be read from inside the process, so the value comes
+    # from the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh -> profiles/*_bench_pmc.json;
+    # FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as reported), averaged per launch; null if absent.
+    traffic = None
+    pj = os.path.join(ROOT, 'profiles', 'r01_bench_pmc.json')
+    if os.path.exists(pj):
+        try:
+            ks = [v for v in json.load(open(pj)).values() if 'hbm_bytes' in v.get('derived', {})]
+            nl = sum(v['launches'] for v in ks)
+            traffic = round(sum(v['derived']['hbm_bytes'] * v['launches'] for v in ks) / nl / 1e9, 3) if nl else None
+        except Exception:
+            traffic = None
+
     if rank == 0:
         total_images = B * world * args.steps
         rec = {
@@ -138,7 +151,7 @@ def main():
                        'detections_last_step': int(last[:, -1].sum().item())},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_f32_kernel (3-D neck, 11 launches/step)',
                          'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/r01_bench_pmc.json)',
                          'algorithmic_gflop_per_launch': round(flops_step / n_launch / 1e9, 2),
                          'avg_launch_ms': round(neck_ms_avg / n_launch, 4), 'neck_ms_per_step': round(neck_ms_avg, 3)},
         }

@@ -18,7 +18,7 @@ class IvxError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('B', 'D', 'H', 'W', 'Cin', 'Cout', 'KD', 'KH', 'KW', 'sd', 'sh', 'sw', 'pd', 'ph', 'pw',
-                 'relu', 'res_mode', 'res_h', 'res_w')]
+                 'relu', 'res_mode', 'res_h', 'res_w', 'wgt_layout')]
 
 
 class AnchorHeadDesc(C.Structure):

@@ -24,7 +24,7 @@ def _spatial3(v, dims, fill):
 
 
 class FusedConv:
-    def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, relu=False, dims=3, eps=1e-5):
+    def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, relu=False, dims=3, eps=1e-5, layout=None):
         """weight: [Cout,Cin,kh,kw] (dims=2) or [Cout,Cin,kd,kh,kw] (dims=3) tensor (any device).
         bn: None or (gamma, beta, running_mean, running_var)."""
         w = weight.detach().to(torch.float32)
@@ -38,6 +38,11 @@ class FusedConv:
         wp = w.permute(0, 2, 3, 4, 1).contiguous()
         if self.cin_pad != self.cin:
             wp = torch.nn.functional.pad(wp, (0, self.cin_pad - self.cin))
+        # layout 1 (chunk-major K) whenever the channel count allows it: see include/imvoxel.h
+        self.layout = 1 if (self.cin_pad % 32 == 0 and layout != 0) else 0
+        if self.layout == 1:
+            co, kd, kh, kw, ci = wp.shape
+            wp = wp.reshape(co, kd, kh, kw, ci // 32, 32).permute(0, 4, 1, 2, 3, 5)
         self._w_host = wp.contiguous()
         scale = torch.ones(self.cout)
         shift = torch.zeros(self.cout)
@@ -63,7 +68,7 @@ class FusedConv:
         if self.w is None:
             raise RuntimeError('FusedConv.to(device) must be called before use')
         return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,
-                            self.relu if relu is None else relu, res, res_mode, naive=naive)
+                            self.relu if relu is None else relu, res, res_mode, naive=naive, wgt_layout=self.layout)
 
     def flops(self, out_positions):
         return 2.0 * out_positions * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]

@@ -33,7 +33,7 @@ struct ConvParams {
   int Do, Ho, Wo;
   int M, K;
   int relu, res_mode, rH, rW;
-  int prio_mode;
+  int kmode;  // 0: k = tap*Cin + ci   1: k = (ci/32)*taps*32 + tap*32 + ci%32
 };
 
 #define IVX_BK 32
@@ -140,7 +140,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
   // per-thread k cursor: k4 = slab*32 + cc*4 = tap*Cin + kc
   int k4 = cc * 4;
   int kc, ka, ke, kf;
-  {
+  if (p.kmode == 1) {  // chunk-major: slab s = (channel chunk s / taps, tap s % taps)
+    kc = cc * 4;
+    ka = ke = kf = 0;
+  } else {
     const int tap = k4 / p.Cin;
     kc = k4 - tap * p.Cin;
     kf = tap % p.KW;
@@ -175,6 +178,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
   };
   auto advance_k = [&]() {
     k4 += IVX_BK;
+    if (p.kmode == 1) {  // next tap of the same 32-channel chunk; after the last tap move to the next chunk
+      if (++kf == p.KW) {
+        kf = 0;
+        if (++ke == p.KH) {
+          ke = 0;
+          if (++ka == p.KD) {
+            ka = 0;
+            kc += IVX_BK;
+          }
+        }
+      }
+      return;
+    }
     kc += IVX_BK;
     while (kc >= p.Cin) {
       kc -= p.Cin;
@@ -266,32 +282,24 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams
   const int wid = tid >> 6;
   const int wr = wid / WC, wc = wid % WC;
 
-  int bid = blockIdx.x;
+  // 1-D grid of 8 * ceil(Mt/8) * Nt workgroups.  Workgroup b runs on XCD b % 8 (observed dispatch rule; used for
+  // speed only): XCD x owns the contiguous M-tiles [x*q, (x+1)*q) so halo re-reads of neighbouring x-slabs hit its own
+  // L2, and inside an XCD the Nt workgroups that share one A-tile are consecutive, so they run together and the
+  // A-tile is fetched into that L2 once instead of once per N-tile.  Ids past the last M-tile exit (< 8*Nt of them).
+  int mt, nt;
   {
-    const int nb = gridDim.x;
-    const int q = nb >> 3, r = nb & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int Nt = (p.Cout + BN - 1) / BN;
+    const int q = gridDim.x / (8 * Nt);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    mt = xcd * q + idx / Nt;
+    nt = idx % Nt;
   }
-  const int m0 = bid * BM;
-  const int n0 = blockIdx.y * BN;
+  if (mt * BM >= p.M) return;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
 
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, w_bytes, 0x00020000);
-
-  // Two workgroups share a CU (one wave of each per SIMD).  Launched together and running identical code they stay
-  // in lockstep, so their load/ds_write/barrier phases coincide and the matrix pipe idles.  Raising the priority of
-  // the wave in the odd hardware wave slot makes the pair alternate instead: one streams MFMAs while the other
-  // refills LDS.  (HW_REG_HW_ID[3:0] = wave slot inside the SIMD; speed only, never correctness.)
-  if (p.prio_mode == 1) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-    if (slot & 1) __builtin_amdgcn_s_setprio(1);
-  } else if (p.prio_mode == 2) {
-    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
-  } else if (p.prio_mode == 3) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-    if (slot & 1) __builtin_amdgcn_s_setprio(3);
-  }
 
   const int cc = tid & 7;
   const int lr = tid >> 3;
@@ -326,7 +334,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams
   }
   int k4 = cc * 4;
   int kc, ka, ke, kf;
-  {
+  if (p.kmode == 1) {  // chunk-major: slab s = (channel chunk s / taps, tap s % taps)
+    kc = cc * 4;
+    ka = ke = kf = 0;
+  } else {
     const int tap = k4 / p.Cin;
     kc = k4 - tap * p.Cin;
     kf = tap % p.KW;
@@ -358,6 +369,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams
   };
   auto advance_k = [&]() {
     k4 += IVX_BK;
+    if (p.kmode == 1) {  // next tap of the same 32-channel chunk; after the last tap move to the next chunk
+      if (++kf == p.KW) {
+        kf = 0;
+        if (++ke == p.KH) {
+          ke = 0;
+          if (++ka == p.KD) {
+            ka = 0;
+            kc += IVX_BK;
+          }
+        }
+      }
+      return;
+    }
     kc += IVX_BK;
     while (kc >= p.Cin) {
       kc -= p.Cin;
@@ -391,34 +415,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams
   store_slab(0);
   __syncthreads();
 
-  const int abl = p.prio_mode;  // >= 10: timing ablations (tools/conv_bench.py), results invalid
   const int frag_off = (lane & 31) * IVX_LDK + 4 * (lane >> 5);
   for (int s = 0; s < S; ++s) {
     const int cur = s & 1;
     const bool more = (s + 1) < S;
-    if (more && abl != 10 && abl != 11 && abl != 13 && abl != 14) {
+    if (more) {
       advance_k();
       load_slab();
     }
     const float *Ac = As + cur * BM * IVX_LDK + wr * TM * 32 * IVX_LDK + frag_off;
     const float *Bc = Bs + cur * BN * IVX_LDK + wc * TN * 32 * IVX_LDK + frag_off;
     f32x4 fa[2][TM], fb[2][TN];
-    if (abl == 14) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[0][i] = fa[1][i] = f32x4{1.f, 2.f, 3.f, 4.f};
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[0][j] = fb[1][j] = f32x4{1.f, 2.f, 3.f, 4.f};
-    }
-    if (abl != 14) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_LDK);
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * IVX_LDK);
-    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int cb = kk & 1, nb = cb ^ 1;
-      if (kk < 3 && abl != 14) {
+      if (kk < 3) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_LDK + (kk + 1) * 8);
 #pragma unroll
@@ -432,8 +447,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][i][q], fb[cb][j][q], acc[i][j], 0, 0, 0);
     }
-    if (more && abl != 10 && abl != 11 && abl != 13 && abl != 14) store_slab(cur ^ 1);
-    if (abl != 11 && abl != 12 && abl != 13 && abl != 14) __syncthreads();
+    if (more) store_slab(cur ^ 1);
+    __syncthreads();
   }
   conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
@@ -461,8 +476,14 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
           const int iw = ow * p.sw - p.pw + f;
           if ((unsigned)iw >= (unsigned)p.W) continue;
           const float *x = p.in + ((((size_t)b * p.D + id) * p.H + ih) * p.W + iw) * p.Cin;
-          const float *w = p.wgt + (size_t)n * p.K + ((a * p.KH + e) * p.KW + f) * p.Cin;
-          for (int c = 0; c < p.Cin; ++c) acc = fmaf(x[c], w[c], acc);
+          const int tap = (a * p.KH + e) * p.KW + f;
+          const int ntap = p.KD * p.KH * p.KW;
+          const float *w = p.wgt + (size_t)n * p.K;
+          if (p.kmode == 1) {
+            for (int c = 0; c < p.Cin; ++c) acc = fmaf(x[c], w[((c >> 5) * ntap + tap) * 32 + (c & 31)], acc);
+          } else {
+            for (int c = 0; c < p.Cin; ++c) acc = fmaf(x[c], w[tap * p.Cin + c], acc);
+          }
         }
       }
     }
@@ -491,6 +512,7 @@ static int fill_params(const ivx_conv_desc *d, const float *in, const float *wgt
   IVX_REQUIRE(M < (1LL << 31) - 512 && K < (1LL << 30), "ivx_conv_fwd: problem too large for 32-bit row index");
   IVX_REQUIRE((int64_t)d->B * d->D * d->H * d->W < (1LL << 31), "ivx_conv_fwd: input voxel count exceeds 2^31");
   IVX_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2, "ivx_conv_fwd: bad res_mode");
+  IVX_REQUIRE(d->wgt_layout == 0 || (d->wgt_layout == 1 && d->Cin % 32 == 0), "ivx_conv_fwd: wgt_layout 1 needs Cin %% 32 == 0");
   IVX_REQUIRE(d->res_mode == 0 || res, "ivx_conv_fwd: res_mode set but res is NULL");
   if (d->res_mode == 2) {
     IVX_REQUIRE(Do == 1 && d->res_h > 0 && d->res_w > 0, "ivx_conv_fwd: res_mode 2 needs a 2-D output and res dims");
@@ -500,7 +522,7 @@ static int fill_params(const ivx_conv_desc *d, const float *in, const float *wgt
   p->Cout = d->Cout; p->KD = d->KD; p->KH = d->KH; p->KW = d->KW;
   p->sd = d->sd; p->sh = d->sh; p->sw = d->sw; p->pd = d->pd; p->ph = d->ph; p->pw = d->pw;
   p->Do = Do; p->Ho = Ho; p->Wo = Wo; p->M = (int)M; p->K = (int)K;
-  p->relu = d->relu; p->res_mode = d->res_mode; p->rH = d->res_h; p->rW = d->res_w; p->prio_mode = 0;
+  p->relu = d->relu; p->res_mode = d->res_mode; p->rH = d->res_h; p->rW = d->res_w; p->kmode = d->wgt_layout;
   return IVX_OK;
 }
 
@@ -523,18 +545,21 @@ static void launch_cfg(const ConvParams &p, hipStream_t st, bool v2) {
   const int64_t w_bytes = (int64_t)p.Cout * p.K * 4;
   // v2 needs 31-bit byte offsets and kernel extents that fit the 8-bit tap masks; otherwise the generic kernel
   v2 = v2 && in_bytes < (1LL << 31) && w_bytes < (1LL << 31) && p.KD <= 8 && p.KH <= 8 && p.KW <= 8;
-  if (v2)
-    hipLaunchKernelGGL((conv_igemm_f32_v2_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
+  // (the generic kernel only knows weight layout 0; ivx_conv_fwd rejects layout 1 when v2 is not applicable)
+  if (v2) {
+    const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
+    const long long g1 = 8 * ((Mt + 7) / 8) * Nt;
+    hipLaunchKernelGGL((conv_igemm_f32_v2_kernel<TM, TN, WR, WC>), dim3((unsigned)g1), dim3(256), 0, st, p, (unsigned)in_bytes,
+                       (unsigned)w_bytes);
+  }
   else
     hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
 }
 
 static int g_tile_override = 0;
-static int g_prio_mode = 0;
 // Tuning knob (A/B experiments, tools/conv_bench.py): 0 = automatic choice by Cout, 1..N = force a tile config.
 extern "C" int ivx_conv_set_tile_override(int cfg) {
-  g_prio_mode = cfg / 1000;
-  g_tile_override = cfg % 1000;
+  g_tile_override = cfg;
   return IVX_OK;
 }
 
@@ -544,8 +569,14 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float
   int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
   if (rc != IVX_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (p.kmode == 1) {
+    const int64_t in_b = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4, w_b = (int64_t)p.Cout * p.K * 4;
+    if (!(in_b < (1LL << 31) && w_b < (1LL << 31) && p.KD <= 8 && p.KH <= 8 && p.KW <= 8) || g_tile_override >= 100) {
+      ivx_set_error("ivx_conv_fwd: wgt_layout 1 is only implemented by the buffer-load kernel (tensor < 2 GiB, kernel extents <= 8)");
+      return IVX_ERR_UNSUPPORTED;
+    }
+  }
   int cfg = g_tile_override;
-  p.prio_mode = g_prio_mode;
   bool v2 = true;
   if (cfg >= 100) {  // 100 + c: force the generic (v1) kernel with tile config c
     v2 = false;
@@ -558,7 +589,7 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float
     const long long nblk = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (p.Cout <= 32)
       cfg = 4;
-    else if (nblk >= 4096)
+    else if (nblk >= 2500)
       cfg = p.Cout > 64 ? 1 : 3;
     else
       cfg = 6;

@@ -63,16 +63,17 @@ def from_channels_last(x, ndim_spatial=3):
 
 # ------------------------------------------------------------------ conv
 def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0), relu=False,
-             res=None, res_mode=0, naive=False, out=None):
+             res=None, res_mode=0, naive=False, out=None, wgt_layout=0):
     """x [B,D,H,W,Cin], wgt [Cout,KD,KH,KW,Cin] (packed), scale/shift [Cout] -> [B,Do,Ho,Wo,Cout]."""
     _chk(x, 'x')
     _chk(wgt, 'wgt')
     B, D, H, W, Cin = x.shape
     Cout = wgt.shape[0]
-    if tuple(wgt.shape[1:]) != (kernel[0], kernel[1], kernel[2], Cin):
-        raise ValueError(f'weight shape {tuple(wgt.shape)} does not match kernel {kernel} / Cin {Cin}')
+    want = (kernel[0], kernel[1], kernel[2], Cin) if wgt_layout == 0 else (Cin // 32, kernel[0], kernel[1], kernel[2], 32)
+    if tuple(wgt.shape[1:]) != want:
+        raise ValueError(f'weight shape {tuple(wgt.shape)} does not match kernel {kernel} / Cin {Cin} / layout {wgt_layout}')
     d = ConvDesc(B, D, H, W, Cin, Cout, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
-                 padding[0], padding[1], padding[2], int(bool(relu)), 0, 0, 0)
+                 padding[0], padding[1], padding[2], int(bool(relu)), 0, 0, 0, int(wgt_layout))
     do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
     L = _lib.lib()
     check(L.ivx_conv_out_dims(C.byref(d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')

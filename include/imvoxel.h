@@ -53,7 +53,10 @@ const char *ivx_last_error(void);
  *                              * wgt[co,kd,kh,kw,ci]) * scale[co] + shift[co] + res[...] )
  *
  * in    [B,D,H,W,Cin]   Cin % 4 == 0 (pad the image to 4 channels with ivx_nchw_to_nhwc)
- * wgt   [Cout,KD,KH,KW,Cin]
+ * wgt   wgt_layout 0: [Cout,KD,KH,KW,Cin]   (k = tap*Cin + ci)
+ *       wgt_layout 1: [Cout,Cin/32,KD,KH,KW,32]  (k = (ci/32)*taps*32 + tap*32 + ci%32; needs Cin % 32 == 0).
+ *       Layout 1 walks all taps of one 32-channel chunk back to back, so the 27 shifted re-reads of an input row
+ *       are one K-slab apart and hit L1/L2 instead of going back to the fabric.
  * scale,shift [Cout] or NULL (1 / 0).  Conv bias and BN fold into them on the host.
  * res   NULL, or res_mode 1: same shape as out; res_mode 2: [B,1,res_h,res_w,Cout] read with
  *       nearest-neighbour up-sampling to (Ho,Wo) (FPN top-down path, F.interpolate 'nearest').
@@ -65,6 +68,7 @@ typedef struct ivx_conv_desc {
   int32_t pd, ph, pw;
   int32_t relu;
   int32_t res_mode, res_h, res_w;
+  int32_t wgt_layout;
 } ivx_conv_desc;
 
 int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *Ho, int32_t *Wo);

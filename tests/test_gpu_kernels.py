@@ -81,6 +81,19 @@ def test_conv_config_variants(ia):
         ref = F.conv3d(x, w, None, 1, 1)
         y = FusedConv(w, padding=1).to('cuda')(xc)
         assert_close(f'cout{cout}', uncl(y), ref, 1e-4, 1e-4)
+    # every tile config of both kernels (buffer-load v2 with either weight layout, generic v1 via override 100+c)
+    from imvoxelnet_amd import _lib
+    L = _lib.lib()
+    w = torch.randn(72, 32, 3, 3, 3, generator=g) * 0.05
+    ref = F.conv3d(x, w, None, (1, 1, 2), 1)
+    try:
+        for layout in (1, 0):
+            fc = FusedConv(w, stride=(1, 1, 2), padding=1, layout=layout).to('cuda')
+            for ov in ((1, 2, 3, 4, 5, 6, 7) if layout == 1 else (1, 3, 6, 101, 102, 103, 104, 105, 106, 107)):
+                L.ivx_conv_set_tile_override(ov)
+                assert_close(f'layout{layout} override{ov}', uncl(fc(xc)), ref, 1e-4, 1e-4)
+    finally:
+        L.ivx_conv_set_tile_override(0)
 
 
 def test_conv_fpn_upsample_residual(ia):

@@ -1,0 +1,216 @@
+"""CPU-only tests of the host side: C-ABI surface, registry / config surface, anchor generator, box utils,
+weight packing, loud failure without a device, and the world_size-2 gloo path of the detection all-gather."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_npz, load_json, ROOT
+from kitti_cfg import kitti_model_cfg, KITTI_TEST_CFG, kitti_meta
+
+
+def test_cabi_library_loads_and_exports_every_declared_symbol():
+    """include/imvoxel.h <-> libimvoxel_hip.so: every declared function is exported (no compute calls here)."""
+    from imvoxelnet_amd import _lib
+    L = _lib.lib()
+    header = open(os.path.join(ROOT, 'include', 'imvoxel.h')).read()
+    declared = set(re.findall(r'\b(ivx_[a-z0-9_]+)\s*\(', header))
+    declared -= {'ivx_stream_t'}
+    assert declared, 'no declarations parsed'
+    for name in sorted(declared):
+        assert hasattr(L, name), f'{name} declared in include/imvoxel.h but not exported'
+    assert set(_lib.EXPORTS) <= declared
+    assert L.ivx_version() >= 100
+    # struct layouts used by the ctypes binding match the header field counts
+    assert ctypes.sizeof(_lib.ConvDesc) == 20 * 4
+    assert ctypes.sizeof(_lib.AnchorHeadDesc) == 17 * 4
+
+
+def test_cabi_argument_validation_without_gpu():
+    """Invalid arguments are rejected with a status + message before any launch (never exit())."""
+    from imvoxelnet_amd import _lib
+    L = _lib.lib()
+    d = _lib.ConvDesc(1, 1, 8, 8, 6, 4, 1, 3, 3, 1, 1, 1, 0, 1, 1, 0, 0, 0, 0, 0)
+    dummy = ctypes.c_void_p(64)
+    rc = L.ivx_conv_fwd(ctypes.byref(d), dummy, dummy, None, None, None, dummy, None)
+    assert rc == -1 and b'multiple of 4' in L.ivx_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, 'conv')
+    assert L.ivx_conv_fwd(ctypes.byref(d), None, None, None, None, None, None, None) == -1
+    h = _lib.AnchorHeadDesc(1, 4, 4, 20, 2, 3, 0, 6, 20, 10, 5, 1, 0, 0.1, 0.01, 0.0, 1.0)
+    assert L.ivx_anchor_head_workspace_bytes(ctypes.byref(h)) == -1          # multi-class: not built, says so
+    assert b'num_classes' in L.ivx_last_error()
+    assert L.ivx_nms_bev(None, 5000, 0.1, 1, None, 0, dummy, dummy, None) == -1
+    assert L.ivx_nms_workspace_bytes(100) >= 100 * 2 * 8
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    from imvoxelnet_amd import ops
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.conv_fwd(torch.zeros(1, 1, 4, 4, 4), torch.zeros(4, 1, 1, 1, 4))
+    with pytest.raises(RuntimeError):
+        ops.to_channels_last(torch.zeros(1, 3, 4, 4))
+
+
+def test_reference_config_builds_the_detector_with_reference_state_dict_keys():
+    import imvoxelnet_amd as ia
+    model = ia.build_detector(kitti_model_cfg(), test_cfg=KITTI_TEST_CFG)
+    assert isinstance(model, ia.ImVoxelNet) and isinstance(model.neck_3d, ia.KittiImVoxelNeck)
+    sd = model.state_dict()
+    neck_keys = [k for k in sd if k.startswith('neck_3d.')]          # incl. 9 num_batches_tracked buffers
+    assert len(neck_keys) == 57                                     # Kitti neck = 57 tensors
+    for k in ('backbone.conv1.weight', 'backbone.layer1.0.downsample.0.weight', 'backbone.layer4.2.bn3.running_var',
+              'neck.lateral_convs.3.conv.bias', 'neck.fpn_convs.0.conv.weight', 'neck_3d.model.1.0.bias',
+              'neck_3d.model.4.bn2.running_mean', 'bbox_head.conv_cls.weight', 'bbox_head.conv_dir_cls.bias'):
+        assert k in sd, k
+    assert sd['neck_3d.model.5.0.weight'].shape == (256, 256, 3, 3, 3)
+    assert model.bbox_head.num_anchors == 2 and abs(float(sd['bbox_head.conv_cls.bias'][0]) + 4.59512) < 1e-4
+    with pytest.raises(KeyError):
+        ia.build_neck(dict(type='NoSuchNeck'))
+    with pytest.raises(NotImplementedError):
+        ia.ImVoxelNet(**{**{k: v for k, v in kitti_model_cfg().items() if k not in ('type', 'pretrained')},
+                         'head_2d': dict(type='LayoutHead')})
+
+
+def test_golden_neck_state_dict_loads_strictly():
+    import imvoxelnet_amd as ia
+    g = load_npz('necks.npz')
+    for name, cls in (('kitti', ia.KittiImVoxelNeck), ('nuscenes', ia.NuScenesImVoxelNeck)):
+        sd = {k[len(name) + 6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + '::sd::')}
+        res = cls(4, 8).load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys and all(k.endswith('num_batches_tracked') for k in res.missing_keys)
+
+
+def test_anchor_generator_matches_reference_bit_exact():
+    import imvoxelnet_amd as ia
+    info = load_json('anchors_fullsize.json')
+    for name, c in info.items():
+        gen = ia.Anchor3DRangeGenerator(ranges=c['ranges'], sizes=c['sizes'], rotations=c['rotations'], reshape_out=True)
+        a = gen.grid_anchors([tuple(c['featmap'])], device='cpu')[0].numpy()
+        assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == c['sha256'], name
+        assert gen.num_base_anchors == 2
+    g = load_npz('anchor_head.npz')
+    gen = ia.Anchor3DRangeGenerator(ranges=g['kitti::ranges'].tolist(), sizes=g['kitti::sizes'].tolist(), rotations=[0, 1.57])
+    assert np.array_equal(gen.grid_anchors([(10, 12)])[0].numpy(), g['kitti::anchors'])
+
+
+def test_box_utils_and_coder_match_reference():
+    import imvoxelnet_amd as ia
+    g = load_npz('box_utils.npz')
+    val = torch.from_numpy(g['limit_period::val'])
+    assert np.array_equal(ia.limit_period(val, 0.5, np.pi).numpy(), g['limit_period::o0.5'])
+    assert np.array_equal(ia.limit_period(val, 1, np.pi).numpy(), g['limit_period::o1'])
+    assert np.array_equal(ia.xywhr2xyxyr(torch.from_numpy(g['xywhr::in'])).numpy(), g['xywhr::out'])
+    r = ia.rotation_3d_in_axis(torch.from_numpy(g['rot::points']), torch.from_numpy(g['rot::angles']), axis=2)
+    assert np.array_equal(r.numpy(), g['rot::axis2'])
+    d = ia.DeltaXYZWLHRBBoxCoder.decode(torch.from_numpy(g['coder::anchors']), torch.from_numpy(g['coder::deltas']))
+    assert np.array_equal(d.numpy(), g['coder::decoded'])
+    t = torch.from_numpy(g['boxes::in'])
+    assert np.array_equal(ia.DepthInstance3DBoxes(t, origin=(.5, .5, .5)).tensor.numpy(), g['boxes::depth_origin_555'])
+    b = ia.LiDARInstance3DBoxes(t)
+    assert np.array_equal(b.bev.numpy(), g['boxes::lidar_bev']) and np.array_equal(b.gravity_center.numpy(), g['boxes::lidar_gravity'])
+    assert len(ia.LiDARInstance3DBoxes([], box_dim=7)) == 0
+    res = ia.bbox3d2result(b, torch.ones(len(b)), torch.zeros(len(b), dtype=torch.long))
+    assert set(res) == {'boxes_3d', 'scores_3d', 'labels_3d'}
+
+
+def test_camera_setup_matches_reference_projection():
+    """ImVoxelNet._compute_projection / new_origin on the host == reference golden (bit exact)."""
+    import imvoxelnet_amd as ia
+    from helpers import sub, meta_from_case
+    g = load_npz('backproject_cases.npz')
+    for case in 'ABCDE':
+        c = sub(g, case + '::')
+        meta = meta_from_case(c)
+        P = ia.ImVoxelNet._compute_projection(meta, 4, None)
+        assert P.dtype == torch.float32 and np.array_equal(P.numpy(), c['projection'])
+        pts = ia.get_points(torch.tensor(c['n_voxels']), torch.from_numpy(c['voxel_size']), torch.from_numpy(c['origin']))
+        assert np.array_equal(pts.numpy(), c['points'])
+
+
+def test_fused_conv_packing():
+    from imvoxelnet_amd.conv import FusedConv
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(5, 3, 7, 7, generator=g)
+    fc = FusedConv(w, bn=(torch.rand(5, generator=g) + .5, torch.randn(5, generator=g), torch.randn(5, generator=g),
+                          torch.rand(5, generator=g) + .5), stride=2, padding=3, relu=True, dims=2)
+    assert fc._w_host.shape == (5, 1, 7, 7, 4) and fc.stride == (1, 2, 2) and fc.padding == (0, 3, 3) and fc.layout == 0
+    assert torch.equal(fc._w_host[..., :3], w.permute(0, 2, 3, 1).unsqueeze(1)) and float(fc._w_host[..., 3].abs().max()) == 0
+    w3 = torch.randn(8, 4, 3, 3, 3, generator=g)
+    b3 = torch.randn(8, generator=g)
+    gam, bet, mu, var = torch.rand(8, generator=g) + .5, torch.randn(8, generator=g), torch.randn(8, generator=g), torch.rand(8, generator=g) + .5
+    f3 = FusedConv(w3, b3, (gam, bet, mu, var), stride=(1, 1, 2), padding=1)
+    x = torch.randn(2, 8, generator=g)      # per-channel pre-BN conv outputs (without bias)
+    want = (x + b3 - mu) / torch.sqrt(var + 1e-5) * gam + bet
+    got = x * f3._scale_host + f3._shift_host
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        f3(torch.zeros(1))
+    w64 = torch.randn(6, 64, 3, 3, 3, generator=g)
+    f64 = FusedConv(w64, padding=1)
+    assert f64.layout == 1 and f64._w_host.shape == (6, 2, 3, 3, 3, 32)
+    assert torch.equal(f64._w_host[2, 1, 0, 2, 1], w64[2, 32:, 0, 2, 1])
+    assert FusedConv(w64, padding=1, layout=0).layout == 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, out_q):
+    import torch.distributed as dist
+    from imvoxelnet_amd import dist as ivd
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    B, M = 2, 5
+    g = torch.Generator().manual_seed(100 + rank)
+    boxes = torch.randn(B, M, 7, generator=g)
+    scores = torch.rand(B, M, generator=g)
+    labels = torch.randint(0, 3, (B, M), generator=g)
+    count = torch.tensor([3 + rank, 1], dtype=torch.int32)
+    gb, gs, gl, gc = ivd.all_gather_detections(boxes, scores, labels, count)
+    a, b = ivd.shard_range(7, rank, world)
+    out_q.put((rank, gb.numpy(), gs.numpy(), gl.numpy(), gc.numpy(), boxes.numpy(), labels.numpy(), (a, b)))
+    dist.destroy_process_group()
+
+
+def test_all_gather_detections_gloo_world2():
+    """N > 1 path on CPU: two processes, gloo, the same packed all-gather bench.py uses over RCCL."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, gb0, gs0, gl0, gc0, b0, l0, sh0), (r1, gb1, gs1, gl1, gc1, b1, l1, sh1) = res
+    assert np.array_equal(gb0, gb1) and np.array_equal(gc0, gc1)              # every rank sees the whole batch
+    assert gb0.shape == (4, 5, 7) and np.array_equal(gb0[:2], b0) and np.array_equal(gb0[2:], b1)
+    assert np.array_equal(gl0[:2], l0) and np.array_equal(gl0[2:], l1) and gl0.dtype == np.int64
+    assert gc0.tolist() == [3, 1, 4, 1]
+    assert sh0 == (0, 4) and sh1 == (4, 7)
+
+
+def test_single_process_gather_is_identity():
+    from imvoxelnet_amd import dist as ivd
+    boxes, scores = torch.randn(3, 4, 7), torch.rand(3, 4)
+    labels, count = torch.randint(0, 2, (3, 4)), torch.tensor([4, 0, 2], dtype=torch.int32)
+    gb, gs, gl, gc = ivd.all_gather_detections(boxes, scores, labels, count)
+    assert torch.equal(gb, boxes) and torch.equal(gs, scores) and torch.equal(gl, labels) and torch.equal(gc, count)
+    a = [ivd.shard_range(10, r, 4) for r in range(4)]
+    assert a == [(0, 3), (3, 6), (6, 8), (8, 10)]

@@ -73,6 +73,7 @@ def main():
     ap.add_argument('--layers', default='all')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--set', default='neck')
+    ap.add_argument('--layout', type=int, default=1)
     a = ap.parse_args()
     if a.set == 'resnet':
         return run2d(a)
@@ -82,13 +83,14 @@ def main():
     for li in layers:
         name, (X, Y, Z), ci, co, st, pd = LAYERS[li]
         x = torch.randn(a.batch, X, Y, Z, ci, device='cuda', generator=g)
-        w = torch.randn(co, 3, 3, 3, ci, device='cuda', generator=g) * 0.02
+        lay = a.layout if ci % 32 == 0 else 0
+        w = torch.randn((co, 3, 3, 3, ci) if lay == 0 else (co, ci // 32, 3, 3, 3, 32), device='cuda', generator=g) * 0.02
         sc = torch.rand(co, device='cuda', generator=g) + 0.5
         sh = torch.randn(co, device='cuda', generator=g)
         for cfg in [int(v) for v in a.cfgs.split(',')]:
             L.ivx_conv_set_tile_override(cfg)
             try:
-                y = ops.conv_fwd(x, w, sc, sh, (3, 3, 3), st, pd, relu=True)
+                y = ops.conv_fwd(x, w, sc, sh, (3, 3, 3), st, pd, relu=True, wgt_layout=lay)
             except Exception as e:  # noqa
                 print(f'{name:24s} cfg {cfg}: {e}')
                 continue
@@ -96,12 +98,12 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                ops.conv_fwd(x, w, sc, sh, (3, 3, 3), st, pd, relu=True, out=y)
+                ops.conv_fwd(x, w, sc, sh, (3, 3, 3), st, pd, relu=True, out=y, wgt_layout=lay)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
             flops = 2.0 * y.numel() * ci * 27
-            print(f'{name:24s} cfg {cfg}: {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s  ({flops / 1e9:.0f} GFLOP)', flush=True)
+            print(f'{name:24s} layout {lay} cfg {cfg}: {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s  ({flops / 1e9:.0f} GFLOP)', flush=True)
         L.ivx_conv_set_tile_override(0)
 
 
