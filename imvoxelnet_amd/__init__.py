@@ -6,9 +6,12 @@ HIP library (that happens on first use and fails loudly if libimvoxel_hip.so is 
 from .registry import (BACKBONES, NECKS, HEADS, DETECTORS, ANCHOR_GENERATORS, BBOX_CODERS, ConfigDict,  # noqa: F401
                        build_backbone, build_neck, build_head, build_detector)
 from .backbones import ResNet, FPN                                           # noqa: F401
-from .necks3d import KittiImVoxelNeck, NuScenesImVoxelNeck, BasicBlock3d    # noqa: F401
+from .necks3d import (KittiImVoxelNeck, NuScenesImVoxelNeck, FastIndoorImVoxelNeck, ImVoxelNeck, BasicBlock3d,  # noqa: F401
+                      BasicBlock3dV2)
 from .anchor import Anchor3DRangeGenerator, DeltaXYZWLHRBBoxCoder          # noqa: F401
 from .heads import Anchor3DHead                                            # noqa: F401
+from .heads_indoor import (ScanNetImVoxelHeadV2, SunRgbdImVoxelHeadV2, ScanNetImVoxelHead,  # noqa: F401
+                           SunRgbdImVoxelHead)
 from .detector import ImVoxelNet, get_points                               # noqa: F401
 from .boxes import (LiDARInstance3DBoxes, DepthInstance3DBoxes, limit_period, xywhr2xyxyr,  # noqa: F401
                     rotation_3d_in_axis, bbox3d2result)

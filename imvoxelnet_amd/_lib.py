@@ -18,7 +18,7 @@ class IvxError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('B', 'D', 'H', 'W', 'Cin', 'Cout', 'KD', 'KH', 'KW', 'sd', 'sh', 'sw', 'pd', 'ph', 'pw',
-                 'relu', 'res_mode', 'res_h', 'res_w', 'wgt_layout')]
+                 'relu', 'res_mode', 'res_h', 'res_w', 'wgt_layout', 'out_mode', 'res_after_act')] + [('post_scale', C.c_float)]
 
 
 class AnchorHeadDesc(C.Structure):
@@ -29,8 +29,9 @@ class AnchorHeadDesc(C.Structure):
 
 
 EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override',
-           'ivx_maxpool2d_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
-           'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_nms_workspace_bytes',
+           'ivx_maxpool2d_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
+           'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_fcos_head_workspace_bytes',
+           'ivx_fcos_head_level_candidates', 'ivx_nms_workspace_bytes',
            'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms']
 
 
@@ -51,6 +52,7 @@ def lib():
         getattr(L, name).argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
     L.ivx_conv_set_tile_override.argtypes = [C.c_int]
     L.ivx_maxpool2d_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ivx_upsample_trilinear2x_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     L.ivx_nchw_to_nhwc.argtypes = [vp, i32, i32, i64, i32, vp, vp]
     L.ivx_nhwc_to_nchw.argtypes = [vp, i32, i64, i32, vp, vp]
     L.ivx_backproject_mean_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(f32), i32, i32, i32,
@@ -58,13 +60,17 @@ def lib():
     L.ivx_anchor_head_workspace_bytes.argtypes = [C.POINTER(AnchorHeadDesc)]
     L.ivx_anchor_head_workspace_bytes.restype = i64
     L.ivx_anchor_head_get_bboxes.argtypes = [C.POINTER(AnchorHeadDesc), vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ivx_fcos_head_workspace_bytes.argtypes = [i32, i32, i32]
+    L.ivx_fcos_head_workspace_bytes.restype = i64
+    L.ivx_fcos_head_level_candidates.argtypes = [vp, vp, vp, vp, f32] + [i32] * 12 + [vp, i64, vp, vp, vp, vp]
     L.ivx_nms_workspace_bytes.argtypes = [i32]
     L.ivx_nms_workspace_bytes.restype = i64
     L.ivx_nms_bev.argtypes = [vp, i32, f32, i32, vp, i64, vp, vp, vp]
     L.ivx_boxes_overlap_bev.argtypes = [vp, i32, vp, i32, i32, vp, vp]
     L.ivx_aligned_3d_nms.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
     for name in EXPORTS:
-        if name not in ('ivx_last_error', 'ivx_anchor_head_workspace_bytes', 'ivx_nms_workspace_bytes'):
+        if name not in ('ivx_last_error', 'ivx_anchor_head_workspace_bytes', 'ivx_nms_workspace_bytes',
+                        'ivx_fcos_head_workspace_bytes'):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -55,6 +55,7 @@ class FusedConv:
         self._identity_epilogue = bias is None and bn is None
         self._scale_host, self._shift_host = scale.contiguous(), shift.contiguous()
         self.relu = relu
+        self.out_mode = 0
         self.w = self.scale = self.shift = None
 
     def to(self, device):
@@ -64,11 +65,35 @@ class FusedConv:
             self.shift = self._shift_host.to(device)
         return self
 
-    def __call__(self, x, res=None, res_mode=0, relu=None, naive=False):
+    def __call__(self, x, res=None, res_mode=0, relu=None, naive=False, res_after_act=False, post_scale=1.0):
         if self.w is None:
             raise RuntimeError('FusedConv.to(device) must be called before use')
         return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,
-                            self.relu if relu is None else relu, res, res_mode, naive=naive, wgt_layout=self.layout)
+                            self.relu if relu is None else relu, res, res_mode, naive=naive, wgt_layout=self.layout,
+                            out_mode=self.out_mode, res_after_act=res_after_act, post_scale=post_scale)
 
     def flops(self, out_positions):
         return 2.0 * out_positions * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
+
+
+class FusedConvTranspose2x(FusedConv):
+    """nn.ConvTranspose3d(kernel 2, stride 2, bias=False) [+ eval BN] [+ ReLU] as ONE 1x1x1 GEMM with 8*Cout columns
+    (column n = ((a*2+e)*2+f)*Cout + co) whose epilogue scatters to out[b, 2d+a, 2h+e, 2w+f, co]
+    (necks/imvoxelnet.py:54-56: the up-blocks of FastIndoorImVoxelNeck).  weight: [Cin, Cout, 2, 2, 2]."""
+
+    def __init__(self, weight, bn=None, relu=False, eps=1e-5):
+        w = weight.detach().to(torch.float32)
+        cin, cout = w.shape[0], w.shape[1]
+        if tuple(w.shape[2:]) != (2, 2, 2):
+            raise ValueError('only kernel 2 / stride 2 transposed convolutions are built')
+        as_conv = w.permute(2, 3, 4, 1, 0).reshape(8 * cout, cin, 1, 1, 1)      # [(a,e,f,co), ci]
+        super().__init__(as_conv, None, None, 1, 0, relu, dims=3, eps=eps)
+        self.out_mode = 1
+        self.cout_real = cout
+        scale, shift = torch.ones(cout), torch.zeros(cout)
+        if bn is not None:
+            g, b, m, v = (t.detach().to(torch.float32).cpu() for t in bn)
+            scale = g / torch.sqrt(v + eps)
+            shift = b - m * scale
+            self._identity_epilogue = False
+        self._scale_host, self._shift_host = scale.contiguous(), shift.contiguous()

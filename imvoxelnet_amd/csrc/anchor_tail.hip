@@ -661,3 +661,141 @@ extern "C" int ivx_aligned_3d_nms(const float *boxes, const float *scores, const
   IVX_CHECK_LAUNCH("ivx_aligned_3d_nms");
   return IVX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Indoor (FCOS-style) head tail: ImVoxelHeadV2._get_bboxes_single per level
+// (mmdet3d/models/dense_heads/imvoxel_head_v2.py:216-285, 305-313 / 444-449, 419-438 / 547-555):
+// trilinear-resized valid mask (.round() => >= 5 of the 8 contributing level-0 voxels), sigmoid scores
+// cls * centerness * valid, top-k(nms_pre) on the class maximum, level points, distance decoding.
+struct FcosP {
+  const float *head_out;     // [B, n, CH]  fused conv output: [centerness | reg (R) | cls (ncls)]
+  const uint8_t *valid0;     // [B, X, Y, Z] level-0 valid mask
+  const float *vs;           // [B, 3] level voxel size  (voxel_size * 2^level, fp32, built on the host)
+  const float *new_origin;   // [B, 3] origin - n_level/2 * vs_level
+  float scale;               // mmcv Scale parameter of this level
+  int B, nx, ny, nz, n, CH, ncls, R, level, X, Y, Z, kpad, k;
+};
+
+__device__ inline float fcos_valid(const FcosP &p, int b, int i) {
+  const int iz = i % p.nz;
+  const int t = i / p.nz;
+  const int iy = t % p.ny, ix = t / p.ny;
+  const uint8_t *v = p.valid0 + (size_t)b * p.X * p.Y * p.Z;
+  if (p.level == 0) return v[((size_t)ix * p.Y + iy) * p.Z + iz] ? 1.0f : 0.0f;
+  const int h = (1 << (p.level - 1)) - 1;
+  const int x0 = (ix << p.level) + h, y0 = (iy << p.level) + h, z0 = (iz << p.level) + h;
+  int cnt = 0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) cnt += v[((size_t)(x0 + a) * p.Y + (y0 + e)) * p.Z + (z0 + f)] ? 1 : 0;
+  return cnt >= 5 ? 1.0f : 0.0f;   // mean of 8 samples, torch.round is half-to-even: 4/8 -> 0
+}
+
+__global__ __launch_bounds__(256) void fcos_scores_kernel(const FcosP p, float *keys) {
+  const size_t total = (size_t)p.B * p.n;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / p.n), i = (int)(idx % p.n);
+    const float *row = p.head_out + idx * p.CH;
+    const float ctr = sigmoid_ref(row[0]);
+    const float vf = fcos_valid(p, b, i);
+    float m = -1.0f;
+    for (int c = 0; c < p.ncls; ++c) {
+      const float s = (sigmoid_ref(row[1 + p.R + c]) * ctr) * vf;
+      m = s > m ? s : m;
+    }
+    keys[idx] = m;
+  }
+}
+
+__global__ __launch_bounds__(64) void fcos_decode_kernel(const FcosP p, const int *topk_idx, float *cand_boxes, float *cand_scores) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= p.k) return;
+  const int i = topk_idx[(size_t)b * p.kpad + j];
+  float *ob = cand_boxes + ((size_t)b * p.k + j) * p.R;
+  float *os = cand_scores + ((size_t)b * p.k + j) * p.ncls;
+  if (i < 0) {
+    for (int q = 0; q < p.R; ++q) ob[q] = 0.f;
+    for (int c = 0; c < p.ncls; ++c) os[c] = 0.f;
+    return;
+  }
+  const int iz = i % p.nz;
+  const int t = i / p.nz;
+  const int iy = t % p.ny, ix = t / p.ny;
+  const float *vs = p.vs + b * 3, *no = p.new_origin + b * 3;
+  const float px = (float)ix * vs[0] + no[0], py = (float)iy * vs[1] + no[1], pz = (float)iz * vs[2] + no[2];
+  const float *row = p.head_out + ((size_t)b * p.n + i) * p.CH;
+  float d[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) d[q] = expf(row[1 + q] * p.scale);
+  if (p.R == 6) {   // ScanNet: axis-aligned corners (imvoxel_head_v2.py:547-555)
+    ob[0] = px - d[0]; ob[1] = py - d[2]; ob[2] = pz - d[4];
+    ob[3] = px + d[1]; ob[4] = py + d[3]; ob[5] = pz + d[5];
+  } else {          // SUN RGB-D: rotated box (imvoxel_head_v2.py:419-438, rotation_3d_in_axis(axis=2))
+    const float alpha = row[1 + 6];
+    const float sx = (d[1] - d[0]) / 2, sy = (d[3] - d[2]) / 2, sz = (d[5] - d[4]) / 2;
+    const float c = cosf(alpha), s = sinf(alpha);
+    ob[0] = px + (sx * c + sy * s);
+    ob[1] = py + (-sx * s + sy * c);
+    ob[2] = pz + sz;
+    ob[3] = d[0] + d[1]; ob[4] = d[2] + d[3]; ob[5] = d[4] + d[5];
+    ob[6] = alpha;
+  }
+  const float ctr = sigmoid_ref(row[0]);
+  const float vf = fcos_valid(p, b, i);
+  for (int c = 0; c < p.ncls; ++c) os[c] = (sigmoid_ref(row[1 + p.R + c]) * ctr) * vf;
+}
+
+extern "C" int64_t ivx_fcos_head_workspace_bytes(int32_t B, int32_t n, int32_t nms_pre) {
+  if (B <= 0 || n <= 0) return -1;
+  const int k = (nms_pre > 0 && nms_pre < n) ? nms_pre : n;
+  if (k > 4096) return -1;
+  const int kpad = next_pow2(k < 64 ? 64 : k);
+  return ivx_align_up((int64_t)B * n * 4, 256) + ivx_align_up((int64_t)B * kpad * 4, 256) + 2 * 256;
+}
+
+extern "C" int ivx_fcos_head_level_candidates(const float *head_out, const uint8_t *valid0, const float *level_vs,
+                                              const float *level_new_origin, float scale, int32_t B, int32_t nx, int32_t ny,
+                                              int32_t nz, int32_t CH, int32_t n_classes, int32_t n_reg, int32_t level, int32_t X,
+                                              int32_t Y, int32_t Z, int32_t nms_pre, void *workspace, int64_t workspace_bytes,
+                                              float *cand_boxes, float *cand_scores, int32_t *cand_count, ivx_stream_t stream) {
+  IVX_REQUIRE(head_out && valid0 && level_vs && level_new_origin && workspace && cand_boxes && cand_scores && cand_count,
+              "ivx_fcos_head_level_candidates: null argument");
+  IVX_REQUIRE(B > 0 && nx > 0 && ny > 0 && nz > 0 && n_classes > 0 && (n_reg == 6 || n_reg == 7) && CH >= 1 + n_reg + n_classes,
+              "ivx_fcos_head_level_candidates: bad dims");
+  IVX_REQUIRE(level >= 0 && level < 8 && (nx << level) == X && (ny << level) == Y && (nz << level) == Z,
+              "ivx_fcos_head_level_candidates: level grid must be the level-0 grid / 2^level");
+  const int64_t n64 = (int64_t)nx * ny * nz;
+  IVX_REQUIRE(n64 < (1LL << 31), "ivx_fcos_head_level_candidates: grid too large");
+  const int n = (int)n64;
+  const int k = (nms_pre > 0 && nms_pre < n) ? nms_pre : n;
+  IVX_REQUIRE(k <= 4096, "ivx_fcos_head_level_candidates: at most 4096 candidates per level (got %d)", k);
+  const int64_t need = ivx_fcos_head_workspace_bytes(B, n, nms_pre);
+  if (workspace_bytes < need) {
+    ivx_set_error("ivx_fcos_head_level_candidates: workspace too small");
+    return IVX_ERR_WORKSPACE;
+  }
+  IVX_REQUIRE(((uintptr_t)workspace & 255) == 0, "ivx_fcos_head_level_candidates: workspace must be 256-byte aligned");
+  FcosP p;
+  p.head_out = head_out; p.valid0 = valid0; p.vs = level_vs; p.new_origin = level_new_origin; p.scale = scale;
+  p.B = B; p.nx = nx; p.ny = ny; p.nz = nz; p.n = n; p.CH = CH; p.ncls = n_classes; p.R = n_reg; p.level = level;
+  p.X = X; p.Y = Y; p.Z = Z; p.k = k; p.kpad = next_pow2(k < 64 ? 64 : k);
+  char *ws = (char *)workspace;
+  float *keys = (float *)ws;
+  int *topk = (int *)(ws + ivx_align_up((int64_t)B * n * 4, 256));
+  int *n1 = (int *)(ws + ivx_align_up((int64_t)B * n * 4, 256) + ivx_align_up((int64_t)B * p.kpad * 4, 256));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = (size_t)B * n;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fcos_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, keys);
+  HeadP hp = {};
+  hp.n = n; hp.nms_pre = nms_pre; hp.kpad = p.kpad; hp.score_thr = 0.f; hp.B = B;
+  hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(1024), (size_t)p.kpad * 8, st, hp, keys, topk, cand_count, n1);
+  hipLaunchKernelGGL(fcos_decode_kernel, dim3((k + 63) / 64, B), dim3(64), 0, st, p, topk, cand_boxes, cand_scores);
+  IVX_CHECK_LAUNCH("ivx_fcos_head_level_candidates");
+  return IVX_OK;
+}

@@ -34,6 +34,10 @@ struct ConvParams {
   int M, K;
   int relu, res_mode, rH, rW;
   int kmode;  // 0: k = tap*Cin + ci   1: k = (ci/32)*taps*32 + tap*32 + ci%32
+  int out_mode;       // 1: ConvTranspose(k2,s2) scatter: column n = tap*Cr + co goes to output voxel 2*(d,h,w) + tap
+  int Cr;             // real output channels (Cout / 8 when out_mode == 1, else Cout)
+  int res_after_act;  // add the residual after the activation (skip connections of the U-shaped necks)
+  float post_scale;   // final multiplier (Atlas neck (x + y) / 2); 1 = none
 };
 
 #define IVX_BK 32
@@ -53,19 +57,48 @@ __device__ __noinline__ size_t res2_row_base(int m, int Ho, int Wo, int rH, int 
   return (((size_t)b * rH + sh_) * rW + sw_) * Cout;
 }
 
+// y = act(acc*scale + shift [+ res]) [+ res] [* post_scale] for one output element; `oidx` is its flat offset.
+__device__ __forceinline__ float conv_finish(const ConvParams &p, float acc, float sc, float sf, size_t ridx) {
+  float v = acc * sc + sf;
+  if (p.res_mode && !p.res_after_act) v += p.res[ridx];
+  if (p.relu) v = v > 0.f ? v : 0.f;
+  if (p.res_mode && p.res_after_act) v += p.res[ridx];
+  return v * p.post_scale;
+}
+
+// Flat output offset of (row m, column n) for out_mode 1 (ConvTranspose3d kernel 2, stride 2): row m is the INPUT
+// voxel (b,d,h,w) (the GEMM is a 1x1x1 conv), column n = ((a*2+e)*2+f)*Cr + co.
+__device__ __noinline__ size_t up2_row_base(int m, int D, int H, int W, int Cr) {
+  const int w = m % W;
+  int t = m / W;
+  const int h = t % H;
+  t /= H;
+  const int d = t % D;
+  const int b = t / D;
+  return ((((size_t)b * 2 * D + 2 * d) * 2 * H + 2 * h) * 2 * W + 2 * w) * Cr;
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
                                               int lane) {
-  // ---- epilogue -------------------------------------------------------------------------------
   const int col_l = lane & 31, hh = lane >> 5;
   float sc[TN], sf[TN];
   int nn[TN];
+  size_t coff[TN];  // out_mode 1: per-column offset inside the 2x2x2 output cell
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     nn[j] = n0 + (wc * TN + j) * 32 + col_l;
     const bool nok = nn[j] < p.Cout;
-    sc[j] = (nok && p.scale) ? p.scale[nn[j]] : 1.0f;
-    sf[j] = (nok && p.shift) ? p.shift[nn[j]] : 0.0f;
+    int ch = nn[j];
+    coff[j] = 0;
+    if (p.out_mode == 1 && nok) {
+      const int tap = nn[j] / p.Cr;
+      ch = nn[j] - tap * p.Cr;
+      const int a = tap >> 2, e = (tap >> 1) & 1, f = tap & 1;
+      coff[j] = (((size_t)a * 2 * p.H + e) * 2 * p.W + f) * p.Cr + ch;
+    }
+    sc[j] = (nok && p.scale) ? p.scale[ch] : 1.0f;
+    sf[j] = (nok && p.shift) ? p.shift[ch] : 0.0f;
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -73,15 +106,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
       if (m >= p.M) continue;
+      if (p.out_mode == 1) {
+        const size_t ob = up2_row_base(m, p.D, p.H, p.W, p.Cr);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (nn[j] >= p.Cout) continue;
+          p.out[ob + coff[j]] = conv_finish(p, acc[i][j][r], sc[j], sf[j], ob + coff[j]);
+        }
+        continue;
+      }
       size_t rbase = (size_t)m * p.Cout;
       if (p.res_mode == 2) rbase = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (nn[j] >= p.Cout) continue;
-        float v = acc[i][j][r] * sc[j] + sf[j];
-        if (p.res_mode) v += p.res[rbase + nn[j]];
-        if (p.relu) v = v > 0.f ? v : 0.f;
-        p.out[(size_t)m * p.Cout + nn[j]] = v;
+        p.out[(size_t)m * p.Cout + nn[j]] = conv_finish(p, acc[i][j][r], sc[j], sf[j], rbase + nn[j]);
       }
     }
   }
@@ -487,14 +526,16 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
         }
       }
     }
-    float v = acc * (p.scale ? p.scale[n] : 1.0f) + (p.shift ? p.shift[n] : 0.0f);
-    if (p.res_mode == 1) {
-      v += p.res[(size_t)m * p.Cout + n];
-    } else if (p.res_mode == 2) {
-      v += p.res[res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + n];
+    if (p.out_mode == 1) {
+      const int tap = n / p.Cr, ch = n - tap * p.Cr;
+      const int a2 = tap >> 2, e2 = (tap >> 1) & 1, f2 = tap & 1;
+      const size_t o = up2_row_base(m, p.D, p.H, p.W, p.Cr) + (((size_t)a2 * 2 * p.H + e2) * 2 * p.W + f2) * p.Cr + ch;
+      p.out[o] = conv_finish(p, acc, p.scale ? p.scale[ch] : 1.0f, p.shift ? p.shift[ch] : 0.0f, o);
+      continue;
     }
-    if (p.relu) v = v > 0.f ? v : 0.f;
-    p.out[idx] = v;
+    size_t ridx = idx;
+    if (p.res_mode == 2) ridx = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + n;
+    p.out[idx] = conv_finish(p, acc, p.scale ? p.scale[n] : 1.0f, p.shift ? p.shift[n] : 0.0f, ridx);
   }
 }
 
@@ -512,6 +553,9 @@ static int fill_params(const ivx_conv_desc *d, const float *in, const float *wgt
   IVX_REQUIRE(M < (1LL << 31) - 512 && K < (1LL << 30), "ivx_conv_fwd: problem too large for 32-bit row index");
   IVX_REQUIRE((int64_t)d->B * d->D * d->H * d->W < (1LL << 31), "ivx_conv_fwd: input voxel count exceeds 2^31");
   IVX_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2, "ivx_conv_fwd: bad res_mode");
+  IVX_REQUIRE(d->out_mode == 0 || (d->out_mode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 1 && d->sd == 1 && d->sh == 1 && d->sw == 1 &&
+                                     d->pd == 0 && d->ph == 0 && d->pw == 0 && d->Cout % 8 == 0 && d->res_mode != 2),
+              "ivx_conv_fwd: out_mode 1 (ConvTranspose k2 s2) needs a 1x1x1 stride-1 GEMM with Cout = 8 * real channels");
   IVX_REQUIRE(d->wgt_layout == 0 || (d->wgt_layout == 1 && d->Cin % 32 == 0), "ivx_conv_fwd: wgt_layout 1 needs Cin %% 32 == 0");
   IVX_REQUIRE(d->res_mode == 0 || res, "ivx_conv_fwd: res_mode set but res is NULL");
   if (d->res_mode == 2) {
@@ -523,6 +567,8 @@ static int fill_params(const ivx_conv_desc *d, const float *in, const float *wgt
   p->sd = d->sd; p->sh = d->sh; p->sw = d->sw; p->pd = d->pd; p->ph = d->ph; p->pw = d->pw;
   p->Do = Do; p->Ho = Ho; p->Wo = Wo; p->M = (int)M; p->K = (int)K;
   p->relu = d->relu; p->res_mode = d->res_mode; p->rH = d->res_h; p->rW = d->res_w; p->kmode = d->wgt_layout;
+  p->out_mode = d->out_mode; p->Cr = d->out_mode == 1 ? d->Cout / 8 : d->Cout; p->res_after_act = d->res_after_act;
+  p->post_scale = d->post_scale == 0.f ? 1.0f : d->post_scale;
   return IVX_OK;
 }
 

@@ -14,6 +14,7 @@ from torch import nn
 
 from . import ops
 from .boxes import bbox3d2result
+from .heads import Anchor3DHead
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
@@ -107,6 +108,7 @@ class ImVoxelNet(nn.Module):
         return ops.backproject_mean(p0, proj, new_origin, crop, self.voxel_size, self.n_voxels)
 
     def detect_cl(self, volume, img_metas, want_candidates=False):
+        """Anchor-head configs (KITTI / nuScenes): raw device tensors (boxes, scores, labels, count)."""
         y = self.neck_3d.forward_cl(volume)                      # [B,X',Y',1,C]
         h = self.bbox_head.forward_cl(y)                         # [B,X',Y',1,CH]
         # the reference transposes to [B,C,Y',X'] (necks/imvoxelnet.py:120): H = Y', W = X'
@@ -119,14 +121,24 @@ class ImVoxelNet(nn.Module):
         p0 = self.features_2d_cl(img)
         volume, valid = self.lift_cl(p0, img_metas)
         y = self.neck_3d.forward_cl(volume)
+        if isinstance(y, (list, tuple)):                      # indoor necks: multi-level [B,C,X,Y,Z]
+            return [ops.from_channels_last(t, 3) for t in y], valid.unsqueeze(1), None
         out = ops.from_channels_last(y, 3)
         return [out[..., 0].transpose(-1, -2)], valid.unsqueeze(1), None
 
+    def detect_indoor_cl(self, volume, valid, img_metas):
+        """Anchor-free indoor configs (SUN RGB-D / ScanNet): list of (boxes object, scores, labels)."""
+        levels = self.neck_3d.forward_cl(volume)
+        return self.bbox_head.get_bboxes_cl(self.bbox_head.forward_cl(levels), valid, img_metas)
+
     def simple_test(self, img, img_metas):
         p0 = self.features_2d_cl(img)
-        volume, _ = self.lift_cl(p0, img_metas)
-        boxes, scores, labels, count = self.detect_cl(volume, img_metas)
-        dets = self.bbox_head._wrap(boxes, scores, labels, count, img_metas)
+        volume, valid = self.lift_cl(p0, img_metas)
+        if isinstance(self.bbox_head, Anchor3DHead):
+            boxes, scores, labels, count = self.detect_cl(volume, img_metas)
+            dets = self.bbox_head._wrap(boxes, scores, labels, count, img_metas)
+        else:
+            dets = self.detect_indoor_cl(volume, valid, img_metas)
         return [bbox3d2result(b, s, l) for b, s, l in dets]
 
     def forward_test(self, img, img_metas, **kwargs):

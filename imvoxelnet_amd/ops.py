@@ -63,7 +63,7 @@ def from_channels_last(x, ndim_spatial=3):
 
 # ------------------------------------------------------------------ conv
 def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0), relu=False,
-             res=None, res_mode=0, naive=False, out=None, wgt_layout=0):
+             res=None, res_mode=0, naive=False, out=None, wgt_layout=0, out_mode=0, res_after_act=False, post_scale=1.0):
     """x [B,D,H,W,Cin], wgt [Cout,KD,KH,KW,Cin] (packed), scale/shift [Cout] -> [B,Do,Ho,Wo,Cout]."""
     _chk(x, 'x')
     _chk(wgt, 'wgt')
@@ -73,15 +73,18 @@ def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1),
     if tuple(wgt.shape[1:]) != want:
         raise ValueError(f'weight shape {tuple(wgt.shape)} does not match kernel {kernel} / Cin {Cin} / layout {wgt_layout}')
     d = ConvDesc(B, D, H, W, Cin, Cout, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
-                 padding[0], padding[1], padding[2], int(bool(relu)), 0, 0, 0, int(wgt_layout))
+                 padding[0], padding[1], padding[2], int(bool(relu)), 0, 0, 0, int(wgt_layout), int(out_mode), int(bool(res_after_act)), float(post_scale))
     do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
     L = _lib.lib()
     check(L.ivx_conv_out_dims(C.byref(d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')
+    oshape = (B, do.value, ho.value, wo.value, Cout)
+    if out_mode == 1:
+        oshape = (B, 2 * D, 2 * H, 2 * W, Cout // 8)
     if res is not None:
         _chk(res, 'res')
         if res_mode == 0:
             res_mode = 1
-        if res_mode == 1 and tuple(res.shape) != (B, do.value, ho.value, wo.value, Cout):
+        if res_mode == 1 and tuple(res.shape) != oshape:
             raise ValueError(f'residual shape {tuple(res.shape)} != output shape')
         if res_mode == 2:
             if res.shape[0] != B or res.shape[1] != 1 or res.shape[4] != Cout:
@@ -91,10 +94,10 @@ def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1),
     for t, n in ((scale, 'scale'), (shift, 'shift')):
         if t is not None:
             _chk(t, n)
-            if t.numel() != Cout:
-                raise ValueError(f'{n} must have Cout elements')
+            if t.numel() != oshape[-1]:
+                raise ValueError(f'{n} must have {oshape[-1]} elements')
     if out is None:
-        out = torch.empty((B, do.value, ho.value, wo.value, Cout), device=x.device, dtype=torch.float32)
+        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
     else:
         _chk(out, 'out')
     fn = L.ivx_conv_fwd_naive if naive else L.ivx_conv_fwd
@@ -110,6 +113,14 @@ def maxpool2d(x, k=3, s=2, p=1):
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     out = torch.empty((B, 1, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
     check(_lib.lib().ivx_maxpool2d_fwd(_ptr(x), B, H, W, Cn, k, s, p, _ptr(out), _stream()), 'ivx_maxpool2d_fwd')
+    return out
+
+
+def upsample_trilinear2x(x):
+    _chk(x, 'x')
+    B, D, H, W, Cn = x.shape
+    out = torch.empty((B, 2 * D, 2 * H, 2 * W, Cn), device=x.device, dtype=torch.float32)
+    check(_lib.lib().ivx_upsample_trilinear2x_fwd(_ptr(x), B, D, H, W, Cn, _ptr(out), _stream()), 'ivx_upsample_trilinear2x_fwd')
     return out
 
 

@@ -58,6 +58,7 @@ const char *ivx_last_error(void);
  *       Layout 1 walks all taps of one 32-channel chunk back to back, so the 27 shifted re-reads of an input row
  *       are one K-slab apart and hit L1/L2 instead of going back to the fabric.
  * scale,shift [Cout] or NULL (1 / 0).  Conv bias and BN fold into them on the host.
+ * Epilogue order: v = acc*scale + shift; [v += res]; [ReLU]; [v += res if res_after_act]; v *= post_scale.
  * res   NULL, or res_mode 1: same shape as out; res_mode 2: [B,1,res_h,res_w,Cout] read with
  *       nearest-neighbour up-sampling to (Ho,Wo) (FPN top-down path, F.interpolate 'nearest').
  * Arithmetic: fp32 inputs, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.            */
@@ -69,6 +70,11 @@ typedef struct ivx_conv_desc {
   int32_t relu;
   int32_t res_mode, res_h, res_w;
   int32_t wgt_layout;
+  int32_t out_mode;      /* 0: normal.  1: nn.ConvTranspose3d(kernel 2, stride 2) as a 1x1x1 GEMM with
+                            Cout = 8*C columns n = ((a*2+e)*2+f)*C + co, scattered to out[b, 2d+a, 2h+e, 2w+f, co]
+                            (out is [B,2D,2H,2W,C]; scale/shift have C entries; res, if any, has the out shape) */
+  int32_t res_after_act; /* 1: the residual is added after the ReLU (skip adds of the U-shaped necks) */
+  float post_scale;      /* final multiplier, 0 or 1 = none (Atlas neck: (x + y) / 2) */
 } ivx_conv_desc;
 
 int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *Ho, int32_t *Wo);
@@ -85,6 +91,11 @@ int ivx_conv_set_tile_override(int cfg);
 /* nn.MaxPool2d(kernel, stride, padding) on NHWC (ResNet stem: 3, 2, 1). */
 int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
                       int32_t s, int32_t p, float *out, ivx_stream_t stream);
+
+/* F.interpolate(scale_factor=2, mode='trilinear', align_corners=False) on NDHWC [B,D,H,W,C] -> [B,2D,2H,2W,C]
+ * (Atlas decoder of ImVoxelNeck, mmdet3d/models/necks/imvoxelnet.py:359).  C % 4 == 0. */
+int ivx_upsample_trilinear2x_fwd(const float *in, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, float *out,
+                                 ivx_stream_t stream);
 
 /* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] (channels >= C zero filled), and NHWC/NDHWC -> NCHW/NCDHW
  * ([B,S,C] -> [B,C,S] with S = product of the spatial dims). */
@@ -148,6 +159,26 @@ int ivx_anchor_head_get_bboxes(const ivx_anchor_head_desc *d, const float *head_
                                float *out_scores, int64_t *out_labels, int32_t *out_count,
                                int64_t *cand_idx, float *cand_boxes, float *cand_scores,
                                ivx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Indoor (anchor-free) head tail, one feature level -- replaces the per-level body of
+ * ImVoxelHeadV2._get_bboxes_single (mmdet3d/models/dense_heads/imvoxel_head_v2.py:245-277 with :224-226, :206-214,
+ * ScanNet decode :547-555 / SUN RGB-D decode :419-438 and the exp(Scale(.)) of forward_single :305-313, :444-449):
+ * valid mask resized to the level (trilinear + round == ">= 5 of the 8 contributing level-0 voxels"), scores =
+ * sigmoid(cls) * sigmoid(centerness) * valid, top-k(nms_pre) by class maximum, level points, distance decoding.
+ *
+ * head_out [B, nx, ny, nz, CH]  fused 3x3x3 head conv: channel 0 centerness, 1..n_reg raw regression, then classes
+ * valid0   [B, X, Y, Z] u8      level-0 mask from ivx_backproject_mean_fwd; (nx,ny,nz) * 2^level == (X,Y,Z)
+ * level_vs, level_new_origin [B,3]  voxel_size * 2^level and origin - n_level/2 * that (host-built fp32, as get_points)
+ * n_reg 6: boxes are corners (x1,y1,z1,x2,y2,z2); n_reg 7: (cx,cy,cz,w,l,h,alpha)
+ * cand_boxes [B, k, n_reg], cand_scores [B, k, n_classes], cand_count [B] with k = min(nms_pre, nx*ny*nz) <= 4096,
+ * candidates in descending class-maximum score.  The (cross-level) NMS is ivx_aligned_3d_nms / ivx_nms_bev.     */
+int64_t ivx_fcos_head_workspace_bytes(int32_t B, int32_t n, int32_t nms_pre);
+int ivx_fcos_head_level_candidates(const float *head_out, const uint8_t *valid0, const float *level_vs,
+                                   const float *level_new_origin, float scale, int32_t B, int32_t nx, int32_t ny,
+                                   int32_t nz, int32_t CH, int32_t n_classes, int32_t n_reg, int32_t level, int32_t X,
+                                   int32_t Y, int32_t Z, int32_t nms_pre, void *workspace, int64_t workspace_bytes,
+                                   float *cand_boxes, float *cand_scores, int32_t *cand_count, ivx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * BEV NMS -- device-side replacement of iou3d_cuda.nms_gpu / nms_normal_gpu

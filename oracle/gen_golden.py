@@ -449,6 +449,66 @@ def gen_e2e_small(ns):
     np.savez_compressed(os.path.join(GOLD, 'e2e_small.npz'), **out)
 
 
+def gen_indoor_heads(ns):
+    """ImVoxelHeadV2 (ScanNet, SUN RGB-D) and V1 (ScanNet with a 1-conv tower): forward + get_bboxes through the
+    real reference classes.  SUN RGB-D uses rotated NMS -> the C restatement is injected (see nms_source)."""
+    class Cfg(dict):
+        __getattr__ = dict.get
+    ns.nms.nms_gpu = orc.nms_gpu
+    ns.nms.nms_normal_gpu = orc.nms_normal_gpu
+    ns.head_v2.box3d_multiclass_nms = ns.nms.box3d_multiclass_nms
+    out = {}
+    cases = {
+        'scannet_v2': (ns.head_v2.ScanNetImVoxelHeadV2, dict(n_classes=5, n_channels=8, n_reg_outs=6, n_scales=3, limit=27, centerness_topk=18),
+                       dict(nms_pre=40, iou_thr=.25, score_thr=.01), 6),
+        'sunrgbd_v2': (ns.head_v2.SunRgbdImVoxelHeadV2, dict(n_classes=4, n_channels=8, n_reg_outs=7, n_scales=3, limit=27, centerness_topk=18),
+                       dict(nms_pre=40, nms_thr=.15, use_rotate_nms=True, score_thr=.0), 7),
+        'scannet_v1': (ns.head_v1.ScanNetImVoxelHead, dict(n_classes=5, n_channels=8, n_convs=1, n_reg_outs=6),
+                       dict(nms_pre=40, iou_thr=.15, score_thr=.01), 6),
+    }
+    for name, (cls, kw, tcfg, R) in cases.items():
+        torch.manual_seed({'scannet_v2': 60, 'sunrgbd_v2': 61, 'scannet_v1': 62}[name])
+        head = cls(train_cfg=None, test_cfg=Cfg(tcfg), **kw)
+        head.voxel_size = (.16, .16, .16)
+        g = torch.Generator().manual_seed(63)
+        randomize_bn(head, g)
+        with torch.no_grad():
+            head.centerness_conv.weight.normal_(0, 0.2)
+            head.reg_conv.weight.normal_(0, 0.05)
+            head.cls_conv.weight.normal_(0, 0.2)
+            head.cls_conv.bias.fill_(-0.5)
+            for i, sc in enumerate(head.scales):
+                sc.scale.fill_(1.0 + 0.25 * i)
+        head.eval()
+        B = 2
+        xs = [torch.randn(B, 8, 8 >> l, 8 >> l, 4 >> l, generator=g) for l in range(3)]
+        valid = (torch.rand(B, 1, 8, 8, 4, generator=g) > 0.35).float()
+        box_t = ns.depth.DepthInstance3DBoxes
+        metas = [dict(box_type_3d=box_t, lidar2img=dict(origin=np.array([0.1 * b, 3.0, -1.0 + 0.5 * b], np.float32))) for b in range(B)]
+        with torch.no_grad():
+            cs, bs, ss = head(xs)
+            res = head.get_bboxes(cs, bs, ss, valid, metas)
+        pre = name + '::'
+        out.update(sd_to_np(head.state_dict(), pre + 'sd::'))
+        out[pre + 'valid'] = valid.numpy()
+        out[pre + 'test_cfg'] = np.array(json.dumps(tcfg))
+        out[pre + 'kw'] = np.array(json.dumps(kw))
+        for l in range(3):
+            out[pre + f'x{l}'] = xs[l].numpy()
+            out[pre + f'centerness{l}'] = cs[l].numpy()
+            out[pre + f'bbox_pred{l}'] = bs[l].numpy()
+            out[pre + f'cls{l}'] = ss[l].numpy()
+        for b in range(B):
+            out[pre + f'origin{b}'] = metas[b]['lidar2img']['origin']
+            boxes, scores, labels = res[b]
+            out[pre + f'boxes{b}'] = boxes.tensor.numpy()
+            out[pre + f'scores{b}'] = scores.numpy()
+            out[pre + f'labels{b}'] = labels.numpy()
+            print('indoor head', name, b, 'kept', len(scores))
+        out[pre + 'nms_source'] = np.array('reference aligned_3d_nms' if R == 6 else 'oracle/ivx_oracle.c rotated NMS')
+    np.savez_compressed(os.path.join(GOLD, 'indoor_heads.npz'), **out)
+
+
 def main():
     ns = ref_import.load()
     gen_backproject(ns)
@@ -458,6 +518,7 @@ def main():
     gen_nms_vectors(ns)
     gen_anchor_head(ns)
     gen_e2e_small(ns)
+    gen_indoor_heads(ns)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

@@ -422,3 +422,73 @@ def _bn_params(gen, sd, p, c):
     sd[p + '.bias'] = torch.randn(c, generator=gen) * 0.1
     sd[p + '.running_mean'] = torch.randn(c, generator=gen) * 0.1
     sd[p + '.running_var'] = torch.rand(c, generator=gen) + 0.5
+
+
+# --------------------------------------------------------------------------
+# anchor-free indoor heads (dense_heads/imvoxel_head_v2.py, imvoxel_head.py)
+def fcos_head_forward(xs, sd, n_reg, n_convs=0, prefix=''):
+    """forward / forward_single (v2:57-58,305-313,444-449; v1:78-79,326-336,454-461): per level
+    (centerness, exp(scale*reg[:6]) [+ raw angle], cls)."""
+    cs, bs, ss = [], [], []
+    for lvl, x in enumerate(xs):
+        r, c = x, x
+        for i in range(n_convs):
+            r = F.relu(bn_eval(F.conv3d(r, sd[f'{prefix}reg_convs.{i}.0.weight'], None, 1, 1), sd, f'{prefix}reg_convs.{i}.1'))
+            c = F.relu(bn_eval(F.conv3d(c, sd[f'{prefix}cls_convs.{i}.0.weight'], None, 1, 1), sd, f'{prefix}cls_convs.{i}.1'))
+        reg = F.conv3d(r, sd[prefix + 'reg_conv.weight'], None, 1, 1)
+        d = torch.exp(reg[:, :6] * sd[f'{prefix}scales.{lvl}.scale'])
+        cs.append(F.conv3d(r, sd[prefix + 'centerness_conv.weight'], None, 1, 1))
+        bs.append(d if n_reg == 6 else torch.cat((d, reg[:, 6:7]), dim=1))
+        ss.append(F.conv3d(c, sd[prefix + 'cls_conv.weight'], sd[prefix + 'cls_conv.bias'], 1, 1))
+    return cs, bs, ss
+
+
+def fcos_get_bboxes_single(cs, bs, ss, valid, origin, voxel_size, n_reg, cfg):
+    """get_bboxes + _get_bboxes_single for ONE sample (v2:216-285): cs/bs/ss are per-level [C,nx,ny,nz] tensors,
+    valid [1,X,Y,Z] float.  Returns (boxes [n, 7], scores, labels) with the box tensor as the box object holds it."""
+    n_classes = ss[0].shape[0]
+    mb, ms = [], []
+    for lvl, (c, b, s) in enumerate(zip(cs, bs, ss)):
+        shape = c.shape[-3:]
+        v = F.interpolate(valid[None], size=tuple(shape), mode='trilinear', align_corners=False)[0].round().bool()
+        pts = torch.from_numpy(get_points(list(shape), np.asarray(voxel_size, np.float32) * np.float32(2 ** lvl), origin))
+        pts = pts.reshape(3, -1).transpose(0, 1)
+        ctr = c.permute(1, 2, 3, 0).reshape(-1).sigmoid()
+        bp = b.permute(1, 2, 3, 0).reshape(-1, n_reg)
+        sc = s.permute(1, 2, 3, 0).reshape(-1, n_classes).sigmoid()
+        vf = v.permute(1, 2, 3, 0).reshape(-1)
+        sc = sc * ctr[:, None] * vf[:, None]
+        mx, _ = sc.max(dim=1)
+        if len(sc) > cfg['nms_pre'] > 0:
+            _, ids = mx.topk(cfg['nms_pre'])
+            bp, sc, pts = bp[ids], sc[ids], pts[ids]
+        if n_reg == 6:      # ScanNet (v2:547-555)
+            box = torch.stack([pts[:, 0] - bp[:, 0], pts[:, 1] - bp[:, 2], pts[:, 2] - bp[:, 4],
+                               pts[:, 0] + bp[:, 1], pts[:, 1] + bp[:, 3], pts[:, 2] + bp[:, 5]], -1)
+        else:               # SUN RGB-D (v2:419-438)
+            shift = torch.stack(((bp[:, 1] - bp[:, 0]) / 2, (bp[:, 3] - bp[:, 2]) / 2, (bp[:, 5] - bp[:, 4]) / 2), dim=-1).view(-1, 1, 3)
+            shift = rotation_3d_in_axis_z(shift, bp[:, 6])[:, 0, :]
+            size = torch.stack((bp[:, 0] + bp[:, 1], bp[:, 2] + bp[:, 3], bp[:, 4] + bp[:, 5]), dim=-1)
+            box = torch.cat((pts + shift, size, bp[:, 6:7]), dim=-1)
+        mb.append(box)
+        ms.append(sc)
+    boxes, scores = torch.cat(mb), torch.cat(ms)
+    if n_reg == 6:          # ScanNet _nms (v2:528-545)
+        scores, labels = scores.max(dim=1)
+        ids = scores > cfg['score_thr']
+        boxes, scores, labels = boxes[ids], scores[ids], labels[ids]
+        ids = aligned_3d_nms(boxes, scores, labels, cfg['iou_thr'])
+        boxes = boxes[ids]
+        boxes = torch.stack(((boxes[:, 0] + boxes[:, 3]) / 2., (boxes[:, 1] + boxes[:, 4]) / 2., (boxes[:, 2] + boxes[:, 5]) / 2.,
+                             boxes[:, 3] - boxes[:, 0], boxes[:, 4] - boxes[:, 1], boxes[:, 5] - boxes[:, 2]), dim=1)
+        boxes = torch.cat((boxes, boxes.new_zeros(boxes.shape[0], 1)), dim=-1)       # box_dim 6 -> fake yaw (base_box3d.py:52-58)
+        scores, labels = scores[ids], labels[ids]
+    else:                   # SUN RGB-D _nms (v2:397-417)
+        scores_p = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1)
+        for_nms = torch.stack((boxes[:, 0] - boxes[:, 3] / 2, boxes[:, 1] - boxes[:, 4] / 2,
+                               boxes[:, 0] + boxes[:, 3] / 2, boxes[:, 1] + boxes[:, 4] / 2, boxes[:, 6]), dim=1)
+        boxes, scores, labels, _ = box3d_multiclass_nms(boxes, for_nms, scores_p, cfg['score_thr'], cfg['nms_pre'],
+                                                        cfg['use_rotate_nms'], cfg['nms_thr'])
+    boxes = boxes.clone()
+    boxes[:, 2] = boxes[:, 2] - boxes[:, 5] * 0.5                                   # origin (.5,.5,.5) -> (.5,.5,0) (base_box3d.py:63-66)
+    return boxes, scores, labels

@@ -227,18 +227,48 @@ def test_unprojection_multiview_indoor(ia):
     assert np.array_equal(got, ref), f'{(got != ref).sum()} values differ (max {np.abs(got - ref).max()})'
 
 
-@pytest.mark.parametrize('name', ['kitti', 'nuscenes'])
+@pytest.mark.parametrize('name', ['kitti', 'nuscenes', 'fast', 'atlas'])
 def test_neck_golden(ia, name):
-    """HIP 3-D neck vs the imported reference module's output (golden)."""
+    """HIP 3-D necks (all four reference variants) vs the imported reference modules' outputs (golden)."""
     g = load_npz('necks.npz')
     sd = sd_from(g, name + '::sd::')
-    cls = ia.KittiImVoxelNeck if name == 'kitti' else ia.NuScenesImVoxelNeck
-    neck = cls(4, 8)
+    neck = {'kitti': lambda: ia.KittiImVoxelNeck(4, 8), 'nuscenes': lambda: ia.NuScenesImVoxelNeck(4, 8),
+            'fast': lambda: ia.FastIndoorImVoxelNeck(4, [1, 1, 1], 8),
+            'atlas': lambda: ia.ImVoxelNeck([4, 8, 16], 4, [1, 2, 2], [2, 1], False)}[name]()
     missing = neck.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys and all('num_batches_tracked' in k for k in missing.missing_keys), missing
     x = torch.from_numpy(g[name + '::x']).cuda()
-    y = neck(x)[0]
-    assert_close(name + ' neck', y, g[name + '::y0'], 1e-3, 1e-4)
+    ys = neck(x)
+    n_out = len([k for k in g.files if k.startswith(name + '::y')])
+    assert len(ys) == n_out
+    for i, y in enumerate(ys):
+        assert_close(f'{name} neck level {i}', y, g[f'{name}::y{i}'], 1e-3, 1e-4)
+
+
+def test_conv_transpose_and_trilinear(ia):
+    """ConvTranspose3d(k2,s2)+BN+ReLU as a scattered GEMM, residual-after-activation, post-scale, trilinear x2."""
+    from imvoxelnet_amd import ops
+    from imvoxelnet_amd.conv import FusedConv, FusedConvTranspose2x
+    g = torch.Generator().manual_seed(21)
+    for cin, cout in ((8, 4), (64, 32), (36, 20)):
+        x = torch.randn(2, cin, 3, 5, 4, generator=g)
+        w = torch.randn(cin, cout, 2, 2, 2, generator=g) * 0.2
+        bn = (torch.rand(cout, generator=g) + .5, torch.randn(cout, generator=g) * .1, torch.randn(cout, generator=g) * .1,
+              torch.rand(cout, generator=g) + .5)
+        ref = F.relu(F.batch_norm(F.conv_transpose3d(x, w, None, 2), bn[2], bn[3], bn[0], bn[1], False, 0., 1e-5))
+        fc = FusedConvTranspose2x(w, bn=bn, relu=True).to('cuda')
+        assert_close(f'convT {cin}->{cout}', uncl(fc(cl(x))), ref, 1e-4, 1e-4)
+        assert_close(f'convT naive {cin}->{cout}', uncl(fc(cl(x), naive=True)), ref, 1e-4, 1e-4)
+    x = torch.randn(1, 16, 5, 6, 7, generator=g)
+    w = torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1
+    skip = torch.randn(1, 16, 5, 6, 7, generator=g)
+    ref = (F.relu(F.conv3d(x, w, None, 1, 1)) + skip) * 0.5
+    y = FusedConv(w, padding=1, relu=True).to('cuda')(cl(x), res=cl(skip), res_after_act=True, post_scale=0.5)
+    assert_close('res_after_act+post_scale', uncl(y), ref, 1e-4, 1e-4)
+    for shape in ((1, 8, 3, 4, 5), (2, 4, 1, 2, 2), (1, 12, 6, 5, 2)):
+        v = torch.randn(*shape, generator=g)
+        ref = F.interpolate(v, scale_factor=2, mode='trilinear', align_corners=False)
+        assert_close(f'trilinear {shape}', uncl(ops.upsample_trilinear2x(cl(v))), ref, 1e-5, 1e-6)
 
 
 def _head_from_golden(ia, g, p, cfg):
@@ -358,3 +388,104 @@ def test_errors_are_loud(ia):
         ops.conv_fwd(torch.zeros(1, 1, 4, 4, 6, device='cuda'), torch.zeros(4, 1, 1, 1, 6, device='cuda'))  # Cin % 4
     with pytest.raises(ValueError):
         ops.conv_fwd(torch.zeros(1, 1, 2, 2, 4, device='cuda'), torch.zeros(4, 1, 3, 3, 4, device='cuda'), kernel=(1, 3, 3))
+
+
+def _indoor_head(ia, name, kw, cfg):
+    cls = {'scannet_v2': ia.ScanNetImVoxelHeadV2, 'sunrgbd_v2': ia.SunRgbdImVoxelHeadV2, 'scannet_v1': ia.ScanNetImVoxelHead}[name]
+    head = cls(test_cfg=cfg, **kw)
+    head.voxel_size = (.16, .16, .16)
+    return head
+
+
+@pytest.mark.parametrize('name', ['scannet_v2', 'sunrgbd_v2', 'scannet_v1'])
+def test_indoor_head_golden(ia, name):
+    """Anchor-free heads (fused 3x3x3 head conv + device tail + device NMS) vs the reference's forward + get_bboxes."""
+    g = load_npz('indoor_heads.npz')
+    p = name + '::'
+    kw, cfg = json.loads(str(g[p + 'kw'])), json.loads(str(g[p + 'test_cfg']))
+    head = _indoor_head(ia, name, kw, cfg)
+    res = head.load_state_dict(sd_from(g, p + 'sd::'), strict=False)
+    assert not res.unexpected_keys and all('num_batches_tracked' in k for k in res.missing_keys), res
+    xs = [torch.from_numpy(g[p + f'x{l}']).cuda() for l in range(3)]
+    cs, bs, ss = head(xs)
+    for l in range(3):
+        assert_close(f'centerness{l}', cs[l], g[p + f'centerness{l}'], 1e-4, 1e-5)
+        assert_close(f'bbox_pred{l}', bs[l], g[p + f'bbox_pred{l}'], 1e-4, 1e-5)
+        assert_close(f'cls{l}', ss[l], g[p + f'cls{l}'], 1e-4, 1e-5)
+    valid = torch.from_numpy(g[p + 'valid']).cuda()
+    metas = [dict(box_type_3d=ia.DepthInstance3DBoxes, lidar2img=dict(origin=g[p + f'origin{b}'])) for b in range(2)]
+    # (1) fast path: raw fused head output + per-level scale
+    fused = head.forward_cl([gpu_cl(x) for x in xs])
+    out_fast = head.get_bboxes_cl(fused, valid > 0, metas)
+    # (2) reference-signature path fed with the reference's own head outputs
+    out_ref = head.get_bboxes([torch.from_numpy(g[p + f'centerness{l}']).cuda() for l in range(3)],
+                              [torch.from_numpy(g[p + f'bbox_pred{l}']).cuda() for l in range(3)],
+                              [torch.from_numpy(g[p + f'cls{l}']).cuda() for l in range(3)], valid, metas)
+    for tag, out in (('fast', out_fast), ('refsig', out_ref)):
+        for b, (boxes, scores, labels) in enumerate(out):
+            assert len(scores) == len(g[p + f'scores{b}']), f'{tag} sample {b}: kept {len(scores)} vs {len(g[p + f"scores{b}"])}'
+            assert np.array_equal(labels.cpu().numpy(), g[p + f'labels{b}']), f'{tag} labels {b}'
+            assert_close(f'{tag} scores{b}', scores, g[p + f'scores{b}'], 1e-4, 1e-6)
+            assert_close(f'{tag} boxes{b}', boxes.tensor, g[p + f'boxes{b}'], 1e-4, 1e-4)
+
+
+def gpu_cl(x):
+    from imvoxelnet_amd import ops
+    return ops.to_channels_last(x.contiguous())
+
+
+def test_indoor_path_vs_oracle(ia):
+    """ScanNet-fast shaped path from FPN level-0 features (3 views, C=32): unprojection -> FastIndoorImVoxelNeck ->
+    ScanNetImVoxelHeadV2 -> aligned NMS, against the CPU oracle on the same seeded weights."""
+    from oracle import imvoxel_oracle as orc
+    from oracle import c_oracle as co
+    nv, vs = (16, 16, 8), (.16, .16, .16)
+    cfg = dict(nms_pre=100, iou_thr=.25, score_thr=.01)
+    neck = ia.FastIndoorImVoxelNeck(32, [1, 1, 1], 16)
+    head = ia.ScanNetImVoxelHeadV2(n_classes=6, n_channels=16, n_reg_outs=6, n_scales=3, limit=27, test_cfg=cfg)
+    head.voxel_size = vs
+    ia.randomize_(neck, 3)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(4)
+        head.centerness_conv.weight.normal_(0, 0.05, generator=g)
+        head.reg_conv.weight.normal_(0, 0.02, generator=g)
+        head.cls_conv.weight.normal_(0, 0.05, generator=g)
+        head.cls_conv.bias.fill_(-1.0)
+    V, FH, FW = 3, 30, 40
+    feat = torch.randn(V, 32, FH, FW, generator=torch.Generator().manual_seed(5))
+    K = np.array([[36., 0, 20, 0], [0, 36., 15, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    Es = []
+    for i in range(V):
+        a = 2 * np.pi * i / V
+        eye = np.array([2.2 * np.cos(a), 2.2 * np.sin(a), 1.0])
+        f = (np.array([0, 0, .5]) - eye); f /= np.linalg.norm(f)
+        r = np.cross(f, [0, 0, 1.0]); r /= np.linalg.norm(r)
+        d = np.cross(f, r)
+        R = np.stack([r, d, f]); E = np.eye(4); E[:3, :3] = R; E[:3, 3] = -R @ eye
+        Es.append(E.astype(np.float32))
+    meta = dict(img_shape=(FH * 4, FW * 4, 3), ori_shape=(FH * 4, FW * 4, 3), box_type_3d=ia.DepthInstance3DBoxes,
+                lidar2img=dict(intrinsic=K, extrinsic=Es, origin=np.array([0, 0, .5], np.float32)))
+    # oracle
+    vol_ref, ok_ref = orc.extract_volume(feat.numpy(), meta, nv, vs)
+    sdn = {k: v.detach().cpu() for k, v in neck.state_dict().items()}
+    sdh = {k: v.detach().cpu() for k, v in head.state_dict().items()}
+    with torch.no_grad():
+        lv = orc.fast_indoor_neck(torch.from_numpy(vol_ref)[None], sdn)
+        cs, bs, ss = orc.fcos_head_forward(lv, sdh, 6)
+        rb, rs, rl = orc.fcos_get_bboxes_single([c[0] for c in cs], [b[0] for b in bs], [s[0] for s in ss],
+                                                torch.from_numpy(ok_ref).float(), meta['lidar2img']['origin'], vs, 6, cfg)
+    # device
+    det = ia.ImVoxelNet.__new__(ia.ImVoxelNet)
+    torch.nn.Module.__init__(det)
+    det.n_voxels, det.voxel_size, det.neck_3d, det.bbox_head = nv, vs, neck, head
+    vol, valid = det.lift_cl(gpu_cl(feat.cuda()), [meta])
+    assert np.array_equal(valid[0].cpu().numpy(), ok_ref[0])
+    assert np.array_equal(vol[0].permute(3, 0, 1, 2).cpu().numpy(), vol_ref)
+    levels = neck.forward_cl(vol)
+    for l in range(3):
+        assert_close(f'neck level {l}', uncl(levels[l]), lv[l], 1e-3, 1e-4)
+    (boxes, scores, labels), = det.detect_indoor_cl(vol, valid, [meta])
+    print('indoor detections', len(scores), 'oracle', len(rs))
+    assert len(scores) == len(rs) and np.array_equal(labels.cpu().numpy(), rl.numpy())
+    assert_close('scores', scores, rs, 1e-3, 1e-5)
+    assert_close('boxes', boxes.tensor, rb, 1e-3, 1e-3)

@@ -28,7 +28,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) <= declared
     assert L.ivx_version() >= 100
     # struct layouts used by the ctypes binding match the header field counts
-    assert ctypes.sizeof(_lib.ConvDesc) == 20 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 23 * 4
     assert ctypes.sizeof(_lib.AnchorHeadDesc) == 17 * 4
 
 
@@ -36,7 +36,7 @@ def test_cabi_argument_validation_without_gpu():
     """Invalid arguments are rejected with a status + message before any launch (never exit())."""
     from imvoxelnet_amd import _lib
     L = _lib.lib()
-    d = _lib.ConvDesc(1, 1, 8, 8, 6, 4, 1, 3, 3, 1, 1, 1, 0, 1, 1, 0, 0, 0, 0, 0)
+    d = _lib.ConvDesc(1, 1, 8, 8, 6, 4, 1, 3, 3, 1, 1, 1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 1.0)
     dummy = ctypes.c_void_p(64)
     rc = L.ivx_conv_fwd(ctypes.byref(d), dummy, dummy, None, None, None, dummy, None)
     assert rc == -1 and b'multiple of 4' in L.ivx_last_error()

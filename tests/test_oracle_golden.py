@@ -183,3 +183,27 @@ def test_e2e_small_orchestration():
             np.testing.assert_allclose(boxes.numpy(), g[f'res{b}::boxes'], rtol=1e-4, atol=1e-5)
             np.testing.assert_allclose(scores.numpy(), g[f'res{b}::scores'], rtol=1e-5, atol=1e-6)
             assert np.array_equal(labels.numpy(), g[f'res{b}::labels'])
+
+
+@pytest.mark.parametrize('name', ['scannet_v2', 'sunrgbd_v2', 'scannet_v1'])
+def test_indoor_heads(name):
+    g = load_npz('indoor_heads.npz')
+    p = name + '::'
+    sd = sd_from(g, p + 'sd::')
+    kw = json.loads(str(g[p + 'kw']))
+    cfg = json.loads(str(g[p + 'test_cfg']))
+    xs = [torch.from_numpy(g[p + f'x{l}']) for l in range(3)]
+    with torch.no_grad():
+        cs, bs, ss = orc.fcos_head_forward(xs, sd, kw['n_reg_outs'], kw.get('n_convs', 0))
+    for l in range(3):
+        np.testing.assert_allclose(cs[l].numpy(), g[p + f'centerness{l}'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bs[l].numpy(), g[p + f'bbox_pred{l}'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ss[l].numpy(), g[p + f'cls{l}'], rtol=1e-5, atol=1e-6)
+    valid = torch.from_numpy(g[p + 'valid'])
+    for b in range(2):
+        boxes, scores, labels = orc.fcos_get_bboxes_single(
+            [torch.from_numpy(g[p + f'centerness{l}'][b]) for l in range(3)], [torch.from_numpy(g[p + f'bbox_pred{l}'][b]) for l in range(3)],
+            [torch.from_numpy(g[p + f'cls{l}'][b]) for l in range(3)], valid[b], g[p + f'origin{b}'], (.16, .16, .16), kw['n_reg_outs'], cfg)
+        assert np.array_equal(labels.numpy(), g[p + f'labels{b}'])
+        np.testing.assert_allclose(scores.numpy(), g[p + f'scores{b}'], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(boxes.numpy(), g[p + f'boxes{b}'], rtol=1e-5, atol=1e-6)
