@@ -492,6 +492,191 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams
   conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// v4: v2 with LDS-DMA staging (buffer_load_dwordx4 ... offen lds): the operands go global -> LDS without passing
+// through VGPRs, so the slab loop has no ds_write pass and no vmcnt -> ds_write dependency.  The DMA writes
+// wave-uniform base + lane*16 B, so LDS rows are unpadded 128-byte rows and bank conflicts are avoided by an XOR
+// swizzle applied on the SOURCE side (lane with slot c of row r fetches k-chunk c ^ ((r>>1)&7)) and again on the
+// fragment read.
+template <int TM, int TN, int WR, int WC>
+__global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams p, const unsigned in_bytes,
+                                                                  const unsigned w_bytes) {
+  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  constexpr int AR = BM / 32, BR = BN / 32;
+  static_assert(WR * WC == 4, "4 waves per workgroup");
+  // LDS-DMA staging: rows are 32 floats (128 B), unpadded; 16-byte slot c of row r holds k-chunk c ^ ((r>>1)&7)
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * IVX_BK];
+  float *As = smem;
+  float *Bs = smem + 2 * BM * IVX_BK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid / WC, wc = wid % WC;
+
+  // 1-D grid of 8 * ceil(Mt/8) * Nt workgroups.  Workgroup b runs on XCD b % 8 (observed dispatch rule; used for
+  // speed only): XCD x owns the contiguous M-tiles [x*q, (x+1)*q) so halo re-reads of neighbouring x-slabs hit its own
+  // L2, and inside an XCD the Nt workgroups that share one A-tile are consecutive, so they run together and the
+  // A-tile is fetched into that L2 once instead of once per N-tile.  Ids past the last M-tile exit (< 8*Nt of them).
+  int mt, nt;
+  {
+    const int Nt = (p.Cout + BN - 1) / BN;
+    const int q = gridDim.x / (8 * Nt);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    mt = xcd * q + idx / Nt;
+    nt = idx % Nt;
+  }
+  if (mt * BM >= p.M) return;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, w_bytes, 0x00020000);
+
+  const int lr = tid >> 3;
+  const int cc = (tid & 7) ^ ((lr >> 1) & 7);   // the k-chunk this lane fetches (its LDS slot is tid & 7)
+  const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+  int a_off[AR];
+  unsigned a_msk[AR];
+#pragma unroll
+  for (int j = 0; j < AR; ++j) {
+    const int m = m0 + lr + 32 * j;
+    a_off[j] = 0;
+    a_msk[j] = 0;
+    if (m < p.M) {
+      const int ow = m % p.Wo;
+      int t = m / p.Wo;
+      const int oh = t % p.Ho;
+      t /= p.Ho;
+      const int od = t % p.Do;
+      const int b = t / p.Do;
+      const int id0 = od * p.sd - p.pd, ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
+      a_off[j] = (((b * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin;
+      unsigned md = 0, mh = 0, mw = 0;
+      for (int a = 0; a < p.KD; ++a) md |= ((unsigned)(id0 + a) < (unsigned)p.D) ? (1u << a) : 0u;
+      for (int e = 0; e < p.KH; ++e) mh |= ((unsigned)(ih0 + e) < (unsigned)p.H) ? (1u << e) : 0u;
+      for (int f = 0; f < p.KW; ++f) mw |= ((unsigned)(iw0 + f) < (unsigned)p.W) ? (1u << f) : 0u;
+      a_msk[j] = md | (mh << 8) | (mw << 16);
+    }
+  }
+  int b_off[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int n = n0 + lr + 32 * j;
+    b_off[j] = n < p.Cout ? n * p.K : -1;
+  }
+  int k4 = cc * 4;
+  int kc, ka, ke, kf;
+  if (p.kmode == 1) {  // chunk-major: slab s = (channel chunk s / taps, tap s % taps)
+    kc = cc * 4;
+    ka = ke = kf = 0;
+  } else {
+    const int tap = k4 / p.Cin;
+    kc = k4 - tap * p.Cin;
+    kf = tap % p.KW;
+    const int t2 = tap / p.KW;
+    ke = t2 % p.KH;
+    ka = t2 / p.KH;
+  }
+  const int S = (p.K + IVX_BK - 1) / IVX_BK;
+  const unsigned OOB = 0x80000000u;
+
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  auto load_slab = [&](int buf) {
+    // branch-free: a k past K turns the tap mask into all-ones, which no row mask can satisfy
+    const unsigned kbad = (k4 < p.K) ? 0u : 0xffffffffu;
+    const int delta = ((ka * p.H + ke) * p.W + kf) * p.Cin + kc;
+    const unsigned tap = ((1u << ka) | (1u << (8 + ke)) | (1u << (16 + kf))) | kbad;
+    float *Ab = As + buf * BM * IVX_BK + wid_u * 8 * IVX_BK;   // wave-uniform base; the DMA adds lane*16 B
+    float *Bb = Bs + buf * BN * IVX_BK + wid_u * 8 * IVX_BK;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+      const unsigned good = ((a_msk[j] & tap) == tap) ? 0xffffffffu : 0u;
+      const unsigned vo = (((unsigned)(a_off[j] + delta) << 2) & good) | (OOB & ~good);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + 32 * j * IVX_BK), 16, vo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const unsigned good = (b_off[j] >= 0 ? 0xffffffffu : 0u) & ~kbad;
+      const unsigned vo = (((unsigned)(b_off[j] + k4) << 2) & good) | (OOB & ~good);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bb + 32 * j * IVX_BK), 16, vo, 0, 0, 0);
+    }
+  };
+  auto advance_k = [&]() {
+    k4 += IVX_BK;
+    if (p.kmode == 1) {  // next tap of the same 32-channel chunk; after the last tap move to the next chunk
+      if (++kf == p.KW) {
+        kf = 0;
+        if (++ke == p.KH) {
+          ke = 0;
+          if (++ka == p.KD) {
+            ka = 0;
+            kc += IVX_BK;
+          }
+        }
+      }
+      return;
+    }
+    kc += IVX_BK;
+    while (kc >= p.Cin) {
+      kc -= p.Cin;
+      if (++kf == p.KW) {
+        kf = 0;
+        if (++ke == p.KH) {
+          ke = 0;
+          ++ka;
+        }
+      }
+    }
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_slab(0);
+  __syncthreads();
+
+  const int frow = (lane & 31) * IVX_BK, fsw = (lane >> 1) & 7, fh = lane >> 5;
+  for (int s = 0; s < S; ++s) {
+    const int cur = s & 1;
+    const bool more = (s + 1) < S;
+    if (more) {
+      advance_k();
+      load_slab(cur ^ 1);
+    }
+    const float *Ac = As + cur * BM * IVX_BK + wr * TM * 32 * IVX_BK + frow;
+    const float *Bc = Bs + cur * BN * IVX_BK + wc * TN * 32 * IVX_BK + frow;
+    f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_BK + ((fh ^ fsw) << 2));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * IVX_BK + ((fh ^ fsw) << 2));
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (kk < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_BK + (((2 * (kk + 1) + fh) ^ fsw) << 2));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * IVX_BK + (((2 * (kk + 1) + fh) ^ fsw) << 2));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][i][q], fb[cb][j][q], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+}
+
 // Validation kernel: one thread per output element, sequential fmaf over (kd,kh,kw,ci).
 __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p) {
   const size_t total = (size_t)p.M * p.Cout;
@@ -602,6 +787,17 @@ static void launch_cfg(const ConvParams &p, hipStream_t st, bool v2) {
     hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
 }
 
+template <int TM, int TN, int WR, int WC>
+static void launch_v4(const ConvParams &p, hipStream_t st) {
+  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4;
+  const int64_t w_bytes = (int64_t)p.Cout * p.K * 4;
+  const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
+  const long long g1 = 8 * ((Mt + 7) / 8) * Nt;
+  hipLaunchKernelGGL((conv_igemm_f32_v4_kernel<TM, TN, WR, WC>), dim3((unsigned)g1), dim3(256), 0, st, p, (unsigned)in_bytes,
+                     (unsigned)w_bytes);
+}
+
 static int g_tile_override = 0;
 // Tuning knob (A/B experiments, tools/conv_bench.py): 0 = automatic choice by Cout, 1..N = force a tile config.
 extern "C" int ivx_conv_set_tile_override(int cfg) {
@@ -630,15 +826,18 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float
   }
   if (cfg == 0) {
     // Tile choice (measured per layer on MI355X, tools/conv_bench.py): big problems want the 128-row tiles with the
-    // best MFMA : staging ratio; when 128 x 128 tiles would not fill the 512 workgroup slots (2 per CU) several
-    // times over -- every ResNet/FPN layer at KITTI resolution -- 64 x 64 tiles win by occupancy.
+    // best MFMA : staging ratio; when 128 x 128 tiles would not fill the 512+ workgroup slots several times over --
+    // every ResNet/FPN layer at KITTI resolution -- 64 x 64 tiles win by occupancy.  The LDS-DMA kernel (v4, 4x) is
+    // used whenever its preconditions hold (tensor < 2 GiB, kernel extents <= 8), else the same tile on v2 / v1.
     const long long nblk = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    const int64_t in_b = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4, w_b = (int64_t)p.Cout * p.K * 4;
+    const bool dma_ok = in_b < (1LL << 31) && w_b < (1LL << 31) && p.KD <= 8 && p.KH <= 8 && p.KW <= 8;
     if (p.Cout <= 32)
-      cfg = 4;
+      cfg = dma_ok ? 44 : 4;
     else if (nblk >= 2500)
-      cfg = p.Cout > 64 ? 1 : 3;
+      cfg = p.Cout > 64 ? (dma_ok ? 41 : 1) : (dma_ok ? 43 : 3);
     else
-      cfg = 6;
+      cfg = dma_ok ? 46 : 6;
   }
   switch (cfg) {
     case 1: launch_cfg<2, 2, 2, 2>(p, st, v2); break;  // 128 x 128, 2 blocks/CU
@@ -647,6 +846,10 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float
     case 4: launch_cfg<1, 1, 4, 1>(p, st, v2); break;  // 128 x 32
     case 5: launch_cfg<1, 2, 4, 1>(p, st, v2); break;  // 128 x 64 (wave 32 x 64)
     case 6: launch_cfg<1, 1, 2, 2>(p, st, v2); break;  // 64 x 64
+    case 41: launch_v4<2, 2, 2, 2>(p, st); break;
+    case 43: launch_v4<2, 1, 2, 2>(p, st); break;
+    case 44: launch_v4<1, 1, 4, 1>(p, st); break;
+    case 46: launch_v4<1, 1, 2, 2>(p, st); break;
     case 7: launch_cfg<1, 2, 2, 2>(p, st, v2); break;  // 64 x 128
 
     default:
