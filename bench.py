@@ -43,6 +43,77 @@ def neck_flops_per_sample(nv, c_in, c_out):
     return 2.0 * macs
 
 
+def bench_other(args, ia, kc, dev, rank, world):
+    """Single-process throughput of the other BASELINE.json workloads (parity-test configurations; not the headline
+    metric).  Same timing method; the roofline entry is the conv kernel over the 3-D neck with FLOPs counted per call."""
+    from imvoxelnet_amd.conv import FusedConv
+    spec = {
+        'nuscenes': (kc.nuscenes_model_cfg(), kc.NUSCENES_TEST_CFG, 6, (928, 1600), 1, lambda: kc.nuscenes_meta(box_type=ia.LiDARInstance3DBoxes)),
+        'scannet_fast': (kc.scannet_fast_model_cfg(), kc.SCANNET_FAST_TEST_CFG, args.views or 50, (480, 640), 1,
+                         lambda: kc.indoor_meta(args.views or 50, box_type=ia.DepthInstance3DBoxes)),
+        'sunrgbd_fast': (kc.sunrgbd_fast_model_cfg(), kc.SUNRGBD_FAST_TEST_CFG, 1, (480, 640), 1,
+                         lambda: kc.indoor_meta(1, origin=(0, 3, -1), box_type=ia.DepthInstance3DBoxes)),
+        'scannet_v1': (kc.scannet_v1_model_cfg(), kc.SCANNET_V1_TEST_CFG, args.views or 50, (480, 640), 1,
+                       lambda: kc.indoor_meta(args.views or 50, box_type=ia.DepthInstance3DBoxes)),
+    }[args.config]
+    cfg, tcfg, V, (H, W), B, mk = spec
+    B = args.batch if args.batch != BATCH_PER_GPU else B
+    model = ia.build_detector(cfg, test_cfg=tcfg)
+    ia.randomize_(model, 0)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        if hasattr(model.bbox_head, 'conv_cls'):
+            model.bbox_head.conv_cls.weight.normal_(0, 0.02, generator=g)
+            model.bbox_head.conv_cls.bias.fill_(-2.0)
+            model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=g)
+        else:
+            model.bbox_head.cls_conv.weight.normal_(0, 0.01, generator=g)
+            model.bbox_head.cls_conv.bias.fill_(-2.0)
+            model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
+    model.prepare(dev)
+    img = torch.randn(B, V, 3, H, W, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+    metas = [mk() for _ in range(B)]
+    n = args.steps + args.warmup
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    neck_flops = [0.0]
+
+    def step(i):
+        p0 = model.features_2d_cl(img)
+        vol, valid = model.lift_cl(p0, metas)
+        ev[i][0].record()
+        FusedConv.flops, FusedConv.count_flops = 0.0, True
+        y = model.neck_3d.forward_cl(vol)
+        FusedConv.count_flops = False
+        neck_flops[0] = FusedConv.flops
+        ev[i][1].record()
+        if isinstance(model.bbox_head, ia.Anchor3DHead):
+            h = model.bbox_head.forward_cl(y)
+            out = model.bbox_head.get_bboxes_cl(h, y.shape[2], y.shape[1], metas, hw_transposed=True)
+            return model.bbox_head._wrap(*out, metas)
+        res = model.bbox_head.get_bboxes_cl(model.bbox_head.forward_cl(y), valid, metas)
+        return [(b.tensor.cpu(), s.cpu(), l.cpu()) for b, s, l in res]
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    neck_ms = sum(ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][1]) for i in range(args.steps)) / args.steps
+    ach = neck_flops[0] / (neck_ms * 1e-3) / 1e12
+    rec = {'metric': f'images/sec/node ({args.config}: {V} view(s) 3x{H}x{W}, {"x".join(map(str, cfg["n_voxels"]))} vox)',
+           'value': round(B * V * args.steps / dt, 3), 'unit': 'images/s', 'scenes_per_s': round(B * args.steps / dt, 3), 'n_gpus': 1,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'detections_last_step': int(sum(len(r[1]) for r in last))},
+           'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_f32 (3-D neck)', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                        'neck_gflop': round(neck_flops[0] / 1e9, 1), 'neck_ms_per_step': round(neck_ms, 3)}}
+    print(json.dumps(rec))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -50,6 +121,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='samples per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config', default='kitti', choices=['kitti', 'nuscenes', 'scannet_fast', 'sunrgbd_fast', 'scannet_v1'],
+                    help='BASELINE.json workload; the headline metric is quoted on kitti (configs[1]), the default')
+    ap.add_argument('--views', type=int, default=0, help='views per scene for the indoor configs (default: reference test value)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -68,8 +142,12 @@ def main():
 
     import imvoxelnet_amd as ia
     from imvoxelnet_amd import dist as ivx_dist
+    import kitti_cfg as kc
     from kitti_cfg import kitti_model_cfg, KITTI_TEST_CFG, kitti_meta
+    from imvoxelnet_amd.conv import FusedConv
 
+    if args.config != 'kitti':
+        return bench_other(args, ia, kc, dev, rank, world)
     model = ia.build_detector(kitti_model_cfg(), test_cfg=KITTI_TEST_CFG)
     ia.randomize_(model, 0)
     with torch.no_grad():   # trained-net-like head statistics so the NMS tail has real work

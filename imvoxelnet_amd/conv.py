@@ -24,6 +24,10 @@ def _spatial3(v, dims, fill):
 
 
 class FusedConv:
+    # optional algorithmic-FLOP accounting (bench.py): 2 * output positions * Cout * Cin * taps per call
+    count_flops = False
+    flops = 0.0
+
     def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, relu=False, dims=3, eps=1e-5, layout=None):
         """weight: [Cout,Cin,kh,kw] (dims=2) or [Cout,Cin,kd,kh,kw] (dims=3) tensor (any device).
         bn: None or (gamma, beta, running_mean, running_var)."""
@@ -68,6 +72,11 @@ class FusedConv:
     def __call__(self, x, res=None, res_mode=0, relu=None, naive=False, res_after_act=False, post_scale=1.0):
         if self.w is None:
             raise RuntimeError('FusedConv.to(device) must be called before use')
+        if FusedConv.count_flops:
+            pos = x.shape[0] * ((x.shape[1] + 2 * self.padding[0] - self.kernel[0]) // self.stride[0] + 1) * \
+                ((x.shape[2] + 2 * self.padding[1] - self.kernel[1]) // self.stride[1] + 1) * \
+                ((x.shape[3] + 2 * self.padding[2] - self.kernel[2]) // self.stride[2] + 1)
+            FusedConv.flops += 2.0 * pos * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
         return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,
                             self.relu if relu is None else relu, res, res_mode, naive=naive, wgt_layout=self.layout,
                             out_mode=self.out_mode, res_after_act=res_after_act, post_scale=post_scale)

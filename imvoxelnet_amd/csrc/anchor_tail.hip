@@ -133,38 +133,32 @@ __device__ inline float iou_normal_dev(const float *a, const float *b) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Suppression mask: one wave64 per (row block, col block) tile; each lane builds one 64-bit word
-// (iou3d_kernel.cu:284-333 / :345-396).  Only col >= row blocks are built: the greedy scan
-// (iou3d.cpp:127-143) never reads the others.  boxes [nb][stride_boxes][5], n1 per batch item.
+// Suppression mask (iou3d_kernel.cu:284-333 / :345-396 restated for wave64): one wave per (row i, column block c);
+// lane j computes IoU(i, 64c + j) and the wave's 64-bit ballot IS the mask word -- one rotated-IoU evaluation per
+// lane instead of the reference's 64 sequential ones per thread.  Only column blocks >= the row's block are built
+// (the greedy scan, iou3d.cpp:127-143, never reads the others); inside the diagonal block only columns > row.
+// boxes [nb][box_stride][5]; n comes from n_arr[bz] (per batch item) or n_fixed.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float *boxes, const int *n_arr, int n_fixed, int box_stride,
                                                       int cb_stride, float thr, int rotated, unsigned long long *mask) {
   const int bz = blockIdx.z;
   const int n = n_arr ? n_arr[bz] : n_fixed;
-  const int row_start = blockIdx.y, col_start = blockIdx.x;
-  if (col_start < row_start) return;
-  if (row_start * 64 >= n || col_start * 64 >= n) return;
+  const int row = blockIdx.y, col_start = blockIdx.x;
+  if (row >= n || col_start * 64 >= n || col_start < (row >> 6)) return;
   const float *bx = boxes + (size_t)bz * box_stride * 5;
-  const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
-  __shared__ float blk[64 * 5];
-  const int t = threadIdx.x;
-  if (t < col_size) {
+  const int col = col_start * 64 + threadIdx.x;
+  bool hit = false;
+  if (col < n && col > row) {
+    float a[5], b[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) blk[t * 5 + q] = bx[(size_t)(64 * col_start + t) * 5 + q];
-  }
-  __syncthreads();
-  if (t < row_size) {
-    const int cur = 64 * row_start + t;
-    float cb_[5];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) cb_[q] = bx[(size_t)cur * 5 + q];
-    unsigned long long w = 0;
-    const int start = (row_start == col_start) ? t + 1 : 0;
-    for (int i = start; i < col_size; ++i) {
-      const float v = rotated ? iou_bev_dev(cb_, blk + i * 5) : iou_normal_dev(cb_, blk + i * 5);
-      if (v > thr) w |= 1ULL << i;
+    for (int q = 0; q < 5; ++q) {
+      a[q] = bx[(size_t)row * 5 + q];
+      b[q] = bx[(size_t)col * 5 + q];
     }
-    mask[((size_t)bz * box_stride + cur) * cb_stride + col_start] = w;
+    const float v = rotated ? iou_bev_dev(a, b) : iou_normal_dev(a, b);
+    hit = v > thr;
   }
+  const unsigned long long w = __ballot(hit);
+  if (threadIdx.x == 0) mask[((size_t)bz * box_stride + row) * cb_stride + col_start] = w;
 }
 
 // Greedy scan by one wave: lane w owns removal word w (n <= 4096).  Returns the number kept (all lanes)
@@ -523,7 +517,7 @@ extern "C" int ivx_anchor_head_get_bboxes(const ivx_anchor_head_desc *d, const f
   hipLaunchKernelGGL(anchor_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, keys);
   hipLaunchKernelGGL(topk_select_kernel, dim3(p.B), dim3(1024), (size_t)p.kpad * 8, st, p, keys, topk, cnt, n1);
   hipLaunchKernelGGL(decode_kernel, dim3(p.kpad / 64, p.B), dim3(64), 0, st, p, keys, topk, cboxes, cscores, cdir, cbev);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(p.cb, p.cb, p.B), dim3(64), 0, st, cbev, n1, 0, p.kpad, p.cb, p.nms_thr, p.rotated, mask);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(p.cb, p.kpad, p.B), dim3(64), 0, st, cbev, n1, 0, p.kpad, p.cb, p.nms_thr, p.rotated, mask);
   hipLaunchKernelGGL(nms_finalize_kernel, dim3(p.B), dim3(256), 0, st, p, n1, mask, cboxes, cscores, cdir, out_boxes, out_scores,
                      (long long *)out_labels, out_count);
   if (cand_idx || cand_boxes || cand_scores)
@@ -569,7 +563,7 @@ extern "C" int ivx_nms_bev(const float *boxes_sorted, int32_t n, float thresh, i
   }
   const int cb = (n + 63) / 64;
   unsigned long long *mask = (unsigned long long *)workspace;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, 1), dim3(64), 0, st, boxes_sorted, (const int *)nullptr, n, n, cb, thresh, rotated, mask);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, n, 1), dim3(64), 0, st, boxes_sorted, (const int *)nullptr, n, n, cb, thresh, rotated, mask);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, mask, n, cb, (long long *)keep, num_out);
   IVX_CHECK_LAUNCH("ivx_nms_bev");
   return IVX_OK;
