@@ -141,7 +141,7 @@ def main():
     dev = torch.device('cuda', torch.cuda.current_device())
 
     import imvoxelnet_amd as ia
-    from imvoxelnet_amd import dist as ivx_dist
+    from imvoxelnet_amd import dist as ivx_dist, ops
     import kitti_cfg as kc
     from kitti_cfg import kitti_model_cfg, KITTI_TEST_CFG, kitti_meta
     from imvoxelnet_amd.conv import FusedConv
@@ -163,12 +163,14 @@ def main():
     img = img_host.to(dev)
     metas = [kitti_meta(t=(0.01 * b, 0.0, 0.0), box_type=ia.LiDARInstance3DBoxes) for b in range(B)]
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps + args.warmup)]
 
     def step(i):
         p0 = model.features_2d_cl(img)
-        vol, _ = model.lift_cl(p0, metas)
+        proj, new_origin, crop = model._camera_setup(metas, 4, p0.device)   # host camera set-up + 3 small H2D copies
+        ev[i][2].record()
+        vol, _ = ops.backproject_mean(p0, proj, new_origin, crop, model.voxel_size, model.n_voxels)
         ev[i][0].record()                                   # HIP events on the stream the kernels launch on
         y = model.neck_3d.forward_cl(vol)
         ev[i][1].record()
@@ -200,6 +202,9 @@ def main():
 
     neck_ms = [ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][1]) for i in range(args.steps)]
     neck_ms_avg = sum(neck_ms) / len(neck_ms)
+    lift_ms = sum(ev[args.warmup + i][2].elapsed_time(ev[args.warmup + i][0]) for i in range(args.steps)) / args.steps
+    # unprojection: algorithmic bytes = features read once + volume written once + mask (173.1 MB/sample)
+    lift_bytes = B * (1 * 64 * 96 * 320 * 4 + 64 * 216 * 248 * 12 * 4 + 216 * 248 * 12)
     n_launch = 11
     flops_step = neck_flops_per_sample((216, 248, 12), 64, 256) * B
     achieved = flops_step / (neck_ms_avg * 1e-3) / 1e12
@@ -232,6 +237,10 @@ def main():
                          'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/r01_bench_pmc.json)',
                          'algorithmic_gflop_per_launch': round(flops_step / n_launch / 1e9, 2),
                          'avg_launch_ms': round(neck_ms_avg / n_launch, 4), 'neck_ms_per_step': round(neck_ms_avg, 3)},
+            'roofline_unprojection': {'bound': 'hbm', 'kernel': 'backproject_single_view_kernel (1 launch/step, event-bracketed)',
+                                      'achieved': round(lift_bytes / (lift_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                                      'frac': round(lift_bytes / (lift_ms * 1e-3) / 8e12, 4), 'ms': round(lift_ms, 4),
+                                      'algorithmic_MB': round(lift_bytes / 1e6, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import imvoxel_oracle as orc

@@ -137,6 +137,69 @@ __global__ __launch_bounds__(256) void backproject_mean_kernel(const BpParams p)
   if (g == 0) p.valid[(size_t)b * p.N + n] = cnt > 0 ? 1 : 0;
 }
 
+// Single-view specialisation (KITTI, SUN RGB-D: V == 1).  With one view the mean is the gathered value itself, so no
+// accumulation is needed and the roles flip: a group of LPV lanes owns LPV consecutive voxels, lane g projects voxel
+// n0 + g (one projection per lane instead of one per group), then the group walks its voxels and every lane
+// copies its VEC channels of voxel n0 + s from the pixel that voxel hit (offset broadcast with __shfl).  Per
+// 1 KiB of volume written a wave issues a handful of instructions, so the kernel is bound by the volume write.
+template <int VEC>
+__global__ __launch_bounds__(256) void backproject_single_view_kernel(const BpParams p) {
+  const int b = blockIdx.y;
+  const int lpv = 1 << p.lpv_log2;
+  const int lane = threadIdx.x & 63;
+  const int g = lane & (lpv - 1);
+  const int gbase = lane & ~(lpv - 1);
+  const int group = (blockIdx.x * 256 + threadIdx.x) >> p.lpv_log2;   // global group index
+  const long long n0 = (long long)group * lpv;
+  const long long n = n0 + g;
+  int off = -1;
+  if (n < p.N) {
+    const int k = (int)(n % p.Z);
+    const int t = (int)(n / p.Z);
+    const int j = t % p.Y;
+    const int i = t / p.Y;
+    const float *no = p.new_origin + b * 3;
+    const float px = __fadd_rn(__fmul_rn((float)i, p.vs0), no[0]);
+    const float py = __fadd_rn(__fmul_rn((float)j, p.vs1), no[1]);
+    const float pz = __fadd_rn(__fmul_rn((float)k, p.vs2), no[2]);
+    const int hc = p.crop_hw[b * 2 + 0], wc = p.crop_hw[b * 2 + 1];
+    const float *P = p.proj + (size_t)b * 12;
+    float u = __fmul_rn(P[0], px);
+    u = __fmaf_rn(P[1], py, u);
+    u = __fmaf_rn(P[2], pz, u);
+    u = __fmaf_rn(P[3], 1.0f, u);
+    float w_ = __fmul_rn(P[4], px);
+    w_ = __fmaf_rn(P[5], py, w_);
+    w_ = __fmaf_rn(P[6], pz, w_);
+    w_ = __fmaf_rn(P[7], 1.0f, w_);
+    float d = __fmul_rn(P[8], px);
+    d = __fmaf_rn(P[9], py, d);
+    d = __fmaf_rn(P[10], pz, d);
+    d = __fmaf_rn(P[11], 1.0f, d);
+    const float xr = rintf(__fdiv_rn(u, d));
+    const float yr = rintf(__fdiv_rn(w_, d));
+    const bool ok = (xr >= 0.f) && (yr >= 0.f) && (xr < (float)wc) && (yr < (float)hc) && (d > 0.f);
+    if (ok) off = ((b * p.FH + (int)yr) * p.FW + (int)xr);
+    p.valid[(size_t)b * p.N + n] = ok ? 1 : 0;
+  }
+  const int nvox = (p.N - n0) < lpv ? (int)(p.N - n0) : lpv;   // group-uniform; <= 0 for groups past the end
+  float *dst0 = p.volume + ((size_t)b * p.N + n0) * p.C;
+  for (int s = 0; s < lpv; ++s) {
+    const int o = __shfl(off, gbase + s, 64);
+    if (s >= nvox) continue;
+    const float *src = p.feat + (size_t)(o < 0 ? 0 : o) * p.C;
+    for (int ch = g; ch < p.nchunk; ch += lpv) {
+      if constexpr (VEC == 4) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (o >= 0) x = *reinterpret_cast<const f32x4 *>(src + ch * 4);
+        *reinterpret_cast<f32x4 *>(dst0 + (size_t)s * p.C + ch * 4) = x;
+      } else {
+        dst0[(size_t)s * p.C + ch] = o >= 0 ? src[ch] : 0.f;
+      }
+    }
+  }
+}
+
 extern "C" int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,
                                         const float *proj, const float *new_origin, const int32_t *crop_hw,
                                         const float *voxel_size, int32_t X, int32_t Y, int32_t Z, float *volume,
@@ -156,6 +219,16 @@ extern "C" int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V,
   int lg = 0;
   while ((1 << lg) < p.nchunk && lg < 6) ++lg;
   p.lpv_log2 = lg;
+  if (V == 1) {
+    // 256 voxels per workgroup regardless of the group width (each lane projects one voxel)
+    dim3 g1((p.N + 255) / 256, B);
+    if (vec == 4)
+      hipLaunchKernelGGL(backproject_single_view_kernel<4>, g1, dim3(256), 0, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL(backproject_single_view_kernel<1>, g1, dim3(256), 0, (hipStream_t)stream, p);
+    IVX_CHECK_LAUNCH("ivx_backproject_mean_fwd");
+    return IVX_OK;
+  }
   const int vox_per_block = 256 >> lg;
   dim3 grid((p.N + vox_per_block - 1) / vox_per_block, B);
   if (vec == 4)

@@ -498,16 +498,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams
 // wave-uniform base + lane*16 B, so LDS rows are unpadded 128-byte rows and bank conflicts are avoided by an XOR
 // swizzle applied on the SOURCE side (lane with slot c of row r fetches k-chunk c ^ ((r>>1)&7)) and again on the
 // fragment read.
-template <int TM, int TN, int WR, int WC>
+template <int TM, int TN, int WR, int WC, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams p, const unsigned in_bytes,
                                                                   const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-  constexpr int AR = BM / 32, BR = BN / 32;
+  constexpr int NCH = BK / 4;          // 16-byte chunks per LDS row (8 or 4)
+  constexpr int RP = 256 / NCH;        // rows covered by one pass of the 256 threads (32 or 64)
+  constexpr int AR = BM / RP, BR = BN / RP;
+  constexpr int SW_SH = BK == 32 ? 1 : 2, SW_MSK = NCH - 1;   // slot c of row r holds k-chunk c ^ ((r >> SW_SH) & SW_MSK)
+  static_assert(BK == 32 || BK == 16, "BK");
+  static_assert(BM % RP == 0 && BN % RP == 0, "tile rows");
   static_assert(WR * WC == 4, "4 waves per workgroup");
   // LDS-DMA staging: rows are 32 floats (128 B), unpadded; 16-byte slot c of row r holds k-chunk c ^ ((r>>1)&7)
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * IVX_BK];
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BK];
   float *As = smem;
-  float *Bs = smem + 2 * BM * IVX_BK;
+  float *Bs = smem + 2 * BM * BK;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -533,14 +538,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, w_bytes, 0x00020000);
 
-  const int lr = tid >> 3;
-  const int cc = (tid & 7) ^ ((lr >> 1) & 7);   // the k-chunk this lane fetches (its LDS slot is tid & 7)
+  const int lr = tid / NCH;
+  const int cc = (tid & (NCH - 1)) ^ ((lr >> SW_SH) & SW_MSK);   // the k-chunk this lane fetches (its LDS slot is tid % NCH)
   const int wid_u = __builtin_amdgcn_readfirstlane(wid);
   int a_off[AR];
   unsigned a_msk[AR];
 #pragma unroll
   for (int j = 0; j < AR; ++j) {
-    const int m = m0 + lr + 32 * j;
+    const int m = m0 + lr + RP * j;
     a_off[j] = 0;
     a_msk[j] = 0;
     if (m < p.M) {
@@ -562,11 +567,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
   int b_off[BR];
 #pragma unroll
   for (int j = 0; j < BR; ++j) {
-    const int n = n0 + lr + 32 * j;
+    const int n = n0 + lr + RP * j;
     b_off[j] = n < p.Cout ? n * p.K : -1;
   }
   int k4 = cc * 4;
   int kc, ka, ke, kf;
+  int khalf = 0;   // BK == 16, chunk-major: which half of the 32-channel chunk this slab covers
   if (p.kmode == 1) {  // chunk-major: slab s = (channel chunk s / taps, tap s % taps)
     kc = cc * 4;
     ka = ke = kf = 0;
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
     ke = t2 % p.KH;
     ka = t2 / p.KH;
   }
-  const int S = (p.K + IVX_BK - 1) / IVX_BK;
+  const int S = (p.K + BK - 1) / BK;
   const unsigned OOB = 0x80000000u;
 
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -587,37 +593,42 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
     const unsigned kbad = (k4 < p.K) ? 0u : 0xffffffffu;
     const int delta = ((ka * p.H + ke) * p.W + kf) * p.Cin + kc;
     const unsigned tap = ((1u << ka) | (1u << (8 + ke)) | (1u << (16 + kf))) | kbad;
-    float *Ab = As + buf * BM * IVX_BK + wid_u * 8 * IVX_BK;   // wave-uniform base; the DMA adds lane*16 B
-    float *Bb = Bs + buf * BN * IVX_BK + wid_u * 8 * IVX_BK;
+    float *Ab = As + buf * BM * BK + wid_u * (64 / NCH) * BK;   // wave-uniform base; the DMA adds lane*16 B
+    float *Bb = Bs + buf * BN * BK + wid_u * (64 / NCH) * BK;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
       const unsigned good = ((a_msk[j] & tap) == tap) ? 0xffffffffu : 0u;
       const unsigned vo = (((unsigned)(a_off[j] + delta) << 2) & good) | (OOB & ~good);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + 32 * j * IVX_BK), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + RP * j * BK), 16, vo, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
       const unsigned good = (b_off[j] >= 0 ? 0xffffffffu : 0u) & ~kbad;
       const unsigned vo = (((unsigned)(b_off[j] + k4) << 2) & good) | (OOB & ~good);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bb + 32 * j * IVX_BK), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bb + RP * j * BK), 16, vo, 0, 0, 0);
     }
   };
   auto advance_k = [&]() {
-    k4 += IVX_BK;
+    k4 += BK;
     if (p.kmode == 1) {  // next tap of the same 32-channel chunk; after the last tap move to the next chunk
+      if (BK == 16) {
+        khalf ^= 1;
+        kc += khalf ? 16 : -16;
+        if (khalf) return;
+      }
       if (++kf == p.KW) {
         kf = 0;
         if (++ke == p.KH) {
           ke = 0;
           if (++ka == p.KD) {
             ka = 0;
-            kc += IVX_BK;
+            kc += 32;
           }
         }
       }
       return;
     }
-    kc += IVX_BK;
+    kc += BK;
     while (kc >= p.Cin) {
       kc -= p.Cin;
       if (++kf == p.KW) {
@@ -640,7 +651,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
   load_slab(0);
   __syncthreads();
 
-  const int frow = (lane & 31) * IVX_BK, fsw = (lane >> 1) & 7, fh = lane >> 5;
+  const int frow = (lane & 31) * BK, fsw = ((lane & 31) >> SW_SH) & SW_MSK, fh = lane >> 5;
   for (int s = 0; s < S; ++s) {
     const int cur = s & 1;
     const bool more = (s + 1) < S;
@@ -648,21 +659,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
       advance_k();
       load_slab(cur ^ 1);
     }
-    const float *Ac = As + cur * BM * IVX_BK + wr * TM * 32 * IVX_BK + frow;
-    const float *Bc = Bs + cur * BN * IVX_BK + wc * TN * 32 * IVX_BK + frow;
+    const float *Ac = As + cur * BM * BK + wr * TM * 32 * BK + frow;
+    const float *Bc = Bs + cur * BN * BK + wc * TN * 32 * BK + frow;
     f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_BK + ((fh ^ fsw) << 2));
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + ((fh ^ fsw) << 2));
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * IVX_BK + ((fh ^ fsw) << 2));
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + ((fh ^ fsw) << 2));
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < BK / 8; ++kk) {
       const int cb = kk & 1, nb = cb ^ 1;
-      if (kk < 3) {
+      if (kk < BK / 8 - 1) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_BK + (((2 * (kk + 1) + fh) ^ fsw) << 2));
+        for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) << 2));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * IVX_BK + (((2 * (kk + 1) + fh) ^ fsw) << 2));
+        for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) << 2));
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -787,14 +798,14 @@ static void launch_cfg(const ConvParams &p, hipStream_t st, bool v2) {
     hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
 }
 
-template <int TM, int TN, int WR, int WC>
+template <int TM, int TN, int WR, int WC, int BK = 32>
 static void launch_v4(const ConvParams &p, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4;
   const int64_t w_bytes = (int64_t)p.Cout * p.K * 4;
   const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
   const long long g1 = 8 * ((Mt + 7) / 8) * Nt;
-  hipLaunchKernelGGL((conv_igemm_f32_v4_kernel<TM, TN, WR, WC>), dim3((unsigned)g1), dim3(256), 0, st, p, (unsigned)in_bytes,
+  hipLaunchKernelGGL((conv_igemm_f32_v4_kernel<TM, TN, WR, WC, BK>), dim3((unsigned)g1), dim3(256), 0, st, p, (unsigned)in_bytes,
                      (unsigned)w_bytes);
 }
 
@@ -835,7 +846,7 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float
     if (p.Cout <= 32)
       cfg = dma_ok ? 44 : 4;
     else if (nblk >= 2500)
-      cfg = p.Cout > 64 ? (dma_ok ? 41 : 1) : (dma_ok ? 43 : 3);
+      cfg = p.Cout > 64 ? (dma_ok ? 51 : 1) : (dma_ok ? 43 : 3);   // 51: 128 x 128 with BK 16 -> 3 workgroups per CU
     else
       cfg = dma_ok ? 46 : 6;
   }
@@ -850,6 +861,8 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float
     case 43: launch_v4<2, 1, 2, 2>(p, st); break;
     case 44: launch_v4<1, 1, 4, 1>(p, st); break;
     case 46: launch_v4<1, 1, 2, 2>(p, st); break;
+    case 51: launch_v4<2, 2, 2, 2, 16>(p, st); break;  // 128 x 128, BK 16: 32 KB LDS, 3 workgroups per CU
+    case 53: launch_v4<2, 1, 2, 2, 16>(p, st); break;
     case 7: launch_cfg<1, 2, 2, 2>(p, st, v2); break;  // 64 x 128
 
     default:

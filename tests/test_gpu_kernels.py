@@ -89,7 +89,7 @@ def test_conv_config_variants(ia):
     try:
         for layout in (1, 0):
             fc = FusedConv(w, stride=(1, 1, 2), padding=1, layout=layout).to('cuda')
-            for ov in ((1, 2, 3, 4, 5, 6, 7, 41, 43, 44, 46) if layout == 1 else (1, 3, 6, 41, 46, 101, 102, 103, 104, 105, 106, 107)):
+            for ov in ((1, 2, 3, 4, 5, 6, 7, 41, 43, 44, 46, 51, 53) if layout == 1 else (1, 3, 6, 41, 46, 51, 53, 101, 102, 103, 104, 105, 106, 107)):
                 L.ivx_conv_set_tile_override(ov)
                 assert_close(f'layout{layout} override{ov}', uncl(fc(xc)), ref, 1e-4, 1e-4)
     finally:
