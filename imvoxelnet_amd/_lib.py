@@ -28,7 +28,7 @@ class AnchorHeadDesc(C.Structure):
                [(n, C.c_float) for n in ('score_thr', 'nms_thr', 'dir_offset', 'dir_limit_offset')]
 
 
-EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override',
+EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
            'ivx_maxpool2d_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
            'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_fcos_head_workspace_bytes',
            'ivx_fcos_head_level_candidates', 'ivx_nms_workspace_bytes',
@@ -51,6 +51,9 @@ def lib():
     for name in ('ivx_conv_fwd', 'ivx_conv_fwd_naive'):
         getattr(L, name).argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
     L.ivx_conv_set_tile_override.argtypes = [C.c_int]
+    L.ivx_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
+    L.ivx_conv_workspace_bytes.restype = i64
+    L.ivx_conv_fwd_ws.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.ivx_maxpool2d_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ivx_upsample_trilinear2x_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     L.ivx_nchw_to_nhwc.argtypes = [vp, i32, i32, i64, i32, vp, vp]
@@ -70,7 +73,7 @@ def lib():
     L.ivx_aligned_3d_nms.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
     for name in EXPORTS:
         if name not in ('ivx_last_error', 'ivx_anchor_head_workspace_bytes', 'ivx_nms_workspace_bytes',
-                        'ivx_fcos_head_workspace_bytes'):
+                        'ivx_fcos_head_workspace_bytes', 'ivx_conv_workspace_bytes'):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -38,6 +38,8 @@ struct ConvParams {
   int Cr;             // real output channels (Cout / 8 when out_mode == 1, else Cout)
   int res_after_act;  // add the residual after the activation (skip connections of the U-shaped necks)
   float post_scale;   // final multiplier (Atlas neck (x + y) / 2); 1 = none
+  int ksplit;         // > 1: split-K, grid.y = slice; raw partial sums go to `partial` [ksplit][M][Cout]
+  float *partial;
 };
 
 #define IVX_BK 32
@@ -496,8 +498,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams
 // v4: v2 with LDS-DMA staging (buffer_load_dwordx4 ... offen lds): the operands go global -> LDS without passing
 // through VGPRs, so the slab loop has no ds_write pass and no vmcnt -> ds_write dependency.  The DMA writes
 // wave-uniform base + lane*16 B, so LDS rows are unpadded 128-byte rows and bank conflicts are avoided by an XOR
-// swizzle applied on the SOURCE side (lane with slot c of row r fetches k-chunk c ^ ((r>>1)&7)) and again on the
-// fragment read.
+// swizzle applied on the SOURCE side (lane with slot c of row r fetches k-chunk c ^ ((r >> SW_SH) & SW_MSK)) and
+// again on the fragment read.  BK (K-slab depth) is 32 or 16; 16 halves the LDS so three workgroups fit on a CU.
 template <int TM, int TN, int WR, int WC, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams p, const unsigned in_bytes,
                                                                   const unsigned w_bytes) {
@@ -570,12 +572,29 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
     const int n = n0 + lr + RP * j;
     b_off[j] = n < p.Cout ? n * p.K : -1;
   }
-  int k4 = cc * 4;
+  // slab range of this workgroup (split-K: grid.y slices the K loop)
+  const int S_all = (p.K + BK - 1) / BK;
+  int s_begin = 0, s_end = S_all;
+  if (p.ksplit > 1) {
+    const int per = (S_all + p.ksplit - 1) / p.ksplit;
+    s_begin = blockIdx.y * per;
+    s_end = s_begin + per < S_all ? s_begin + per : S_all;
+  }
+  int k4 = s_begin * BK + cc * 4;
   int kc, ka, ke, kf;
   int khalf = 0;   // BK == 16, chunk-major: which half of the 32-channel chunk this slab covers
-  if (p.kmode == 1) {  // chunk-major: slab s = (channel chunk s / taps, tap s % taps)
-    kc = cc * 4;
-    ka = ke = kf = 0;
+  if (p.kmode == 1) {  // chunk-major: slab s = (32-channel chunk, tap, half)
+    constexpr int HPS = 32 / BK;                       // slabs per (chunk, tap)
+    const int ntap = p.KD * p.KH * p.KW;
+    const int chunk = s_begin / (ntap * HPS);
+    const int rem = s_begin - chunk * ntap * HPS;
+    const int tap = rem / HPS;
+    khalf = rem - tap * HPS;
+    kc = chunk * 32 + khalf * 16 + cc * 4;
+    kf = tap % p.KW;
+    const int t2 = tap / p.KW;
+    ke = t2 % p.KH;
+    ka = t2 / p.KH;
   } else {
     const int tap = k4 / p.Cin;
     kc = k4 - tap * p.Cin;
@@ -584,7 +603,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
     ke = t2 % p.KH;
     ka = t2 / p.KH;
   }
-  const int S = (p.K + BK - 1) / BK;
+  const int S = s_end - s_begin;
   const unsigned OOB = 0x80000000u;
 
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -685,7 +704,51 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
     }
     __syncthreads();
   }
+  if (p.ksplit > 1) {
+    // raw partial sums; ivx split-K reduce kernel applies the epilogue
+    float *part = p.partial + (size_t)blockIdx.y * p.M * p.Cout;
+    const int col_l = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + (wc * TN + j) * 32 + col_l;
+          if (n < p.Cout) part[(size_t)m * p.Cout + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+}
+
+// Epilogue + store of one output element (row m, column n) from its finished accumulator: shared by the validation
+// kernel and the split-K reduction.
+__device__ __forceinline__ void conv_store_one(const ConvParams &p, int m, int n, float acc) {
+  if (p.out_mode == 1) {
+    const int tap = n / p.Cr, ch = n - tap * p.Cr;
+    const int a2 = tap >> 2, e2 = (tap >> 1) & 1, f2 = tap & 1;
+    const size_t o = up2_row_base(m, p.D, p.H, p.W, p.Cr) + (((size_t)a2 * 2 * p.H + e2) * 2 * p.W + f2) * p.Cr + ch;
+    p.out[o] = conv_finish(p, acc, p.scale ? p.scale[ch] : 1.0f, p.shift ? p.shift[ch] : 0.0f, o);
+    return;
+  }
+  const size_t idx = (size_t)m * p.Cout + n;
+  size_t ridx = idx;
+  if (p.res_mode == 2) ridx = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + n;
+  p.out[idx] = conv_finish(p, acc, p.scale ? p.scale[n] : 1.0f, p.shift ? p.shift[n] : 0.0f, ridx);
+}
+
+// Split-K reduction: out = epilogue(sum over slices in slice order) -- deterministic.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
+  const size_t total = (size_t)p.M * p.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int z = 0; z < p.ksplit; ++z) acc += p.partial[(size_t)z * total + idx];
+    conv_store_one(p, (int)(idx / p.Cout), (int)(idx % p.Cout), acc);
+  }
 }
 
 // Validation kernel: one thread per output element, sequential fmaf over (kd,kh,kw,ci).
@@ -722,16 +785,7 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
         }
       }
     }
-    if (p.out_mode == 1) {
-      const int tap = n / p.Cr, ch = n - tap * p.Cr;
-      const int a2 = tap >> 2, e2 = (tap >> 1) & 1, f2 = tap & 1;
-      const size_t o = up2_row_base(m, p.D, p.H, p.W, p.Cr) + (((size_t)a2 * 2 * p.H + e2) * 2 * p.W + f2) * p.Cr + ch;
-      p.out[o] = conv_finish(p, acc, p.scale ? p.scale[ch] : 1.0f, p.shift ? p.shift[ch] : 0.0f, o);
-      continue;
-    }
-    size_t ridx = idx;
-    if (p.res_mode == 2) ridx = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + n;
-    p.out[idx] = conv_finish(p, acc, p.scale ? p.scale[n] : 1.0f, p.shift ? p.shift[n] : 0.0f, ridx);
+    conv_store_one(p, m, n, acc);
   }
 }
 
@@ -765,6 +819,7 @@ static int fill_params(const ivx_conv_desc *d, const float *in, const float *wgt
   p->relu = d->relu; p->res_mode = d->res_mode; p->rH = d->res_h; p->rW = d->res_w; p->kmode = d->wgt_layout;
   p->out_mode = d->out_mode; p->Cr = d->out_mode == 1 ? d->Cout / 8 : d->Cout; p->res_after_act = d->res_after_act;
   p->post_scale = d->post_scale == 0.f ? 1.0f : d->post_scale;
+  p->ksplit = 1; p->partial = nullptr;
   return IVX_OK;
 }
 
@@ -805,7 +860,7 @@ static void launch_v4(const ConvParams &p, hipStream_t st) {
   const int64_t w_bytes = (int64_t)p.Cout * p.K * 4;
   const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
   const long long g1 = 8 * ((Mt + 7) / 8) * Nt;
-  hipLaunchKernelGGL((conv_igemm_f32_v4_kernel<TM, TN, WR, WC, BK>), dim3((unsigned)g1), dim3(256), 0, st, p, (unsigned)in_bytes,
+  hipLaunchKernelGGL((conv_igemm_f32_v4_kernel<TM, TN, WR, WC, BK>), dim3((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, st, p, (unsigned)in_bytes,
                      (unsigned)w_bytes);
 }
 
@@ -816,60 +871,127 @@ extern "C" int ivx_conv_set_tile_override(int cfg) {
   return IVX_OK;
 }
 
+struct ConvPlan {
+  int cfg;       // tile / kernel selector (see the switch in run_conv)
+  bool v2;       // for cfg < 40: buffer-load kernel (true) or the generic kernel (false)
+  int ksplit;    // 1 = no split-K
+};
+
+static bool dma_applicable(const ConvParams &p) {
+  const int64_t in_b = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4, w_b = (int64_t)p.Cout * p.K * 4;
+  return in_b < (1LL << 31) && w_b < (1LL << 31) && p.KD <= 8 && p.KH <= 8 && p.KW <= 8;
+}
+
+// Kernel / tile / split-K choice (measured per layer on MI355X with tools/conv_bench.py).
+//  * Big problems want the 128-row tiles with the best MFMA : staging ratio (BK 16 keeps LDS at 32 KB so three
+//    workgroups share a CU).  When 128 x 128 tiles would not fill the workgroup slots several times over -- every
+//    ResNet/FPN layer at KITTI resolution, the indoor necks -- 64 x 64 tiles win by occupancy.
+//  * When even 64 x 64 tiles leave most of the 256 CUs idle and K is long (ResNet stage 4, FPN laterals on C5, the
+//    coarse levels of the indoor necks), K is split across grid.y and a second pass sums the slices.
+//  * The LDS-DMA kernel (cfg 4x/5x) is used whenever its preconditions hold, else the same tile on v2 / v1.
+static ConvPlan plan_conv(const ConvParams &p, bool allow_split) {
+  ConvPlan pl = {g_tile_override, true, 1};
+  if (pl.cfg >= 100) {  // 100 + c: force the generic (v1) kernel with tile config c
+    pl.v2 = false;
+    pl.cfg -= 100;
+    return pl;
+  }
+  if (pl.cfg != 0) return pl;
+  const bool dma_ok = dma_applicable(p);
+  const long long nblk = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+  if (p.Cout <= 32) {
+    pl.cfg = dma_ok ? 44 : 4;
+  } else if (nblk >= 2500) {
+    pl.cfg = p.Cout > 64 ? (dma_ok ? 51 : 1) : (dma_ok ? 43 : 3);
+  } else {
+    pl.cfg = dma_ok ? 46 : 6;
+    if (dma_ok && allow_split && g_tile_override == 0) {
+      const long long tiles = (long long)((p.M + 63) / 64) * ((p.Cout + 63) / 64);
+      const int S = (p.K + 31) / 32;
+      if (tiles < 384 && S >= 16) {
+        long long ks = (768 + tiles - 1) / tiles;
+        if (ks > S / 8) ks = S / 8;
+        if (ks > 32) ks = 32;
+        if (ks >= 2) pl.ksplit = (int)ks;
+      }
+    }
+  }
+  return pl;
+}
+
+static int run_conv(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
+  if (p.kmode == 1 && (!dma_applicable(p) || !pl.v2)) {
+    ivx_set_error("ivx_conv_fwd: wgt_layout 1 is only implemented by the buffer-load kernels (tensor < 2 GiB, kernel extents <= 8)");
+    return IVX_ERR_UNSUPPORTED;
+  }
+  const bool v2 = pl.v2;
+  switch (pl.cfg) {
+    case 1: launch_cfg<2, 2, 2, 2>(p, st, v2); break;  // 128 x 128, 2 workgroups/CU
+    case 2: launch_cfg<2, 2, 4, 1>(p, st, v2); break;  // 256 x 64, 1 workgroup/CU
+    case 3: launch_cfg<2, 1, 2, 2>(p, st, v2); break;  // 128 x 64
+    case 4: launch_cfg<1, 1, 4, 1>(p, st, v2); break;  // 128 x 32
+    case 5: launch_cfg<1, 2, 4, 1>(p, st, v2); break;  // 128 x 64 (wave 32 x 64)
+    case 6: launch_cfg<1, 1, 2, 2>(p, st, v2); break;  // 64 x 64
+    case 7: launch_cfg<1, 2, 2, 2>(p, st, v2); break;  // 64 x 128
+    case 41: launch_v4<2, 2, 2, 2>(p, st); break;      // LDS-DMA: 128 x 128, BK 32
+    case 43: launch_v4<2, 1, 2, 2>(p, st); break;      //          128 x 64
+    case 44: launch_v4<1, 1, 4, 1>(p, st); break;      //          128 x 32
+    case 46: launch_v4<1, 1, 2, 2>(p, st); break;      //          64 x 64
+    case 51: launch_v4<2, 2, 2, 2, 16>(p, st); break;  //          128 x 128, BK 16: 32 KB LDS, 3 workgroups/CU
+    case 53: launch_v4<2, 1, 2, 2, 16>(p, st); break;
+    default:
+      ivx_set_error("ivx_conv_fwd: unknown tile override %d", pl.cfg);
+      return IVX_ERR_INVALID_ARG;
+  }
+  if (p.ksplit > 1) {
+    const size_t total = (size_t)p.M * p.Cout;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  }
+  return IVX_OK;
+}
+
 extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
                             const float *shift, const float *res, float *out, ivx_stream_t stream) {
   ConvParams p;
   int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
   if (rc != IVX_OK) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  if (p.kmode == 1) {
-    const int64_t in_b = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4, w_b = (int64_t)p.Cout * p.K * 4;
-    if (!(in_b < (1LL << 31) && w_b < (1LL << 31) && p.KD <= 8 && p.KH <= 8 && p.KW <= 8) || g_tile_override >= 100) {
-      ivx_set_error("ivx_conv_fwd: wgt_layout 1 is only implemented by the buffer-load kernel (tensor < 2 GiB, kernel extents <= 8)");
-      return IVX_ERR_UNSUPPORTED;
-    }
-  }
-  int cfg = g_tile_override;
-  bool v2 = true;
-  if (cfg >= 100) {  // 100 + c: force the generic (v1) kernel with tile config c
-    v2 = false;
-    cfg -= 100;
-  }
-  if (cfg == 0) {
-    // Tile choice (measured per layer on MI355X, tools/conv_bench.py): big problems want the 128-row tiles with the
-    // best MFMA : staging ratio; when 128 x 128 tiles would not fill the 512+ workgroup slots several times over --
-    // every ResNet/FPN layer at KITTI resolution -- 64 x 64 tiles win by occupancy.  The LDS-DMA kernel (v4, 4x) is
-    // used whenever its preconditions hold (tensor < 2 GiB, kernel extents <= 8), else the same tile on v2 / v1.
-    const long long nblk = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-    const int64_t in_b = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4, w_b = (int64_t)p.Cout * p.K * 4;
-    const bool dma_ok = in_b < (1LL << 31) && w_b < (1LL << 31) && p.KD <= 8 && p.KH <= 8 && p.KW <= 8;
-    if (p.Cout <= 32)
-      cfg = dma_ok ? 44 : 4;
-    else if (nblk >= 2500)
-      cfg = p.Cout > 64 ? (dma_ok ? 51 : 1) : (dma_ok ? 43 : 3);   // 51: 128 x 128 with BK 16 -> 3 workgroups per CU
-    else
-      cfg = dma_ok ? 46 : 6;
-  }
-  switch (cfg) {
-    case 1: launch_cfg<2, 2, 2, 2>(p, st, v2); break;  // 128 x 128, 2 blocks/CU
-    case 2: launch_cfg<2, 2, 4, 1>(p, st, v2); break;  // 256 x 64, 1 block/CU
-    case 3: launch_cfg<2, 1, 2, 2>(p, st, v2); break;  // 128 x 64, 2 blocks/CU
-    case 4: launch_cfg<1, 1, 4, 1>(p, st, v2); break;  // 128 x 32
-    case 5: launch_cfg<1, 2, 4, 1>(p, st, v2); break;  // 128 x 64 (wave 32 x 64)
-    case 6: launch_cfg<1, 1, 2, 2>(p, st, v2); break;  // 64 x 64
-    case 41: launch_v4<2, 2, 2, 2>(p, st); break;
-    case 43: launch_v4<2, 1, 2, 2>(p, st); break;
-    case 44: launch_v4<1, 1, 4, 1>(p, st); break;
-    case 46: launch_v4<1, 1, 2, 2>(p, st); break;
-    case 51: launch_v4<2, 2, 2, 2, 16>(p, st); break;  // 128 x 128, BK 16: 32 KB LDS, 3 workgroups per CU
-    case 53: launch_v4<2, 1, 2, 2, 16>(p, st); break;
-    case 7: launch_cfg<1, 2, 2, 2>(p, st, v2); break;  // 64 x 128
-
-    default:
-      ivx_set_error("ivx_conv_fwd: unknown tile override %d", cfg);
-      return IVX_ERR_INVALID_ARG;
-  }
+  const ConvPlan pl = plan_conv(p, false);
+  rc = run_conv(p, pl, (hipStream_t)stream);
+  if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_fwd");
+  return IVX_OK;
+}
+
+extern "C" int64_t ivx_conv_workspace_bytes(const ivx_conv_desc *d) {
+  ConvParams p;
+  float dummy;
+  if (fill_params(d, &dummy, &dummy, nullptr, nullptr, d && d->res_mode ? &dummy : nullptr, &dummy, &p) != IVX_OK) return -1;
+  const ConvPlan pl = plan_conv(p, true);
+  return pl.ksplit > 1 ? ivx_align_up((int64_t)pl.ksplit * p.M * p.Cout * 4, 256) : 0;
+}
+
+extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
+                               const float *shift, const float *res, float *out, void *workspace, int64_t workspace_bytes,
+                               ivx_stream_t stream) {
+  ConvParams p;
+  int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
+  if (rc != IVX_OK) return rc;
+  ConvPlan pl = plan_conv(p, true);
+  if (pl.ksplit > 1) {
+    const int64_t need = (int64_t)pl.ksplit * p.M * p.Cout * 4;
+    if (!workspace || workspace_bytes < need) {
+      ivx_set_error("ivx_conv_fwd_ws: workspace too small (%lld < %lld); size it with ivx_conv_workspace_bytes", (long long)workspace_bytes,
+                    (long long)need);
+      return IVX_ERR_WORKSPACE;
+    }
+    p.ksplit = pl.ksplit;
+    p.partial = (float *)workspace;
+  }
+  rc = run_conv(p, pl, (hipStream_t)stream);
+  if (rc != IVX_OK) return rc;
+  IVX_CHECK_LAUNCH("ivx_conv_fwd_ws");
   return IVX_OK;
 }
 

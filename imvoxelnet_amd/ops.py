@@ -100,8 +100,14 @@ def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1),
         out = torch.empty(oshape, device=x.device, dtype=torch.float32)
     else:
         _chk(out, 'out')
-    fn = L.ivx_conv_fwd_naive if naive else L.ivx_conv_fwd
-    check(fn(C.byref(d), _ptr(x), _ptr(wgt), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _stream()), 'ivx_conv_fwd')
+    if naive:
+        check(L.ivx_conv_fwd_naive(C.byref(d), _ptr(x), _ptr(wgt), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _stream()),
+              'ivx_conv_fwd_naive')
+        return out
+    wsb = L.ivx_conv_workspace_bytes(C.byref(d))
+    ws = torch.empty((wsb,), device=x.device, dtype=torch.uint8) if wsb > 0 else None
+    check(L.ivx_conv_fwd_ws(C.byref(d), _ptr(x), _ptr(wgt), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _ptr(ws), max(wsb, 0),
+                            _stream()), 'ivx_conv_fwd_ws')
     return out
 
 

@@ -80,6 +80,13 @@ typedef struct ivx_conv_desc {
 int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *Ho, int32_t *Wo);
 int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
                  const float *shift, const float *res, float *out, ivx_stream_t stream);
+/* Same as ivx_conv_fwd with a caller-owned workspace of ivx_conv_workspace_bytes(d) bytes (0 for most layers): lets
+ * the library split K across workgroups for layers whose output is too small to fill the chip (ResNet stage 4, FPN
+ * laterals on C5, coarse levels of the indoor necks); slices are summed in a fixed order (deterministic).        */
+int64_t ivx_conv_workspace_bytes(const ivx_conv_desc *d);
+int ivx_conv_fwd_ws(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale, const float *shift,
+                    const float *res, float *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
+
 /* Validation kernel: same contract, one thread per output element, plain FMA loop. Used by the
  * GPU tests to cross-check the MFMA kernel at full size; never called by the product path.   */
 int ivx_conv_fwd_naive(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,

@@ -36,6 +36,10 @@ CONV_CASES = [
     ('k3_2d_c64_s2', 1, 64, 1, 30, 44, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1), False, True, False, True),
     ('stem7x7', 1, 4, 1, 64, 96, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), False, True, False, True),
     ('k3_c256_big_k', 1, 256, 6, 6, 3, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, True, True, True),
+    # small output, long K: the split-K path (K sliced over grid.y + deterministic reduction with the fused epilogue)
+    ('splitk_res4_3x3', 2, 512, 1, 12, 20, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, True, True, True),
+    ('splitk_fpn_lat3', 1, 2048, 1, 12, 40, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), True, False, False, False),
+    ('splitk_3d_coarse', 1, 256, 5, 5, 2, 192, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, True, True, True),
 ]
 
 
@@ -68,6 +72,14 @@ def test_conv_vs_torch_fp32(ia, case):
     assert_close(name + ' naive-vs-torch', uncl(yn), ref, 1e-4, 1e-4)
     assert_close(name + ' mfma-vs-torch', uncl(y), ref, 1e-4, 1e-4)
     assert_close(name + ' mfma-vs-naive', uncl(y), uncl(yn), 1e-4, 5e-5)
+    if name.startswith('splitk'):
+        import ctypes as C
+        from imvoxelnet_amd import _lib
+        d = _lib.ConvDesc(B, D, H, W, Cin, Cout, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2], int(relu), int(res), 0, 0,
+                          fc.layout, 0, 0, 1.0)
+        assert _lib.lib().ivx_conv_workspace_bytes(C.byref(d)) > 0, 'this case is meant to exercise split-K'
+        y2 = fc(xc, res=rc)
+        assert torch.equal(y, y2), 'split-K must be deterministic'
 
 
 def test_conv_config_variants(ia):
