@@ -38,8 +38,11 @@ struct ConvParams {
   int Cr;             // real output channels (Cout / 8 when out_mode == 1, else Cout)
   int res_after_act;  // add the residual after the activation (skip connections of the U-shaped necks)
   float post_scale;   // final multiplier (Atlas neck (x + y) / 2); 1 = none
-  int ksplit;         // > 1: split-K, grid.y = slice; raw partial sums go to `partial` [ksplit][M][Cout]
+  int ksplit;         // > 1: split-K, grid.y = slice; raw partial sums go to `partial` [ksplit][8*q_count*BM][Cout]
   float *partial;
+  // M-tile range of this launch (LDS-DMA kernel): XCD x owns tiles [x*q_total, (x+1)*q_total); this launch covers the
+  // q_count tiles starting at q_begin inside every XCD's range.  Whole problem: q_begin 0, q_count q_total.
+  int q_total, q_begin, q_count, bm;
 };
 
 #define IVX_BK 32
@@ -525,13 +528,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
   // speed only): XCD x owns the contiguous M-tiles [x*q, (x+1)*q) so halo re-reads of neighbouring x-slabs hit its own
   // L2, and inside an XCD the Nt workgroups that share one A-tile are consecutive, so they run together and the
   // A-tile is fetched into that L2 once instead of once per N-tile.  Ids past the last M-tile exit (< 8*Nt of them).
-  int mt, nt;
+  int mt, nt, ct;   // ct: compact tile id inside this launch (split-K partial rows)
   {
     const int Nt = (p.Cout + BN - 1) / BN;
-    const int q = gridDim.x / (8 * Nt);
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    mt = xcd * q + idx / Nt;
-    nt = idx % Nt;
+    const int lt = idx / Nt;
+    nt = idx - lt * Nt;
+    mt = xcd * p.q_total + p.q_begin + lt;
+    ct = xcd * p.q_count + lt;
   }
   if (mt * BM >= p.M) return;
   const int m0 = mt * BM;
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
   }
   if (p.ksplit > 1) {
     // raw partial sums; ivx split-K reduce kernel applies the epilogue
-    float *part = p.partial + (size_t)blockIdx.y * p.M * p.Cout;
+    float *part = p.partial + ((size_t)blockIdx.y * 8 * p.q_count + ct) * BM * p.Cout;   // rows of this tile, slice y
     const int col_l = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int n = n0 + (wc * TN + j) * 32 + col_l;
-          if (n < p.Cout) part[(size_t)m * p.Cout + n] = acc[i][j][r];
+          if (n < p.Cout) part[(size_t)(m - m0) * p.Cout + n] = acc[i][j][r];
         }
       }
     return;
@@ -741,13 +745,21 @@ __device__ __forceinline__ void conv_store_one(const ConvParams &p, int m, int n
   p.out[idx] = conv_finish(p, acc, p.scale ? p.scale[n] : 1.0f, p.shift ? p.shift[n] : 0.0f, ridx);
 }
 
-// Split-K reduction: out = epilogue(sum over slices in slice order) -- deterministic.
+// Split-K reduction: out = epilogue(sum over slices in slice order) -- deterministic.  Partial rows are compact:
+// row cr = (xcd*q_count + local_tile)*bm + row_in_tile  <->  m = (xcd*q_total + q_begin + local_tile)*bm + row_in_tile.
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
-  const size_t total = (size_t)p.M * p.Cout;
+  const size_t rows = (size_t)8 * p.q_count * p.bm;
+  const size_t total = rows * p.Cout;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % p.Cout);
+    const size_t cr = idx / p.Cout;
+    const int ctile = (int)(cr / p.bm), rit = (int)(cr - (size_t)ctile * p.bm);
+    const int xcd = ctile / p.q_count, lt = ctile - xcd * p.q_count;
+    const long long m = (long long)(xcd * p.q_total + p.q_begin + lt) * p.bm + rit;
+    if (m >= p.M) continue;
     float acc = 0.f;
     for (int z = 0; z < p.ksplit; ++z) acc += p.partial[(size_t)z * total + idx];
-    conv_store_one(p, (int)(idx / p.Cout), (int)(idx % p.Cout), acc);
+    conv_store_one(p, (int)m, n, acc);
   }
 }
 
@@ -819,7 +831,7 @@ static int fill_params(const ivx_conv_desc *d, const float *in, const float *wgt
   p->relu = d->relu; p->res_mode = d->res_mode; p->rH = d->res_h; p->rW = d->res_w; p->kmode = d->wgt_layout;
   p->out_mode = d->out_mode; p->Cr = d->out_mode == 1 ? d->Cout / 8 : d->Cout; p->res_after_act = d->res_after_act;
   p->post_scale = d->post_scale == 0.f ? 1.0f : d->post_scale;
-  p->ksplit = 1; p->partial = nullptr;
+  p->ksplit = 1; p->partial = nullptr; p->q_total = 0; p->q_begin = 0; p->q_count = 0; p->bm = 0;
   return IVX_OK;
 }
 
@@ -854,12 +866,18 @@ static void launch_cfg(const ConvParams &p, hipStream_t st, bool v2) {
 }
 
 template <int TM, int TN, int WR, int WC, int BK = 32>
-static void launch_v4(const ConvParams &p, hipStream_t st) {
+static void launch_v4(ConvParams &p, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4;
   const int64_t w_bytes = (int64_t)p.Cout * p.K * 4;
   const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
-  const long long g1 = 8 * ((Mt + 7) / 8) * Nt;
+  p.bm = BM;
+  if (p.q_total == 0) {  // whole problem in one launch
+    p.q_total = (int)((Mt + 7) / 8);
+    p.q_begin = 0;
+    p.q_count = p.q_total;
+  }
+  const long long g1 = 8LL * p.q_count * Nt;
   hipLaunchKernelGGL((conv_igemm_f32_v4_kernel<TM, TN, WR, WC, BK>), dim3((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, st, p, (unsigned)in_bytes,
                      (unsigned)w_bytes);
 }
@@ -872,10 +890,28 @@ extern "C" int ivx_conv_set_tile_override(int cfg) {
 }
 
 struct ConvPlan {
-  int cfg;       // tile / kernel selector (see the switch in run_conv)
+  int cfg;       // tile / kernel selector (see launch_one)
   bool v2;       // for cfg < 40: buffer-load kernel (true) or the generic kernel (false)
-  int ksplit;    // 1 = no split-K
+  int ksplit;    // > 1: split K over the whole problem (small outputs)
+  int tail_ks;   // > 1: the last partial round of M-tiles runs as a second launch with K split tail_ks ways
+  int q_total;   // M-tiles per XCD (LDS-DMA kernels)
+  int qa;        // M-tiles per XCD covered by the first launch when tail_ks > 1
+  int bm;        // tile rows of the chosen config
+  int64_t ws_bytes;
 };
+
+struct TileInfo { int bm, bn, bk, wg_per_cu; };
+static bool tile_info(int cfg, TileInfo *t) {
+  switch (cfg) {
+    case 41: *t = {128, 128, 32, 2}; return true;
+    case 43: *t = {128, 64, 32, 3}; return true;
+    case 44: *t = {128, 32, 32, 4}; return true;
+    case 46: *t = {64, 64, 32, 5}; return true;
+    case 51: *t = {128, 128, 16, 3}; return true;
+    case 53: *t = {128, 64, 16, 5}; return true;
+    default: return false;
+  }
+}
 
 static bool dma_applicable(const ConvParams &p) {
   const int64_t in_b = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4, w_b = (int64_t)p.Cout * p.K * 4;
@@ -888,42 +924,69 @@ static bool dma_applicable(const ConvParams &p) {
 //    ResNet/FPN layer at KITTI resolution, the indoor necks -- 64 x 64 tiles win by occupancy.
 //  * When even 64 x 64 tiles leave most of the 256 CUs idle and K is long (ResNet stage 4, FPN laterals on C5, the
 //    coarse levels of the indoor necks), K is split across grid.y and a second pass sums the slices.
+//  * Grid tail: with uniform tiles the last partial round costs a whole workgroup time on a few CUs while the rest
+//    idle (measured: 10 044 tiles on 768 slots = 13.08 rounds runs 4 % slower per tile than exactly 13 rounds).
+//    When the remainder is at most half a round, the full rounds run as one launch and the remainder as a second
+//    launch with K split so that it fills every slot once (needs the caller's workspace: ivx_conv_fwd_ws).
 //  * The LDS-DMA kernel (cfg 4x/5x) is used whenever its preconditions hold, else the same tile on v2 / v1.
-static ConvPlan plan_conv(const ConvParams &p, bool allow_split) {
-  ConvPlan pl = {g_tile_override, true, 1};
+static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
+  ConvPlan pl = {g_tile_override, true, 1, 1, 0, 0, 0, 0};
   if (pl.cfg >= 100) {  // 100 + c: force the generic (v1) kernel with tile config c
     pl.v2 = false;
     pl.cfg -= 100;
     return pl;
   }
-  if (pl.cfg != 0) return pl;
   const bool dma_ok = dma_applicable(p);
-  const long long nblk = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-  if (p.Cout <= 32) {
-    pl.cfg = dma_ok ? 44 : 4;
-  } else if (nblk >= 2500) {
-    pl.cfg = p.Cout > 64 ? (dma_ok ? 51 : 1) : (dma_ok ? 43 : 3);
-  } else {
-    pl.cfg = dma_ok ? 46 : 6;
-    if (dma_ok && allow_split && g_tile_override == 0) {
-      const long long tiles = (long long)((p.M + 63) / 64) * ((p.Cout + 63) / 64);
-      const int S = (p.K + 31) / 32;
-      if (tiles < 384 && S >= 16) {
-        long long ks = (768 + tiles - 1) / tiles;
-        if (ks > S / 8) ks = S / 8;
-        if (ks > 32) ks = 32;
-        if (ks >= 2) pl.ksplit = (int)ks;
+  bool small = false;
+  if (pl.cfg == 0) {
+    const long long nblk = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    if (p.Cout <= 32) {
+      pl.cfg = dma_ok ? 44 : 4;
+    } else if (nblk >= 2500) {
+      pl.cfg = p.Cout > 64 ? (dma_ok ? 51 : 1) : (dma_ok ? 43 : 3);
+    } else {
+      pl.cfg = dma_ok ? 46 : 6;
+      small = true;
+    }
+  }
+  TileInfo t;
+  if (!tile_info(pl.cfg, &t) || !dma_ok) return pl;
+  const long long Mt = (p.M + t.bm - 1) / t.bm, Nt = (p.Cout + t.bn - 1) / t.bn;
+  pl.q_total = (int)((Mt + 7) / 8);
+  pl.bm = t.bm;
+  if (!allow_ws || g_tile_override != 0) return pl;
+  const int S = (p.K + t.bk - 1) / t.bk;
+  if (small) {
+    const long long tiles = Mt * Nt;
+    if (tiles < 384 && S >= 16) {
+      long long ks = (768 + tiles - 1) / tiles;
+      if (ks > S / 8) ks = S / 8;
+      if (ks > 32) ks = 32;
+      if (ks >= 2) {
+        pl.ksplit = (int)ks;
+        pl.ws_bytes = ivx_align_up((int64_t)ks * 8 * pl.q_total * t.bm * p.Cout * 4, 256);
       }
+    }
+    return pl;
+  }
+  // tail plan
+  const long long spx = 32LL * t.wg_per_cu;              // workgroup slots per XCD
+  const long long bpx = (long long)pl.q_total * Nt;      // workgroups per XCD
+  const long long fr = bpx / spx, rem = bpx - fr * spx;
+  if (fr >= 2 && rem > 0 && 2 * rem <= spx && (fr * spx) % Nt == 0) {
+    long long ks = spx / rem;
+    if (ks > S / 8) ks = S / 8;
+    if (ks > 16) ks = 16;
+    if (ks >= 2) {
+      pl.tail_ks = (int)ks;
+      pl.qa = (int)(fr * spx / Nt);
+      pl.ws_bytes = ivx_align_up((int64_t)ks * 8 * (pl.q_total - pl.qa) * t.bm * p.Cout * 4, 256);
     }
   }
   return pl;
 }
 
-static int run_conv(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
-  if (p.kmode == 1 && (!dma_applicable(p) || !pl.v2)) {
-    ivx_set_error("ivx_conv_fwd: wgt_layout 1 is only implemented by the buffer-load kernels (tensor < 2 GiB, kernel extents <= 8)");
-    return IVX_ERR_UNSUPPORTED;
-  }
+static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
   const bool v2 = pl.v2;
   switch (pl.cfg) {
     case 1: launch_cfg<2, 2, 2, 2>(p, st, v2); break;  // 128 x 128, 2 workgroups/CU
@@ -943,12 +1006,38 @@ static int run_conv(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
       ivx_set_error("ivx_conv_fwd: unknown tile override %d", pl.cfg);
       return IVX_ERR_INVALID_ARG;
   }
-  if (p.ksplit > 1) {
-    const size_t total = (size_t)p.M * p.Cout;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  return IVX_OK;
+}
+
+static void launch_reduce(const ConvParams &p, hipStream_t st) {
+  const size_t total = (size_t)8 * p.q_count * p.bm * p.Cout;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+}
+
+static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStream_t st) {
+  if (p.kmode == 1 && (!dma_applicable(p) || !pl.v2)) {
+    ivx_set_error("ivx_conv_fwd: wgt_layout 1 is only implemented by the buffer-load kernels (tensor < 2 GiB, kernel extents <= 8)");
+    return IVX_ERR_UNSUPPORTED;
   }
+  int rc;
+  if (pl.tail_ks > 1) {
+    // full rounds ...
+    p.q_total = pl.q_total; p.q_begin = 0; p.q_count = pl.qa; p.ksplit = 1; p.partial = nullptr;
+    if ((rc = launch_one(p, pl, st)) != IVX_OK) return rc;
+    // ... then the remainder, K split so that it fills every workgroup slot once
+    p.q_begin = pl.qa; p.q_count = pl.q_total - pl.qa; p.ksplit = pl.tail_ks; p.partial = (float *)workspace;
+    if ((rc = launch_one(p, pl, st)) != IVX_OK) return rc;
+    launch_reduce(p, st);
+    return IVX_OK;
+  }
+  if (pl.ksplit > 1) {
+    p.ksplit = pl.ksplit;
+    p.partial = (float *)workspace;
+  }
+  if ((rc = launch_one(p, pl, st)) != IVX_OK) return rc;
+  if (pl.ksplit > 1) launch_reduce(p, st);
   return IVX_OK;
 }
 
@@ -958,7 +1047,7 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float
   int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
   if (rc != IVX_OK) return rc;
   const ConvPlan pl = plan_conv(p, false);
-  rc = run_conv(p, pl, (hipStream_t)stream);
+  rc = run_conv(p, pl, nullptr, (hipStream_t)stream);
   if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_fwd");
   return IVX_OK;
@@ -968,8 +1057,7 @@ extern "C" int64_t ivx_conv_workspace_bytes(const ivx_conv_desc *d) {
   ConvParams p;
   float dummy;
   if (fill_params(d, &dummy, &dummy, nullptr, nullptr, d && d->res_mode ? &dummy : nullptr, &dummy, &p) != IVX_OK) return -1;
-  const ConvPlan pl = plan_conv(p, true);
-  return pl.ksplit > 1 ? ivx_align_up((int64_t)pl.ksplit * p.M * p.Cout * 4, 256) : 0;
+  return plan_conv(p, true).ws_bytes;
 }
 
 extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
@@ -978,18 +1066,13 @@ extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const float *in, const fl
   ConvParams p;
   int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
   if (rc != IVX_OK) return rc;
-  ConvPlan pl = plan_conv(p, true);
-  if (pl.ksplit > 1) {
-    const int64_t need = (int64_t)pl.ksplit * p.M * p.Cout * 4;
-    if (!workspace || workspace_bytes < need) {
-      ivx_set_error("ivx_conv_fwd_ws: workspace too small (%lld < %lld); size it with ivx_conv_workspace_bytes", (long long)workspace_bytes,
-                    (long long)need);
-      return IVX_ERR_WORKSPACE;
-    }
-    p.ksplit = pl.ksplit;
-    p.partial = (float *)workspace;
+  const ConvPlan pl = plan_conv(p, true);
+  if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes)) {
+    ivx_set_error("ivx_conv_fwd_ws: workspace too small (%lld < %lld); size it with ivx_conv_workspace_bytes", (long long)workspace_bytes,
+                  (long long)pl.ws_bytes);
+    return IVX_ERR_WORKSPACE;
   }
-  rc = run_conv(p, pl, (hipStream_t)stream);
+  rc = run_conv(p, pl, workspace, (hipStream_t)stream);
   if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_fwd_ws");
   return IVX_OK;

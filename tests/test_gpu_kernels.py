@@ -108,6 +108,28 @@ def test_conv_config_variants(ia):
         L.ivx_conv_set_tile_override(0)
 
 
+def test_conv_grid_tail_split(ia):
+    """Large-M layer whose last partial round of tiles is run as a second, K-split launch (plan_conv tail plan):
+    same result as the validation kernel, deterministic, and the plan really asks for a workspace."""
+    import ctypes as C
+    from imvoxelnet_amd import _lib
+    from imvoxelnet_amd.conv import FusedConv
+    g = torch.Generator(device='cuda').manual_seed(31)
+    x = torch.randn(1, 1, 580, 560, 128, device='cuda', generator=g)
+    w = torch.randn(64, 128, 3, 3, generator=torch.Generator().manual_seed(32)) * 0.03
+    bn = (torch.rand(64) + .5, torch.randn(64) * .1, torch.randn(64) * .1, torch.rand(64) + .5)
+    r = torch.randn(1, 1, 580, 560, 64, device='cuda', generator=g)
+    fc = FusedConv(w, bn=bn, padding=1, relu=True, dims=2).to('cuda')
+    d = _lib.ConvDesc(1, 1, 580, 560, 128, 64, 1, 3, 3, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, fc.layout, 0, 0, 1.0)
+    assert _lib.lib().ivx_conv_workspace_bytes(C.byref(d)) > 0, 'expected the tail plan (2 full rounds + remainder)'
+    y = fc(x, res=r)
+    yn = fc(x, res=r, naive=True)
+    err = (y - yn).abs().max().item()
+    print('tail-split vs naive max err', err)
+    assert err < 1e-4
+    assert torch.equal(y, fc(x, res=r))
+
+
 def test_conv_fpn_upsample_residual(ia):
     """res_mode 2: lateral 1x1 conv + nearest-upsampled coarser level (exact x2 and non-integer ratio)."""
     from imvoxelnet_amd.conv import FusedConv

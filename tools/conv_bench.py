@@ -19,6 +19,9 @@ LAYERS = [
     ('down2 128->256 s112', (216, 248, 6), 128, 256, (1, 1, 2), (1, 1, 1)),
     ('b3.conv 256->256 z3', (216, 248, 3), 256, 256, (1, 1, 1), (1, 1, 1)),
     ('last 256->256 p0', (216, 248, 3), 256, 256, (1, 1, 1), (0, 0, 0)),
+    # tail experiment: 128->128 at exactly 13 x 768 M-tiles (B=4) vs the KITTI shape's 13.08 rounds
+    ('b2-like exact 9984 tiles', (208, 256, 6), 128, 128, (1, 1, 1), (1, 1, 1)),
+    ('b2-like 9984+384 tiles', (216, 256, 6), 128, 128, (1, 1, 1), (1, 1, 1)),
 ]
 
 
