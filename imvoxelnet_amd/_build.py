@@ -13,6 +13,7 @@ SOURCES = [
     ('pool_layout.hip', []),
     ('backproject.hip', ['-ffp-contract=off']),
     ('anchor_tail.hip', ['-ffp-contract=off']),
+    ('dcn.hip', []),
     ('api_common.cpp', []),
 ]
 

@@ -16,12 +16,16 @@ from .registry import BACKBONES, NECKS
 
 
 class _Bottleneck(nn.Module):
-    def __init__(self, cin, planes, stride, downsample):
+    def __init__(self, cin, planes, stride, downsample, dcn=False):
         super().__init__()
         self.stride = stride
+        self.dcn = dcn
         self.conv1 = ConvParams(cin, planes, 1, dims=2)
         self.bn1 = BNParams(planes)
         self.conv2 = ConvParams(planes, planes, 3, dims=2)
+        if dcn:   # ModulatedDeformConv2dPack: offsets (2*9) + masks (9) from a companion 3x3 conv, zero-initialised
+            self.conv2.conv_offset = ConvParams(planes, 27, 3, bias=True, dims=2)
+            nn.init.zeros_(self.conv2.conv_offset.weight)
         self.bn2 = BNParams(planes)
         self.conv3 = ConvParams(planes, planes * 4, 1, dims=2)
         self.bn3 = BNParams(planes * 4)
@@ -33,7 +37,14 @@ class _Bottleneck(nn.Module):
     def prepare(self, device):
         # style='pytorch': the stride sits on the 3x3 conv
         self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2).to(device)
-        self.f2 = FusedConv(self.conv2.weight, bn=self.bn2.tensors(), stride=self.stride, padding=1, relu=True, dims=2).to(device)
+        if self.dcn:
+            co = self.conv2.conv_offset
+            self.f_off = FusedConv(co.weight, co.bias, stride=self.stride, padding=1, dims=2).to(device)
+            w = self.conv2.weight.detach()                               # [Cout, C, 3, 3] -> 1x1 over K = (tap, c)
+            w_col = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1, 1, 1)
+            self.f2 = FusedConv(w_col, bn=self.bn2.tensors(), relu=True, dims=2).to(device)
+        else:
+            self.f2 = FusedConv(self.conv2.weight, bn=self.bn2.tensors(), stride=self.stride, padding=1, relu=True, dims=2).to(device)
         self.f3 = FusedConv(self.conv3.weight, bn=self.bn3.tensors(), relu=True, dims=2).to(device)  # relu after the add
         self.fd = None
         if self.downsample is not None:
@@ -41,7 +52,12 @@ class _Bottleneck(nn.Module):
 
     def forward_cl(self, x):
         idt = x if self.fd is None else self.fd(x)
-        return self.f3(self.f2(self.f1(x)), res=idt)
+        y = self.f1(x)
+        if self.dcn:
+            y = self.f2(ops.dcn_im2col(y, self.f_off(y), 3, self.stride, 1, 1))
+        else:
+            y = self.f2(y)
+        return self.f3(y, res=idt)
 
 
 @BACKBONES.register_module()
@@ -49,14 +65,17 @@ class ResNet(nn.Module):
     arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
     def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_cfg=None, norm_eval=True,
-                 style='pytorch', in_channels=3, **kwargs):
+                 style='pytorch', in_channels=3, dcn=None, stage_with_dcn=(False, False, False, False), **kwargs):
         super().__init__()
         if depth not in self.arch:
             raise KeyError(f'ResNet depth {depth} is not built (bottleneck depths: {sorted(self.arch)})')
         if style != 'pytorch':
             raise NotImplementedError("only style='pytorch' (stride on the 3x3 conv) is built")
-        if kwargs.get('dcn') is not None:
-            raise NotImplementedError('DCNv2 stages (nuScenes reference config) are not built; see DESIGN.md')
+        if dcn is not None:
+            if dcn.get('type') != 'DCNv2' or dcn.get('deform_groups', 1) != 1:
+                raise NotImplementedError('only dcn=dict(type="DCNv2", deform_groups=1) (the nuScenes ImVoxelNet config) is built')
+            if dcn.get('fallback_on_stride', False):
+                raise NotImplementedError('fallback_on_stride=True is not built')
         self.out_indices = tuple(out_indices)
         self.conv1 = ConvParams(in_channels, 64, 7, dims=2)
         self.bn1 = BNParams(64)
@@ -66,7 +85,8 @@ class ResNet(nn.Module):
             planes = 64 * 2 ** i
             layer = []
             for j in range(nb):
-                layer.append(_Bottleneck(cin, planes, (2 if i > 0 else 1) if j == 0 else 1, downsample=(j == 0)))
+                layer.append(_Bottleneck(cin, planes, (2 if i > 0 else 1) if j == 0 else 1, downsample=(j == 0),
+                                         dcn=dcn is not None and bool(stage_with_dcn[i])))
                 cin = planes * 4
             setattr(self, f'layer{i + 1}', nn.Sequential(*layer))
         self.num_stages = len(blocks)

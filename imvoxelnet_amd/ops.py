@@ -122,6 +122,21 @@ def maxpool2d(x, k=3, s=2, p=1):
     return out
 
 
+def dcn_im2col(x, offset_mask, kernel=3, stride=1, pad=1, dil=1):
+    """x [B,1,H,W,C], offset_mask [B,1,Ho,Wo,>=3*k*k] -> modulated deformable columns [B,1,Ho,Wo,k*k*C]."""
+    _chk(x, 'x')
+    _chk(offset_mask, 'offset_mask')
+    B, D, H, W, Cn = x.shape
+    Ho = (H + 2 * pad - (dil * (kernel - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (kernel - 1) + 1)) // stride + 1
+    if D != 1 or tuple(offset_mask.shape[:4]) != (B, 1, Ho, Wo):
+        raise ValueError('offset/mask map does not match the output size')
+    col = torch.empty((B, 1, Ho, Wo, kernel * kernel * Cn), device=x.device, dtype=torch.float32)
+    check(_lib.lib().ivx_dcn_im2col_fwd(_ptr(x), _ptr(offset_mask), B, H, W, Cn, kernel, kernel, stride, pad, dil,
+                                        offset_mask.shape[4], _ptr(col), _stream()), 'ivx_dcn_im2col_fwd')
+    return col
+
+
 def upsample_trilinear2x(x):
     _chk(x, 'x')
     B, D, H, W, Cn = x.shape

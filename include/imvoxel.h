@@ -95,6 +95,16 @@ int ivx_conv_fwd_naive(const ivx_conv_desc *d, const float *in, const float *wgt
 /* Tuning knob for A/B experiments only: 0 = automatic tile choice (default), 1..6 = force a tile config. */
 int ivx_conv_set_tile_override(int cfg);
 
+/* Modulated deformable convolution (DCNv2; mmcv ModulatedDeformConv2dPack, deform_groups = 1) -- nuScenes reference
+ * backbone, configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14.  Builds the modulated, bilinearly sampled columns
+ *   col[b,ho,wo,k,c] = sigmoid(m_k) * bilinear(x[b,:,:,c], ho*s - p + i*d + dh_k, wo*s - p + j*d + dw_k)     (k = i*kw + j)
+ * from x [B,H,W,C] and the raw output offset_mask [B,Ho,Wo,om_channels] of the companion conv_offset (channels
+ * dh_0,dw_0,...,dh_{K-1},dw_{K-1},m_0..m_{K-1}).  The contraction over (k,c) is ivx_conv_fwd with a 1x1 kernel and
+ * Cin = kh*kw*C on col viewed as [B,1,Ho,Wo,kh*kw*C].  C % 4 == 0. */
+int ivx_dcn_im2col_fwd(const float *x, const float *offset_mask, int32_t B, int32_t H, int32_t W, int32_t C, int32_t kh,
+                       int32_t kw, int32_t stride, int32_t pad, int32_t dil, int32_t om_channels, float *col,
+                       ivx_stream_t stream);
+
 /* nn.MaxPool2d(kernel, stride, padding) on NHWC (ResNet stem: 3, 2, 1). */
 int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
                       int32_t s, int32_t p, float *out, ivx_stream_t stream);

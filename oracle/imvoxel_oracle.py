@@ -175,6 +175,40 @@ def _bn2(x, sd, p):
     return bn_eval(x, sd, p)
 
 
+def modulated_deform_conv2d(x, raw_offset_mask, weight, stride=1, pad=1, dil=1):
+    """DCNv2 (mmcv-full 1.2.7 ModulatedDeformConv2dPack, deform_groups=1) restated in torch: PARITY UNPINNED (mmcv is
+    not in the reference tree).  x [B,C,H,W]; raw_offset_mask [B,3*K,Ho,Wo] = conv_offset(x): channels 2k / 2k+1 are
+    (dh, dw) of tap k, channels 2K+k the mask logits; weight [Co,C,kh,kw]."""
+    B, C, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    K = kh * kw
+    Ho, Wo = raw_offset_mask.shape[-2:]
+    mask = torch.sigmoid(raw_offset_mask[:, 2 * K:3 * K])
+    hs = torch.arange(Ho, dtype=torch.float32).view(1, Ho, 1) * stride - pad
+    ws = torch.arange(Wo, dtype=torch.float32).view(1, 1, Wo) * stride - pad
+    xf = x.reshape(B, C, H * W)
+    out = torch.zeros(B, Co, Ho, Wo)
+    for k in range(K):
+        i, j = k // kw, k % kw
+        h_im = hs + i * dil + raw_offset_mask[:, 2 * k]
+        w_im = ws + j * dil + raw_offset_mask[:, 2 * k + 1]
+        inside = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
+        h_low, w_low = torch.floor(h_im), torch.floor(w_im)
+        lh, lw = h_im - h_low, w_im - w_low
+        val = torch.zeros(B, C, Ho, Wo)
+        for (hy, wx, wt, ok) in ((h_low, w_low, (1 - lh) * (1 - lw), (h_low >= 0) & (w_low >= 0)),
+                                 (h_low, w_low + 1, (1 - lh) * lw, (h_low >= 0) & (w_low + 1 <= W - 1)),
+                                 (h_low + 1, w_low, lh * (1 - lw), (h_low + 1 <= H - 1) & (w_low >= 0)),
+                                 (h_low + 1, w_low + 1, lh * lw, (h_low + 1 <= H - 1) & (w_low + 1 <= W - 1))):
+            ok = ok & inside
+            lin = (hy.clamp(0, H - 1) * W + wx.clamp(0, W - 1)).long().view(B, 1, Ho * Wo).expand(B, C, Ho * Wo)
+            g = torch.gather(xf, 2, lin).view(B, C, Ho, Wo)
+            val = val + g * (wt * ok.float()).unsqueeze(1)
+        val = val * mask[:, k:k + 1]
+        out = out + torch.einsum('oc,bchw->bohw', weight[:, :, i, j], val)
+    return out
+
+
 def resnet50(x, sd, prefix='backbone.'):
     x = F.relu(_bn2(F.conv2d(x, sd[prefix + 'conv1.weight'], None, 2, 3), sd, prefix + 'bn1'))
     x = F.max_pool2d(x, 3, 2, 1)
@@ -185,7 +219,11 @@ def resnet50(x, sd, prefix='backbone.'):
             stride = 2 if (bi == 0 and li > 0) else 1
             idt = x
             o = F.relu(_bn2(F.conv2d(x, sd[p + '.conv1.weight']), sd, p + '.bn1'))
-            o = F.relu(_bn2(F.conv2d(o, sd[p + '.conv2.weight'], None, stride, 1), sd, p + '.bn2'))
+            if p + '.conv2.conv_offset.weight' in sd:      # DCNv2 stage (nuScenes reference backbone)
+                om = F.conv2d(o, sd[p + '.conv2.conv_offset.weight'], sd[p + '.conv2.conv_offset.bias'], stride, 1)
+                o = F.relu(_bn2(modulated_deform_conv2d(o, om, sd[p + '.conv2.weight'], stride, 1, 1), sd, p + '.bn2'))
+            else:
+                o = F.relu(_bn2(F.conv2d(o, sd[p + '.conv2.weight'], None, stride, 1), sd, p + '.bn2'))
             o = _bn2(F.conv2d(o, sd[p + '.conv3.weight']), sd, p + '.bn3')
             if bi == 0:
                 idt = _bn2(F.conv2d(x, sd[p + '.downsample.0.weight'], None, stride), sd, p + '.downsample.1')

@@ -42,9 +42,13 @@ def _resnet_fpn(cf):
                 neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=cf, num_outs=4))
 
 
-def nuscenes_model_cfg(n_voxels=(312, 312, 12)):
-    """imvoxelnet_nuscenes.py:1-68 with a plain ResNet-50 (the reference adds DCNv2 in stages 3-4: not built)."""
-    return dict(type='ImVoxelNet', pretrained=None, **_resnet_fpn(64),
+def nuscenes_model_cfg(n_voxels=(312, 312, 12), dcn=True):
+    """imvoxelnet_nuscenes.py:1-68 (ResNet-50 with DCNv2 in stages 3-4, as the reference; dcn=False: plain ResNet-50)."""
+    trunk = _resnet_fpn(64)
+    if dcn:
+        trunk['backbone'].update(dcn=dict(type='DCNv2', deform_groups=1, fallback_on_stride=False),
+                                 stage_with_dcn=(False, False, True, True))
+    return dict(type='ImVoxelNet', pretrained=None, **trunk,
                 neck_3d=dict(type='NuScenesImVoxelNeck', in_channels=64, out_channels=256),
                 bbox_head=dict(type='Anchor3DHead', num_classes=1, in_channels=256, feat_channels=256, use_direction_classifier=True,
                                anchor_generator=dict(type='Anchor3DRangeGenerator', sizes=[[1.98, 4.67, 1.74]],

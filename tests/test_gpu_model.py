@@ -44,6 +44,27 @@ def test_resnet50_fpn_vs_oracle(ia):
     assert_close('fpn0', p, ref0, 2e-3, 2e-3 * float(ref0.abs().max()))
 
 
+def test_resnet50_dcnv2_vs_oracle(ia):
+    """nuScenes reference backbone: ResNet-50 with DCNv2 in stages 3-4 (deformable im2col kernel + MFMA GEMM) against
+    the torch restatement of mmcv's ModulatedDeformConv2dPack (parity unpinned upstream)."""
+    from oracle import imvoxel_oracle as orc
+    bb = ia.ResNet(depth=50, dcn=dict(type='DCNv2', deform_groups=1, fallback_on_stride=False), stage_with_dcn=(False, False, True, True))
+    ia.randomize_(bb, 4)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        for name, m in bb.named_modules():
+            if name.endswith('conv_offset'):          # sub-pixel offsets of a few pixels, mixed mask values
+                m.weight.normal_(0, 0.02, generator=g)
+                m.bias.normal_(0, 0.5, generator=g)
+    img = torch.randn(2, 3, 96, 128, generator=torch.Generator().manual_seed(6))
+    sd = {'backbone.' + k: v for k, v in _cpu_sd(bb).items()}
+    with torch.no_grad():
+        feats = orc.resnet50(img, sd)
+    outs = bb(img.cuda())
+    for i, (o, r) in enumerate(zip(outs, feats)):
+        assert_close(f'C{i + 2} (dcn)', o, r, 2e-3, 2e-3 * float(r.abs().max()))
+
+
 def test_kitti_full_path_vs_oracle(ia):
     """BASELINE config 2 at full size (1 x 3x384x1280, 216x248x12 voxels), batch 1: feature volume within 1e-3,
     valid mask exact, identical kept anchors after NMS (north_star parity clause)."""

@@ -207,3 +207,21 @@ def test_indoor_heads(name):
         assert np.array_equal(labels.numpy(), g[p + f'labels{b}'])
         np.testing.assert_allclose(scores.numpy(), g[p + f'scores{b}'], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(boxes.numpy(), g[p + f'boxes{b}'], rtol=1e-5, atol=1e-6)
+
+
+def test_dcn_restatement_reduces_to_plain_conv():
+    """Sanity pin of the (unpinned) DCNv2 restatement: zero offsets and mask logits -> 0.5 * ordinary convolution;
+    integer offsets -> the shifted convolution tap."""
+    g = torch.Generator().manual_seed(70)
+    x = torch.randn(2, 6, 9, 11, generator=g)
+    w = torch.randn(5, 6, 3, 3, generator=g)
+    for stride in (1, 2):
+        Ho, Wo = (9 + 2 - 3) // stride + 1, (11 + 2 - 3) // stride + 1
+        om = torch.zeros(2, 27, Ho, Wo)
+        ref = 0.5 * torch.nn.functional.conv2d(x, w, None, stride, 1)
+        np.testing.assert_allclose(orc.modulated_deform_conv2d(x, om, w, stride, 1, 1).numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    om = torch.zeros(2, 27, 9, 11)
+    om[:, 18:] = 20.0                      # mask ~ 1
+    om[:, 0:18:2] = 1.0                    # every tap shifted one row down
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (1, 1, 0, 2)), w, None, 1, 0)   # rows h..h+2 instead of h-1..h+1
+    np.testing.assert_allclose(orc.modulated_deform_conv2d(x, om, w, 1, 1, 1).numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
