@@ -79,6 +79,45 @@ class BaseInstance3DBoxes:
         gc[:, 2] = bc[:, 2] + self.tensor[:, 5] * 0.5
         return gc
 
+    top_height = property(lambda self: self.tensor[:, 2] + self.tensor[:, 5])
+    bottom_height = property(lambda self: self.tensor[:, 2])
+
+    def new_box(self, data):
+        t = self.tensor.new_tensor(data) if not isinstance(data, torch.Tensor) else data.to(self.tensor.device)
+        return type(self)(t, box_dim=self.box_dim, with_yaw=self.with_yaw)
+
+    @classmethod
+    def height_overlaps(cls, boxes1, boxes2, mode='iou'):
+        """base_box3d.py:352-381."""
+        lowest_top = torch.min(boxes1.top_height.view(-1, 1), boxes2.top_height.view(1, -1))
+        highest_bottom = torch.max(boxes1.bottom_height.view(-1, 1), boxes2.bottom_height.view(1, -1))
+        return torch.clamp(lowest_top - highest_bottom, min=0)
+
+    # hook so CPU-only tests can substitute the oracle; the product path is the device kernel
+    _bev_overlap_fn = None
+
+    @classmethod
+    def overlaps(cls, boxes1, boxes2, mode='iou'):
+        """base_box3d.py:383-443: 3-D IoU / IoF = rotated-BEV overlap x height overlap / (v1 + v2 - overlap).  Like the
+        reference, the BEV overlap runs on the device whatever device the boxes live on."""
+        assert type(boxes1) == type(boxes2), f'boxes of different types: {type(boxes1)} and {type(boxes2)}'
+        assert mode in ('iou', 'iof')
+        rows, cols = len(boxes1), len(boxes2)
+        if rows * cols == 0:
+            return boxes1.tensor.new(rows, cols)
+        overlaps_h = cls.height_overlaps(boxes1, boxes2)
+        b1, b2 = xywhr2xyxyr(boxes1.bev), xywhr2xyxyr(boxes2.bev)
+        if cls._bev_overlap_fn is not None:
+            overlaps_bev = cls._bev_overlap_fn(b1, b2)
+        else:
+            from .nms import boxes_overlap_bev
+            overlaps_bev = boxes_overlap_bev(b1.contiguous().cuda(), b2.contiguous().cuda())
+        overlaps_3d = overlaps_bev.to(boxes1.tensor.device) * overlaps_h
+        v1, v2 = boxes1.volume.view(-1, 1), boxes2.volume.view(1, -1)
+        if mode == 'iou':
+            return overlaps_3d / torch.clamp(v1 + v2 - overlaps_3d, min=1e-8)
+        return overlaps_3d / torch.clamp(v1, min=1e-8)
+
     def to(self, device):
         return type(self)(self.tensor.to(device), box_dim=self.box_dim, with_yaw=self.with_yaw)
 

@@ -509,6 +509,78 @@ def gen_indoor_heads(ns):
     np.savez_compressed(os.path.join(GOLD, 'indoor_heads.npz'), **out)
 
 
+def gen_indoor_eval(ns):
+    """Reference indoor_eval (core/evaluation/indoor_eval.py) on synthetic scenes.  Its 3-D IoU goes through
+    BaseInstance3DBoxes.overlaps -> iou3d_cuda.boxes_overlap_bev_gpu (CUDA): the C restatement is injected and
+    Tensor.cuda() is made a no-op for the duration so the reference's own overlaps() code runs on the CPU."""
+    import types
+    from oracle import c_oracle as co
+    import importlib.util
+    sys.modules['mmcv.utils'] = types.ModuleType('mmcv.utils')
+    sys.modules['mmcv.utils'].print_log = lambda *a, **k: None
+    tt = types.ModuleType('terminaltables')
+
+    class AsciiTable:
+        def __init__(self, data):
+            self.table = ''
+    tt.AsciiTable = AsciiTable
+    sys.modules['terminaltables'] = tt
+    spec = importlib.util.spec_from_file_location('ref_indoor_eval', os.path.join(ref_import.REF, 'mmdet3d/core/evaluation/indoor_eval.py'))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+
+    class FakeIou3d:
+        @staticmethod
+        def boxes_overlap_bev_gpu(a, b, out):
+            out.copy_(torch.from_numpy(co.boxes_overlap_bev(a.numpy(), b.numpy())))
+    ns.base.iou3d_cuda = FakeIou3d
+    Depth = ns.depth.DepthInstance3DBoxes
+    Depth.convert_to = lambda self, dst, rt_mat=None: self          # boxes are already in depth mode
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        rng = np.random.RandomState(80)
+        n_scenes, n_cls = 6, 4
+        gt_annos, dt_annos, store = [], [], {}
+        for sidx in range(n_scenes):
+            n = rng.randint(0, 7) if sidx != 2 else 0
+            ctr = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+            size = rng.uniform(0.4, 1.6, (n, 3)).astype(np.float32)
+            yaw = rng.uniform(-1.5, 1.5, (n, 1)).astype(np.float32)
+            gtb = np.concatenate([ctr, size, yaw], 1)
+            cls = rng.randint(0, n_cls, (n,)).astype(np.int64)
+            gt_annos.append(dict(gt_num=n, gt_boxes_upright_depth=gtb, **{'class': cls}))
+            # detections: jittered copies of most gts (+ duplicates) and some false positives
+            keep = rng.rand(n) < 0.8
+            det = gtb[keep] + rng.normal(0, 0.08, (keep.sum(), 7)).astype(np.float32)
+            dcls = cls[keep].copy()
+            flip = rng.rand(len(dcls)) < 0.15
+            dcls[flip] = rng.randint(0, n_cls, flip.sum())
+            nfp = rng.randint(1, 5)
+            fpb = np.concatenate([rng.uniform(-3, 3, (nfp, 3)), rng.uniform(0.4, 1.6, (nfp, 3)), rng.uniform(-1.5, 1.5, (nfp, 1))], 1).astype(np.float32)
+            det = np.concatenate([det, det[:1], fpb]) if len(det) else fpb
+            dcls = np.concatenate([dcls, dcls[:1], rng.randint(0, n_cls, nfp)]) if len(dcls) else rng.randint(0, n_cls, nfp)
+            scores = rng.uniform(0.05, 1.0, len(det)).astype(np.float32)
+            det_bc = det.copy()
+            det_bc[:, 2] -= det_bc[:, 5] * 0.5            # detections are stored bottom-centred (as simple_test returns them)
+            dt_annos.append(dict(boxes_3d=Depth(torch.from_numpy(det_bc)), scores_3d=torch.from_numpy(scores),
+                                 labels_3d=torch.from_numpy(dcls.astype(np.int64))))
+            store[f's{sidx}::gt_boxes'] = gtb
+            store[f's{sidx}::gt_class'] = cls
+            store[f's{sidx}::det_boxes'] = det_bc
+            store[f's{sidx}::det_scores'] = scores
+            store[f's{sidx}::det_labels'] = dcls.astype(np.int64)
+        label2cat = {i: f'c{i}' for i in range(n_cls)}
+        from enum import IntEnum
+        res = ev.indoor_eval(gt_annos, dt_annos, [0.25, 0.5], label2cat, box_type_3d=Depth, box_mode_3d=2)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    store['result'] = np.array(json.dumps(res))
+    store['n_scenes'] = np.array(n_scenes)
+    np.savez_compressed(os.path.join(GOLD, 'indoor_eval.npz'), **store)
+    print('indoor_eval', {k: round(v, 4) for k, v in res.items() if k.startswith('m')})
+
+
 def main():
     ns = ref_import.load()
     gen_backproject(ns)
@@ -519,6 +591,7 @@ def main():
     gen_anchor_head(ns)
     gen_e2e_small(ns)
     gen_indoor_heads(ns)
+    gen_indoor_eval(ns)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

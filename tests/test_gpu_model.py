@@ -113,3 +113,13 @@ def test_kitti_full_path_vs_oracle(ia):
     out = model.simple_test(dimg, [meta])
     assert len(out) == 1 and len(out[0]['scores_3d']) == len(rs)
     assert_close('e2e boxes', out[0]['boxes_3d'].tensor, rb, 2e-3, 2e-3)
+
+
+def test_indoor_eval_on_device_matches_reference(ia):
+    """indoor_eval with the 3-D IoU from the device kernel (BaseInstance3DBoxes.overlaps -> ivx_boxes_overlap_bev)."""
+    from test_host_cpu import _eval_inputs
+    gt, dt, want = _eval_inputs()
+    got = ia.indoor_eval(gt, dt, [0.25, 0.5], {i: f'c{i}' for i in range(4)}, box_type_3d=ia.DepthInstance3DBoxes, box_mode_3d=2)
+    assert set(got) == set(want)
+    for k in want:
+        assert abs(got[k] - want[k]) < 1e-5, (k, got[k], want[k])

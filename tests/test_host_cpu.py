@@ -214,3 +214,71 @@ def test_single_process_gather_is_identity():
     assert torch.equal(gb, boxes) and torch.equal(gs, scores) and torch.equal(gl, labels) and torch.equal(gc, count)
     a = [ivd.shard_range(10, r, 4) for r in range(4)]
     assert a == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def _eval_inputs():
+    import imvoxelnet_amd as ia
+    g = load_npz('indoor_eval.npz')
+    gt, dt = [], []
+    for s in range(int(g['n_scenes'])):
+        gb = g[f's{s}::gt_boxes']
+        gt.append(dict(gt_num=len(gb), gt_boxes_upright_depth=gb, **{'class': g[f's{s}::gt_class']}))
+        dt.append(dict(boxes_3d=ia.DepthInstance3DBoxes(torch.from_numpy(g[f's{s}::det_boxes'])),
+                       scores_3d=torch.from_numpy(g[f's{s}::det_scores']), labels_3d=torch.from_numpy(g[f's{s}::det_labels'])))
+    return gt, dt, json.loads(str(g['result']))
+
+
+def test_indoor_eval_matches_reference_cpu():
+    """indoor_eval bookkeeping == the reference's (golden), with the BEV overlap supplied by the C oracle because the
+    device kernel cannot run here (the -m gpu twin uses the real kernel)."""
+    import imvoxelnet_amd as ia
+    from imvoxelnet_amd.boxes import BaseInstance3DBoxes
+    from oracle import c_oracle as co
+    gt, dt, want = _eval_inputs()
+    BaseInstance3DBoxes._bev_overlap_fn = staticmethod(lambda a, b: torch.from_numpy(co.boxes_overlap_bev(a.numpy(), b.numpy())))
+    try:
+        got = ia.indoor_eval(gt, dt, [0.25, 0.5], {i: f'c{i}' for i in range(4)}, box_type_3d=ia.DepthInstance3DBoxes, box_mode_3d=2)
+    finally:
+        BaseInstance3DBoxes._bev_overlap_fn = None
+    assert set(got) == set(want)
+    for k in want:
+        assert abs(got[k] - want[k]) < 1e-6, (k, got[k], want[k])
+    ap = ia.average_precision(np.array([0.2, 0.4, 0.4, 0.8]), np.array([1.0, 0.5, 0.6, 0.5]))
+    assert abs(float(ap[0]) - (0.2 * 1.0 + 0.2 * 0.6 + 0.4 * 0.5)) < 1e-6
+
+
+def test_input_side_adapters(tmp_path):
+    """Checkpoint round trip with the reference's container format, the image pipeline's shape semantics and the
+    calibration adapters (values follow the reference dataset classes line by line)."""
+    import imvoxelnet_amd as ia
+    from imvoxelnet_amd import data
+    neck = ia.KittiImVoxelNeck(4, 8)
+    ia.randomize_(neck, 9)
+    f = tmp_path / 'ckpt.pth'
+    torch.save(dict(meta=dict(CLASSES=('Car',)), state_dict={'module.' + k: v for k, v in neck.state_dict().items()}), f)
+    neck2 = ia.KittiImVoxelNeck(4, 8)
+    ck = data.load_checkpoint(neck2, str(f), strict=True)
+    assert neck2.CLASSES == ('Car',) and not ck['_missing_keys'] and not ck['_unexpected_keys']
+    assert all(torch.equal(a, b) for a, b in zip(neck.state_dict().values(), neck2.state_dict().values()))
+    with pytest.raises(RuntimeError):
+        data.load_checkpoint(ia.NuScenesImVoxelNeck(8, 8), str(f), strict=True)
+    # KITTI: 375 x 1242 -> Resize((1280, 384), keep_ratio) -> 384 x 1272 -> Pad 32 -> 384 x 1280   (SURVEY section 3.5)
+    img = (np.random.RandomState(0).rand(375, 1242, 3) * 255).astype(np.uint8)
+    t, meta = data.prepare_image(img, (1280, 384))
+    assert tuple(t.shape) == (3, 384, 1280) and meta['img_shape'] == (384, 1272, 3) and meta['ori_shape'] == (375, 1242, 3)
+    assert float(t[:, :, 1272:].abs().max()) == 0.0
+    px = (img[0, 0, ::-1].astype(np.float32) - np.array(data.IMG_NORM_CFG['mean'], np.float32)) / np.array(data.IMG_NORM_CFG['std'], np.float32)
+    t1, _ = data.prepare_image(img[:352, :1216], (1216, 352))          # no resize: normalisation is exact
+    assert np.allclose(t1[:, 0, 0].numpy(), px, atol=1e-5)
+    P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884], [0, 0, 0, 1]])
+    R0 = np.eye(4)
+    Tr = np.array([[0, -1, 0, 0.0], [0, 0, -1, -0.08], [1, 0, 0, -0.27], [0, 0, 0, 1]], np.float64)
+    l2i = data.kitti_lidar2img(P2, R0, Tr)
+    assert np.allclose(l2i['origin'], [34.56, 0, -1]) and l2i['intrinsic'][0, 3] == 0 and l2i['extrinsic'][0].dtype == np.float32
+    assert np.allclose(l2i['extrinsic'][0][:3, 3], Tr[:3, 3] + np.linalg.inv(P2[:3, :3]) @ P2[:3, 3], atol=1e-6)
+    s = data.sunrgbd_lidar2img(np.arange(9.), np.arange(9.).reshape(3, 3))
+    assert np.allclose(s['intrinsic'][:3, :3], np.arange(9.).reshape(3, 3).T) and np.allclose(s['origin'], [0, 3, -1])
+    sc = data.scannet_lidar2img(np.eye(4), [np.eye(4), np.diag([1., 2, 4, 1])], np.eye(4))
+    assert np.allclose(sc['extrinsic'][1], np.diag([1, .5, .25, 1])) and np.allclose(sc['origin'], [0, 0, .5])
+    n = data.nuscenes_lidar2img([np.eye(4)] * 6)
+    assert len(n['extrinsic']) == 6 and np.allclose(n['origin'], [0, 0, -1])
