@@ -28,6 +28,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
 BATCH_PER_GPU = 4
 
 
@@ -124,6 +125,9 @@ def main():
     ap.add_argument('--config', default='kitti', choices=['kitti', 'nuscenes', 'scannet_fast', 'sunrgbd_fast', 'scannet_v1'],
                     help='BASELINE.json workload; the headline metric is quoted on kitti (configs[1]), the default')
     ap.add_argument('--views', type=int, default=0, help='views per scene for the indoor configs (default: reference test value)')
+    ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
+                    help='f32 (default) = the reference precision and the headline metric; bf16 = optional reduced-precision '
+                         'storage mode (kitti only), reported with dtype "bf16" and priced against the bf16 MFMA peak')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -158,7 +162,10 @@ def main():
         model.bbox_head.conv_cls.bias.fill_(-2.0)
         model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
         model.bbox_head.conv_dir_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(7))
-    model.prepare(dev)
+    bf16 = args.storage == 'bf16'
+    model.prepare(dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    esz = 2 if bf16 else 4
 
     B = args.batch
     g = torch.Generator().manual_seed(1000 + rank)
@@ -207,7 +214,7 @@ def main():
     neck_ms_avg = sum(neck_ms) / len(neck_ms)
     lift_ms = sum(ev[args.warmup + i][2].elapsed_time(ev[args.warmup + i][0]) for i in range(args.steps)) / args.steps
     # unprojection: algorithmic bytes = features read once + volume written once + mask (173.1 MB/sample)
-    lift_bytes = B * (1 * 64 * 96 * 320 * 4 + 64 * 216 * 248 * 12 * 4 + 216 * 248 * 12)
+    lift_bytes = B * (1 * 64 * 96 * 320 * esz + 64 * 216 * 248 * 12 * esz + 216 * 248 * 12)
     n_launch = 11
     flops_step = neck_flops_per_sample((216, 248, 12), 64, 256) * B
     achieved = flops_step / (neck_ms_avg * 1e-3) / 1e12
@@ -217,7 +224,7 @@ def main():
     # FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as reported), averaged per launch; null if absent.
     traffic = None
     pj = os.path.join(ROOT, 'profiles', 'r01_bench_pmc.json')
-    if os.path.exists(pj):
+    if os.path.exists(pj) and not bf16:
         try:
             ks = [v for v in json.load(open(pj)).values() if 'hbm_bytes' in v.get('derived', {})]
             nl = sum(v['launches'] for v in ks)
@@ -231,13 +238,13 @@ def main():
             'metric': 'images/sec/node (KITTI 3x384x1280, 216x248x12 vox)',
             'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'data': 'synthetic',
             'config': {'workload': 'kitti_mono_1x3x384x1280_vox216x248x12_resnet50_fpn64_kittineck_anchor3dhead',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
                        'detections_last_step': int(last[:, -1].sum().item())},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_f32_kernel (3-D neck, 11 launches/step)',
-                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/r01_bench_pmc.json)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, 11 launches/step)' % ('__bf16' if bf16 else 'float'),
+                         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/r01_bench_pmc.json)',
                          'algorithmic_gflop_per_launch': round(flops_step / n_launch / 1e9, 2),
                          'avg_launch_ms': round(neck_ms_avg / n_launch, 4), 'neck_ms_per_step': round(neck_ms_avg, 3)},
             'roofline_unprojection': {'bound': 'hbm', 'kernel': 'backproject_single_view_kernel (1 launch/step, event-bracketed)',
@@ -245,6 +252,8 @@ def main():
                                       'frac': round(lift_bytes / (lift_ms * 1e-3) / 8e12, 4), 'ms': round(lift_ms, 4),
                                       'algorithmic_MB': round(lift_bytes / 1e6, 1)},
         }
+        if bf16:
+            rec['note'] = 'reduced-precision storage mode (bf16 activations/weights, fp32 accumulate); NOT the headline metric, which is quoted at fp32'
         if world == 1 and not args.no_cpu_baseline:
             from oracle import imvoxel_oracle as orc
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}

@@ -18,7 +18,8 @@ class IvxError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('B', 'D', 'H', 'W', 'Cin', 'Cout', 'KD', 'KH', 'KW', 'sd', 'sh', 'sw', 'pd', 'ph', 'pw',
-                 'relu', 'res_mode', 'res_h', 'res_w', 'wgt_layout', 'out_mode', 'res_after_act')] + [('post_scale', C.c_float)]
+                 'relu', 'res_mode', 'res_h', 'res_w', 'wgt_layout', 'out_mode', 'res_after_act')] + [('post_scale', C.c_float),
+                                                                  ('in_dtype', C.c_int32), ('out_dtype', C.c_int32)]
 
 
 class AnchorHeadDesc(C.Structure):
@@ -29,7 +30,7 @@ class AnchorHeadDesc(C.Structure):
 
 
 EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
-           'ivx_maxpool2d_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
+           'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
            'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_fcos_head_workspace_bytes',
            'ivx_fcos_head_level_candidates', 'ivx_nms_workspace_bytes',
            'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms']

@@ -38,6 +38,9 @@ class _Bottleneck(nn.Module):
         # style='pytorch': the stride sits on the 3x3 conv
         self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2).to(device)
         if self.dcn:
+            from .conv import current_storage_dtype
+            if current_storage_dtype() != torch.float32:
+                raise NotImplementedError('the DCNv2 stages are built for float32 storage only')
             co = self.conv2.conv_offset
             self.f_off = FusedConv(co.weight, co.bias, stride=self.stride, padding=1, dims=2).to(device)
             w = self.conv2.weight.detach()                               # [Cout, C, 3, 3] -> 1x1 over K = (tap, c)

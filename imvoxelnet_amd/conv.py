@@ -23,31 +23,66 @@ def _spatial3(v, dims, fill):
     return v
 
 
+_storage = [torch.float32]
+
+
+class storage_dtype:
+    """with storage_dtype(torch.bfloat16): FusedConvs built inside store activations and weights as bf16 (optional
+    reduced-precision mode; the default and the reference's precision is float32).  Accumulation stays fp32."""
+
+    def __init__(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError('storage dtype must be torch.float32 or torch.bfloat16')
+        self.dtype = dtype
+
+    def __enter__(self):
+        _storage.append(self.dtype)
+        return self
+
+    def __exit__(self, *exc):
+        _storage.pop()
+        return False
+
+
+def current_storage_dtype():
+    return _storage[-1]
+
+
 class FusedConv:
     # optional algorithmic-FLOP accounting (bench.py): 2 * output positions * Cout * Cin * taps per call
     count_flops = False
     flops = 0.0
 
-    def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, relu=False, dims=3, eps=1e-5, layout=None):
+    def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, relu=False, dims=3, eps=1e-5, layout=None,
+                 dtype=None, out_dtype=None):
         """weight: [Cout,Cin,kh,kw] (dims=2) or [Cout,Cin,kd,kh,kw] (dims=3) tensor (any device).
-        bn: None or (gamma, beta, running_mean, running_var)."""
+        bn: None or (gamma, beta, running_mean, running_var).
+        dtype: storage type of the input and the packed weights (float32 = the reference's precision; bfloat16 is the
+        optional reduced-precision mode); out_dtype: storage type of the output / residual (default: dtype)."""
+        dtype = _storage[-1] if dtype is None else dtype
+        out_dtype = dtype if out_dtype is None else out_dtype
         w = weight.detach().to(torch.float32)
+        if dtype == torch.bfloat16 and w.shape[1] % 8 != 0:
+            dtype = torch.float32      # e.g. the 3-channel stem: fp32 image in, reduced-precision map out
+        self.dtype, self.out_dtype = dtype, out_dtype
         if dims == 2:
             w = w.unsqueeze(2)
         self.stride = _spatial3(stride, dims, 1)
         self.padding = _spatial3(padding, dims, 0)
         self.cout, self.cin = w.shape[0], w.shape[1]
         self.kernel = tuple(w.shape[2:])
-        self.cin_pad = (self.cin + 3) // 4 * 4
+        epc = 8 if dtype == torch.bfloat16 else 4          # elements per 16-byte chunk
+        ck = 64 if dtype == torch.bfloat16 else 32         # channels per 128-byte chunk (layout 1)
+        self.cin_pad = (self.cin + epc - 1) // epc * epc
         wp = w.permute(0, 2, 3, 4, 1).contiguous()
         if self.cin_pad != self.cin:
             wp = torch.nn.functional.pad(wp, (0, self.cin_pad - self.cin))
         # layout 1 (chunk-major K) whenever the channel count allows it: see include/imvoxel.h
-        self.layout = 1 if (self.cin_pad % 32 == 0 and layout != 0) else 0
+        self.layout = 1 if (self.cin_pad % ck == 0 and layout != 0) else 0
         if self.layout == 1:
             co, kd, kh, kw, ci = wp.shape
-            wp = wp.reshape(co, kd, kh, kw, ci // 32, 32).permute(0, 4, 1, 2, 3, 5)
-        self._w_host = wp.contiguous()
+            wp = wp.reshape(co, kd, kh, kw, ci // ck, ck).permute(0, 4, 1, 2, 3, 5)
+        self._w_host = wp.contiguous().to(dtype)
         scale = torch.ones(self.cout)
         shift = torch.zeros(self.cout)
         if bias is not None:
@@ -79,7 +114,8 @@ class FusedConv:
             FusedConv.flops += 2.0 * pos * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
         return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,
                             self.relu if relu is None else relu, res, res_mode, naive=naive, wgt_layout=self.layout,
-                            out_mode=self.out_mode, res_after_act=res_after_act, post_scale=post_scale)
+                            out_mode=self.out_mode, res_after_act=res_after_act, post_scale=post_scale,
+                            out_dtype=self.out_dtype)
 
     def flops(self, out_positions):
         return 2.0 * out_positions * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
@@ -90,13 +126,13 @@ class FusedConvTranspose2x(FusedConv):
     (column n = ((a*2+e)*2+f)*Cout + co) whose epilogue scatters to out[b, 2d+a, 2h+e, 2w+f, co]
     (necks/imvoxelnet.py:54-56: the up-blocks of FastIndoorImVoxelNeck).  weight: [Cin, Cout, 2, 2, 2]."""
 
-    def __init__(self, weight, bn=None, relu=False, eps=1e-5):
+    def __init__(self, weight, bn=None, relu=False, eps=1e-5, dtype=None, out_dtype=None):
         w = weight.detach().to(torch.float32)
         cin, cout = w.shape[0], w.shape[1]
         if tuple(w.shape[2:]) != (2, 2, 2):
             raise ValueError('only kernel 2 / stride 2 transposed convolutions are built')
         as_conv = w.permute(2, 3, 4, 1, 0).reshape(8 * cout, cin, 1, 1, 1)      # [(a,e,f,co), ci]
-        super().__init__(as_conv, None, None, 1, 0, relu, dims=3, eps=eps)
+        super().__init__(as_conv, None, None, 1, 0, relu, dims=3, eps=eps, dtype=dtype, out_dtype=out_dtype)
         self.out_mode = 1
         self.cout_real = cout
         scale, shift = torch.ones(cout), torch.zeros(cout)

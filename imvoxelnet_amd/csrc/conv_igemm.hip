@@ -23,6 +23,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvParams {
   const float *in, *wgt, *scale, *shift, *res;
@@ -43,7 +44,19 @@ struct ConvParams {
   // M-tile range of this launch (LDS-DMA kernel): XCD x owns tiles [x*q_total, (x+1)*q_total); this launch covers the
   // q_count tiles starting at q_begin inside every XCD's range.  Whole problem: q_begin 0, q_count q_total.
   int q_total, q_begin, q_count, bm;
+  int in_bf16;        // in / wgt are bf16 (LDS-DMA kernel only); accumulation is always fp32
+  int out_bf16;       // out / res are bf16 (converted round-to-nearest-even in the epilogue)
 };
+
+__device__ __forceinline__ float conv_ld_res(const ConvParams &p, size_t i) {
+  return p.out_bf16 ? (float)reinterpret_cast<const __bf16 *>(p.res)[i] : p.res[i];
+}
+__device__ __forceinline__ void conv_st_out(const ConvParams &p, size_t i, float v) {
+  if (p.out_bf16)
+    reinterpret_cast<__bf16 *>(p.out)[i] = (__bf16)v;
+  else
+    p.out[i] = v;
+}
 
 #define IVX_BK 32
 #define IVX_LDK 36
@@ -65,9 +78,9 @@ __device__ __noinline__ size_t res2_row_base(int m, int Ho, int Wo, int rH, int 
 // y = act(acc*scale + shift [+ res]) [+ res] [* post_scale] for one output element; `oidx` is its flat offset.
 __device__ __forceinline__ float conv_finish(const ConvParams &p, float acc, float sc, float sf, size_t ridx) {
   float v = acc * sc + sf;
-  if (p.res_mode && !p.res_after_act) v += p.res[ridx];
+  if (p.res_mode && !p.res_after_act) v += conv_ld_res(p, ridx);
   if (p.relu) v = v > 0.f ? v : 0.f;
-  if (p.res_mode && p.res_after_act) v += p.res[ridx];
+  if (p.res_mode && p.res_after_act) v += conv_ld_res(p, ridx);
   return v * p.post_scale;
 }
 
@@ -116,7 +129,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if (nn[j] >= p.Cout) continue;
-          p.out[ob + coff[j]] = conv_finish(p, acc[i][j][r], sc[j], sf[j], ob + coff[j]);
+          conv_st_out(p, ob + coff[j], conv_finish(p, acc[i][j][r], sc[j], sf[j], ob + coff[j]));
         }
         continue;
       }
@@ -125,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (nn[j] >= p.Cout) continue;
-        p.out[(size_t)m * p.Cout + nn[j]] = conv_finish(p, acc[i][j][r], sc[j], sf[j], rbase + nn[j]);
+        conv_st_out(p, (size_t)m * p.Cout + nn[j], conv_finish(p, acc[i][j][r], sc[j], sf[j], rbase + nn[j]));
       }
     }
   }
@@ -503,21 +516,24 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams
 // wave-uniform base + lane*16 B, so LDS rows are unpadded 128-byte rows and bank conflicts are avoided by an XOR
 // swizzle applied on the SOURCE side (lane with slot c of row r fetches k-chunk c ^ ((r >> SW_SH) & SW_MSK)) and
 // again on the fragment read.  BK (K-slab depth) is 32 or 16; 16 halves the LDS so three workgroups fit on a CU.
-template <int TM, int TN, int WR, int WC, int BK>
-__global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams p, const unsigned in_bytes,
+template <typename T, int TM, int TN, int WR, int WC, int BK>
+__global__ __launch_bounds__(256) void conv_igemm_v4_kernel(const ConvParams p, const unsigned in_bytes,
                                                                   const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-  constexpr int NCH = BK / 4;          // 16-byte chunks per LDS row (8 or 4)
+  constexpr int EL = sizeof(T);        // 4 (fp32) or 2 (bf16)
+  constexpr int EPC = 16 / EL;         // elements per 16-byte chunk
+  constexpr int CK = 128 / EL;         // channels per chunk of the chunk-major K order (128 bytes)
+  constexpr int NCH = BK / EPC;        // 16-byte chunks per LDS row (8 or 4)
   constexpr int RP = 256 / NCH;        // rows covered by one pass of the 256 threads (32 or 64)
   constexpr int AR = BM / RP, BR = BN / RP;
-  constexpr int SW_SH = BK == 32 ? 1 : 2, SW_MSK = NCH - 1;   // slot c of row r holds k-chunk c ^ ((r >> SW_SH) & SW_MSK)
-  static_assert(BK == 32 || BK == 16, "BK");
+  constexpr int SW_SH = NCH == 8 ? 1 : 2, SW_MSK = NCH - 1;   // slot c of row r holds k-chunk c ^ ((r >> SW_SH) & SW_MSK)
+  static_assert(NCH == 8 || NCH == 4, "BK: LDS rows are 128 or 64 bytes");
   static_assert(BM % RP == 0 && BN % RP == 0, "tile rows");
   static_assert(WR * WC == 4, "4 waves per workgroup");
-  // LDS-DMA staging: rows are 32 floats (128 B), unpadded; 16-byte slot c of row r holds k-chunk c ^ ((r>>1)&7)
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BK];
-  float *As = smem;
-  float *Bs = smem + 2 * BM * BK;
+  // LDS-DMA staging: rows are BK elements (128 or 64 B), unpadded
+  __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * BK];
+  T *As = smem;
+  T *Bs = smem + 2 * BM * BK;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -584,17 +600,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
     s_begin = blockIdx.y * per;
     s_end = s_begin + per < S_all ? s_begin + per : S_all;
   }
-  int k4 = s_begin * BK + cc * 4;
+  int k4 = s_begin * BK + cc * EPC;
   int kc, ka, ke, kf;
-  int khalf = 0;   // BK == 16, chunk-major: which half of the 32-channel chunk this slab covers
-  if (p.kmode == 1) {  // chunk-major: slab s = (32-channel chunk, tap, half)
-    constexpr int HPS = 32 / BK;                       // slabs per (chunk, tap)
+  int khalf = 0;   // 64-byte rows, chunk-major: which half of the 128-byte channel chunk this slab covers
+  if (p.kmode == 1) {  // chunk-major: slab s = (CK-channel chunk, tap, half)
+    constexpr int HPS = CK / BK;                       // slabs per (chunk, tap)
     const int ntap = p.KD * p.KH * p.KW;
     const int chunk = s_begin / (ntap * HPS);
     const int rem = s_begin - chunk * ntap * HPS;
     const int tap = rem / HPS;
     khalf = rem - tap * HPS;
-    kc = chunk * 32 + khalf * 16 + cc * 4;
+    kc = chunk * CK + khalf * (CK / 2) + cc * EPC;
     kf = tap % p.KW;
     const int t2 = tap / p.KW;
     ke = t2 % p.KH;
@@ -616,27 +632,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
     const unsigned kbad = (k4 < p.K) ? 0u : 0xffffffffu;
     const int delta = ((ka * p.H + ke) * p.W + kf) * p.Cin + kc;
     const unsigned tap = ((1u << ka) | (1u << (8 + ke)) | (1u << (16 + kf))) | kbad;
-    float *Ab = As + buf * BM * BK + wid_u * (64 / NCH) * BK;   // wave-uniform base; the DMA adds lane*16 B
-    float *Bb = Bs + buf * BN * BK + wid_u * (64 / NCH) * BK;
+    T *Ab = As + buf * BM * BK + wid_u * (64 / NCH) * BK;   // wave-uniform base; the DMA adds lane*16 B
+    T *Bb = Bs + buf * BN * BK + wid_u * (64 / NCH) * BK;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
       const unsigned good = ((a_msk[j] & tap) == tap) ? 0xffffffffu : 0u;
-      const unsigned vo = (((unsigned)(a_off[j] + delta) << 2) & good) | (OOB & ~good);
+      const unsigned vo = (((unsigned)(a_off[j] + delta) * EL) & good) | (OOB & ~good);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + RP * j * BK), 16, vo, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
       const unsigned good = (b_off[j] >= 0 ? 0xffffffffu : 0u) & ~kbad;
-      const unsigned vo = (((unsigned)(b_off[j] + k4) << 2) & good) | (OOB & ~good);
+      const unsigned vo = (((unsigned)(b_off[j] + k4) * EL) & good) | (OOB & ~good);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bb + RP * j * BK), 16, vo, 0, 0, 0);
     }
   };
   auto advance_k = [&]() {
     k4 += BK;
     if (p.kmode == 1) {  // next tap of the same 32-channel chunk; after the last tap move to the next chunk
-      if (BK == 16) {
+      if (BK < CK) {
         khalf ^= 1;
-        kc += khalf ? 16 : -16;
+        kc += khalf ? CK / 2 : -(CK / 2);
         if (khalf) return;
       }
       if (++kf == p.KW) {
@@ -645,7 +661,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
           ke = 0;
           if (++ka == p.KD) {
             ka = 0;
-            kc += 32;
+            kc += CK;
           }
         }
       }
@@ -682,29 +698,40 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_v4_kernel(const ConvParams
       advance_k();
       load_slab(cur ^ 1);
     }
-    const float *Ac = As + cur * BM * BK + wr * TM * 32 * BK + frow;
-    const float *Bc = Bs + cur * BN * BK + wc * TN * 32 * BK + frow;
+    const T *Ac = As + cur * BM * BK + wr * TM * 32 * BK + frow;
+    const T *Bc = Bs + cur * BN * BK + wc * TN * 32 * BK + frow;
+    // one 16-byte read per operand tile and k-step: half-wave h takes chunk 2*kk + h (4 fp32 k -> 4 MFMAs 32x32x2,
+    // or 8 bf16 k -> 1 MFMA 32x32x16); A and B use the same k permutation, so the sum over k is unchanged
     f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + ((fh ^ fsw) << 2));
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + ((fh ^ fsw) * EPC));
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + ((fh ^ fsw) << 2));
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + ((fh ^ fsw) * EPC));
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
+    for (int kk = 0; kk < NCH / 2; ++kk) {
       const int cb = kk & 1, nb = cb ^ 1;
-      if (kk < BK / 8 - 1) {
+      if (kk < NCH / 2 - 1) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) << 2));
+        for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) << 2));
+        for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
       }
+      if constexpr (EL == 4) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][i][q], fb[cb][j][q], acc[i][j], 0, 0, 0);
+      } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][i][q], fb[cb][j][q], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cb][i]), __builtin_bit_cast(bf16x8, fb[cb][j]),
+                                                               acc[i][j], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -736,13 +763,13 @@ __device__ __forceinline__ void conv_store_one(const ConvParams &p, int m, int n
     const int tap = n / p.Cr, ch = n - tap * p.Cr;
     const int a2 = tap >> 2, e2 = (tap >> 1) & 1, f2 = tap & 1;
     const size_t o = up2_row_base(m, p.D, p.H, p.W, p.Cr) + (((size_t)a2 * 2 * p.H + e2) * 2 * p.W + f2) * p.Cr + ch;
-    p.out[o] = conv_finish(p, acc, p.scale ? p.scale[ch] : 1.0f, p.shift ? p.shift[ch] : 0.0f, o);
+    conv_st_out(p, o, conv_finish(p, acc, p.scale ? p.scale[ch] : 1.0f, p.shift ? p.shift[ch] : 0.0f, o));
     return;
   }
   const size_t idx = (size_t)m * p.Cout + n;
   size_t ridx = idx;
   if (p.res_mode == 2) ridx = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + n;
-  p.out[idx] = conv_finish(p, acc, p.scale ? p.scale[n] : 1.0f, p.shift ? p.shift[n] : 0.0f, ridx);
+  conv_st_out(p, idx, conv_finish(p, acc, p.scale ? p.scale[n] : 1.0f, p.shift ? p.shift[n] : 0.0f, ridx));
 }
 
 // Split-K reduction: out = epilogue(sum over slices in slice order) -- deterministic.  Partial rows are compact:
@@ -785,14 +812,16 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
         for (int f = 0; f < p.KW; ++f) {
           const int iw = ow * p.sw - p.pw + f;
           if ((unsigned)iw >= (unsigned)p.W) continue;
-          const float *x = p.in + ((((size_t)b * p.D + id) * p.H + ih) * p.W + iw) * p.Cin;
+          const size_t xo = ((((size_t)b * p.D + id) * p.H + ih) * p.W + iw) * p.Cin;
           const int tap = (a * p.KH + e) * p.KW + f;
           const int ntap = p.KD * p.KH * p.KW;
-          const float *w = p.wgt + (size_t)n * p.K;
-          if (p.kmode == 1) {
-            for (int c = 0; c < p.Cin; ++c) acc = fmaf(x[c], w[((c >> 5) * ntap + tap) * 32 + (c & 31)], acc);
-          } else {
-            for (int c = 0; c < p.Cin; ++c) acc = fmaf(x[c], w[tap * p.Cin + c], acc);
+          const size_t wo = (size_t)n * p.K;
+          const int ck = p.in_bf16 ? 64 : 32;   // channels per 128-byte chunk of the chunk-major order
+          for (int c = 0; c < p.Cin; ++c) {
+            const size_t wi = wo + (p.kmode == 1 ? (size_t)((c / ck) * ntap + tap) * ck + (c % ck) : (size_t)tap * p.Cin + c);
+            const float xv = p.in_bf16 ? (float)reinterpret_cast<const __bf16 *>(p.in)[xo + c] : p.in[xo + c];
+            const float wv = p.in_bf16 ? (float)reinterpret_cast<const __bf16 *>(p.wgt)[wi] : p.wgt[wi];
+            acc = fmaf(xv, wv, acc);
           }
         }
       }
@@ -801,8 +830,8 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
   }
 }
 
-static int fill_params(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
-                       const float *shift, const float *res, float *out, ConvParams *p) {
+static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
+                       const float *shift, const void *res, void *out, ConvParams *p) {
   IVX_REQUIRE(d && in && wgt && out, "ivx_conv_fwd: null argument");
   IVX_REQUIRE(d->B > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "ivx_conv_fwd: non-positive dims");
   IVX_REQUIRE(d->Cin % 4 == 0, "ivx_conv_fwd: Cin (%d) must be a multiple of 4 (pad the input channels)", d->Cin);
@@ -818,12 +847,19 @@ static int fill_params(const ivx_conv_desc *d, const float *in, const float *wgt
   IVX_REQUIRE(d->out_mode == 0 || (d->out_mode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 1 && d->sd == 1 && d->sh == 1 && d->sw == 1 &&
                                      d->pd == 0 && d->ph == 0 && d->pw == 0 && d->Cout % 8 == 0 && d->res_mode != 2),
               "ivx_conv_fwd: out_mode 1 (ConvTranspose k2 s2) needs a 1x1x1 stride-1 GEMM with Cout = 8 * real channels");
-  IVX_REQUIRE(d->wgt_layout == 0 || (d->wgt_layout == 1 && d->Cin % 32 == 0), "ivx_conv_fwd: wgt_layout 1 needs Cin %% 32 == 0");
+  IVX_REQUIRE((d->in_dtype == IVX_F32 || d->in_dtype == IVX_BF16) && (d->out_dtype == IVX_F32 || d->out_dtype == IVX_BF16),
+              "ivx_conv_fwd: dtypes are IVX_F32 (0) or IVX_BF16 (1)");
+  const int ck = d->in_dtype == IVX_BF16 ? 64 : 32;
+  IVX_REQUIRE(d->wgt_layout == 0 || (d->wgt_layout == 1 && d->Cin % ck == 0),
+              "ivx_conv_fwd: wgt_layout 1 needs Cin %% %d == 0 (128-byte channel chunks)", ck);
+  IVX_REQUIRE(d->in_dtype == IVX_F32 || d->Cin % 8 == 0, "ivx_conv_fwd: bf16 input needs Cin %% 8 == 0");
   IVX_REQUIRE(d->res_mode == 0 || res, "ivx_conv_fwd: res_mode set but res is NULL");
   if (d->res_mode == 2) {
     IVX_REQUIRE(Do == 1 && d->res_h > 0 && d->res_w > 0, "ivx_conv_fwd: res_mode 2 needs a 2-D output and res dims");
   }
-  p->in = in; p->wgt = wgt; p->scale = scale; p->shift = shift; p->res = d->res_mode ? res : nullptr; p->out = out;
+  p->in = (const float *)in; p->wgt = (const float *)wgt; p->scale = scale; p->shift = shift;
+  p->res = d->res_mode ? (const float *)res : nullptr; p->out = (float *)out;
+  p->in_bf16 = d->in_dtype == IVX_BF16; p->out_bf16 = d->out_dtype == IVX_BF16;
   p->B = d->B; p->D = d->D; p->H = d->H; p->W = d->W; p->Cin = d->Cin;
   p->Cout = d->Cout; p->KD = d->KD; p->KH = d->KH; p->KW = d->KW;
   p->sd = d->sd; p->sh = d->sh; p->sw = d->sw; p->pd = d->pd; p->ph = d->ph; p->pw = d->pw;
@@ -865,11 +901,11 @@ static void launch_cfg(const ConvParams &p, hipStream_t st, bool v2) {
     hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
 }
 
-template <int TM, int TN, int WR, int WC, int BK = 32>
+template <typename T, int TM, int TN, int WR, int WC, int BK>
 static void launch_v4(ConvParams &p, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-  const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4;
-  const int64_t w_bytes = (int64_t)p.Cout * p.K * 4;
+  const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * sizeof(T);
+  const int64_t w_bytes = (int64_t)p.Cout * p.K * sizeof(T);
   const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
   p.bm = BM;
   if (p.q_total == 0) {  // whole problem in one launch
@@ -878,7 +914,7 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
     p.q_count = p.q_total;
   }
   const long long g1 = 8LL * p.q_count * Nt;
-  hipLaunchKernelGGL((conv_igemm_f32_v4_kernel<TM, TN, WR, WC, BK>), dim3((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, st, p, (unsigned)in_bytes,
+  hipLaunchKernelGGL((conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK>), dim3((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, st, p, (unsigned)in_bytes,
                      (unsigned)w_bytes);
 }
 
@@ -909,12 +945,22 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 46: *t = {64, 64, 32, 5}; return true;
     case 51: *t = {128, 128, 16, 3}; return true;
     case 53: *t = {128, 64, 16, 5}; return true;
+    case 52: *t = {256, 64, 16, 3}; return true;
+    // bf16 (cfg + 20: same tile, same LDS bytes, BK counts bf16 elements)
+    case 61: *t = {128, 128, 64, 2}; return true;
+    case 63: *t = {128, 64, 64, 3}; return true;
+    case 64: *t = {128, 32, 64, 4}; return true;
+    case 66: *t = {64, 64, 64, 5}; return true;
+    case 71: *t = {128, 128, 32, 3}; return true;
+    case 73: *t = {128, 64, 32, 5}; return true;
+    case 72: *t = {256, 64, 32, 3}; return true;
     default: return false;
   }
 }
 
 static bool dma_applicable(const ConvParams &p) {
-  const int64_t in_b = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4, w_b = (int64_t)p.Cout * p.K * 4;
+  const int el = p.in_bf16 ? 2 : 4;
+  const int64_t in_b = (int64_t)p.B * p.D * p.H * p.W * p.Cin * el, w_b = (int64_t)p.Cout * p.K * el;
   return in_b < (1LL << 31) && w_b < (1LL << 31) && p.KD <= 8 && p.KH <= 8 && p.KW <= 8;
 }
 
@@ -948,6 +994,11 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
       pl.cfg = dma_ok ? 46 : 6;
       small = true;
     }
+  }
+  if (p.in_bf16 && pl.cfg >= 41 && pl.cfg <= 53) {
+    // same tile, bf16 instantiation; with 8x the MFMA rate the kernel is LDS-bound and the 128-byte-row 128 x 128
+    // tile (fewest barriers per flop) beats the three-workgroups-per-CU variant (measured, tools/conv_bench.py)
+    pl.cfg = (g_tile_override == 0 && pl.cfg == 51) ? 61 : pl.cfg + 20;
   }
   TileInfo t;
   if (!tile_info(pl.cfg, &t) || !dma_ok) return pl;
@@ -996,12 +1047,20 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 5: launch_cfg<1, 2, 4, 1>(p, st, v2); break;  // 128 x 64 (wave 32 x 64)
     case 6: launch_cfg<1, 1, 2, 2>(p, st, v2); break;  // 64 x 64
     case 7: launch_cfg<1, 2, 2, 2>(p, st, v2); break;  // 64 x 128
-    case 41: launch_v4<2, 2, 2, 2>(p, st); break;      // LDS-DMA: 128 x 128, BK 32
-    case 43: launch_v4<2, 1, 2, 2>(p, st); break;      //          128 x 64
-    case 44: launch_v4<1, 1, 4, 1>(p, st); break;      //          128 x 32
-    case 46: launch_v4<1, 1, 2, 2>(p, st); break;      //          64 x 64
-    case 51: launch_v4<2, 2, 2, 2, 16>(p, st); break;  //          128 x 128, BK 16: 32 KB LDS, 3 workgroups/CU
-    case 53: launch_v4<2, 1, 2, 2, 16>(p, st); break;
+    case 41: launch_v4<float, 2, 2, 2, 2, 32>(p, st); break;   // LDS-DMA: 128 x 128, 128-byte LDS rows
+    case 43: launch_v4<float, 2, 1, 2, 2, 32>(p, st); break;   //          128 x 64
+    case 44: launch_v4<float, 1, 1, 4, 1, 32>(p, st); break;   //          128 x 32
+    case 46: launch_v4<float, 1, 1, 2, 2, 32>(p, st); break;   //          64 x 64
+    case 51: launch_v4<float, 2, 2, 2, 2, 16>(p, st); break;   //          128 x 128, 64-byte rows: 32 KB LDS, 3 workgroups/CU
+    case 53: launch_v4<float, 2, 1, 2, 2, 16>(p, st); break;
+    case 52: launch_v4<float, 2, 2, 4, 1, 16>(p, st); break;   //          256 x 64, 64-byte rows: 40 KB LDS
+    case 61: launch_v4<__bf16, 2, 2, 2, 2, 64>(p, st); break;  // bf16 operands, v_mfma_f32_32x32x16_bf16
+    case 63: launch_v4<__bf16, 2, 1, 2, 2, 64>(p, st); break;
+    case 64: launch_v4<__bf16, 1, 1, 4, 1, 64>(p, st); break;
+    case 66: launch_v4<__bf16, 1, 1, 2, 2, 64>(p, st); break;
+    case 71: launch_v4<__bf16, 2, 2, 2, 2, 32>(p, st); break;
+    case 73: launch_v4<__bf16, 2, 1, 2, 2, 32>(p, st); break;
+    case 72: launch_v4<__bf16, 2, 2, 4, 1, 32>(p, st); break;
     default:
       ivx_set_error("ivx_conv_fwd: unknown tile override %d", pl.cfg);
       return IVX_ERR_INVALID_ARG;
@@ -1017,6 +1076,11 @@ static void launch_reduce(const ConvParams &p, hipStream_t st) {
 }
 
 static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStream_t st) {
+  TileInfo ti;
+  if (p.in_bf16 && (!dma_applicable(p) || !(tile_info(pl.cfg, &ti) && pl.cfg >= 61))) {
+    ivx_set_error("ivx_conv_fwd: bf16 input is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
+    return IVX_ERR_UNSUPPORTED;
+  }
   if (p.kmode == 1 && (!dma_applicable(p) || !pl.v2)) {
     ivx_set_error("ivx_conv_fwd: wgt_layout 1 is only implemented by the buffer-load kernels (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;
@@ -1041,8 +1105,8 @@ static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStrea
   return IVX_OK;
 }
 
-extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
-                            const float *shift, const float *res, float *out, ivx_stream_t stream) {
+extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
+                            const float *shift, const void *res, void *out, ivx_stream_t stream) {
   ConvParams p;
   int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
   if (rc != IVX_OK) return rc;
@@ -1060,8 +1124,8 @@ extern "C" int64_t ivx_conv_workspace_bytes(const ivx_conv_desc *d) {
   return plan_conv(p, true).ws_bytes;
 }
 
-extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
-                               const float *shift, const float *res, float *out, void *workspace, int64_t workspace_bytes,
+extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
+                               const float *shift, const void *res, void *out, void *workspace, int64_t workspace_bytes,
                                ivx_stream_t stream) {
   ConvParams p;
   int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
@@ -1078,8 +1142,8 @@ extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const float *in, const fl
   return IVX_OK;
 }
 
-extern "C" int ivx_conv_fwd_naive(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
-                                  const float *shift, const float *res, float *out, ivx_stream_t stream) {
+extern "C" int ivx_conv_fwd_naive(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
+                                  const float *shift, const void *res, void *out, ivx_stream_t stream) {
   ConvParams p;
   int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
   if (rc != IVX_OK) return rc;

@@ -7,9 +7,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// nn.MaxPool2d(k, s, p) on NHWC, C % 4 == 0: one thread per (output pixel, 4 channels).
-__global__ __launch_bounds__(256) void maxpool2d_nhwc_kernel(const float *in, int B, int H, int W, int C, int k, int s,
-                                                             int pd, int Ho, int Wo, float *out) {
+// nn.MaxPool2d(k, s, p) on NHWC, C % 4 == 0: one thread per (output pixel, 4 channels).  T = float or __bf16 (the max
+// of bf16 values is exact, so the bf16 instantiation is the same op on the reduced-precision storage).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2d_nhwc_kernel(const T *in, int B, int H, int W, int C, int k, int s,
+                                                             int pd, int Ho, int Wo, T *out) {
+  typedef T tx4 __attribute__((ext_vector_type(4)));
   const int C4 = C >> 2;
   const size_t total = (size_t)B * Ho * Wo * C4;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -19,28 +22,32 @@ __global__ __launch_bounds__(256) void maxpool2d_nhwc_kernel(const float *in, in
     t /= Wo;
     const int oh = (int)(t % Ho);
     const int b = (int)(t / Ho);
-    f32x4 m = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-    // -inf padding semantics of torch: start from -inf; use -FLT_MAX then fix below if no tap (never: k > p)
-    bool any = false;
+    // -inf padding semantics of torch (a window always holds at least one tap because 2p <= k)
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int e = 0; e < k; ++e) {
       const int ih = oh * s - pd + e;
       if ((unsigned)ih >= (unsigned)H) continue;
       for (int f = 0; f < k; ++f) {
         const int iw = ow * s - pd + f;
         if ((unsigned)iw >= (unsigned)W) continue;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (((size_t)b * H + ih) * W + iw) * C + c4 * 4);
+        const tx4 v = *reinterpret_cast<const tx4 *>(in + (((size_t)b * H + ih) * W + iw) * C + c4 * 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) m[q] = (v[q] > m[q] || v[q] != v[q]) ? v[q] : m[q];
-        any = true;
+        for (int q = 0; q < 4; ++q) {
+          const float x = (float)v[q];
+          m[q] = (x > m[q] || x != x) ? x : m[q];
+        }
       }
     }
-    if (!any) m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    *reinterpret_cast<f32x4 *>(out + idx * 4) = m;
+    tx4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = (T)m[q];
+    *reinterpret_cast<tx4 *>(out + idx * 4) = o;
   }
 }
 
-extern "C" int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s,
-                                 int32_t p, float *out, ivx_stream_t stream) {
+template <typename T>
+static int maxpool2d_launch(const T *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p, T *out,
+                            ivx_stream_t stream) {
   IVX_REQUIRE(in && out, "ivx_maxpool2d_fwd: null argument");
   IVX_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ivx_maxpool2d_fwd: bad dims (C %% 4 must be 0)");
   IVX_REQUIRE(k > 0 && s > 0 && p >= 0 && 2 * p <= k, "ivx_maxpool2d_fwd: bad window");
@@ -49,10 +56,20 @@ extern "C" int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t 
   const size_t total = (size_t)B * Ho * Wo * (C / 4);
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(maxpool2d_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, B, H, W, C, k, s, p,
+  hipLaunchKernelGGL(maxpool2d_nhwc_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, B, H, W, C, k, s, p,
                      Ho, Wo, out);
   IVX_CHECK_LAUNCH("ivx_maxpool2d_fwd");
   return IVX_OK;
+}
+
+extern "C" int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s,
+                                 int32_t p, float *out, ivx_stream_t stream) {
+  return maxpool2d_launch<float>(in, B, H, W, C, k, s, p, out, stream);
+}
+
+extern "C" int ivx_maxpool2d_fwd_bf16(const void *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s,
+                                      int32_t p, void *out, ivx_stream_t stream) {
+  return maxpool2d_launch<__bf16>((const __bf16 *)in, B, H, W, C, k, s, p, (__bf16 *)out, stream);
 }
 
 // [B,C,S] -> [B,S,Cpad] through a 32x33 LDS tile so both sides are coalesced.

@@ -54,10 +54,16 @@ class ImVoxelNet(nn.Module):
         self.neck_3d.init_weights()
         self.bbox_head.init_weights()
 
-    def prepare(self, device):
-        """Pack every layer's parameters for the device kernels (call again after changing weights)."""
-        for m in (self.backbone, self.neck, self.neck_3d, self.bbox_head):
-            m.prepare(device)
+    def prepare(self, device, dtype=torch.float32):
+        """Pack every layer's parameters for the device kernels (call again after changing weights).
+        dtype: storage type of activations and weights between layers.  float32 (default) is the reference's precision
+        and the one every parity claim is made for; bfloat16 is an optional reduced-precision mode (fp32 accumulate,
+        fp32 epilogues, fp32 head output and detection tail) built for the single-view anchor-head configs."""
+        from .conv import storage_dtype
+        with storage_dtype(dtype):
+            for m in (self.backbone, self.neck, self.neck_3d, self.bbox_head):
+                m.prepare(device)
+        self.storage_dtype = dtype
         return self
 
     # ------------------------------------------------------------------ host-side camera set-up

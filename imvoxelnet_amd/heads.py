@@ -71,7 +71,7 @@ class Anchor3DHead(nn.Module):
     def prepare(self, device):
         w = torch.cat([self.conv_cls.weight, self.conv_reg.weight, self.conv_dir_cls.weight], 0)
         b = torch.cat([self.conv_cls.bias, self.conv_reg.bias, self.conv_dir_cls.bias], 0)
-        self.fhead = FusedConv(w, b, dims=2).to(device)
+        self.fhead = FusedConv(w, b, dims=2, out_dtype=torch.float32).to(device)   # the tail decodes fp32 scores / deltas
         self._device = device
         return self
 
@@ -79,7 +79,7 @@ class Anchor3DHead(nn.Module):
         """x [B,*,*,*,C] channels-last map -> fused head output [B,*,*,*,A*(ncls+7+2)]."""
         if self._device is None:
             self.prepare(x.device)
-        return self.fhead(x)
+        return self.fhead(x if x.dtype == self.fhead.dtype else x.to(self.fhead.dtype))
 
     def forward_single(self, x):
         """x [B,C,H,W] -> (cls_score, bbox_pred, dir_cls_preds) in the reference layout."""

@@ -17,6 +17,9 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_DT = {torch.float32: 0, torch.bfloat16: 1}   # IVX_F32 / IVX_BF16
+
+
 def _chk(t, name, dtype=torch.float32):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f'{name} must be a torch.Tensor')
@@ -49,7 +52,9 @@ def to_channels_last(x, pad_to=None):
 
 
 def from_channels_last(x, ndim_spatial=3):
-    """[B,D,H,W,C] -> [B,C,D,H,W] (or [B,C,H,W] when ndim_spatial == 2)."""
+    """[B,D,H,W,C] -> [B,C,D,H,W] (or [B,C,H,W] when ndim_spatial == 2); the reference layout is always fp32."""
+    if x.dtype == torch.bfloat16:
+        x = x.float()
     _chk(x, 'x')
     B, D, H, W, Cn = x.shape
     S = D * H * W
@@ -63,17 +68,27 @@ def from_channels_last(x, ndim_spatial=3):
 
 # ------------------------------------------------------------------ conv
 def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0), relu=False,
-             res=None, res_mode=0, naive=False, out=None, wgt_layout=0, out_mode=0, res_after_act=False, post_scale=1.0):
-    """x [B,D,H,W,Cin], wgt [Cout,KD,KH,KW,Cin] (packed), scale/shift [Cout] -> [B,Do,Ho,Wo,Cout]."""
-    _chk(x, 'x')
-    _chk(wgt, 'wgt')
+             res=None, res_mode=0, naive=False, out=None, wgt_layout=0, out_mode=0, res_after_act=False, post_scale=1.0,
+             out_dtype=None):
+    """x [B,D,H,W,Cin], wgt [Cout,KD,KH,KW,Cin] (packed), scale/shift [Cout] -> [B,Do,Ho,Wo,Cout].
+    x and wgt are fp32 (the reference's precision) or both bf16; out_dtype (default: x.dtype) is the storage type of
+    the output and of the residual.  Accumulation and the epilogue are fp32 in every case."""
+    if x.dtype not in _DT:
+        raise TypeError(f'x must be float32 or bfloat16, got {x.dtype}')
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    if out_dtype not in _DT:
+        raise TypeError(f'out_dtype must be float32 or bfloat16, got {out_dtype}')
+    _chk(x, 'x', x.dtype)
+    _chk(wgt, 'wgt', x.dtype)
     B, D, H, W, Cin = x.shape
     Cout = wgt.shape[0]
-    want = (kernel[0], kernel[1], kernel[2], Cin) if wgt_layout == 0 else (Cin // 32, kernel[0], kernel[1], kernel[2], 32)
+    ck = 64 if x.dtype == torch.bfloat16 else 32
+    want = (kernel[0], kernel[1], kernel[2], Cin) if wgt_layout == 0 else (Cin // ck, kernel[0], kernel[1], kernel[2], ck)
     if tuple(wgt.shape[1:]) != want:
         raise ValueError(f'weight shape {tuple(wgt.shape)} does not match kernel {kernel} / Cin {Cin} / layout {wgt_layout}')
     d = ConvDesc(B, D, H, W, Cin, Cout, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
-                 padding[0], padding[1], padding[2], int(bool(relu)), 0, 0, 0, int(wgt_layout), int(out_mode), int(bool(res_after_act)), float(post_scale))
+                 padding[0], padding[1], padding[2], int(bool(relu)), 0, 0, 0, int(wgt_layout), int(out_mode), int(bool(res_after_act)), float(post_scale),
+                 _DT[x.dtype], _DT[out_dtype])
     do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
     L = _lib.lib()
     check(L.ivx_conv_out_dims(C.byref(d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')
@@ -81,7 +96,7 @@ def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1),
     if out_mode == 1:
         oshape = (B, 2 * D, 2 * H, 2 * W, Cout // 8)
     if res is not None:
-        _chk(res, 'res')
+        _chk(res, 'res', out_dtype)
         if res_mode == 0:
             res_mode = 1
         if res_mode == 1 and tuple(res.shape) != oshape:
@@ -97,9 +112,9 @@ def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1),
             if t.numel() != oshape[-1]:
                 raise ValueError(f'{n} must have {oshape[-1]} elements')
     if out is None:
-        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+        out = torch.empty(oshape, device=x.device, dtype=out_dtype)
     else:
-        _chk(out, 'out')
+        _chk(out, 'out', out_dtype)
     if naive:
         check(L.ivx_conv_fwd_naive(C.byref(d), _ptr(x), _ptr(wgt), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _stream()),
               'ivx_conv_fwd_naive')
@@ -112,13 +127,16 @@ def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1),
 
 
 def maxpool2d(x, k=3, s=2, p=1):
-    _chk(x, 'x')
+    if x.dtype not in _DT:
+        raise TypeError(f'x must be float32 or bfloat16, got {x.dtype}')
+    _chk(x, 'x', x.dtype)
     B, D, H, W, Cn = x.shape
     if D != 1:
         raise ValueError('maxpool2d expects a 2-D map (D == 1)')
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-    out = torch.empty((B, 1, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
-    check(_lib.lib().ivx_maxpool2d_fwd(_ptr(x), B, H, W, Cn, k, s, p, _ptr(out), _stream()), 'ivx_maxpool2d_fwd')
+    out = torch.empty((B, 1, Ho, Wo, Cn), device=x.device, dtype=x.dtype)
+    fn = _lib.lib().ivx_maxpool2d_fwd if x.dtype == torch.float32 else _lib.lib().ivx_maxpool2d_fwd_bf16
+    check(fn(_ptr(x), B, H, W, Cn, k, s, p, _ptr(out), _stream()), 'ivx_maxpool2d_fwd')
     return out
 
 
@@ -148,7 +166,14 @@ def upsample_trilinear2x(x):
 # ------------------------------------------------------------------ unprojection
 def backproject_mean(feat, proj, new_origin, crop_hw, voxel_size, n_voxels):
     """feat [B*V,1,FH,FW,C] channels-last, proj [B,V,3,4], new_origin [B,3], crop_hw [B,2] int32 (device)
-    -> volume [B,X,Y,Z,C] fp32, valid [B,X,Y,Z] bool."""
+    -> volume [B,X,Y,Z,C] (feat's dtype), valid [B,X,Y,Z] bool.
+    bf16 storage (optional reduced-precision mode): with one view the lift is a pure gather-copy (no arithmetic on the
+    features, imvoxelnet.py:75 divides by a count of 1), so a bf16 map with C channels is passed as C/2 32-bit words."""
+    if feat.dtype == torch.bfloat16:
+        if proj.shape[1] != 1 or feat.shape[-1] % 2:
+            raise NotImplementedError('bf16 unprojection is built for single-view inputs with an even channel count')
+        vol, valid = backproject_mean(feat.view(torch.float32), proj, new_origin, crop_hw, voxel_size, n_voxels)
+        return vol.view(torch.bfloat16), valid
     _chk(feat, 'feat')
     _chk(proj, 'proj')
     _chk(new_origin, 'new_origin')

@@ -61,7 +61,13 @@ const char *ivx_last_error(void);
  * Epilogue order: v = acc*scale + shift; [v += res]; [ReLU]; [v += res if res_after_act]; v *= post_scale.
  * res   NULL, or res_mode 1: same shape as out; res_mode 2: [B,1,res_h,res_w,Cout] read with
  *       nearest-neighbour up-sampling to (Ho,Wo) (FPN top-down path, F.interpolate 'nearest').
- * Arithmetic: fp32 inputs, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.            */
+ * Arithmetic: fp32 inputs, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate -- the reference's precision and
+ * the default.  Optional reduced-precision storage (the reference has no such mode; BASELINE config 5):
+ *   in_dtype  IVX_BF16: in and wgt are bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate); needs Cin % 8 == 0,
+ *             wgt_layout 1 then uses 64-channel chunks [Cout,Cin/64,KD,KH,KW,64]; scale/shift stay fp32.
+ *   out_dtype IVX_BF16: out and res are bf16 (epilogue in fp32, one round-to-nearest-even at the store).  */
+#define IVX_F32 0
+#define IVX_BF16 1
 typedef struct ivx_conv_desc {
   int32_t B, D, H, W, Cin;
   int32_t Cout, KD, KH, KW;
@@ -75,22 +81,24 @@ typedef struct ivx_conv_desc {
                             (out is [B,2D,2H,2W,C]; scale/shift have C entries; res, if any, has the out shape) */
   int32_t res_after_act; /* 1: the residual is added after the ReLU (skip adds of the U-shaped necks) */
   float post_scale;      /* final multiplier, 0 or 1 = none (Atlas neck: (x + y) / 2) */
+  int32_t in_dtype;      /* IVX_F32 (default) or IVX_BF16: element type of in and wgt */
+  int32_t out_dtype;     /* IVX_F32 (default) or IVX_BF16: element type of out and res */
 } ivx_conv_desc;
 
 int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *Ho, int32_t *Wo);
-int ivx_conv_fwd(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
-                 const float *shift, const float *res, float *out, ivx_stream_t stream);
+int ivx_conv_fwd(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
+                 const float *shift, const void *res, void *out, ivx_stream_t stream);
 /* Same as ivx_conv_fwd with a caller-owned workspace of ivx_conv_workspace_bytes(d) bytes (0 for most layers): lets
  * the library split K across workgroups for layers whose output is too small to fill the chip (ResNet stage 4, FPN
  * laterals on C5, coarse levels of the indoor necks); slices are summed in a fixed order (deterministic).        */
 int64_t ivx_conv_workspace_bytes(const ivx_conv_desc *d);
-int ivx_conv_fwd_ws(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale, const float *shift,
-                    const float *res, float *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
+int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale, const float *shift,
+                    const void *res, void *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
 
 /* Validation kernel: same contract, one thread per output element, plain FMA loop. Used by the
  * GPU tests to cross-check the MFMA kernel at full size; never called by the product path.   */
-int ivx_conv_fwd_naive(const ivx_conv_desc *d, const float *in, const float *wgt, const float *scale,
-                       const float *shift, const float *res, float *out, ivx_stream_t stream);
+int ivx_conv_fwd_naive(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
+                       const float *shift, const void *res, void *out, ivx_stream_t stream);
 
 /* Tuning knob for A/B experiments only: 0 = automatic tile choice (default), 1..6 = force a tile config. */
 int ivx_conv_set_tile_override(int cfg);
@@ -108,6 +116,9 @@ int ivx_dcn_im2col_fwd(const float *x, const float *offset_mask, int32_t B, int3
 /* nn.MaxPool2d(kernel, stride, padding) on NHWC (ResNet stem: 3, 2, 1). */
 int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
                       int32_t s, int32_t p, float *out, ivx_stream_t stream);
+/* Same on bf16 storage (optional reduced-precision mode; a max of bf16 values is exact). */
+int ivx_maxpool2d_fwd_bf16(const void *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                           int32_t s, int32_t p, void *out, ivx_stream_t stream);
 
 /* F.interpolate(scale_factor=2, mode='trilinear', align_corners=False) on NDHWC [B,D,H,W,C] -> [B,2D,2H,2W,C]
  * (Atlas decoder of ImVoxelNeck, mmdet3d/models/necks/imvoxelnet.py:359).  C % 4 == 0. */

@@ -108,6 +108,75 @@ def test_conv_config_variants(ia):
         L.ivx_conv_set_tile_override(0)
 
 
+BF16_CASES = [
+    # name, B, Cin, D,H,W, Cout, k, stride, pad, res, relu
+    ('bf_k3_c64_s1', 1, 64, 10, 12, 12, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, True),
+    ('bf_k3_c128_256_s2', 1, 128, 8, 8, 6, 256, (3, 3, 3), (2, 2, 2), (1, 1, 1), False, True),
+    ('bf_k3_c64_cout72_s112', 2, 64, 9, 11, 12, 72, (3, 3, 3), (1, 1, 2), (1, 1, 1), False, False),
+    ('bf_k1_c256_64', 2, 256, 1, 24, 40, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, False),
+    ('bf_k3_c24_layout0', 1, 24, 5, 6, 7, 40, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, True),
+    ('bf_splitk_res4_3x3', 2, 512, 1, 12, 20, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), True, True),
+]
+
+
+@pytest.mark.parametrize('case', BF16_CASES, ids=[c[0] for c in BF16_CASES])
+def test_conv_bf16_storage(ia, case):
+    """Optional reduced-precision mode (not the reference's precision; BASELINE config 5): bf16 in / wgt, fp32 MFMA
+    accumulate, fp32 epilogue.  Reference = fp32 conv of the bf16-rounded operands (products of bf16 are exact in fp32,
+    so only the summation order differs): tolerance 2e-4 with fp32 output, one bf16 ulp (2^-7 relative) with bf16 output."""
+    from imvoxelnet_amd.conv import FusedConv
+    name, B, Cin, D, H, W, Cout, k, s, p, res, relu = case
+    g = torch.Generator().manual_seed(abs(hash(name)) % 10000)
+    bf = torch.bfloat16
+    x = torch.randn(B, Cin, D, H, W, generator=g).to(bf).float()
+    w = (torch.randn((Cout, Cin) + k, generator=g) * (2.0 / (Cin * k[0] * k[1] * k[2])) ** 0.5).to(bf).float()
+    bnp = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1,
+           torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5)
+    ref = F.batch_norm(F.conv3d(x, w, None, s, p), bnp[2], bnp[3], bnp[0], bnp[1], False, 0.0, 1e-5)
+    r = torch.randn(ref.shape, generator=g).to(bf).float() if res else None
+    xc = cl(x).to(bf)
+    for out_dtype in (torch.float32, bf):
+        rr = None
+        full = ref
+        if res and out_dtype == bf:        # the residual has the output's storage type
+            rr = cl(r).to(bf)
+            full = ref + r
+        if relu:
+            full = F.relu(full)
+        fc = FusedConv(w, None, bnp, stride=s, padding=p, relu=relu, dtype=bf, out_dtype=out_dtype).to('cuda')
+        y = fc(xc, res=rr)
+        yn = fc(xc, res=rr, naive=True)
+        assert y.dtype == out_dtype
+        if out_dtype == bf:
+            assert_close(name + ' bf16-out mfma-vs-torch', uncl(y.float()), full, 2 ** -7, 1e-3)
+            assert_close(name + ' bf16-out mfma-vs-naive', uncl(y.float()), uncl(yn.float()), 2 ** -7, 1e-3)
+        else:
+            assert_close(name + ' f32-out mfma-vs-torch', uncl(y), full, 2e-4, 2e-4)
+            assert_close(name + ' f32-out mfma-vs-naive', uncl(y), uncl(yn), 2e-4, 1e-4)
+        assert torch.equal(y, fc(xc, res=rr))
+
+
+def test_conv_bf16_tile_variants(ia):
+    """Every bf16 tile configuration (override 61..73; 41/51 map to 61/71) on one problem."""
+    from imvoxelnet_amd import _lib
+    from imvoxelnet_amd.conv import FusedConv
+    g = torch.Generator().manual_seed(17)
+    bf = torch.bfloat16
+    x = torch.randn(1, 64, 6, 9, 7, generator=g).to(bf).float()
+    w = (torch.randn(72, 64, 3, 3, 3, generator=g) * 0.05).to(bf).float()
+    ref = F.conv3d(x, w, None, (1, 1, 2), 1)
+    xc = cl(x).to(bf)
+    L = _lib.lib()
+    try:
+        for layout in (1, 0):
+            fc = FusedConv(w, stride=(1, 1, 2), padding=1, layout=layout, dtype=bf, out_dtype=torch.float32).to('cuda')
+            for ov in (61, 63, 64, 66, 71, 72, 73, 41, 51):
+                L.ivx_conv_set_tile_override(ov)
+                assert_close(f'bf16 layout{layout} override{ov}', uncl(fc(xc)), ref, 2e-4, 2e-4)
+    finally:
+        L.ivx_conv_set_tile_override(0)
+
+
 def test_conv_grid_tail_split(ia):
     """Large-M layer whose last partial round of tiles is run as a second, K-split launch (plan_conv tail plan):
     same result as the validation kernel, deterministic, and the plan really asks for a workspace."""

@@ -115,6 +115,50 @@ def test_kitti_full_path_vs_oracle(ia):
     assert_close('e2e boxes', out[0]['boxes_3d'].tensor, rb, 2e-3, 2e-3)
 
 
+def test_kitti_bf16_storage_mode_tracks_fp32(ia):
+    """Optional reduced-precision mode (BASELINE config 5; the reference itself is fp32-only): bf16 activations and
+    weights, fp32 accumulate / epilogue / head output / tail.  Checked against THIS library's fp32 path (which is the
+    one pinned to the oracle) at the full KITTI size.  Tolerances (relative to the tensor's max magnitude): FPN level 0
+    3e-2, neck output 5e-2, head logits 5e-2; the 10 best detections agree within 0.3 m / 0.05 score."""
+    model = ia.build_detector(kitti_model_cfg(), test_cfg=KITTI_TEST_CFG)
+    ia.randomize_(model, 123)
+    with torch.no_grad():
+        model.bbox_head.conv_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(5))
+        model.bbox_head.conv_cls.bias.fill_(-2.0)
+        model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
+        model.bbox_head.conv_dir_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(7))
+    meta = kitti_meta(box_type=ia.LiDARInstance3DBoxes)
+    img = torch.randn(2, 1, 3, 384, 1280, generator=torch.Generator().manual_seed(11)).cuda()
+    outs = {}
+    for name, dt in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+        model.prepare(torch.device('cuda'), dtype=dt)
+        p0 = model.features_2d_cl(img)
+        vol, valid = model.lift_cl(p0, [meta, meta])
+        assert p0.dtype == dt and vol.dtype == dt
+        y = model.neck_3d.forward_cl(vol)
+        h = model.bbox_head.forward_cl(y)
+        assert h.dtype == torch.float32
+        det = model.simple_test(img, [meta, meta])
+        outs[name] = (p0.float(), valid, y.float(), h, det)
+    model.prepare(torch.device('cuda'))
+    a, b = outs['f32'], outs['bf16']
+    assert torch.equal(a[1], b[1]), 'the valid mask is geometry only'
+    for nm, i, tol in (('fpn0', 0, 3e-2), ('neck', 2, 5e-2), ('head', 3, 5e-2)):
+        err = (a[i] - b[i]).abs().max().item() / a[i].abs().max().item()
+        print(f'bf16 vs f32 {nm}: max err / max |x| = {err:.4f}')
+        assert err < tol, (nm, err)
+    for da, db in zip(a[4], b[4]):
+        na, nb = len(da['scores_3d']), len(db['scores_3d'])
+        print('detections f32', na, 'bf16', nb)
+        assert na > 0 and abs(na - nb) <= max(3, na // 5)
+        k = min(10, na, nb)
+        ca, cb = da['boxes_3d'].tensor[:k, :3], db['boxes_3d'].tensor[:k, :3]
+        d = torch.cdist(ca, cb).min(dim=1).values
+        print('top-k centre distance to the nearest bf16 detection', d.tolist())
+        assert (d < 0.3).float().mean().item() >= 0.8
+        assert abs(float(da['scores_3d'][0]) - float(db['scores_3d'][0])) < 0.05
+
+
 def test_indoor_eval_on_device_matches_reference(ia):
     """indoor_eval with the 3-D IoU from the device kernel (BaseInstance3DBoxes.overlaps -> ivx_boxes_overlap_bev)."""
     from test_host_cpu import _eval_inputs

@@ -28,7 +28,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) <= declared
     assert L.ivx_version() >= 100
     # struct layouts used by the ctypes binding match the header field counts
-    assert ctypes.sizeof(_lib.ConvDesc) == 23 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 25 * 4     # ivx_conv_desc: 22 int32 + float + 2 int32 dtypes
     assert ctypes.sizeof(_lib.AnchorHeadDesc) == 17 * 4
 
 

@@ -77,6 +77,7 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--set', default='neck')
     ap.add_argument('--layout', type=int, default=1)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     a = ap.parse_args()
     if a.set == 'resnet':
         return run2d(a)
@@ -85,9 +86,11 @@ def main():
     g = torch.Generator(device='cuda').manual_seed(0)
     for li in layers:
         name, (X, Y, Z), ci, co, st, pd = LAYERS[li]
-        x = torch.randn(a.batch, X, Y, Z, ci, device='cuda', generator=g)
-        lay = a.layout if ci % 32 == 0 else 0
-        w = torch.randn((co, 3, 3, 3, ci) if lay == 0 else (co, ci // 32, 3, 3, 3, 32), device='cuda', generator=g) * 0.02
+        dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+        ck = 64 if a.dtype == 'bf16' else 32
+        x = torch.randn(a.batch, X, Y, Z, ci, device='cuda', generator=g).to(dt)
+        lay = a.layout if ci % ck == 0 else 0
+        w = (torch.randn((co, 3, 3, 3, ci) if lay == 0 else (co, ci // ck, 3, 3, 3, ck), device='cuda', generator=g) * 0.02).to(dt)
         sc = torch.rand(co, device='cuda', generator=g) + 0.5
         sh = torch.randn(co, device='cuda', generator=g)
         for cfg in [int(v) for v in a.cfgs.split(',')]:
