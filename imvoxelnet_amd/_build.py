@@ -15,6 +15,7 @@ SOURCES = [
     ('anchor_tail.hip', ['-ffp-contract=off']),
     ('dcn.hip', []),
     ('api_common.cpp', []),
+    ('kitti_eval.cpp', []),
 ]
 
 

@@ -33,7 +33,8 @@ EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd',
            'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
            'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_fcos_head_workspace_bytes',
            'ivx_fcos_head_level_candidates', 'ivx_nms_workspace_bytes',
-           'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms']
+           'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms',
+           'ivx_kitti_image_box_overlap', 'ivx_kitti_compute_statistics', 'ivx_kitti_collect_scores', 'ivx_kitti_fused_statistics']
 
 
 def lib():

@@ -581,6 +581,144 @@ def gen_indoor_eval(ns):
     print('indoor_eval', {k: round(v, 4) for k, v in res.items() if k.startswith('m')})
 
 
+def synth_kitti_annos(seed=90, n_img=60):
+    """Synthetic KITTI-format annotation / detection dicts (camera frame) that exercise every branch of the AP code:
+    all three classes plus Van / Person_sitting / DontCare, heights around the per-difficulty minimum, occlusion and
+    truncation levels around the limits, missed objects, duplicates, class flips and false positives."""
+    rng = np.random.RandomState(seed)
+    names = ['Car', 'Pedestrian', 'Cyclist', 'Van', 'Person_sitting', 'DontCare']
+    dims_by = {'Car': (3.9, 1.56, 1.6), 'Van': (5.0, 2.1, 1.9), 'Pedestrian': (0.8, 1.73, 0.6), 'Person_sitting': (0.8, 1.2, 0.6),
+               'Cyclist': (1.76, 1.73, 0.6), 'DontCare': (1.0, 1.0, 1.0)}
+    gts, dts = [], []
+    for i in range(n_img):
+        n = rng.randint(1, 9)
+        nm = rng.choice(names, n, p=[0.4, 0.2, 0.15, 0.1, 0.05, 0.1])
+        z = rng.uniform(6, 55, n)
+        x = rng.uniform(-12, 12, n)
+        y = rng.uniform(1.4, 1.9, n)
+        dims = np.array([dims_by[k] for k in nm]) * rng.uniform(0.85, 1.15, (n, 3))
+        ry = rng.uniform(-np.pi, np.pi, n)
+        h2d = 721.5 * dims[:, 1] / z * rng.uniform(0.9, 1.1, n)           # pixel height: crosses 25 / 40 px with depth
+        w2d = h2d * rng.uniform(0.6, 2.2, n)
+        cx, cy = 609.5 + 721.5 * x / z, 172.8 + rng.uniform(-10, 30, n)
+        bbox = np.stack([cx - w2d / 2, cy - h2d / 2, cx + w2d / 2, cy + h2d / 2], 1)
+        gt = dict(name=np.array(nm), truncated=rng.choice([0.0, 0.1, 0.2, 0.4, 0.6], n, p=[.5, .2, .1, .1, .1]),
+                  occluded=rng.choice([0, 1, 2, 3], n, p=[.5, .25, .15, .1]), alpha=rng.uniform(-np.pi, np.pi, n),
+                  bbox=bbox, dimensions=dims, location=np.stack([x, y, z], 1), rotation_y=ry)
+        real = nm != 'DontCare'
+        keep = real & (rng.rand(n) < 0.8)
+        k = int(keep.sum())
+        jit = rng.normal(0, 1, (k, 3)) * np.array([[0.08, 0.02, 0.12]]) * rng.choice([1.0, 3.0], (k, 1), p=[0.7, 0.3])
+        dloc = gt['location'][keep] + jit
+        ddim = dims[keep] * rng.uniform(0.96, 1.04, (k, 3))
+        dry = ry[keep] + rng.normal(0, 0.05, k)
+        dbox = bbox[keep] + rng.normal(0, 2.0, (k, 4))
+        dname = nm[keep].copy()
+        dname[np.isin(dname, ['Van'])] = 'Car'
+        dname[np.isin(dname, ['Person_sitting'])] = 'Pedestrian'
+        flip = rng.rand(k) < 0.1
+        dname[flip] = rng.choice(['Car', 'Pedestrian', 'Cyclist'], int(flip.sum()))
+        dalpha = gt['alpha'][keep] + rng.normal(0, 0.2, k)
+        # duplicates of the first kept object and a few false positives (some on DontCare regions, some tiny)
+        nfp = rng.randint(0, 4)
+        if k:
+            dloc = np.concatenate([dloc, dloc[:1] + 0.05]); ddim = np.concatenate([ddim, ddim[:1]]); dry = np.concatenate([dry, dry[:1]])
+            dbox = np.concatenate([dbox, dbox[:1] + 1.0]); dname = np.concatenate([dname, dname[:1]]); dalpha = np.concatenate([dalpha, dalpha[:1]])
+        fz = rng.uniform(6, 55, nfp)
+        fl = np.stack([rng.uniform(-12, 12, nfp), rng.uniform(1.4, 1.9, nfp), fz], 1)
+        fd = np.array([dims_by['Car']] * nfp).reshape(nfp, 3) * rng.uniform(0.8, 1.2, (nfp, 3))
+        fh = rng.uniform(15, 90, nfp)
+        fcx, fcy = rng.uniform(100, 1100, nfp), rng.uniform(150, 220, nfp)
+        fb = np.stack([fcx - fh, fcy - fh / 2, fcx + fh, fcy + fh / 2], 1)
+        dc = bbox[nm == 'DontCare']
+        if len(dc) and nfp:
+            fb[0] = dc[0] + rng.normal(0, 1.0, 4)
+        dloc = np.concatenate([dloc.reshape(-1, 3), fl]); ddim = np.concatenate([ddim.reshape(-1, 3), fd]); dry = np.concatenate([dry, rng.uniform(-3, 3, nfp)])
+        dbox = np.concatenate([dbox.reshape(-1, 4), fb]); dname = np.concatenate([dname, rng.choice(['Car', 'Pedestrian', 'Cyclist'], nfp)])
+        dalpha = np.concatenate([dalpha, rng.uniform(-3, 3, nfp)])
+        nd = len(dname)
+        dt = dict(name=np.array(dname), truncated=np.zeros(nd), occluded=np.zeros(nd, dtype=np.int64), alpha=dalpha, bbox=dbox,
+                  dimensions=ddim, location=dloc, rotation_y=dry, score=rng.uniform(0.05, 1.0, nd))
+        gts.append(gt)
+        dts.append(dt)
+    return gts, dts
+
+
+def gen_kitti_eval(ns):
+    """Reference kitti_eval (core/evaluation/kitti_utils/eval.py) on synthetic annotations.  numba is absent, so
+    numba.jit is the identity and the reference's numba-CUDA *device functions* of rotate_iou.py (rbbox_to_corners,
+    quadrilateral_intersection, sort_vertex_in_convex_polygon, area, inter, devRotateIoUEval) run as plain Python with
+    cuda.local.array -> numpy float32 arrays; only the kernel launcher rotate_iou_gpu_eval is replaced by a pair loop
+    that calls the reference's devRotateIoUEval with the launcher's argument order (query box first)."""
+    import types
+    import importlib.util
+    nb = sys.modules['numba']
+    nb.float32 = np.float32
+    nb.prange = range
+    cuda = types.ModuleType('numba.cuda')
+
+    def cjit(*a, **k):
+        if a and callable(a[0]):
+            return a[0]
+        return lambda f: f
+    cuda.jit = cjit
+    cuda.local = types.SimpleNamespace(array=lambda shape, dtype: np.zeros(shape, dtype=dtype))
+    nb.cuda = cuda
+    sys.modules['numba.cuda'] = cuda
+    pkg = types.ModuleType('ref_kitti_utils')
+    pkg.__path__ = [os.path.join(ref_import.REF, 'mmdet3d/core/evaluation/kitti_utils')]
+    sys.modules['ref_kitti_utils'] = pkg
+    mods = {}
+    for name in ('rotate_iou', 'eval'):
+        spec = importlib.util.spec_from_file_location(f'ref_kitti_utils.{name}', os.path.join(pkg.__path__[0], name + '.py'))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f'ref_kitti_utils.{name}'] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    riou, ev = mods['rotate_iou'], mods['eval']
+
+    def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):
+        boxes = boxes.astype(np.float32)
+        query_boxes = query_boxes.astype(np.float32)
+        out = np.zeros((boxes.shape[0], query_boxes.shape[0]), dtype=np.float32)
+        for i in range(boxes.shape[0]):
+            for j in range(query_boxes.shape[0]):
+                out[i, j] = riou.devRotateIoUEval(query_boxes[j], boxes[i], criterion)
+        return out
+    riou.rotate_iou_gpu_eval = rotate_iou_gpu_eval
+
+    store = {}
+    # (1) rotated IoU vectors: random pairs + touching / identical / contained / disjoint cases
+    rng = np.random.RandomState(91)
+    a = np.concatenate([rng.uniform(-4, 4, (40, 2)), rng.uniform(0.5, 5, (40, 2)), rng.uniform(-3.2, 3.2, (40, 1))], 1).astype(np.float32)
+    b = np.concatenate([a[:20, :2] + rng.normal(0, 0.8, (20, 2)), a[:20, 2:4] * rng.uniform(0.7, 1.3, (20, 2)),
+                        a[:20, 4:] + rng.normal(0, 0.5, (20, 1))], 1).astype(np.float32)
+    b = np.concatenate([b, a[:3], np.array([[0, 0, 2, 2, 0], [0.5, 0, 1, 1, 0.3], [50, 50, 1, 1, 0]], dtype=np.float32)])
+    store['riou::boxes'], store['riou::query'] = a, b
+    for crit in (-1, 0, 1, 2):
+        store[f'riou::out{crit}'] = rotate_iou_gpu_eval(a, b, crit)
+    # (2) whole evaluation
+    gts, dts = synth_kitti_annos()
+    for tag, annos in (('gt', gts), ('dt', dts)):       # the inputs travel with the fixture (flat arrays + per-image counts)
+        store[f'anno::{tag}::count'] = np.array([len(a['name']) for a in annos], dtype=np.int64)
+        for key in annos[0]:
+            store[f'anno::{tag}::{key}'] = np.concatenate([np.asarray(a[key]) for a in annos], 0)
+    res_str, res = ev.kitti_eval(gts, dts, ['Car', 'Pedestrian', 'Cyclist'], eval_types=['bbox', 'bev', '3d'])
+    res1_str, res1 = ev.kitti_eval(gts, dts, ['Car'], eval_types=['bbox', 'bev', '3d'])
+    store['eval::result_str'] = np.array(res_str)
+    store['eval::result'] = np.array(json.dumps({k: float(v) for k, v in res.items()}))
+    store['eval::car_only_str'] = np.array(res1_str)
+    store['eval::car_only'] = np.array(json.dumps({k: float(v) for k, v in res1.items()}))
+    # per-image 3-D / BEV overlap matrices of the first images (dt x gt), for the overlap restatement
+    ov3, _, _, _ = ev.calculate_iou_partly(dts[:6], gts[:6], 2, 6)
+    ovb, _, _, _ = ev.calculate_iou_partly(dts[:6], gts[:6], 1, 6)
+    for i in range(6):
+        store[f'eval::ov3d{i}'] = ov3[i]
+        store[f'eval::ovbev{i}'] = ovb[i]
+    np.savez_compressed(os.path.join(GOLD, 'kitti_eval.npz'), **store)
+    print('kitti_eval', res_str)
+
+
 def main():
     ns = ref_import.load()
     gen_backproject(ns)
@@ -592,6 +730,7 @@ def main():
     gen_e2e_small(ns)
     gen_indoor_heads(ns)
     gen_indoor_eval(ns)
+    gen_kitti_eval(ns)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

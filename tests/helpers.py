@@ -29,3 +29,17 @@ def sd_from(npz, prefix):
 def meta_from_case(c):
     return dict(img_shape=tuple(int(v) for v in c['img_shape']), ori_shape=tuple(int(v) for v in c['ori_shape']),
                 lidar2img=dict(intrinsic=c['intrinsic'], extrinsic=list(c['extrinsic']), origin=c['origin']))
+
+
+def kitti_annos_from_golden(g):
+    """Rebuild the per-image annotation / detection dicts of tests/golden/kitti_eval.npz."""
+    out = []
+    for tag in ('gt', 'dt'):
+        counts = g[f'anno::{tag}::count']
+        keys = [k.split('::')[2] for k in g.files if k.startswith(f'anno::{tag}::') and not k.endswith('::count')]
+        annos, o = [], 0
+        for n in counts:
+            annos.append({k: g[f'anno::{tag}::{k}'][o:o + n] for k in keys})
+            o += int(n)
+        out.append(annos)
+    return out

@@ -592,3 +592,24 @@ def test_indoor_path_vs_oracle(ia):
     assert len(scores) == len(rs) and np.array_equal(labels.cpu().numpy(), rl.numpy())
     assert_close('scores', scores, rs, 1e-3, 1e-5)
     assert_close('boxes', boxes.tensor, rb, 1e-3, 1e-3)
+
+
+def test_kitti_eval_device_overlaps_match_reference(ia):
+    """kitti_eval with the rotated overlaps from the device kernel (ivx_boxes_overlap_bev) against the reference's
+    kitti_eval on the synthetic annotations of tests/golden/kitti_eval.npz: every AP within 1e-6, identical report."""
+    from helpers import kitti_annos_from_golden
+    from imvoxelnet_amd import kitti_ap as ke
+    g = load_npz('kitti_eval.npz')
+    same = (g['riou::boxes'][:, None, :] == g['riou::query'][None, :, :]).all(-1)      # degenerate upstream, see the CPU test
+    for crit in (-1, 0, 1, 2):
+        got = ke.rotate_iou_eval(g['riou::boxes'], g['riou::query'], crit)
+        err = np.abs(got - g[f'riou::out{crit}'])[~same].max()
+        print('criterion', crit, 'max err', err)
+        assert err < 2e-5
+    gts, dts = kitti_annos_from_golden(g)
+    res_str, res = ke.kitti_eval(gts, dts, ['Car', 'Pedestrian', 'Cyclist'])
+    ref = json.loads(str(g['eval::result']))
+    assert set(res) == set(ref)
+    for k, v in ref.items():
+        assert abs(float(res[k]) - v) < 1e-6, (k, float(res[k]), v)
+    assert res_str == str(g['eval::result_str'])
