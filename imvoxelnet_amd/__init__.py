@@ -17,7 +17,7 @@ from .boxes import (LiDARInstance3DBoxes, DepthInstance3DBoxes, limit_period, xy
                     rotation_3d_in_axis, bbox3d2result)
 from .nms import nms_gpu, nms_normal_gpu, box3d_multiclass_nms, aligned_3d_nms, boxes_iou_bev  # noqa: F401
 from .evaluation import indoor_eval, average_precision, eval_det_cls, eval_map_recall  # noqa: F401
-from .kitti_ap import kitti_eval, kitti_eval_coco_style  # noqa: F401
+from .kitti_ap import kitti_eval, kitti_eval_coco_style, bbox2result_kitti  # noqa: F401
 from .params import randomize_                                              # noqa: F401
 
 __version__ = '0.1.0'

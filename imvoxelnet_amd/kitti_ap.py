@@ -392,3 +392,93 @@ def kitti_eval_coco_style(gt_annos, dt_annos, current_classes, overlap_fn=None):
         if compute_aos:
             result += f'aos  AP:{mAPaos[j, 0]:.2f}, {mAPaos[j, 1]:.2f}, {mAPaos[j, 2]:.2f}\n'
     return result
+
+
+# ---------------------------------------------------------------------------------------------- detections -> annotations
+def _limit_period(val, offset=0.5, period=np.pi):
+    return val - np.floor(val / period + offset) * period
+
+
+def convert_valid_bboxes(boxes_lidar, scores, labels, info, pcd_limit_range=(0, -40, -3, 70.4, 40, 0.0)):
+    """LiDAR-frame detections of one sample -> camera-frame boxes + projected 2-D boxes, restricted to boxes that touch
+    the image and whose bottom centre lies inside `pcd_limit_range` (datasets/kitti_dataset.py:587-674).
+    boxes_lidar [n,7] (x,y,z,w,l,h,yaw) fp32 with z the bottom; info: {'image': {'image_idx', 'image_shape'},
+    'calib': {'R0_rect','Tr_velo_to_cam','P2'}} as in the reference's info files."""
+    boxes = np.array(boxes_lidar, dtype=np.float32).reshape(-1, 7)
+    scores = np.asarray(scores).reshape(-1)
+    labels = np.asarray(labels).reshape(-1)
+    sample_idx = info['image']['image_idx']
+    empty = dict(bbox=np.zeros([0, 4]), box3d_camera=np.zeros([0, 7]), box3d_lidar=np.zeros([0, 7]), scores=np.zeros([0]),
+                 label_preds=np.zeros([0, 4]), sample_idx=sample_idx)
+    boxes[:, 6] = _limit_period(boxes[:, 6] - np.float32(np.pi), 0.5, np.float32(np.pi * 2))       # :616-617
+    if len(boxes) == 0:
+        return empty
+    rect = info['calib']['R0_rect'].astype(np.float32)
+    trv2c = info['calib']['Tr_velo_to_cam'].astype(np.float32)
+    p2 = info['calib']['P2'].astype(np.float32)
+    rt = rect @ trv2c
+    xyz1 = np.concatenate([boxes[:, :3], np.ones((len(boxes), 1), dtype=np.float32)], 1)
+    cam_xyz = (xyz1 @ rt.T)[:, :3]
+    cam = np.concatenate([cam_xyz, boxes[:, [4, 5, 3]], boxes[:, 6:7]], 1)          # sizes (l, h, w): box_3d_mode.py:104-108
+    # camera-box corners, origin (0.5, 1, 0.5), rotated about the y axis (cam_box3d.py:99-139)
+    cn = np.stack(np.unravel_index(np.arange(8), [2] * 3), axis=1)[[0, 1, 3, 2, 4, 5, 7, 6]].astype(np.float32)
+    cn = cn - np.array([0.5, 1, 0.5], dtype=np.float32)
+    corners = cam[:, None, 3:6] * cn[None]
+    s, c = np.sin(cam[:, 6]), np.cos(cam[:, 6])
+    x = corners[..., 0] * c[:, None] + corners[..., 2] * s[:, None]
+    z = -corners[..., 0] * s[:, None] + corners[..., 2] * c[:, None]
+    corners = np.stack([x, corners[..., 1], z], -1) + cam[:, None, :3]
+    pts4 = np.concatenate([corners, np.ones(corners.shape[:2] + (1,), dtype=np.float32)], -1)
+    uvw = pts4 @ p2.T
+    uv = uvw[..., :2] / uvw[..., 2:3]
+    box2d = np.concatenate([uv.min(1), uv.max(1)], 1)
+    h, w = info['image']['image_shape'][:2]
+    valid_cam = (box2d[:, 0] < w) & (box2d[:, 1] < h) & (box2d[:, 2] > 0) & (box2d[:, 3] > 0)
+    lim = np.asarray(pcd_limit_range, dtype=np.float32)
+    valid_pcd = ((boxes[:, :3] > lim[:3]) & (boxes[:, :3] < lim[3:])).all(-1)
+    keep = valid_cam & valid_pcd
+    if keep.sum() == 0:
+        return empty
+    return dict(bbox=box2d[keep], box3d_camera=cam[keep], box3d_lidar=boxes[keep], scores=scores[keep], label_preds=labels[keep],
+                sample_idx=sample_idx)
+
+
+def bbox2result_kitti(net_outputs, data_infos, class_names, pcd_limit_range=(0, -40, -3, 70.4, 40, 0.0), submission_prefix=None):
+    """simple_test outputs -> KITTI-format detection annotations for kitti_eval (datasets/kitti_dataset.py:360-472).
+    net_outputs: list of dict(boxes_3d, scores_3d, labels_3d) (boxes_3d: LiDARInstance3DBoxes or an [n,7] array)."""
+    import os
+    assert len(net_outputs) == len(data_infos), 'invalid list length of network outputs'
+    if submission_prefix is not None:
+        os.makedirs(submission_prefix, exist_ok=True)
+    det_annos = []
+    for pred, info in zip(net_outputs, data_infos):
+        b = pred['boxes_3d']
+        b = b.tensor if hasattr(b, 'tensor') else b
+        b = b.detach().cpu().numpy() if hasattr(b, 'detach') else np.asarray(b)
+        sc = pred['scores_3d']
+        sc = sc.detach().cpu().numpy() if hasattr(sc, 'detach') else np.asarray(sc)
+        lb = pred['labels_3d']
+        lb = lb.detach().cpu().numpy() if hasattr(lb, 'detach') else np.asarray(lb)
+        image_shape = np.asarray(info['image']['image_shape'][:2])
+        d = convert_valid_bboxes(b, sc, lb, info, pcd_limit_range)
+        n = len(d['bbox'])
+        if n > 0:
+            bbox = d['bbox'].copy()
+            bbox[:, 2:] = np.minimum(bbox[:, 2:], image_shape[::-1])
+            bbox[:, :2] = np.maximum(bbox[:, :2], 0)
+            cam, lid = d['box3d_camera'], d['box3d_lidar']
+            anno = dict(name=np.array([class_names[int(k)] for k in d['label_preds']]), truncated=np.zeros(n), occluded=np.zeros(n, dtype=np.int64),
+                        alpha=-np.arctan2(-lid[:, 1], lid[:, 0]) + cam[:, 6], bbox=bbox, dimensions=cam[:, 3:6], location=cam[:, :3],
+                        rotation_y=cam[:, 6], score=d['scores'])
+        else:
+            anno = dict(name=np.array([]), truncated=np.array([]), occluded=np.array([]), alpha=np.array([]), bbox=np.zeros([0, 4]),
+                        dimensions=np.zeros([0, 3]), location=np.zeros([0, 3]), rotation_y=np.array([]), score=np.array([]))
+        if submission_prefix is not None:
+            with open(f"{submission_prefix}/{info['image']['image_idx']:06d}.txt", 'w') as f:
+                for i in range(n):      # KITTI text format: dims written as h w l
+                    f.write('{} -1 -1 {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f}\n'.format(
+                        anno['name'][i], anno['alpha'][i], *anno['bbox'][i], anno['dimensions'][i][1], anno['dimensions'][i][2],
+                        anno['dimensions'][i][0], *anno['location'][i], anno['rotation_y'][i], anno['score'][i]))
+        anno['sample_idx'] = np.array([info['image']['image_idx']] * n, dtype=np.int64)
+        det_annos.append(anno)
+    return det_annos

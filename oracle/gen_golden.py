@@ -719,6 +719,76 @@ def gen_kitti_eval(ns):
     print('kitti_eval', res_str)
 
 
+def gen_kitti_format(ns):
+    """Reference KittiDataset.bbox2result_kitti / convert_valid_bboxes (datasets/kitti_dataset.py:360-472,587-674) on
+    synthetic LiDAR-frame detections.  The dataset module is loaded with stand-ins for mmcv / mmdet / Custom3DDataset
+    (none of which the two methods touch besides mmcv.track_iter_progress); the box classes are the reference's."""
+    import types
+    import importlib.util
+    base = 'mmdet3d/core/bbox/structures/'
+    cam = ref_import._load('mmdet3d.core.bbox.structures.cam_box3d', base + 'cam_box3d.py')
+    mode = ref_import._load('mmdet3d.core.bbox.structures.box_3d_mode', base + 'box_3d_mode.py')
+    mmcv = sys.modules['mmcv']
+    mmcv.track_iter_progress = lambda x: x
+    mmcv.mkdir_or_exist = lambda p: os.makedirs(p, exist_ok=True)
+    mu = types.ModuleType('mmcv.utils')
+    mu.print_log = lambda *a, **k: None
+    sys.modules['mmcv.utils'] = mu
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda c: c
+    md = types.ModuleType('mmdet.datasets')
+    md.DATASETS = _Reg()
+    sys.modules['mmdet.datasets'] = md
+    core = sys.modules['mmdet3d.core']
+    core.show_result = None
+    cb = sys.modules['mmdet3d.core.bbox']
+    cb.Box3DMode, cb.CameraInstance3DBoxes, cb.Coord3DMode = mode.Box3DMode, cam.CameraInstance3DBoxes, None   # Coord3DMode: show() only
+    cb.points_cam2img = ns.utils.points_cam2img
+    cb.LiDARInstance3DBoxes = ns.lidar.LiDARInstance3DBoxes
+    pk = types.ModuleType('mmdet3d.datasets')
+    pk.__path__ = [os.path.join(ref_import.REF, 'mmdet3d/datasets')]
+    sys.modules['mmdet3d.datasets'] = pk
+    c3 = types.ModuleType('mmdet3d.datasets.custom_3d')
+    c3.Custom3DDataset = object
+    sys.modules['mmdet3d.datasets.custom_3d'] = c3
+    spec = importlib.util.spec_from_file_location('mmdet3d.datasets.kitti_dataset', os.path.join(ref_import.REF, 'mmdet3d/datasets/kitti_dataset.py'))
+    kd = importlib.util.module_from_spec(spec)
+    sys.modules['mmdet3d.datasets.kitti_dataset'] = kd
+    spec.loader.exec_module(kd)
+    # LiDARInstance3DBoxes.convert_to needs Box3DMode from its own module namespace
+    ns.lidar.LiDARInstance3DBoxes.convert_to = lambda self, dst, rt_mat=None: mode.Box3DMode.convert(self, mode.Box3DMode.LIDAR, dst, rt_mat)
+
+    rng = np.random.RandomState(95)
+    rect = np.eye(4); rect[:3, :3] = [[0.9999, 0.0098, -0.0074], [-0.0099, 0.9999, -0.0043], [0.0074, 0.0044, 0.9999]]
+    trv2c = np.eye(4); trv2c[:3] = [[0.0075, -0.99997, -0.0006, -0.0041], [0.0148, 0.0007, -0.9999, -0.0763], [0.9999, 0.0075, 0.0148, -0.2718]]
+    p2 = np.eye(4); p2[:3] = [[721.5377, 0, 609.5593, 44.857], [0, 721.5377, 172.854, 0.2163], [0, 0, 1, 0.0027]]
+    infos, outs, store = [], [], {}
+    for i in range(5):
+        n = [10, 0, 16, 4, 24][i]
+        xyz = np.stack([rng.uniform(-5, 80, n), rng.uniform(-45, 45, n), rng.uniform(-3.3, 0.3, n)], 1)
+        wlh = np.stack([rng.uniform(0.5, 2, n), rng.uniform(0.6, 4.5, n), rng.uniform(1.2, 2, n)], 1)
+        yaw = rng.uniform(-4, 4, (n, 1))
+        b = np.concatenate([xyz, wlh, yaw], 1).astype(np.float32)
+        sc = rng.uniform(0.1, 1, n).astype(np.float32)
+        lb = rng.randint(0, 3, n).astype(np.int64)
+        info = dict(image=dict(image_idx=100 + i, image_shape=np.array([375, 1242], dtype=np.int32)),
+                    calib=dict(R0_rect=rect, Tr_velo_to_cam=trv2c, P2=p2))
+        infos.append(info)
+        outs.append(dict(boxes_3d=ns.lidar.LiDARInstance3DBoxes(torch.from_numpy(b.copy())), scores_3d=torch.from_numpy(sc), labels_3d=torch.from_numpy(lb)))
+        store[f'in{i}::boxes'], store[f'in{i}::scores'], store[f'in{i}::labels'] = b, sc, lb
+    fake = types.SimpleNamespace(data_infos=infos, pcd_limit_range=[0, -40, -3, 70.4, 40, 0.0])
+    fake.convert_valid_bboxes = lambda box_dict, info: kd.KittiDataset.convert_valid_bboxes(fake, box_dict, info)
+    annos = kd.KittiDataset.bbox2result_kitti(fake, outs, ['Pedestrian', 'Cyclist', 'Car'])
+    for i, a in enumerate(annos):
+        for k, v in a.items():
+            store[f'out{i}::{k}'] = np.asarray(v)
+    store['calib::R0_rect'], store['calib::Tr_velo_to_cam'], store['calib::P2'] = rect, trv2c, p2
+    np.savez_compressed(os.path.join(GOLD, 'kitti_format.npz'), **store)
+    print('kitti_format kept', [len(a['score']) for a in annos])
+
+
 def main():
     ns = ref_import.load()
     gen_backproject(ns)
@@ -731,6 +801,7 @@ def main():
     gen_indoor_heads(ns)
     gen_indoor_eval(ns)
     gen_kitti_eval(ns)
+    gen_kitti_format(ns)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

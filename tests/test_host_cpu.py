@@ -369,3 +369,27 @@ def test_kitti_statistics_single_image_known_answers():
     assert st[:3] == [1.0, 0.0, 1.0] and th == [0.9]
     st, _ = run(ov, gt, dt, [0, 0], [0, 0, 0, 0], np.zeros((0, 4)), aos=True)
     assert abs(st[3] - (1.0 + np.cos(0.0 - 0.1)) / 2.0) < 1e-12
+
+
+def test_bbox2result_kitti_matches_reference():
+    """Detections (LiDAR frame) -> KITTI annotation dicts against the reference's KittiDataset.bbox2result_kitti
+    (tests/golden/kitti_format.npz): same boxes kept, fp32 geometry within 1e-4 px / 1e-5 m."""
+    from helpers import load_npz
+    from imvoxelnet_amd import kitti_ap as ke
+    g = load_npz('kitti_format.npz')
+    calib = dict(R0_rect=g['calib::R0_rect'], Tr_velo_to_cam=g['calib::Tr_velo_to_cam'], P2=g['calib::P2'])
+    infos = [dict(image=dict(image_idx=100 + i, image_shape=np.array([375, 1242], dtype=np.int32)), calib=calib) for i in range(5)]
+    outs = [dict(boxes_3d=g[f'in{i}::boxes'], scores_3d=g[f'in{i}::scores'], labels_3d=g[f'in{i}::labels']) for i in range(5)]
+    annos = ke.bbox2result_kitti(outs, infos, ['Pedestrian', 'Cyclist', 'Car'])
+    assert len(annos) == 5
+    kept = 0
+    for i, a in enumerate(annos):
+        ref = {k[len(f'out{i}::'):]: g[k] for k in g.files if k.startswith(f'out{i}::')}
+        assert set(a) == set(ref)
+        assert len(a['score']) == len(ref['score'])
+        kept += len(a['score'])
+        assert list(a['name']) == list(ref['name'])
+        assert np.array_equal(a['sample_idx'], ref['sample_idx'])
+        for k, tol in (('bbox', 1e-3), ('location', 1e-5), ('dimensions', 1e-6), ('rotation_y', 1e-6), ('alpha', 1e-5), ('score', 0)):
+            assert np.abs(np.asarray(a[k], dtype=np.float64) - ref[k].astype(np.float64)).max(initial=0) <= tol, (i, k)
+    assert kept >= 10
