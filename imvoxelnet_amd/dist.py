@@ -42,7 +42,7 @@ def all_gather_detections(boxes, scores, labels, count, group=None):
     """Every rank contributes its [B_local, ...] detections (same B_local and max_num on every rank) and
     receives the detections of the whole batch in rank order."""
     packed = pack_detections(boxes, scores, labels, count)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return unpack_detections(packed, scores.shape[1])
     world = dist.get_world_size(group)
     out = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=packed.dtype, device=packed.device)

@@ -1,11 +1,14 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 (ROCm 7.2 rocpd sqlite) kernel trace: per-kernel calls / total / avg / min / max, and
-per-(kernel, grid) rows for the conv kernel.  Usage: rocpd_summary.py results.db [> profiles/xxx.md]"""
+per-(kernel, grid) rows for the conv kernel.  Usage: rocpd_summary.py results.db [steps] [> profiles/xxx.md]
+With `steps` (timed + warm-up steps of the profiled bench.py run) it also prints the per-step total of the conv launches
+of the 3-D neck (every conv launch >= 0.3 ms plus the K-split tail launches and reductions), the number bench.py's
+event-bracketed `neck_ms_per_step` must agree with."""
 import sqlite3
 import sys
 
 
-def main(path):
+def main(path, steps=0):
     c = sqlite3.connect(path)
     cols = [r[1] for r in c.execute('pragma table_info(kernels)')]
     name = 'name' if 'name' in cols else 'kernel_name'
@@ -18,6 +21,7 @@ def main(path):
     for n, k, t, a, mn, mx in rows:
         print(f'| `{n[:110]}` | {k} | {t / 1e6:.3f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | {100 * t / tot:.2f} |')
     gcols = [x for x in ('grid_x', 'grid_size_x', 'grid_size') if x in cols]
+    gx = gy = None
     if gcols:
         gx = gcols[0]
         gy = gx.replace('x', 'y') if 'x' in gx else None
@@ -29,5 +33,20 @@ def main(path):
             print(f'| `{r[0][:60]}` | {r[1:-2]} | {r[-2]} | {r[-1] / 1e3:.1f} |')
 
 
+    if steps:
+        big = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%conv_igemm%' and end-start >= 300000").fetchone()
+        gy_ok = gcols and gy and gy in cols
+        tail = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%conv_igemm%' and end-start < 300000 and {gy} > 1 and {gx} <= 65536").fetchone() if gy_ok else (0, 0)
+        red = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%splitk_reduce%'").fetchone()
+        print(f'\n## 3-D neck reconciliation ({steps} steps profiled)\n')
+        print('| launches | per step | ms per step |')
+        print('|---|---|---|')
+        print(f'| conv launches >= 0.3 ms (the 11 neck layers, main launch) | {big[0] / steps:.1f} | {(big[1] or 0) / 1e6 / steps:.3f} |')
+        print(f'| K-split launches (neck tails + small 2-D layers) | {tail[0] / steps:.1f} | {(tail[1] or 0) / 1e6 / steps:.3f} |')
+        print(f'| split-K reductions | {red[0] / steps:.1f} | {(red[1] or 0) / 1e6 / steps:.3f} |')
+        print(f'\nneck kernel time per step ~ {((big[1] or 0)) / 1e6 / steps:.2f} ms (+ its share of the K-split rows); bench.py '
+              'brackets the same launches with HIP events (`roofline.neck_ms_per_step`).')
+
+
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)
