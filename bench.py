@@ -125,6 +125,9 @@ def main():
     ap.add_argument('--config', default='kitti', choices=['kitti', 'nuscenes', 'scannet_fast', 'sunrgbd_fast', 'scannet_v1'],
                     help='BASELINE.json workload; the headline metric is quoted on kitti (configs[1]), the default')
     ap.add_argument('--views', type=int, default=0, help='views per scene for the indoor configs (default: reference test value)')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the device side of the step as one captured hipGraph (kitti config); the roofline entry is then '
+                         'taken from the eager warm-up steps, which run the same kernels with HIP events around the neck')
     ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
                     help='f32 (default) = the reference precision and the headline metric; bf16 = optional reduced-precision '
                          'storage mode (kitti only), reported with dtype "bf16" and priced against the bf16 MFMA peak')
@@ -195,6 +198,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    if args.graph:
+        if args.warmup < 1:
+            raise SystemExit('--graph needs at least one eager warm-up step (the roofline entry is measured there)')
+        graphed = model.capture_graph(img, metas)
+
+        def step(i):   # noqa: F811  -- same work, one graph launch
+            boxes, scores, labels, count = graphed.replay_device(img, metas)
+            if world > 1 or force_dist:
+                boxes, scores, labels, count = ivx_dist.all_gather_detections(boxes, scores, labels, count)
+            return ivx_dist.pack_detections(boxes, scores, labels, count).cpu()
+        step(0)
+        torch.cuda.synchronize()
     if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -211,9 +226,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    neck_ms = [ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][1]) for i in range(args.steps)]
+    ev_ids = range(args.warmup) if args.graph else range(args.warmup, args.warmup + args.steps)
+    if args.graph and args.warmup > 1:
+        ev_ids = range(1, args.warmup)       # skip the very first (cold) step
+    neck_ms = [ev[i][0].elapsed_time(ev[i][1]) for i in ev_ids]
     neck_ms_avg = sum(neck_ms) / len(neck_ms)
-    lift_ms = sum(ev[args.warmup + i][2].elapsed_time(ev[args.warmup + i][0]) for i in range(args.steps)) / args.steps
+    lift_ms = sum(ev[i][2].elapsed_time(ev[i][0]) for i in ev_ids) / len(neck_ms)
     # unprojection: algorithmic bytes = features read once + volume written once + mask (173.1 MB/sample)
     lift_bytes = B * (1 * 64 * 96 * 320 * esz + 64 * 216 * 248 * 12 * esz + 216 * 248 * 12)
     n_launch = 9     # conv layers of KittiImVoxelNeck = ivx_conv_fwd_ws calls per step (each: one main launch, plus a K-split
@@ -242,7 +260,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'data': 'synthetic',
             'config': {'workload': 'kitti_mono_1x3x384x1280_vox216x248x12_resnet50_fpn64_kittineck_anchor3dhead',
-                       'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'hip_graph': bool(args.graph),
                        'detections_last_step': int(last[:, -1].sum().item())},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, 9 conv layers/step)' % ('__bf16' if bf16 else 'float'),
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',

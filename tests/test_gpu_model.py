@@ -159,6 +159,33 @@ def test_kitti_bf16_storage_mode_tracks_fp32(ia):
         assert abs(float(da['scores_3d'][0]) - float(db['scores_3d'][0])) < 0.05
 
 
+def test_graphed_simple_test_equals_eager(ia):
+    """ImVoxelNet.capture_graph: the hipGraph replay returns exactly the eager results, also after the image and the
+    camera parameters change (static input buffers are refreshed before every replay)."""
+    model = ia.build_detector(kitti_model_cfg(n_voxels=(104, 120, 12)), test_cfg=KITTI_TEST_CFG)
+    ia.randomize_(model, 21)
+    with torch.no_grad():
+        model.bbox_head.conv_cls.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(5))
+        model.bbox_head.conv_cls.bias.fill_(-1.0)
+        model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
+    model.prepare(torch.device('cuda'))
+    g = torch.Generator().manual_seed(3)
+    imgs = [torch.randn(2, 1, 3, 192, 640, generator=g).cuda() for _ in range(3)]
+    metas = [[kitti_meta(img_hw=(192, 640), t=(0.02 * k, 0.01 * b, 0.0), box_type=ia.LiDARInstance3DBoxes) for b in range(2)] for k in range(3)]
+    graphed = model.capture_graph(imgs[0], metas[0])
+    total = 0
+    for img, meta in zip(imgs[::-1], metas[::-1]):
+        ref = model.simple_test(img, meta)
+        got = graphed(img, meta)
+        for r, o in zip(ref, got):
+            assert torch.equal(r['scores_3d'], o['scores_3d']) and torch.equal(r['labels_3d'], o['labels_3d'])
+            assert torch.equal(r['boxes_3d'].tensor, o['boxes_3d'].tensor)
+            total += len(r['scores_3d'])
+    assert total > 0
+    with pytest.raises(ValueError):
+        graphed(imgs[0][:1], metas[0][:1])
+
+
 def test_indoor_eval_on_device_matches_reference(ia):
     """indoor_eval with the 3-D IoU from the device kernel (BaseInstance3DBoxes.overlaps -> ivx_boxes_overlap_bev)."""
     from test_host_cpu import _eval_inputs
