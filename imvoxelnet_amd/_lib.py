@@ -33,7 +33,7 @@ EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd',
            'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
            'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_fcos_head_workspace_bytes',
            'ivx_fcos_head_level_candidates', 'ivx_nms_workspace_bytes',
-           'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms',
+           'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms', 'ivx_multiclass_nms_workspace_bytes', 'ivx_multiclass_nms_bev',
            'ivx_kitti_image_box_overlap', 'ivx_kitti_compute_statistics', 'ivx_kitti_collect_scores', 'ivx_kitti_fused_statistics']
 
 
@@ -74,9 +74,12 @@ def lib():
     L.ivx_nms_bev.argtypes = [vp, i32, f32, i32, vp, i64, vp, vp, vp]
     L.ivx_boxes_overlap_bev.argtypes = [vp, i32, vp, i32, i32, vp, vp]
     L.ivx_aligned_3d_nms.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
+    L.ivx_multiclass_nms_workspace_bytes.argtypes = [i32, i32]
+    L.ivx_multiclass_nms_workspace_bytes.restype = i64
+    L.ivx_multiclass_nms_bev.argtypes = [vp, vp, i32, i32, i32, f32, f32, i32, i32, vp, i64, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ('ivx_last_error', 'ivx_anchor_head_workspace_bytes', 'ivx_nms_workspace_bytes',
-                        'ivx_fcos_head_workspace_bytes', 'ivx_conv_workspace_bytes'):
+                        'ivx_fcos_head_workspace_bytes', 'ivx_conv_workspace_bytes', 'ivx_multiclass_nms_workspace_bytes'):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

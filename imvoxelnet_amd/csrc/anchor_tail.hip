@@ -569,6 +569,184 @@ extern "C" int ivx_nms_bev(const float *boxes_sorted, int32_t n, float thresh, i
   return IVX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused multi-class BEV NMS (box3d_multiclass_nms, core/post_processing/box3d_nms.py:8-88): the reference loops over
+// the classes on the host (mask filter, sort, nms_gpu with a blocking D2H, gathers, concat, final top-max_num); here
+// every class is one slice of four launches and nothing returns to the host.
+//   mc_select_sort: per class, candidates with score > score_thr sorted by score (descending; ties -> lower index),
+//                   their boxes gathered contiguously for the mask kernel
+//   nms_mask_kernel (shared with the single-class path, blockIdx.z = class)
+//   mc_scan:        one wave per class runs the greedy scan
+//   mc_finalize:    class-major concatenation when it fits max_num, else a k-way merge of the (already sorted)
+//                   per-class lists = the reference's final scores.sort(descending)[:max_num]
+struct McP {
+  const float *boxes;    // [n][5]
+  const float *scores;   // [n][score_stride]
+  int n, ns, npad, score_stride, num_classes, max_num, rotated;
+  float score_thr, nms_thr;
+  int *sidx;             // [C][ns]  candidate -> original index, sorted
+  float *sscore;         // [C][ns]
+  float *cboxes;         // [C][ns][5]
+  int *n_arr;            // [C]
+  int *kept;             // [C][ns]  positions (in the sorted list) that survive
+  int *nk;               // [C]
+  unsigned long long *mask;
+};
+
+__global__ __launch_bounds__(1024) void mc_select_sort_kernel(const McP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long mk[];   // npad keys
+  __shared__ int s_cnt;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  int local = 0;
+  for (int i = tid; i < p.npad; i += blockDim.x) {
+    unsigned long long k = 0ULL;
+    if (i < p.n) {
+      const float sc = p.scores[(size_t)i * p.score_stride + c];
+      if (sc > p.score_thr) {
+        k = ((unsigned long long)f2key(sc) << 32) | (unsigned int)(~(unsigned int)i);
+        ++local;
+      }
+    }
+    mk[i] = k;
+  }
+  atomicAdd(&s_cnt, local);
+  __syncthreads();
+  bitonic_sort_desc(mk, p.npad);
+  const int cnt = s_cnt;
+  if (tid == 0) p.n_arr[c] = cnt;
+  for (int j = tid; j < cnt; j += blockDim.x) {
+    const unsigned long long k = mk[j];
+    const int idx = (int)(~(unsigned int)(k & 0xffffffffULL));
+    p.sidx[(size_t)c * p.ns + j] = idx;
+    p.sscore[(size_t)c * p.ns + j] = key2f((unsigned int)(k >> 32));
+#pragma unroll
+    for (int q = 0; q < 5; ++q) p.cboxes[((size_t)c * p.ns + j) * 5 + q] = p.boxes[(size_t)idx * 5 + q];
+  }
+}
+
+__global__ __launch_bounds__(64) void mc_scan_kernel(const McP p) {
+  __shared__ int keep_s[4096];
+  const int c = blockIdx.x;
+  const int n = p.n_arr[c];
+  const int cb = p.ns >> 6;
+  const int nk = greedy_scan_wave(p.mask + (size_t)c * p.ns * cb, n, cb, n, keep_s);
+  __syncthreads();
+  for (int j = threadIdx.x; j < nk; j += 64) p.kept[(size_t)c * p.ns + j] = keep_s[j];
+  if (threadIdx.x == 0) p.nk[c] = nk;
+}
+
+__global__ __launch_bounds__(64) void mc_finalize_kernel(const McP p, long long *out_idx, long long *out_label, int *out_count) {
+  const int lane = threadIdx.x;
+  const int C = p.num_classes;
+  const int mine = lane < C ? p.nk[lane] : 0;
+  int total = mine, before = 0;   // inclusive scan over lanes -> offset of class `lane` in the concatenation
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(total, off, 64);
+    if (lane >= off) total += v;
+  }
+  before = total - mine;
+  const int all = __shfl(total, 63, 64);
+  if (all <= p.max_num) {
+    for (int c = 0; c < C; ++c) {
+      const int nkc = __shfl(mine, c, 64), base = __shfl(before, c, 64);
+      for (int j = lane; j < nkc; j += 64) {
+        out_idx[base + j] = p.sidx[(size_t)c * p.ns + p.kept[(size_t)c * p.ns + j]];
+        out_label[base + j] = c;
+      }
+    }
+    if (lane == 0) *out_count = all;
+    return;
+  }
+  // k-way merge: lane c walks class c's kept list (descending scores); ties -> lower class (stable w.r.t. concatenation)
+  int head = 0;
+  for (int t = 0; t < p.max_num; ++t) {
+    unsigned long long key = 0ULL;
+    if (lane < C && head < mine) {
+      const float sc = p.sscore[(size_t)lane * p.ns + p.kept[(size_t)lane * p.ns + head]];
+      key = ((unsigned long long)f2key(sc) << 8) | (unsigned long long)(255 - lane);
+    }
+    unsigned long long best = key;
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(best, off, 64);
+      best = o > best ? o : best;
+    }
+    const int win = 255 - (int)(best & 0xffULL);
+    if (lane == win) {
+      out_idx[t] = p.sidx[(size_t)lane * p.ns + p.kept[(size_t)lane * p.ns + head]];
+      out_label[t] = lane;
+      ++head;
+    }
+  }
+  if (lane == 0) *out_count = p.max_num;
+}
+
+static int mc_layout(int32_t n, int32_t num_classes, McP *p, int64_t *total) {
+  IVX_REQUIRE(n >= 0 && n <= 4096, "ivx_multiclass_nms_bev: n must be in 0..4096 (got %d)", n);
+  IVX_REQUIRE(num_classes >= 1 && num_classes <= 64, "ivx_multiclass_nms_bev: num_classes must be in 1..64 (got %d)", num_classes);
+  const int ns = n > 0 ? (n + 63) / 64 * 64 : 64;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { const int64_t o = off; off += ivx_align_up(bytes, 256); return o; };
+  const int64_t o_sidx = take((int64_t)num_classes * ns * 4), o_ss = take((int64_t)num_classes * ns * 4);
+  const int64_t o_cb = take((int64_t)num_classes * ns * 5 * 4), o_na = take((int64_t)num_classes * 4);
+  const int64_t o_kept = take((int64_t)num_classes * ns * 4), o_nk = take((int64_t)num_classes * 4);
+  const int64_t o_mask = take((int64_t)num_classes * ns * (ns / 64) * 8);
+  if (p) {
+    p->ns = ns;
+    p->npad = next_pow2(n > 1 ? n : 2);
+    p->sidx = (int *)o_sidx; p->sscore = (float *)o_ss; p->cboxes = (float *)o_cb; p->n_arr = (int *)o_na;
+    p->kept = (int *)o_kept; p->nk = (int *)o_nk; p->mask = (unsigned long long *)o_mask;
+  }
+  *total = off;
+  return IVX_OK;
+}
+
+extern "C" int64_t ivx_multiclass_nms_workspace_bytes(int32_t n, int32_t num_classes) {
+  int64_t t = 0;
+  if (mc_layout(n, num_classes, nullptr, &t) != IVX_OK) return -1;
+  return t;
+}
+
+extern "C" int ivx_multiclass_nms_bev(const float *boxes, const float *scores, int32_t n, int32_t score_stride, int32_t num_classes,
+                                      float score_thr, float nms_thr, int32_t rotated, int32_t max_num, void *workspace,
+                                      int64_t workspace_bytes, int64_t *out_idx, int64_t *out_label, int32_t *out_count,
+                                      ivx_stream_t stream) {
+  McP p;
+  int64_t need = 0;
+  if (mc_layout(n, num_classes, &p, &need) != IVX_OK) return IVX_ERR_INVALID_ARG;
+  IVX_REQUIRE(out_idx && out_label && out_count, "ivx_multiclass_nms_bev: null output");
+  IVX_REQUIRE(score_stride >= num_classes && max_num > 0, "ivx_multiclass_nms_bev: bad score_stride / max_num");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(out_count, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) {
+      ivx_set_error("ivx_multiclass_nms_bev: memset failed: %s", hipGetErrorString(e));
+      return IVX_ERR_HIP;
+    }
+    return IVX_OK;
+  }
+  IVX_REQUIRE(boxes && scores && workspace, "ivx_multiclass_nms_bev: null argument");
+  if (workspace_bytes < need) {
+    ivx_set_error("ivx_multiclass_nms_bev: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)need);
+    return IVX_ERR_WORKSPACE;
+  }
+  char *w = (char *)workspace;
+  p.sidx = (int *)(w + (int64_t)p.sidx); p.sscore = (float *)(w + (int64_t)p.sscore); p.cboxes = (float *)(w + (int64_t)p.cboxes);
+  p.n_arr = (int *)(w + (int64_t)p.n_arr); p.kept = (int *)(w + (int64_t)p.kept); p.nk = (int *)(w + (int64_t)p.nk);
+  p.mask = (unsigned long long *)(w + (int64_t)p.mask);
+  p.boxes = boxes; p.scores = scores; p.n = n; p.score_stride = score_stride; p.num_classes = num_classes; p.max_num = max_num;
+  p.rotated = rotated; p.score_thr = score_thr; p.nms_thr = nms_thr;
+  const int cb = p.ns / 64;
+  hipLaunchKernelGGL(mc_select_sort_kernel, dim3(num_classes), dim3(1024), (size_t)p.npad * 8, st, p);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, n, num_classes), dim3(64), 0, st, p.cboxes, (const int *)p.n_arr, 0, p.ns, cb, nms_thr,
+                     rotated, p.mask);
+  hipLaunchKernelGGL(mc_scan_kernel, dim3(num_classes), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(mc_finalize_kernel, dim3(1), dim3(64), 0, st, p, (long long *)out_idx, (long long *)out_label, out_count);
+  IVX_CHECK_LAUNCH("ivx_multiclass_nms_bev");
+  return IVX_OK;
+}
+
 __global__ void overlap_pairs_kernel(const float *a, int na, const float *b, int nb, int iou, float *out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y;

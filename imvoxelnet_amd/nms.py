@@ -39,8 +39,31 @@ def boxes_overlap_bev(boxes_a, boxes_b):
 
 
 def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg, mlvl_dir_scores=None):
-    """post_processing/box3d_nms.py:8-88.  General (multi-class) form; the single-class anchor-head
-    configs use the fully fused device tail (ops.anchor_head_get_bboxes) instead."""
+    """post_processing/box3d_nms.py:8-88 as ONE fused device call (ivx_multiclass_nms_bev: per-class filter + sort +
+    rotated/normal NMS for all classes concurrently, class-major concat, final top-max_num) followed by gathers; the
+    only host round trip is the survivor count.  Falls back to the per-class loop over the same device NMS for
+    n > 4096 candidates or > 64 classes.  (The single-class anchor-head configs use ops.anchor_head_get_bboxes.)"""
+    num_classes = mlvl_scores.shape[1] - 1
+    n = mlvl_bboxes.shape[0]
+    if n > 4096 or num_classes > 64:
+        return _box3d_multiclass_nms_loop(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg, mlvl_dir_scores)
+    if n == 0 or num_classes == 0:
+        z = mlvl_scores.new_zeros
+        return z((0, mlvl_bboxes.size(-1))), z((0,)), z((0,), dtype=torch.long), z((0,))
+    idx, labels, cnt = ops.multiclass_nms_bev(mlvl_bboxes_for_nms.contiguous().float(), mlvl_scores.contiguous().float(), num_classes,
+                                              score_thr, cfg['nms_thr'], cfg['use_rotate_nms'], max_num)
+    k = int(cnt.item())
+    idx, labels = idx[:k], labels[:k]
+    bboxes = mlvl_bboxes[idx]
+    scores = mlvl_scores[idx, labels]
+    dir_scores = mlvl_dir_scores[idx] if mlvl_dir_scores is not None else mlvl_scores.new_zeros((0,))
+    if k == 0:
+        dir_scores = mlvl_scores.new_zeros((0,))
+    return bboxes, scores, labels, dir_scores
+
+
+def _box3d_multiclass_nms_loop(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg, mlvl_dir_scores=None):
+    """The reference's control flow (host loop over classes) on the device NMS; kept for sizes beyond the fused op."""
     num_classes = mlvl_scores.shape[1] - 1
     bboxes, scores, labels, dir_scores = [], [], [], []
     fn = nms_gpu if cfg['use_rotate_nms'] else nms_normal_gpu

@@ -243,6 +243,29 @@ def nms_bev_sorted(boxes_sorted, thresh, rotated=True):
     return keep, num
 
 
+def multiclass_nms_bev(boxes, scores, num_classes, score_thr, nms_thr, rotated, max_num):
+    """boxes [n,5] BEV (x1,y1,x2,y2,ry), scores [n, >= num_classes] -> (idx [m] int64 into the n candidates,
+    labels [m] int64, count [1] int32), all on the device; m = min(max_num, n * num_classes) slots, `count` valid."""
+    _chk(boxes, 'boxes')
+    _chk(scores, 'scores')
+    n = boxes.shape[0]
+    if scores.shape[0] != n or scores.shape[1] < num_classes or boxes.shape[1] != 5:
+        raise ValueError('boxes must be [n,5] and scores [n, >= num_classes]')
+    L = _lib.lib()
+    wsb = L.ivx_multiclass_nms_workspace_bytes(n, int(num_classes))
+    if wsb < 0:
+        check(-1, 'ivx_multiclass_nms_workspace_bytes')
+    ws = torch.empty((max(int(wsb), 256),), device=boxes.device, dtype=torch.uint8)
+    m = max(1, min(int(max_num), n * int(num_classes)))
+    idx = torch.empty((m,), device=boxes.device, dtype=torch.int64)
+    lab = torch.empty((m,), device=boxes.device, dtype=torch.int64)
+    cnt = torch.empty((1,), device=boxes.device, dtype=torch.int32)
+    check(L.ivx_multiclass_nms_bev(_ptr(boxes), _ptr(scores), n, scores.shape[1], int(num_classes), float(score_thr), float(nms_thr),
+                                   int(bool(rotated)), int(max_num), _ptr(ws), ws.numel(), _ptr(idx), _ptr(lab), _ptr(cnt), _stream()),
+          'ivx_multiclass_nms_bev')
+    return idx, lab, cnt
+
+
 def boxes_overlap_bev(a, b, iou=False):
     _chk(a, 'a')
     _chk(b, 'b')

@@ -229,6 +229,19 @@ int ivx_boxes_overlap_bev(const float *a, int32_t na, const float *b, int32_t nb
 int ivx_aligned_3d_nms(const float *boxes, const float *scores, const int64_t *classes, int32_t n,
                        float thresh, int64_t *pick, int32_t *num_out, ivx_stream_t stream);
 
+/* Fused multi-class BEV NMS -- replaces box3d_multiclass_nms (mmdet3d/core/post_processing/box3d_nms.py:8-88), i.e.
+ * the host loop over classes around nms_gpu / nms_normal_gpu with its per-class D2H, for n <= 4096 candidates and
+ * num_classes <= 64.  boxes [n,5] (x1,y1,x2,y2,ry); scores [n,score_stride], class c in column c.  Per class the
+ * candidates with score > score_thr are sorted by score (descending, ties -> lower index) and greedily suppressed at
+ * IoU > nms_thr; the survivors are concatenated class-major, or, when more than max_num survive, cut to the max_num
+ * best by score (descending; ties -> lower class).  out_idx (index into the n candidates) and out_label hold
+ * min(max_num, n * num_classes) int64 entries; *out_count receives the number written.                            */
+int64_t ivx_multiclass_nms_workspace_bytes(int32_t n, int32_t num_classes);
+int ivx_multiclass_nms_bev(const float *boxes, const float *scores, int32_t n, int32_t score_stride, int32_t num_classes,
+                           float score_thr, float nms_thr, int32_t rotated, int32_t max_num, void *workspace,
+                           int64_t workspace_bytes, int64_t *out_idx, int64_t *out_label, int32_t *out_count,
+                           ivx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * KITTI AP evaluation, host side: the per-image matching loops the reference compiles with numba.jit.
  * HOST pointers, row-major double matrices, no device work, no stream -- the rotated BEV / 3-D overlaps that feed

@@ -613,3 +613,32 @@ def test_kitti_eval_device_overlaps_match_reference(ia):
     for k, v in ref.items():
         assert abs(float(res[k]) - v) < 1e-6, (k, float(res[k]), v)
     assert res_str == str(g['eval::result_str'])
+
+
+@pytest.mark.parametrize('rotated', [True, False])
+def test_fused_multiclass_nms_equals_class_loop(ia, rotated):
+    """ivx_multiclass_nms_bev (all classes in one pass on the device) against the reference's control flow -- the host
+    loop over classes around the single-class device NMS, which the golden head tests pin to the reference: same
+    boxes, labels and order, both when everything fits max_num (class-major order) and when the final top-max_num cut
+    applies (score order); empty classes, a class with a single candidate, score threshold."""
+    from imvoxelnet_amd import nms
+    g = torch.Generator().manual_seed(41 + int(rotated))
+    for n, ncls, thr, max_num in ((300, 4, 0.3, 1000), (1500, 10, 0.0, 500), (900, 3, 0.6, 50), (64, 2, 0.2, 10), (1, 3, 0.0, 5)):
+        ctr = torch.rand(n, 2, generator=g) * 12
+        wl = torch.rand(n, 2, generator=g) * 2 + 0.5
+        bev = torch.cat([ctr - wl / 2, ctr + wl / 2, (torch.rand(n, 1, generator=g) - 0.5) * 6], 1).cuda()
+        boxes3d = torch.cat([ctr, torch.rand(n, 5, generator=g)], 1).cuda()
+        scores = torch.rand(n, ncls + 1, generator=g)
+        scores[:, 1] *= 0.1 if ncls > 2 else 1.0          # a class that mostly falls under the threshold
+        if ncls > 2:
+            scores[:, 2] = 0.0
+            scores[n // 2, 2] = 0.9                          # a class with exactly one candidate
+        scores = scores.cuda()
+        dirs = torch.randint(0, 2, (n,), generator=g).cuda()
+        cfg = dict(use_rotate_nms=rotated, nms_thr=0.25)
+        a = nms._box3d_multiclass_nms_loop(boxes3d, bev, scores, thr, max_num, cfg, dirs)
+        b = nms.box3d_multiclass_nms(boxes3d, bev, scores, thr, max_num, cfg, dirs)
+        print('n', n, 'classes', ncls, 'kept', len(a[1]))
+        assert len(a[1]) == len(b[1])
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), (n, ncls)
