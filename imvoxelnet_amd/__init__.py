@@ -10,6 +10,7 @@ from .necks3d import (KittiImVoxelNeck, NuScenesImVoxelNeck, FastIndoorImVoxelNe
                       BasicBlock3dV2)
 from .anchor import Anchor3DRangeGenerator, DeltaXYZWLHRBBoxCoder          # noqa: F401
 from .heads import Anchor3DHead                                            # noqa: F401
+from .heads_layout import LayoutHead, get_extrinsics                       # noqa: F401
 from .heads_indoor import (ScanNetImVoxelHeadV2, SunRgbdImVoxelHeadV2, ScanNetImVoxelHead,  # noqa: F401
                            SunRgbdImVoxelHead)
 from .detector import ImVoxelNet, get_points                               # noqa: F401

@@ -30,7 +30,7 @@ class AnchorHeadDesc(C.Structure):
 
 
 EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
-           'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
+           'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd',
            'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_fcos_head_workspace_bytes',
            'ivx_fcos_head_level_candidates', 'ivx_nms_workspace_bytes',
            'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms', 'ivx_multiclass_nms_workspace_bytes', 'ivx_multiclass_nms_bev',
@@ -57,6 +57,7 @@ def lib():
     L.ivx_conv_workspace_bytes.restype = i64
     L.ivx_conv_fwd_ws.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.ivx_maxpool2d_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ivx_global_avgpool_fwd.argtypes = [vp, i32, i64, i32, vp, vp]
     L.ivx_upsample_trilinear2x_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     L.ivx_dcn_im2col_fwd.argtypes = [vp, vp] + [i32] * 10 + [vp, vp]
     L.ivx_nchw_to_nhwc.argtypes = [vp, i32, i32, i64, i32, vp, vp]

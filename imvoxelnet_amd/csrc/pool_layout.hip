@@ -177,3 +177,28 @@ extern "C" int ivx_upsample_trilinear2x_fwd(const float *in, int32_t B, int32_t 
   IVX_CHECK_LAUNCH("ivx_upsample_trilinear2x_fwd");
   return IVX_OK;
 }
+
+// Global average pool over the spatial positions of a channels-last map: in [B,S,C] -> out [B,C]
+// (`x.mean(dim=(2, 3))` of LayoutHead.forward, mmdet3d/models/dense_heads/layout_head.py:42).  One workgroup per
+// (64-channel group, sample): 4 spatial phases x 64 channels, each lane walks its phase with coalesced 256-byte rows,
+// then the four partial sums are combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const float *in, int S, int C, float *out) {
+  __shared__ float part[4][64];
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ph = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C)
+    for (int s = ph; s < S; s += 4) acc += in[((size_t)b * S + s) * C + c];
+  part[ph][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (ph == 0 && c < C) out[(size_t)b * C + c] = (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]) / (float)S;
+}
+
+extern "C" int ivx_global_avgpool_fwd(const float *in, int32_t B, int64_t S, int32_t C, float *out, ivx_stream_t stream) {
+  IVX_REQUIRE(in && out, "ivx_global_avgpool_fwd: null argument");
+  IVX_REQUIRE(B > 0 && B <= 65535 && S > 0 && S < (1LL << 31) && C > 0, "ivx_global_avgpool_fwd: bad dims");
+  hipLaunchKernelGGL(global_avgpool_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, in, (int)S, C, out);
+  IVX_CHECK_LAUNCH("ivx_global_avgpool_fwd");
+  return IVX_OK;
+}

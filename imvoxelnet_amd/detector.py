@@ -33,8 +33,6 @@ class ImVoxelNet(nn.Module):
     def __init__(self, backbone, neck, neck_3d, bbox_head, n_voxels, voxel_size, head_2d=None, train_cfg=None,
                  test_cfg=None, pretrained=None):
         super().__init__()
-        if head_2d is not None:
-            raise NotImplementedError('head_2d (LayoutHead, SUN RGB-D Total configs) is outside the built path')
         self.backbone = build_backbone(backbone)
         self.neck = build_neck(neck)
         self.neck_3d = build_neck(neck_3d)
@@ -42,7 +40,7 @@ class ImVoxelNet(nn.Module):
         bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
         self.bbox_head = build_head(bbox_head)
         self.bbox_head.voxel_size = voxel_size
-        self.head_2d = None
+        self.head_2d = build_head(head_2d) if head_2d is not None else None      # LayoutHead (SUN RGB-D Total configs)
         self.n_voxels = tuple(int(v) for v in n_voxels)
         self.voxel_size = tuple(float(v) for v in voxel_size)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
@@ -53,6 +51,8 @@ class ImVoxelNet(nn.Module):
         self.neck.init_weights()
         self.neck_3d.init_weights()
         self.bbox_head.init_weights()
+        if self.head_2d is not None:
+            self.head_2d.init_weights()
 
     def prepare(self, device, dtype=torch.float32):
         """Pack every layer's parameters for the device kernels (call again after changing weights).
@@ -63,26 +63,34 @@ class ImVoxelNet(nn.Module):
         with storage_dtype(dtype):
             for m in (self.backbone, self.neck, self.neck_3d, self.bbox_head):
                 m.prepare(device)
+            if self.head_2d is not None:
+                self.head_2d.prepare(device)
         self.storage_dtype = dtype
         return self
 
     # ------------------------------------------------------------------ host-side camera set-up
     @staticmethod
     def _compute_projection(img_meta, stride, angles=None):
-        """detectors/imvoxelnet.py:114-129 with the same torch CPU ops (angles: SUN RGB-D Total only)."""
-        if angles is not None:
-            raise NotImplementedError('predicted-angle extrinsics (head_2d) are outside the built path')
+        """detectors/imvoxelnet.py:114-129 with the same torch CPU ops.  angles (SUN RGB-D Total test mode): the list
+        of predicted (pitch, roll) the reference iterates as if they were views (:121-124; one entry at batch size 1)."""
         intrinsic = torch.tensor(img_meta['lidar2img']['intrinsic'][:3, :3])
         ratio = img_meta['ori_shape'][0] / (img_meta['img_shape'][0] / stride)
         intrinsic[:2] /= ratio
-        return torch.stack([intrinsic @ torch.tensor(e)[:3] for e in img_meta['lidar2img']['extrinsic']])
+        if angles is not None:
+            from .heads_layout import get_extrinsics
+            extrinsics = [get_extrinsics(a).to(intrinsic.device) for a in angles]
+        else:
+            extrinsics = [torch.tensor(e) for e in img_meta['lidar2img']['extrinsic']]
+        return torch.stack([intrinsic @ e[:3] for e in extrinsics])
 
-    def _camera_setup(self, img_metas, stride, device):
+    def _camera_setup(self, img_metas, stride, device, angles=None):
         proj, orig, crop = [], [], []
         nv = torch.tensor(self.n_voxels)
         vs = torch.tensor(self.voxel_size)
-        for meta in img_metas:
-            p = self._compute_projection(meta, stride, None)
+        for b, meta in enumerate(img_metas):
+            # the reference hands the whole batch's angle list to every sample (:60), which only works at batch size 1
+            # (the SUN RGB-D Total test setting); here sample b gets its own prediction
+            p = self._compute_projection(meta, stride, None if angles is None else [angles[b]])
             if p.dtype != torch.float32:
                 raise TypeError('lidar2img intrinsic/extrinsic must be float32 (as the reference datasets produce)')
             proj.append(p)
@@ -98,19 +106,21 @@ class ImVoxelNet(nn.Module):
                 torch.tensor(crop, dtype=torch.int32).to(device))
 
     # ------------------------------------------------------------------ channels-last fast path
-    def features_2d_cl(self, img):
-        """img [B,V,3,H,W] -> FPN level 0, channels-last [B*V,1,H/4,W/4,Cf]."""
-        B = img.shape[0]
+    def features_2d_cl(self, img, img_metas=None, want_2d=False):
+        """img [B,V,3,H,W] -> FPN level 0, channels-last [B*V,1,H/4,W/4,Cf]
+        (with want_2d: also the LayoutHead output (angles, layouts) computed from C5, or None without a head_2d)."""
         x = img.reshape([-1] + list(img.shape)[2:]).contiguous()
         feats = self.backbone.forward_cl(ops.to_channels_last(x, pad_to=4))
+        features_2d = self.head_2d.forward_cl(feats[-1], img_metas) if (want_2d and self.head_2d is not None) else None
         p0 = self.neck.forward_cl(list(feats))[0]
         stride = x.shape[-1] / p0.shape[3]
         assert stride == 4, 'stride of FPN level 0 must be 4 (detectors/imvoxelnet.py:53-54)'
-        return p0
+        return (p0, features_2d) if want_2d else p0
 
-    def lift_cl(self, p0, img_metas):
-        """FPN level 0 [B*V,1,h,w,C] + metas -> (volume [B,X,Y,Z,C], valid [B,X,Y,Z] bool)."""
-        proj, new_origin, crop = self._camera_setup(img_metas, 4, p0.device)
+    def lift_cl(self, p0, img_metas, angles=None):
+        """FPN level 0 [B*V,1,h,w,C] + metas -> (volume [B,X,Y,Z,C], valid [B,X,Y,Z] bool).
+        angles: predicted (pitch, roll) list of the LayoutHead (test mode of the Total configs) or None."""
+        proj, new_origin, crop = self._camera_setup(img_metas, 4, p0.device, angles)
         return ops.backproject_mean(p0, proj, new_origin, crop, self.voxel_size, self.n_voxels)
 
     def detect_cl(self, volume, img_metas, want_candidates=False):
@@ -123,14 +133,16 @@ class ImVoxelNet(nn.Module):
 
     # ------------------------------------------------------------------ reference surface
     def extract_feat(self, img, img_metas, mode='test'):
-        """-> (list of neck outputs in the reference layout, valids [B,1,X,Y,Z] bool, None)."""
-        p0 = self.features_2d_cl(img)
-        volume, valid = self.lift_cl(p0, img_metas)
+        """-> (list of neck outputs in the reference layout, valids [B,1,X,Y,Z] bool, features_2d), features_2d =
+        (angles, layouts) of the LayoutHead or None (detectors/imvoxelnet.py:45-80)."""
+        p0, features_2d = self.features_2d_cl(img, img_metas, want_2d=True)
+        angles = features_2d[0] if features_2d is not None and mode == 'test' else None        # :60
+        volume, valid = self.lift_cl(p0, img_metas, angles)
         y = self.neck_3d.forward_cl(volume)
         if isinstance(y, (list, tuple)):                      # indoor necks: multi-level [B,C,X,Y,Z]
-            return [ops.from_channels_last(t, 3) for t in y], valid.unsqueeze(1), None
+            return [ops.from_channels_last(t, 3) for t in y], valid.unsqueeze(1), features_2d
         out = ops.from_channels_last(y, 3)
-        return [out[..., 0].transpose(-1, -2)], valid.unsqueeze(1), None
+        return [out[..., 0].transpose(-1, -2)], valid.unsqueeze(1), features_2d
 
     def detect_indoor_cl(self, volume, valid, img_metas):
         """Anchor-free indoor configs (SUN RGB-D / ScanNet): list of (boxes object, scores, labels)."""
@@ -138,14 +150,20 @@ class ImVoxelNet(nn.Module):
         return self.bbox_head.get_bboxes_cl(self.bbox_head.forward_cl(levels), valid, img_metas)
 
     def simple_test(self, img, img_metas):
-        p0 = self.features_2d_cl(img)
-        volume, valid = self.lift_cl(p0, img_metas)
+        p0, features_2d = self.features_2d_cl(img, img_metas, want_2d=True)
+        volume, valid = self.lift_cl(p0, img_metas, features_2d[0] if features_2d is not None else None)
         if isinstance(self.bbox_head, Anchor3DHead):
             boxes, scores, labels, count = self.detect_cl(volume, img_metas)
             dets = self.bbox_head._wrap(boxes, scores, labels, count, img_metas)
         else:
             dets = self.detect_indoor_cl(volume, valid, img_metas)
-        return [bbox3d2result(b, s, l) for b, s, l in dets]
+        results = [bbox3d2result(b, s, l) for b, s, l in dets]
+        if features_2d is not None:                            # detectors/imvoxelnet.py:101-105
+            angles, layouts = self.head_2d.get_bboxes(*features_2d, img_metas)
+            for i in range(len(results)):
+                results[i]['angles'] = angles[i]
+                results[i]['layout'] = layouts[i]
+        return results
 
     def capture_graph(self, img, img_metas, warmup=2):
         """Capture the device side of simple_test for this input shape as ONE hipGraph (anchor-head configs): every

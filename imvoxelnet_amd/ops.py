@@ -140,6 +140,16 @@ def maxpool2d(x, k=3, s=2, p=1):
     return out
 
 
+def global_avgpool(x):
+    """[B,D,H,W,C] channels-last -> [B,1,1,1,C]: mean over every spatial position."""
+    _chk(x, 'x')
+    B, Cn = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * Cn)
+    out = torch.empty((B, 1, 1, 1, Cn), device=x.device, dtype=torch.float32)
+    check(_lib.lib().ivx_global_avgpool_fwd(_ptr(x), B, S, Cn, _ptr(out), _stream()), 'ivx_global_avgpool_fwd')
+    return out
+
+
 def dcn_im2col(x, offset_mask, kernel=3, stride=1, pad=1, dil=1):
     """x [B,1,H,W,C], offset_mask [B,1,Ho,Wo,>=3*k*k] -> modulated deformable columns [B,1,Ho,Wo,k*k*C]."""
     _chk(x, 'x')

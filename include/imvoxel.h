@@ -229,6 +229,10 @@ int ivx_boxes_overlap_bev(const float *a, int32_t na, const float *b, int32_t nb
 int ivx_aligned_3d_nms(const float *boxes, const float *scores, const int64_t *classes, int32_t n,
                        float thresh, int64_t *pick, int32_t *num_out, ivx_stream_t stream);
 
+/* Global average pool of a channels-last map: in [B,S,C] -> out [B,C]; `x.mean(dim=(2,3))` of LayoutHead.forward
+ * (mmdet3d/models/dense_heads/layout_head.py:42, SUN RGB-D Total configs).                                        */
+int ivx_global_avgpool_fwd(const float *in, int32_t B, int64_t S, int32_t C, float *out, ivx_stream_t stream);
+
 /* Fused multi-class BEV NMS -- replaces box3d_multiclass_nms (mmdet3d/core/post_processing/box3d_nms.py:8-88), i.e.
  * the host loop over classes around nms_gpu / nms_normal_gpu with its per-class D2H, for n <= 4096 candidates and
  * num_classes <= 64.  boxes [n,5] (x1,y1,x2,y2,ry); scores [n,score_stride], class c in column c.  Per class the

@@ -789,6 +789,33 @@ def gen_kitti_format(ns):
     print('kitti_format kept', [len(a['score']) for a in annos])
 
 
+def gen_layout_head(ns):
+    """Reference LayoutHead (dense_heads/layout_head.py) forward + get_extrinsics / _compute_projection with predicted
+    angles (detectors/imvoxelnet.py:114-129,164-187) on seeded weights and a random C5 map."""
+    sys.modules['mmdet3d.core.bbox.structures'].limit_period = ns.utils.limit_period
+    lh = ref_import._load('mmdet3d.models.dense_heads.layout_head', 'mmdet3d/models/dense_heads/layout_head.py')
+    torch.manual_seed(97)
+    head = lh.LayoutHead(n_channels=256, linear_size=64, dropout=0.0).eval()
+    with torch.no_grad():
+        for p in head.parameters():
+            p.mul_(6.0)            # wider outputs so limit_period actually wraps some angles
+        x = torch.randn(3, 256, 6, 8) + 0.3
+        angles, layouts = head.forward(x, [None] * 3)
+    store = {'x': x.numpy()}
+    for k, v in head.state_dict().items():
+        store['sd::' + k] = v.numpy()
+    store['angles'] = torch.stack(angles).numpy()
+    store['layouts'] = torch.stack(layouts).numpy()
+    store['extrinsics'] = torch.stack([ns.detector.get_extrinsics(a) for a in angles]).numpy()
+    K = np.eye(4, dtype=np.float32)
+    K[:3, :3] = [[529.5, 0, 365.0], [0, 529.5, 265.0], [0, 0, 1]]
+    meta = dict(img_shape=(480, 640, 3), ori_shape=(530, 730, 3), lidar2img=dict(intrinsic=K, extrinsic=[np.eye(4, dtype=np.float32)]))
+    store['projection'] = ns.detector.ImVoxelNet._compute_projection(meta, 4, [angles[1]]).numpy()
+    store['intrinsic'] = K
+    np.savez_compressed(os.path.join(GOLD, 'layout_head.npz'), **store)
+    print('layout_head angles', store['angles'].round(3).tolist())
+
+
 def main():
     ns = ref_import.load()
     gen_backproject(ns)
@@ -802,6 +829,7 @@ def main():
     gen_indoor_eval(ns)
     gen_kitti_eval(ns)
     gen_kitti_format(ns)
+    gen_layout_head(ns)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

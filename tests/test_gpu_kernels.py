@@ -642,3 +642,44 @@ def test_fused_multiclass_nms_equals_class_loop(ia, rotated):
         assert len(a[1]) == len(b[1])
         for x, y in zip(a, b):
             assert torch.equal(x, y), (n, ncls)
+
+
+def test_layout_head_golden(ia):
+    """LayoutHead (SUN RGB-D Total configs) on the device -- global average pool + two MLPs as 1x1 convs -- against the
+    imported reference head: angles / layouts within 1e-4 (the pooled sum and the fp32 GEMMs differ only in order)."""
+    g = load_npz('layout_head.npz')
+    head = ia.LayoutHead(n_channels=256, linear_size=64, dropout=0.0)
+    head.load_state_dict(sd_from(g, 'sd::'), strict=True)
+    x = torch.from_numpy(g['x']).cuda()
+    angles, layouts = head.forward(x, [None] * x.shape[0])
+    assert_close('angles', torch.stack(angles), torch.from_numpy(g['angles']), 1e-4, 1e-4)
+    assert_close('layouts', torch.stack(layouts), torch.from_numpy(g['layouts']), 1e-4, 1e-4)
+    pooled = ia.ops.global_avgpool(cl(torch.from_numpy(g['x'])))
+    assert_close('pool', pooled.reshape(x.shape[0], -1), torch.from_numpy(g['x']).mean(dim=(2, 3)), 1e-5, 1e-6)
+    boxes = head.get_bboxes(angles, layouts, [dict(box_type_3d=ia.DepthInstance3DBoxes)] * x.shape[0])[1]
+    assert boxes[0].tensor.shape == (1, 7)
+
+
+def test_total_config_end_to_end(ia):
+    """SUN RGB-D Total wiring: head_2d builds, its predicted angles drive the unprojection (the volume equals the one
+    obtained by handing the same extrinsics through the metas), and simple_test returns 'angles' and 'layout'."""
+    import copy
+    from kitti_cfg import sunrgbd_fast_model_cfg, SUNRGBD_FAST_TEST_CFG, indoor_meta
+    cfg = sunrgbd_fast_model_cfg()
+    cfg['head_2d'] = dict(type='LayoutHead', n_channels=2048, linear_size=256, dropout=0.0)
+    model = ia.build_detector(cfg, test_cfg=SUNRGBD_FAST_TEST_CFG)
+    ia.randomize_(model, 5)
+    model.prepare(torch.device('cuda'))
+    meta = indoor_meta(1, origin=(0, 3, -1), box_type=ia.DepthInstance3DBoxes)
+    img = torch.randn(1, 1, 3, 480, 640, generator=torch.Generator().manual_seed(2)).cuda()
+    p0, f2d = model.features_2d_cl(img, [meta], want_2d=True)
+    assert f2d is not None and f2d[0][0].shape == (2,) and f2d[1][0].shape == (7,)
+    vol_a, valid_a = model.lift_cl(p0, [meta], f2d[0])
+    meta2 = copy.deepcopy(meta)
+    meta2['lidar2img']['extrinsic'] = [ia.get_extrinsics(f2d[0][0]).numpy()]
+    vol_b, valid_b = model.lift_cl(p0, [meta2])
+    assert torch.equal(vol_a, vol_b) and torch.equal(valid_a, valid_b)
+    out = model.simple_test(img, [meta])
+    assert 'angles' in out[0] and 'layout' in out[0] and out[0]['layout'].tensor.shape == (1, 7)
+    feats, valids, features_2d = model.extract_feat(img, [meta], 'test')
+    assert features_2d is not None and valids.shape[1] == 1
