@@ -1,22 +1,22 @@
-// Channels-last implicit-GEMM convolution on the CDNA4 matrix cores, exact fp32.
+// Channels-last implicit-GEMM convolution on the CDNA4 matrix cores: exact fp32 (default) or bf16 storage.
 //
-//   GEMM view:  M = B*Do*Ho*Wo output positions, N = Cout, K = KD*KH*KW*Cin (k = tap*Cin + ci)
-//   MFMA:       v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate == an fmaf chain, 64 cyc/SIMD)
+//   GEMM view:  M = B*Do*Ho*Wo output positions, N = Cout, K = KD*KH*KW*Cin; im2col is done on the fly.
+//   MFMA:       v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate == an fmaf chain, 64 cyc/SIMD), or
+//               v_mfma_f32_32x32x16_bf16 for the optional bf16 storage mode (fp32 accumulate).
 //   Workgroup:  256 threads = 4 wave64, block tile BM x BN = (WR*TM*32) x (WC*TN*32),
 //               each wave owns TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each).
-//   K loop:     slabs of BK = 32 floats.  The im2col gather is done on the fly: a thread owns
-//               one 16-byte chunk column (4 consecutive ci of one tap) of BM/32 A rows and BN/32
-//               B rows, loads them with global_load_dwordx4 one slab ahead (register prefetch),
-//               and stages them in double-buffered LDS with ds_write_b128.
-//   LDS:        row stride 36 floats (144 B = 9 sixteen-byte slots, odd) so the ds_read_b128 of a
-//               fragment (32 rows x 16 B per half-wave) is bank-conflict free.
-//   Fragments:  lane l reads 4 consecutive k (16 B) of row (l & 31); half-wave h = l>>5 takes the
-//               k-group 4h..4h+3 of every 8, so one ds_read_b128 per operand feeds 4 MFMAs.  The
-//               k permutation is the same for A and B, so the sum over k is unchanged.
-//   Epilogue:   y = acc*scale[n] + shift[n] (+ residual, same-shape or nearest-upsampled) (ReLU),
-//               stored with 32 consecutive lanes on 32 consecutive channels (128-byte rows).
-//   Grid:       x = M tiles with an XCD-aware bijective remap (block b runs on XCD b % 8; give every
-//               XCD a contiguous range of M tiles so halo re-reads hit its own L2), y = N tiles.
+//   Kernels:    conv_igemm_v4_kernel (production: buffer loads with hardware zero-fill, LDS-DMA staging, XOR
+//               swizzled LDS rows, chunk-major K order, split-K / grid-tail plan) -- see its header below;
+//               conv_igemm_f32_kernel (generic: global loads into registers one slab ahead, ds_write_b128 into
+//               padded 144-byte LDS rows, 64-bit addressing) for tensors >= 2 GiB or kernel extents > 8;
+//               conv_naive_f32_kernel (validation only).
+//   Fragments:  lane l reads 16 bytes of row (l & 31); half-wave h = l>>5 takes the k-chunk 2*kk + h, so one
+//               ds_read_b128 per operand feeds 4 fp32 MFMAs (or 1 bf16 MFMA).  The k permutation is the same for A
+//               and B, so the sum over k is unchanged.
+//   Epilogue:   y = acc*scale[n] + shift[n] (+ residual, same-shape or nearest-upsampled) (ReLU) ..., stored with
+//               32 consecutive lanes on 32 consecutive channels (128-byte rows).
+//   Grid:       M tiles with an XCD-aware remap (block b runs on XCD b % 8; every XCD gets a contiguous range of
+//               M tiles so halo re-reads hit its own L2).
 //
 // Reference call sites replaced: see include/imvoxel.h (ivx_conv_fwd).
 #include "ivx_common.h"
@@ -314,205 +314,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// v2: same tiling, cheaper slab loop.
-//   * operands are fetched with raw buffer loads (buffer_load_dwordx4 ... offen): an out-of-image tap, a
-//     row past M or a k past K gets the out-of-range offset 0x80000000 and the hardware returns zeros --
-//     no exec-mask branches, no 64-bit address arithmetic in the loop (needs the tensor < 2 GiB);
-//   * per-row tap validity is a precomputed bit mask (kernel extents <= 8), per-slab work per load is
-//     one AND/compare, one add, one select;
-//   * MFMA fragments are double-buffered in registers: the ds_read_b128 of k-group kk+1 is issued before
-//     the 16 MFMAs of group kk.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <int TM, int TN, int WR, int WC>
-__global__ __launch_bounds__(256) void conv_igemm_f32_v2_kernel(const ConvParams p, const unsigned in_bytes,
-                                                                  const unsigned w_bytes) {
-  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-  constexpr int AR = BM / 32, BR = BN / 32;
-  static_assert(WR * WC == 4, "4 waves per workgroup");
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * IVX_LDK];
-  float *As = smem;
-  float *Bs = smem + 2 * BM * IVX_LDK;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int wr = wid / WC, wc = wid % WC;
-
-  // 1-D grid of 8 * ceil(Mt/8) * Nt workgroups.  Workgroup b runs on XCD b % 8 (observed dispatch rule; used for
-  // speed only): XCD x owns the contiguous M-tiles [x*q, (x+1)*q) so halo re-reads of neighbouring x-slabs hit its own
-  // L2, and inside an XCD the Nt workgroups that share one A-tile are consecutive, so they run together and the
-  // A-tile is fetched into that L2 once instead of once per N-tile.  Ids past the last M-tile exit (< 8*Nt of them).
-  int mt, nt;
-  {
-    const int Nt = (p.Cout + BN - 1) / BN;
-    const int q = gridDim.x / (8 * Nt);
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    mt = xcd * q + idx / Nt;
-    nt = idx % Nt;
-  }
-  if (mt * BM >= p.M) return;
-  const int m0 = mt * BM;
-  const int n0 = nt * BN;
-
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, w_bytes, 0x00020000);
-
-  const int cc = tid & 7;
-  const int lr = tid >> 3;
-  int a_off[AR];
-  unsigned a_msk[AR];
-#pragma unroll
-  for (int j = 0; j < AR; ++j) {
-    const int m = m0 + lr + 32 * j;
-    a_off[j] = 0;
-    a_msk[j] = 0;
-    if (m < p.M) {
-      const int ow = m % p.Wo;
-      int t = m / p.Wo;
-      const int oh = t % p.Ho;
-      t /= p.Ho;
-      const int od = t % p.Do;
-      const int b = t / p.Do;
-      const int id0 = od * p.sd - p.pd, ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
-      a_off[j] = (((b * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin;
-      unsigned md = 0, mh = 0, mw = 0;
-      for (int a = 0; a < p.KD; ++a) md |= ((unsigned)(id0 + a) < (unsigned)p.D) ? (1u << a) : 0u;
-      for (int e = 0; e < p.KH; ++e) mh |= ((unsigned)(ih0 + e) < (unsigned)p.H) ? (1u << e) : 0u;
-      for (int f = 0; f < p.KW; ++f) mw |= ((unsigned)(iw0 + f) < (unsigned)p.W) ? (1u << f) : 0u;
-      a_msk[j] = md | (mh << 8) | (mw << 16);
-    }
-  }
-  int b_off[BR];
-#pragma unroll
-  for (int j = 0; j < BR; ++j) {
-    const int n = n0 + lr + 32 * j;
-    b_off[j] = n < p.Cout ? n * p.K : -1;
-  }
-  int k4 = cc * 4;
-  int kc, ka, ke, kf;
-  if (p.kmode == 1) {  // chunk-major: slab s = (channel chunk s / taps, tap s % taps)
-    kc = cc * 4;
-    ka = ke = kf = 0;
-  } else {
-    const int tap = k4 / p.Cin;
-    kc = k4 - tap * p.Cin;
-    kf = tap % p.KW;
-    const int t2 = tap / p.KW;
-    ke = t2 % p.KH;
-    ka = t2 / p.KH;
-  }
-  const int S = (p.K + IVX_BK - 1) / IVX_BK;
-  const unsigned OOB = 0x80000000u;
-
-  u32x4 ra[AR], rb[BR];
-  auto load_slab = [&]() {
-    // branch-free: a k past K turns the tap mask into all-ones, which no row mask can satisfy
-    const unsigned kbad = (k4 < p.K) ? 0u : 0xffffffffu;
-    const int delta = ((ka * p.H + ke) * p.W + kf) * p.Cin + kc;
-    const unsigned tap = ((1u << ka) | (1u << (8 + ke)) | (1u << (16 + kf))) | kbad;
-#pragma unroll
-    for (int j = 0; j < AR; ++j) {
-      const unsigned good = ((a_msk[j] & tap) == tap) ? 0xffffffffu : 0u;
-      const unsigned vo = (((unsigned)(a_off[j] + delta) << 2) & good) | (OOB & ~good);
-      ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      const unsigned good = (b_off[j] >= 0 ? 0xffffffffu : 0u) & ~kbad;
-      const unsigned vo = (((unsigned)(b_off[j] + k4) << 2) & good) | (OOB & ~good);
-      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo, 0, 0);
-    }
-  };
-  auto advance_k = [&]() {
-    k4 += IVX_BK;
-    if (p.kmode == 1) {  // next tap of the same 32-channel chunk; after the last tap move to the next chunk
-      if (++kf == p.KW) {
-        kf = 0;
-        if (++ke == p.KH) {
-          ke = 0;
-          if (++ka == p.KD) {
-            ka = 0;
-            kc += IVX_BK;
-          }
-        }
-      }
-      return;
-    }
-    kc += IVX_BK;
-    while (kc >= p.Cin) {
-      kc -= p.Cin;
-      if (++kf == p.KW) {
-        kf = 0;
-        if (++ke == p.KH) {
-          ke = 0;
-          ++ka;
-        }
-      }
-    }
-  };
-  auto store_slab = [&](int buf) {
-    float *Ab = As + buf * BM * IVX_LDK + lr * IVX_LDK + cc * 4;
-    float *Bb = Bs + buf * BN * IVX_LDK + lr * IVX_LDK + cc * 4;
-#pragma unroll
-    for (int j = 0; j < AR; ++j) *reinterpret_cast<u32x4 *>(Ab + 32 * j * IVX_LDK) = ra[j];
-#pragma unroll
-    for (int j = 0; j < BR; ++j) *reinterpret_cast<u32x4 *>(Bb + 32 * j * IVX_LDK) = rb[j];
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  load_slab();
-  store_slab(0);
-  __syncthreads();
-
-  const int frag_off = (lane & 31) * IVX_LDK + 4 * (lane >> 5);
-  for (int s = 0; s < S; ++s) {
-    const int cur = s & 1;
-    const bool more = (s + 1) < S;
-    if (more) {
-      advance_k();
-      load_slab();
-    }
-    const float *Ac = As + cur * BM * IVX_LDK + wr * TM * 32 * IVX_LDK + frag_off;
-    const float *Bc = Bs + cur * BN * IVX_LDK + wc * TN * 32 * IVX_LDK + frag_off;
-    f32x4 fa[2][TM], fb[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_LDK);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * IVX_LDK);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int cb = kk & 1, nb = cb ^ 1;
-      if (kk < 3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * IVX_LDK + (kk + 1) * 8);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * IVX_LDK + (kk + 1) * 8);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][i][q], fb[cb][j][q], acc[i][j], 0, 0, 0);
-    }
-    if (more) store_slab(cur ^ 1);
-    __syncthreads();
-  }
-  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
-}
-
-// ------------------------------------------------------------------------------------------------
-// v4: v2 with LDS-DMA staging (buffer_load_dwordx4 ... offen lds): the operands go global -> LDS without passing
-// through VGPRs, so the slab loop has no ds_write pass and no vmcnt -> ds_write dependency.  The DMA writes
+// v4, the production kernel: same tiling as the generic kernel above, cheaper slab loop.
+//   * operands are fetched with raw buffer loads: an out-of-image tap, a row past M or a k past K gets the
+//     out-of-range offset 0x80000000 and the hardware returns zeros -- no exec-mask branches, no 64-bit address
+//     arithmetic in the loop (needs the tensor < 2 GiB); per-row tap validity is a precomputed bit mask (kernel
+//     extents <= 8), so the per-slab work per load is one AND/compare, one add, one select;
+//   * LDS-DMA staging (buffer_load_dwordx4 ... offen lds): the operands go global -> LDS without passing through
+//     VGPRs, so the slab loop has no ds_write pass and no vmcnt -> ds_write dependency;
+//   * MFMA fragments are double-buffered in registers: the ds_read_b128 of k-group kk+1 is issued before the MFMAs
+//     of group kk.  The DMA writes
 // wave-uniform base + lane*16 B, so LDS rows are unpadded 128-byte rows and bank conflicts are avoided by an XOR
 // swizzle applied on the SOURCE side (lane with slot c of row r fetches k-chunk c ^ ((r >> SW_SH) & SW_MSK)) and
 // again on the fragment read.  BK (K-slab depth) is 32 or 16; 16 halves the LDS so three workgroups fit on a CU.
@@ -882,23 +692,12 @@ extern "C" int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *H
   return IVX_OK;
 }
 
+// Generic kernel (64-bit addressing, any kernel extent; weight layout 0 only): the fallback for tensors >= 2 GiB.
 template <int TM, int TN, int WR, int WC>
-static void launch_cfg(const ConvParams &p, hipStream_t st, bool v2) {
+static void launch_cfg(const ConvParams &p, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
-  const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 4;
-  const int64_t w_bytes = (int64_t)p.Cout * p.K * 4;
-  // v2 needs 31-bit byte offsets and kernel extents that fit the 8-bit tap masks; otherwise the generic kernel
-  v2 = v2 && in_bytes < (1LL << 31) && w_bytes < (1LL << 31) && p.KD <= 8 && p.KH <= 8 && p.KW <= 8;
-  // (the generic kernel only knows weight layout 0; ivx_conv_fwd rejects layout 1 when v2 is not applicable)
-  if (v2) {
-    const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
-    const long long g1 = 8 * ((Mt + 7) / 8) * Nt;
-    hipLaunchKernelGGL((conv_igemm_f32_v2_kernel<TM, TN, WR, WC>), dim3((unsigned)g1), dim3(256), 0, st, p, (unsigned)in_bytes,
-                       (unsigned)w_bytes);
-  }
-  else
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
 }
 
 template <typename T, int TM, int TN, int WR, int WC, int BK>
@@ -918,8 +717,9 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
                      (unsigned)w_bytes);
 }
 
-static int g_tile_override = 0;
-// Tuning knob (A/B experiments, tools/conv_bench.py): 0 = automatic choice by Cout, 1..N = force a tile config.
+static thread_local int g_tile_override = 0;
+// Tuning knob (A/B experiments, tools/conv_bench.py; per calling thread): 0 = automatic choice, else force a tile
+// config of launch_one (1..7 generic kernel, 41..53 LDS-DMA fp32, 61..73 LDS-DMA bf16).
 extern "C" int ivx_conv_set_tile_override(int cfg) {
   g_tile_override = cfg;
   return IVX_OK;
@@ -927,7 +727,6 @@ extern "C" int ivx_conv_set_tile_override(int cfg) {
 
 struct ConvPlan {
   int cfg;       // tile / kernel selector (see launch_one)
-  bool v2;       // for cfg < 40: buffer-load kernel (true) or the generic kernel (false)
   int ksplit;    // > 1: split K over the whole problem (small outputs)
   int tail_ks;   // > 1: the last partial round of M-tiles runs as a second launch with K split tail_ks ways
   int q_total;   // M-tiles per XCD (LDS-DMA kernels)
@@ -974,14 +773,10 @@ static bool dma_applicable(const ConvParams &p) {
 //    idle (measured: 10 044 tiles on 768 slots = 13.08 rounds runs 4 % slower per tile than exactly 13 rounds).
 //    When the remainder is at most half a round, the full rounds run as one launch and the remainder as a second
 //    launch with K split so that it fills every slot once (needs the caller's workspace: ivx_conv_fwd_ws).
-//  * The LDS-DMA kernel (cfg 4x/5x) is used whenever its preconditions hold, else the same tile on v2 / v1.
+//  * The LDS-DMA kernel (cfg 4x/5x fp32, 6x/7x bf16) is used whenever its preconditions hold, else the same tile on
+//    the generic kernel (cfg 1..7).
 static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
-  ConvPlan pl = {g_tile_override, true, 1, 1, 0, 0, 0, 0};
-  if (pl.cfg >= 100) {  // 100 + c: force the generic (v1) kernel with tile config c
-    pl.v2 = false;
-    pl.cfg -= 100;
-    return pl;
-  }
+  ConvPlan pl = {g_tile_override, 1, 1, 0, 0, 0, 0};
   const bool dma_ok = dma_applicable(p);
   bool small = false;
   if (pl.cfg == 0) {
@@ -1038,15 +833,14 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
 }
 
 static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
-  const bool v2 = pl.v2;
   switch (pl.cfg) {
-    case 1: launch_cfg<2, 2, 2, 2>(p, st, v2); break;  // 128 x 128, 2 workgroups/CU
-    case 2: launch_cfg<2, 2, 4, 1>(p, st, v2); break;  // 256 x 64, 1 workgroup/CU
-    case 3: launch_cfg<2, 1, 2, 2>(p, st, v2); break;  // 128 x 64
-    case 4: launch_cfg<1, 1, 4, 1>(p, st, v2); break;  // 128 x 32
-    case 5: launch_cfg<1, 2, 4, 1>(p, st, v2); break;  // 128 x 64 (wave 32 x 64)
-    case 6: launch_cfg<1, 1, 2, 2>(p, st, v2); break;  // 64 x 64
-    case 7: launch_cfg<1, 2, 2, 2>(p, st, v2); break;  // 64 x 128
+    case 1: launch_cfg<2, 2, 2, 2>(p, st); break;  // 128 x 128, 2 workgroups/CU
+    case 2: launch_cfg<2, 2, 4, 1>(p, st); break;  // 256 x 64, 1 workgroup/CU
+    case 3: launch_cfg<2, 1, 2, 2>(p, st); break;  // 128 x 64
+    case 4: launch_cfg<1, 1, 4, 1>(p, st); break;  // 128 x 32
+    case 5: launch_cfg<1, 2, 4, 1>(p, st); break;  // 128 x 64 (wave 32 x 64)
+    case 6: launch_cfg<1, 1, 2, 2>(p, st); break;  // 64 x 64
+    case 7: launch_cfg<1, 2, 2, 2>(p, st); break;  // 64 x 128
     case 41: launch_v4<float, 2, 2, 2, 2, 32>(p, st); break;   // LDS-DMA: 128 x 128, 128-byte LDS rows
     case 43: launch_v4<float, 2, 1, 2, 2, 32>(p, st); break;   //          128 x 64
     case 44: launch_v4<float, 1, 1, 4, 1, 32>(p, st); break;   //          128 x 32
@@ -1081,8 +875,8 @@ static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStrea
     ivx_set_error("ivx_conv_fwd: bf16 input is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;
   }
-  if (p.kmode == 1 && (!dma_applicable(p) || !pl.v2)) {
-    ivx_set_error("ivx_conv_fwd: wgt_layout 1 is only implemented by the buffer-load kernels (tensor < 2 GiB, kernel extents <= 8)");
+  if (p.kmode == 1 && (!dma_applicable(p) || pl.cfg < 40)) {
+    ivx_set_error("ivx_conv_fwd: wgt_layout 1 is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;
   }
   int rc;

@@ -100,7 +100,8 @@ int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const void *wgt, con
 int ivx_conv_fwd_naive(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
                        const float *shift, const void *res, void *out, ivx_stream_t stream);
 
-/* Tuning knob for A/B experiments only: 0 = automatic tile choice (default), 1..6 = force a tile config. */
+/* Tuning knob for A/B experiments only (per calling thread): 0 = automatic tile choice (default); 1..7 force a tile
+ * of the generic kernel, 41..53 of the LDS-DMA fp32 kernel, 61..73 of its bf16 instantiation. */
 int ivx_conv_set_tile_override(int cfg);
 
 /* Modulated deformable convolution (DCNv2; mmcv ModulatedDeformConv2dPack, deform_groups = 1) -- nuScenes reference

@@ -93,7 +93,7 @@ def test_conv_config_variants(ia):
         ref = F.conv3d(x, w, None, 1, 1)
         y = FusedConv(w, padding=1).to('cuda')(xc)
         assert_close(f'cout{cout}', uncl(y), ref, 1e-4, 1e-4)
-    # every tile config of both kernels (buffer-load v2 with either weight layout, generic v1 via override 100+c)
+    # every tile config of both kernels (LDS-DMA with either weight layout, generic kernel 1..7 with layout 0)
     from imvoxelnet_amd import _lib
     L = _lib.lib()
     w = torch.randn(72, 32, 3, 3, 3, generator=g) * 0.05
@@ -101,7 +101,7 @@ def test_conv_config_variants(ia):
     try:
         for layout in (1, 0):
             fc = FusedConv(w, stride=(1, 1, 2), padding=1, layout=layout).to('cuda')
-            for ov in ((1, 2, 3, 4, 5, 6, 7, 41, 43, 44, 46, 51, 53) if layout == 1 else (1, 3, 6, 41, 46, 51, 53, 101, 102, 103, 104, 105, 106, 107)):
+            for ov in ((41, 43, 44, 46, 51, 52, 53) if layout == 1 else (1, 2, 3, 4, 5, 6, 7, 41, 46, 51, 53)):
                 L.ivx_conv_set_tile_override(ov)
                 assert_close(f'layout{layout} override{ov}', uncl(fc(xc)), ref, 1e-4, 1e-4)
     finally:
