@@ -899,13 +899,63 @@ static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStrea
   return IVX_OK;
 }
 
+// Batch slicing: the LDS-DMA kernel addresses its operands with 31-bit buffer offsets.  When the input of a launch
+// reaches 2 GiB (e.g. the first KITTI neck layers from batch 13 up) the batch is cut into the largest slices that fit
+// and the slices run back to back on the stream, sharing the workspace; B is the outermost dimension, so a slice is a
+// pointer offset.  Returns the number of samples per slice (B = no slicing needed or not possible).
+static int conv_batch_slice(const ConvParams &p) {
+  if (dma_applicable(p) || p.B == 1 || p.KD > 8 || p.KH > 8 || p.KW > 8) return p.B;
+  const int el = p.in_bf16 ? 2 : 4;
+  const int64_t in_s = (int64_t)p.D * p.H * p.W * p.Cin * el;
+  if ((int64_t)p.Cout * p.K * el >= (1LL << 31) || in_s >= (1LL << 31)) return p.B;
+  const int64_t nb = ((1LL << 31) - 1) / in_s;
+  return (int)(nb < p.B ? nb : p.B);
+}
+
+static ConvParams conv_slice_params(const ConvParams &p, int b0, int nb) {
+  ConvParams q = p;
+  const size_t in_el = p.in_bf16 ? 2 : 4, out_el = p.out_bf16 ? 2 : 4;
+  const size_t in_s = (size_t)p.D * p.H * p.W * p.Cin;
+  const size_t out_s = p.out_mode == 1 ? (size_t)8 * p.D * p.H * p.W * p.Cr : (size_t)p.Do * p.Ho * p.Wo * p.Cout;
+  q.B = nb;
+  q.M = nb * p.Do * p.Ho * p.Wo;
+  q.in = (const float *)((const char *)p.in + (size_t)b0 * in_s * in_el);
+  q.out = (float *)((char *)p.out + (size_t)b0 * out_s * out_el);
+  if (p.res) {
+    const size_t res_s = p.res_mode == 2 ? (size_t)p.rH * p.rW * p.Cout : out_s;
+    q.res = (const float *)((const char *)p.res + (size_t)b0 * res_s * out_el);
+  }
+  return q;
+}
+
+// Plan (and with `launch`, run) the whole problem: one call, or one call per batch slice.  *need = workspace bytes.
+static int conv_dispatch(const ConvParams &p, bool allow_ws, bool launch, void *workspace, int64_t workspace_bytes, hipStream_t st,
+                         int64_t *need, const char *who) {
+  const int nb = conv_batch_slice(p);
+  *need = 0;
+  for (int b0 = 0; b0 < p.B; b0 += nb) {
+    ConvParams q = nb == p.B ? p : conv_slice_params(p, b0, (p.B - b0) < nb ? (p.B - b0) : nb);
+    const ConvPlan pl = plan_conv(q, allow_ws);
+    if (pl.ws_bytes > *need) *need = pl.ws_bytes;
+    if (!launch) continue;
+    if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes)) {
+      ivx_set_error("%s: workspace too small (%lld < %lld); size it with ivx_conv_workspace_bytes", who, (long long)workspace_bytes,
+                    (long long)pl.ws_bytes);
+      return IVX_ERR_WORKSPACE;
+    }
+    const int rc = run_conv(q, pl, workspace, st);
+    if (rc != IVX_OK) return rc;
+  }
+  return IVX_OK;
+}
+
 extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
                             const float *shift, const void *res, void *out, ivx_stream_t stream) {
   ConvParams p;
   int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
   if (rc != IVX_OK) return rc;
-  const ConvPlan pl = plan_conv(p, false);
-  rc = run_conv(p, pl, nullptr, (hipStream_t)stream);
+  int64_t need;
+  rc = conv_dispatch(p, false, true, nullptr, 0, (hipStream_t)stream, &need, "ivx_conv_fwd");
   if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_fwd");
   return IVX_OK;
@@ -915,7 +965,9 @@ extern "C" int64_t ivx_conv_workspace_bytes(const ivx_conv_desc *d) {
   ConvParams p;
   float dummy;
   if (fill_params(d, &dummy, &dummy, nullptr, nullptr, d && d->res_mode ? &dummy : nullptr, &dummy, &p) != IVX_OK) return -1;
-  return plan_conv(p, true).ws_bytes;
+  int64_t need;
+  if (conv_dispatch(p, true, false, nullptr, 0, nullptr, &need, "ivx_conv_workspace_bytes") != IVX_OK) return -1;
+  return need;
 }
 
 extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
@@ -924,13 +976,8 @@ extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const voi
   ConvParams p;
   int rc = fill_params(d, in, wgt, scale, shift, res, out, &p);
   if (rc != IVX_OK) return rc;
-  const ConvPlan pl = plan_conv(p, true);
-  if (pl.ws_bytes > 0 && (!workspace || workspace_bytes < pl.ws_bytes)) {
-    ivx_set_error("ivx_conv_fwd_ws: workspace too small (%lld < %lld); size it with ivx_conv_workspace_bytes", (long long)workspace_bytes,
-                  (long long)pl.ws_bytes);
-    return IVX_ERR_WORKSPACE;
-  }
-  rc = run_conv(p, pl, workspace, (hipStream_t)stream);
+  int64_t need;
+  rc = conv_dispatch(p, true, true, workspace, workspace_bytes, (hipStream_t)stream, &need, "ivx_conv_fwd_ws");
   if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_fwd_ws");
   return IVX_OK;

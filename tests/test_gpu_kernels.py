@@ -683,3 +683,22 @@ def test_total_config_end_to_end(ia):
     assert 'angles' in out[0] and 'layout' in out[0] and out[0]['layout'].tensor.shape == (1, 7)
     feats, valids, features_2d = model.extract_feat(img, [meta], 'test')
     assert features_2d is not None and valids.shape[1] == 1
+
+
+def test_conv_batch_slicing_beyond_2gib(ia):
+    """A conv whose input exceeds the 31-bit buffer range of the LDS-DMA kernel (2.1 GiB here; the first KITTI neck
+    layers from batch 13 up) is cut into batch slices inside the library: same result as running the halves separately,
+    with a residual, and the workspace query covers the slices."""
+    from imvoxelnet_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(77)
+    B, D, H, W, C = 6, 96, 124, 120, 64                       # 6 x 366 MB = 2.19 GB of fp32 input
+    x = torch.randn(B, D, H, W, C, device='cuda', generator=g)
+    assert x.numel() * 4 >= 2 ** 31
+    w = torch.randn(64, 2, 3, 3, 3, 32, device='cuda', generator=g) * 0.03      # layout 1: [Cout, Cin/32, kd, kh, kw, 32]
+    sc = torch.rand(64, device='cuda', generator=g) + 0.5
+    sh = torch.randn(64, device='cuda', generator=g)
+    r = torch.randn(B, D, H, W, 64, device='cuda', generator=g)
+    y = ops.conv_fwd(x, w, sc, sh, (3, 3, 3), (1, 1, 1), (1, 1, 1), relu=True, res=r, wgt_layout=1)
+    for lo, hi in ((0, 3), (3, 6)):
+        yh = ops.conv_fwd(x[lo:hi].contiguous(), w, sc, sh, (3, 3, 3), (1, 1, 1), (1, 1, 1), relu=True, res=r[lo:hi].contiguous(), wgt_layout=1)
+        assert torch.equal(y[lo:hi], yh), (lo, hi)
