@@ -72,15 +72,22 @@ def bench_other(args, ia, kc, dev, rank, world):
             model.bbox_head.cls_conv.bias.fill_(-2.0)
             model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
     model.prepare(dev)
-    img = torch.randn(B, V, 3, H, W, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+    # view sharding: every rank holds the same scene(s) and works on its slice of the views
+    img = torch.randn(B, V, 3, H, W, generator=torch.Generator().manual_seed(1000 + (0 if args.shard == 'views' else rank))).to(dev)
     metas = [mk() for _ in range(B)]
     n = args.steps + args.warmup
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     neck_flops = [0.0]
 
+    view_sharded = args.shard == 'views'
+
     def step(i):
-        p0 = model.features_2d_cl(img)
-        vol, valid = model.lift_cl(p0, metas)
+        if view_sharded:
+            from imvoxelnet_amd.dist import view_sharded_lift
+            vol, valid = view_sharded_lift(model, img, metas)       # 2-D trunk + partial lift on this rank's views, all-reduce
+        else:
+            p0 = model.features_2d_cl(img)
+            vol, valid = model.lift_cl(p0, metas)
         ev[i][0].record()
         FusedConv.flops, FusedConv.count_flops = 0.0, True
         y = model.neck_3d.forward_cl(vol)
@@ -94,21 +101,36 @@ def bench_other(args, ia, kc, dev, rank, world):
         res = model.bbox_head.get_bboxes_cl(model.bbox_head.forward_cl(y), valid, metas)
         return [(b.tensor.cpu(), s.cpu(), l.cpu()) for b, s, l in res]
 
+    multi = dist.is_available() and dist.is_initialized()
+    if multi and not view_sharded:
+        raise SystemExit('--config other than kitti runs single-process, or with --shard views under torch.distributed.run')
     for i in range(args.warmup):
         step(i)
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(args.warmup + i)
     torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        if rank != 0:
+            return
     neck_ms = sum(ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][1]) for i in range(args.steps)) / args.steps
     ach = neck_flops[0] / (neck_ms * 1e-3) / 1e12
     rec = {'metric': f'images/sec/node ({args.config}: {V} view(s) 3x{H}x{W}, {"x".join(map(str, cfg["n_voxels"]))} vox)',
-           'value': round(B * V * args.steps / dt, 3), 'unit': 'images/s', 'scenes_per_s': round(B * args.steps / dt, 3), 'n_gpus': 1,
+           'value': round(B * V * args.steps / dt, 3), 'unit': 'images/s', 'scenes_per_s': round(B * args.steps / dt, 3), 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'detections_last_step': int(sum(len(r[1]) for r in last))},
+           'scaling': 'strong' if view_sharded else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'shard': args.shard, 'detections_last_step': int(sum(len(r[1]) for r in last))},
            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_f32 (3-D neck)', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
                         'neck_gflop': round(neck_flops[0] / 1e9, 1), 'neck_ms_per_step': round(neck_ms, 3)}}
@@ -125,6 +147,9 @@ def main():
     ap.add_argument('--config', default='kitti', choices=['kitti', 'nuscenes', 'scannet_fast', 'sunrgbd_fast', 'scannet_v1'],
                     help='BASELINE.json workload; the headline metric is quoted on kitti (configs[1]), the default')
     ap.add_argument('--views', type=int, default=0, help='views per scene for the indoor configs (default: reference test value)')
+    ap.add_argument('--shard', default='samples', choices=['samples', 'views'],
+                    help="multi-GPU partition: 'samples' (default; weak scaling, the headline mode) or 'views' (indoor multi-view "
+                         "configs: the views of each scene are split over the ranks, one RCCL all-reduce of the partial volume; strong scaling)")
     ap.add_argument('--graph', action='store_true',
                     help='replay the device side of the step as one captured hipGraph (kitti config); the roofline entry is then '
                          'taken from the eager warm-up steps, which run the same kernels with HIP events around the neck')
@@ -158,7 +183,10 @@ def main():
     from imvoxelnet_amd.conv import FusedConv
 
     if args.config != 'kitti':
-        return bench_other(args, ia, kc, dev, rank, world)
+        bench_other(args, ia, kc, dev, rank, world)
+        if world > 1 or force_dist:
+            dist.destroy_process_group()
+        return
     model = ia.build_detector(kitti_model_cfg(), test_cfg=KITTI_TEST_CFG)
     ia.randomize_(model, 0)
     with torch.no_grad():   # trained-net-like head statistics so the NMS tail has real work

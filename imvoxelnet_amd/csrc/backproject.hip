@@ -32,6 +32,7 @@ struct BpParams {
   const int *crop_hw;       // [B, 2]
   float *volume;            // [B, N, C]
   uint8_t *valid;           // [B, N]
+  int *count;               // [B, N]  (sum mode: number of views that saw the voxel)
   float vs0, vs1, vs2;
   int V, FH, FW, C;
   int X, Y, Z;
@@ -40,7 +41,9 @@ struct BpParams {
   int lpv_log2; // lanes per voxel = 1 << lpv_log2
 };
 
-template <int VEC>
+// MEAN = true: the reference's view mean + valid mask.  MEAN = false (view-sharded multi-GPU mode): the raw sum over
+// this rank's views and the per-voxel view count, to be all-reduced and normalised by volume_normalize_kernel.
+template <int VEC, bool MEAN = true>
 __global__ __launch_bounds__(256) void backproject_mean_kernel(const BpParams p) {
   const int b = blockIdx.y;
   const int lpv = 1 << p.lpv_log2;
@@ -127,14 +130,34 @@ __global__ __launch_bounds__(256) void backproject_mean_kernel(const BpParams p)
       if constexpr (VEC == 4) {
         f32x4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = cnt ? __fdiv_rn(acc[q][e], dn) : 0.f;
+        for (int e = 0; e < 4; ++e) y[e] = MEAN ? (cnt ? __fdiv_rn(acc[q][e], dn) : 0.f) : acc[q][e];
         *reinterpret_cast<f32x4 *>(dst + ch * 4) = y;
       } else {
-        dst[ch] = cnt ? __fdiv_rn(acc[q][0], dn) : 0.f;
+        dst[ch] = MEAN ? (cnt ? __fdiv_rn(acc[q][0], dn) : 0.f) : acc[q][0];
       }
     }
   }
-  if (g == 0) p.valid[(size_t)b * p.N + n] = cnt > 0 ? 1 : 0;
+  if (g == 0) {
+    if (MEAN)
+      p.valid[(size_t)b * p.N + n] = cnt > 0 ? 1 : 0;
+    else
+      p.count[(size_t)b * p.N + n] = cnt;
+  }
+}
+
+// volume[b,n,:] = count ? sum / count : 0 (in place), valid = count > 0 (detectors/imvoxelnet.py:70-74 after the
+// all-reduce of the per-rank partial sums).  One float4 per thread.
+__global__ __launch_bounds__(256) void volume_normalize_kernel(float *volume, const int *count, uint8_t *valid, long long total4, int C4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long vox = i / C4;
+    const int cnt = count[vox];
+    f32x4 x = *reinterpret_cast<f32x4 *>(volume + i * 4);
+    const float dn = (float)cnt;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = cnt ? __fdiv_rn(x[e], dn) : 0.f;
+    *reinterpret_cast<f32x4 *>(volume + i * 4) = x;
+    if (i % C4 == 0) valid[vox] = cnt > 0 ? 1 : 0;
+  }
 }
 
 // Single-view specialisation (KITTI, SUN RGB-D: V == 1).  With one view the mean is the gathered value itself, so no
@@ -200,17 +223,18 @@ __global__ __launch_bounds__(256) void backproject_single_view_kernel(const BpPa
   }
 }
 
-extern "C" int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,
-                                        const float *proj, const float *new_origin, const int32_t *crop_hw,
-                                        const float *voxel_size, int32_t X, int32_t Y, int32_t Z, float *volume,
-                                        uint8_t *valid, ivx_stream_t stream) {
-  IVX_REQUIRE(feat && proj && new_origin && crop_hw && voxel_size && volume && valid, "ivx_backproject_mean_fwd: null argument");
+static int backproject_launch(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C, const float *proj,
+                              const float *new_origin, const int32_t *crop_hw, const float *voxel_size, int32_t X, int32_t Y,
+                              int32_t Z, float *volume, uint8_t *valid, int32_t *count, ivx_stream_t stream) {
+  const bool mean = count == nullptr;
+  IVX_REQUIRE(feat && proj && new_origin && crop_hw && voxel_size && volume && (valid || count), "ivx_backproject_mean_fwd: null argument");
   IVX_REQUIRE(B > 0 && V > 0 && FH > 0 && FW > 0 && C > 0 && X > 0 && Y > 0 && Z > 0, "ivx_backproject_mean_fwd: non-positive dims");
   IVX_REQUIRE((int64_t)X * Y * Z < (1LL << 31), "ivx_backproject_mean_fwd: voxel grid too large");
   IVX_REQUIRE((int64_t)B * V * FH * FW < (1LL << 31), "ivx_backproject_mean_fwd: feature maps too large");
   IVX_REQUIRE(B <= 65535, "ivx_backproject_mean_fwd: batch too large");
   BpParams p;
   p.feat = feat; p.proj = proj; p.new_origin = new_origin; p.crop_hw = crop_hw; p.volume = volume; p.valid = valid;
+  p.count = count;
   p.vs0 = voxel_size[0]; p.vs1 = voxel_size[1]; p.vs2 = voxel_size[2];
   p.V = V; p.FH = FH; p.FW = FW; p.C = C; p.X = X; p.Y = Y; p.Z = Z; p.N = X * Y * Z;
   const int vec = (C % 4 == 0) ? 4 : 1;
@@ -219,6 +243,13 @@ extern "C" int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V,
   int lg = 0;
   while ((1 << lg) < p.nchunk && lg < 6) ++lg;
   p.lpv_log2 = lg;
+  if (!mean) {
+    IVX_REQUIRE(vec == 4, "ivx_backproject_sum_fwd: C %% 4 must be 0");
+    const int vpb = 256 >> lg;
+    hipLaunchKernelGGL((backproject_mean_kernel<4, false>), dim3((p.N + vpb - 1) / vpb, B), dim3(256), 0, (hipStream_t)stream, p);
+    IVX_CHECK_LAUNCH("ivx_backproject_sum_fwd");
+    return IVX_OK;
+  }
   if (V == 1) {
     // 256 voxels per workgroup regardless of the group width (each lane projects one voxel)
     dim3 g1((p.N + 255) / 256, B);
@@ -236,5 +267,33 @@ extern "C" int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V,
   else
     hipLaunchKernelGGL(backproject_mean_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
   IVX_CHECK_LAUNCH("ivx_backproject_mean_fwd");
+  return IVX_OK;
+}
+
+extern "C" int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,
+                                        const float *proj, const float *new_origin, const int32_t *crop_hw,
+                                        const float *voxel_size, int32_t X, int32_t Y, int32_t Z, float *volume,
+                                        uint8_t *valid, ivx_stream_t stream) {
+  IVX_REQUIRE(valid, "ivx_backproject_mean_fwd: null argument");
+  return backproject_launch(feat, B, V, FH, FW, C, proj, new_origin, crop_hw, voxel_size, X, Y, Z, volume, valid, nullptr, stream);
+}
+
+extern "C" int ivx_backproject_sum_fwd(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,
+                                       const float *proj, const float *new_origin, const int32_t *crop_hw,
+                                       const float *voxel_size, int32_t X, int32_t Y, int32_t Z, float *volume_sum,
+                                       int32_t *count, ivx_stream_t stream) {
+  IVX_REQUIRE(count, "ivx_backproject_sum_fwd: null argument");
+  return backproject_launch(feat, B, V, FH, FW, C, proj, new_origin, crop_hw, voxel_size, X, Y, Z, volume_sum, nullptr, count, stream);
+}
+
+extern "C" int ivx_volume_normalize_fwd(float *volume, const int32_t *count, int64_t n_voxels, int32_t C, uint8_t *valid,
+                                        ivx_stream_t stream) {
+  IVX_REQUIRE(volume && count && valid, "ivx_volume_normalize_fwd: null argument");
+  IVX_REQUIRE(n_voxels > 0 && C > 0 && C % 4 == 0, "ivx_volume_normalize_fwd: bad dims (C %% 4 must be 0)");
+  const long long total4 = (long long)n_voxels * (C / 4);
+  long long blocks = (total4 + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(volume_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, volume, count, valid, total4, C / 4);
+  IVX_CHECK_LAUNCH("ivx_volume_normalize_fwd");
   return IVX_OK;
 }

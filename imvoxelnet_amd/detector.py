@@ -165,6 +165,20 @@ class ImVoxelNet(nn.Module):
                 results[i]['layout'] = layouts[i]
         return results
 
+    def simple_test_view_sharded(self, img, img_metas, group=None):
+        """simple_test with the VIEWS of the scene(s) sharded over the ranks of `group` (second mode): every
+        rank computes the 2-D features and the partial unprojection of its views, one all-reduce of the partial volume
+        sums and view counts (RCCL) is the only exchange, the 3-D neck / head / NMS then run replicated, so every rank
+        returns the full result.  Same output as simple_test up to fp32 rounding of the view sum."""
+        from .dist import view_sharded_lift
+        volume, valid = view_sharded_lift(self, img, img_metas, group=group)
+        if isinstance(self.bbox_head, Anchor3DHead):
+            boxes, scores, labels, count = self.detect_cl(volume, img_metas)
+            dets = self.bbox_head._wrap(boxes, scores, labels, count, img_metas)
+        else:
+            dets = self.detect_indoor_cl(volume, valid, img_metas)
+        return [bbox3d2result(b, s, l) for b, s, l in dets]
+
     def capture_graph(self, img, img_metas, warmup=2):
         """Capture the device side of simple_test for this input shape as ONE hipGraph (anchor-head configs): every
         launch from the layout change of the image to the NMS tail is recorded once on a capture stream and replayed

@@ -4,7 +4,12 @@ only exchange is one all-gather of fixed-size padded detections per batch.  It r
 based collect_results_cpu/gpu used by the reference's multi_gpu_test (tools/test.py:131-136).
 
 Payload per sample: max_num x (7 box + score + label) fp32 + count  (KITTI: 50 x 9 x 4 B = 1.8 kB), so the
-collective is latency-bound; there is deliberately no other data-path collective.
+collective is latency-bound; the sample-sharded mode deliberately has no other data-path collective.
+
+Second, optional mode for single-scene latency with many views: VIEW sharding.  Each rank runs the 2-D
+trunk and the partial unprojection on its slice of the views, the partial view sums and view counts are all-reduced
+(the one real exchange step of the path: 26-300 MB fp32 per scene, ring all-reduce over xGMI), every rank normalises
+and continues with the (replicated) 3-D neck and head.  See view_sharded_lift / ImVoxelNet.simple_test_view_sharded.
 """
 import torch
 import torch.distributed as dist
@@ -17,9 +22,14 @@ def shard_range(n_items, rank, world):
     return start, start + q + (1 if rank < r else 0)
 
 
+def _rank_world(rank, world):
+    """Defaults from the process group; (0, 1) when torch.distributed is not initialised (single process)."""
+    on = dist.is_available() and dist.is_initialized()
+    return ((dist.get_rank() if on else 0) if rank is None else rank, (dist.get_world_size() if on else 1) if world is None else world)
+
+
 def shard_batch(img, img_metas, rank=None, world=None):
-    rank = dist.get_rank() if rank is None else rank
-    world = dist.get_world_size() if world is None else world
+    rank, world = _rank_world(rank, world)
     a, b = shard_range(len(img_metas), rank, world)
     return img[a:b], img_metas[a:b]
 
@@ -48,3 +58,45 @@ def all_gather_detections(boxes, scores, labels, count, group=None):
     out = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(out, packed, group=group)
     return unpack_detections(out, scores.shape[1])
+
+
+def shard_views(img, img_metas, rank=None, world=None):
+    """img [B,V,3,H,W], metas with V extrinsics each -> this rank's contiguous slice of the views (same slice for
+    every sample).  Returns (img_local [B,V_local,...], metas_local, (v0, v1))."""
+    rank, world = _rank_world(rank, world)
+    v0, v1 = shard_range(img.shape[1], rank, world)
+    metas = []
+    for m in img_metas:
+        m2 = dict(m)
+        l2i = dict(m['lidar2img'])
+        l2i['extrinsic'] = list(m['lidar2img']['extrinsic'])[v0:v1]
+        m2['lidar2img'] = l2i
+        metas.append(m2)
+    return img[:, v0:v1].contiguous(), metas, (v0, v1)
+
+
+def all_reduce_volume(vol_sum, count, group=None):
+    """Sum the per-rank partial view sums [B,X,Y,Z,C] fp32 and view counts [B,X,Y,Z] int32 over the ranks, in place.
+    Two collectives per batch; a no-op without an initialised process group."""
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(vol_sum, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
+    return vol_sum, count
+
+
+def view_sharded_lift(model, img, img_metas, rank=None, world=None, group=None):
+    """The exchange step of the view-sharded mode.  img [B,V,3,H,W] and img_metas are the FULL inputs (present on every
+    rank); returns the complete (volume [B,X,Y,Z,C], valid [B,X,Y,Z] bool) on every rank."""
+    from . import ops
+    img_l, metas_l, (v0, v1) = shard_views(img, img_metas, rank, world)
+    if v1 > v0:
+        p0 = model.features_2d_cl(img_l)
+        proj, origin, crop = model._camera_setup(metas_l, 4, p0.device)
+        vol, cnt = ops.backproject_sum(p0, proj, origin, crop, model.voxel_size, model.n_voxels)
+    else:     # more ranks than views: this rank contributes zeros
+        B = img.shape[0]
+        cf = model.neck.out_channels
+        vol = torch.zeros((B,) + tuple(model.n_voxels) + (cf,), device=img.device, dtype=torch.float32)
+        cnt = torch.zeros((B,) + tuple(model.n_voxels), device=img.device, dtype=torch.int32)
+    all_reduce_volume(vol, cnt, group)
+    return ops.volume_normalize_(vol, cnt)

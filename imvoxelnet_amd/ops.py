@@ -201,6 +201,38 @@ def backproject_mean(feat, proj, new_origin, crop_hw, voxel_size, n_voxels):
     return vol, valid.view(torch.bool)
 
 
+def backproject_sum(feat, proj, new_origin, crop_hw, voxel_size, n_voxels):
+    """View-sharded mode: like backproject_mean but returns the raw view sum [B,X,Y,Z,C] and the int32 view count
+    [B,X,Y,Z] of THIS rank's views (to be all-reduced, then volume_normalize_)."""
+    _chk(feat, 'feat')
+    _chk(proj, 'proj')
+    _chk(new_origin, 'new_origin')
+    _chk(crop_hw, 'crop_hw', torch.int32)
+    B, V = proj.shape[0], proj.shape[1]
+    BV, D, FH, FW, Cn = feat.shape
+    if BV != B * V or D != 1 or tuple(proj.shape[2:]) != (3, 4):
+        raise ValueError('feat / proj shapes do not agree')
+    X, Y, Z = (int(v) for v in n_voxels)
+    vol = torch.empty((B, X, Y, Z, Cn), device=feat.device, dtype=torch.float32)
+    cnt = torch.empty((B, X, Y, Z), device=feat.device, dtype=torch.int32)
+    vs = (C.c_float * 3)(*[float(v) for v in voxel_size])
+    check(_lib.lib().ivx_backproject_sum_fwd(_ptr(feat), B, V, FH, FW, Cn, _ptr(proj), _ptr(new_origin), _ptr(crop_hw),
+                                             vs, X, Y, Z, _ptr(vol), _ptr(cnt), _stream()), 'ivx_backproject_sum_fwd')
+    return vol, cnt
+
+
+def volume_normalize_(vol_sum, count):
+    """In place: vol = count ? vol / count : 0; returns (vol, valid bool [B,X,Y,Z])."""
+    _chk(vol_sum, 'vol_sum')
+    _chk(count, 'count', torch.int32)
+    if tuple(count.shape) != tuple(vol_sum.shape[:-1]):
+        raise ValueError('count must have the spatial shape of the volume')
+    valid = torch.empty(count.shape, device=vol_sum.device, dtype=torch.uint8)
+    check(_lib.lib().ivx_volume_normalize_fwd(_ptr(vol_sum), _ptr(count), count.numel(), vol_sum.shape[-1], _ptr(valid), _stream()),
+          'ivx_volume_normalize_fwd')
+    return vol_sum, valid.view(torch.bool)
+
+
 # ------------------------------------------------------------------ detection tail
 def anchor_head_get_bboxes(head_out, anchors, H, W, num_anchors, num_classes, offs, cfg, dir_offset=0.0,
                            dir_limit_offset=1.0, hw_transposed=False, want_candidates=False):

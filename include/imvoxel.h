@@ -151,6 +151,20 @@ int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V, int32_t FH
                              const float *voxel_size /*host*/, int32_t X, int32_t Y, int32_t Z,
                              float *volume, uint8_t *valid, ivx_stream_t stream);
 
+/* View-sharded multi-GPU mode (second mode: one exchange step): every rank lifts ITS views with
+ * ivx_backproject_sum_fwd -- same geometry, but the raw sum over the rank's views (volume_sum [B,X,Y,Z,C]) and the
+ * per-voxel number of views that saw the voxel (count [B,X,Y,Z] int32) instead of the mean --, the two tensors are
+ * all-reduced over the ranks (RCCL), and ivx_volume_normalize_fwd turns the totals into the reference's result in
+ * place: volume = count ? sum / count : 0, valid = count > 0 (detectors/imvoxelnet.py:70-74).  C % 4 == 0.
+ * The view sum is then ordered rank by rank instead of strictly by view: equal to the single-GPU result to fp32
+ * rounding of the additions (the valid mask is exact).                                                         */
+int ivx_backproject_sum_fwd(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,
+                            const float *proj, const float *new_origin, const int32_t *crop_hw,
+                            const float *voxel_size, int32_t X, int32_t Y, int32_t Z, float *volume_sum,
+                            int32_t *count, ivx_stream_t stream);
+int ivx_volume_normalize_fwd(float *volume, const int32_t *count, int64_t n_voxels, int32_t C, uint8_t *valid,
+                             ivx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Anchor3DHead tail -- replaces Anchor3DHead.get_bboxes_single
  * (mmdet3d/models/dense_heads/anchor3d_head.py:428-517) for a batch, single feature level,

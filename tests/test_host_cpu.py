@@ -409,3 +409,55 @@ def test_get_extrinsics_and_projection_with_predicted_angles():
     meta = dict(img_shape=(480, 640, 3), ori_shape=(530, 730, 3), lidar2img=dict(intrinsic=g['intrinsic'], extrinsic=[np.eye(4, dtype=np.float32)]))
     p = ia.ImVoxelNet._compute_projection(meta, 4, [torch.from_numpy(g['angles'][1])])
     assert np.array_equal(p.numpy(), g['projection'])
+
+
+def _view_shard_worker(rank, world, port, out_q):
+    """One rank of the view-sharded mode on CPU: the per-rank partial unprojection comes from the C oracle (there is no
+    CPU product path), the sharding and the exchange are the product's (dist.shard_views / all_reduce_volume)."""
+    import torch.distributed as dist
+    from imvoxelnet_amd import dist as ivd
+    from oracle import c_oracle as co
+    from helpers import load_npz, sub
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    c = sub(load_npz('backproject_cases.npz'), 'C::')            # a 6-view golden case
+    V = c['feat'].shape[0]
+    img = torch.zeros(1, V, 3, 8, 8)
+    meta = dict(lidar2img=dict(extrinsic=[np.eye(4, dtype=np.float32) * (v + 1) for v in range(V)], intrinsic=np.eye(4, dtype=np.float32)))
+    img_l, metas_l, (v0, v1) = ivd.shard_views(img, [meta], rank, world)
+    assert img_l.shape[1] == v1 - v0 and len(metas_l[0]['lidar2img']['extrinsic']) == v1 - v0
+    assert all(float(e[0, 0]) == v + 1 for e, v in zip(metas_l[0]['lidar2img']['extrinsic'], range(v0, v1)))
+    h, w = int(c['img_shape'][0]) // 4, int(c['img_shape'][1]) // 4          # the crop the detector applies (:67-68)
+    vol_v, valid_v = co.backproject(c['feat'][v0:v1], c['points'], c['projection'][v0:v1], h, w)
+    part = torch.from_numpy(vol_v.sum(0)).permute(1, 2, 3, 0).contiguous().unsqueeze(0)         # [1,X,Y,Z,C]
+    cnt = torch.from_numpy(valid_v.sum(0)[0].astype(np.int32)).unsqueeze(0)
+    ivd.all_reduce_volume(part, cnt)
+    out_q.put((rank, (v0, v1), part.numpy(), cnt.numpy()))
+    dist.destroy_process_group()
+
+
+def test_view_sharded_exchange_gloo_world2():
+    """Second multi-GPU mode (views sharded, one all-reduce of partial volume sums + view counts): two gloo processes;
+    after the exchange and the normalisation every rank holds the reference's view-mean volume and valid mask."""
+    import torch.multiprocessing as mp
+    from helpers import sub
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_view_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    c = sub(load_npz('backproject_cases.npz'), 'C::')
+    V = c['feat'].shape[0]
+    assert res[0][1] == (0, V // 2) and res[1][1] == (V // 2, V)
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    tot, cnt = res[0][2][0], res[0][3][0]
+    mean = np.where(cnt[..., None] > 0, tot / np.maximum(cnt, 1)[..., None], 0.0).astype(np.float32)
+    ref = np.transpose(c['mean'], (1, 2, 3, 0))
+    assert np.array_equal(cnt > 0, c['mean_valid'][0])
+    assert np.abs(mean - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
