@@ -326,8 +326,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 // wave-uniform base + lane*16 B, so LDS rows are unpadded 128-byte rows and bank conflicts are avoided by an XOR
 // swizzle applied on the SOURCE side (lane with slot c of row r fetches k-chunk c ^ ((r >> SW_SH) & SW_MSK)) and
 // again on the fragment read.  BK (K-slab depth) is 32 or 16; 16 halves the LDS so three workgroups fit on a CU.
-template <typename T, int TM, int TN, int WR, int WC, int BK>
-__global__ __launch_bounds__(256) void conv_igemm_v4_kernel(const ConvParams p, const unsigned in_bytes,
+template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE = 1>
+__global__ __launch_bounds__(256, WPE) void conv_igemm_v4_kernel(const ConvParams p, const unsigned in_bytes,
                                                                   const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   constexpr int EL = sizeof(T);        // 4 (fp32) or 2 (bf16)
@@ -700,7 +700,7 @@ static void launch_cfg(const ConvParams &p, hipStream_t st) {
   hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
 }
 
-template <typename T, int TM, int TN, int WR, int WC, int BK>
+template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE = 1>
 static void launch_v4(ConvParams &p, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * sizeof(T);
@@ -713,7 +713,7 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
     p.q_count = p.q_total;
   }
   const long long g1 = 8LL * p.q_count * Nt;
-  hipLaunchKernelGGL((conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK>), dim3((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, st, p, (unsigned)in_bytes,
+  hipLaunchKernelGGL((conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE>), dim3((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, st, p, (unsigned)in_bytes,
                      (unsigned)w_bytes);
 }
 
@@ -745,6 +745,10 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 51: *t = {128, 128, 16, 3}; return true;
     case 53: *t = {128, 64, 16, 5}; return true;
     case 52: *t = {256, 64, 16, 3}; return true;
+    case 54: *t = {128, 128, 16, 4}; return true;
+    case 55: *t = {128, 128, 16, 5}; return true;
+    case 56: *t = {128, 64, 16, 6}; return true;
+    case 74: *t = {128, 128, 32, 4}; return true;
     // bf16 (cfg + 20: same tile, same LDS bytes, BK counts bf16 elements)
     case 61: *t = {128, 128, 64, 2}; return true;
     case 63: *t = {128, 64, 64, 3}; return true;
@@ -764,9 +768,10 @@ static bool dma_applicable(const ConvParams &p) {
 }
 
 // Kernel / tile / split-K choice (measured per layer on MI355X with tools/conv_bench.py).
-//  * Big problems want the 128-row tiles with the best MFMA : staging ratio (BK 16 keeps LDS at 32 KB so three
-//    workgroups share a CU).  When 128 x 128 tiles would not fill the workgroup slots several times over -- every
-//    ResNet/FPN layer at KITTI resolution, the indoor necks -- 64 x 64 tiles win by occupancy.
+//  * Big problems want the 128-row tiles with the best MFMA : staging ratio; BK 16 keeps LDS at 32 KB and the
+//    128 x 128 kernel is compiled for <= 128 registers (launch bound 4 waves/SIMD), so four workgroups share a CU
+//    (+2.5 % per layer over three; measured).  When 128 x 128 tiles would not fill the workgroup slots several
+//    times over -- every ResNet/FPN layer at KITTI resolution, the indoor necks -- 64 x 64 tiles win by occupancy.
 //  * When even 64 x 64 tiles leave most of the 256 CUs idle and K is long (ResNet stage 4, FPN laterals on C5, the
 //    coarse levels of the indoor necks), K is split across grid.y and a second pass sums the slices.
 //  * Grid tail: with uniform tiles the last partial round costs a whole workgroup time on a few CUs while the rest
@@ -784,16 +789,18 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     if (p.Cout <= 32) {
       pl.cfg = dma_ok ? 44 : 4;
     } else if (nblk >= 2500) {
-      pl.cfg = p.Cout > 64 ? (dma_ok ? 51 : 1) : (dma_ok ? 43 : 3);
+      pl.cfg = p.Cout > 64 ? (dma_ok ? 54 : 1) : (dma_ok ? 43 : 3);
     } else {
       pl.cfg = dma_ok ? 46 : 6;
       small = true;
     }
   }
-  if (p.in_bf16 && pl.cfg >= 41 && pl.cfg <= 53) {
+  if (p.in_bf16 && pl.cfg >= 41 && pl.cfg <= 56) {
     // same tile, bf16 instantiation; with 8x the MFMA rate the kernel is LDS-bound and the 128-byte-row 128 x 128
-    // tile (fewest barriers per flop) beats the three-workgroups-per-CU variant (measured, tools/conv_bench.py)
-    pl.cfg = (g_tile_override == 0 && pl.cfg == 51) ? 61 : pl.cfg + 20;
+    // tile (fewest barriers per flop) beats the 3 / 4 workgroups-per-CU variants (measured, tools/conv_bench.py)
+    if (g_tile_override == 0 && pl.cfg == 54) pl.cfg = 61;
+    else if (pl.cfg == 54) pl.cfg = 74;
+    else if (pl.cfg <= 53) pl.cfg += 20;
   }
   TileInfo t;
   if (!tile_info(pl.cfg, &t) || !dma_ok) return pl;
@@ -848,6 +855,10 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 51: launch_v4<float, 2, 2, 2, 2, 16>(p, st); break;   //          128 x 128, 64-byte rows: 32 KB LDS, 3 workgroups/CU
     case 53: launch_v4<float, 2, 1, 2, 2, 16>(p, st); break;
     case 52: launch_v4<float, 2, 2, 4, 1, 16>(p, st); break;   //          256 x 64, 64-byte rows: 40 KB LDS
+    case 54: launch_v4<float, 2, 2, 2, 2, 16, 4>(p, st); break;  // 51 squeezed to 128 registers: 4 workgroups/CU
+    case 55: launch_v4<float, 2, 2, 2, 2, 16, 5>(p, st); break;  //    ... to 102 registers: 5 workgroups/CU (all 160 KB of LDS)
+    case 56: launch_v4<float, 2, 1, 2, 2, 16, 6>(p, st); break;  // 53 at 6 workgroups/CU
+    case 74: launch_v4<__bf16, 2, 2, 2, 2, 32, 4>(p, st); break; // 71 at 4 workgroups/CU
     case 61: launch_v4<__bf16, 2, 2, 2, 2, 64>(p, st); break;  // bf16 operands, v_mfma_f32_32x32x16_bf16
     case 63: launch_v4<__bf16, 2, 1, 2, 2, 64>(p, st); break;
     case 64: launch_v4<__bf16, 1, 1, 4, 1, 64>(p, st); break;
