@@ -702,3 +702,89 @@ def test_conv_batch_slicing_beyond_2gib(ia):
     for lo, hi in ((0, 3), (3, 6)):
         yh = ops.conv_fwd(x[lo:hi].contiguous(), w, sc, sh, (3, 3, 3), (1, 1, 1), (1, 1, 1), relu=True, res=r[lo:hi].contiguous(), wgt_layout=1)
         assert torch.equal(y[lo:hi], yh), (lo, hi)
+
+
+def test_conv_randomized_sweep_vs_validation_kernel(ia):
+    """Seeded sweep over 80 random convolution problems (kernel extents, strides, paddings, channel counts that hit both
+    weight layouts, residual / ReLU / post-scale epilogues, M from a handful of rows to several tile rounds, both
+    storage types): the MFMA path (whatever plan_conv picks: tile, split-K, grid-tail plan) against the one-thread-per-
+    output validation kernel on the same device buffers.  fp32: 2e-4 of the tensor's max; bf16 output: one bf16 ulp."""
+    from imvoxelnet_amd import ops
+    rng = np.random.RandomState(2024)
+    g = torch.Generator(device='cuda').manual_seed(2024)
+    worst = 0.0
+    for it in range(80):
+        bf = it % 5 == 4
+        kd, kh, kw = [(1, 1, 1), (3, 3, 3), (1, 3, 3), (3, 1, 1), (1, 1, 3), (2, 2, 2)][rng.randint(6)]
+        cin = int(rng.choice([64, 128, 192] if bf else [4, 8, 24, 32, 64, 96, 160]))
+        cout = int(rng.choice([8, 20, 32, 64, 72, 128, 200, 256]))
+        B = int(rng.randint(1, 4))
+        D = int(rng.randint(kd, 9)) if kd > 1 or rng.rand() < 0.5 else 1
+        H, W = int(rng.randint(max(kh, 2), 40)), int(rng.randint(max(kw, 2), 48))
+        s = tuple(int(rng.randint(1, 3)) for _ in range(3))
+        p = (int(rng.randint(0, (kd + 1) // 2 + 0)), int(rng.randint(0, kh // 2 + 1)), int(rng.randint(0, kw // 2 + 1)))
+        if D + 2 * p[0] < kd:
+            continue
+        dt = torch.bfloat16 if bf else torch.float32
+        ck = 64 if bf else 32
+        layout = 1 if (cin % ck == 0 and rng.rand() < 0.7) else 0
+        x = torch.randn(B, D, H, W, cin, device='cuda', generator=g).to(dt)
+        wshape = (cout, kd, kh, kw, cin) if layout == 0 else (cout, cin // ck, kd, kh, kw, ck)
+        w = (torch.randn(wshape, device='cuda', generator=g) * (1.0 / (cin * kd * kh * kw)) ** 0.5).to(dt)
+        sc = torch.rand(cout, device='cuda', generator=g) + 0.5 if rng.rand() < 0.7 else None
+        sh = torch.randn(cout, device='cuda', generator=g) if sc is not None else None
+        relu = bool(rng.rand() < 0.5)
+        y0 = ops.conv_fwd(x, w, sc, sh, (kd, kh, kw), s, p, relu=relu, wgt_layout=layout, naive=True)
+        res = torch.randn(y0.shape, device='cuda', generator=g).to(dt) if rng.rand() < 0.4 else None
+        kw_ = dict(relu=relu, res=res, wgt_layout=layout, res_after_act=bool(res is not None and rng.rand() < 0.3),
+                   post_scale=0.5 if rng.rand() < 0.2 else 1.0)
+        yn = ops.conv_fwd(x, w, sc, sh, (kd, kh, kw), s, p, naive=True, **kw_)
+        y = ops.conv_fwd(x, w, sc, sh, (kd, kh, kw), s, p, **kw_)
+        scale = max(1.0, float(yn.float().abs().max()))
+        err = float((y.float() - yn.float()).abs().max()) / scale
+        tol = 2 ** -7 if bf else 2e-4
+        worst = max(worst, err / tol)
+        assert err <= tol, (it, (B, D, H, W, cin, cout), (kd, kh, kw), s, p, layout, bf, err)
+    print('randomized conv sweep: worst error / tolerance', worst)
+
+
+def test_unprojection_randomized_cameras_bit_exact(ia):
+    """24 random scenes (1-9 views, C in {4, 12, 64, 96, 256}, random rotations / positions including cameras inside the
+    grid, behind it and looking away, cropped feature maps, grids with odd extents): the fused kernels (multi-view,
+    single-view and the view-sharded sum + normalise pair) against the C oracle -- volume bit-identical, mask exact."""
+    from imvoxelnet_amd import ops
+    from oracle import c_oracle as co
+    rng = np.random.RandomState(77)
+    for it in range(24):
+        V = int(rng.choice([1, 1, 2, 3, 5, 9]))
+        Cn = int(rng.choice([4, 12, 64, 96, 256]))
+        FH, FW = int(rng.randint(6, 40)), int(rng.randint(6, 48))
+        feat = torch.randn(V, Cn, FH, FW, generator=torch.Generator().manual_seed(1000 + it))
+        f = rng.uniform(8, 60)
+        K = np.array([[f, 0, FW / 2 + rng.uniform(-3, 3), 0], [0, f, FH / 2 + rng.uniform(-3, 3), 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+        Es = []
+        for v in range(V):
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            a, b, c, d = q
+            R = np.array([[a*a+b*b-c*c-d*d, 2*(b*c-a*d), 2*(b*d+a*c)], [2*(b*c+a*d), a*a-b*b+c*c-d*d, 2*(c*d-a*b)],
+                          [2*(b*d-a*c), 2*(c*d+a*b), a*a-b*b-c*c+d*d]])
+            E = np.eye(4); E[:3, :3] = R; E[:3, 3] = rng.uniform(-3, 3, 3)
+            Es.append(E.astype(np.float32))
+        P = co.compute_projection(K, Es, 1.0)
+        nv = (int(rng.randint(3, 20)), int(rng.randint(3, 20)), int(rng.randint(1, 9)))
+        vs = tuple(float(rng.choice([.08, .16, .32])) for _ in range(3))
+        origin = rng.uniform(-1, 1, 3).astype(np.float32)
+        hc, wc = int(rng.randint(FH // 2, FH + 1)), int(rng.randint(FW // 2, FW + 1))
+        pts = co.get_points(nv, vs, origin)
+        ref, ok = co.backproject_mean(feat.numpy(), pts, P, hc, wc)
+        no = (torch.from_numpy(origin) - torch.tensor(nv) / 2. * torch.tensor(vs))[None].cuda().contiguous()
+        crop = torch.tensor([[hc, wc]], dtype=torch.int32).cuda()
+        Pd = torch.from_numpy(P)[None].cuda().contiguous()
+        vol, valid = ops.backproject_mean(cl(feat), Pd, no, crop, vs, nv)
+        got = vol[0].permute(3, 0, 1, 2).cpu().numpy()
+        assert np.array_equal(valid[0].cpu().numpy(), ok[0]), it
+        assert np.array_equal(got, ref), (it, V, Cn, int((got != ref).sum()))
+        if Cn % 4 == 0:
+            s, c = ops.backproject_sum(cl(feat), Pd, no, crop, vs, nv)
+            vol2, valid2 = ops.volume_normalize_(s, c)
+            assert torch.equal(valid2, valid) and torch.equal(vol2, vol), it
