@@ -7,7 +7,6 @@ The pool and the six Linear layers run on the device (ivx_global_avgpool_fwd, 1x
 the epilogue; Dropout is the identity in eval mode); the final limit_period / exp on 9 numbers per sample is done on
 the host after the one small D2H the reference also needs (its extrinsics are built from `angles` on the CPU).
 """
-import numpy as np
 import torch
 from torch import nn
 

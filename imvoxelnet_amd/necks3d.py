@@ -3,7 +3,6 @@
 ([B,C,X,Y,Z] in; Kitti/NuScenes: one [B,256,Y',X'] out); forward_cl is the channels-last fast path the
 detector chains without layout changes.
 """
-import torch
 from torch import nn
 
 from . import ops

@@ -206,7 +206,6 @@ def gen_necks(ns):
 
 def gen_anchor_head(ns):
     ah = ns.anchor_head
-    from types import SimpleNamespace
 
     class Cfg(dict):
         __getattr__ = dict.get
@@ -571,7 +570,6 @@ def gen_indoor_eval(ns):
             store[f's{sidx}::det_scores'] = scores
             store[f's{sidx}::det_labels'] = dcls.astype(np.int64)
         label2cat = {i: f'c{i}' for i in range(n_cls)}
-        from enum import IntEnum
         res = ev.indoor_eval(gt_annos, dt_annos, [0.25, 0.5], label2cat, box_type_3d=Depth, box_mode_3d=2)
     finally:
         torch.Tensor.cuda = real_cuda

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import assert_close, cl, uncl
+from gpu_util import assert_close, uncl
 from kitti_cfg import kitti_model_cfg, KITTI_TEST_CFG, kitti_meta
 
 pytestmark = pytest.mark.gpu

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from helpers import load_npz, load_json, ROOT
-from kitti_cfg import kitti_model_cfg, KITTI_TEST_CFG, kitti_meta
+from kitti_cfg import kitti_model_cfg, KITTI_TEST_CFG
 
 
 def test_cabi_library_loads_and_exports_every_declared_symbol():
