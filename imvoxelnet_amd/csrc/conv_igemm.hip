@@ -326,7 +326,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 // wave-uniform base + lane*16 B, so LDS rows are unpadded 128-byte rows and bank conflicts are avoided by an XOR
 // swizzle applied on the SOURCE side (lane with slot c of row r fetches k-chunk c ^ ((r >> SW_SH) & SW_MSK)) and
 // again on the fragment read.  BK (K-slab depth) is 32 or 16; 16 halves the LDS so three workgroups fit on a CU.
-template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE = 1>
+// s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched): the LDS-DMA loads are VMEM operations; the compiler does not order
+// them against the ds_reads of a LATER loop iteration, so the wait before the publishing barrier is explicit.
+__device__ __forceinline__ void lds_dma_wait_all() { __builtin_amdgcn_s_waitcnt(0x0f70); }
+
+template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE, int UNI>
 __global__ __launch_bounds__(256, WPE) void conv_igemm_v4_kernel(const ConvParams p, const unsigned in_bytes,
                                                                   const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
@@ -410,8 +414,16 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_v4_kernel(const ConvParam
     s_begin = blockIdx.y * per;
     s_end = s_begin + per < S_all ? s_begin + per : S_all;
   }
-  int k4 = s_begin * BK + cc * EPC;
-  int kc, ka, ke, kf;
+  // K-loop state.  UNI (the production case: chunk-major weights, or tap-major with Cin % BK == 0): every lane of a
+  // slab works on the same filter tap, so tap indices, the tap's input offset and its validity mask are wave-uniform
+  // (scalar registers / SALU) and the per-slab vector work is one and/compare/add/select per A row and one add per B
+  // row.  Otherwise (tiny Cin: the 3-channel stem, odd test shapes) the tap differs per 16-byte chunk and the state is
+  // per lane.
+  const int S = s_end - s_begin;
+  const unsigned OOB = 0x80000000u;
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  int k4 = s_begin * BK + cc * EPC;      // per lane (generic path)
+  int kc, ka, ke, kf;                    // generic: per lane; UNI: uniform (kc without the lane's chunk offset)
   int khalf = 0;   // 64-byte rows, chunk-major: which half of the 128-byte channel chunk this slab covers
   if (p.kmode == 1) {  // chunk-major: slab s = (CK-channel chunk, tap, half)
     constexpr int HPS = CK / BK;                       // slabs per (chunk, tap)
@@ -420,46 +432,69 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_v4_kernel(const ConvParam
     const int rem = s_begin - chunk * ntap * HPS;
     const int tap = rem / HPS;
     khalf = rem - tap * HPS;
-    kc = chunk * CK + khalf * (CK / 2) + cc * EPC;
+    kc = chunk * CK + khalf * (CK / 2) + (UNI ? 0 : cc * EPC);
     kf = tap % p.KW;
     const int t2 = tap / p.KW;
     ke = t2 % p.KH;
     ka = t2 / p.KH;
   } else {
-    const int tap = k4 / p.Cin;
-    kc = k4 - tap * p.Cin;
+    const int kfirst = UNI ? s_begin * BK : k4;
+    const int tap = kfirst / p.Cin;
+    kc = kfirst - tap * p.Cin;
     kf = tap % p.KW;
     const int t2 = tap / p.KW;
     ke = t2 % p.KH;
     ka = t2 / p.KH;
   }
-  const int S = s_end - s_begin;
-  const unsigned OOB = 0x80000000u;
+  int a_base[AR];          // UNI: a_off + the lane's chunk offset (elements)
+  unsigned b_base[BR];     // UNI: byte offset of (row n, the lane's chunk) or the out-of-range marker
+  unsigned kb = (unsigned)(s_begin * BK) * EL;   // UNI: byte offset of the slab inside a weight row
+  if constexpr (UNI) {
+#pragma unroll
+    for (int j = 0; j < AR; ++j) a_base[j] = a_off[j] + cc * EPC;
+#pragma unroll
+    for (int j = 0; j < BR; ++j) b_base[j] = b_off[j] >= 0 ? (unsigned)(b_off[j] + cc * EPC) * EL : OOB;
+  }
 
-  typedef __attribute__((address_space(3))) void *lds_ptr_t;
   auto load_slab = [&](int buf) {
-    // branch-free: a k past K turns the tap mask into all-ones, which no row mask can satisfy
-    const unsigned kbad = (k4 < p.K) ? 0u : 0xffffffffu;
-    const int delta = ((ka * p.H + ke) * p.W + kf) * p.Cin + kc;
-    const unsigned tap = ((1u << ka) | (1u << (8 + ke)) | (1u << (16 + kf))) | kbad;
     T *Ab = As + buf * BM * BK + wid_u * (64 / NCH) * BK;   // wave-uniform base; the DMA adds lane*16 B
     T *Bb = Bs + buf * BN * BK + wid_u * (64 / NCH) * BK;
+    if constexpr (UNI) {
+      const int delta = ((ka * p.H + ke) * p.W + kf) * p.Cin + kc;                       // scalar
+      const unsigned tap = (1u << ka) | (1u << (8 + ke)) | (1u << (16 + kf));           // scalar
 #pragma unroll
-    for (int j = 0; j < AR; ++j) {
-      const unsigned good = ((a_msk[j] & tap) == tap) ? 0xffffffffu : 0u;
-      const unsigned vo = (((unsigned)(a_off[j] + delta) * EL) & good) | (OOB & ~good);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + RP * j * BK), 16, vo, 0, 0, 0);
-    }
+      for (int j = 0; j < AR; ++j) {
+        const unsigned vo = ((a_msk[j] & tap) == tap) ? (unsigned)(a_base[j] + delta) * EL : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + RP * j * BK), 16, vo, 0, 0, 0);
+      }
 #pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      const unsigned good = (b_off[j] >= 0 ? 0xffffffffu : 0u) & ~kbad;
-      const unsigned vo = (((unsigned)(b_off[j] + k4) * EL) & good) | (OOB & ~good);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bb + RP * j * BK), 16, vo, 0, 0, 0);
+      for (int j = 0; j < BR; ++j) {
+        const unsigned vo = b_base[j] + kb;   // an out-of-range marker stays out of range: kb < 2^31
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bb + RP * j * BK), 16, vo, 0, 0, 0);
+      }
+    } else {
+      // branch-free: a k past K turns the tap mask into all-ones, which no row mask can satisfy
+      const unsigned kbad = (k4 < p.K) ? 0u : 0xffffffffu;
+      const int delta = ((ka * p.H + ke) * p.W + kf) * p.Cin + kc;
+      const unsigned tap = ((1u << ka) | (1u << (8 + ke)) | (1u << (16 + kf))) | kbad;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) {
+        const unsigned good = ((a_msk[j] & tap) == tap) ? 0xffffffffu : 0u;
+        const unsigned vo = (((unsigned)(a_off[j] + delta) * EL) & good) | (OOB & ~good);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + RP * j * BK), 16, vo, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < BR; ++j) {
+        const unsigned good = (b_off[j] >= 0 ? 0xffffffffu : 0u) & ~kbad;
+        const unsigned vo = (((unsigned)(b_off[j] + k4) * EL) & good) | (OOB & ~good);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bb + RP * j * BK), 16, vo, 0, 0, 0);
+      }
     }
   };
   auto advance_k = [&]() {
     k4 += BK;
-    if (p.kmode == 1) {  // next tap of the same 32-channel chunk; after the last tap move to the next chunk
+    kb += BK * EL;
+    if (p.kmode == 1) {  // next tap of the same channel chunk; after the last tap move to the next chunk
       if (BK < CK) {
         khalf ^= 1;
         kc += khalf ? CK / 2 : -(CK / 2);
@@ -497,17 +532,21 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_v4_kernel(const ConvParam
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Software pipeline over two LDS buffers with a prefetch distance of two slabs.  The fragments of a slab's LAST k-step
+  // are read into registers before the barrier, so after the barrier the buffer of the CURRENT slab is already free:
+  // the DMA of slab s+2 is issued into it right there and has the last MFMA group of slab s plus all but the last
+  // group of slab s+1 to land (a full slab of MFMA time), instead of being issued only at the top of the next slab.
   load_slab(0);
-  __syncthreads();
+  if (S > 1) {
+    advance_k();
+    load_slab(1);
+  }
+  lds_dma_wait_all();
+  __syncthreads();   // slabs 0 (and 1) landed in every wave's view
 
   const int frow = (lane & 31) * BK, fsw = ((lane & 31) >> SW_SH) & SW_MSK, fh = lane >> 5;
   for (int s = 0; s < S; ++s) {
     const int cur = s & 1;
-    const bool more = (s + 1) < S;
-    if (more) {
-      advance_k();
-      load_slab(cur ^ 1);
-    }
     const T *Ac = As + cur * BM * BK + wr * TM * 32 * BK + frow;
     const T *Bc = Bs + cur * BN * BK + wc * TN * 32 * BK + frow;
     // one 16-byte read per operand tile and k-step: half-wave h takes chunk 2*kk + h (4 fp32 k -> 4 MFMAs 32x32x2,
@@ -525,6 +564,15 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_v4_kernel(const ConvParam
         for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
+      } else {
+        // every wave holds its last fragments of buffer `cur`; slab s+1 (other buffer) must have landed: each wave
+        // waits for its own DMA (issued one barrier ago), the barrier then publishes all of them
+        lds_dma_wait_all();
+        __syncthreads();
+        if (s + 2 < S) {
+          advance_k();
+          load_slab(cur);
+        }
       }
       if constexpr (EL == 4) {
 #pragma unroll
@@ -543,7 +591,6 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_v4_kernel(const ConvParam
                                                                acc[i][j], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
   if (p.ksplit > 1) {
     // raw partial sums; ivx split-K reduce kernel applies the epilogue
@@ -713,8 +760,11 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
     p.q_count = p.q_total;
   }
   const long long g1 = 8LL * p.q_count * Nt;
-  hipLaunchKernelGGL((conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE>), dim3((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, st, p, (unsigned)in_bytes,
-                     (unsigned)w_bytes);
+  const dim3 grid((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1);
+  // every slab lies inside one filter tap -> uniform K-loop state
+  const bool uni = p.kmode == 1 || p.Cin % BK == 0;
+  auto kern = uni ? conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1> : conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 0>;
+  hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
 }
 
 static thread_local int g_tile_override = 0;
