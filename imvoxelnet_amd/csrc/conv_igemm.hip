@@ -798,6 +798,7 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 54: *t = {128, 128, 16, 4}; return true;
     case 55: *t = {128, 128, 16, 5}; return true;
     case 56: *t = {128, 64, 16, 6}; return true;
+    case 57: *t = {256, 64, 16, 4}; return true;
     case 74: *t = {128, 128, 32, 4}; return true;
     // bf16 (cfg + 20: same tile, same LDS bytes, BK counts bf16 elements)
     case 61: *t = {128, 128, 64, 2}; return true;
@@ -908,6 +909,7 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 54: launch_v4<float, 2, 2, 2, 2, 16, 4>(p, st); break;  // 51 squeezed to 128 registers: 4 workgroups/CU
     case 55: launch_v4<float, 2, 2, 2, 2, 16, 5>(p, st); break;  //    ... to 102 registers: 5 workgroups/CU (all 160 KB of LDS)
     case 56: launch_v4<float, 2, 1, 2, 2, 16, 6>(p, st); break;  // 53 at 6 workgroups/CU
+    case 57: launch_v4<float, 2, 2, 4, 1, 16, 4>(p, st); break;  // 52 at 4 workgroups/CU
     case 74: launch_v4<__bf16, 2, 2, 2, 2, 32, 4>(p, st); break; // 71 at 4 workgroups/CU
     case 61: launch_v4<__bf16, 2, 2, 2, 2, 64>(p, st); break;  // bf16 operands, v_mfma_f32_32x32x16_bf16
     case 63: launch_v4<__bf16, 2, 1, 2, 2, 64>(p, st); break;
