@@ -41,7 +41,7 @@ def main(path, steps=0):
         print(f'\n## 3-D neck reconciliation ({steps} steps profiled)\n')
         print('| launches | per step | ms per step |')
         print('|---|---|---|')
-        print(f'| conv launches >= 0.3 ms (the 11 neck layers, main launch) | {big[0] / steps:.1f} | {(big[1] or 0) / 1e6 / steps:.3f} |')
+        print(f'| conv launches >= 0.3 ms (the 9 neck layers: main launch, + the >= 0.3 ms tail launch of one layer) | {big[0] / steps:.1f} | {(big[1] or 0) / 1e6 / steps:.3f} |')
         print(f'| K-split launches (neck tails + small 2-D layers) | {tail[0] / steps:.1f} | {(tail[1] or 0) / 1e6 / steps:.3f} |')
         print(f'| split-K reductions | {red[0] / steps:.1f} | {(red[1] or 0) / 1e6 / steps:.3f} |')
         print(f'\nneck kernel time per step ~ {((big[1] or 0)) / 1e6 / steps:.2f} ms (+ its share of the K-split rows); bench.py '
