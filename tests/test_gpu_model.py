@@ -239,3 +239,53 @@ def test_view_sharded_mode_matches_single_gpu(ia):
     assert torch.equal(a[0]['scores_3d'], b[0]['scores_3d'])
     assert torch.equal(a[0]['labels_3d'], b[0]['labels_3d'])
     assert torch.equal(a[0]['boxes_3d'].tensor, b[0]['boxes_3d'].tensor)
+
+
+def test_detections_to_kitti_ap_chain(ia):
+    """simple_test -> bbox2result_kitti -> kitti_eval on the device overlaps: with the model's own (score-thresholded)
+    detections as ground truth the precision is 1 at every recall sample that exists, for the 2-D, BEV and 3-D metrics,
+    and dropping the best half of the detections from the "ground truth" lowers the AP (a false-positive path) -- the whole chain is wired consistently."""
+    model = ia.build_detector(kitti_model_cfg(), test_cfg=KITTI_TEST_CFG)
+    ia.randomize_(model, 123)
+    with torch.no_grad():
+        model.bbox_head.conv_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(5))
+        model.bbox_head.conv_cls.bias.fill_(-2.0)
+        model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
+    model.prepare(torch.device('cuda'))
+    metas = [kitti_meta(t=(0.01 * b, 0.0, 0.0), box_type=ia.LiDARInstance3DBoxes) for b in range(3)]
+    img = torch.randn(3, 1, 3, 384, 1280, generator=torch.Generator().manual_seed(11)).cuda()
+    outs = model.simple_test(img, metas)
+    assert sum(len(o['scores_3d']) for o in outs) > 10
+    rect = np.eye(4, dtype=np.float32)
+    trv2c = np.array([[0, -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float32)
+    p2 = np.array([[721.5377, 0, 609.5593, 0], [0, 721.5377, 172.854, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    infos = [dict(image=dict(image_idx=i, image_shape=np.array([384, 1280], np.int32)),
+                  calib=dict(R0_rect=rect, Tr_velo_to_cam=trv2c, P2=p2)) for i in range(3)]
+    dts = ia.bbox2result_kitti(outs, infos, ['Car'])
+    assert sum(len(d['score']) for d in dts) > 5
+    gts = []
+    for d in dts:
+        n = len(d['score'])
+        gts.append(dict(name=d['name'].copy(), truncated=np.zeros(n), occluded=np.zeros(n, dtype=np.int64), alpha=d['alpha'].copy(),
+                        bbox=d['bbox'].copy(), dimensions=d['dimensions'].copy(), location=d['location'].copy(),
+                        rotation_y=d['rotation_y'].copy()))
+    keep = [d for d, g in zip(dts, gts) if len(g['name'])]
+    gts = [g for g in gts if len(g['name'])]
+    _, res = ia.kitti_eval(gts, keep, ['Car'])
+    # perfect detections: precision 1 at every sampled recall point that exists (with N valid objects only the first
+    # ~N of the 41 recall samples exist, so the 11-point AP is 100 * (#existing sample points) / 11, not 100)
+    from imvoxelnet_amd import kitti_ap as ke
+    mo = np.stack([np.array([[0.7, 0.5, 0.5, 0.7, 0.5]] * 3)] * 1)[:, :, [0]]
+    for metric in (0, 1, 2):
+        pr = ke.eval_class(gts, keep, [0], [2], metric, mo)['precision'][0, 0, 0]
+        nz = pr[pr > 0]
+        assert len(nz) >= 8 and np.allclose(nz, 1.0), (metric, pr)
+        assert np.all(pr[len(nz):] == 0)
+    assert res['KITTI/Car_3D_hard_strict'] > 60.0
+    half = []
+    for d, g in zip(keep, gts):
+        order = np.argsort(-d['score'])
+        sel = np.sort(order[len(order) // 2:]) if len(order) > 1 else order
+        half.append({k: v[sel] for k, v in g.items()})
+    _, res2 = ia.kitti_eval(half, keep, ['Car'])
+    assert res2['KITTI/Car_3D_hard_strict'] < res['KITTI/Car_3D_hard_strict']
