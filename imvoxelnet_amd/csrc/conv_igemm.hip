@@ -331,19 +331,20 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 __device__ __forceinline__ void lds_dma_wait_all() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 
 template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE, int UNI>
-__global__ __launch_bounds__(256, WPE) void conv_igemm_v4_kernel(const ConvParams p, const unsigned in_bytes,
+__global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const ConvParams p, const unsigned in_bytes,
                                                                   const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   constexpr int EL = sizeof(T);        // 4 (fp32) or 2 (bf16)
   constexpr int EPC = 16 / EL;         // elements per 16-byte chunk
   constexpr int CK = 128 / EL;         // channels per chunk of the chunk-major K order (128 bytes)
   constexpr int NCH = BK / EPC;        // 16-byte chunks per LDS row (8 or 4)
-  constexpr int RP = 256 / NCH;        // rows covered by one pass of the 256 threads (32 or 64)
+  constexpr int NT = 64 * WR * WC;     // 4 waves (256 threads) or 8 waves (512: the B slab is shared by twice the MFMAs)
+  constexpr int RP = NT / NCH;         // rows covered by one pass of the workgroup's threads
   constexpr int AR = BM / RP, BR = BN / RP;
   constexpr int SW_SH = NCH == 8 ? 1 : 2, SW_MSK = NCH - 1;   // slot c of row r holds k-chunk c ^ ((r >> SW_SH) & SW_MSK)
   static_assert(NCH == 8 || NCH == 4, "BK: LDS rows are 128 or 64 bytes");
   static_assert(BM % RP == 0 && BN % RP == 0, "tile rows");
-  static_assert(WR * WC == 4, "4 waves per workgroup");
+  static_assert(WR * WC == 4 || WR * WC == 8, "4 or 8 waves per workgroup");
   // LDS-DMA staging: rows are BK elements (128 or 64 B), unpadded
   __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * BK];
   T *As = smem;
@@ -764,7 +765,7 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
   // every slab lies inside one filter tap -> uniform K-loop state
   const bool uni = p.kmode == 1 || p.Cin % BK == 0;
   auto kern = uni ? conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1> : conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 0>;
-  hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
 }
 
 static thread_local int g_tile_override = 0;
