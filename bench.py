@@ -71,7 +71,7 @@ def bench_other(args, ia, kc, dev, rank, world):
             model.bbox_head.cls_conv.weight.normal_(0, 0.01, generator=g)
             model.bbox_head.cls_conv.bias.fill_(-2.0)
             model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
-    model.prepare(dev)
+    model.prepare(dev, dtype=torch.bfloat16 if args.storage == 'bf16' else torch.float32)
     # view sharding: every rank holds the same scene(s) and works on its slice of the views
     img = torch.randn(B, V, 3, H, W, generator=torch.Generator().manual_seed(1000 + (0 if args.shard == 'views' else rank))).to(dev)
     metas = [mk() for _ in range(B)]
@@ -129,10 +129,11 @@ def bench_other(args, ia, kc, dev, rank, world):
     rec = {'metric': f'images/sec/node ({args.config}: {V} view(s) 3x{H}x{W}, {"x".join(map(str, cfg["n_voxels"]))} vox)',
            'value': round(B * V * args.steps / dt, 3), 'unit': 'images/s', 'scenes_per_s': round(B * args.steps / dt, 3), 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-           'scaling': 'strong' if view_sharded else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'scaling': 'strong' if view_sharded else 'weak', 'vs_baseline': None, 'dtype': args.storage, 'data': 'synthetic',
            'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'shard': args.shard, 'detections_last_step': int(sum(len(r[1]) for r in last))},
-           'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_f32 (3-D neck)', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+           'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck)' % ('__bf16' if args.storage == 'bf16' else 'float'),
+                        'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS), 4), 'traffic': None,
                         'neck_gflop': round(neck_flops[0] / 1e9, 1), 'neck_ms_per_step': round(neck_ms, 3)}}
     print(json.dumps(rec))
 

@@ -30,7 +30,7 @@ class AnchorHeadDesc(C.Structure):
 
 
 EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
-           'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
+           'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
            'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_fcos_head_workspace_bytes',
            'ivx_fcos_head_level_candidates', 'ivx_nms_workspace_bytes',
            'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms', 'ivx_multiclass_nms_workspace_bytes', 'ivx_multiclass_nms_bev',
@@ -65,6 +65,8 @@ def lib():
     L.ivx_backproject_mean_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(f32), i32, i32, i32,
                                            vp, vp, vp]
     L.ivx_backproject_sum_fwd.argtypes = L.ivx_backproject_mean_fwd.argtypes
+    L.ivx_backproject_mean_fwd_bf16.argtypes = L.ivx_backproject_mean_fwd.argtypes
+    L.ivx_upsample_trilinear2x_fwd_bf16.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     L.ivx_volume_normalize_fwd.argtypes = [vp, vp, i64, i32, vp, vp]
     L.ivx_anchor_head_workspace_bytes.argtypes = [C.POINTER(AnchorHeadDesc)]
     L.ivx_anchor_head_workspace_bytes.restype = i64

@@ -43,8 +43,11 @@ struct BpParams {
 
 // MEAN = true: the reference's view mean + valid mask.  MEAN = false (view-sharded multi-GPU mode): the raw sum over
 // this rank's views and the per-voxel view count, to be all-reduced and normalised by volume_normalize_kernel.
-template <int VEC, bool MEAN = true>
+// T = float (the reference's precision) or __bf16 (optional storage mode: features / volume stored as bf16, the view sum
+// and the division in fp32, one rounding at the store; VEC 4 only).
+template <int VEC, bool MEAN = true, typename T = float>
 __global__ __launch_bounds__(256) void backproject_mean_kernel(const BpParams p) {
+  typedef T tv4 __attribute__((ext_vector_type(4)));
   const int b = blockIdx.y;
   const int lpv = 1 << p.lpv_log2;
   const int lane = threadIdx.x & 63;
@@ -102,17 +105,18 @@ __global__ __launch_bounds__(256) void backproject_mean_kernel(const BpParams p)
       const int o = __shfl(off, gbase + s, 64);
       if (o >= 0) {
         ++cnt;
-        const float *src = p.feat + (size_t)o * p.C;
+        const T *src = reinterpret_cast<const T *>(p.feat) + (size_t)o * p.C;
 #pragma unroll
         for (int q = 0; q < MAXCH; ++q) {
           const int ch = g + q * lpv;
           if (ch < p.nchunk) {
             if constexpr (VEC == 4) {
-              const f32x4 x = *reinterpret_cast<const f32x4 *>(src + ch * 4);
+              const tv4 xr = *reinterpret_cast<const tv4 *>(src + ch * 4);
+              const f32x4 x = {(float)xr[0], (float)xr[1], (float)xr[2], (float)xr[3]};
 #pragma unroll
               for (int e = 0; e < 4; ++e) acc[q][e] = __fadd_rn(acc[q][e], x[e]);
             } else {
-              acc[q][0] = __fadd_rn(acc[q][0], src[ch]);
+              acc[q][0] = __fadd_rn(acc[q][0], (float)src[ch]);
             }
           }
         }
@@ -122,18 +126,18 @@ __global__ __launch_bounds__(256) void backproject_mean_kernel(const BpParams p)
 
   if (!active) return;
   const float dn = (float)cnt;
-  float *dst = p.volume + ((size_t)b * p.N + n) * p.C;
+  T *dst = reinterpret_cast<T *>(p.volume) + ((size_t)b * p.N + n) * p.C;
 #pragma unroll
   for (int q = 0; q < MAXCH; ++q) {
     const int ch = g + q * lpv;
     if (ch < p.nchunk) {
       if constexpr (VEC == 4) {
-        f32x4 y;
+        tv4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = MEAN ? (cnt ? __fdiv_rn(acc[q][e], dn) : 0.f) : acc[q][e];
-        *reinterpret_cast<f32x4 *>(dst + ch * 4) = y;
+        for (int e = 0; e < 4; ++e) y[e] = (T)(MEAN ? (cnt ? __fdiv_rn(acc[q][e], dn) : 0.f) : acc[q][e]);
+        *reinterpret_cast<tv4 *>(dst + ch * 4) = y;
       } else {
-        dst[ch] = MEAN ? (cnt ? __fdiv_rn(acc[q][0], dn) : 0.f) : acc[q][0];
+        dst[ch] = (T)(MEAN ? (cnt ? __fdiv_rn(acc[q][0], dn) : 0.f) : acc[q][0]);
       }
     }
   }
@@ -295,5 +299,31 @@ extern "C" int ivx_volume_normalize_fwd(float *volume, const int32_t *count, int
   if (blocks > 256 * 64) blocks = 256 * 64;
   hipLaunchKernelGGL(volume_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, volume, count, valid, total4, C / 4);
   IVX_CHECK_LAUNCH("ivx_volume_normalize_fwd");
+  return IVX_OK;
+}
+
+// bf16 storage (optional reduced-precision mode): feat / volume are bf16, everything else as ivx_backproject_mean_fwd.
+// Multi-view launches only (with one view the lift is a byte copy: pass the bf16 map as C/2 32-bit words to
+// ivx_backproject_mean_fwd).  C % 4 == 0.
+extern "C" int ivx_backproject_mean_fwd_bf16(const void *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,
+                                             const float *proj, const float *new_origin, const int32_t *crop_hw,
+                                             const float *voxel_size, int32_t X, int32_t Y, int32_t Z, void *volume,
+                                             uint8_t *valid, ivx_stream_t stream) {
+  IVX_REQUIRE(feat && proj && new_origin && crop_hw && voxel_size && volume && valid, "ivx_backproject_mean_fwd_bf16: null argument");
+  IVX_REQUIRE(B > 0 && V > 0 && FH > 0 && FW > 0 && C > 0 && C % 4 == 0 && X > 0 && Y > 0 && Z > 0, "ivx_backproject_mean_fwd_bf16: bad dims (C %% 4 must be 0)");
+  IVX_REQUIRE((int64_t)X * Y * Z < (1LL << 31) && (int64_t)B * V * FH * FW < (1LL << 31) && B <= 65535, "ivx_backproject_mean_fwd_bf16: problem too large");
+  BpParams p;
+  p.feat = (const float *)feat; p.proj = proj; p.new_origin = new_origin; p.crop_hw = crop_hw; p.volume = (float *)volume; p.valid = valid;
+  p.count = nullptr;
+  p.vs0 = voxel_size[0]; p.vs1 = voxel_size[1]; p.vs2 = voxel_size[2];
+  p.V = V; p.FH = FH; p.FW = FW; p.C = C; p.X = X; p.Y = Y; p.Z = Z; p.N = X * Y * Z;
+  p.nchunk = C / 4;
+  IVX_REQUIRE(p.nchunk <= 64 * 4, "ivx_backproject_mean_fwd_bf16: C=%d too large (max 1024)", C);
+  int lg = 0;
+  while ((1 << lg) < p.nchunk && lg < 6) ++lg;
+  p.lpv_log2 = lg;
+  const int vpb = 256 >> lg;
+  hipLaunchKernelGGL((backproject_mean_kernel<4, true, __bf16>), dim3((p.N + vpb - 1) / vpb, B), dim3(256), 0, (hipStream_t)stream, p);
+  IVX_CHECK_LAUNCH("ivx_backproject_mean_fwd_bf16");
   return IVX_OK;
 }

@@ -134,8 +134,9 @@ extern "C" int ivx_nhwc_to_nchw(const float *in, int32_t B, int64_t S, int32_t C
 // F.interpolate(scale_factor=2, mode='trilinear', align_corners=False) on NDHWC (the Atlas decoder,
 // necks/imvoxelnet.py:359).  Source coordinate per axis: max(0.5*(o + 0.5) - 0.5, 0); i1 = min(i0 + 1, n - 1).
 // The 8-corner blend follows ATen's CPU order: d outermost, then h, then w.
-__global__ __launch_bounds__(256) void upsample_trilinear2x_kernel(const float *in, int B, int D, int H, int W, int C,
-                                                                    float *out) {
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_trilinear2x_kernel(const T *in, int B, int D, int H, int W, int C, T *out) {
+  typedef T tx4 __attribute__((ext_vector_type(4)));
   const int C4 = C >> 2;
   const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
   const size_t total = (size_t)B * Do * Ho * Wo * C4;
@@ -153,29 +154,40 @@ __global__ __launch_bounds__(256) void upsample_trilinear2x_kernel(const float *
     const float ld1 = sd - d0, lh1 = sh - h0, lw1 = sw - w0;
     const float ld0 = 1.f - ld1, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
     auto at = [&](int d, int h, int w) {
-      return *reinterpret_cast<const f32x4 *>(in + ((((size_t)b * D + d) * H + h) * W + w) * C + c4 * 4);
+      const tx4 v = *reinterpret_cast<const tx4 *>(in + ((((size_t)b * D + d) * H + h) * W + w) * C + c4 * 4);
+      return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     };
     const f32x4 v000 = at(d0, h0, w0), v001 = at(d0, h0, w1), v010 = at(d0, h1, w0), v011 = at(d0, h1, w1);
     const f32x4 v100 = at(d1, h0, w0), v101 = at(d1, h0, w1), v110 = at(d1, h1, w0), v111 = at(d1, h1, w1);
-    f32x4 o;
+    tx4 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      o[q] = ld0 * (lh0 * (lw0 * v000[q] + lw1 * v001[q]) + lh1 * (lw0 * v010[q] + lw1 * v011[q])) +
-             ld1 * (lh0 * (lw0 * v100[q] + lw1 * v101[q]) + lh1 * (lw0 * v110[q] + lw1 * v111[q]));
-    *reinterpret_cast<f32x4 *>(out + idx * 4) = o;
+      o[q] = (T)(ld0 * (lh0 * (lw0 * v000[q] + lw1 * v001[q]) + lh1 * (lw0 * v010[q] + lw1 * v011[q])) +
+                 ld1 * (lh0 * (lw0 * v100[q] + lw1 * v101[q]) + lh1 * (lw0 * v110[q] + lw1 * v111[q])));
+    *reinterpret_cast<tx4 *>(out + idx * 4) = o;
   }
 }
 
-extern "C" int ivx_upsample_trilinear2x_fwd(const float *in, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, float *out,
-                                            ivx_stream_t stream) {
+template <typename T>
+static int upsample_launch(const T *in, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, T *out, ivx_stream_t stream) {
   IVX_REQUIRE(in && out, "ivx_upsample_trilinear2x_fwd: null argument");
   IVX_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ivx_upsample_trilinear2x_fwd: bad dims (C %% 4 must be 0)");
   const size_t total = (size_t)B * 8 * D * H * W * (C / 4);
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(upsample_trilinear2x_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, B, D, H, W, C, out);
+  hipLaunchKernelGGL(upsample_trilinear2x_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, B, D, H, W, C, out);
   IVX_CHECK_LAUNCH("ivx_upsample_trilinear2x_fwd");
   return IVX_OK;
+}
+
+extern "C" int ivx_upsample_trilinear2x_fwd(const float *in, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, float *out,
+                                            ivx_stream_t stream) {
+  return upsample_launch<float>(in, B, D, H, W, C, out, stream);
+}
+
+extern "C" int ivx_upsample_trilinear2x_fwd_bf16(const void *in, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, void *out,
+                                                 ivx_stream_t stream) {
+  return upsample_launch<__bf16>((const __bf16 *)in, B, D, H, W, C, (__bf16 *)out, stream);
 }
 
 // Global average pool over the spatial positions of a channels-last map: in [B,S,C] -> out [B,C]

@@ -54,12 +54,12 @@ class _ImVoxelHeadBase(nn.Module):
         zeros = torch.zeros(1 + self.n_reg_outs)
         if self.n_convs == 0:
             w = torch.cat([self.centerness_conv.weight, self.reg_conv.weight, self.cls_conv.weight], 0)
-            self.fhead = FusedConv(w, torch.cat([zeros, self.cls_conv.bias.detach().cpu()]), padding=1).to(device)
+            self.fhead = FusedConv(w, torch.cat([zeros, self.cls_conv.bias.detach().cpu()]), padding=1, out_dtype=torch.float32).to(device)
         else:
             self.ftow_reg = [FusedConv(t[0].weight, bn=t[1].tensors(), padding=1, relu=True).to(device) for t in self.reg_convs]
             self.ftow_cls = [FusedConv(t[0].weight, bn=t[1].tensors(), padding=1, relu=True).to(device) for t in self.cls_convs]
-            self.freg = FusedConv(torch.cat([self.centerness_conv.weight, self.reg_conv.weight], 0), padding=1).to(device)
-            self.fcls = FusedConv(self.cls_conv.weight, self.cls_conv.bias, padding=1).to(device)
+            self.freg = FusedConv(torch.cat([self.centerness_conv.weight, self.reg_conv.weight], 0), padding=1, out_dtype=torch.float32).to(device)
+            self.fcls = FusedConv(self.cls_conv.weight, self.cls_conv.bias, padding=1, out_dtype=torch.float32).to(device)   # the tail reads fp32
         self._scale_vals = [float(s.scale) for s in self.scales]
         self._device = device
         return self

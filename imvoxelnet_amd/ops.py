@@ -166,10 +166,13 @@ def dcn_im2col(x, offset_mask, kernel=3, stride=1, pad=1, dil=1):
 
 
 def upsample_trilinear2x(x):
-    _chk(x, 'x')
+    if x.dtype not in _DT:
+        raise TypeError(f'x must be float32 or bfloat16, got {x.dtype}')
+    _chk(x, 'x', x.dtype)
     B, D, H, W, Cn = x.shape
-    out = torch.empty((B, 2 * D, 2 * H, 2 * W, Cn), device=x.device, dtype=torch.float32)
-    check(_lib.lib().ivx_upsample_trilinear2x_fwd(_ptr(x), B, D, H, W, Cn, _ptr(out), _stream()), 'ivx_upsample_trilinear2x_fwd')
+    out = torch.empty((B, 2 * D, 2 * H, 2 * W, Cn), device=x.device, dtype=x.dtype)
+    fn = _lib.lib().ivx_upsample_trilinear2x_fwd if x.dtype == torch.float32 else _lib.lib().ivx_upsample_trilinear2x_fwd_bf16
+    check(fn(_ptr(x), B, D, H, W, Cn, _ptr(out), _stream()), 'ivx_upsample_trilinear2x_fwd')
     return out
 
 
@@ -180,10 +183,24 @@ def backproject_mean(feat, proj, new_origin, crop_hw, voxel_size, n_voxels):
     bf16 storage (optional reduced-precision mode): with one view the lift is a pure gather-copy (no arithmetic on the
     features, imvoxelnet.py:75 divides by a count of 1), so a bf16 map with C channels is passed as C/2 32-bit words."""
     if feat.dtype == torch.bfloat16:
-        if proj.shape[1] != 1 or feat.shape[-1] % 2:
-            raise NotImplementedError('bf16 unprojection is built for single-view inputs with an even channel count')
-        vol, valid = backproject_mean(feat.view(torch.float32), proj, new_origin, crop_hw, voxel_size, n_voxels)
-        return vol.view(torch.bfloat16), valid
+        if proj.shape[1] == 1 and feat.shape[-1] % 2 == 0:
+            vol, valid = backproject_mean(feat.view(torch.float32), proj, new_origin, crop_hw, voxel_size, n_voxels)
+            return vol.view(torch.bfloat16), valid
+        _chk(feat, 'feat', torch.bfloat16)
+        _chk(proj, 'proj')
+        _chk(new_origin, 'new_origin')
+        _chk(crop_hw, 'crop_hw', torch.int32)
+        B, V = proj.shape[0], proj.shape[1]
+        BV, D, FH, FW, Cn = feat.shape
+        if BV != B * V or D != 1 or tuple(proj.shape[2:]) != (3, 4):
+            raise ValueError('feat / proj shapes do not agree')
+        X, Y, Z = (int(v) for v in n_voxels)
+        vol = torch.empty((B, X, Y, Z, Cn), device=feat.device, dtype=torch.bfloat16)
+        valid = torch.empty((B, X, Y, Z), device=feat.device, dtype=torch.uint8)
+        vs = (C.c_float * 3)(*[float(v) for v in voxel_size])
+        check(_lib.lib().ivx_backproject_mean_fwd_bf16(_ptr(feat), B, V, FH, FW, Cn, _ptr(proj), _ptr(new_origin), _ptr(crop_hw),
+                                                       vs, X, Y, Z, _ptr(vol), _ptr(valid), _stream()), 'ivx_backproject_mean_fwd_bf16')
+        return vol, valid.view(torch.bool)
     _chk(feat, 'feat')
     _chk(proj, 'proj')
     _chk(new_origin, 'new_origin')

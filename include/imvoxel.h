@@ -151,6 +151,16 @@ int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V, int32_t FH
                              const float *voxel_size /*host*/, int32_t X, int32_t Y, int32_t Z,
                              float *volume, uint8_t *valid, ivx_stream_t stream);
 
+/* bf16 storage variants (optional reduced-precision mode; sums, divisions and interpolation weights in fp32, one
+ * rounding at the store): multi-view lift and the Atlas decoder's trilinear x2 up-sampling.  A single-view bf16 lift
+ * is a byte copy: pass the map to ivx_backproject_mean_fwd as C/2 32-bit words.                                 */
+int ivx_backproject_mean_fwd_bf16(const void *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,
+                                  const float *proj, const float *new_origin, const int32_t *crop_hw,
+                                  const float *voxel_size, int32_t X, int32_t Y, int32_t Z, void *volume,
+                                  uint8_t *valid, ivx_stream_t stream);
+int ivx_upsample_trilinear2x_fwd_bf16(const void *in, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, void *out,
+                                      ivx_stream_t stream);
+
 /* View-sharded multi-GPU mode (second mode: one exchange step): every rank lifts ITS views with
  * ivx_backproject_sum_fwd -- same geometry, but the raw sum over the rank's views (volume_sum [B,X,Y,Z,C]) and the
  * per-voxel number of views that saw the voxel (count [B,X,Y,Z] int32) instead of the mean --, the two tensors are

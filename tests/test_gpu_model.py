@@ -289,3 +289,53 @@ def test_detections_to_kitti_ap_chain(ia):
         half.append({k: v[sel] for k, v in g.items()})
     _, res2 = ia.kitti_eval(half, keep, ['Car'])
     assert res2['KITTI/Car_3D_hard_strict'] < res['KITTI/Car_3D_hard_strict']
+
+
+@pytest.mark.parametrize('cfg_name', ['scannet_v1', 'scannet_fast'])
+def test_indoor_bf16_storage_mode_tracks_fp32(ia, cfg_name):
+    """Optional bf16 storage on the multi-view indoor path (BASELINE config 5's dtype; the reference is fp32-only):
+    bf16 multi-view lift (fp32 view sum), Atlas / FastIndoor necks incl. the trilinear and transposed-conv up-paths,
+    fp32 head outputs and tail.  Against this library's fp32 path: valid mask identical, volume and neck levels within
+    3 % / 6 % of the tensor's max, fused head outputs within 8 %, detection count within 25 % and best score within 0.05
+    (the synthetic heads produce near-tied scores, so individual low-margin detections may swap)."""
+    import kitti_cfg as kc
+    cfg, tcfg = ((kc.scannet_v1_model_cfg(), kc.SCANNET_V1_TEST_CFG) if cfg_name == 'scannet_v1'
+                 else (kc.scannet_fast_model_cfg(), kc.SCANNET_FAST_TEST_CFG))
+    model = ia.build_detector(cfg, test_cfg=tcfg)
+    ia.randomize_(model, 31)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        model.bbox_head.cls_conv.weight.normal_(0, 0.01, generator=g)
+        model.bbox_head.cls_conv.bias.fill_(-2.0)
+        model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
+    V = 5
+    meta = kc.indoor_meta(V, box_type=ia.DepthInstance3DBoxes)
+    img = torch.randn(1, V, 3, 480, 640, generator=torch.Generator().manual_seed(4)).cuda()
+    outs = {}
+    for name, dt in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+        model.prepare(torch.device('cuda'), dtype=dt)
+        p0 = model.features_2d_cl(img)
+        vol, valid = model.lift_cl(p0, [meta])
+        assert vol.dtype == dt
+        levels = model.neck_3d.forward_cl(vol)
+        heads = model.bbox_head.forward_cl(levels)
+        det = model.simple_test(img, [meta])
+        outs[name] = (vol.float(), valid, [lv.float() for lv in levels], det, [h.float() for h in heads])
+    model.prepare(torch.device('cuda'))
+    a, b = outs['f32'], outs['bf16']
+    assert torch.equal(a[1], b[1])
+    err = (a[0] - b[0]).abs().max().item() / a[0].abs().max().item()
+    print(cfg_name, 'volume err / max', err)
+    assert err < 3e-2
+    for i, (x, y) in enumerate(zip(a[2], b[2])):
+        e = (x - y).abs().max().item() / x.abs().max().item()
+        print(cfg_name, 'neck level', i, 'err / max', e)
+        assert e < 6e-2
+    for i, (x, y) in enumerate(zip(a[4], b[4])):                 # fused head outputs (centerness, regression, class logits)
+        e = (x - y).abs().max().item() / x.abs().max().item()
+        print(cfg_name, 'head level', i, 'err / max', e)
+        assert e < 8e-2
+    na, nb = len(a[3][0]['scores_3d']), len(b[3][0]['scores_3d'])
+    print(cfg_name, 'detections', na, nb)
+    assert na > 0 and abs(na - nb) <= max(5, na // 4)
+    assert abs(float(a[3][0]['scores_3d'].max()) - float(b[3][0]['scores_3d'].max())) < 0.05
