@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   constexpr int SW_SH = NCH == 8 ? 1 : 2, SW_MSK = NCH - 1;   // slot c of row r holds k-chunk c ^ ((r >> SW_SH) & SW_MSK)
   static_assert(NCH == 8 || NCH == 4, "BK: LDS rows are 128 or 64 bytes");
   static_assert(BM % RP == 0 && BN % RP == 0, "tile rows");
-  static_assert(WR * WC == 4 || WR * WC == 8, "4 or 8 waves per workgroup");
+  static_assert(WR * WC == 4 || WR * WC == 8 || WR * WC == 16, "4, 8 or 16 waves per workgroup");
   // LDS-DMA staging: rows are BK elements (128 or 64 B), unpadded
   __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * BK];
   T *As = smem;
@@ -801,6 +801,9 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 56: *t = {128, 64, 16, 6}; return true;
     case 57: *t = {256, 64, 16, 4}; return true;
     case 74: *t = {128, 128, 32, 4}; return true;
+    case 81: *t = {256, 128, 32, 2}; return true;
+    case 82: *t = {256, 256, 32, 1}; return true;
+    case 83: *t = {256, 128, 64, 1}; return true;
     // bf16 (cfg + 20: same tile, same LDS bytes, BK counts bf16 elements)
     case 61: *t = {128, 128, 64, 2}; return true;
     case 63: *t = {128, 64, 64, 3}; return true;
@@ -848,9 +851,10 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     }
   }
   if (p.in_bf16 && pl.cfg >= 41 && pl.cfg <= 56) {
-    // same tile, bf16 instantiation; with 8x the MFMA rate the kernel is LDS-bound and the 128-byte-row 128 x 128
-    // tile (fewest barriers per flop) beats the 3 / 4 workgroups-per-CU variants (measured, tools/conv_bench.py)
-    if (g_tile_override == 0 && pl.cfg == 54) pl.cfg = 61;
+    // same tile, bf16 instantiation -- except for the big layers: at 8x the MFMA rate the kernel is bound by the
+    // L2 -> LDS staging traffic (ablation: +33 % without the loads), so the 256 x 128 / 256 x 256 workgroups of 8 / 16
+    // waves, which move 25 % / 50 % fewer bytes per flop, win there (measured, tools/conv_bench.py --dtype bf16)
+    if (g_tile_override == 0 && pl.cfg == 54) pl.cfg = p.Cout > 128 ? 82 : 81;   // 16 / 8 waves: less L2->LDS traffic per flop
     else if (pl.cfg == 54) pl.cfg = 74;
     else if (pl.cfg <= 53) pl.cfg += 20;
   }
@@ -912,6 +916,9 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 56: launch_v4<float, 2, 1, 2, 2, 16, 6>(p, st); break;  // 53 at 6 workgroups/CU
     case 57: launch_v4<float, 2, 2, 4, 1, 16, 4>(p, st); break;  // 52 at 4 workgroups/CU
     case 74: launch_v4<__bf16, 2, 2, 2, 2, 32, 4>(p, st); break; // 71 at 4 workgroups/CU
+    case 81: launch_v4<__bf16, 2, 2, 4, 2, 32, 4>(p, st); break; // 8 waves, 256 x 128: 25 % less L2->LDS traffic per flop
+    case 82: launch_v4<__bf16, 2, 2, 4, 4, 32, 4>(p, st); break; // 16 waves, 256 x 256: half the traffic per flop
+    case 83: launch_v4<__bf16, 2, 2, 4, 2, 64, 2>(p, st); break; // 8 waves, 256 x 128, 128-byte rows
     case 61: launch_v4<__bf16, 2, 2, 2, 2, 64>(p, st); break;  // bf16 operands, v_mfma_f32_32x32x16_bf16
     case 63: launch_v4<__bf16, 2, 1, 2, 2, 64>(p, st); break;
     case 64: launch_v4<__bf16, 1, 1, 4, 1, 64>(p, st); break;

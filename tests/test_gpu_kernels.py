@@ -170,7 +170,7 @@ def test_conv_bf16_tile_variants(ia):
     try:
         for layout in (1, 0):
             fc = FusedConv(w, stride=(1, 1, 2), padding=1, layout=layout, dtype=bf, out_dtype=torch.float32).to('cuda')
-            for ov in (61, 63, 64, 66, 71, 72, 73, 74, 41, 51, 54):
+            for ov in (61, 63, 64, 66, 71, 72, 73, 74, 81, 82, 83, 41, 51, 54):
                 L.ivx_conv_set_tile_override(ov)
                 assert_close(f'bf16 layout{layout} override{ov}', uncl(fc(xc)), ref, 2e-4, 2e-4)
     finally:
