@@ -44,6 +44,44 @@ def neck_flops_per_sample(nv, c_in, c_out):
     return 2.0 * macs
 
 
+def bench_lift(args, ia, kc, dev):
+    """Unprojection-only stress (BASELINE configs 4 / 5: "HBM-bound gather stress"): the fused multi-view lift alone on
+    synthetic FPN maps, timed with HIP events over `steps` launches.  Algorithmic bytes per scene =
+    features read once + volume written once + valid mask."""
+    from imvoxelnet_amd import ops
+    spec = {'lift_nuscenes': (6, 64, (232, 400), (192, 192, 32), (.32, .32, .32), lambda: kc.nuscenes_meta(box_type=ia.LiDARInstance3DBoxes), 1),
+            'lift_scannet': (50, 64, (120, 160), (80, 80, 32), (.08, .08, .08), lambda: kc.indoor_meta(50, box_type=ia.DepthInstance3DBoxes), 2)}[args.config]
+    V, Cf, (fh, fw), nv, vs, mk, B = spec
+    esz = 2 if args.storage == 'bf16' else 4
+    model = type('M', (), {'_compute_projection': staticmethod(ia.ImVoxelNet._compute_projection)})()   # camera set-up only
+    model.n_voxels, model.voxel_size = nv, vs
+    metas = [mk() for _ in range(B)]
+    proj, origin, crop = ia.ImVoxelNet._camera_setup(model, metas, 4, dev)
+    feat = torch.randn(B * V, 1, fh, fw, Cf, generator=torch.Generator().manual_seed(7)).to(dev)
+    if args.storage == 'bf16':
+        feat = feat.to(torch.bfloat16)
+    for _ in range(max(1, args.warmup)):
+        vol, valid = ops.backproject_mean(feat, proj, origin, crop, vs, nv)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(args.steps):
+        vol, valid = ops.backproject_mean(feat, proj, origin, crop, vs, nv)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    n = nv[0] * nv[1] * nv[2]
+    by = B * (V * Cf * fh * fw * esz + Cf * n * esz + n)
+    print(json.dumps({'metric': f'scenes/sec, unprojection only ({args.config}: {V} views {Cf}x{fh}x{fw} -> {"x".join(map(str, nv))})',
+                      'value': round(B / (ms * 1e-3), 1), 'unit': 'scenes/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+                      'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage,
+                      'data': 'synthetic', 'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B,
+                                                      'valid_fraction': round(float(valid.float().mean()), 4)},
+                      'roofline': {'bound': 'hbm', 'kernel': 'backproject_mean_kernel', 'achieved': round(by / (ms * 1e-3) / 1e9, 1), 'peak': 8000.0,
+                                   'unit': 'GB/s', 'frac': round(by / (ms * 1e-3) / 8e12, 4), 'traffic': None,
+                                   'algorithmic_MB_per_scene': round(by / B / 1e6, 1)}}))
+
+
 def bench_other(args, ia, kc, dev, rank, world):
     """Single-process throughput of the other BASELINE.json workloads (parity-test configurations; not the headline
     metric).  Same timing method; the roofline entry is the conv kernel over the 3-D neck with FLOPs counted per call."""
@@ -145,7 +183,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='samples per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--config', default='kitti', choices=['kitti', 'nuscenes', 'scannet_fast', 'sunrgbd_fast', 'scannet_v1'],
+    ap.add_argument('--config', default='kitti', choices=['kitti', 'nuscenes', 'scannet_fast', 'sunrgbd_fast', 'scannet_v1', 'lift_nuscenes', 'lift_scannet'],
                     help='BASELINE.json workload; the headline metric is quoted on kitti (configs[1]), the default')
     ap.add_argument('--views', type=int, default=0, help='views per scene for the indoor configs (default: reference test value)')
     ap.add_argument('--shard', default='samples', choices=['samples', 'views'],
@@ -183,6 +221,8 @@ def main():
     from kitti_cfg import kitti_model_cfg, KITTI_TEST_CFG, kitti_meta
     from imvoxelnet_amd.conv import FusedConv
 
+    if args.config.startswith('lift_'):
+        return bench_lift(args, ia, kc, dev)
     if args.config != 'kitti':
         bench_other(args, ia, kc, dev, rank, world)
         if world > 1 or force_dist:
