@@ -800,6 +800,9 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 55: *t = {128, 128, 16, 5}; return true;
     case 56: *t = {128, 64, 16, 6}; return true;
     case 57: *t = {256, 64, 16, 4}; return true;
+    case 47: *t = {64, 64, 16, 6}; return true;
+    case 48: *t = {64, 128, 16, 5}; return true;
+    case 49: *t = {128, 64, 16, 5}; return true;
     case 74: *t = {128, 128, 32, 4}; return true;
     case 81: *t = {256, 128, 32, 2}; return true;
     case 82: *t = {256, 256, 32, 1}; return true;
@@ -809,6 +812,7 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 63: *t = {128, 64, 64, 3}; return true;
     case 64: *t = {128, 32, 64, 4}; return true;
     case 66: *t = {64, 64, 64, 5}; return true;
+    case 67: *t = {64, 64, 32, 6}; return true;
     case 71: *t = {128, 128, 32, 3}; return true;
     case 73: *t = {128, 64, 32, 5}; return true;
     case 72: *t = {256, 64, 32, 3}; return true;
@@ -846,7 +850,9 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     } else if (nblk >= 2500) {
       pl.cfg = p.Cout > 64 ? (dma_ok ? 54 : 1) : (dma_ok ? 43 : 3);
     } else {
-      pl.cfg = dma_ok ? 46 : 6;
+      // short-K layers (1x1 convolutions, 3x3 on 64 channels, the stem) are staging/latency-bound: the 64-byte-row
+      // variant at six workgroups per CU keeps more loads in flight; long-K layers prefer the 128-byte rows
+      pl.cfg = dma_ok ? (p.K <= 640 ? 47 : 46) : 6;
       small = true;
     }
   }
@@ -856,7 +862,8 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     // waves, which move 25 % / 50 % fewer bytes per flop, win there (measured, tools/conv_bench.py --dtype bf16)
     if (g_tile_override == 0 && pl.cfg == 54) pl.cfg = p.Cout > 128 ? 82 : 81;   // 16 / 8 waves: less L2->LDS traffic per flop
     else if (pl.cfg == 54) pl.cfg = 74;
-    else if (pl.cfg <= 53) pl.cfg += 20;
+    else if (pl.cfg == 48 || pl.cfg == 49) pl.cfg = 66;
+    else if (pl.cfg <= 53) pl.cfg += 20;   // 41..47, 51..53 -> 61..67, 71..73
   }
   TileInfo t;
   if (!tile_info(pl.cfg, &t) || !dma_ok) return pl;
@@ -915,6 +922,9 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 55: launch_v4<float, 2, 2, 2, 2, 16, 5>(p, st); break;  //    ... to 102 registers: 5 workgroups/CU (all 160 KB of LDS)
     case 56: launch_v4<float, 2, 1, 2, 2, 16, 6>(p, st); break;  // 53 at 6 workgroups/CU
     case 57: launch_v4<float, 2, 2, 4, 1, 16, 4>(p, st); break;  // 52 at 4 workgroups/CU
+    case 47: launch_v4<float, 1, 1, 2, 2, 16, 6>(p, st); break;  // 64 x 64, 64-byte rows: 16 KB LDS, 6 workgroups/CU
+    case 48: launch_v4<float, 1, 2, 2, 2, 16, 5>(p, st); break;  // 64 x 128
+    case 49: launch_v4<float, 2, 1, 2, 2, 16, 5>(p, st); break;  // 128 x 64 at 5 workgroups/CU
     case 74: launch_v4<__bf16, 2, 2, 2, 2, 32, 4>(p, st); break; // 71 at 4 workgroups/CU
     case 81: launch_v4<__bf16, 2, 2, 4, 2, 32, 4>(p, st); break; // 8 waves, 256 x 128: 25 % less L2->LDS traffic per flop
     case 82: launch_v4<__bf16, 2, 2, 4, 4, 32, 4>(p, st); break; // 16 waves, 256 x 256: half the traffic per flop
@@ -923,6 +933,7 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 63: launch_v4<__bf16, 2, 1, 2, 2, 64>(p, st); break;
     case 64: launch_v4<__bf16, 1, 1, 4, 1, 64>(p, st); break;
     case 66: launch_v4<__bf16, 1, 1, 2, 2, 64>(p, st); break;
+    case 67: launch_v4<__bf16, 1, 1, 2, 2, 32, 6>(p, st); break;
     case 71: launch_v4<__bf16, 2, 2, 2, 2, 32>(p, st); break;
     case 73: launch_v4<__bf16, 2, 1, 2, 2, 32>(p, st); break;
     case 72: launch_v4<__bf16, 2, 2, 4, 1, 32>(p, st); break;
