@@ -848,7 +848,7 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     if (p.Cout <= 32) {
       pl.cfg = dma_ok ? 44 : 4;
     } else if (nblk >= 2500) {
-      pl.cfg = p.Cout > 64 ? (dma_ok ? 54 : 1) : (dma_ok ? 43 : 3);
+      pl.cfg = p.Cout > 64 ? (dma_ok ? 54 : 1) : (dma_ok ? (p.K <= 640 ? 49 : 43) : 3);   // 49: the stem
     } else {
       // short-K layers (1x1 convolutions, 3x3 on 64 channels, the stem) are staging/latency-bound: the 64-byte-row
       // variant at six workgroups per CU keeps more loads in flight; long-K layers prefer the 128-byte rows
