@@ -848,7 +848,7 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     if (p.Cout <= 32) {
       pl.cfg = dma_ok ? 44 : 4;
     } else if (nblk >= 2500) {
-      pl.cfg = p.Cout > 64 ? (dma_ok ? 54 : 1) : (dma_ok ? (p.K <= 640 ? 49 : 43) : 3);   // 49: the stem
+      pl.cfg = p.Cout > 64 ? (dma_ok ? 54 : 1) : (dma_ok ? (p.K <= 640 ? 49 : 56) : 3);   // 49: the stem
     } else {
       // short-K layers (1x1 convolutions, 3x3 on 64 channels, the stem) are staging/latency-bound: the 64-byte-row
       // variant at six workgroups per CU keeps more loads in flight; long-K layers prefer the 128-byte rows
@@ -856,13 +856,15 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
       small = true;
     }
   }
-  if (p.in_bf16 && pl.cfg >= 41 && pl.cfg <= 56) {
+  if (p.in_bf16 && pl.cfg >= 41 && pl.cfg <= 57) {
     // same tile, bf16 instantiation -- except for the big layers: at 8x the MFMA rate the kernel is bound by the
     // L2 -> LDS staging traffic (ablation: +33 % without the loads), so the 256 x 128 / 256 x 256 workgroups of 8 / 16
     // waves, which move 25 % / 50 % fewer bytes per flop, win there (measured, tools/conv_bench.py --dtype bf16)
     if (g_tile_override == 0 && pl.cfg == 54) pl.cfg = p.Cout > 128 ? 82 : 81;   // 16 / 8 waves: less L2->LDS traffic per flop
-    else if (pl.cfg == 54) pl.cfg = 74;
-    else if (pl.cfg == 48 || pl.cfg == 49) pl.cfg = 66;
+    else if (pl.cfg == 54 || pl.cfg == 55) pl.cfg = 74;
+    else if (pl.cfg == 48) pl.cfg = 66;
+    else if (pl.cfg == 49 || pl.cfg == 56) pl.cfg = 73;
+    else if (pl.cfg == 57) pl.cfg = 72;
     else if (pl.cfg <= 53) pl.cfg += 20;   // 41..47, 51..53 -> 61..67, 71..73
   }
   TileInfo t;

@@ -184,12 +184,12 @@ def test_conv_grid_tail_split(ia):
     from imvoxelnet_amd import _lib
     from imvoxelnet_amd.conv import FusedConv
     g = torch.Generator(device='cuda').manual_seed(31)
-    x = torch.randn(1, 1, 580, 560, 128, device='cuda', generator=g)
+    x = torch.randn(1, 1, 672, 676, 128, device='cuda', generator=g)
     w = torch.randn(64, 128, 3, 3, generator=torch.Generator().manual_seed(32)) * 0.03
     bn = (torch.rand(64) + .5, torch.randn(64) * .1, torch.randn(64) * .1, torch.rand(64) + .5)
-    r = torch.randn(1, 1, 580, 560, 64, device='cuda', generator=g)
+    r = torch.randn(1, 1, 672, 676, 64, device='cuda', generator=g)
     fc = FusedConv(w, bn=bn, padding=1, relu=True, dims=2).to('cuda')
-    d = _lib.ConvDesc(1, 1, 580, 560, 128, 64, 1, 3, 3, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, fc.layout, 0, 0, 1.0)
+    d = _lib.ConvDesc(1, 1, 672, 676, 128, 64, 1, 3, 3, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, fc.layout, 0, 0, 1.0)
     assert _lib.lib().ivx_conv_workspace_bytes(C.byref(d)) > 0, 'expected the tail plan (2 full rounds + remainder)'
     y = fc(x, res=r)
     yn = fc(x, res=r, naive=True)
@@ -687,8 +687,8 @@ def test_total_config_end_to_end(ia):
 
 def test_conv_batch_slicing_beyond_2gib(ia):
     """A conv whose input exceeds the 31-bit buffer range of the LDS-DMA kernel (2.1 GiB here; the first KITTI neck
-    layers from batch 13 up) is cut into batch slices inside the library: same result as running the halves separately,
-    with a residual, and the workspace query covers the slices."""
+    layers from batch 13 up) is cut into batch slices inside the library: same result (to fp32 rounding of the
+    plan-dependent K-split) as running the halves separately, with a residual; the workspace query covers the slices."""
     from imvoxelnet_amd import ops
     g = torch.Generator(device='cuda').manual_seed(77)
     B, D, H, W, C = 6, 96, 124, 120, 64                       # 6 x 366 MB = 2.19 GB of fp32 input
@@ -701,7 +701,9 @@ def test_conv_batch_slicing_beyond_2gib(ia):
     y = ops.conv_fwd(x, w, sc, sh, (3, 3, 3), (1, 1, 1), (1, 1, 1), relu=True, res=r, wgt_layout=1)
     for lo, hi in ((0, 3), (3, 6)):
         yh = ops.conv_fwd(x[lo:hi].contiguous(), w, sc, sh, (3, 3, 3), (1, 1, 1), (1, 1, 1), relu=True, res=r[lo:hi].contiguous(), wgt_layout=1)
-        assert torch.equal(y[lo:hi], yh), (lo, hi)
+        # different batch sizes may get different grid-tail plans (K-split of the last tiles): equal up to fp32 rounding
+        err = (y[lo:hi] - yh).abs().max().item() / yh.abs().max().item()
+        assert err < 1e-5, (lo, hi, err)
 
 
 def test_conv_randomized_sweep_vs_validation_kernel(ia):
