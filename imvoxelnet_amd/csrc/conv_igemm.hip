@@ -876,8 +876,9 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
   const int S = (p.K + t.bk - 1) / t.bk;
   if (small) {
     const long long tiles = Mt * Nt;
-    if (tiles < 384 && S >= 16) {
-      long long ks = (768 + tiles - 1) / tiles;
+    const long long slots = 256LL * t.wg_per_cu;           // resident workgroups on the chip
+    if (2 * tiles <= slots && S >= 16) {                    // under half a round: split K until the slots are filled once
+      long long ks = (slots + tiles - 1) / tiles;
       if (ks > S / 8) ks = S / 8;
       if (ks > 32) ks = 32;
       if (ks >= 2) {
