@@ -790,3 +790,27 @@ def test_unprojection_randomized_cameras_bit_exact(ia):
             s, c = ops.backproject_sum(cl(feat), Pd, no, crop, vs, nv)
             vol2, valid2 = ops.volume_normalize_(s, c)
             assert torch.equal(valid2, valid) and torch.equal(vol2, vol), it
+
+
+def test_conv_fwd_without_workspace_entry_point(ia):
+    """ivx_conv_fwd (the entry point without a caller workspace: no split-K / tail plans) gives the validation kernel's
+    result on a small-output long-K layer, where ivx_conv_fwd_ws would split K."""
+    import ctypes as C
+    from imvoxelnet_amd import _lib, ops
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(1, 1, 12, 20, 512, device='cuda', generator=g)
+    w = torch.randn(256, 16, 1, 3, 3, 32, device='cuda', generator=g) * 0.02
+    d = _lib.ConvDesc(1, 1, 12, 20, 512, 256, 1, 3, 3, 1, 1, 1, 0, 1, 1, 1, 0, 0, 0, 1, 0, 0, 1.0)
+    L = _lib.lib()
+    assert L.ivx_conv_workspace_bytes(C.byref(d)) > 0            # the _ws entry point would split K here
+    out = torch.empty(1, 1, 12, 20, 256, device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.ivx_conv_fwd(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), None, None, None, C.c_void_p(out.data_ptr()), st)
+    assert rc == 0, L.ivx_last_error()
+    ref = ops.conv_fwd(x, w, None, None, (1, 3, 3), (1, 1, 1), (0, 1, 1), relu=True, wgt_layout=1, naive=True)
+    assert (out - ref).abs().max().item() < 2e-4
+    # too-small workspace is refused with the documented status
+    ws = torch.empty(256, device='cuda', dtype=torch.uint8)
+    rc = L.ivx_conv_fwd_ws(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), None, None, None, C.c_void_p(out.data_ptr()),
+                           C.c_void_p(ws.data_ptr()), 256, st)
+    assert rc == -4 and b'workspace' in L.ivx_last_error()
