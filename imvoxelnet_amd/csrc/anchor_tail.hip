@@ -589,6 +589,7 @@ struct McP {
   float *cboxes;         // [C][ns][5]
   int *n_arr;            // [C]
   int *kept;             // [C][ns]  positions (in the sorted list) that survive
+  float *kscore;         // [C][ns]  their scores (descending), compact
   int *nk;               // [C]
   unsigned long long *mask;
 };
@@ -626,60 +627,120 @@ __global__ __launch_bounds__(1024) void mc_select_sort_kernel(const McP p) {
   }
 }
 
-__global__ __launch_bounds__(64) void mc_scan_kernel(const McP p) {
+// Shared hit matrix (three or more classes): the boxes, hence the pairwise IoUs, are the same for every class -- only the
+// visiting order differs -- so hit[a][b] = IoU(box a, box b) > thr is built ONCE over the original indices (full rows:
+// the order is not known here) instead of once per class over the sorted candidates.
+__global__ __launch_bounds__(64) void nms_hit_full_kernel(const float *boxes, int n, int cb, float thr, int rotated,
+                                                          unsigned long long *mask) {
+  const int row = blockIdx.y, col = blockIdx.x * 64 + threadIdx.x;
+  bool hit = false;
+  if (col < n && col != row) {
+    float a[5], b[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      a[q] = boxes[(size_t)row * 5 + q];
+      b[q] = boxes[(size_t)col * 5 + q];
+    }
+    const float v = rotated ? iou_bev_dev(a, b) : iou_normal_dev(a, b);
+    hit = v > thr;
+  }
+  const unsigned long long w = __ballot(hit);
+  if (threadIdx.x == 0) mask[(size_t)row * cb + blockIdx.x] = w;
+}
+
+// Greedy scan of class c over the shared hit matrix: candidates are visited in score order (sidx), the removal set is a
+// bit per ORIGINAL box index (lane w owns word w).  Row a is only consulted once box a has been kept, and then only its
+// bits for boxes visited LATER matter, so every decision uses iou(kept earlier box, later box) -- the argument order of
+// the reference's nms_gpu -- and the result is identical to the per-class form (which does half the IoUs per class and
+// is therefore kept for one or two classes).
+__device__ int greedy_scan_shared(const unsigned long long *mask, const int *order_s, int n, int cb, int *keep_out) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long remv = 0;
+  int nk = 0;
+  for (int i = 0; i < n; ++i) {
+    const int a = order_s[i];
+    const unsigned long long rw = __shfl(remv, a >> 6, 64);
+    if (!((rw >> (a & 63)) & 1ULL)) {
+      if (lane == 0) keep_out[nk] = i;
+      ++nk;
+      if (lane < cb) remv |= mask[(size_t)a * cb + lane];
+    }
+  }
+  return nk;
+}
+
+__global__ __launch_bounds__(64) void mc_scan_kernel(const McP p, const int shared) {
   __shared__ int keep_s[4096];
+  __shared__ int order_s[4096];
   const int c = blockIdx.x;
   const int n = p.n_arr[c];
   const int cb = p.ns >> 6;
-  const int nk = greedy_scan_wave(p.mask + (size_t)c * p.ns * cb, n, cb, n, keep_s);
+  int nk;
+  if (shared) {
+    for (int i = threadIdx.x; i < n; i += 64) order_s[i] = p.sidx[(size_t)c * p.ns + i];
+    __syncthreads();
+    nk = greedy_scan_shared(p.mask, order_s, n, cb, keep_s);
+  } else {
+    nk = greedy_scan_wave(p.mask + (size_t)c * p.ns * cb, n, cb, n, keep_s);
+  }
   __syncthreads();
-  for (int j = threadIdx.x; j < nk; j += 64) p.kept[(size_t)c * p.ns + j] = keep_s[j];
+  for (int j = threadIdx.x; j < nk; j += 64) {
+    p.kept[(size_t)c * p.ns + j] = keep_s[j];
+    p.kscore[(size_t)c * p.ns + j] = p.sscore[(size_t)c * p.ns + keep_s[j]];
+  }
   if (threadIdx.x == 0) p.nk[c] = nk;
 }
 
-__global__ __launch_bounds__(64) void mc_finalize_kernel(const McP p, long long *out_idx, long long *out_label, int *out_count) {
-  const int lane = threadIdx.x;
+// Final selection.  One thread per surviving box (class c, position j < min(nk[c], max_num) of its score-ordered list).
+// When everything fits max_num the output is the class-major concatenation.  Otherwise the output is the max_num best
+// by score (descending; ties -> lower class, then earlier position): the rank of an element is the number of elements
+// that precede it, found with one binary search per class over the compact, descending per-class score lists -- fully
+// parallel and deterministic (the reference does scores.sort(descending=True)[:max_num] on the concatenation).
+__global__ __launch_bounds__(256) void mc_finalize_kernel(const McP p, long long *out_idx, long long *out_label, int *out_count) {
+  __shared__ int s_nk[64], s_before[65];
   const int C = p.num_classes;
-  const int mine = lane < C ? p.nk[lane] : 0;
-  int total = mine, before = 0;   // inclusive scan over lanes -> offset of class `lane` in the concatenation
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(total, off, 64);
-    if (lane >= off) total += v;
-  }
-  before = total - mine;
-  const int all = __shfl(total, 63, 64);
-  if (all <= p.max_num) {
-    for (int c = 0; c < C; ++c) {
-      const int nkc = __shfl(mine, c, 64), base = __shfl(before, c, 64);
-      for (int j = lane; j < nkc; j += 64) {
-        out_idx[base + j] = p.sidx[(size_t)c * p.ns + p.kept[(size_t)c * p.ns + j]];
-        out_label[base + j] = c;
-      }
+  if (threadIdx.x < 64) s_nk[threadIdx.x] = threadIdx.x < C ? p.nk[threadIdx.x] : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int c = 0; c < 64; ++c) {
+      s_before[c] = acc;
+      acc += s_nk[c];
     }
-    if (lane == 0) *out_count = all;
+    s_before[64] = acc;
+  }
+  __syncthreads();
+  const int all = s_before[64];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = all <= p.max_num ? all : p.max_num;
+  const int cap = p.ns < p.max_num ? p.ns : p.max_num;      // elements per class that can reach the output
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)C * cap) return;
+  const int c = (int)(e / cap), j = (int)(e - (long long)c * cap);
+  if (j >= s_nk[c]) return;
+  const long long src = p.sidx[(size_t)c * p.ns + p.kept[(size_t)c * p.ns + j]];
+  if (all <= p.max_num) {
+    out_idx[s_before[c] + j] = src;
+    out_label[s_before[c] + j] = c;
     return;
   }
-  // k-way merge: lane c walks class c's kept list (descending scores); ties -> lower class (stable w.r.t. concatenation)
-  int head = 0;
-  for (int t = 0; t < p.max_num; ++t) {
-    unsigned long long key = 0ULL;
-    if (lane < C && head < mine) {
-      const float sc = p.sscore[(size_t)lane * p.ns + p.kept[(size_t)lane * p.ns + head]];
-      key = ((unsigned long long)f2key(sc) << 8) | (unsigned long long)(255 - lane);
+  const float sc = p.kscore[(size_t)c * p.ns + j];
+  int rank = j;
+  for (int o = 0; o < C; ++o) {
+    if (o == c) continue;
+    // number of leading elements of class o that come before (sc, c): score > sc, or == sc when o < c
+    const float *ks = p.kscore + (size_t)o * p.ns;
+    int lo = 0, hi = s_nk[o];
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const float v = ks[mid];
+      const bool before = (v > sc) || (v == sc && o < c);
+      if (before) lo = mid + 1; else hi = mid;
     }
-    unsigned long long best = key;
-    for (int off = 32; off > 0; off >>= 1) {
-      const unsigned long long o = __shfl_xor(best, off, 64);
-      best = o > best ? o : best;
-    }
-    const int win = 255 - (int)(best & 0xffULL);
-    if (lane == win) {
-      out_idx[t] = p.sidx[(size_t)lane * p.ns + p.kept[(size_t)lane * p.ns + head]];
-      out_label[t] = lane;
-      ++head;
-    }
+    rank += lo;
+    if (rank >= p.max_num) return;
   }
-  if (lane == 0) *out_count = p.max_num;
+  out_idx[rank] = src;
+  out_label[rank] = c;
 }
 
 static int mc_layout(int32_t n, int32_t num_classes, McP *p, int64_t *total) {
@@ -691,12 +752,13 @@ static int mc_layout(int32_t n, int32_t num_classes, McP *p, int64_t *total) {
   const int64_t o_sidx = take((int64_t)num_classes * ns * 4), o_ss = take((int64_t)num_classes * ns * 4);
   const int64_t o_cb = take((int64_t)num_classes * ns * 5 * 4), o_na = take((int64_t)num_classes * 4);
   const int64_t o_kept = take((int64_t)num_classes * ns * 4), o_nk = take((int64_t)num_classes * 4);
+  const int64_t o_ks = take((int64_t)num_classes * ns * 4);
   const int64_t o_mask = take((int64_t)num_classes * ns * (ns / 64) * 8);
   if (p) {
     p->ns = ns;
     p->npad = next_pow2(n > 1 ? n : 2);
     p->sidx = (int *)o_sidx; p->sscore = (float *)o_ss; p->cboxes = (float *)o_cb; p->n_arr = (int *)o_na;
-    p->kept = (int *)o_kept; p->nk = (int *)o_nk; p->mask = (unsigned long long *)o_mask;
+    p->kept = (int *)o_kept; p->nk = (int *)o_nk; p->mask = (unsigned long long *)o_mask; p->kscore = (float *)o_ks;
   }
   *total = off;
   return IVX_OK;
@@ -734,15 +796,24 @@ extern "C" int ivx_multiclass_nms_bev(const float *boxes, const float *scores, i
   char *w = (char *)workspace;
   p.sidx = (int *)(w + (int64_t)p.sidx); p.sscore = (float *)(w + (int64_t)p.sscore); p.cboxes = (float *)(w + (int64_t)p.cboxes);
   p.n_arr = (int *)(w + (int64_t)p.n_arr); p.kept = (int *)(w + (int64_t)p.kept); p.nk = (int *)(w + (int64_t)p.nk);
+  p.kscore = (float *)(w + (int64_t)p.kscore);
   p.mask = (unsigned long long *)(w + (int64_t)p.mask);
   p.boxes = boxes; p.scores = scores; p.n = n; p.score_stride = score_stride; p.num_classes = num_classes; p.max_num = max_num;
   p.rotated = rotated; p.score_thr = score_thr; p.nms_thr = nms_thr;
   const int cb = p.ns / 64;
   hipLaunchKernelGGL(mc_select_sort_kernel, dim3(num_classes), dim3(1024), (size_t)p.npad * 8, st, p);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, n, num_classes), dim3(64), 0, st, p.cboxes, (const int *)p.n_arr, 0, p.ns, cb, nms_thr,
-                     rotated, p.mask);
-  hipLaunchKernelGGL(mc_scan_kernel, dim3(num_classes), dim3(64), 0, st, p);
-  hipLaunchKernelGGL(mc_finalize_kernel, dim3(1), dim3(64), 0, st, p, (long long *)out_idx, (long long *)out_label, out_count);
+  const int shared = num_classes >= 3;
+  if (shared)
+    hipLaunchKernelGGL(nms_hit_full_kernel, dim3(cb, n), dim3(64), 0, st, boxes, n, cb, nms_thr, rotated, p.mask);
+  else
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, n, num_classes), dim3(64), 0, st, p.cboxes, (const int *)p.n_arr, 0, p.ns, cb, nms_thr,
+                       rotated, p.mask);
+  hipLaunchKernelGGL(mc_scan_kernel, dim3(num_classes), dim3(64), 0, st, p, shared);
+  {
+    const int cap = p.ns < max_num ? p.ns : max_num;
+    const unsigned blocks = (unsigned)(((long long)num_classes * cap + 255) / 256);
+    hipLaunchKernelGGL(mc_finalize_kernel, dim3(blocks), dim3(256), 0, st, p, (long long *)out_idx, (long long *)out_label, out_count);
+  }
   IVX_CHECK_LAUNCH("ivx_multiclass_nms_bev");
   return IVX_OK;
 }
