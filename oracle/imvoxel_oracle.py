@@ -425,7 +425,7 @@ def simple_test_anchor(img, img_metas, sd, cfg):
     """ImVoxelNet.simple_test (detectors/imvoxelnet.py:93-106) for ResNet-50 + FPN +
     {Kitti,NuScenes}ImVoxelNeck + Anchor3DHead.  img [B,V,3,H,W] fp32 torch.  cfg keys:
     n_voxels, voxel_size, neck ('kitti'|'nuscenes'), anchor (ranges,sizes,rotations), test_cfg,
-    num_classes.  Returns list of (boxes[n,7], scores[n], labels[n]) and intermediates."""
+    num_classes, dir_offset / dir_limit_offset (anchor3d_head.py:61-62,511-515, defaults 0 / 1).  Returns list of (boxes[n,7], scores[n], labels[n]) and intermediates."""
     B = img.shape[0]
     x = img.reshape([-1] + list(img.shape[2:]))
     with torch.no_grad():
@@ -444,7 +444,8 @@ def simple_test_anchor(img, img_metas, sd, cfg):
         a = cfg['anchor']
         anchors = grid_anchors(cls.shape[-2:], a['ranges'], a['sizes'], a['rotations'])
         res = [anchor_head_get_bboxes_single(cls[b], reg[b], dr[b], anchors, cfg.get('num_classes', 1),
-                                             cfg['test_cfg']) for b in range(B)]
+                                             cfg['test_cfg'], cfg.get('dir_offset', 0.0),
+                                             cfg.get('dir_limit_offset', 1.0)) for b in range(B)]
     return res, dict(fpn0=f0, volume=vol, valids=torch.stack(valids), neck=y, cls=cls, reg=reg, dir=dr)
 
 

@@ -115,6 +115,55 @@ def test_kitti_full_path_vs_oracle(ia):
     assert_close('e2e boxes', out[0]['boxes_3d'].tensor, rb, 2e-3, 2e-3)
 
 
+def test_nuscenes_full_path_vs_oracle(ia):
+    """BASELINE config 3 at full size (6 x 3x928x1600 through ResNet-50 + DCNv2 + FPN, 312x312x12 voxels, NuScenes neck,
+    dir_offset pi/4, nms_pre 1000 / max_num 500): six-view feature volume, valid mask (exact), neck, kept boxes."""
+    from oracle import imvoxel_oracle as orc
+    from kitti_cfg import nuscenes_model_cfg, nuscenes_meta, NUSCENES_TEST_CFG
+    model = ia.build_detector(nuscenes_model_cfg(), test_cfg=NUSCENES_TEST_CFG)
+    ia.randomize_(model, 321)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(9)
+        for name, m in model.backbone.named_modules():
+            if name.endswith('conv_offset'):
+                m.weight.normal_(0, 0.02, generator=g)
+                m.bias.normal_(0, 0.5, generator=g)
+        model.bbox_head.conv_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(5))
+        model.bbox_head.conv_cls.bias.fill_(-2.0)
+        model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
+        model.bbox_head.conv_dir_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(7))
+    meta = nuscenes_meta(box_type=ia.LiDARInstance3DBoxes)
+    img = torch.randn(1, 6, 3, 928, 1600, generator=torch.Generator().manual_seed(12))
+    sd = _cpu_sd(model)
+    cfg = dict(n_voxels=(312, 312, 12), voxel_size=(.32, .32, .32), neck='nuscenes', num_classes=1, test_cfg=NUSCENES_TEST_CFG,
+               dir_offset=0.7854, dir_limit_offset=0,
+               anchor=dict(ranges=[[-49.92, -49.92, -1.0, 49.92 - .64, 49.92 - .64, -1.0]], sizes=[[1.98, 4.67, 1.74]], rotations=[0, 1.57]))
+    ref, mid = orc.simple_test_anchor(img, [meta], sd, cfg)
+
+    dimg = img.cuda()
+    p0 = model.features_2d_cl(dimg)
+    assert_close('fpn0', uncl(p0)[:, :, 0], mid['fpn0'][0], 3e-3, 3e-3 * float(mid['fpn0'].abs().max()))
+    vol, valid = model.lift_cl(p0, [meta])
+    assert np.array_equal(valid.cpu().numpy(), mid['valids'][:, 0].numpy())
+    assert_close('volume', vol.permute(0, 4, 1, 2, 3), mid['volume'], 3e-3, 3e-3 * float(mid['volume'].abs().max()))
+    vol_ref = mid['volume'].permute(0, 2, 3, 4, 1).contiguous().cuda()
+    y = model.neck_3d.forward_cl(vol_ref)
+    assert_close('neck', y[:, :, :, 0].permute(0, 3, 2, 1), mid['neck'], 2e-3, 2e-3 * float(mid['neck'].abs().max()))
+    boxes, scores, labels, count, _ = model.detect_cl(vol_ref, [meta], want_candidates=True)
+    rb, rs, rl = ref[0]
+    n = int(count[0])
+    print('detections', n, 'reference', len(rs))
+    assert n > 0 and abs(n - len(rs)) <= 0.01 * len(rs)
+    # 1000 candidates -> 500 kept at IoU 0.2: candidates whose scores differ in the 6th digit may swap ranks between the
+    # two fp32 evaluations, so boxes are matched by value, not by position
+    gb, gs = boxes[0, :n].cpu(), scores[0, :n].cpu()
+    d = torch.cdist(rb[:, :3], gb[:, :3], compute_mode='donot_use_mm_for_euclid_dist')
+    near, j = d.min(dim=1)
+    ok = (near < 1e-2) & ((gs[j] - rs).abs() < 1e-3) & ((gb[j] - rb).abs().max(dim=1).values < 1e-2)
+    print('matched', int(ok.sum()), 'of', len(rs), ' same position:', int((j == torch.arange(len(rs))).sum()))
+    assert ok.float().mean().item() >= 0.99
+
+
 def test_kitti_bf16_storage_mode_tracks_fp32(ia):
     """Optional reduced-precision mode (BASELINE config 5; the reference itself is fp32-only): bf16 activations and
     weights, fp32 accumulate / epilogue / head output / tail.  Checked against THIS library's fp32 path (which is the
