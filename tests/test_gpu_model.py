@@ -164,6 +164,64 @@ def test_nuscenes_full_path_vs_oracle(ia):
     assert ok.float().mean().item() >= 0.99
 
 
+@pytest.mark.parametrize('cfg_name', ['scannet_fast', 'sunrgbd_fast'])
+def test_indoor_full_path_vs_oracle(ia, cfg_name):
+    """BASELINE configs 4 / 5 shapes at full size (ScanNet fast: 50 views 3x480x640; SUN RGB-D fast: 1 view; 40x40x16
+    voxels, FastIndoorImVoxelNeck, V2 heads with 18 / 10 classes, nms_pre 1000): volume, valid mask, neck levels and
+    the detections after aligned / rotated multi-class NMS against the oracle."""
+    from oracle import imvoxel_oracle as orc
+    import kitti_cfg as kc
+    if cfg_name == 'scannet_fast':
+        mcfg, tcfg, V, n_reg = kc.scannet_fast_model_cfg(), kc.SCANNET_FAST_TEST_CFG, 50, 6
+        meta = kc.indoor_meta(V, box_type=ia.DepthInstance3DBoxes)
+    else:
+        mcfg, tcfg, V, n_reg = kc.sunrgbd_fast_model_cfg(), kc.SUNRGBD_FAST_TEST_CFG, 1, 7
+        meta = kc.indoor_meta(1, origin=(0, 3, -1), box_type=ia.DepthInstance3DBoxes)
+    model = ia.build_detector(mcfg, test_cfg=tcfg)
+    ia.randomize_(model, 77)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        model.bbox_head.cls_conv.weight.normal_(0, 0.001, generator=g)      # neck outputs reach ~300: keep the logits O(1)
+        model.bbox_head.cls_conv.bias.fill_(-2.0)
+        model.bbox_head.centerness_conv.weight.normal_(0, 0.0005, generator=g)
+        model.bbox_head.reg_conv.weight.normal_(0, 0.0002, generator=g)
+    img = torch.randn(1, V, 3, 480, 640, generator=torch.Generator().manual_seed(13))
+    sd = _cpu_sd(model)
+    nv, vs = mcfg['n_voxels'], mcfg['voxel_size']
+    with torch.no_grad():
+        f0 = orc.fpn_level0(orc.resnet50(img[0], sd), sd)
+        vol_ref, ok_ref = orc.extract_volume(f0.numpy(), meta, nv, vs)
+        sdn = {k[len('neck_3d.'):]: v for k, v in sd.items() if k.startswith('neck_3d.')}
+        sdh = {k[len('bbox_head.'):]: v for k, v in sd.items() if k.startswith('bbox_head.')}
+        lv = orc.fast_indoor_neck(torch.from_numpy(vol_ref)[None], sdn)
+        cs, bs, ss = orc.fcos_head_forward(lv, sdh, n_reg)
+        rb, rs, rl = orc.fcos_get_bboxes_single([c[0] for c in cs], [b[0] for b in bs], [s[0] for s in ss],
+                                                torch.from_numpy(ok_ref).float(), meta['lidar2img']['origin'], vs, n_reg, tcfg)
+    model.prepare(torch.device('cuda'))
+    p0 = model.features_2d_cl(img.cuda())
+    assert_close('fpn0', uncl(p0)[:, :, 0], f0, 3e-3, 3e-3 * float(f0.abs().max()))
+    vol, valid = model.lift_cl(p0, [meta])
+    assert np.array_equal(valid[0].cpu().numpy(), ok_ref[0])
+    vmax = float(np.abs(vol_ref).max())
+    assert_close('volume', vol[0].permute(3, 0, 1, 2), vol_ref, 3e-3, 3e-3 * vmax)
+    # neck, head and NMS from the ORACLE's volume, so the 3-D stack and the tail are compared on identical inputs
+    vol_in = torch.from_numpy(vol_ref).permute(1, 2, 3, 0)[None].contiguous().cuda()
+    levels = model.neck_3d.forward_cl(vol_in)
+    for l in range(3):
+        assert_close(f'neck level {l}', uncl(levels[l]), lv[l], 2e-3, 2e-3 * float(lv[l].abs().max()))
+    (boxes, scores, labels), = model.detect_indoor_cl(vol_in, valid, [meta])
+    n = len(scores)
+    print(cfg_name, 'detections', n, 'oracle', len(rs))
+    assert n > 0 and abs(n - len(rs)) <= max(1, 0.01 * len(rs))
+    gb, gs, gl = boxes.tensor.cpu(), scores.cpu(), labels.cpu()
+    d = torch.cdist(rb[:, :3], gb[:, :3], compute_mode='donot_use_mm_for_euclid_dist')
+    d = d + 1e3 * (rl[:, None] != gl[None, :]).float()          # the same class only
+    near, j = d.min(dim=1)
+    ok = (near < 1e-3) & ((gs[j] - rs).abs() < 1e-4) & ((gb[j] - rb).abs().max(dim=1).values < 2e-3)
+    print('matched', int(ok.sum()), 'of', len(rs), ' same position:', int((j == torch.arange(len(rs))).sum()))
+    assert ok.float().mean().item() >= 0.99
+
+
 def test_kitti_bf16_storage_mode_tracks_fp32(ia):
     """Optional reduced-precision mode (BASELINE config 5; the reference itself is fp32-only): bf16 activations and
     weights, fp32 accumulate / epilogue / head output / tail.  Checked against THIS library's fp32 path (which is the
