@@ -115,7 +115,7 @@ def bench_other(args, ia, kc, dev, rank, world):
     metas = [mk() for _ in range(B)]
     n = args.steps + args.warmup
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-    neck_flops = [0.0]
+    neck_flops, neck_exec = [0.0], [0.0]    # direct-convolution FLOPs / FLOPs executed (fewer for Winograd-form layers)
 
     view_sharded = args.shard == 'views'
 
@@ -127,10 +127,10 @@ def bench_other(args, ia, kc, dev, rank, world):
             p0 = model.features_2d_cl(img)
             vol, valid = model.lift_cl(p0, metas)
         ev[i][0].record()
-        FusedConv.flops, FusedConv.count_flops = 0.0, True
+        FusedConv.flops, FusedConv.exec_flops, FusedConv.count_flops = 0.0, 0.0, True
         y = model.neck_3d.forward_cl(vol)
         FusedConv.count_flops = False
-        neck_flops[0] = FusedConv.flops
+        neck_flops[0], neck_exec[0] = FusedConv.flops, FusedConv.exec_flops
         ev[i][1].record()
         if isinstance(model.bbox_head, ia.Anchor3DHead):
             h = model.bbox_head.forward_cl(y)
@@ -163,7 +163,7 @@ def bench_other(args, ia, kc, dev, rank, world):
         if rank != 0:
             return
     neck_ms = sum(ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][1]) for i in range(args.steps)) / args.steps
-    ach = neck_flops[0] / (neck_ms * 1e-3) / 1e12
+    ach = neck_exec[0] / (neck_ms * 1e-3) / 1e12      # executed FLOPs over the whole neck time (transform kernels included)
     rec = {'metric': f'images/sec/node ({args.config}: {V} view(s) 3x{H}x{W}, {"x".join(map(str, cfg["n_voxels"]))} vox)',
            'value': round(B * V * args.steps / dt, 3), 'unit': 'images/s', 'scenes_per_s': round(B * args.steps / dt, 3), 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
@@ -172,7 +172,8 @@ def bench_other(args, ia, kc, dev, rank, world):
            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck)' % ('__bf16' if args.storage == 'bf16' else 'float'),
                         'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS), 4), 'traffic': None,
-                        'neck_gflop': round(neck_flops[0] / 1e9, 1), 'neck_ms_per_step': round(neck_ms, 3)}}
+                        'neck_gflop': round(neck_exec[0] / 1e9, 1), 'neck_direct_gflop': round(neck_flops[0] / 1e9, 1),
+                        'direct_equivalent_tflops': round(neck_flops[0] / (neck_ms * 1e-3) / 1e12, 2), 'neck_ms_per_step': round(neck_ms, 3)}}
     print(json.dumps(rec))
 
 
@@ -249,13 +250,18 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps + args.warmup)]
 
+    from imvoxelnet_amd.conv import FusedConv
+    traces = [[] for _ in range(args.steps + args.warmup)]
+
     def step(i):
         p0 = model.features_2d_cl(img)
         proj, new_origin, crop = model._camera_setup(metas, 4, p0.device)   # host camera set-up + 3 small H2D copies
         ev[i][2].record()
         vol, _ = ops.backproject_mean(p0, proj, new_origin, crop, model.voxel_size, model.n_voxels)
         ev[i][0].record()                                   # HIP events on the stream the kernels launch on
+        FusedConv.trace = traces[i]                         # per-stage events of the nine neck layers
         y = model.neck_3d.forward_cl(vol)
+        FusedConv.trace = None
         ev[i][1].record()
         h = model.bbox_head.forward_cl(y)
         boxes, scores, labels, count = model.bbox_head.get_bboxes_cl(h, y.shape[2], y.shape[1], metas, hw_transposed=True)
@@ -303,10 +309,24 @@ def main():
     lift_ms = sum(ev[i][2].elapsed_time(ev[i][0]) for i in ev_ids) / len(neck_ms)
     # unprojection: algorithmic bytes = features read once + volume written once + mask (173.1 MB/sample)
     lift_bytes = B * (1 * 64 * 96 * 320 * esz + 64 * 216 * 248 * 12 * esz + 216 * 248 * 12)
-    n_launch = 9     # conv layers of KittiImVoxelNeck = ivx_conv_fwd_ws calls per step (each: one main launch, plus a K-split
-                     # tail launch + reduction where the plan splits the last partial round; see rocprof summary)
+    # The nine conv layers of KittiImVoxelNeck.  Layers with >= 128 channels run in the F(2x2,3x3) minimal-filtering form
+    # (imvoxelnet_amd/csrc/winograd.hip): input transform -> ONE grouped launch of the implicit-GEMM kernel -> output
+    # transform.  The roofline entry is the implicit-GEMM kernel over its nine launches per step (direct layers: the conv
+    # itself; Winograd layers: the grouped GEMM), with the FLOPs the kernel EXECUTES (16/36 of the direct count for a
+    # Winograd layer) over the event-bracketed duration of exactly those launches; direct_equivalent_tflops divides the
+    # direct-convolution FLOPs of the whole neck by the whole neck time (it may exceed the MFMA peak).
+    n_launch = 9
     flops_step = neck_flops_per_sample((216, 248, 12), 64, 256) * B
-    achieved = flops_step / (neck_ms_avg * 1e-3) / 1e12
+    tr = [t for i in ev_ids for t in traces[i]]
+    nst = len(list(ev_ids))
+    mfma = [t for t in tr if t[0] in ('direct', 'wino_gemm')]
+    mfma_ms = sum(t[1].elapsed_time(t[2]) for t in mfma) / nst
+    mfma_flops = sum(t[3] for t in mfma) / nst
+    n_launch = max(1, round(len(mfma) / nst))
+    achieved = mfma_flops / (mfma_ms * 1e-3) / 1e12
+    xf = [t for t in tr if t[0] in ('wino_input', 'wino_output')]
+    xf_ms = sum(t[1].elapsed_time(t[2]) for t in xf) / nst
+    xf_bytes = sum(t[4] for t in xf) / nst
 
     # HBM traffic of the neck conv launches: PMC counters cannot be read from inside the process, so the value comes
     # from the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh -> profiles/*_bench_pmc.json;
@@ -334,8 +354,16 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, 9 conv layers/step)' % ('__bf16' if bf16 else 'float'),
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/r01_bench_pmc.json)',
-                         'algorithmic_gflop_per_launch': round(flops_step / n_launch / 1e9, 2),
-                         'avg_launch_ms': round(neck_ms_avg / n_launch, 4), 'neck_ms_per_step': round(neck_ms_avg, 3)},
+                         'algorithmic_gflop_per_launch': round(mfma_flops / n_launch / 1e9, 2),
+                         'avg_launch_ms': round(mfma_ms / n_launch, 4), 'launches_per_step': n_launch,
+                         'neck_ms_per_step': round(neck_ms_avg, 3), 'neck_direct_gflop_per_step': round(flops_step / 1e9, 1),
+                         'direct_equivalent_tflops': round(flops_step / (neck_ms_avg * 1e-3) / 1e12, 2),
+                         'winograd_layers_per_step': len([t for t in tr if t[0] == 'wino_gemm']) // nst},
+            'roofline_winograd_transforms': None if not xf else {
+                'bound': 'hbm', 'kernel': 'wino_input_kernel + wino_output_kernel (%d launches/step, event-bracketed)' % (len(xf) // nst),
+                'achieved': round(xf_bytes / (xf_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                'frac': round(xf_bytes / (xf_ms * 1e-3) / 8e12, 4), 'ms_per_step': round(xf_ms, 3),
+                'algorithmic_GB_per_step': round(xf_bytes / 1e9, 2)},
             'roofline_unprojection': {'bound': 'hbm', 'kernel': 'backproject_single_view_kernel (1 launch/step, event-bracketed)',
                                       'achieved': round(lift_bytes / (lift_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
                                       'frac': round(lift_bytes / (lift_ms * 1e-3) / 8e12, 4), 'ms': round(lift_ms, 4),

@@ -10,6 +10,7 @@ ARCH = 'gfx950'
 # (source, extra flags).  The geometry / index kernels must keep the reference's operation order.
 SOURCES = [
     ('conv_igemm.hip', []),
+    ('winograd.hip', []),
     ('pool_layout.hip', []),
     ('backproject.hip', ['-ffp-contract=off']),
     ('anchor_tail.hip', ['-ffp-contract=off']),

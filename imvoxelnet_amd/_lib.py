@@ -30,6 +30,8 @@ class AnchorHeadDesc(C.Structure):
 
 
 EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
+           'ivx_conv_winograd_supported', 'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_weights', 'ivx_conv_winograd_workspace_bytes',
+           'ivx_conv_winograd_input', 'ivx_conv_winograd_gemm', 'ivx_conv_winograd_output', 'ivx_conv_winograd_fwd',
            'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
            'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_fcos_head_workspace_bytes',
            'ivx_fcos_head_level_candidates', 'ivx_nms_workspace_bytes',
@@ -56,6 +58,17 @@ def lib():
     L.ivx_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
     L.ivx_conv_workspace_bytes.restype = i64
     L.ivx_conv_fwd_ws.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    D = C.POINTER(ConvDesc)
+    L.ivx_conv_winograd_supported.argtypes = [D]
+    L.ivx_conv_winograd_weight_elems.argtypes = [D]
+    L.ivx_conv_winograd_weight_elems.restype = i64
+    L.ivx_conv_winograd_weights.argtypes = [D, vp, vp, vp]
+    L.ivx_conv_winograd_workspace_bytes.argtypes = [D]
+    L.ivx_conv_winograd_workspace_bytes.restype = i64
+    L.ivx_conv_winograd_input.argtypes = [D, vp, vp, i64, vp]
+    L.ivx_conv_winograd_gemm.argtypes = [D, vp, vp, i64, vp]
+    L.ivx_conv_winograd_output.argtypes = [D, vp, vp, vp, vp, vp, i64, vp]
+    L.ivx_conv_winograd_fwd.argtypes = [D, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.ivx_maxpool2d_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ivx_global_avgpool_fwd.argtypes = [vp, i32, i64, i32, vp, vp]
     L.ivx_upsample_trilinear2x_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
@@ -84,7 +97,8 @@ def lib():
     L.ivx_multiclass_nms_bev.argtypes = [vp, vp, i32, i32, i32, f32, f32, i32, i32, vp, i64, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ('ivx_last_error', 'ivx_anchor_head_workspace_bytes', 'ivx_nms_workspace_bytes',
-                        'ivx_fcos_head_workspace_bytes', 'ivx_conv_workspace_bytes', 'ivx_multiclass_nms_workspace_bytes'):
+                        'ivx_fcos_head_workspace_bytes', 'ivx_conv_workspace_bytes', 'ivx_multiclass_nms_workspace_bytes',
+                        'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_workspace_bytes'):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -6,6 +6,8 @@ A `FusedConv` is the deploy form of  Conv{2,3}d [+bias] -> [eval BatchNorm] -> [
 The reference never fuses Conv3d+BN (tools/fuse_conv_bn.py handles Conv2d only); applying the BN affine
 in the epilogue instead of folding it into the weights keeps the accumulate identical to conv-then-BN.
 """
+import os
+
 import torch
 
 from . import ops
@@ -49,9 +51,22 @@ def current_storage_dtype():
 
 
 class FusedConv:
-    # optional algorithmic-FLOP accounting (bench.py): 2 * output positions * Cout * Cin * taps per call
+    # optional algorithmic-FLOP accounting (bench.py): 2 * output positions * Cout * Cin * taps per call;
+    # exec_flops counts what the MFMA kernel actually executes (fewer for layers run in the Winograd form)
     count_flops = False
     flops = 0.0
+    exec_flops = 0.0
+    # fp32 3x3xk layers with stride 1 on the first two axes, >= winograd_min_ch input or output channels and
+    # >= winograd_min_pos input positions run as F(2x2,3x3) (ivx_conv_winograd_fwd).  Measured on the KITTI neck (batch 4,
+    # tools/conv_bench.py --winograd): 256->256 16.2 -> 9.1 ms, 128->128 8.2 -> 5.7, 128->256 8.2 -> 5.6, 64->128 4.5 -> 3.9;
+    # the 64->64 layers tie (the two transforms move 8x the activation bytes) and the small indoor volumes stay direct
+    winograd = os.environ.get('IVX_WINOGRAD', '1') != '0'
+    winograd_min_ch = 128
+    winograd_min_pos = 100000
+    # optional per-call timing (bench.py): when a list, every call appends
+    # (kind, start_event, end_event, executed_flops, bytes) with kind 'direct' | 'wino_input' | 'wino_gemm' | 'wino_output';
+    # the events bracket exactly the launches of that stage on the current stream
+    trace = None
 
     def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, relu=False, dims=3, eps=1e-5, layout=None,
                  dtype=None, out_dtype=None):
@@ -83,6 +98,13 @@ class FusedConv:
             co, kd, kh, kw, ci = wp.shape
             wp = wp.reshape(co, kd, kh, kw, ci // ck, ck).permute(0, 4, 1, 2, 3, 5)
         self._w_host = wp.contiguous().to(dtype)
+        # candidate for the minimal-filtering form: keep the tap-major fp32 filters for ivx_conv_winograd_weights
+        self._w0_host = None
+        if (dims == 3 and dtype == torch.float32 and out_dtype == torch.float32 and self.kernel[0] == 3 and self.kernel[1] == 3
+                and self.stride[0] == 1 and self.stride[1] == 1 and self.cin_pad == self.cin and self.cout % 4 == 0
+                and max(self.cin, self.cout) >= FusedConv.winograd_min_ch and self.cin % 4 == 0 and type(self) is FusedConv):
+            self._w0_host = w.permute(0, 2, 3, 4, 1).contiguous()
+        self.u = None
         scale = torch.ones(self.cout)
         shift = torch.zeros(self.cout)
         if bias is not None:
@@ -99,6 +121,8 @@ class FusedConv:
 
     def to(self, device):
         self.w = self._w_host.to(device)
+        if self._w0_host is not None and FusedConv.winograd:
+            self.u = ops.conv_winograd_weights(self._w0_host.to(device), self.layout)
         if not self._identity_epilogue:
             self.scale = self._scale_host.to(device)
             self.shift = self._shift_host.to(device)
@@ -107,11 +131,41 @@ class FusedConv:
     def __call__(self, x, res=None, res_mode=0, relu=None, naive=False, res_after_act=False, post_scale=1.0):
         if self.w is None:
             raise RuntimeError('FusedConv.to(device) must be called before use')
+        wino = (self.u is not None and FusedConv.winograd and not naive and res_mode in (0, 1) and x.dtype == torch.float32
+                and x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] >= FusedConv.winograd_min_pos
+                and ops.conv_winograd_supported(tuple(x.shape), self.cout, self.kernel, self.stride, self.padding))
         if FusedConv.count_flops:
-            pos = x.shape[0] * ((x.shape[1] + 2 * self.padding[0] - self.kernel[0]) // self.stride[0] + 1) * \
-                ((x.shape[2] + 2 * self.padding[1] - self.kernel[1]) // self.stride[1] + 1) * \
-                ((x.shape[3] + 2 * self.padding[2] - self.kernel[2]) // self.stride[2] + 1)
-            FusedConv.flops += 2.0 * pos * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
+            od, oh, ow = ((x.shape[1 + a] + 2 * self.padding[a] - self.kernel[a]) // self.stride[a] + 1 for a in range(3))
+            direct = 2.0 * x.shape[0] * od * oh * ow * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
+            FusedConv.flops += direct
+            FusedConv.exec_flops += (2.0 * 16 * x.shape[0] * ((od + 1) // 2) * ((oh + 1) // 2) * ow * self.cout * self.cin *
+                                     self.kernel[2]) if wino else direct
+        if wino:
+            if FusedConv.trace is not None:
+                ops.winograd_trace = []
+            y = ops.conv_winograd_fwd(x, self.u, self.scale, self.shift, self.kernel[2], self.stride[2], self.padding,
+                                      self.relu if relu is None else relu, res, wgt_layout=self.layout,
+                                      res_after_act=res_after_act, post_scale=post_scale)
+            if FusedConv.trace is not None:
+                tiles = y.shape[0] * ((y.shape[1] + 1) // 2) * ((y.shape[2] + 1) // 2)
+                v_bytes = 4.0 * 16 * tiles * x.shape[3] * self.cin       # transformed input: 16 planes [tiles, Z, Cin]
+                m_bytes = 4.0 * 16 * tiles * y.shape[3] * self.cout      # 16 partial outputs [tiles, Zo, Cout]
+                by = {'input': 4.0 * x.numel() + v_bytes, 'gemm': v_bytes + m_bytes,
+                      'output': m_bytes + 4.0 * y.numel() * (2 if res is not None else 1)}
+                FusedConv.trace += [('wino_' + n, e0, e1, fl, by[n]) for n, e0, e1, fl in ops.winograd_trace]
+                ops.winograd_trace = None
+            return y
+        if FusedConv.trace is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
+            e1.record()
+            FusedConv.trace.append(('direct', e0, e1, 2.0 * y.numel() * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
+                                    if self.out_mode == 0 else 2.0 * x.numel() * self.cout, 0.0))
+            return y
+        return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
+
+    def _direct(self, x, res, res_mode, relu, naive, res_after_act, post_scale):
         return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,
                             self.relu if relu is None else relu, res, res_mode, naive=naive, wgt_layout=self.layout,
                             out_mode=self.out_mode, res_after_act=res_after_act, post_scale=post_scale,

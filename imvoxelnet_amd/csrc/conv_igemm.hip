@@ -46,6 +46,10 @@ struct ConvParams {
   int q_total, q_begin, q_count, bm;
   int in_bf16;        // in / wgt are bf16 (LDS-DMA kernel only); accumulation is always fp32
   int out_bf16;       // out / res are bf16 (converted round-to-nearest-even in the epilogue)
+  // grouped launch (LDS-DMA kernel, grid.z = group; the Winograd-domain GEMMs): group g reads in + g*g_in, wgt + g*g_w
+  // and writes out + g*g_out (element strides; all 0 for an ordinary convolution)
+  long long g_in, g_w, g_out;
+  int groups;
 };
 
 __device__ __forceinline__ float conv_ld_res(const ConvParams &p, size_t i) {
@@ -98,7 +102,7 @@ __device__ __noinline__ size_t up2_row_base(int m, int D, int H, int W, int Cr) 
 
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
-                                              int lane) {
+                                              int lane, size_t obase = 0) {
   const int col_l = lane & 31, hh = lane >> 5;
   float sc[TN], sf[TN];
   int nn[TN];
@@ -138,7 +142,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (nn[j] >= p.Cout) continue;
-        conv_st_out(p, (size_t)m * p.Cout + nn[j], conv_finish(p, acc[i][j][r], sc[j], sf[j], rbase + nn[j]));
+        conv_st_out(p, obase + (size_t)m * p.Cout + nn[j], conv_finish(p, acc[i][j][r], sc[j], sf[j], rbase + nn[j]));
       }
     }
   }
@@ -372,8 +376,11 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   const int m0 = mt * BM;
   const int n0 = nt * BN;
 
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, w_bytes, 0x00020000);
+  const size_t gz = blockIdx.z;   // group of a grouped launch (strides are 0 otherwise)
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.in + gz * (size_t)p.g_in * EL), 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.wgt + gz * (size_t)p.g_w * EL), 0, w_bytes, 0x00020000);
 
   const int lr = tid / NCH;
   const int cc = (tid & (NCH - 1)) ^ ((lr >> SW_SH) & SW_MSK);   // the k-chunk this lane fetches (its LDS slot is tid % NCH)
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
       }
     return;
   }
-  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane);
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane, gz * (size_t)p.g_out);
 }
 
 // Epilogue + store of one output element (row m, column n) from its finished accumulator: shared by the validation
@@ -726,6 +733,7 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   p->out_mode = d->out_mode; p->Cr = d->out_mode == 1 ? d->Cout / 8 : d->Cout; p->res_after_act = d->res_after_act;
   p->post_scale = d->post_scale == 0.f ? 1.0f : d->post_scale;
   p->ksplit = 1; p->partial = nullptr; p->q_total = 0; p->q_begin = 0; p->q_count = 0; p->bm = 0;
+  p->groups = 1; p->g_in = p->g_w = p->g_out = 0;
   return IVX_OK;
 }
 
@@ -761,7 +769,7 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
     p.q_count = p.q_total;
   }
   const long long g1 = 8LL * p.q_count * Nt;
-  const dim3 grid((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1);
+  const dim3 grid((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1, p.groups > 1 ? p.groups : 1);
   // every slab lies inside one filter tap -> uniform K-loop state
   const bool uni = p.kmode == 1 || p.Cin % BK == 0;
   auto kern = uni ? conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1> : conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 0>;
@@ -1044,6 +1052,36 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const void *in, const void *
   if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_fwd");
   return IVX_OK;
+}
+
+// Internal (winograd.hip): `groups` independent convolutions of the same shape in ONE launch of the LDS-DMA kernel
+// (grid.z = group), identity epilogue.  `d` describes one group; operands of group g start g*stride elements further.
+int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w,
+                            float *out, long long g_out, hipStream_t st) {
+  ConvParams p;
+  int rc = fill_params(d, in, wgt, nullptr, nullptr, nullptr, out, &p);
+  if (rc != IVX_OK) return rc;
+  IVX_REQUIRE(groups >= 1 && groups <= 65535, "ivx_conv_grouped_launch: bad group count");
+  IVX_REQUIRE(d->in_dtype == IVX_F32 && d->out_dtype == IVX_F32 && d->out_mode == 0 && d->res_mode == 0,
+              "ivx_conv_grouped_launch: fp32, plain output only");
+  if (!dma_applicable(p)) {
+    ivx_set_error("ivx_conv_grouped_launch: one group must stay below 2 GiB");
+    return IVX_ERR_UNSUPPORTED;
+  }
+  p.groups = groups; p.g_in = g_in; p.g_w = g_w; p.g_out = g_out;
+  ConvPlan pl = {g_tile_override, 1, 1, 0, 0, 0, 0};
+  if (pl.cfg == 0) {
+    const long long nblk = (long long)groups * ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    if (p.Cout <= 32) pl.cfg = 44;
+    else if (nblk >= 2500) pl.cfg = p.Cout > 64 ? 54 : (p.K <= 640 ? 49 : 56);
+    else pl.cfg = p.K <= 640 ? 47 : 46;
+  }
+  TileInfo t;
+  if (!tile_info(pl.cfg, &t) || pl.cfg >= 61) {
+    ivx_set_error("ivx_conv_grouped_launch: tile %d is not an fp32 LDS-DMA tile", pl.cfg);
+    return IVX_ERR_INVALID_ARG;
+  }
+  return launch_one(p, pl, st);
 }
 
 extern "C" int64_t ivx_conv_workspace_bytes(const ivx_conv_desc *d) {

@@ -126,6 +126,95 @@ def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1),
     return out
 
 
+def _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, res_mode=0, res_after_act=False, post_scale=1.0):
+    return ConvDesc(B, D, H, W, Cin, Cout, 3, 3, kw, 1, 1, stride_w, padding[0], padding[1], padding[2], int(bool(relu)),
+                    int(res_mode), 0, 0, int(wgt_layout), 0, int(bool(res_after_act)), float(post_scale), 0, 0)
+
+
+def conv_winograd_supported(x_shape, Cout, kernel, stride, padding):
+    """True when ivx_conv_winograd_fwd can run this fp32 convolution (3x3xKW, stride 1 on the first two axes, planes < 2 GiB)."""
+    if kernel[0] != 3 or kernel[1] != 3 or stride[0] != 1 or stride[1] != 1 or x_shape[4] % 4 or Cout % 4:
+        return False
+    B, D, H, W, Cin = x_shape
+    d = _wino_desc(B, D, H, W, Cin, Cout, kernel[2], stride[2], padding, False, 0)
+    return bool(_lib.lib().ivx_conv_winograd_supported(C.byref(d)))
+
+
+def conv_winograd_weights(wgt, wgt_layout):
+    """wgt [Cout,3,3,KW,Cin] fp32 (layout 0, on the device) -> transformed filters u [16, Cout, KW*Cin] whose K order is
+    `wgt_layout` (0: tap-major, 1: 32-channel chunks)."""
+    _chk(wgt, 'wgt')
+    Cout, kd, kh, kw, Cin = wgt.shape
+    if kd != 3 or kh != 3:
+        raise ValueError('Winograd F(2x2,3x3) needs a 3x3 kernel on the first two axes')
+    d = _wino_desc(1, 4, 4, max(kw, 1), Cin, Cout, kw, 1, (1, 1, kw // 2), False, wgt_layout)
+    L = _lib.lib()
+    n = L.ivx_conv_winograd_weight_elems(C.byref(d))
+    if n < 0:
+        check(-1, 'ivx_conv_winograd_weight_elems')
+    u = torch.empty((16, Cout, kw * Cin), device=wgt.device, dtype=torch.float32)
+    assert u.numel() == n
+    check(L.ivx_conv_winograd_weights(C.byref(d), _ptr(wgt), _ptr(u), _stream()), 'ivx_conv_winograd_weights')
+    return u
+
+
+# optional stage timing of the Winograd path (bench.py): list of (stage, start_event, end_event, executed_flops)
+winograd_trace = None
+
+
+def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1, 1, 1), relu=False, res=None, out=None,
+                      wgt_layout=0, res_after_act=False, post_scale=1.0):
+    """Same result as conv_fwd for a 3x3xkw kernel with stride (1,1,stride_w), computed in the F(2x2,3x3) minimal-filtering
+    form (fp32).  x [B,D,H,W,Cin]; u from conv_winograd_weights."""
+    _chk(x, 'x')
+    _chk(u, 'u')
+    B, D, H, W, Cin = x.shape
+    Cout = u.shape[1]
+    if tuple(u.shape) != (16, Cout, kw * Cin):
+        raise ValueError(f'transformed filters {tuple(u.shape)} do not match kw {kw} / Cin {Cin}')
+    d = _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, 1 if res is not None else 0, res_after_act,
+                   post_scale)
+    do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
+    L = _lib.lib()
+    check(L.ivx_conv_out_dims(C.byref(d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')
+    oshape = (B, do.value, ho.value, wo.value, Cout)
+    if res is not None:
+        _chk(res, 'res')
+        if tuple(res.shape) != oshape:
+            raise ValueError(f'residual shape {tuple(res.shape)} != output shape')
+    for t, n in ((scale, 'scale'), (shift, 'shift')):
+        if t is not None:
+            _chk(t, n)
+            if t.numel() != Cout:
+                raise ValueError(f'{n} must have {Cout} elements')
+    if out is None:
+        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, 'out')
+    wsb = L.ivx_conv_winograd_workspace_bytes(C.byref(d))
+    if wsb < 0:
+        check(-1, 'ivx_conv_winograd_workspace_bytes')
+    ws = torch.empty((wsb,), device=x.device, dtype=torch.uint8)
+    if winograd_trace is None:
+        check(L.ivx_conv_winograd_fwd(C.byref(d), _ptr(x), _ptr(u), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _ptr(ws), wsb,
+                                      _stream()), 'ivx_conv_winograd_fwd')
+        return out
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    check(L.ivx_conv_winograd_input(C.byref(d), _ptr(x), _ptr(ws), wsb, _stream()), 'ivx_conv_winograd_input')
+    ev[1].record()
+    check(L.ivx_conv_winograd_gemm(C.byref(d), _ptr(u), _ptr(ws), wsb, _stream()), 'ivx_conv_winograd_gemm')
+    ev[2].record()
+    check(L.ivx_conv_winograd_output(C.byref(d), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _ptr(ws), wsb, _stream()),
+          'ivx_conv_winograd_output')
+    ev[3].record()
+    tiles = B * ((oshape[1] + 1) // 2) * ((oshape[2] + 1) // 2)
+    winograd_trace.append(('input', ev[0], ev[1], 0.0))
+    winograd_trace.append(('gemm', ev[1], ev[2], 2.0 * 16 * tiles * oshape[3] * Cout * kw * Cin))
+    winograd_trace.append(('output', ev[2], ev[3], 0.0))
+    return out
+
+
 def maxpool2d(x, k=3, s=2, p=1):
     if x.dtype not in _DT:
         raise TypeError(f'x must be float32 or bfloat16, got {x.dtype}')

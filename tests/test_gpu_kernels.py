@@ -792,6 +792,88 @@ def test_unprojection_randomized_cameras_bit_exact(ia):
             assert torch.equal(valid2, valid) and torch.equal(vol2, vol), it
 
 
+@pytest.mark.parametrize('case', [
+    # B, (X,Y,Z), Cin, Cout, kw, stride_z, pad, residual, relu, layout
+    (2, (9, 14, 5), 8, 12, 3, 1, (1, 1, 1), True, True, 0),       # odd X: a half-filled last tile row
+    (1, (12, 10, 6), 32, 64, 3, 2, (1, 1, 1), False, True, 1),    # z stride 2 (the neck's down-convs), chunk-major K
+    (2, (10, 12, 3), 64, 32, 3, 1, (0, 0, 0), False, False, 1),   # padding 0 on every axis (KITTI neck's last conv): z 3 -> 1
+    (1, (16, 16, 4), 36, 20, 1, 1, (1, 1, 0), True, False, 0),    # z kernel 1, Cin not a chunk multiple
+    (3, (31, 17, 2), 128, 128, 3, 1, (1, 1, 1), True, True, 1),   # odd X and Y, 128 channels
+])
+def test_conv_winograd_matches_direct(ia, case):
+    """ivx_conv_winograd_fwd (F(2x2,3x3) over the first two axes, grouped implicit-GEMM launch) against the one-thread-per-
+    output validation kernel and torch conv3d on the same inputs: same contract, fp32 rounding differences only."""
+    from imvoxelnet_amd import ops
+    B, (X, Y, Z), ci, co, kw, sz, pad, use_res, relu, layout = case
+    g = torch.Generator().manual_seed(X * 131 + ci)
+    x = torch.randn(B, X, Y, Z, ci, generator=g).cuda()
+    w = (torch.randn(co, 3, 3, kw, ci, generator=g) * (2.0 / (9 * kw * ci)) ** 0.5).cuda()
+    scale = (torch.rand(co, generator=g) + 0.5).cuda()
+    shift = (torch.randn(co, generator=g) * 0.1).cuda()
+    ref = ops.conv_fwd(x, w, scale, shift, (3, 3, kw), (1, 1, sz), pad, relu, naive=True)
+    res = torch.randn(ref.shape, generator=g).cuda() if use_res else None
+    ref = ops.conv_fwd(x, w, scale, shift, (3, 3, kw), (1, 1, sz), pad, relu, res=res, naive=True)
+    assert ops.conv_winograd_supported(tuple(x.shape), co, (3, 3, kw), (1, 1, sz), pad)
+    u = ops.conv_winograd_weights(w, layout)
+    got = ops.conv_winograd_fwd(x, u, scale, shift, kw, sz, pad, relu, res, wgt_layout=layout)
+    assert got.shape == ref.shape
+    assert_close('winograd vs naive', got, ref, 1e-4, 1e-4 * float(ref.abs().max()))
+    tref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).cpu().double(), w.permute(0, 4, 1, 2, 3).cpu().double(),
+                                      stride=(1, 1, sz), padding=pad).permute(0, 2, 3, 4, 1)
+    tref = tref * scale.cpu().double() + shift.cpu().double()
+    if use_res:
+        tref = tref + res.cpu().double()
+    if relu:
+        tref = tref.clamp_min(0)
+    assert_close('winograd vs torch fp64', got, tref.float(), 1e-4, 1e-4 * float(tref.abs().max()))
+    # staged entry points (bench timing hooks) give the same bits as the one-shot call
+    ops.winograd_trace = []
+    try:
+        got2 = ops.conv_winograd_fwd(x, u, scale, shift, kw, sz, pad, relu, res, wgt_layout=layout)
+        assert [t[0] for t in ops.winograd_trace] == ['input', 'gemm', 'output']
+    finally:
+        ops.winograd_trace = None
+    assert torch.equal(got, got2)
+
+
+def test_conv_winograd_fused_conv_switch(ia):
+    """FusedConv picks the Winograd form for a wide 128-channel 3x3x3 layer and gives the direct kernel's result."""
+    from imvoxelnet_amd.conv import FusedConv
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(128, 128, 3, 3, 3, generator=g) * 0.02
+    bn = (torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1, torch.randn(128, generator=g) * 0.1,
+          torch.rand(128, generator=g) + 0.5)
+    x = torch.randn(2, 108, 124, 6, 128, generator=g).cuda()
+    res = torch.randn(2, 108, 124, 6, 128, generator=g).cuda()
+    f = FusedConv(w, bn=bn, padding=1, relu=True).to(x.device)
+    assert f.u is not None
+    FusedConv.flops, FusedConv.exec_flops, FusedConv.count_flops = 0.0, 0.0, True
+    try:
+        y = f(x, res=res)
+    finally:
+        FusedConv.count_flops = False
+    assert abs(FusedConv.exec_flops / FusedConv.flops - 16 / 36) < 1e-6          # it did take the minimal-filtering path
+    old = FusedConv.winograd
+    FusedConv.winograd = False
+    try:
+        yd = f(x, res=res)
+    finally:
+        FusedConv.winograd = old
+    assert_close('FusedConv winograd vs direct', y, yd, 1e-4, 2e-5 * float(yd.abs().max()))
+
+
+def test_conv_winograd_errors(ia):
+    from imvoxelnet_amd import ops
+    x = torch.zeros(1, 8, 8, 4, 8).cuda()
+    assert not ops.conv_winograd_supported(tuple(x.shape), 8, (3, 3, 3), (2, 2, 1), (1, 1, 1))      # strided on a transformed axis
+    assert not ops.conv_winograd_supported(tuple(x.shape), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    u = torch.zeros(16, 8, 3 * 8).cuda()
+    with pytest.raises(ValueError):
+        ops.conv_winograd_fwd(x, u[:, :, :8].contiguous(), kw=3)                                     # filters of another shape
+    with pytest.raises(ValueError):
+        ops.conv_winograd_fwd(x, u, kw=3, res=torch.zeros(1, 8, 8, 3, 8).cuda())                      # residual shape
+
+
 def test_conv_fwd_without_workspace_entry_point(ia):
     """ivx_conv_fwd (the entry point without a caller workspace: no split-K / tail plans) gives the validation kernel's
     result on a small-output long-K layer, where ivx_conv_fwd_ws would split K."""
