@@ -59,16 +59,16 @@ def lib():
     L.ivx_conv_workspace_bytes.restype = i64
     L.ivx_conv_fwd_ws.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, i64, vp]
     D = C.POINTER(ConvDesc)
-    L.ivx_conv_winograd_supported.argtypes = [D]
-    L.ivx_conv_winograd_weight_elems.argtypes = [D]
+    L.ivx_conv_winograd_supported.argtypes = [D, i32]
+    L.ivx_conv_winograd_weight_elems.argtypes = [D, i32]
     L.ivx_conv_winograd_weight_elems.restype = i64
-    L.ivx_conv_winograd_weights.argtypes = [D, vp, vp, vp]
-    L.ivx_conv_winograd_workspace_bytes.argtypes = [D]
+    L.ivx_conv_winograd_weights.argtypes = [D, i32, vp, vp, vp]
+    L.ivx_conv_winograd_workspace_bytes.argtypes = [D, i32]
     L.ivx_conv_winograd_workspace_bytes.restype = i64
-    L.ivx_conv_winograd_input.argtypes = [D, vp, vp, i64, vp]
-    L.ivx_conv_winograd_gemm.argtypes = [D, vp, vp, i64, vp]
-    L.ivx_conv_winograd_output.argtypes = [D, vp, vp, vp, vp, vp, i64, vp]
-    L.ivx_conv_winograd_fwd.argtypes = [D, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.ivx_conv_winograd_input.argtypes = [D, i32, vp, vp, i64, vp]
+    L.ivx_conv_winograd_gemm.argtypes = [D, i32, vp, vp, i64, vp]
+    L.ivx_conv_winograd_output.argtypes = [D, i32, vp, vp, vp, vp, vp, i64, vp]
+    L.ivx_conv_winograd_fwd.argtypes = [D, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.ivx_maxpool2d_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ivx_global_avgpool_fwd.argtypes = [vp, i32, i64, i32, vp, vp]
     L.ivx_upsample_trilinear2x_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]

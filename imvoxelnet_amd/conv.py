@@ -57,12 +57,14 @@ class FusedConv:
     flops = 0.0
     exec_flops = 0.0
     # fp32 3x3xk layers with stride 1 on the first two axes, >= winograd_min_ch input or output channels and
-    # >= winograd_min_pos input positions run as F(2x2,3x3) (ivx_conv_winograd_fwd).  Measured on the KITTI neck (batch 4,
-    # tools/conv_bench.py --winograd): 256->256 16.2 -> 9.1 ms, 128->128 8.2 -> 5.7, 128->256 8.2 -> 5.6, 64->128 4.5 -> 3.9;
-    # the 64->64 layers tie (the two transforms move 8x the activation bytes) and the small indoor volumes stay direct
+    # >= winograd_min_pos input positions run as F(m x m, 3x3) (ivx_conv_winograd_fwd), m = winograd_tile.  Measured on the
+    # KITTI neck (batch 4, tools/conv_bench.py --winograd), direct -> m = 2 -> m = 4 in ms: 256->256 16.1 -> 9.1 -> 5.3,
+    # 128->128 8.2 -> 5.7 -> 3.3, 128->256 (z stride 2) 8.2 -> 5.6 -> 3.3, 64->128 4.6 -> 3.9 -> 2.3, 64->64 4.8 -> 4.3 -> 2.6.
+    # The small indoor volumes stay direct (too few tiles per transformed plane to fill the chip).
     winograd = os.environ.get('IVX_WINOGRAD', '1') != '0'
-    winograd_min_ch = 128
-    winograd_min_pos = 100000
+    winograd_tile = int(os.environ.get('IVX_WINOGRAD_TILE', '4'))     # m of F(m x m, 3x3): 2 or 4
+    winograd_min_ch = 64
+    winograd_min_pos = int(os.environ.get('IVX_WINOGRAD_MIN_POS', '100000'))
     # optional per-call timing (bench.py): when a list, every call appends
     # (kind, start_event, end_event, executed_flops, bytes) with kind 'direct' | 'wino_input' | 'wino_gemm' | 'wino_output';
     # the events bracket exactly the launches of that stage on the current stream
@@ -122,7 +124,7 @@ class FusedConv:
     def to(self, device):
         self.w = self._w_host.to(device)
         if self._w0_host is not None and FusedConv.winograd:
-            self.u = ops.conv_winograd_weights(self._w0_host.to(device), self.layout)
+            self.u = ops.conv_winograd_weights(self._w0_host.to(device), self.layout, FusedConv.winograd_tile)
         if not self._identity_epilogue:
             self.scale = self._scale_host.to(device)
             self.shift = self._shift_host.to(device)
@@ -133,13 +135,14 @@ class FusedConv:
             raise RuntimeError('FusedConv.to(device) must be called before use')
         wino = (self.u is not None and FusedConv.winograd and not naive and res_mode in (0, 1) and x.dtype == torch.float32
                 and x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] >= FusedConv.winograd_min_pos
-                and ops.conv_winograd_supported(tuple(x.shape), self.cout, self.kernel, self.stride, self.padding))
+                and ops.conv_winograd_supported(tuple(x.shape), self.cout, self.kernel, self.stride, self.padding, self._tile()))
         if FusedConv.count_flops:
             od, oh, ow = ((x.shape[1 + a] + 2 * self.padding[a] - self.kernel[a]) // self.stride[a] + 1 for a in range(3))
             direct = 2.0 * x.shape[0] * od * oh * ow * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
             FusedConv.flops += direct
-            FusedConv.exec_flops += (2.0 * 16 * x.shape[0] * ((od + 1) // 2) * ((oh + 1) // 2) * ow * self.cout * self.cin *
-                                     self.kernel[2]) if wino else direct
+            m = self._tile()
+            FusedConv.exec_flops += (2.0 * (m + 2) ** 2 * x.shape[0] * ((od + m - 1) // m) * ((oh + m - 1) // m) * ow * self.cout *
+                                     self.cin * self.kernel[2]) if wino else direct
         if wino:
             if FusedConv.trace is not None:
                 ops.winograd_trace = []
@@ -147,9 +150,10 @@ class FusedConv:
                                       self.relu if relu is None else relu, res, wgt_layout=self.layout,
                                       res_after_act=res_after_act, post_scale=post_scale)
             if FusedConv.trace is not None:
-                tiles = y.shape[0] * ((y.shape[1] + 1) // 2) * ((y.shape[2] + 1) // 2)
-                v_bytes = 4.0 * 16 * tiles * x.shape[3] * self.cin       # transformed input: 16 planes [tiles, Z, Cin]
-                m_bytes = 4.0 * 16 * tiles * y.shape[3] * self.cout      # 16 partial outputs [tiles, Zo, Cout]
+                m = self._tile()
+                tiles = y.shape[0] * ((y.shape[1] + m - 1) // m) * ((y.shape[2] + m - 1) // m)
+                v_bytes = 4.0 * (m + 2) ** 2 * tiles * x.shape[3] * self.cin       # transformed input: (m+2)^2 planes [tiles, Z, Cin]
+                m_bytes = 4.0 * (m + 2) ** 2 * tiles * y.shape[3] * self.cout      # (m+2)^2 partial outputs [tiles, Zo, Cout]
                 by = {'input': 4.0 * x.numel() + v_bytes, 'gemm': v_bytes + m_bytes,
                       'output': m_bytes + 4.0 * y.numel() * (2 if res is not None else 1)}
                 FusedConv.trace += [('wino_' + n, e0, e1, fl, by[n]) for n, e0, e1, fl in ops.winograd_trace]
@@ -164,6 +168,9 @@ class FusedConv:
                                     if self.out_mode == 0 else 2.0 * x.numel() * self.cout, 0.0))
             return y
         return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
+
+    def _tile(self):
+        return 2 if self.u is None or self.u.shape[0] == 16 else 4
 
     def _direct(self, x, res, res_mode, relu, naive, res_after_act, post_scale):
         return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,

@@ -1,18 +1,21 @@
-// Winograd F(2x2, 3x3) over the first two spatial axes of a channels-last 3-D convolution (gfx950).
+// Winograd minimal filtering F(m x m, 3x3), m = 2 or 4, over the first two spatial axes of a channels-last 3-D convolution
+// (gfx950).
 //
 // The 3-D necks (mmdet3d/models/necks/imvoxelnet.py:99-113,181-230) are 3x3x3 convolutions on volumes that are wide in
 // (x, y) and shallow in z (12 / 6 / 3 slices), and their 128- and 256-channel layers are bound by the fp32 MFMA rate.
-// The minimal-filtering form over (x, y) needs 16 multiplications per 2x2 output tile and z-tap instead of 36:
+// With n = m + 2, the minimal-filtering form over (x, y) needs n*n multiplications per m x m output tile and z-tap
+// instead of 9*m*m (16 vs 36 for m = 2, 36 vs 144 for m = 4):
 //
-//   V[xi][b,tx,ty,z,:]  = (Bt d B)[i][j]          d = 4x4 input patch at x = 2tx - pd + i, y = 2ty - ph + j   (xi = 4i + j)
+//   V[xi][b,tx,ty,z,:]  = (Bt d B)[i][j]          d = n x n input patch at x = m*tx - pd + i, y = m*ty - ph + j   (xi = n*i + j)
 //   U[xi][co,kz,:]      = (G g Gt)[i][j]          g = the 3x3 (kd,kh) slice of the filter for z-tap kz
-//   M[xi]               = conv_z(V[xi], U[xi])    16 independent 1x1xKW convolutions (stride / padding of the z axis)
-//   out[b,2tx+a,2ty+e]  = epilogue((At m A)[a][e])
+//   M[xi]               = conv_z(V[xi], U[xi])    n*n independent 1x1xKW convolutions (stride / padding of the z axis)
+//   out[b,m*tx+a,m*ty+e] = epilogue((At M A)[a][e])
 //
-// The 16 convolutions of M run as ONE grouped launch of the LDS-DMA implicit-GEMM kernel (conv_igemm.hip, grid.z = xi);
-// the two transforms are streaming kernels (16-byte accesses, one thread per four channels).  The z axis stays a direct
+// The n*n convolutions of M run as ONE grouped launch of the LDS-DMA implicit-GEMM kernel (conv_igemm.hip, grid.z = xi);
+// the two transforms are streaming kernels (one thread per 4 (m = 2) or 2 (m = 4) channels).  The z axis stays a direct
 // convolution because it is too shallow to tile.  Arithmetic is fp32 throughout; the result differs from the direct form
-// by fp32 rounding only (different summation order).
+// by fp32 rounding only: measured max deviation / max|out| on a 256-channel layer 6e-7 (m = 2) and 1e-5 (m = 4, whose
+// transforms carry the interpolation points +-2) against 2e-6 for the direct fp32 sum (tests/test_gpu_kernels.py).
 #include "ivx_common.h"
 
 int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w,
@@ -26,23 +29,89 @@ struct WinoP {
   float *V, *Mw;
   int B, X, Y, Z, C;        // input volume
   int Xo, Yo, Zo, Co;       // output volume
-  int TX, TY;               // 2x2 output tiles
+  int TX, TY;               // m x m output tiles
   int px, py;               // padding of the transformed axes
   int relu, res_mode, res_after_act;
   float post_scale;
 };
 
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+// channel vectors: 4 floats per thread for m = 2, 2 for m = 4 (36 live values per thread instead of 16)
+template <int W> struct VecT;
+template <> struct VecT<4> { typedef float4 T; };
+template <> struct VecT<2> { typedef float2 T; };
+__device__ __forceinline__ float4 vzero(float4 *) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float2 vzero(float2 *) { return make_float2(0.f, 0.f); }
+__device__ __forceinline__ float4 vone(float4 *) { return make_float4(1.f, 1.f, 1.f, 1.f); }
+__device__ __forceinline__ float2 vone(float2 *) { return make_float2(1.f, 1.f); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 operator*(float s, float2 a) { return make_float2(s * a.x, s * a.y); }
 
-// V = Bt d B, Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1].  One thread: four channels of one (b, tx, ty, z).
+// 1-D transforms.  m = 2 (points 0, +-1, inf):  Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   At = [1 1 1 0; 0 1 -1 -1]
+//                                               G  = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+// m = 4 (points 0, +-1, +-2, inf):  Bt = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//                                   At = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+//                                   G  = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+template <int MT, typename V> struct Wino1D;
+template <typename V> struct Wino1D<2, V> {
+  static __device__ __forceinline__ void in(const V (&d)[4], V (&t)[4]) {
+    t[0] = d[0] - d[2];
+    t[1] = d[1] + d[2];
+    t[2] = d[2] - d[1];
+    t[3] = d[1] - d[3];
+  }
+  static __device__ __forceinline__ void out(const V (&m)[4], V (&y)[2]) {
+    y[0] = (m[0] + m[1]) + m[2];
+    y[1] = (m[1] - m[2]) - m[3];
+  }
+  static __device__ __forceinline__ void wgt(const float (&g)[3], float (&u)[4]) {
+    u[0] = g[0];
+    u[1] = 0.5f * (g[0] + g[1] + g[2]);
+    u[2] = 0.5f * (g[0] - g[1] + g[2]);
+    u[3] = g[2];
+  }
+};
+template <typename V> struct Wino1D<4, V> {
+  static __device__ __forceinline__ void in(const V (&d)[6], V (&t)[6]) {
+    const V a = d[4] - 4.0f * d[2], b = d[3] - 4.0f * d[1];
+    const V c = d[4] - d[2], e = 2.0f * (d[3] - d[1]);
+    t[0] = (4.0f * d[0] - 5.0f * d[2]) + d[4];
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = c + e;
+    t[4] = c - e;
+    t[5] = (4.0f * d[1] - 5.0f * d[3]) + d[5];
+  }
+  static __device__ __forceinline__ void out(const V (&m)[6], V (&y)[4]) {
+    const V s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
+    y[0] = (m[0] + s1) + s2;
+    y[1] = d1 + 2.0f * d2;
+    y[2] = s1 + 4.0f * s2;
+    y[3] = (d1 + 8.0f * d2) + m[5];
+  }
+  static __device__ __forceinline__ void wgt(const float (&g)[3], float (&u)[6]) {
+    u[0] = 0.25f * g[0];
+    u[1] = (-1.0f / 6.0f) * (g[0] + g[1] + g[2]);
+    u[2] = (-1.0f / 6.0f) * (g[0] - g[1] + g[2]);
+    u[3] = (1.0f / 24.0f) * g[0] + (1.0f / 12.0f) * g[1] + (1.0f / 6.0f) * g[2];
+    u[4] = (1.0f / 24.0f) * g[0] - (1.0f / 12.0f) * g[1] + (1.0f / 6.0f) * g[2];
+    u[5] = g[2];
+  }
+};
+
+// V = Bt d B.  One thread: VW channels of one (b, tx, ty, z); xi plane stride = all threads.
+template <int MT, int VW>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
-  const int C4 = p.C >> 2;
-  const long long per_tile = (long long)p.Z * C4;                   // contiguous float4s of one (x, y) column
-  const long long total = (long long)p.B * p.TX * p.TY * per_tile;
-  const long long plane = total;                                     // float4s per xi plane
-  const float4 *in = reinterpret_cast<const float4 *>(p.in);
-  float4 *V = reinterpret_cast<float4 *>(p.V);
+  typedef typename VecT<VW>::T V;
+  constexpr int N = MT + 2;
+  const int CV = p.C / VW;
+  const long long per_tile = (long long)p.Z * CV;                    // contiguous vectors of one (x, y) column
+  const long long total = (long long)p.B * p.TX * p.TY * per_tile;   // = vectors per xi plane
+  const V *in = reinterpret_cast<const V *>(p.in);
+  V *Vw = reinterpret_cast<V *>(p.V);
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const long long zc = t % per_tile;
     long long q = t / per_tile;
@@ -50,36 +119,29 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
     q /= p.TY;
     const int tx = (int)(q % p.TX);
     const int b = (int)(q / p.TX);
-    const int x0 = 2 * tx - p.px, y0 = 2 * ty - p.py;
-    float4 d[4][4];
+    const int x0 = MT * tx - p.px, y0 = MT * ty - p.py;
+    V w[N][N];   // w[i][j]: column transform (Bt d) of input column j
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int x = x0 + i;
+    for (int j = 0; j < N; ++j) {
+      const int y = y0 + j;
+      V d[N];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int y = y0 + j;
+      for (int i = 0; i < N; ++i) {
+        const int x = x0 + i;
         const bool ok = (unsigned)x < (unsigned)p.X && (unsigned)y < (unsigned)p.Y;
-        d[i][j] = ok ? in[(((long long)b * p.X + x) * p.Y + y) * per_tile + zc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        d[i] = ok ? in[(((long long)b * p.X + x) * p.Y + y) * per_tile + zc] : vzero((V *)nullptr);
       }
-    }
-    float4 w[4][4];
+      V c[N];
+      Wino1D<MT, V>::in(d, c);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {   // rows: Bt d
-      w[0][j] = f4sub(d[0][j], d[2][j]);
-      w[1][j] = f4add(d[1][j], d[2][j]);
-      w[2][j] = f4sub(d[2][j], d[1][j]);
-      w[3][j] = f4sub(d[1][j], d[3][j]);
+      for (int i = 0; i < N; ++i) w[i][j] = c[i];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {   // columns: (Bt d) B
-      const float4 v0 = f4sub(w[i][0], w[i][2]);
-      const float4 v1 = f4add(w[i][1], w[i][2]);
-      const float4 v2 = f4sub(w[i][2], w[i][1]);
-      const float4 v3 = f4sub(w[i][1], w[i][3]);
-      V[(long long)(4 * i + 0) * plane + t] = v0;
-      V[(long long)(4 * i + 1) * plane + t] = v1;
-      V[(long long)(4 * i + 2) * plane + t] = v2;
-      V[(long long)(4 * i + 3) * plane + t] = v3;
+    for (int i = 0; i < N; ++i) {   // rows: (Bt d) B
+      V v[N];
+      Wino1D<MT, V>::in(w[i], v);
+#pragma unroll
+      for (int j = 0; j < N; ++j) Vw[(long long)(N * i + j) * total + t] = v[j];
     }
   }
 }
@@ -91,105 +153,106 @@ __device__ __forceinline__ float wino_finish(const WinoP &p, float acc, float sc
   if (p.res_mode && p.res_after_act) v += r;
   return v * p.post_scale;
 }
+__device__ __forceinline__ float4 wino_finish_v(const WinoP &p, float4 a, float4 sc, float4 sf, float4 r) {
+  return make_float4(wino_finish(p, a.x, sc.x, sf.x, r.x), wino_finish(p, a.y, sc.y, sf.y, r.y), wino_finish(p, a.z, sc.z, sf.z, r.z),
+                     wino_finish(p, a.w, sc.w, sf.w, r.w));
+}
+__device__ __forceinline__ float2 wino_finish_v(const WinoP &p, float2 a, float2 sc, float2 sf, float2 r) {
+  return make_float2(wino_finish(p, a.x, sc.x, sf.x, r.x), wino_finish(p, a.y, sc.y, sf.y, r.y));
+}
 
-// out = epilogue(At m A), At = [1 1 1 0; 0 1 -1 -1].  One thread: four channels of one (b, tx, ty, zo) -> 2x2 outputs.
+// out = epilogue(At M A).  One thread: VW channels of one (b, tx, ty, zo) -> m x m outputs.
+template <int MT, int VW>
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
-  const int C4 = p.Co >> 2;
-  const long long per_tile = (long long)p.Zo * C4;
+  typedef typename VecT<VW>::T V;
+  constexpr int N = MT + 2;
+  const int CV = p.Co / VW;
+  const long long per_tile = (long long)p.Zo * CV;
   const long long total = (long long)p.B * p.TX * p.TY * per_tile;
-  const long long plane = total;
-  const float4 *Mw = reinterpret_cast<const float4 *>(p.Mw);
-  const float4 *res = reinterpret_cast<const float4 *>(p.res);
-  float4 *out = reinterpret_cast<float4 *>(p.out);
+  const V *Mw = reinterpret_cast<const V *>(p.Mw);
+  const V *res = reinterpret_cast<const V *>(p.res);
+  V *out = reinterpret_cast<V *>(p.out);
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const long long zc = t % per_tile;
-    const int c4 = (int)(zc % C4);
+    const int cv = (int)(zc % CV);
     long long q = t / per_tile;
     const int ty = (int)(q % p.TY);
     q /= p.TY;
     const int tx = (int)(q % p.TX);
     const int b = (int)(q / p.TX);
-    float4 r[2][4];
+    V r[MT][N];   // r[a][j] = (At M)[a][j]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {   // At m
-      const float4 m0 = Mw[(long long)(0 + j) * plane + t], m1 = Mw[(long long)(4 + j) * plane + t];
-      const float4 m2 = Mw[(long long)(8 + j) * plane + t], m3 = Mw[(long long)(12 + j) * plane + t];
-      r[0][j] = f4add(f4add(m0, m1), m2);
-      r[1][j] = f4sub(f4sub(m1, m2), m3);
+    for (int j = 0; j < N; ++j) {
+      V m[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) m[i] = Mw[(long long)(N * i + j) * total + t];
+      V y[MT];
+      Wino1D<MT, V>::out(m, y);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) r[a][j] = y[a];
     }
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.scale) sc = reinterpret_cast<const float4 *>(p.scale)[c4];
-    if (p.shift) sf = reinterpret_cast<const float4 *>(p.shift)[c4];
+    const V sc = p.scale ? reinterpret_cast<const V *>(p.scale)[cv] : vone((V *)nullptr);
+    const V sf = p.shift ? reinterpret_cast<const V *>(p.shift)[cv] : vzero((V *)nullptr);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int x = 2 * tx + a;
+    for (int a = 0; a < MT; ++a) {
+      const int x = MT * tx + a;
       if (x >= p.Xo) continue;
-      const float4 y0 = f4add(f4add(r[a][0], r[a][1]), r[a][2]);
-      const float4 y1 = f4sub(f4sub(r[a][1], r[a][2]), r[a][3]);
+      V yy[MT];
+      Wino1D<MT, V>::out(r[a], yy);
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int y = 2 * ty + e;
+      for (int e = 0; e < MT; ++e) {
+        const int y = MT * ty + e;
         if (y >= p.Yo) continue;
-        const float4 acc = e == 0 ? y0 : y1;
         const long long o = (((long long)b * p.Xo + x) * p.Yo + y) * per_tile + zc;
-        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+        V rr = vzero((V *)nullptr);
         if (p.res_mode) rr = res[o];
-        float4 v;
-        v.x = wino_finish(p, acc.x, sc.x, sf.x, rr.x);
-        v.y = wino_finish(p, acc.y, sc.y, sf.y, rr.y);
-        v.z = wino_finish(p, acc.z, sc.z, sf.z, rr.z);
-        v.w = wino_finish(p, acc.w, sc.w, sf.w, rr.w);
-        out[o] = v;
+        out[o] = wino_finish_v(p, yy[e], sc, sf, rr);
       }
     }
   }
 }
 
-// U = G g Gt, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].  wgt is layout 0 [Co,3,3,KW,Ci]; U is [16][Co][K] with the K order
-// of `kmode` (0: k = kz*Ci + ci; 1: k = (ci/32)*KW*32 + kz*32 + ci%32), i.e. each xi holds a packed 1x1xKW filter bank.
+// U = G g Gt.  wgt is layout 0 [Co,3,3,KW,Ci]; U is [n*n][Co][K] with the K order of `kmode` (0: k = kz*Ci + ci;
+// 1: k = (ci/32)*KW*32 + kz*32 + ci%32), i.e. each xi holds a packed 1x1xKW filter bank.
+template <int MT>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int Co, int KW, int Ci,
                                                           int kmode) {
+  constexpr int N = MT + 2;
   const long long total = (long long)Co * KW * Ci;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int ci = (int)(t % Ci);
   const int kz = (int)((t / Ci) % KW);
   const int co = (int)(t / ((long long)Ci * KW));
-  float g[3][3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int e = 0; e < 3; ++e) g[a][e] = w[((((long long)co * 3 + a) * 3 + e) * KW + kz) * Ci + ci];
-  float h[4][3];
+  float h[N][3];   // h[i][e] = (G g)[i][e]
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
-    h[0][e] = g[0][e];
-    h[1][e] = 0.5f * (g[0][e] + g[1][e] + g[2][e]);
-    h[2][e] = 0.5f * (g[0][e] - g[1][e] + g[2][e]);
-    h[3][e] = g[2][e];
+    float g[3], c[N];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) g[a] = w[((((long long)co * 3 + a) * 3 + e) * KW + kz) * Ci + ci];
+    Wino1D<MT, float>::wgt(g, c);
+#pragma unroll
+    for (int i = 0; i < N; ++i) h[i][e] = c[i];
   }
   const long long K = (long long)KW * Ci;
   const long long k = kmode == 1 ? ((long long)(ci >> 5) * KW + kz) * 32 + (ci & 31) : (long long)kz * Ci + ci;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float u0 = h[i][0];
-    const float u1 = 0.5f * (h[i][0] + h[i][1] + h[i][2]);
-    const float u2 = 0.5f * (h[i][0] - h[i][1] + h[i][2]);
-    const float u3 = h[i][2];
-    U[((long long)(4 * i + 0) * Co + co) * K + k] = u0;
-    U[((long long)(4 * i + 1) * Co + co) * K + k] = u1;
-    U[((long long)(4 * i + 2) * Co + co) * K + k] = u2;
-    U[((long long)(4 * i + 3) * Co + co) * K + k] = u3;
+  for (int i = 0; i < N; ++i) {
+    float u[N];
+    Wino1D<MT, float>::wgt(h[i], u);
+#pragma unroll
+    for (int j = 0; j < N; ++j) U[((long long)(N * i + j) * Co + co) * K + k] = u[j];
   }
 }
 
 struct WinoDims {
-  int Xo, Yo, Zo, TX, TY;
+  int Xo, Yo, Zo, TX, TY, n2;
   int64_t v_elems, m_elems;   // elements of one xi plane of V / M
 };
 
-int wino_dims(const ivx_conv_desc *d, WinoDims *w, const char *who) {
+int wino_dims(const ivx_conv_desc *d, int tile, WinoDims *w, const char *who) {
   IVX_REQUIRE(d, "%s: null descriptor", who);
+  IVX_REQUIRE(tile == 2 || tile == 4, "%s: tile must be 2 (F(2x2,3x3)) or 4 (F(4x4,3x3)), got %d", who, tile);
   IVX_REQUIRE(d->KD == 3 && d->KH == 3 && d->sd == 1 && d->sh == 1, "%s: needs a 3x3 kernel with stride 1 on the first two axes", who);
   IVX_REQUIRE(d->KW >= 1 && d->KW <= 8 && d->sw >= 1 && d->pd >= 0 && d->ph >= 0 && d->pw >= 0, "%s: bad z kernel / stride / padding", who);
   IVX_REQUIRE(d->B > 0 && d->D > 0 && d->H > 0 && d->W > 0, "%s: non-positive dims", who);
@@ -200,7 +263,8 @@ int wino_dims(const ivx_conv_desc *d, WinoDims *w, const char *who) {
   int32_t Xo, Yo, Zo;
   if (ivx_conv_out_dims(d, &Xo, &Yo, &Zo) != IVX_OK) return IVX_ERR_INVALID_ARG;
   w->Xo = Xo; w->Yo = Yo; w->Zo = Zo;
-  w->TX = (Xo + 1) / 2; w->TY = (Yo + 1) / 2;
+  w->TX = (Xo + tile - 1) / tile; w->TY = (Yo + tile - 1) / tile;
+  w->n2 = (tile + 2) * (tile + 2);
   w->v_elems = (int64_t)d->B * w->TX * w->TY * d->W * d->Cin;
   w->m_elems = (int64_t)d->B * w->TX * w->TY * Zo * d->Cout;
   return IVX_OK;
@@ -222,50 +286,53 @@ unsigned wino_blocks(int64_t items) {
 
 }  // namespace
 
-extern "C" int ivx_conv_winograd_supported(const ivx_conv_desc *d) {
+extern "C" int ivx_conv_winograd_supported(const ivx_conv_desc *d, int32_t tile) {
   WinoDims w;
-  if (wino_dims(d, &w, "ivx_conv_winograd_supported") != IVX_OK) return 0;
+  if (wino_dims(d, tile, &w, "ivx_conv_winograd_supported") != IVX_OK) return 0;
   // one xi plane is one group of the grouped launch: 31-bit buffer offsets
   if (w.v_elems * 4 >= (1LL << 31) || w.m_elems >= (1LL << 31) - 512 * (int64_t)d->Cout) return 0;
   if ((int64_t)d->Cout * d->KW * d->Cin * 4 >= (1LL << 31)) return 0;
   return 1;
 }
 
-extern "C" int64_t ivx_conv_winograd_weight_elems(const ivx_conv_desc *d) {
+extern "C" int64_t ivx_conv_winograd_weight_elems(const ivx_conv_desc *d, int32_t tile) {
   WinoDims w;
-  if (wino_dims(d, &w, "ivx_conv_winograd_weight_elems") != IVX_OK) return -1;
-  return (int64_t)16 * d->Cout * d->KW * d->Cin;
+  if (wino_dims(d, tile, &w, "ivx_conv_winograd_weight_elems") != IVX_OK) return -1;
+  return (int64_t)w.n2 * d->Cout * d->KW * d->Cin;
 }
 
-extern "C" int ivx_conv_winograd_weights(const ivx_conv_desc *d, const float *wgt, float *u, ivx_stream_t stream) {
+extern "C" int ivx_conv_winograd_weights(const ivx_conv_desc *d, int32_t tile, const float *wgt, float *u, ivx_stream_t stream) {
   WinoDims w;
-  int rc = wino_dims(d, &w, "ivx_conv_winograd_weights");
+  int rc = wino_dims(d, tile, &w, "ivx_conv_winograd_weights");
   if (rc != IVX_OK) return rc;
   IVX_REQUIRE(wgt && u, "ivx_conv_winograd_weights: null argument");
   const int64_t total = (int64_t)d->Cout * d->KW * d->Cin;
-  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout,
-                     d->KW, d->Cin, d->wgt_layout);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (tile == 2)
+    hipLaunchKernelGGL(wino_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout);
+  else
+    hipLaunchKernelGGL(wino_weight_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout);
   IVX_CHECK_LAUNCH("ivx_conv_winograd_weights");
   return IVX_OK;
 }
 
-extern "C" int64_t ivx_conv_winograd_workspace_bytes(const ivx_conv_desc *d) {
+extern "C" int64_t ivx_conv_winograd_workspace_bytes(const ivx_conv_desc *d, int32_t tile) {
   WinoDims w;
-  if (wino_dims(d, &w, "ivx_conv_winograd_workspace_bytes") != IVX_OK) return -1;
-  return ivx_align_up(16 * w.v_elems * 4, 256) + ivx_align_up(16 * w.m_elems * 4, 256);
+  if (wino_dims(d, tile, &w, "ivx_conv_winograd_workspace_bytes") != IVX_OK) return -1;
+  return ivx_align_up(w.n2 * w.v_elems * 4, 256) + ivx_align_up(w.n2 * w.m_elems * 4, 256);
 }
 
 namespace {
-int wino_setup(const ivx_conv_desc *d, const void *in, const float *scale, const float *shift, const void *res, void *out,
+int wino_setup(const ivx_conv_desc *d, int tile, const void *in, const float *scale, const float *shift, const void *res, void *out,
                void *workspace, int64_t workspace_bytes, WinoDims *w, WinoP *p, const char *who) {
-  int rc = wino_dims(d, w, who);
+  int rc = wino_dims(d, tile, w, who);
   if (rc != IVX_OK) return rc;
   IVX_REQUIRE(workspace, "%s: null workspace", who);
-  if (!ivx_conv_winograd_supported(d)) {
+  if (!ivx_conv_winograd_supported(d, tile)) {
     ivx_set_error("%s: one transformed plane must stay below 2 GiB (use ivx_conv_fwd)", who);
     return IVX_ERR_UNSUPPORTED;
   }
-  const int64_t need = ivx_conv_winograd_workspace_bytes(d);
+  const int64_t need = ivx_conv_winograd_workspace_bytes(d, tile);
   if (workspace_bytes < need) {
     ivx_set_error("%s: workspace too small (%lld < %lld); size it with ivx_conv_winograd_workspace_bytes", who,
                   (long long)workspace_bytes, (long long)need);
@@ -274,7 +341,7 @@ int wino_setup(const ivx_conv_desc *d, const void *in, const float *scale, const
   p->in = (const float *)in; p->scale = scale; p->shift = shift; p->res = d->res_mode ? (const float *)res : nullptr;
   p->out = (float *)out;
   p->V = (float *)workspace;
-  p->Mw = (float *)((char *)workspace + ivx_align_up(16 * w->v_elems * 4, 256));
+  p->Mw = (float *)((char *)workspace + ivx_align_up(w->n2 * w->v_elems * 4, 256));
   p->B = d->B; p->X = d->D; p->Y = d->H; p->Z = d->W; p->C = d->Cin;
   p->Xo = w->Xo; p->Yo = w->Yo; p->Zo = w->Zo; p->Co = d->Cout;
   p->TX = w->TX; p->TY = w->TY; p->px = d->pd; p->py = d->ph;
@@ -285,53 +352,60 @@ int wino_setup(const ivx_conv_desc *d, const void *in, const float *scale, const
 }  // namespace
 
 // The three stages are separate entry points so that a caller can time them (bench.py); ivx_conv_winograd_fwd runs all.
-extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *d, const void *in, void *workspace, int64_t workspace_bytes,
+extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *d, int32_t tile, const void *in, void *workspace, int64_t workspace_bytes,
                                        ivx_stream_t stream) {
   WinoDims w;
   WinoP p;
   float dummy;
   IVX_REQUIRE(in, "ivx_conv_winograd_input: null argument");
-  int rc = wino_setup(d, in, nullptr, nullptr, &dummy, &dummy, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_input");
+  int rc = wino_setup(d, tile, in, nullptr, nullptr, &dummy, &dummy, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_input");
   if (rc != IVX_OK) return rc;
-  hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(w.v_elems / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  if (tile == 2)
+    hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wino_blocks(w.v_elems / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
   IVX_CHECK_LAUNCH("ivx_conv_winograd_input");
   return IVX_OK;
 }
 
-extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *d, const float *u, void *workspace, int64_t workspace_bytes,
+extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *d, int32_t tile, const float *u, void *workspace, int64_t workspace_bytes,
                                       ivx_stream_t stream) {
   WinoDims w;
   WinoP p;
   float dummy;
   IVX_REQUIRE(u, "ivx_conv_winograd_gemm: null argument");
-  int rc = wino_setup(d, &dummy, nullptr, nullptr, &dummy, &dummy, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_gemm");
+  int rc = wino_setup(d, tile, &dummy, nullptr, nullptr, &dummy, &dummy, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_gemm");
   if (rc != IVX_OK) return rc;
   const ivx_conv_desc g = wino_group_desc(d, w);
-  rc = ivx_conv_grouped_launch(&g, 16, p.V, w.v_elems, u, (long long)d->Cout * d->KW * d->Cin, p.Mw, w.m_elems, (hipStream_t)stream);
+  rc = ivx_conv_grouped_launch(&g, w.n2, p.V, w.v_elems, u, (long long)d->Cout * d->KW * d->Cin, p.Mw, w.m_elems, (hipStream_t)stream);
   if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_winograd_gemm");
   return IVX_OK;
 }
 
-extern "C" int ivx_conv_winograd_output(const ivx_conv_desc *d, const float *scale, const float *shift, const void *res, void *out,
-                                        void *workspace, int64_t workspace_bytes, ivx_stream_t stream) {
+extern "C" int ivx_conv_winograd_output(const ivx_conv_desc *d, int32_t tile, const float *scale, const float *shift, const void *res,
+                                        void *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream) {
   WinoDims w;
   WinoP p;
   float dummy;
   IVX_REQUIRE(out, "ivx_conv_winograd_output: null argument");
   IVX_REQUIRE(!d || d->res_mode == 0 || res, "ivx_conv_winograd_output: res_mode set but res is NULL");
-  int rc = wino_setup(d, &dummy, scale, shift, res, out, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_output");
+  int rc = wino_setup(d, tile, &dummy, scale, shift, res, out, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_output");
   if (rc != IVX_OK) return rc;
-  hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks(w.m_elems / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  if (tile == 2)
+    hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wino_blocks(w.m_elems / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
   IVX_CHECK_LAUNCH("ivx_conv_winograd_output");
   return IVX_OK;
 }
 
-extern "C" int ivx_conv_winograd_fwd(const ivx_conv_desc *d, const void *in, const float *u, const float *scale, const float *shift,
-                                     const void *res, void *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream) {
-  int rc = ivx_conv_winograd_input(d, in, workspace, workspace_bytes, stream);
+extern "C" int ivx_conv_winograd_fwd(const ivx_conv_desc *d, int32_t tile, const void *in, const float *u, const float *scale,
+                                     const float *shift, const void *res, void *out, void *workspace, int64_t workspace_bytes,
+                                     ivx_stream_t stream) {
+  int rc = ivx_conv_winograd_input(d, tile, in, workspace, workspace_bytes, stream);
   if (rc != IVX_OK) return rc;
-  rc = ivx_conv_winograd_gemm(d, u, workspace, workspace_bytes, stream);
+  rc = ivx_conv_winograd_gemm(d, tile, u, workspace, workspace_bytes, stream);
   if (rc != IVX_OK) return rc;
-  return ivx_conv_winograd_output(d, scale, shift, res, out, workspace, workspace_bytes, stream);
+  return ivx_conv_winograd_output(d, tile, scale, shift, res, out, workspace, workspace_bytes, stream);
 }

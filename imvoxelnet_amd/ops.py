@@ -131,30 +131,30 @@ def _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, r
                     int(res_mode), 0, 0, int(wgt_layout), 0, int(bool(res_after_act)), float(post_scale), 0, 0)
 
 
-def conv_winograd_supported(x_shape, Cout, kernel, stride, padding):
+def conv_winograd_supported(x_shape, Cout, kernel, stride, padding, tile=2):
     """True when ivx_conv_winograd_fwd can run this fp32 convolution (3x3xKW, stride 1 on the first two axes, planes < 2 GiB)."""
-    if kernel[0] != 3 or kernel[1] != 3 or stride[0] != 1 or stride[1] != 1 or x_shape[4] % 4 or Cout % 4:
+    if kernel[0] != 3 or kernel[1] != 3 or stride[0] != 1 or stride[1] != 1 or x_shape[4] % 4 or Cout % 4 or tile not in (2, 4):
         return False
     B, D, H, W, Cin = x_shape
     d = _wino_desc(B, D, H, W, Cin, Cout, kernel[2], stride[2], padding, False, 0)
-    return bool(_lib.lib().ivx_conv_winograd_supported(C.byref(d)))
+    return bool(_lib.lib().ivx_conv_winograd_supported(C.byref(d), tile))
 
 
-def conv_winograd_weights(wgt, wgt_layout):
-    """wgt [Cout,3,3,KW,Cin] fp32 (layout 0, on the device) -> transformed filters u [16, Cout, KW*Cin] whose K order is
-    `wgt_layout` (0: tap-major, 1: 32-channel chunks)."""
+def conv_winograd_weights(wgt, wgt_layout, tile=2):
+    """wgt [Cout,3,3,KW,Cin] fp32 (layout 0, on the device) -> transformed filters u [(tile+2)^2, Cout, KW*Cin] whose K order
+    is `wgt_layout` (0: tap-major, 1: 32-channel chunks)."""
     _chk(wgt, 'wgt')
     Cout, kd, kh, kw, Cin = wgt.shape
     if kd != 3 or kh != 3:
-        raise ValueError('Winograd F(2x2,3x3) needs a 3x3 kernel on the first two axes')
+        raise ValueError('Winograd F(m x m, 3x3) needs a 3x3 kernel on the first two axes')
     d = _wino_desc(1, 4, 4, max(kw, 1), Cin, Cout, kw, 1, (1, 1, kw // 2), False, wgt_layout)
     L = _lib.lib()
-    n = L.ivx_conv_winograd_weight_elems(C.byref(d))
+    n = L.ivx_conv_winograd_weight_elems(C.byref(d), tile)
     if n < 0:
         check(-1, 'ivx_conv_winograd_weight_elems')
-    u = torch.empty((16, Cout, kw * Cin), device=wgt.device, dtype=torch.float32)
+    u = torch.empty(((tile + 2) ** 2, Cout, kw * Cin), device=wgt.device, dtype=torch.float32)
     assert u.numel() == n
-    check(L.ivx_conv_winograd_weights(C.byref(d), _ptr(wgt), _ptr(u), _stream()), 'ivx_conv_winograd_weights')
+    check(L.ivx_conv_winograd_weights(C.byref(d), tile, _ptr(wgt), _ptr(u), _stream()), 'ivx_conv_winograd_weights')
     return u
 
 
@@ -164,13 +164,14 @@ winograd_trace = None
 
 def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1, 1, 1), relu=False, res=None, out=None,
                       wgt_layout=0, res_after_act=False, post_scale=1.0):
-    """Same result as conv_fwd for a 3x3xkw kernel with stride (1,1,stride_w), computed in the F(2x2,3x3) minimal-filtering
-    form (fp32).  x [B,D,H,W,Cin]; u from conv_winograd_weights."""
+    """Same result as conv_fwd for a 3x3xkw kernel with stride (1,1,stride_w), computed in the F(m x m, 3x3) minimal-filtering
+    form (fp32).  x [B,D,H,W,Cin]; u from conv_winograd_weights (its first dimension, 16 or 36, selects m = 2 or 4)."""
     _chk(x, 'x')
     _chk(u, 'u')
     B, D, H, W, Cin = x.shape
     Cout = u.shape[1]
-    if tuple(u.shape) != (16, Cout, kw * Cin):
+    tile = {16: 2, 36: 4}.get(u.shape[0])
+    if tile is None or tuple(u.shape) != ((tile + 2) ** 2, Cout, kw * Cin):
         raise ValueError(f'transformed filters {tuple(u.shape)} do not match kw {kw} / Cin {Cin}')
     d = _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, 1 if res is not None else 0, res_after_act,
                    post_scale)
@@ -191,26 +192,26 @@ def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1
         out = torch.empty(oshape, device=x.device, dtype=torch.float32)
     else:
         _chk(out, 'out')
-    wsb = L.ivx_conv_winograd_workspace_bytes(C.byref(d))
+    wsb = L.ivx_conv_winograd_workspace_bytes(C.byref(d), tile)
     if wsb < 0:
         check(-1, 'ivx_conv_winograd_workspace_bytes')
     ws = torch.empty((wsb,), device=x.device, dtype=torch.uint8)
     if winograd_trace is None:
-        check(L.ivx_conv_winograd_fwd(C.byref(d), _ptr(x), _ptr(u), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _ptr(ws), wsb,
-                                      _stream()), 'ivx_conv_winograd_fwd')
+        check(L.ivx_conv_winograd_fwd(C.byref(d), tile, _ptr(x), _ptr(u), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _ptr(ws),
+                                      wsb, _stream()), 'ivx_conv_winograd_fwd')
         return out
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     ev[0].record()
-    check(L.ivx_conv_winograd_input(C.byref(d), _ptr(x), _ptr(ws), wsb, _stream()), 'ivx_conv_winograd_input')
+    check(L.ivx_conv_winograd_input(C.byref(d), tile, _ptr(x), _ptr(ws), wsb, _stream()), 'ivx_conv_winograd_input')
     ev[1].record()
-    check(L.ivx_conv_winograd_gemm(C.byref(d), _ptr(u), _ptr(ws), wsb, _stream()), 'ivx_conv_winograd_gemm')
+    check(L.ivx_conv_winograd_gemm(C.byref(d), tile, _ptr(u), _ptr(ws), wsb, _stream()), 'ivx_conv_winograd_gemm')
     ev[2].record()
-    check(L.ivx_conv_winograd_output(C.byref(d), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _ptr(ws), wsb, _stream()),
+    check(L.ivx_conv_winograd_output(C.byref(d), tile, _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _ptr(ws), wsb, _stream()),
           'ivx_conv_winograd_output')
     ev[3].record()
-    tiles = B * ((oshape[1] + 1) // 2) * ((oshape[2] + 1) // 2)
+    tiles = B * ((oshape[1] + tile - 1) // tile) * ((oshape[2] + tile - 1) // tile)
     winograd_trace.append(('input', ev[0], ev[1], 0.0))
-    winograd_trace.append(('gemm', ev[1], ev[2], 2.0 * 16 * tiles * oshape[3] * Cout * kw * Cin))
+    winograd_trace.append(('gemm', ev[1], ev[2], 2.0 * u.shape[0] * tiles * oshape[3] * Cout * kw * Cin))
     winograd_trace.append(('output', ev[2], ev[3], 0.0))
     return out
 

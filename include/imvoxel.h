@@ -100,29 +100,34 @@ int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const void *wgt, con
 int ivx_conv_fwd_naive(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
                        const float *shift, const void *res, void *out, ivx_stream_t stream);
 
-/* Minimal-filtering (Winograd F(2x2,3x3)) form of the same convolution for 3x3xKW kernels with stride 1 on the first two
- * spatial axes (D, H) -- the 128- / 256-channel layers of the KITTI / nuScenes necks
- * (mmdet3d/models/necks/imvoxelnet.py:99-113,181-230), which are bound by the fp32 MFMA rate: 16 instead of 36
- * multiplications per 2x2 output tile and W-tap.  Same contract, epilogue and fp32 arithmetic as ivx_conv_fwd (the result
- * differs by fp32 rounding only); the W axis keeps its kernel extent, stride and padding as a direct convolution.
+/* Minimal-filtering (Winograd F(m x m, 3x3), tile m = 2 or 4) form of the same convolution for 3x3xKW kernels with stride 1
+ * on the first two spatial axes (D, H) -- the 128- / 256-channel layers of the KITTI / nuScenes necks
+ * (mmdet3d/models/necks/imvoxelnet.py:99-113,181-230), which are bound by the fp32 MFMA rate: (m+2)^2 instead of 9*m*m
+ * multiplications per m x m output tile and W-tap (16 vs 36 for tile 2, 36 vs 144 for tile 4).  Same contract, epilogue and
+ * fp32 arithmetic as ivx_conv_fwd; the result differs by fp32 rounding only (tile 2: at the level of the direct sum; tile 4:
+ * about 5x the direct sum's rounding error, 1e-5 of the output range on a 256-channel layer).  The W axis keeps its kernel
+ * extent, stride and padding as a direct convolution.
  * Restrictions: KD = KH = 3, sd = sh = 1, fp32, out_mode 0, res_mode 0/1, Cin % 4 == 0, Cout % 4 == 0, and one transformed
- * plane [B, ceil(Do/2), ceil(Ho/2), W, Cin] below 2 GiB (ivx_conv_winograd_supported returns 1 when all hold).
- *   u          transformed filters, ivx_conv_winograd_weight_elems(d) floats: [16][Cout][KW*Cin] with the K order of
- *              d->wgt_layout; made once per layer by ivx_conv_winograd_weights from wgt in layout 0 [Cout,3,3,KW,Cin].
- *   workspace  ivx_conv_winograd_workspace_bytes(d) bytes (the transformed input and the 16 partial outputs).
- * ivx_conv_winograd_fwd = _input (transform the input into the workspace) + _gemm (16 independent 1x1xKW convolutions,
- * one grouped launch of the implicit-GEMM kernel) + _output (inverse transform + epilogue); the stages are exported
- * separately so that a caller can time them. */
-int ivx_conv_winograd_supported(const ivx_conv_desc *d);
-int64_t ivx_conv_winograd_weight_elems(const ivx_conv_desc *d);
-int ivx_conv_winograd_weights(const ivx_conv_desc *d, const float *wgt, float *u, ivx_stream_t stream);
-int64_t ivx_conv_winograd_workspace_bytes(const ivx_conv_desc *d);
-int ivx_conv_winograd_input(const ivx_conv_desc *d, const void *in, void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
-int ivx_conv_winograd_gemm(const ivx_conv_desc *d, const float *u, void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
-int ivx_conv_winograd_output(const ivx_conv_desc *d, const float *scale, const float *shift, const void *res, void *out,
-                             void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
-int ivx_conv_winograd_fwd(const ivx_conv_desc *d, const void *in, const float *u, const float *scale, const float *shift,
-                          const void *res, void *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
+ * plane [B, ceil(Do/m), ceil(Ho/m), W, Cin] below 2 GiB (ivx_conv_winograd_supported returns 1 when all hold).
+ *   u          transformed filters, ivx_conv_winograd_weight_elems(d, tile) floats: [(m+2)^2][Cout][KW*Cin] with the K order
+ *              of d->wgt_layout; made once per layer by ivx_conv_winograd_weights from wgt in layout 0 [Cout,3,3,KW,Cin].
+ *   workspace  ivx_conv_winograd_workspace_bytes(d, tile) bytes (the transformed input and the (m+2)^2 partial outputs).
+ * ivx_conv_winograd_fwd = _input (transform the input into the workspace) + _gemm ((m+2)^2 independent 1x1xKW
+ * convolutions, one grouped launch of the implicit-GEMM kernel) + _output (inverse transform + epilogue); the stages are
+ * exported separately so that a caller can time them. */
+int ivx_conv_winograd_supported(const ivx_conv_desc *d, int32_t tile);
+int64_t ivx_conv_winograd_weight_elems(const ivx_conv_desc *d, int32_t tile);
+int ivx_conv_winograd_weights(const ivx_conv_desc *d, int32_t tile, const float *wgt, float *u, ivx_stream_t stream);
+int64_t ivx_conv_winograd_workspace_bytes(const ivx_conv_desc *d, int32_t tile);
+int ivx_conv_winograd_input(const ivx_conv_desc *d, int32_t tile, const void *in, void *workspace, int64_t workspace_bytes,
+                            ivx_stream_t stream);
+int ivx_conv_winograd_gemm(const ivx_conv_desc *d, int32_t tile, const float *u, void *workspace, int64_t workspace_bytes,
+                           ivx_stream_t stream);
+int ivx_conv_winograd_output(const ivx_conv_desc *d, int32_t tile, const float *scale, const float *shift, const void *res,
+                             void *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
+int ivx_conv_winograd_fwd(const ivx_conv_desc *d, int32_t tile, const void *in, const float *u, const float *scale,
+                          const float *shift, const void *res, void *out, void *workspace, int64_t workspace_bytes,
+                          ivx_stream_t stream);
 
 /* Tuning knob for A/B experiments only (per calling thread): 0 = automatic tile choice (default); 1..7 force a tile
  * of the generic kernel, 41..53 of the LDS-DMA fp32 kernel, 61..73 of its bf16 instantiation. */
