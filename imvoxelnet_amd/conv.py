@@ -60,11 +60,13 @@ class FusedConv:
     # >= winograd_min_pos input positions run as F(m x m, 3x3) (ivx_conv_winograd_fwd), m = winograd_tile.  Measured on the
     # KITTI neck (batch 4, tools/conv_bench.py --winograd), direct -> m = 2 -> m = 4 in ms: 256->256 16.1 -> 9.1 -> 5.3,
     # 128->128 8.2 -> 5.7 -> 3.3, 128->256 (z stride 2) 8.2 -> 5.6 -> 3.3, 64->128 4.6 -> 3.9 -> 2.3, 64->64 4.8 -> 4.3 -> 2.6.
-    # The small indoor volumes stay direct (too few tiles per transformed plane to fill the chip).
+    # Also a gain on the indoor necks down to a few thousand positions (SUN RGB-D fast 123 -> 159 scenes/s, nuScenes 30.7 -> 38.4);
+    # only the coarsest levels (< winograd_min_pos positions) stay direct.
     winograd = os.environ.get('IVX_WINOGRAD', '1') != '0'
     winograd_tile = int(os.environ.get('IVX_WINOGRAD_TILE', '4'))     # m of F(m x m, 3x3): 2 or 4
     winograd_min_ch = 64
-    winograd_min_pos = int(os.environ.get('IVX_WINOGRAD_MIN_POS', '100000'))
+    winograd_2d_min_ch = int(os.environ.get('IVX_WINOGRAD_2D_MIN_CH', '128'))   # 2-D 3x3 layers (ResNet conv2, FPN outputs)
+    winograd_min_pos = int(os.environ.get('IVX_WINOGRAD_MIN_POS', '2000'))
     # optional per-call timing (bench.py): when a list, every call appends
     # (kind, start_event, end_event, executed_flops, bytes) with kind 'direct' | 'wino_input' | 'wino_gemm' | 'wino_output';
     # the events bracket exactly the launches of that stage on the current stream
@@ -101,11 +103,16 @@ class FusedConv:
             wp = wp.reshape(co, kd, kh, kw, ci // ck, ck).permute(0, 4, 1, 2, 3, 5)
         self._w_host = wp.contiguous().to(dtype)
         # candidate for the minimal-filtering form: keep the tap-major fp32 filters for ivx_conv_winograd_weights
+        # 3-D layers transform their first two axes (the z axis stays direct); a 2-D 3x3 layer [B,1,H,W,C] is the same thing
+        # on the view [B,H,W,1,C] with a 3x3x1 kernel (identical memory for the activations and the tap-major filters)
         self._w0_host = None
-        if (dims == 3 and dtype == torch.float32 and out_dtype == torch.float32 and self.kernel[0] == 3 and self.kernel[1] == 3
-                and self.stride[0] == 1 and self.stride[1] == 1 and self.cin_pad == self.cin and self.cout % 4 == 0
-                and max(self.cin, self.cout) >= FusedConv.winograd_min_ch and self.cin % 4 == 0 and type(self) is FusedConv):
-            self._w0_host = w.permute(0, 2, 3, 4, 1).contiguous()
+        self._wino2d = self.kernel == (1, 3, 3) and self.stride == (1, 1, 1)
+        wino3d = self.kernel[0] == 3 and self.kernel[1] == 3 and self.stride[0] == 1 and self.stride[1] == 1
+        min_ch = FusedConv.winograd_2d_min_ch if self._wino2d else FusedConv.winograd_min_ch
+        if ((wino3d or self._wino2d) and dtype == torch.float32 and out_dtype == torch.float32 and self.cin_pad == self.cin
+                and self.cout % 4 == 0 and max(self.cin, self.cout) >= min_ch and self.cin % 4 == 0 and type(self) is FusedConv):
+            w0 = w.permute(0, 2, 3, 4, 1).contiguous()                       # [Cout,kd,kh,kw,Cin]
+            self._w0_host = w0.reshape(self.cout, 3, 3, 1, self.cin) if self._wino2d else w0
         self.u = None
         scale = torch.ones(self.cout)
         shift = torch.zeros(self.cout)
@@ -134,31 +141,39 @@ class FusedConv:
         if self.w is None:
             raise RuntimeError('FusedConv.to(device) must be called before use')
         wino = (self.u is not None and FusedConv.winograd and not naive and res_mode in (0, 1) and x.dtype == torch.float32
-                and x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] >= FusedConv.winograd_min_pos
-                and ops.conv_winograd_supported(tuple(x.shape), self.cout, self.kernel, self.stride, self.padding, self._tile()))
+                and x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] >= FusedConv.winograd_min_pos)
+        # the convolution as the Winograd entry points see it: transformed axes first, direct axis last
+        B = x.shape[0]
+        if self._wino2d:
+            xs, wk, wst, wpad = (B, x.shape[2], x.shape[3], 1, self.cin), (3, 3, 1), (1, 1, 1), (self.padding[1], self.padding[2], 0)
+        else:
+            xs, wk, wst, wpad = tuple(x.shape), self.kernel, self.stride, self.padding
+        wino = wino and ops.conv_winograd_supported(xs, self.cout, wk, wst, wpad, self._tile())
         if FusedConv.count_flops:
             od, oh, ow = ((x.shape[1 + a] + 2 * self.padding[a] - self.kernel[a]) // self.stride[a] + 1 for a in range(3))
             direct = 2.0 * x.shape[0] * od * oh * ow * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
             FusedConv.flops += direct
             m = self._tile()
-            FusedConv.exec_flops += (2.0 * (m + 2) ** 2 * x.shape[0] * ((od + m - 1) // m) * ((oh + m - 1) // m) * ow * self.cout *
-                                     self.cin * self.kernel[2]) if wino else direct
+            t1, t2, t3 = (oh, ow, 1) if self._wino2d else (od, oh, ow)
+            FusedConv.exec_flops += (2.0 * (m + 2) ** 2 * x.shape[0] * ((t1 + m - 1) // m) * ((t2 + m - 1) // m) * t3 * self.cout *
+                                     self.cin * wk[2]) if wino else direct
         if wino:
             if FusedConv.trace is not None:
                 ops.winograd_trace = []
-            y = ops.conv_winograd_fwd(x, self.u, self.scale, self.shift, self.kernel[2], self.stride[2], self.padding,
-                                      self.relu if relu is None else relu, res, wgt_layout=self.layout,
-                                      res_after_act=res_after_act, post_scale=post_scale)
+            xv = x.view(xs)
+            rv = None if res is None else res.view(B, res.shape[2], res.shape[3], 1, self.cout) if self._wino2d else res
+            y = ops.conv_winograd_fwd(xv, self.u, self.scale, self.shift, wk[2], wst[2], wpad, self.relu if relu is None else relu,
+                                      rv, wgt_layout=self.layout, res_after_act=res_after_act, post_scale=post_scale)
             if FusedConv.trace is not None:
                 m = self._tile()
                 tiles = y.shape[0] * ((y.shape[1] + m - 1) // m) * ((y.shape[2] + m - 1) // m)
-                v_bytes = 4.0 * (m + 2) ** 2 * tiles * x.shape[3] * self.cin       # transformed input: (m+2)^2 planes [tiles, Z, Cin]
+                v_bytes = 4.0 * (m + 2) ** 2 * tiles * xv.shape[3] * self.cin      # transformed input: (m+2)^2 planes [tiles, Z, Cin]
                 m_bytes = 4.0 * (m + 2) ** 2 * tiles * y.shape[3] * self.cout      # (m+2)^2 partial outputs [tiles, Zo, Cout]
                 by = {'input': 4.0 * x.numel() + v_bytes, 'gemm': v_bytes + m_bytes,
                       'output': m_bytes + 4.0 * y.numel() * (2 if res is not None else 1)}
                 FusedConv.trace += [('wino_' + n, e0, e1, fl, by[n]) for n, e0, e1, fl in ops.winograd_trace]
                 ops.winograd_trace = None
-            return y
+            return y.view(B, 1, y.shape[1], y.shape[2], self.cout) if self._wino2d else y
         if FusedConv.trace is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -1073,7 +1073,11 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
   if (pl.cfg == 0) {
     const long long nblk = (long long)groups * ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (p.Cout <= 32) pl.cfg = 44;
-    else if (nblk >= 2500) pl.cfg = p.Cout > 64 ? 54 : (p.K <= 640 ? 49 : 56);
+    // measured on the Winograd-domain GEMMs of the KITTI neck (tools/conv_bench.py --winograd --wcfgs ...): K is only
+    // KW*Cin here (192 .. 768), so a workgroup's prologue and epilogue weigh more than in the direct form and one more
+    // resident workgroup per CU pays: 128 x 64 at six per CU for Cout <= 64 (1.51 vs 1.85 ms at five), 128 x 128 at five
+    // per CU up to K = 512 (2.50 vs 2.90 ms at four); at K = 768 four and five tie
+    else if (nblk >= 2500) pl.cfg = p.Cout > 64 ? (p.K <= 512 ? 55 : 54) : 56;
     else pl.cfg = p.K <= 640 ? 47 : 46;
   }
   TileInfo t;

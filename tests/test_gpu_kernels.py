@@ -901,3 +901,25 @@ def test_conv_fwd_without_workspace_entry_point(ia):
     rc = L.ivx_conv_fwd_ws(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), None, None, None, C.c_void_p(out.data_ptr()),
                            C.c_void_p(ws.data_ptr()), 256, st)
     assert rc == -4 and b'workspace' in L.ivx_last_error()
+
+
+def test_conv_winograd_2d_layers(ia):
+    """2-D 3x3 stride-1 layers (ResNet conv2, FPN output convs) take the same Winograd path on the [B,H,W,1,C] view."""
+    from imvoxelnet_amd.conv import FusedConv
+    g = torch.Generator().manual_seed(8)
+    for (ci, co, H, W, B) in ((128, 128, 48, 160, 2), (256, 256, 23, 37, 3), (512, 512, 12, 40, 5)):
+        w = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5
+        bn = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+              torch.rand(co, generator=g) + 0.5)
+        x = torch.randn(B, 1, H, W, ci, generator=g).cuda()
+        f = FusedConv(w, bn=bn, padding=1, relu=True, dims=2).to(x.device)
+        assert f.u is not None and f._wino2d
+        FusedConv.flops, FusedConv.exec_flops, FusedConv.count_flops = 0.0, 0.0, True
+        try:
+            y = f(x)
+        finally:
+            FusedConv.count_flops = False
+        assert FusedConv.exec_flops < 0.5 * FusedConv.flops           # the minimal-filtering path ran
+        yn = f(x, naive=True)
+        assert y.shape == yn.shape == (B, 1, H, W, co)
+        assert_close(f'2-D winograd {ci}->{co} {H}x{W}', y, yn, 1e-4, 1e-4 * float(yn.abs().max()))

@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--layout', type=int, default=1)
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--winograd', action='store_true', help='also time the F(m x m, 3x3) form of each stride-1 layer')
+    ap.add_argument('--wcfgs', default='0', help='tile overrides of the grouped GEMM to sweep')
     ap.add_argument('--tile', type=int, default=4, help='m of the Winograd form (2 or 4)')
     a = ap.parse_args()
     if a.set == 'resnet':
@@ -117,23 +118,26 @@ def main():
             # the same layer in the F(2x2,3x3) form: per-stage times from the staged entry points
             w0 = w if lay == 0 else w.permute(0, 2, 3, 4, 1, 5).reshape(co, 3, 3, 3, ci).contiguous()
             u = ops.conv_winograd_weights(w0, lay, a.tile)
-            yw = ops.conv_winograd_fwd(x, u, sc, sh, 3, st[2], pd, True, wgt_layout=lay)
-            torch.cuda.synchronize()
-            err = (yw - y).abs().max().item() / max(y.abs().max().item(), 1e-30)
-            ops.winograd_trace = []
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(a.iters):
-                ops.conv_winograd_fwd(x, u, sc, sh, 3, st[2], pd, True, out=yw, wgt_layout=lay)
-            e1.record()
-            torch.cuda.synchronize()
-            tr, ops.winograd_trace = ops.winograd_trace, None
-            ms = e0.elapsed_time(e1) / a.iters
-            stage = {k: sum(s0.elapsed_time(s1) for n, s0, s1, _ in tr if n == k) / a.iters for k in ('input', 'gemm', 'output')}
-            gf = sum(f for n, _, _, f in tr if n == 'gemm') / a.iters
-            print(f'{name:24s} winograd F{a.tile}   : {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s direct-equivalent | input {stage["input"]:.3f}'
-                  f' gemm {stage["gemm"]:.3f} ({gf / stage["gemm"] / 1e9:.1f} TFLOP/s executed) output {stage["output"]:.3f} ms | '
-                  f'max rel diff vs direct {err:.2e}', flush=True)
+            for wcfg in [int(v) for v in a.wcfgs.split(',')]:      # tile override of the grouped GEMM
+                L.ivx_conv_set_tile_override(wcfg)
+                yw = ops.conv_winograd_fwd(x, u, sc, sh, 3, st[2], pd, True, wgt_layout=lay)
+                torch.cuda.synchronize()
+                err = (yw - y).abs().max().item() / max(y.abs().max().item(), 1e-30)
+                ops.winograd_trace = []
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    ops.conv_winograd_fwd(x, u, sc, sh, 3, st[2], pd, True, out=yw, wgt_layout=lay)
+                e1.record()
+                torch.cuda.synchronize()
+                tr, ops.winograd_trace = ops.winograd_trace, None
+                ms = e0.elapsed_time(e1) / a.iters
+                stage = {k: sum(s0.elapsed_time(s1) for n, s0, s1, _ in tr if n == k) / a.iters for k in ('input', 'gemm', 'output')}
+                gf = sum(f for n, _, _, f in tr if n == 'gemm') / a.iters
+                print(f'{name:24s} winograd F{a.tile} cfg {wcfg}: {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s direct-equivalent | input '
+                      f'{stage["input"]:.3f} gemm {stage["gemm"]:.3f} ({gf / stage["gemm"] / 1e9:.1f} TFLOP/s executed) output '
+                      f'{stage["output"]:.3f} ms | max rel diff vs direct {err:.2e}', flush=True)
+            L.ivx_conv_set_tile_override(0)
 
 
 if __name__ == '__main__':
