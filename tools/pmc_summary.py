@@ -35,7 +35,7 @@ def main():
             ms, name = d.get(r['Dispatch_Id'], (0.0, r['Kernel_Name']))
             if a.match not in name or ms < a.min_ms:
                 continue
-            key = name.split('(')[0][:80]
+            key = name.replace('(anonymous namespace)::', '').split('(')[0][:80]
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
             if r['Counter_Name'] in ('GRBM_GUI_ACTIVE', 'FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU'):
                 dur[(key, r['Counter_Name'])].append(ms)

@@ -38,14 +38,21 @@ def main(path, steps=0):
         gy_ok = gcols and gy and gy in cols
         tail = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%conv_igemm%' and end-start < 300000 and {gy} > 1 and {gx} <= 65536").fetchone() if gy_ok else (0, 0)
         red = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%splitk_reduce%'").fetchone()
+        xin = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%wino_input_kernel%' and end-start >= 100000").fetchone()
+        xout = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%wino_output_kernel%' and end-start >= 100000").fetchone()
         print(f'\n## 3-D neck reconciliation ({steps} steps profiled)\n')
-        print('| launches | per step | ms per step |')
-        print('|---|---|---|')
-        print(f'| conv launches >= 0.3 ms (the 9 neck layers: main launch, + the >= 0.3 ms tail launch of one layer) | {big[0] / steps:.1f} | {(big[1] or 0) / 1e6 / steps:.3f} |')
-        print(f'| K-split launches (neck tails + small 2-D layers) | {tail[0] / steps:.1f} | {(tail[1] or 0) / 1e6 / steps:.3f} |')
-        print(f'| split-K reductions | {red[0] / steps:.1f} | {(red[1] or 0) / 1e6 / steps:.3f} |')
-        print(f'\nneck kernel time per step ~ {((big[1] or 0)) / 1e6 / steps:.2f} ms (+ its share of the K-split rows); bench.py '
-              'brackets the same launches with HIP events (`roofline.neck_ms_per_step`).')
+        print('| launches | per step | ms per step | avg ms |')
+        print('|---|---|---|---|')
+        print(f'| implicit-GEMM launches >= 0.3 ms (the 9 neck layers: direct conv, or the grouped Winograd-domain GEMM) | {big[0] / steps:.1f} | '
+              f'{(big[1] or 0) / 1e6 / steps:.3f} | {(big[1] or 0) / 1e6 / max(big[0], 1):.4f} |')
+        print(f'| wino_input_kernel launches >= 0.1 ms | {xin[0] / steps:.1f} | {(xin[1] or 0) / 1e6 / steps:.3f} | {(xin[1] or 0) / 1e6 / max(xin[0], 1):.4f} |')
+        print(f'| wino_output_kernel launches >= 0.1 ms | {xout[0] / steps:.1f} | {(xout[1] or 0) / 1e6 / steps:.3f} | {(xout[1] or 0) / 1e6 / max(xout[0], 1):.4f} |')
+        print(f'| K-split launches (small 2-D layers) | {tail[0] / steps:.1f} | {(tail[1] or 0) / 1e6 / steps:.3f} | |')
+        print(f'| split-K reductions | {red[0] / steps:.1f} | {(red[1] or 0) / 1e6 / steps:.3f} | |')
+        tot_n = ((big[1] or 0) + (xin[1] or 0) + (xout[1] or 0)) / 1e6 / steps
+        print(f'\nneck kernel time per step ~ {tot_n:.2f} ms = GEMM launches + transforms; bench.py brackets the same launches with HIP events: '
+              '`roofline.avg_launch_ms` x `launches_per_step` is the first row (its avg ms column is `roofline.avg_launch_ms`), '
+              '`roofline_winograd_transforms.ms_per_step` the sum of rows two and three, `roofline.neck_ms_per_step` the total.')
 
 
 if __name__ == '__main__':
