@@ -923,3 +923,29 @@ def test_conv_winograd_2d_layers(ia):
         yn = f(x, naive=True)
         assert y.shape == yn.shape == (B, 1, H, W, co)
         assert_close(f'2-D winograd {ci}->{co} {H}x{W}', y, yn, 1e-4, 1e-4 * float(yn.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [((216, 248, 12), 64, 64, (1, 1, 1), (1, 1, 1)), ((216, 248, 6), 128, 256, (1, 1, 2), (1, 1, 1)),
+                                   ((216, 248, 3), 256, 256, (1, 1, 1), (0, 0, 0))])
+def test_conv_winograd_fullsize_kitti_layers(ia, shape):
+    """BASELINE config 2 sizes, batch 4: the F(4x4,3x3) form of a neck layer against the direct MFMA kernel on the same
+    data (both fp32; tolerance 1e-4 of the output range), and linearity of the whole three-stage pipeline."""
+    from imvoxelnet_amd import ops
+    (X, Y, Z), ci, co, st, pad = shape
+    g = torch.Generator(device='cuda').manual_seed(ci + Z)
+    x = torch.randn(4, X, Y, Z, ci, device='cuda', generator=g).clamp_min_(0)
+    w = torch.randn(co, 3, 3, 3, ci, device='cuda', generator=g) * (2.0 / (27 * ci)) ** 0.5
+    sc = torch.rand(co, device='cuda', generator=g) + 0.5
+    sh = torch.randn(co, device='cuda', generator=g) * 0.1
+    ref = ops.conv_fwd(x, w, sc, sh, (3, 3, 3), st, pad, relu=True)
+    u = ops.conv_winograd_weights(w, 0, 4)
+    got = ops.conv_winograd_fwd(x, u, sc, sh, 3, st[2], pad, True)
+    rng = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    print(f'{ci}->{co} z{Z}: max|diff| {err:.3e} of range {rng:.3e}')
+    assert got.shape == ref.shape and err <= 1e-4 * rng
+    # linearity without the epilogue: W(2x) == 2 W(x) exactly (power-of-two scaling commutes with every fp32 operation)
+    a = ops.conv_winograd_fwd(x, u, None, None, 3, st[2], pad, False)
+    x.mul_(2.0)
+    b = ops.conv_winograd_fwd(x, u, None, None, 3, st[2], pad, False)
+    assert torch.equal(b, a * 2.0)

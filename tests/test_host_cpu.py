@@ -50,6 +50,48 @@ def test_cabi_argument_validation_without_gpu():
     assert L.ivx_nms_workspace_bytes(100) >= 100 * 2 * 8
 
 
+def test_cabi_winograd_planning_without_gpu():
+    """Host-side planning of the minimal-filtering convolution (no launch): eligibility, filter and workspace sizes."""
+    from imvoxelnet_amd import _lib, ops
+    L = _lib.lib()
+
+    def desc(B, D, H, W, ci, co, kd=3, kh=3, kw=3, sd=1, sh=1, sw=1, pad=(1, 1, 1)):
+        return _lib.ConvDesc(B, D, H, W, ci, co, kd, kh, kw, sd, sh, sw, pad[0], pad[1], pad[2], 0, 0, 0, 0, 0, 0, 0, 1.0, 0, 0)
+    d = desc(4, 216, 248, 3, 256, 256)                      # the 256 -> 256 layers of the KITTI neck, batch 4
+    for tile, n2 in ((2, 16), (4, 36)):
+        tx, ty = 216 // tile, 248 // tile
+        assert L.ivx_conv_winograd_supported(ctypes.byref(d), tile) == 1
+        assert L.ivx_conv_winograd_weight_elems(ctypes.byref(d), tile) == n2 * 256 * 3 * 256
+        plane = 4 * tx * ty * 3 * 256 * 4                   # bytes of one transformed plane (input and output alike here)
+        assert L.ivx_conv_winograd_workspace_bytes(ctypes.byref(d), tile) == 2 * n2 * plane
+    assert L.ivx_conv_winograd_supported(ctypes.byref(d), 3) == 0 and b'tile' in L.ivx_last_error()
+    # odd extents round the tile grid up; z stride / padding follow the direct rule
+    d = desc(1, 9, 14, 12, 64, 128, sw=2)
+    assert L.ivx_conv_winograd_workspace_bytes(ctypes.byref(d), 4) == 36 * (3 * 4 * 12 * 64 + 3 * 4 * 6 * 128) * 4
+    # not eligible: stride on a transformed axis, 1x3x3 kernel given in (D,H,W) order, a plane of 2 GiB or more
+    assert L.ivx_conv_winograd_supported(ctypes.byref(desc(1, 64, 64, 8, 64, 64, sd=2, sh=2)), 4) == 0
+    assert L.ivx_conv_winograd_supported(ctypes.byref(desc(1, 1, 64, 64, 64, 64, kd=1, pad=(0, 1, 1))), 4) == 0
+    assert ops.conv_winograd_supported((64, 216, 248, 12, 64), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), 4)
+    assert not ops.conv_winograd_supported((256, 216, 248, 12, 64), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), 4)
+    assert L.ivx_conv_winograd_fwd(ctypes.byref(d), 4, None, None, None, None, None, None, None, 0, None) == -1   # null arguments
+
+
+def test_fused_conv_winograd_candidates():
+    """Which layers keep tap-major filters for the Winograd form: fp32, 3x3 stride 1 on the transformed axes, wide enough."""
+    from imvoxelnet_amd.conv import FusedConv
+    w3 = torch.zeros(64, 64, 3, 3, 3)
+    assert FusedConv(w3, padding=1)._w0_host is not None                                   # neck ResModule conv
+    assert FusedConv(w3, stride=(1, 1, 2), padding=1)._w0_host is not None                 # z-strided down-conv
+    assert FusedConv(w3, stride=2, padding=1)._w0_host is None                             # strided in x, y
+    assert FusedConv(torch.zeros(32, 32, 3, 3, 3), padding=1)._w0_host is None             # too narrow
+    assert FusedConv(w3, padding=1, dtype=torch.bfloat16)._w0_host is None                 # reduced-precision mode stays direct
+    f2 = FusedConv(torch.zeros(128, 128, 3, 3), padding=1, dims=2)                         # ResNet conv2 / FPN output conv
+    assert f2._wino2d and tuple(f2._w0_host.shape) == (128, 3, 3, 1, 128)
+    assert FusedConv(torch.zeros(64, 64, 3, 3), padding=1, dims=2)._w0_host is None        # 2-D layers need >= 128 channels
+    assert FusedConv(torch.zeros(256, 256, 1, 1), dims=2)._w0_host is None
+    assert FusedConv(torch.zeros(64, 4, 7, 7), stride=2, padding=3, dims=2)._w0_host is None   # the stem
+
+
 def test_ops_fail_loudly_on_cpu_tensors():
     from imvoxelnet_amd import ops
     with pytest.raises(RuntimeError, match='no CPU fallback'):
