@@ -63,7 +63,7 @@ class FusedConv:
     # Also a gain on the indoor necks down to a few thousand positions (SUN RGB-D fast 123 -> 159 scenes/s, nuScenes 30.7 -> 38.4);
     # only the coarsest levels (< winograd_min_pos positions) stay direct.
     winograd = os.environ.get('IVX_WINOGRAD', '1') != '0'
-    winograd_tile = int(os.environ.get('IVX_WINOGRAD_TILE', '4'))     # m of F(m x m, 3x3): 2 or 4
+    winograd_tile = int(os.environ.get('IVX_WINOGRAD_TILE', '6'))     # m of F(m x m, 3x3): 2, 4 or 6
     winograd_min_ch = 64
     winograd_2d_min_ch = int(os.environ.get('IVX_WINOGRAD_2D_MIN_CH', '128'))   # 2-D 3x3 layers (ResNet conv2, FPN outputs)
     winograd_min_pos = int(os.environ.get('IVX_WINOGRAD_MIN_POS', '2000'))
@@ -185,7 +185,7 @@ class FusedConv:
         return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
 
     def _tile(self):
-        return 2 if self.u is None or self.u.shape[0] == 16 else 4
+        return FusedConv.winograd_tile if self.u is None else {16: 2, 36: 4, 64: 6}[self.u.shape[0]]
 
     def _direct(self, x, res, res_mode, relu, naive, res_after_act, post_scale):
         return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,

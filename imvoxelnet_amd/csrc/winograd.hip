@@ -102,6 +102,47 @@ template <typename V> struct Wino1D<4, V> {
   }
 };
 
+// m = 6 (points 0, +-1, +-2, +-1/2, inf): the matrices of the widely used F(6,3) construction
+//   Bt = [1 0 -21/4 0 21/4 0 -1 0; 0 1 1 -17/4 -17/4 1 1 0; 0 -1 1 17/4 -17/4 -1 1 0; 0 1/2 1/4 -5/2 -5/4 2 1 0;
+//         0 -1/2 1/4 5/2 -5/4 -2 1 0; 0 2 4 -5/2 -5 1/2 1 0; 0 -2 4 5/2 -5 -1/2 1 0; 0 -1 0 21/4 0 -21/4 0 1]
+//   At = [1 1 1 1 1 1 1 0; 0 1 -1 2 -2 1/2 -1/2 0; 0 1 1 4 4 1/4 1/4 0; 0 1 -1 8 -8 1/8 -1/8 0; 0 1 1 16 16 1/16 1/16 0;
+//         0 1 -1 32 -32 1/32 -1/32 1]
+//   G  = [1 0 0; -2/9 -2/9 -2/9; -2/9 2/9 -2/9; 1/90 1/45 2/45; 1/90 -1/45 2/45; 32/45 16/45 8/45; 32/45 -16/45 8/45; 0 0 1]
+template <typename V> struct Wino1D<6, V> {
+  static __device__ __forceinline__ void in(const V (&d)[8], V (&t)[8]) {
+    t[0] = (d[0] - d[6]) + 5.25f * (d[4] - d[2]);
+    t[7] = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
+    const V a12 = (d[2] + d[6]) - 4.25f * d[4], b12 = (d[1] + d[5]) - 4.25f * d[3];
+    t[1] = a12 + b12;
+    t[2] = a12 - b12;
+    const V a34 = (d[6] + 0.25f * d[2]) - 1.25f * d[4], b34 = (0.5f * d[1] - 2.5f * d[3]) + 2.0f * d[5];
+    t[3] = a34 + b34;
+    t[4] = a34 - b34;
+    const V a56 = d[6] + 4.0f * (d[2] - 1.25f * d[4]), b56 = (2.0f * d[1] - 2.5f * d[3]) + 0.5f * d[5];
+    t[5] = a56 + b56;
+    t[6] = a56 - b56;
+  }
+  static __device__ __forceinline__ void out(const V (&m)[8], V (&y)[6]) {
+    const V sa = m[1] + m[2], da = m[1] - m[2], sb = m[3] + m[4], db = m[3] - m[4], sc = m[5] + m[6], dc = m[5] - m[6];
+    y[0] = ((m[0] + sa) + sb) + sc;
+    y[1] = (da + 2.0f * db) + 0.5f * dc;
+    y[2] = (sa + 4.0f * sb) + 0.25f * sc;
+    y[3] = (da + 8.0f * db) + 0.125f * dc;
+    y[4] = (sa + 16.0f * sb) + 0.0625f * sc;
+    y[5] = ((da + 32.0f * db) + 0.03125f * dc) + m[7];
+  }
+  static __device__ __forceinline__ void wgt(const float (&g)[3], float (&u)[8]) {
+    u[0] = g[0];
+    u[1] = (-2.0f / 9.0f) * (g[0] + g[1] + g[2]);
+    u[2] = (-2.0f / 9.0f) * (g[0] - g[1] + g[2]);
+    u[3] = (1.0f / 90.0f) * g[0] + (1.0f / 45.0f) * g[1] + (2.0f / 45.0f) * g[2];
+    u[4] = (1.0f / 90.0f) * g[0] - (1.0f / 45.0f) * g[1] + (2.0f / 45.0f) * g[2];
+    u[5] = (32.0f / 45.0f) * g[0] + (16.0f / 45.0f) * g[1] + (8.0f / 45.0f) * g[2];
+    u[6] = (32.0f / 45.0f) * g[0] - (16.0f / 45.0f) * g[1] + (8.0f / 45.0f) * g[2];
+    u[7] = g[2];
+  }
+};
+
 // V = Bt d B.  One thread: VW channels of one (b, tx, ty, z); xi plane stride = all threads.
 template <int MT, int VW>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
@@ -252,7 +293,7 @@ struct WinoDims {
 
 int wino_dims(const ivx_conv_desc *d, int tile, WinoDims *w, const char *who) {
   IVX_REQUIRE(d, "%s: null descriptor", who);
-  IVX_REQUIRE(tile == 2 || tile == 4, "%s: tile must be 2 (F(2x2,3x3)) or 4 (F(4x4,3x3)), got %d", who, tile);
+  IVX_REQUIRE(tile == 2 || tile == 4 || tile == 6, "%s: tile must be 2, 4 or 6 (F(m x m, 3x3)), got %d", who, tile);
   IVX_REQUIRE(d->KD == 3 && d->KH == 3 && d->sd == 1 && d->sh == 1, "%s: needs a 3x3 kernel with stride 1 on the first two axes", who);
   IVX_REQUIRE(d->KW >= 1 && d->KW <= 8 && d->sw >= 1 && d->pd >= 0 && d->ph >= 0 && d->pw >= 0, "%s: bad z kernel / stride / padding", who);
   IVX_REQUIRE(d->B > 0 && d->D > 0 && d->H > 0 && d->W > 0, "%s: non-positive dims", who);
@@ -310,8 +351,10 @@ extern "C" int ivx_conv_winograd_weights(const ivx_conv_desc *d, int32_t tile, c
   const dim3 grid((unsigned)((total + 255) / 256));
   if (tile == 2)
     hipLaunchKernelGGL(wino_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout);
-  else
+  else if (tile == 4)
     hipLaunchKernelGGL(wino_weight_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout);
+  else
+    hipLaunchKernelGGL(wino_weight_kernel<6>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout);
   IVX_CHECK_LAUNCH("ivx_conv_winograd_weights");
   return IVX_OK;
 }
@@ -362,8 +405,10 @@ extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *d, int32_t tile, con
   if (rc != IVX_OK) return rc;
   if (tile == 2)
     hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wino_blocks(w.v_elems / 4)), dim3(256), 0, (hipStream_t)stream, p);
-  else
+  else if (tile == 4)
     hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((wino_input_kernel<6, 2>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
   IVX_CHECK_LAUNCH("ivx_conv_winograd_input");
   return IVX_OK;
 }
@@ -394,8 +439,10 @@ extern "C" int ivx_conv_winograd_output(const ivx_conv_desc *d, int32_t tile, co
   if (rc != IVX_OK) return rc;
   if (tile == 2)
     hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wino_blocks(w.m_elems / 4)), dim3(256), 0, (hipStream_t)stream, p);
-  else
+  else if (tile == 4)
     hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
   IVX_CHECK_LAUNCH("ivx_conv_winograd_output");
   return IVX_OK;
 }

@@ -133,7 +133,7 @@ def _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, r
 
 def conv_winograd_supported(x_shape, Cout, kernel, stride, padding, tile=2):
     """True when ivx_conv_winograd_fwd can run this fp32 convolution (3x3xKW, stride 1 on the first two axes, planes < 2 GiB)."""
-    if kernel[0] != 3 or kernel[1] != 3 or stride[0] != 1 or stride[1] != 1 or x_shape[4] % 4 or Cout % 4 or tile not in (2, 4):
+    if kernel[0] != 3 or kernel[1] != 3 or stride[0] != 1 or stride[1] != 1 or x_shape[4] % 4 or Cout % 4 or tile not in (2, 4, 6):
         return False
     B, D, H, W, Cin = x_shape
     d = _wino_desc(B, D, H, W, Cin, Cout, kernel[2], stride[2], padding, False, 0)
@@ -165,12 +165,12 @@ winograd_trace = None
 def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1, 1, 1), relu=False, res=None, out=None,
                       wgt_layout=0, res_after_act=False, post_scale=1.0):
     """Same result as conv_fwd for a 3x3xkw kernel with stride (1,1,stride_w), computed in the F(m x m, 3x3) minimal-filtering
-    form (fp32).  x [B,D,H,W,Cin]; u from conv_winograd_weights (its first dimension, 16 or 36, selects m = 2 or 4)."""
+    form (fp32).  x [B,D,H,W,Cin]; u from conv_winograd_weights (its first dimension, 16 / 36 / 64, selects m = 2 / 4 / 6)."""
     _chk(x, 'x')
     _chk(u, 'u')
     B, D, H, W, Cin = x.shape
     Cout = u.shape[1]
-    tile = {16: 2, 36: 4}.get(u.shape[0])
+    tile = {16: 2, 36: 4, 64: 6}.get(u.shape[0])
     if tile is None or tuple(u.shape) != ((tile + 2) ** 2, Cout, kw * Cin):
         raise ValueError(f'transformed filters {tuple(u.shape)} do not match kw {kw} / Cin {Cin}')
     d = _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, 1 if res is not None else 0, res_after_act,

@@ -35,3 +35,18 @@ def cl(x):
 def uncl(y):
     """channels-last device [B,D,H,W,C] -> numpy [B,C,D,H,W]."""
     return y.permute(0, 4, 1, 2, 3).contiguous().cpu().numpy()
+
+
+class direct_conv_only:
+    """with direct_conv_only(): FusedConv runs every layer on the direct implicit-GEMM kernel (tests of that kernel's
+    tiles, split-K and tail plans; the Winograd form has its own tests)."""
+
+    def __enter__(self):
+        from imvoxelnet_amd.conv import FusedConv
+        self._old, FusedConv.winograd = FusedConv.winograd, False
+        return self
+
+    def __exit__(self, *exc):
+        from imvoxelnet_amd.conv import FusedConv
+        FusedConv.winograd = self._old
+        return False
