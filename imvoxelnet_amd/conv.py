@@ -63,7 +63,12 @@ class FusedConv:
     # Also a gain on the indoor necks down to a few thousand positions (SUN RGB-D fast 123 -> 159 scenes/s, nuScenes 30.7 -> 38.4);
     # only the coarsest levels (< winograd_min_pos positions) stay direct.
     winograd = os.environ.get('IVX_WINOGRAD', '1') != '0'
-    winograd_tile = int(os.environ.get('IVX_WINOGRAD_TILE', '6'))     # m of F(m x m, 3x3): 2, 4 or 6
+    # m of F(m x m, 3x3): 0 = automatic (6 when a sample's output plane has >= winograd_tile6_min_plane positions on the
+    # transformed axes -- the KITTI / nuScenes necks, full-resolution 2-D maps -- else 4: on the 40 x 40 and 80 x 80 indoor
+    # volumes the 6 x 6 tiles waste up to 10 % at the border and leave too few tiles per plane; measured SUN RGB-D fast
+    # 166 scenes/s with m = 4 vs 157 with m = 6, KITTI 118.6 vs 135.9 images/s); 2, 4 or 6 force one tile everywhere
+    winograd_tile = int(os.environ.get('IVX_WINOGRAD_TILE', '0'))
+    winograd_tile6_min_plane = 16384
     winograd_min_ch = 64
     winograd_2d_min_ch = int(os.environ.get('IVX_WINOGRAD_2D_MIN_CH', '128'))   # 2-D 3x3 layers (ResNet conv2, FPN outputs)
     winograd_min_pos = int(os.environ.get('IVX_WINOGRAD_MIN_POS', '2000'))
@@ -113,7 +118,8 @@ class FusedConv:
                 and self.cout % 4 == 0 and max(self.cin, self.cout) >= min_ch and self.cin % 4 == 0 and type(self) is FusedConv):
             w0 = w.permute(0, 2, 3, 4, 1).contiguous()                       # [Cout,kd,kh,kw,Cin]
             self._w0_host = w0.reshape(self.cout, 3, 3, 1, self.cin) if self._wino2d else w0
-        self.u = None
+        self.u = None          # {tile: transformed filters}, filled by to() / on first use of a tile
+        self._w0 = None
         scale = torch.ones(self.cout)
         shift = torch.zeros(self.cout)
         if bias is not None:
@@ -131,7 +137,10 @@ class FusedConv:
     def to(self, device):
         self.w = self._w_host.to(device)
         if self._w0_host is not None and FusedConv.winograd:
-            self.u = ops.conv_winograd_weights(self._w0_host.to(device), self.layout, FusedConv.winograd_tile)
+            self._w0 = self._w0_host.to(device)        # tap-major filters stay resident: a tile's filters are made on first use
+            self.u = {}
+            if FusedConv.winograd_tile:
+                self._filters(FusedConv.winograd_tile)
         if not self._identity_epilogue:
             self.scale = self._scale_host.to(device)
             self.shift = self._shift_host.to(device)
@@ -148,12 +157,13 @@ class FusedConv:
             xs, wk, wst, wpad = (B, x.shape[2], x.shape[3], 1, self.cin), (3, 3, 1), (1, 1, 1), (self.padding[1], self.padding[2], 0)
         else:
             xs, wk, wst, wpad = tuple(x.shape), self.kernel, self.stride, self.padding
-        wino = wino and ops.conv_winograd_supported(xs, self.cout, wk, wst, wpad, self._tile())
+        m = FusedConv.winograd_tile or (6 if (xs[1] + 2 * wpad[0] - 2) * (xs[2] + 2 * wpad[1] - 2) >= FusedConv.winograd_tile6_min_plane
+                                        else 4)
+        wino = wino and ops.conv_winograd_supported(xs, self.cout, wk, wst, wpad, m)
         if FusedConv.count_flops:
             od, oh, ow = ((x.shape[1 + a] + 2 * self.padding[a] - self.kernel[a]) // self.stride[a] + 1 for a in range(3))
             direct = 2.0 * x.shape[0] * od * oh * ow * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
             FusedConv.flops += direct
-            m = self._tile()
             t1, t2, t3 = (oh, ow, 1) if self._wino2d else (od, oh, ow)
             FusedConv.exec_flops += (2.0 * (m + 2) ** 2 * x.shape[0] * ((t1 + m - 1) // m) * ((t2 + m - 1) // m) * t3 * self.cout *
                                      self.cin * wk[2]) if wino else direct
@@ -162,10 +172,9 @@ class FusedConv:
                 ops.winograd_trace = []
             xv = x.view(xs)
             rv = None if res is None else res.view(B, res.shape[2], res.shape[3], 1, self.cout) if self._wino2d else res
-            y = ops.conv_winograd_fwd(xv, self.u, self.scale, self.shift, wk[2], wst[2], wpad, self.relu if relu is None else relu,
+            y = ops.conv_winograd_fwd(xv, self._filters(m), self.scale, self.shift, wk[2], wst[2], wpad, self.relu if relu is None else relu,
                                       rv, wgt_layout=self.layout, res_after_act=res_after_act, post_scale=post_scale)
             if FusedConv.trace is not None:
-                m = self._tile()
                 tiles = y.shape[0] * ((y.shape[1] + m - 1) // m) * ((y.shape[2] + m - 1) // m)
                 v_bytes = 4.0 * (m + 2) ** 2 * tiles * xv.shape[3] * self.cin      # transformed input: (m+2)^2 planes [tiles, Z, Cin]
                 m_bytes = 4.0 * (m + 2) ** 2 * tiles * y.shape[3] * self.cout      # (m+2)^2 partial outputs [tiles, Zo, Cout]
@@ -184,8 +193,10 @@ class FusedConv:
             return y
         return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
 
-    def _tile(self):
-        return FusedConv.winograd_tile if self.u is None else {16: 2, 36: 4, 64: 6}[self.u.shape[0]]
+    def _filters(self, tile):
+        if tile not in self.u:
+            self.u[tile] = ops.conv_winograd_weights(self._w0, self.layout, tile)
+        return self.u[tile]
 
     def _direct(self, x, res, res_mode, relu, naive, res_after_act, post_scale):
         return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,

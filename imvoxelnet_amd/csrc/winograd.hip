@@ -1,10 +1,10 @@
-// Winograd minimal filtering F(m x m, 3x3), m = 2 or 4, over the first two spatial axes of a channels-last 3-D convolution
+// Winograd minimal filtering F(m x m, 3x3), m = 2, 4 or 6, over the first two spatial axes of a channels-last 3-D convolution
 // (gfx950).
 //
 // The 3-D necks (mmdet3d/models/necks/imvoxelnet.py:99-113,181-230) are 3x3x3 convolutions on volumes that are wide in
 // (x, y) and shallow in z (12 / 6 / 3 slices), and their 128- and 256-channel layers are bound by the fp32 MFMA rate.
 // With n = m + 2, the minimal-filtering form over (x, y) needs n*n multiplications per m x m output tile and z-tap
-// instead of 9*m*m (16 vs 36 for m = 2, 36 vs 144 for m = 4):
+// instead of 9*m*m (16 vs 36 for m = 2, 36 vs 144 for m = 4, 64 vs 324 for m = 6):
 //
 //   V[xi][b,tx,ty,z,:]  = (Bt d B)[i][j]          d = n x n input patch at x = m*tx - pd + i, y = m*ty - ph + j   (xi = n*i + j)
 //   U[xi][co,kz,:]      = (G g Gt)[i][j]          g = the 3x3 (kd,kh) slice of the filter for z-tap kz
@@ -12,10 +12,10 @@
 //   out[b,m*tx+a,m*ty+e] = epilogue((At M A)[a][e])
 //
 // The n*n convolutions of M run as ONE grouped launch of the LDS-DMA implicit-GEMM kernel (conv_igemm.hip, grid.z = xi);
-// the two transforms are streaming kernels (one thread per 4 (m = 2) or 2 (m = 4) channels).  The z axis stays a direct
+// the two transforms are streaming kernels (one thread per 4 (m = 2) or 2 (m = 4, 6) channels).  The z axis stays a direct
 // convolution because it is too shallow to tile.  Arithmetic is fp32 throughout; the result differs from the direct form
-// by fp32 rounding only: measured max deviation / max|out| on a 256-channel layer 6e-7 (m = 2) and 1e-5 (m = 4, whose
-// transforms carry the interpolation points +-2) against 2e-6 for the direct fp32 sum (tests/test_gpu_kernels.py).
+// by fp32 rounding only: measured max deviation from the direct MFMA kernel on the KITTI neck layers, as a fraction of the
+// output range: m = 2 up to 4e-6, m = 4 up to 2.4e-5, m = 6 up to 4e-5 (profiles/r01_conv_layers.log).
 #include "ivx_common.h"
 
 int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w,

@@ -100,12 +100,12 @@ int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const void *wgt, con
 int ivx_conv_fwd_naive(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
                        const float *shift, const void *res, void *out, ivx_stream_t stream);
 
-/* Minimal-filtering (Winograd F(m x m, 3x3), tile m = 2 or 4) form of the same convolution for 3x3xKW kernels with stride 1
- * on the first two spatial axes (D, H) -- the 128- / 256-channel layers of the KITTI / nuScenes necks
+/* Minimal-filtering (Winograd F(m x m, 3x3), tile m = 2, 4 or 6) form of the same convolution for 3x3xKW kernels with
+ * stride 1 on the first two spatial axes (D, H) -- the 3x3x3 layers of the KITTI / nuScenes necks
  * (mmdet3d/models/necks/imvoxelnet.py:99-113,181-230), which are bound by the fp32 MFMA rate: (m+2)^2 instead of 9*m*m
- * multiplications per m x m output tile and W-tap (16 vs 36 for tile 2, 36 vs 144 for tile 4).  Same contract, epilogue and
- * fp32 arithmetic as ivx_conv_fwd; the result differs by fp32 rounding only (tile 2: at the level of the direct sum; tile 4:
- * about 5x the direct sum's rounding error, 1e-5 of the output range on a 256-channel layer).  The W axis keeps its kernel
+ * multiplications per m x m output tile and W-tap (16 vs 36, 36 vs 144, 64 vs 324).  Same contract, epilogue and fp32
+ * arithmetic as ivx_conv_fwd; the result differs by fp32 rounding only (max deviation from the direct kernel on a
+ * 256-channel layer, as a fraction of the output range: tile 2 4e-6, tile 4 2e-5, tile 6 4e-5).  The W axis keeps its kernel
  * extent, stride and padding as a direct convolution.
  * Restrictions: KD = KH = 3, sd = sh = 1, fp32, out_mode 0, res_mode 0/1, Cin % 4 == 0, Cout % 4 == 0, and one transformed
  * plane [B, ceil(Do/m), ceil(Ho/m), W, Cin] below 2 GiB (ivx_conv_winograd_supported returns 1 when all hold).

@@ -858,7 +858,7 @@ def test_conv_winograd_fused_conv_switch(ia):
         y = f(x, res=res)
     finally:
         FusedConv.count_flops = False
-    m = FusedConv.winograd_tile
+    m = FusedConv.winograd_tile or (6 if 108 * 124 >= FusedConv.winograd_tile6_min_plane else 4)
     tiles = -(-108 // m) * -(-124 // m)
     assert abs(FusedConv.exec_flops / FusedConv.flops - (m + 2) ** 2 * tiles / (9.0 * 108 * 124)) < 1e-6   # the minimal-filtering path ran
     old = FusedConv.winograd

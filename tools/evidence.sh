@@ -14,7 +14,7 @@ IVX_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-no
     bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_dist1.json
 for c in nuscenes sunrgbd_fast scannet_fast scannet_v1; do python bench.py --config $c --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT/other.jsonl; done
 for c in scannet_v1 scannet_fast sunrgbd_fast; do python bench.py --config $c --storage bf16 --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl; done
-python tools/conv_bench.py --winograd --tile 4 --iters 3 --layers 0,1,2,3,4,5 > $OUT/conv_layers.log 2>&1
+for t in 2 4 6; do python tools/conv_bench.py --winograd --tile $t --iters 3 --layers 0,1,2,3,4,5 2>&1 | grep -v amdgpu.ids; done > $OUT/conv_layers.log
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $ROOT/$OUT/trace_bench.log 2>&1)
 tail -1 $OUT/trace_bench.log > $OUT/bench_profiled.json
 DB=$(find $OUT/trace -name "*.db" | head -1)
