@@ -9,8 +9,9 @@ A step = one pass of the hot path (ImVoxelNet.simple_test: ResNet-50 + FPN -> un
 batch of synthetic KITTI-shaped input already resident in HBM.  Workload = BASELINE.json configs[1]:
 1 view 3x384x1280, 216x248x12 voxels, batch 4 per GPU, fp32 (the reference's arithmetic type).
 
-Prints ONE JSON line (rank 0) with `roofline` (the conv kernel on the 3-D neck, measured live with HIP events
-on the launch stream inside the timed region) and, at N == 1, `cpu_baseline` (the oracle's torch-fp32/C port of
+Prints ONE JSON line (rank 0) with `roofline` (the implicit-GEMM kernel over its launches on the 3-D neck -- executed
+FLOPs, the neck runs in the Winograd F(6x6,3x3) form -- measured live with HIP events on the launch stream inside the timed
+region), `roofline_winograd_transforms` (the HBM-bound transform kernels around those launches) and, at N == 1, `cpu_baseline` (the oracle's torch-fp32/C port of
 the same path timed on this box's host cores on one image).
 """
 import argparse
@@ -309,11 +310,11 @@ def main():
     lift_ms = sum(ev[i][2].elapsed_time(ev[i][0]) for i in ev_ids) / len(neck_ms)
     # unprojection: algorithmic bytes = features read once + volume written once + mask (173.1 MB/sample)
     lift_bytes = B * (1 * 64 * 96 * 320 * esz + 64 * 216 * 248 * 12 * esz + 216 * 248 * 12)
-    # The nine conv layers of KittiImVoxelNeck.  Layers with >= 128 channels run in the F(2x2,3x3) minimal-filtering form
+    # The nine conv layers of KittiImVoxelNeck.  They run in the F(6x6,3x3) minimal-filtering form
     # (imvoxelnet_amd/csrc/winograd.hip): input transform -> ONE grouped launch of the implicit-GEMM kernel -> output
     # transform.  The roofline entry is the implicit-GEMM kernel over its nine launches per step (direct layers: the conv
-    # itself; Winograd layers: the grouped GEMM), with the FLOPs the kernel EXECUTES (16/36 of the direct count for a
-    # Winograd layer) over the event-bracketed duration of exactly those launches; direct_equivalent_tflops divides the
+    # itself; Winograd layers: the grouped GEMM), with the FLOPs the kernel EXECUTES (64/324 of the direct count for an
+    # F(6x6,3x3) layer) over the event-bracketed duration of exactly those launches; direct_equivalent_tflops divides the
     # direct-convolution FLOPs of the whole neck by the whole neck time (it may exceed the MFMA peak).
     n_launch = 9
     flops_step = neck_flops_per_sample((216, 248, 12), 64, 256) * B

@@ -57,11 +57,11 @@ class FusedConv:
     flops = 0.0
     exec_flops = 0.0
     # fp32 3x3xk layers with stride 1 on the first two axes, >= winograd_min_ch input or output channels and
-    # >= winograd_min_pos input positions run as F(m x m, 3x3) (ivx_conv_winograd_fwd), m = winograd_tile.  Measured on the
-    # KITTI neck (batch 4, tools/conv_bench.py --winograd), direct -> m = 2 -> m = 4 in ms: 256->256 16.1 -> 9.1 -> 5.3,
-    # 128->128 8.2 -> 5.7 -> 3.3, 128->256 (z stride 2) 8.2 -> 5.6 -> 3.3, 64->128 4.6 -> 3.9 -> 2.3, 64->64 4.8 -> 4.3 -> 2.6.
-    # Also a gain on the indoor necks down to a few thousand positions (SUN RGB-D fast 123 -> 159 scenes/s, nuScenes 30.7 -> 38.4);
-    # only the coarsest levels (< winograd_min_pos positions) stay direct.
+    # >= winograd_min_pos input positions run as F(m x m, 3x3) (ivx_conv_winograd_fwd).  Measured on the KITTI neck
+    # (batch 4, tools/conv_bench.py --winograd, profiles/r01_conv_layers.log), direct -> m = 2 -> 4 -> 6 in ms:
+    # 256->256 16.1 -> 9.0 -> 5.3 -> 4.3, 128->128 8.2 -> 5.7 -> 3.3 -> 2.7, 64->128 (z stride 2) 4.6 -> 3.9 -> 2.3 -> 1.9,
+    # 64->64 4.8 -> 4.3 -> 2.6 -> 2.2.  Also a gain on the indoor necks down to a few thousand positions (SUN RGB-D fast
+    # 123 -> 165 scenes/s); only the coarsest levels (< winograd_min_pos positions) stay direct.
     winograd = os.environ.get('IVX_WINOGRAD', '1') != '0'
     # m of F(m x m, 3x3): 0 = automatic (6 when a sample's output plane has >= winograd_tile6_min_plane positions on the
     # transformed axes -- the KITTI / nuScenes necks, full-resolution 2-D maps -- else 4: on the 40 x 40 and 80 x 80 indoor

@@ -805,7 +805,7 @@ def test_unprojection_randomized_cameras_bit_exact(ia):
 ])
 @pytest.mark.parametrize('tile', [2, 4, 6])
 def test_conv_winograd_matches_direct(ia, case, tile):
-    """ivx_conv_winograd_fwd (F(2x2,3x3) / F(4x4,3x3) over the first two axes, grouped implicit-GEMM launch) against the
+    """ivx_conv_winograd_fwd (F(m x m, 3x3), m = 2 / 4 / 6, over the first two axes, grouped implicit-GEMM launch) against the
     one-thread-per-output validation kernel and torch conv3d (fp64) on the same inputs: same contract, fp32 rounding
     differences only (<= 1e-4 of the output range)."""
     from imvoxelnet_amd import ops

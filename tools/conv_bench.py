@@ -115,7 +115,7 @@ def main():
             print(f'{name:24s} layout {lay} cfg {cfg}: {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s  ({flops / 1e9:.0f} GFLOP)', flush=True)
         L.ivx_conv_set_tile_override(0)
         if a.winograd and a.dtype == 'f32' and st[0] == 1 and st[1] == 1:
-            # the same layer in the F(2x2,3x3) form: per-stage times from the staged entry points
+            # the same layer in the F(m x m, 3x3) form: per-stage times from the staged entry points
             w0 = w if lay == 0 else w.permute(0, 2, 3, 4, 1, 5).reshape(co, 3, 3, 3, ci).contiguous()
             u = ops.conv_winograd_weights(w0, lay, a.tile)
             for wcfg in [int(v) for v in a.wcfgs.split(',')]:      # tile override of the grouped GEMM
