@@ -204,8 +204,6 @@ class FusedConv:
                             out_mode=self.out_mode, res_after_act=res_after_act, post_scale=post_scale,
                             out_dtype=self.out_dtype)
 
-    def flops(self, out_positions):
-        return 2.0 * out_positions * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
 
 
 class FusedConvTranspose2x(FusedConv):
