@@ -73,8 +73,9 @@ class FusedConv:
     winograd_2d_min_ch = int(os.environ.get('IVX_WINOGRAD_2D_MIN_CH', '128'))   # 2-D 3x3 layers (ResNet conv2, FPN outputs)
     winograd_min_pos = int(os.environ.get('IVX_WINOGRAD_MIN_POS', '2000'))
     # optional per-call timing (bench.py): when a list, every call appends
-    # (kind, start_event, end_event, executed_flops, bytes) with kind 'direct' | 'wino_input' | 'wino_gemm' | 'wino_output';
-    # the events bracket exactly the launches of that stage on the current stream
+    # (kind, start_event, end_event, executed_flops, bytes, is_3d) with kind 'direct' | 'wino_input' | 'wino_gemm' |
+    # 'wino_output'; the events bracket exactly the launches of that stage on the stream they run on; is_3d tells the 3-D
+    # neck layers from the 2-D trunk
     trace = None
 
     def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, relu=False, dims=3, eps=1e-5, layout=None,
@@ -149,17 +150,11 @@ class FusedConv:
     def __call__(self, x, res=None, res_mode=0, relu=None, naive=False, res_after_act=False, post_scale=1.0):
         if self.w is None:
             raise RuntimeError('FusedConv.to(device) must be called before use')
-        wino = (self.u is not None and FusedConv.winograd and not naive and res_mode in (0, 1) and x.dtype == torch.float32
-                and x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] >= FusedConv.winograd_min_pos)
-        # the convolution as the Winograd entry points see it: transformed axes first, direct axis last
         B = x.shape[0]
-        if self._wino2d:
-            xs, wk, wst, wpad = (B, x.shape[2], x.shape[3], 1, self.cin), (3, 3, 1), (1, 1, 1), (self.padding[1], self.padding[2], 0)
-        else:
-            xs, wk, wst, wpad = tuple(x.shape), self.kernel, self.stride, self.padding
-        m = FusedConv.winograd_tile or (6 if (xs[1] + 2 * wpad[0] - 2) * (xs[2] + 2 * wpad[1] - 2) >= FusedConv.winograd_tile6_min_plane
-                                        else 4)
-        wino = wino and ops.conv_winograd_supported(xs, self.cout, wk, wst, wpad, m)
+        m, xs, wk, wst, wpad = self.wino_tile(tuple(x.shape), x.dtype, res_mode, naive)
+        wino = m > 0
+        if not wino:
+            m = FusedConv.winograd_tile or 6      # only used by the executed-FLOP accounting below (not reached: wino False)
         if FusedConv.count_flops:
             od, oh, ow = ((x.shape[1 + a] + 2 * self.padding[a] - self.kernel[a]) // self.stride[a] + 1 for a in range(3))
             direct = 2.0 * x.shape[0] * od * oh * ow * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
@@ -180,7 +175,7 @@ class FusedConv:
                 m_bytes = 4.0 * (m + 2) ** 2 * tiles * y.shape[3] * self.cout      # (m+2)^2 partial outputs [tiles, Zo, Cout]
                 by = {'input': 4.0 * x.numel() + v_bytes, 'gemm': v_bytes + m_bytes,
                       'output': m_bytes + 4.0 * y.numel() * (2 if res is not None else 1)}
-                FusedConv.trace += [('wino_' + n, e0, e1, fl, by[n]) for n, e0, e1, fl in ops.winograd_trace]
+                FusedConv.trace += [('wino_' + n, e0, e1, fl, by[n], x.shape[1] > 1) for n, e0, e1, fl in ops.winograd_trace]
                 ops.winograd_trace = None
             return y.view(B, 1, y.shape[1], y.shape[2], self.cout) if self._wino2d else y
         if FusedConv.trace is not None:
@@ -189,9 +184,25 @@ class FusedConv:
             y = self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
             e1.record()
             FusedConv.trace.append(('direct', e0, e1, 2.0 * y.numel() * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
-                                    if self.out_mode == 0 else 2.0 * x.numel() * self.cout, 0.0))
+                                    if self.out_mode == 0 else 2.0 * x.numel() * self.cout, 0.0, x.shape[1] > 1))
             return y
         return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
+
+    def wino_tile(self, x_shape, dtype=torch.float32, res_mode=0, naive=False):
+        """-> (m, xs, wk, wst, wpad): m = tile of the F(m x m, 3x3) form this layer takes for an input of shape x_shape
+        (0: the direct kernel), and the convolution as the Winograd entry points see it (transformed axes first, direct
+        axis last; a 2-D 3x3 layer [B,1,H,W,C] is the view [B,H,W,1,C] with a 3x3x1 kernel)."""
+        B = x_shape[0]
+        if self._wino2d:
+            xs, wk, wst, wpad = (B, x_shape[2], x_shape[3], 1, self.cin), (3, 3, 1), (1, 1, 1), (self.padding[1], self.padding[2], 0)
+        else:
+            xs, wk, wst, wpad = tuple(x_shape), self.kernel, self.stride, self.padding
+        ok = (self.u is not None and FusedConv.winograd and not naive and res_mode in (0, 1) and dtype == torch.float32
+              and x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3] >= FusedConv.winograd_min_pos)
+        m = FusedConv.winograd_tile or (6 if (xs[1] + 2 * wpad[0] - 2) * (xs[2] + 2 * wpad[1] - 2) >= FusedConv.winograd_tile6_min_plane
+                                        else 4)
+        ok = ok and ops.conv_winograd_supported(xs, self.cout, wk, wst, wpad, m)
+        return (m if ok else 0), xs, wk, wst, wpad
 
     def _filters(self, tile):
         if tile not in self.u:

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void backproject_mean_kernel(const BpParams p)
   const float px = __fadd_rn(__fmul_rn((float)i, p.vs0), no[0]);
   const float py = __fadd_rn(__fmul_rn((float)j, p.vs1), no[1]);
   const float pz = __fadd_rn(__fmul_rn((float)k, p.vs2), no[2]);
-  const int hc = p.crop_hw[b * 2 + 0], wc = p.crop_hw[b * 2 + 1];
+  const int hc = min(p.crop_hw[b * 2 + 0], p.FH), wc = min(p.crop_hw[b * 2 + 1], p.FW);   // slice semantics (detectors/imvoxelnet.py:69): clamped to the map
 
   constexpr int MAXCH = 4;  // channel chunks per lane when ceil(C/VEC) > 64 lanes (C up to 1024 for VEC 4)
   float acc[MAXCH][VEC];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void backproject_single_view_kernel(const BpPa
     const float px = __fadd_rn(__fmul_rn((float)i, p.vs0), no[0]);
     const float py = __fadd_rn(__fmul_rn((float)j, p.vs1), no[1]);
     const float pz = __fadd_rn(__fmul_rn((float)k, p.vs2), no[2]);
-    const int hc = p.crop_hw[b * 2 + 0], wc = p.crop_hw[b * 2 + 1];
+    const int hc = min(p.crop_hw[b * 2 + 0], p.FH), wc = min(p.crop_hw[b * 2 + 1], p.FW);   // slice semantics (detectors/imvoxelnet.py:69): clamped to the map
     const float *P = p.proj + (size_t)b * 12;
     float u = __fmul_rn(P[0], px);
     u = __fmaf_rn(P[1], py, u);

@@ -103,14 +103,16 @@ class _ImVoxelHeadBase(nn.Module):
         no = torch.stack([torch.tensor(m['lidar2img']['origin']).float() - nv / 2. * vs for m in img_metas])
         return vs.unsqueeze(0).expand(len(img_metas), 3).contiguous().to(device), no.contiguous().to(device)
 
-    def get_candidates_cl(self, fused, valid, img_metas, scales=None):
-        """-> per-sample (boxes [n,R], scores [n,ncls]) concatenated over levels (device tensors)."""
+    def get_candidates_cl(self, fused, valid, img_metas, scales=None, want_index=False):
+        """-> per-sample (boxes [n,R], scores [n,ncls]) concatenated over levels (device tensors).
+        want_index (parity tests): also the source location of every candidate, int64 [n] = level * 2^32 + flat voxel
+        index inside the level grid (the top-k indices the tail leaves in its workspace)."""
         cfg = self.test_cfg
         B = fused[0].shape[0]
         v0 = valid.reshape(B, *valid.shape[-3:]).to(torch.uint8).contiguous()
         X, Y, Z = v0.shape[1:]
         L = _lib.lib()
-        boxes_l, scores_l = [], []
+        boxes_l, scores_l, index_l = [], [], []
         for lvl, f in enumerate(fused):
             nx, ny, nz, CH = f.shape[1:]
             n = nx * ny * nz
@@ -130,7 +132,15 @@ class _ImVoxelHeadBase(nn.Module):
                 ops._stream()), 'ivx_fcos_head_level_candidates')
             boxes_l.append(cb)
             scores_l.append(cs)
+            if want_index:   # workspace layout of ivx_fcos_head_level_candidates: keys [B,n] f32 | top-k indices [B,kpad] i32 | ...
+                kpad = 1 << (max(k, 64) - 1).bit_length()
+                off = (B * n * 4 + 255) // 256 * 256
+                topk = ws[off:off + B * kpad * 4].view(torch.int32).view(B, kpad)[:, :k]
+                index_l.append(topk.to(torch.int64) + (lvl << 32))
         boxes, scores = torch.cat(boxes_l, 1), torch.cat(scores_l, 1)
+        if want_index:
+            index = torch.cat(index_l, 1)
+            return [(boxes[b], scores[b], index[b]) for b in range(B)]
         return [(boxes[b], scores[b]) for b in range(B)]
 
     def get_bboxes_cl(self, fused, valid, img_metas, scales=None):

@@ -216,6 +216,49 @@ def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1
     return out
 
 
+class WinogradLayerPlan:
+    """One fp32 3x3xkw layer in the F(m x m, 3x3) form for a fixed input shape: descriptor, output shape and workspace
+    size, with the three stages as separate calls on caller-owned buffers (pipeline.py runs the transform stages of one
+    batch chunk beside the grouped GEMM of another on a second stream)."""
+
+    def __init__(self, x_shape, Cout, kw, stride_w, padding, relu, wgt_layout, tile, has_res=False, res_after_act=False,
+                 post_scale=1.0):
+        B, D, H, W, Cin = x_shape
+        self.tile = int(tile)
+        self.d = _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, 1 if has_res else 0, res_after_act,
+                            post_scale)
+        do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
+        L = _lib.lib()
+        check(L.ivx_conv_out_dims(C.byref(self.d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')
+        self.x_shape = tuple(x_shape)
+        self.oshape = (B, do.value, ho.value, wo.value, Cout)
+        self.ws_bytes = L.ivx_conv_winograd_workspace_bytes(C.byref(self.d), self.tile)
+        if self.ws_bytes < 0:
+            check(-1, 'ivx_conv_winograd_workspace_bytes')
+        n2 = (self.tile + 2) ** 2
+        tiles = B * ((self.oshape[1] + tile - 1) // tile) * ((self.oshape[2] + tile - 1) // tile)
+        self.gemm_flops = 2.0 * n2 * tiles * self.oshape[3] * Cout * kw * Cin
+        self.v_bytes = 4.0 * n2 * tiles * W * Cin
+        self.m_bytes = 4.0 * n2 * tiles * self.oshape[3] * Cout
+
+    def input(self, x, ws):
+        check(_lib.lib().ivx_conv_winograd_input(C.byref(self.d), self.tile, _ptr(x), _ptr(ws), ws.numel(), _stream()),
+              'ivx_conv_winograd_input')
+
+    def gemm(self, u, ws):
+        check(_lib.lib().ivx_conv_winograd_gemm(C.byref(self.d), self.tile, _ptr(u), _ptr(ws), ws.numel(), _stream()),
+              'ivx_conv_winograd_gemm')
+
+    def output(self, scale, shift, res, out, ws):
+        check(_lib.lib().ivx_conv_winograd_output(C.byref(self.d), self.tile, _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _ptr(ws),
+                                                  ws.numel(), _stream()), 'ivx_conv_winograd_output')
+
+
+def winograd_set_transform_blocks(n):
+    """n > 0: cap the grid of the Winograd transform kernels at n workgroups (this thread); 0 = default."""
+    check(_lib.lib().ivx_conv_winograd_set_transform_blocks(int(n)), 'ivx_conv_winograd_set_transform_blocks')
+
+
 def maxpool2d(x, k=3, s=2, p=1):
     if x.dtype not in _DT:
         raise TypeError(f'x must be float32 or bfloat16, got {x.dtype}')

@@ -132,6 +132,10 @@ int ivx_conv_winograd_fwd(const ivx_conv_desc *d, int32_t tile, const void *in, 
 /* Tuning knob for A/B experiments only (per calling thread): 0 = automatic tile choice (default); 1..7 force a tile
  * of the generic kernel, 41..53 of the LDS-DMA fp32 kernel, 61..73 of its bf16 instantiation. */
 int ivx_conv_set_tile_override(int cfg);
+/* Per calling thread: n > 0 caps the grid of the Winograd transform kernels (grid-stride loops) at n workgroups, so a
+ * transform launch leaves most workgroup slots free and can run beside the MFMA-bound grouped GEMM of another sample on a
+ * second stream; 0 (default) = one workgroup per 256 work items. */
+int ivx_conv_winograd_set_transform_blocks(int n);
 
 /* Modulated deformable convolution (DCNv2; mmcv ModulatedDeformConv2dPack, deform_groups = 1) -- nuScenes reference
  * backbone, configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14.  Builds the modulated, bilinearly sampled columns

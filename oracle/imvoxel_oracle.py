@@ -482,11 +482,13 @@ def fcos_head_forward(xs, sd, n_reg, n_convs=0, prefix=''):
     return cs, bs, ss
 
 
-def fcos_get_bboxes_single(cs, bs, ss, valid, origin, voxel_size, n_reg, cfg):
+def fcos_get_bboxes_single(cs, bs, ss, valid, origin, voxel_size, n_reg, cfg, return_candidates=False):
     """get_bboxes + _get_bboxes_single for ONE sample (v2:216-285): cs/bs/ss are per-level [C,nx,ny,nz] tensors,
-    valid [1,X,Y,Z] float.  Returns (boxes [n, 7], scores, labels) with the box tensor as the box object holds it."""
+    valid [1,X,Y,Z] float.  Returns (boxes [n, 7], scores, labels) with the box tensor as the box object holds it.
+    return_candidates: additionally (cand_boxes [m,R], cand_scores [m,ncls], cand_index [m] = level * 2^32 + flat voxel
+    index) -- the concatenated per-level top-k lists the NMS works on (index-parity tests)."""
     n_classes = ss[0].shape[0]
-    mb, ms = [], []
+    mb, ms, mi = [], [], []
     for lvl, (c, b, s) in enumerate(zip(cs, bs, ss)):
         shape = c.shape[-3:]
         v = F.interpolate(valid[None], size=tuple(shape), mode='trilinear', align_corners=False)[0].round().bool()
@@ -498,9 +500,11 @@ def fcos_get_bboxes_single(cs, bs, ss, valid, origin, voxel_size, n_reg, cfg):
         vf = v.permute(1, 2, 3, 0).reshape(-1)
         sc = sc * ctr[:, None] * vf[:, None]
         mx, _ = sc.max(dim=1)
+        ids = torch.arange(len(sc))
         if len(sc) > cfg['nms_pre'] > 0:
             _, ids = mx.topk(cfg['nms_pre'])
             bp, sc, pts = bp[ids], sc[ids], pts[ids]
+        mi.append(ids.to(torch.int64) + (lvl << 32))
         if n_reg == 6:      # ScanNet (v2:547-555)
             box = torch.stack([pts[:, 0] - bp[:, 0], pts[:, 1] - bp[:, 2], pts[:, 2] - bp[:, 4],
                                pts[:, 0] + bp[:, 1], pts[:, 1] + bp[:, 3], pts[:, 2] + bp[:, 5]], -1)
@@ -512,6 +516,7 @@ def fcos_get_bboxes_single(cs, bs, ss, valid, origin, voxel_size, n_reg, cfg):
         mb.append(box)
         ms.append(sc)
     boxes, scores = torch.cat(mb), torch.cat(ms)
+    cand = (boxes.clone(), scores.clone(), torch.cat(mi))
     if n_reg == 6:          # ScanNet _nms (v2:528-545)
         scores, labels = scores.max(dim=1)
         ids = scores > cfg['score_thr']
@@ -530,4 +535,6 @@ def fcos_get_bboxes_single(cs, bs, ss, valid, origin, voxel_size, n_reg, cfg):
                                                         cfg['use_rotate_nms'], cfg['nms_thr'])
     boxes = boxes.clone()
     boxes[:, 2] = boxes[:, 2] - boxes[:, 5] * 0.5                                   # origin (.5,.5,.5) -> (.5,.5,0) (base_box3d.py:63-66)
+    if return_candidates:
+        return boxes, scores, labels, cand
     return boxes, scores, labels

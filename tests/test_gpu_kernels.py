@@ -303,6 +303,22 @@ def test_unprojection_fullsize_kitti(ia):
     assert torch.equal(v1, m1.unsqueeze(-1).float().expand_as(v1))
 
 
+def test_unprojection_crop_larger_than_map_is_clamped(ia):
+    """A meta whose img_shape // 4 exceeds the padded feature map (stale metas): the reference's slice
+    feature[:, :, :h, :w] clamps to the tensor (detectors/imvoxelnet.py:67-69), so the result equals the full-map crop --
+    no out-of-bounds gather."""
+    from imvoxelnet_amd import ops
+    c = sub(load_npz('backproject_cases.npz'), 'A::')
+    P = torch.from_numpy(c['projection'])[None].cuda().contiguous()
+    nv, vs = c['n_voxels'], c['voxel_size']
+    new_origin = (torch.from_numpy(c['origin']) - torch.tensor(nv) / 2. * torch.from_numpy(vs))[None].cuda().contiguous()
+    feat = cl(c['feat'])
+    FH, FW = feat.shape[2], feat.shape[3]
+    full = ops.backproject_mean(feat, P, new_origin, torch.tensor([[FH, FW]], dtype=torch.int32).cuda(), vs, nv)
+    over = ops.backproject_mean(feat, P, new_origin, torch.tensor([[FH + 9, FW + 1000]], dtype=torch.int32).cuda(), vs, nv)
+    assert torch.equal(full[0], over[0]) and torch.equal(full[1], over[1])
+
+
 def test_unprojection_multiview_indoor(ia):
     """20 views, C=256 (ScanNet-fast shape, smaller grid): the wave-shuffle view distribution path."""
     from imvoxelnet_amd import ops
