@@ -178,6 +178,50 @@ def bench_other(args, ia, kc, dev, rank, world):
     print(json.dumps(rec))
 
 
+def self_launch(n):
+    """Re-exec this command under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def bench_dry(args, rank, world):
+    """--dry: the launch / sharding / collection plumbing of the N > 1 path without a GPU (CPU test with --backend gloo):
+    every rank takes its slice of a synthetic global batch of detections, the slices are all-gathered exactly as in the
+    timed step, rank 0 checks the reassembled batch and prints the JSON line (value is NOT a measurement)."""
+    from imvoxelnet_amd import dist as ivx_dist
+    B, M = args.batch, 50
+    g = torch.Generator().manual_seed(7)
+    gb, gs = torch.randn(B * world, M, 7, generator=g), torch.rand(B * world, M, generator=g)
+    gl, gc = torch.randint(0, 3, (B * world, M), generator=g), torch.randint(0, M + 1, (B * world,), generator=g, dtype=torch.int32)
+    a, b = ivx_dist.shard_range(B * world, rank, world)
+    multi = dist.is_available() and dist.is_initialized()
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        boxes, scores, labels, count = ivx_dist.all_gather_detections(gb[a:b], gs[a:b], gl[a:b], gc[a:b])
+    if multi:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.equal(boxes, gb) and torch.equal(scores, gs) and torch.equal(labels, gl) and torch.equal(count, gc))
+    if rank == 0:
+        print(json.dumps({'metric': 'images/sec/node (KITTI 3x384x1280, 216x248x12 vox)', 'value': 0.0, 'unit': 'images/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / (args.steps + args.warmup) * 1e3, 3),
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'dry': True, 'gathered_ok': ok,
+                          'config': {'workload': 'plumbing only (no GPU work)', 'batch_per_gpu': B, 'global_batch': B * world,
+                                     'parallelism': f'dp{world}', 'backend': args.backend}}))
+    if multi:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit('dry run: the all-gathered batch differs from the global batch')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -185,6 +229,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='samples per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-repeats', type=int, default=3, help='timed images of the cpu_baseline leg (after one warm-up image)')
     ap.add_argument('--config', default='kitti', choices=['kitti', 'nuscenes', 'scannet_fast', 'sunrgbd_fast', 'scannet_v1', 'lift_nuscenes', 'lift_scannet'],
                     help='BASELINE.json workload; the headline metric is quoted on kitti (configs[1]), the default')
     ap.add_argument('--views', type=int, default=0, help='views per scene for the indoor configs (default: reference test value)')
@@ -197,8 +242,19 @@ def main():
     ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
                     help='f32 (default) = the reference precision and the headline metric; bf16 = optional reduced-precision '
                          'storage mode (kitti only), reported with dtype "bf16" and priced against the bf16 MFMA peak')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="process-group backend: 'nccl' (= RCCL; GPU runs) or 'gloo' (CPU plumbing test with --dry)")
+    ap.add_argument('--dry', action='store_true', help='no GPU work: exercise the N-rank launch, batch sharding and detection all-gather only')
+    ap.add_argument('--api', default='simple_test', choices=['simple_test', 'composed'],
+                    help="what a timed step calls: 'simple_test' (default) = the drop-in public call ImVoxelNet.simple_test(img, img_metas) "
+                         "(reference: tools/benchmark.py:74 model(return_loss=False, rescale=True, **data)); 'composed' = the same stages "
+                         "called one by one with the packed D2H of round 1")
     args = ap.parse_args()
 
+    # One process per GPU.  Under torch.distributed.run (the reference's launcher is tools/dist_test.sh:9-10,
+    # `torch.distributed.launch --nproc_per_node=$GPUS`) RANK / WORLD_SIZE are set; a bare `python bench.py --gpus N`
+    # launches the N ranks itself.
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args.gpus)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -206,15 +262,21 @@ def main():
     if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        try:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-        except TypeError:      # older torch: no device_id argument
-            dist.init_process_group('nccl', rank=rank, world_size=world)
-    else:
+        if args.backend == 'gloo':
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            try:
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            except TypeError:      # older torch: no device_id argument
+                dist.init_process_group('nccl', rank=rank, world_size=world)
+        world = dist.get_world_size()      # n_gpus reported = the ranks the process group actually has
+    elif not args.dry:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
-        print(f'# note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE', file=sys.stderr)
+        print(f'# note: --gpus {args.gpus} but the process group has {world} rank(s); reporting {world}', file=sys.stderr)
+    if args.dry:
+        return bench_dry(args, rank, world)
     dev = torch.device('cuda', torch.cuda.current_device())
 
     import imvoxelnet_amd as ia
@@ -223,6 +285,9 @@ def main():
     from kitti_cfg import kitti_model_cfg, KITTI_TEST_CFG, kitti_meta
     from imvoxelnet_amd.conv import FusedConv
 
+    if os.environ.get('IVX_NARROW_EPILOGUE') == '1':       # A/B of the conv epilogue (default: LDS-transposed wide stores)
+        from imvoxelnet_amd import _lib
+        _lib.lib().ivx_conv_set_epilogue_mode(1)
     if args.config.startswith('lift_'):
         return bench_lift(args, ia, kc, dev)
     if args.config != 'kitti':
@@ -248,28 +313,38 @@ def main():
     img = img_host.to(dev)
     metas = [kitti_meta(t=(0.01 * b, 0.0, 0.0), box_type=ia.LiDARInstance3DBoxes) for b in range(B)]
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps + args.warmup)]
+    multi = world > 1 or force_dist
+    nsteps = args.steps + args.warmup
+    traces = [[] for _ in range(nsteps)]      # per step: the conv stage launches (FusedConv.trace)
+    lifts = [[] for _ in range(nsteps)]       # per step: the unprojection launch (ops.stage_trace)
 
-    from imvoxelnet_amd.conv import FusedConv
-    traces = [[] for _ in range(args.steps + args.warmup)]
+    if args.api == 'simple_test':
+        def step(i):
+            """The drop-in call, as tools/benchmark.py:74 times it: returns the list of result dicts on the host."""
+            FusedConv.trace, ops.stage_trace = traces[i], lifts[i]
+            try:
+                return model.simple_test(img, metas, gather=multi)
+            finally:
+                FusedConv.trace, ops.stage_trace = None, None
 
-    def step(i):
-        p0 = model.features_2d_cl(img)
-        proj, new_origin, crop = model._camera_setup(metas, 4, p0.device)   # host camera set-up + 3 small H2D copies
-        ev[i][2].record()
-        vol, _ = ops.backproject_mean(p0, proj, new_origin, crop, model.voxel_size, model.n_voxels)
-        ev[i][0].record()                                   # HIP events on the stream the kernels launch on
-        FusedConv.trace = traces[i]                         # per-stage events of the nine neck layers
-        y = model.neck_3d.forward_cl(vol)
-        FusedConv.trace = None
-        ev[i][1].record()
-        h = model.bbox_head.forward_cl(y)
-        boxes, scores, labels, count = model.bbox_head.get_bboxes_cl(h, y.shape[2], y.shape[1], metas, hw_transposed=True)
-        if world > 1 or force_dist:
-            boxes, scores, labels, count = ivx_dist.all_gather_detections(boxes, scores, labels, count)
-        # D2H of the results (bbox3d2result in the reference): one packed copy
-        return ivx_dist.pack_detections(boxes, scores, labels, count).cpu()
+        def n_det(out):
+            return int(sum(len(r['scores_3d']) for r in out))
+    else:
+        def step(i):
+            FusedConv.trace, ops.stage_trace = traces[i], lifts[i]
+            p0 = model.features_2d_cl(img)
+            proj, new_origin, crop = model._camera_setup(metas, 4, p0.device)   # host camera set-up + 3 small H2D copies
+            vol, _ = ops.backproject_mean(p0, proj, new_origin, crop, model.voxel_size, model.n_voxels)
+            y = model.neck_3d.forward_cl(vol)
+            FusedConv.trace, ops.stage_trace = None, None
+            h = model.bbox_head.forward_cl(y)
+            boxes, scores, labels, count = model.bbox_head.get_bboxes_cl(h, y.shape[2], y.shape[1], metas, hw_transposed=True)
+            if multi:
+                boxes, scores, labels, count = ivx_dist.all_gather_detections(boxes, scores, labels, count)
+            return ivx_dist.pack_detections(boxes, scores, labels, count).cpu()      # one packed D2H copy
+
+        def n_det(out):
+            return int(out[:, -1].sum().item())
 
     for i in range(args.warmup):
         step(i)
@@ -281,23 +356,26 @@ def main():
 
         def step(i):   # noqa: F811  -- same work, one graph launch
             boxes, scores, labels, count = graphed.replay_device(img, metas)
-            if world > 1 or force_dist:
+            if multi:
                 boxes, scores, labels, count = ivx_dist.all_gather_detections(boxes, scores, labels, count)
             return ivx_dist.pack_detections(boxes, scores, labels, count).cpu()
+
+        def n_det(out):   # noqa: F811
+            return int(out[:, -1].sum().item())
         step(0)
         torch.cuda.synchronize()
-    if world > 1 or force_dist:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1 or force_dist:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1 or force_dist:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -305,21 +383,26 @@ def main():
     ev_ids = range(args.warmup) if args.graph else range(args.warmup, args.warmup + args.steps)
     if args.graph and args.warmup > 1:
         ev_ids = range(1, args.warmup)       # skip the very first (cold) step
-    neck_ms = [ev[i][0].elapsed_time(ev[i][1]) for i in ev_ids]
-    neck_ms_avg = sum(neck_ms) / len(neck_ms)
-    lift_ms = sum(ev[i][2].elapsed_time(ev[i][0]) for i in ev_ids) / len(neck_ms)
+    ev_ids = list(ev_ids)
+    nst = len(ev_ids)
+    # The nine conv layers of KittiImVoxelNeck run in the F(6x6,3x3) minimal-filtering form (csrc/winograd.hip): input
+    # transform -> ONE grouped launch of the implicit-GEMM kernel -> output transform, and (pipeline.py) the batch is cut
+    # into slices so the transform kernels of one slice stream through HBM on a second stream while the matrix cores work
+    # on the other slice.  The roofline entry is the implicit-GEMM kernel over its launches on the 3-D neck with the
+    # FLOPs the kernel EXECUTES (64/324 of the direct count for an F(6x6,3x3) layer) over the event-bracketed duration of
+    # exactly those launches; direct_equivalent_tflops divides the direct-convolution FLOPs of the whole neck by the whole
+    # neck time (it may exceed the MFMA peak).
+    flops_step = neck_flops_per_sample((216, 248, 12), 64, 256) * B
+    neck_ms, tr = [], []
+    for i in ev_ids:
+        t3 = [t for t in traces[i] if t[5]]                      # 3-D layers only (the 2-D trunk is traced too)
+        first = t3[0][1]
+        neck_ms.append(max(first.elapsed_time(t[2]) for t in t3))   # first neck launch -> the last one to finish (two streams)
+        tr += t3
+    neck_ms_avg = sum(neck_ms) / nst
+    lift_ms = sum(l[1].elapsed_time(l[2]) for i in ev_ids for l in lifts[i]) / nst
     # unprojection: algorithmic bytes = features read once + volume written once + mask (173.1 MB/sample)
     lift_bytes = B * (1 * 64 * 96 * 320 * esz + 64 * 216 * 248 * 12 * esz + 216 * 248 * 12)
-    # The nine conv layers of KittiImVoxelNeck.  They run in the F(6x6,3x3) minimal-filtering form
-    # (imvoxelnet_amd/csrc/winograd.hip): input transform -> ONE grouped launch of the implicit-GEMM kernel -> output
-    # transform.  The roofline entry is the implicit-GEMM kernel over its nine launches per step (direct layers: the conv
-    # itself; Winograd layers: the grouped GEMM), with the FLOPs the kernel EXECUTES (64/324 of the direct count for an
-    # F(6x6,3x3) layer) over the event-bracketed duration of exactly those launches; direct_equivalent_tflops divides the
-    # direct-convolution FLOPs of the whole neck by the whole neck time (it may exceed the MFMA peak).
-    n_launch = 9
-    flops_step = neck_flops_per_sample((216, 248, 12), 64, 256) * B
-    tr = [t for i in ev_ids for t in traces[i]]
-    nst = len(list(ev_ids))
     mfma = [t for t in tr if t[0] in ('direct', 'wino_gemm')]
     mfma_ms = sum(t[1].elapsed_time(t[2]) for t in mfma) / nst
     mfma_flops = sum(t[3] for t in mfma) / nst
@@ -328,22 +411,29 @@ def main():
     xf = [t for t in tr if t[0] in ('wino_input', 'wino_output')]
     xf_ms = sum(t[1].elapsed_time(t[2]) for t in xf) / nst
     xf_bytes = sum(t[4] for t in xf) / nst
+    t2d = [t for i in ev_ids for t in traces[i] if not t[5]]   # the 2-D trunk (ResNet-50 + FPN level 0) and the head conv
+    t2d_ms = sum(t[1].elapsed_time(t[2]) for t in t2d) / nst
+    t2d_flops = sum(t[3] for t in t2d if t[0] in ('direct', 'wino_gemm')) / nst
 
     # HBM traffic of the neck conv launches: PMC counters cannot be read from inside the process, so the value comes
     # from the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh -> profiles/*_bench_pmc.json;
     # FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as reported), averaged per launch; null if absent.
-    traffic = None
-    pj = os.path.join(ROOT, 'profiles', 'r01_bench_pmc.json')
-    if os.path.exists(pj) and not bf16:
-        try:   # the summary covers the main launch of every neck layer (launches >= 1 ms): HBM bytes averaged per launch
-            ks = [v for v in json.load(open(pj)).values() if 'hbm_bytes' in v.get('derived', {})]
-            nl = sum(v['launches'] for v in ks)
-            traffic = round(sum(v['derived']['hbm_bytes'] * v['launches'] for v in ks) / nl / 1e9, 3) if nl else None
-        except Exception:
-            traffic = None
+    traffic, traffic_src = None, None
+    for name in ('r02_bench_pmc.json', 'r01_bench_pmc.json'):
+        pj = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(pj) and not bf16:
+            try:   # the summary covers the main launch of every neck layer: HBM bytes averaged per launch
+                ks = [v for v in json.load(open(pj)).values() if 'hbm_bytes' in v.get('derived', {})]
+                nl = sum(v['launches'] for v in ks)
+                traffic = round(sum(v['derived']['hbm_bytes'] * v['launches'] for v in ks) / nl / 1e9, 3) if nl else None
+                traffic_src = 'profiles/' + name
+            except Exception:
+                traffic = None
+            break
 
     if rank == 0:
         total_images = B * world * args.steps
+        from imvoxelnet_amd import pipeline
         rec = {
             'metric': 'images/sec/node (KITTI 3x384x1280, 216x248x12 vox)',
             'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
@@ -351,17 +441,22 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'data': 'synthetic',
             'config': {'workload': 'kitti_mono_1x3x384x1280_vox216x248x12_resnet50_fpn64_kittineck_anchor3dhead',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'hip_graph': bool(args.graph),
-                       'detections_last_step': int(last[:, -1].sum().item())},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, 9 conv layers/step)' % ('__bf16' if bf16 else 'float'),
+                       'api': 'hipGraph replay' if args.graph else ('ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages'),
+                       'neck_pipeline_chunks': pipeline.CHUNKS if FusedConv.winograd else 0,
+                       'detections_last_step': n_det(last)},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, %d launches/step)' % ('__bf16' if bf16 else 'float', n_launch),
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/r01_bench_pmc.json)',
+                         'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': f'GB/launch (rocprofv3 PMC, {traffic_src})',
                          'algorithmic_gflop_per_launch': round(mfma_flops / n_launch / 1e9, 2),
                          'avg_launch_ms': round(mfma_ms / n_launch, 4), 'launches_per_step': n_launch,
+                         'mfma_launch_ms_per_step': round(mfma_ms, 3),
                          'neck_ms_per_step': round(neck_ms_avg, 3), 'neck_direct_gflop_per_step': round(flops_step / 1e9, 1),
+                         'neck_executed_tflops': round(mfma_flops / (neck_ms_avg * 1e-3) / 1e12, 2),
                          'direct_equivalent_tflops': round(flops_step / (neck_ms_avg * 1e-3) / 1e12, 2),
-                         'winograd_layers_per_step': len([t for t in tr if t[0] == 'wino_gemm']) // nst},
+                         'winograd_gemm_launches_per_step': len([t for t in tr if t[0] == 'wino_gemm']) // nst},
             'roofline_winograd_transforms': None if not xf else {
-                'bound': 'hbm', 'kernel': 'wino_input_kernel + wino_output_kernel (%d launches/step, event-bracketed)' % (len(xf) // nst),
+                'bound': 'hbm', 'kernel': 'wino_input_kernel + wino_output_kernel (%d launches/step, event-bracketed; they run beside '
+                                          'the GEMM of the other batch slice when pipelined)' % (len(xf) // nst),
                 'achieved': round(xf_bytes / (xf_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
                 'frac': round(xf_bytes / (xf_ms * 1e-3) / 8e12, 4), 'ms_per_step': round(xf_ms, 3),
                 'algorithmic_GB_per_step': round(xf_bytes / 1e9, 2)},
@@ -369,6 +464,11 @@ def main():
                                       'achieved': round(lift_bytes / (lift_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
                                       'frac': round(lift_bytes / (lift_ms * 1e-3) / 8e12, 4), 'ms': round(lift_ms, 4),
                                       'algorithmic_MB': round(lift_bytes / 1e6, 1)},
+            'roofline_trunk_2d': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel (ResNet-50 + FPN level 0 + head conv, %d launches/step, '
+                                                             'event-bracketed incl. their transform / split-K passes)' % (len(t2d) // nst),
+                                  'achieved': round(t2d_flops / (t2d_ms * 1e-3) / 1e12, 2) if t2d_ms > 0 else None, 'peak': peak, 'unit': 'TFLOP/s',
+                                  'frac': round(t2d_flops / (t2d_ms * 1e-3) / 1e12 / peak, 4) if t2d_ms > 0 else None,
+                                  'ms_per_step': round(t2d_ms, 3), 'executed_gflop_per_step': round(t2d_flops / 1e9, 1)},
         }
         if bf16:
             rec['note'] = 'reduced-precision storage mode (bf16 activations/weights, fp32 accumulate); NOT the headline metric, which is quoted at fp32'
@@ -378,13 +478,18 @@ def main():
             cfg = dict(n_voxels=(216, 248, 12), voxel_size=(.32, .32, .32), neck='kitti', num_classes=1, test_cfg=KITTI_TEST_CFG,
                        anchor=dict(ranges=[[0, -39.68, -1.78, 69.12 - .32, 39.68 - .32, -1.78]], sizes=[[1.6, 3.9, 1.56]],
                                    rotations=[0, 1.57]))
-            tc = time.perf_counter()
-            orc.simple_test_anchor(img_host[:1], metas[:1], sd, cfg)
-            tc = time.perf_counter() - tc
+            ts = []
+            for k in range(1 + args.cpu_repeats):            # one untimed warm-up image, then `cpu_repeats` timed ones
+                tc = time.perf_counter()
+                orc.simple_test_anchor(img_host[k % B:k % B + 1], metas[k % B:k % B + 1], sd, cfg)
+                ts.append(time.perf_counter() - tc)
+            ts = ts[1:]
+            tc = sum(ts) / len(ts)
             rec['cpu_baseline'] = {'value': round(1.0 / tc, 4), 'unit': 'images/s', 'cores': torch.get_num_threads(),
                                    'kind': 'port', 'host_cpus': os.cpu_count(),
-                                   'sample': '1 image (1x3x384x1280 -> 216x248x12) through the oracle port '
-                                             '(torch-CPU fp32 convs + C unprojection/NMS), %.1f s' % tc}
+                                   'sample': '%d images (1x3x384x1280 -> 216x248x12 each, one at a time) through the oracle port (torch-CPU fp32 '
+                                             'convs + C unprojection/NMS) after one untimed warm-up image: %s s, mean %.2f s'
+                                             % (len(ts), ' / '.join('%.2f' % t for t in ts), tc)}
         print(json.dumps(rec))
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -11,7 +11,7 @@ from torch import nn
 
 from . import ops
 from .conv import FusedConv
-from .params import ConvParams, BNParams
+from .params import ConvParams, BNParams, invalidate_packed_on_load
 from .registry import BACKBONES, NECKS
 
 
@@ -94,11 +94,23 @@ class ResNet(nn.Module):
             setattr(self, f'layer{i + 1}', nn.Sequential(*layer))
         self.num_stages = len(blocks)
         self._device = None
+        invalidate_packed_on_load(self)
 
     def init_weights(self, pretrained=None):
-        if pretrained is not None and not str(pretrained).startswith('torchvision://'):
-            sd = torch.load(pretrained, map_location='cpu')
-            self.load_state_dict(sd.get('state_dict', sd), strict=False)
+        """mmdet ResNet.init_weights(pretrained): a checkpoint path is loaded; the model-zoo scheme of the reference configs
+        ('torchvision://resnet50', imvoxelnet_kitti.py:3) needs torchvision's download cache, which this package does
+        not have -- it is NOT silently ignored: a warning says the backbone stays randomly initialised until a
+        checkpoint is loaded (released ImVoxelNet checkpoints contain the backbone: data.load_checkpoint)."""
+        if pretrained is None:
+            return
+        if str(pretrained).startswith(('torchvision://', 'open-mmlab://', 'http://', 'https://')):
+            import warnings
+            warnings.warn(f"pretrained='{pretrained}' is a model-zoo URL and cannot be fetched here: the backbone keeps its random "
+                          'initialisation until a checkpoint is loaded (imvoxelnet_amd.load_checkpoint)', RuntimeWarning, stacklevel=2)
+            return
+        from .data import torch_load_trusted
+        sd = torch_load_trusted(pretrained, map_location='cpu')
+        self.load_state_dict(sd.get('state_dict', sd) if isinstance(sd, dict) else sd, strict=False)
 
     def prepare(self, device):
         self.stem = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), stride=2, padding=3, relu=True, dims=2).to(device)
@@ -149,6 +161,7 @@ class FPN(nn.Module):
             self.lateral_convs.append(lat)
             self.fpn_convs.append(out)
         self._device = None
+        invalidate_packed_on_load(self)
 
     def init_weights(self):
         pass

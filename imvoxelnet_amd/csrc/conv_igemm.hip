@@ -50,6 +50,7 @@ struct ConvParams {
   // and writes out + g*g_out (element strides; all 0 for an ordinary convolution)
   long long g_in, g_w, g_out;
   int groups;
+  int narrow_epilogue;  // A/B knob: 1 = the one-channel-per-lane epilogue everywhere (ivx_conv_set_epilogue_mode)
 };
 
 __device__ __forceinline__ float conv_ld_res(const ConvParams &p, size_t i) {
@@ -143,6 +144,55 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
       for (int j = 0; j < TN; ++j) {
         if (nn[j] >= p.Cout) continue;
         conv_st_out(p, obase + (size_t)m * p.Cout + nn[j], conv_finish(p, acc[i][j][r], sc[j], sf[j], rbase + nn[j]));
+      }
+    }
+  }
+}
+
+// Wide-store epilogue of the LDS-DMA kernel (fp32 output, plain layout, same-shape or no residual, Cout % 4 == 0).
+// The MFMA accumulator layout gives a lane ONE channel of 16 rows, so the direct epilogue above issues 16 dword stores per
+// 32x32 tile and lane (64 per wave for a 64x64 quadrant): the store issue, not the bytes, sets its duration, and while a
+// wave sits in it its SIMD runs with one MFMA wave fewer.  With short K (the Winograd-domain GEMMs: K = 192 .. 768, the
+// 1x1 layers of the 2-D trunk) that is the largest loss of the kernel.  Here each 32x32 tile is transposed through the
+// wave's own slice of the (now idle) staging LDS -- 16 ds_write_b32, 4 ds_read_b128 -- so that a lane owns 4 consecutive
+// channels: the tile leaves as 4 dwordx4 stores per lane (8 rows x 128 bytes per wave instruction, whole cache lines), the
+// residual arrives as 4 dwordx4 loads, scale / shift as one float4 each.  No barrier is needed: after the K loop's last
+// barrier every wave holds its remaining fragments in registers, and a wave touches only its own 4 KB slice.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_wide(const ConvParams &p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
+                                                   int lane, float *stage, size_t obase) {
+  const int col_l = lane & 31, hh = lane >> 5;
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;     // read side: row rrow + 8q, channels c4 .. c4+3 of the tile
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = n0 + (wc * TN + j) * 32 + c4;
+    const bool nok = nb < p.Cout;                        // Cout % 4 == 0: a 4-channel chunk is inside or outside as a whole
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+    if (nok && p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + nb);
+    if (nok && p.shift) sf = *reinterpret_cast<const f32x4 *>(p.shift + nb);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col_l] = acc[i][j][r];
+      const int mb = m0 + (wr * TM + i) * 32 + rrow;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(stage + (rrow + 8 * q) * 32 + c4);
+        const int m = mb + 8 * q;
+        if (m < p.M && nok) {
+          const size_t o = (size_t)m * p.Cout + nb;
+          v = v * sc + sf;
+          f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+          if (p.res_mode) rr = *reinterpret_cast<const f32x4 *>(p.res + o);
+          if (p.res_mode && !p.res_after_act) v += rr;
+          if (p.relu) {
+            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+          }
+          if (p.res_mode && p.res_after_act) v += rr;
+          v *= p.post_scale;
+          *reinterpret_cast<f32x4 *>(p.out + obase + o) = v;
+        }
       }
     }
   }
@@ -618,6 +668,11 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
       }
     return;
   }
+  if (p.out_mode == 0 && !p.out_bf16 && p.res_mode != 2 && (p.Cout & 3) == 0 && !p.narrow_epilogue) {
+    static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
+    conv_epilogue_wide<TM, TN>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, gz * (size_t)p.g_out);
+    return;
+  }
   conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane, gz * (size_t)p.g_out);
 }
 
@@ -695,6 +750,14 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
   }
 }
 
+static thread_local int g_narrow_epilogue = 0;
+// Tuning knob (A/B experiments; per calling thread): 1 = one-channel-per-lane epilogue stores in the LDS-DMA kernel,
+// 0 (default) = the LDS-transposed wide-store epilogue where it applies.
+extern "C" int ivx_conv_set_epilogue_mode(int narrow) {
+  g_narrow_epilogue = narrow ? 1 : 0;
+  return IVX_OK;
+}
+
 static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
                        const float *shift, const void *res, void *out, ConvParams *p) {
   IVX_REQUIRE(d && in && wgt && out, "ivx_conv_fwd: null argument");
@@ -734,6 +797,7 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   p->post_scale = d->post_scale == 0.f ? 1.0f : d->post_scale;
   p->ksplit = 1; p->partial = nullptr; p->q_total = 0; p->q_begin = 0; p->q_count = 0; p->bm = 0;
   p->groups = 1; p->g_in = p->g_w = p->g_out = 0;
+  p->narrow_epilogue = g_narrow_epilogue;
   return IVX_OK;
 }
 

@@ -14,10 +14,21 @@ IMG_NORM_CFG = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375],
 
 
 # ------------------------------------------------------------------ checkpoints
+def torch_load_trusted(filename, map_location='cpu'):
+    """torch.load for mmcv-style .pth files.  They are pickled dicts with 'meta' (strings, config text) and possibly
+    optimizer state next to 'state_dict', which torch >= 2.6's default weights_only=True refuses with an opaque
+    unpickling error; the caller vouches for the file, as mmcv.runner.load_checkpoint does."""
+    try:
+        return torch.load(filename, map_location=map_location, weights_only=False)
+    except TypeError:           # torch < 1.13: no weights_only argument
+        return torch.load(filename, map_location=map_location)
+
+
 def load_checkpoint(model, filename, map_location='cpu', strict=False):
     """mmcv.runner.load_checkpoint for the released ImVoxelNet .pth files: a dict with 'state_dict' (and 'meta'),
-    keys optionally prefixed with 'module.'.  Returns the checkpoint dict; call model.prepare(device) afterwards."""
-    ckpt = torch.load(filename, map_location=map_location)
+    keys optionally prefixed with 'module.'.  Returns the checkpoint dict.  A model that was already prepared is re-packed for
+    the device by its load_state_dict hook; otherwise call model.prepare(device) (or just run it)."""
+    ckpt = torch_load_trusted(filename, map_location=map_location)
     sd = ckpt.get('state_dict', ckpt) if isinstance(ckpt, dict) else ckpt
     sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
     res = model.load_state_dict(sd, strict=False)

@@ -44,6 +44,11 @@ class ImVoxelNet(nn.Module):
         self.n_voxels = tuple(int(v) for v in n_voxels)
         self.voxel_size = tuple(float(v) for v in voxel_size)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.storage_dtype, self._prepared_device = None, None
+        # weights loaded AFTER prepare() (load_state_dict / data.load_checkpoint) must reach the packed device copies: the
+        # sub-modules drop theirs (params.invalidate_packed_on_load), and the detector re-packs in the dtype it was prepared in
+        self.register_load_state_dict_post_hook(
+            lambda mod, keys: mod.prepare(mod._prepared_device, dtype=mod.storage_dtype) if mod._prepared_device is not None else None)
         self.init_weights(pretrained=pretrained)
 
     def init_weights(self, pretrained=None):
@@ -65,7 +70,7 @@ class ImVoxelNet(nn.Module):
                 m.prepare(device)
             if self.head_2d is not None:
                 self.head_2d.prepare(device)
-        self.storage_dtype = dtype
+        self.storage_dtype, self._prepared_device = dtype, device
         return self
 
     # ------------------------------------------------------------------ host-side camera set-up
@@ -149,11 +154,21 @@ class ImVoxelNet(nn.Module):
         levels = self.neck_3d.forward_cl(volume)
         return self.bbox_head.get_bboxes_cl(self.bbox_head.forward_cl(levels), valid, img_metas)
 
-    def simple_test(self, img, img_metas):
+    def simple_test(self, img, img_metas, gather=False):
+        """detectors/imvoxelnet.py:93-106.  gather (anchor-head configs, torch.distributed initialised): every rank passes
+        its slice of the batch and receives the detections of the WHOLE batch in rank order -- one all-gather of the
+        fixed-size padded device tensors (dist.all_gather_detections) in place of mmdet's pickle-based collect_results
+        after the loop (tools/test.py:131-136)."""
         p0, features_2d = self.features_2d_cl(img, img_metas, want_2d=True)
         volume, valid = self.lift_cl(p0, img_metas, features_2d[0] if features_2d is not None else None)
         if isinstance(self.bbox_head, Anchor3DHead):
             boxes, scores, labels, count = self.detect_cl(volume, img_metas)
+            if gather:
+                from .dist import all_gather_detections
+                boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)
+                img_metas = [img_metas[i % len(img_metas)] for i in range(boxes.shape[0])]     # box type of the other ranks' samples
+            if features_2d is None:
+                return self._results_one_copy(boxes, scores, labels, count, img_metas)
             dets = self.bbox_head._wrap(boxes, scores, labels, count, img_metas)
         else:
             dets = self.detect_indoor_cl(volume, valid, img_metas)
@@ -164,6 +179,22 @@ class ImVoxelNet(nn.Module):
                 results[i]['angles'] = angles[i]
                 results[i]['layout'] = layouts[i]
         return results
+
+    @staticmethod
+    def _results_one_copy(boxes, scores, labels, count, img_metas):
+        """bbox3d2result (core/bbox/transforms.py:49-67) for the fixed-size padded device tensors of the anchor tail: ONE
+        packed D2H copy for the whole batch instead of three copies (and syncs) per sample; the box objects are built
+        on the host from it."""
+        from .boxes import LiDARInstance3DBoxes
+        from .dist import pack_detections, unpack_detections
+        packed = pack_detections(boxes, scores, labels, count).cpu()         # the one sync of the step
+        b, s, l, c = unpack_detections(packed, scores.shape[1])
+        res = []
+        for i, meta in enumerate(img_metas):
+            n = int(c[i])
+            box_type = meta.get('box_type_3d', LiDARInstance3DBoxes)
+            res.append(dict(boxes_3d=box_type(b[i, :n], box_dim=7), scores_3d=s[i, :n].clone(), labels_3d=l[i, :n].clone()))
+        return res
 
     def simple_test_view_sharded(self, img, img_metas, group=None):
         """simple_test with the VIEWS of the scene(s) sharded over the ranks of `group` (second mode): every
@@ -191,7 +222,7 @@ class ImVoxelNet(nn.Module):
         return GraphedSimpleTest(self, img, img_metas, warmup)
 
     def forward_test(self, img, img_metas, **kwargs):
-        return self.simple_test(img, img_metas)
+        return self.simple_test(img, img_metas, gather=bool(kwargs.get('gather', False)))
 
     def forward(self, img, img_metas, return_loss=False, **kwargs):
         if return_loss:

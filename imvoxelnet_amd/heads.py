@@ -10,7 +10,7 @@ from torch import nn
 from . import ops
 from .boxes import LiDARInstance3DBoxes
 from .conv import FusedConv
-from .params import ConvParams
+from .params import ConvParams, invalidate_packed_on_load
 from .registry import HEADS, ConfigDict, build_anchor_generator, build_bbox_coder
 
 
@@ -53,6 +53,7 @@ class Anchor3DHead(nn.Module):
         self.conv_dir_cls = ConvParams(feat_channels, self.num_anchors * 2, 1, bias=True, dims=2)
         self.voxel_size = None
         self._device = None
+        invalidate_packed_on_load(self)
         self.init_weights()
 
     def init_weights(self):

@@ -16,7 +16,7 @@ from .boxes import DepthInstance3DBoxes
 from .conv import FusedConv
 from .heads import bias_init_with_prob
 from .nms import aligned_3d_nms, box3d_multiclass_nms
-from .params import ConvParams, BNParams, ScaleParams
+from .params import ConvParams, BNParams, ScaleParams, invalidate_packed_on_load
 from .registry import HEADS, ConfigDict
 
 
@@ -41,6 +41,7 @@ class _ImVoxelHeadBase(nn.Module):
         self.scales = nn.ModuleList([ScaleParams(1.) for _ in range(self.n_scales)])
         self.voxel_size = None
         self._device = None
+        invalidate_packed_on_load(self)
         self.init_weights()
 
     _v1 = False

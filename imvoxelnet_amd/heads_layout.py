@@ -13,6 +13,7 @@ from torch import nn
 from . import ops
 from .boxes import limit_period
 from .conv import FusedConv
+from .params import invalidate_packed_on_load
 from .registry import HEADS
 
 
@@ -42,6 +43,7 @@ class LayoutHead(nn.Module):
         self.angle_mlp = _mlp_params(n_channels, linear_size, 2)
         self.layout_mlp = _mlp_params(n_channels, linear_size, 7)
         self._device = None
+        invalidate_packed_on_load(self)
 
     def init_weights(self):
         pass

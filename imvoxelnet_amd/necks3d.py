@@ -7,7 +7,7 @@ from torch import nn
 
 from . import ops
 from .conv import FusedConv
-from .params import ConvParams, BNParams
+from .params import ConvParams, BNParams, invalidate_packed_on_load
 from .registry import NECKS
 
 
@@ -49,6 +49,7 @@ class _StackNeck(nn.Module):
             BasicBlock3d(c * 2, c * 2), _conv_bn_relu_params(c * 2, c * 4),
             BasicBlock3d(c * 4, c * 4), _conv_bn_relu_params(c * 4, out_channels))
         self._device = None
+        invalidate_packed_on_load(self)
 
     def init_weights(self):
         pass
@@ -181,6 +182,7 @@ class FastIndoorImVoxelNeck(nn.Module):
                                                              ConvParams(c // 2, c // 2, 3), BNParams(c // 2), nn.Identity()))
             setattr(self, f'out_block_{i}', nn.Sequential(ConvParams(c, out_channels, 3), BNParams(out_channels), nn.Identity()))
         self._device = None
+        invalidate_packed_on_load(self)
 
     def init_weights(self):
         pass
@@ -299,6 +301,7 @@ class ImVoxelNeck(nn.Module):
         self.conv_blocks = nn.ModuleList([nn.Sequential(ConvParams(c, out_channels, 3, bias=True), BNParams(out_channels), nn.Identity())
                                           for c in channels])
         self._device = None
+        invalidate_packed_on_load(self)
 
     def init_weights(self):
         pass

@@ -310,14 +310,29 @@ def upsample_trilinear2x(x):
 
 
 # ------------------------------------------------------------------ unprojection
+# optional stage timing (bench.py): when a list, backproject_mean appends ('lift', start_event, end_event) around its launch
+stage_trace = None
+
+
 def backproject_mean(feat, proj, new_origin, crop_hw, voxel_size, n_voxels):
+    if stage_trace is None:
+        return _backproject_mean(feat, proj, new_origin, crop_hw, voxel_size, n_voxels)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = _backproject_mean(feat, proj, new_origin, crop_hw, voxel_size, n_voxels)
+    e1.record()
+    stage_trace.append(('lift', e0, e1))
+    return out
+
+
+def _backproject_mean(feat, proj, new_origin, crop_hw, voxel_size, n_voxels):
     """feat [B*V,1,FH,FW,C] channels-last, proj [B,V,3,4], new_origin [B,3], crop_hw [B,2] int32 (device)
     -> volume [B,X,Y,Z,C] (feat's dtype), valid [B,X,Y,Z] bool.
     bf16 storage (optional reduced-precision mode): with one view the lift is a pure gather-copy (no arithmetic on the
     features, imvoxelnet.py:75 divides by a count of 1), so a bf16 map with C channels is passed as C/2 32-bit words."""
     if feat.dtype == torch.bfloat16:
         if proj.shape[1] == 1 and feat.shape[-1] % 2 == 0:
-            vol, valid = backproject_mean(feat.view(torch.float32), proj, new_origin, crop_hw, voxel_size, n_voxels)
+            vol, valid = _backproject_mean(feat.view(torch.float32), proj, new_origin, crop_hw, voxel_size, n_voxels)
             return vol.view(torch.bfloat16), valid
         _chk(feat, 'feat', torch.bfloat16)
         _chk(proj, 'proj')

@@ -98,3 +98,14 @@ def _parent(root, name):
     for part in name.split('.')[:-1]:
         mod = getattr(mod, part)
     return mod
+
+
+def invalidate_packed_on_load(module):
+    """The device kernels work on PACKED copies of the parameters made by module.prepare().  Loading weights afterwards
+    (load_state_dict, data.load_checkpoint -- on this module or on any parent) must not leave stale packed copies in
+    use: the post-hook drops them, and the next forward_cl re-packs from the new parameters (fp32 storage; a model
+    prepared in another storage dtype is re-prepared in that dtype by the detector's own hook)."""
+    def _drop(mod, incompatible_keys):
+        mod._device = None
+    module.register_load_state_dict_post_hook(_drop)
+    return module

@@ -29,9 +29,12 @@ def _env_int(name, default):
         return default
 
 
-# knobs (A/B experiments; defaults chosen from profiles/r02_overlap.md)
-CHUNKS = _env_int('IVX_PIPE_CHUNKS', 2)            # 0 / 1 = sequential path
-XF_BLOCKS = _env_int('IVX_PIPE_XF_BLOCKS', 512)    # grid cap of the transform kernels while pipelined (0 = uncapped)
+# knobs.  MEASURED (profiles/r02_overlap.md): on MI355X the two kinds of kernel barely overlap -- issued together, a grouped
+# GEMM and a transform pair take 80-95 % of the SUM of their stand-alone times whatever the grid cap, stream priority or GEMM
+# occupancy, and the whole KITTI neck gains 0.2-1.8 % (24.84 -> 24.40 ms at best).  The pipeline therefore stays OFF by
+# default (IVX_PIPE_CHUNKS=2 switches it on); it is kept because it is exact and costs nothing when off.
+CHUNKS = _env_int('IVX_PIPE_CHUNKS', 0)            # 0 / 1 = sequential path
+XF_BLOCKS = _env_int('IVX_PIPE_XF_BLOCKS', 2048)   # grid cap of the transform kernels while pipelined (0 = uncapped)
 XF_PRIORITY = _env_int('IVX_PIPE_XF_PRIO', -1)     # stream priority of the transform stream (-1 = high, 0 = normal)
 
 _streams = {}

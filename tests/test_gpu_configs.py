@@ -149,6 +149,18 @@ def test_scannet_v1_50view_full_path_vs_oracle(ia):
     assert_close('fpn0', uncl(p0)[:, :, 0], f0, 0, 2e-4 * float(f0.abs().max()))
     vol, valid = model.lift_cl(p0, [meta])
     assert np.array_equal(valid[0].cpu().numpy(), ok_ref[0])
+    # geometry first: the product's host camera set-up (torch CPU ops, as the reference) against the oracle's (C), then the
+    # 50-view lift of the ORACLE's FPN maps, which must reproduce the oracle volume bit for bit (same pixels, same order)
+    proj, new_origin, crop = model._camera_setup([meta], 4, torch.device('cpu'))
+    P_ref = orc.compute_projection(meta, 4)
+    print('projection matrices equal:', np.array_equal(proj[0].numpy(), P_ref), ' max |d|', float(np.abs(proj[0].numpy() - P_ref).max()))
+    from imvoxelnet_amd import ops
+    vol_o, valid_o = ops.backproject_mean(cl(f0), torch.from_numpy(P_ref)[None].cuda().contiguous(), new_origin.cuda(), crop.cuda(), vs, nv)
+    got_o = vol_o[0].permute(3, 0, 1, 2).cpu().numpy()
+    bad = np.argwhere((got_o != vol_ref).any(0))
+    print('lift of the oracle maps with the oracle projection:', len(bad), 'voxels differ', bad[:4].tolist())
+    assert np.array_equal(got_o, vol_ref), f'{len(bad)} voxels differ from the C oracle'
+    assert np.array_equal(proj[0].numpy(), P_ref), 'host camera set-up differs from the oracle (see the printed maximum)'
     assert_close('volume', vol[0].permute(3, 0, 1, 2), vol_ref, 0, 2e-4 * float(np.abs(vol_ref).max()))
     vol_in = torch.from_numpy(vol_ref).permute(1, 2, 3, 0)[None].contiguous().cuda()
     levels = model.neck_3d.forward_cl(vol_in)

@@ -503,3 +503,32 @@ def test_view_sharded_exchange_gloo_world2():
     ref = np.transpose(c['mean'], (1, 2, 3, 0))
     assert np.array_equal(cnt > 0, c['mean_valid'][0])
     assert np.abs(mean - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('how', ['bare', 'torchrun'])
+def test_bench_launches_n_ranks(how):
+    """`python bench.py --gpus 2` starts two ranks by itself (and runs as given under torch.distributed.run, the driver's
+    form); n_gpus in the JSON line is the world size the process group reports.  --dry --backend gloo: plumbing only
+    (rank launch, batch sharding, detection all-gather), no GPU.  Reference launcher: tools/dist_test.sh:9-10."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+    tail = [bench, '--gpus', '2', '--backend', 'gloo', '--dry', '--steps', '2', '--warmup', '1']
+    if how == 'bare':
+        cmd = [sys.executable] + tail
+    else:
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(port)] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['dry'] is True and rec['gathered_ok'] is True
+    assert rec['config']['global_batch'] == 8 and rec['config']['parallelism'] == 'dp2'
