@@ -146,6 +146,8 @@ def bench_other(args, ia, kc, dev, rank, world):
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    if native_trace:
+        model._native.trace(True)          # drop the warm-up records; the event pool they created is kept
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -318,7 +320,12 @@ def main():
     traces = [[] for _ in range(nsteps)]      # per step: the conv stage launches (FusedConv.trace)
     lifts = [[] for _ in range(nsteps)]       # per step: the unprojection launch (ops.stage_trace)
 
+    native_trace = False
     if args.api == 'simple_test':
+        native_trace = model._native is not None and not args.graph      # stage events are recorded inside the native handle
+        if native_trace:
+            model._native.trace(True)
+
         def step(i):
             """The drop-in call, as tools/benchmark.py:74 times it: returns the list of result dicts on the host."""
             FusedConv.trace, ops.stage_trace = traces[i], lifts[i]
@@ -384,7 +391,6 @@ def main():
     if args.graph and args.warmup > 1:
         ev_ids = range(1, args.warmup)       # skip the very first (cold) step
     ev_ids = list(ev_ids)
-    nst = len(ev_ids)
     # The nine conv layers of KittiImVoxelNeck run in the F(6x6,3x3) minimal-filtering form (csrc/winograd.hip): input
     # transform -> ONE grouped launch of the implicit-GEMM kernel -> output transform, and (pipeline.py) the batch is cut
     # into slices so the transform kernels of one slice stream through HBM on a second stream while the matrix cores work
@@ -393,26 +399,40 @@ def main():
     # exactly those launches; direct_equivalent_tflops divides the direct-convolution FLOPs of the whole neck by the whole
     # neck time (it may exceed the MFMA peak).
     flops_step = neck_flops_per_sample((216, 248, 12), 64, 256) * B
-    neck_ms, tr = [], []
-    for i in ev_ids:
-        t3 = [t for t in traces[i] if t[5]]                      # 3-D layers only (the 2-D trunk is traced too)
-        first = t3[0][1]
-        neck_ms.append(max(first.elapsed_time(t[2]) for t in t3))   # first neck launch -> the last one to finish (two streams)
-        tr += t3
+    # uniform stage records (kind, ms, start_ms, flops, bytes, is_3d) per traced step, from either source
+    KIND = {0: 'direct', 1: 'wino_input', 2: 'wino_gemm', 3: 'wino_output', 4: 'lift', 5: 'tail'}
+    per_step = []
+    if native_trace:
+        recs = model._native.trace_records()
+        n_per = len(recs) // args.steps
+        for k in range(args.steps):
+            per_step.append([(KIND[r['stage']], r['ms'], r['start_ms'], r['flops'], r['bytes'], r['is3d']) for r in recs[k * n_per:(k + 1) * n_per]])
+    else:
+        for i in ev_ids:
+            first = traces[i][0][1]
+            rows = [(t[0], t[1].elapsed_time(t[2]), first.elapsed_time(t[1]), t[3], t[4], t[5]) for t in traces[i]]
+            rows += [('lift', l[1].elapsed_time(l[2]), first.elapsed_time(l[1]), 0.0, 0.0, True) for l in lifts[i]]
+            per_step.append(rows)
+    nst = len(per_step)
+    neck_ms = []
+    for rows in per_step:
+        t3 = [r for r in rows if r[5] and r[0] != 'lift']              # the 3-D neck layers (the 2-D trunk is traced too)
+        neck_ms.append(max(r[2] + r[1] for r in t3) - min(r[2] for r in t3))   # first neck launch -> the last one to finish
+    tr = [r for rows in per_step for r in rows if r[5] and r[0] != 'lift']
     neck_ms_avg = sum(neck_ms) / nst
-    lift_ms = sum(l[1].elapsed_time(l[2]) for i in ev_ids for l in lifts[i]) / nst
+    lift_ms = sum(r[1] for rows in per_step for r in rows if r[0] == 'lift') / nst
     # unprojection: algorithmic bytes = features read once + volume written once + mask (173.1 MB/sample)
     lift_bytes = B * (1 * 64 * 96 * 320 * esz + 64 * 216 * 248 * 12 * esz + 216 * 248 * 12)
     mfma = [t for t in tr if t[0] in ('direct', 'wino_gemm')]
-    mfma_ms = sum(t[1].elapsed_time(t[2]) for t in mfma) / nst
+    mfma_ms = sum(t[1] for t in mfma) / nst
     mfma_flops = sum(t[3] for t in mfma) / nst
     n_launch = max(1, round(len(mfma) / nst))
     achieved = mfma_flops / (mfma_ms * 1e-3) / 1e12
     xf = [t for t in tr if t[0] in ('wino_input', 'wino_output')]
-    xf_ms = sum(t[1].elapsed_time(t[2]) for t in xf) / nst
+    xf_ms = sum(t[1] for t in xf) / nst
     xf_bytes = sum(t[4] for t in xf) / nst
-    t2d = [t for i in ev_ids for t in traces[i] if not t[5]]   # the 2-D trunk (ResNet-50 + FPN level 0) and the head conv
-    t2d_ms = sum(t[1].elapsed_time(t[2]) for t in t2d) / nst
+    t2d = [r for rows in per_step for r in rows if not r[5] and r[0] != 'tail']   # ResNet-50 + FPN level 0 + the head conv
+    t2d_ms = sum(t[1] for t in t2d) / nst
     t2d_flops = sum(t[3] for t in t2d if t[0] in ('direct', 'wino_gemm')) / nst
 
     # HBM traffic of the neck conv launches: PMC counters cannot be read from inside the process, so the value comes
@@ -442,6 +462,7 @@ def main():
             'config': {'workload': 'kitti_mono_1x3x384x1280_vox216x248x12_resnet50_fpn64_kittineck_anchor3dhead',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'hip_graph': bool(args.graph),
                        'api': 'hipGraph replay' if args.graph else ('ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages'),
+                       'device_side': 'native model handle (ivx_model_forward)' if native_trace else 'layer-by-layer over the op-level C-ABI',
                        'neck_pipeline_chunks': pipeline.CHUNKS if FusedConv.winograd else 0,
                        'detections_last_step': n_det(last)},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, %d launches/step)' % ('__bf16' if bf16 else 'float', n_launch),

@@ -17,6 +17,7 @@ SOURCES = [
     ('dcn.hip', []),
     ('api_common.cpp', []),
     ('kitti_eval.cpp', []),
+    ('model.cpp', ['-ffp-contract=off']),
 ]
 
 
@@ -46,7 +47,7 @@ def build(force=False, verbose=False):
         if force or _stale(o, [s] + headers):
             cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o] + extra
             if src.endswith('.cpp'):
-                cmd = [hipcc, '-O2', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+                cmd = [hipcc, '-O2', '-std=c++17', '-fPIC', '-c', s, '-o', o] + extra
             if verbose:
                 print(' '.join(cmd))
             subprocess.check_call(cmd)

@@ -29,13 +29,33 @@ class AnchorHeadDesc(C.Structure):
                [(n, C.c_float) for n in ('score_thr', 'nms_thr', 'dir_offset', 'dir_limit_offset')]
 
 
-EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_winograd_set_transform_blocks', 'ivx_conv_set_epilogue_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
+class ModelCfg(C.Structure):
+    """ivx_model_cfg (include/imvoxel.h)."""
+    _fields_ = [('neck_type', C.c_int32), ('with_trunk', C.c_int32), ('fpn_channels', C.c_int32), ('neck_out_channels', C.c_int32),
+                ('n_voxels', C.c_int32 * 3), ('voxel_size', C.c_float * 3), ('num_classes', C.c_int32), ('n_sizes', C.c_int32),
+                ('n_rotations', C.c_int32), ('anchor_range', C.c_float * 6), ('anchor_sizes', C.c_float * 12),
+                ('anchor_rotations', C.c_float * 4), ('nms_pre', C.c_int32), ('max_num', C.c_int32), ('use_rotate_nms', C.c_int32),
+                ('score_thr', C.c_float), ('nms_thr', C.c_float), ('dir_offset', C.c_float), ('dir_limit_offset', C.c_float),
+                ('winograd', C.c_int32), ('winograd_tile', C.c_int32)]
+
+
+class TraceRec(C.Structure):
+    """ivx_trace_rec."""
+    _fields_ = [('step', C.c_int32), ('stage', C.c_int32), ('is3d', C.c_int32), ('ms', C.c_float), ('start_ms', C.c_float), ('flops', C.c_double),
+                ('bytes', C.c_double), ('name', C.c_char * 48)]
+
+
+EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_winograd_set_transform_blocks', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_stagger', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
            'ivx_conv_winograd_supported', 'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_weights', 'ivx_conv_winograd_workspace_bytes',
            'ivx_conv_winograd_input', 'ivx_conv_winograd_gemm', 'ivx_conv_winograd_output', 'ivx_conv_winograd_fwd',
            'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
            'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_fcos_head_workspace_bytes',
            'ivx_fcos_head_level_candidates', 'ivx_nms_workspace_bytes',
            'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms', 'ivx_multiclass_nms_workspace_bytes', 'ivx_multiclass_nms_bev',
+           'ivx_create', 'ivx_destroy', 'ivx_weights_load', 'ivx_weights_finalize', 'ivx_model_workspace_bytes', 'ivx_model_forward',
+           'ivx_backbone_fpn_workspace_bytes', 'ivx_backbone_fpn_fwd', 'ivx_neck3d_workspace_bytes', 'ivx_neck3d_out_dims',
+           'ivx_neck3d_kitti_fwd', 'ivx_neck3d_nuscenes_fwd', 'ivx_model_anchors', 'ivx_compute_projection', 'ivx_voxel_new_origin',
+           'ivx_model_trace', 'ivx_model_trace_count', 'ivx_model_trace_read',
            'ivx_kitti_image_box_overlap', 'ivx_kitti_compute_statistics', 'ivx_kitti_collect_scores', 'ivx_kitti_fused_statistics']
 
 
@@ -57,6 +77,7 @@ def lib():
     L.ivx_conv_set_tile_override.argtypes = [C.c_int]
     L.ivx_conv_winograd_set_transform_blocks.argtypes = [C.c_int]
     L.ivx_conv_set_epilogue_mode.argtypes = [C.c_int]
+    L.ivx_conv_set_stagger.argtypes = [C.c_int]
     L.ivx_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
     L.ivx_conv_workspace_bytes.restype = i64
     L.ivx_conv_fwd_ws.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, i64, vp]
@@ -97,10 +118,33 @@ def lib():
     L.ivx_multiclass_nms_workspace_bytes.argtypes = [i32, i32]
     L.ivx_multiclass_nms_workspace_bytes.restype = i64
     L.ivx_multiclass_nms_bev.argtypes = [vp, vp, i32, i32, i32, f32, f32, i32, i32, vp, i64, vp, vp, vp, vp]
+    L.ivx_create.argtypes = [C.POINTER(ModelCfg), C.POINTER(vp)]
+    L.ivx_destroy.argtypes = [vp]
+    L.ivx_weights_load.argtypes = [vp, C.c_char_p, vp, C.POINTER(i64), i32]
+    L.ivx_weights_finalize.argtypes = [vp, vp]
+    L.ivx_model_workspace_bytes.argtypes = [vp, i32, i32, i32, i32]
+    L.ivx_model_workspace_bytes.restype = i64
+    L.ivx_model_forward.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]
+    L.ivx_backbone_fpn_workspace_bytes.argtypes = [vp, i32, i32, i32]
+    L.ivx_backbone_fpn_workspace_bytes.restype = i64
+    L.ivx_backbone_fpn_fwd.argtypes = [vp, vp, i32, i32, i32, vp, vp, i64, vp]
+    L.ivx_neck3d_workspace_bytes.argtypes = [vp, i32]
+    L.ivx_neck3d_workspace_bytes.restype = i64
+    L.ivx_neck3d_out_dims.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.ivx_neck3d_kitti_fwd.argtypes = [vp, vp, i32, vp, vp, i64, vp]
+    L.ivx_neck3d_nuscenes_fwd.argtypes = [vp, vp, i32, vp, vp, i64, vp]
+    L.ivx_model_anchors.argtypes = [vp, i32, i32, vp, i64]
+    L.ivx_compute_projection.argtypes = [vp, vp, i32, C.c_double, vp]
+    L.ivx_voxel_new_origin.argtypes = [vp, vp, vp, vp]
+    L.ivx_model_trace.argtypes = [vp, i32]
+    L.ivx_model_trace_count.argtypes = [vp]
+    L.ivx_model_trace_count.restype = i32
+    L.ivx_model_trace_read.argtypes = [vp, i32, C.POINTER(TraceRec)]
     for name in EXPORTS:
         if name not in ('ivx_last_error', 'ivx_anchor_head_workspace_bytes', 'ivx_nms_workspace_bytes',
                         'ivx_fcos_head_workspace_bytes', 'ivx_conv_workspace_bytes', 'ivx_multiclass_nms_workspace_bytes',
-                        'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_workspace_bytes'):
+                        'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_workspace_bytes', 'ivx_model_workspace_bytes',
+                        'ivx_backbone_fpn_workspace_bytes', 'ivx_neck3d_workspace_bytes', 'ivx_model_trace_count'):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -1,0 +1,942 @@
+// Model-level C-ABI (include/imvoxel.h, section "model handle"): the anchor-head ImVoxelNet forward path as ONE native
+// object -- layer sequence, weight packing, Winograd / tile selection, workspace planning and execution live here, so a
+// host without Python runs  image -> ResNet-50 -> FPN level 0 -> unprojection -> Kitti/NuScenes neck -> Anchor3DHead ->
+// decode + NMS  through ivx_create / ivx_weights_load / ivx_model_forward (tests/c/e2e_small.c is such a host).
+//
+// Reference structure restated (not its code): mmdet3d/models/detectors/imvoxelnet.py:45-106 (the sequence),
+// necks/imvoxelnet.py:94-154,191-230 (the two stack necks), dense_heads/anchor3d_head.py:122-153 (three 1x1 convs, run
+// as one fused conv), mmdet 2.10 ResNet(depth=50, style='pytorch') / FPN (level 0 only; parity unpinned).
+// Host-only C++ (no kernels): every device operation is one of this library's own C-ABI entry points.
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/imvoxel.h"
+
+void ivx_set_error(const char *fmt, ...);
+
+#define M_REQUIRE(cond, ...)        \
+  do {                              \
+    if (!(cond)) {                  \
+      ivx_set_error(__VA_ARGS__);   \
+      return IVX_ERR_INVALID_ARG;   \
+    }                               \
+  } while (0)
+#define M_HIP(call, what)                                                        \
+  do {                                                                           \
+    hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      ivx_set_error("%s: %s", what, hipGetErrorString(e_));                      \
+      return IVX_ERR_HIP;                                                        \
+    }                                                                            \
+  } while (0)
+#define M_TRY(call)                 \
+  do {                              \
+    int rc_ = (call);               \
+    if (rc_ != IVX_OK) return rc_;  \
+  } while (0)
+
+namespace {
+
+inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+
+// One Conv{2,3}d [+bias] [+eval BN] [+ReLU] of the reference, in its deploy form (imvoxelnet_amd/conv.py FusedConv).
+struct ConvLayer {
+  std::string name;
+  int dims = 3;                       // 2: [Cout,Cin,kh,kw] weights, 3: [Cout,Cin,kd,kh,kw]
+  int cin = 0, cout = 0;
+  int k[3] = {1, 1, 1}, s[3] = {1, 1, 1}, p[3] = {0, 0, 0};
+  bool relu = false;
+  std::vector<std::string> w_keys;    // > 1: filter banks concatenated along Cout (the fused head conv)
+  std::vector<std::string> b_keys;    // parallel to w_keys; "" = no bias
+  std::string bn;                     // BatchNorm prefix or ""
+  // deploy form
+  int cin_pad = 0, layout = 0;
+  bool wino_cand = false, wino2d = false, identity_epilogue = true;
+  float *w = nullptr, *w0 = nullptr, *scale = nullptr, *shift = nullptr;
+  std::map<int, float *> u;           // tile -> transformed filters
+};
+
+enum StepKind { ST_IMG2CL, ST_CONV, ST_MAXPOOL, ST_LIFT, ST_TAIL };
+
+struct Step {
+  StepKind kind;
+  int layer = -1;
+  int in = -1, res = -1, out = -1, out2 = -1;   // tensor ids (out2: the valid mask of the lift)
+  int res_mode = 0;
+};
+
+struct TInfo {
+  int B = 0, D = 0, H = 0, W = 0, C = 0;
+  int64_t bytes = 0, off = -1;
+  int first = -1, last = -1;
+  int64_t elems() const { return (int64_t)B * D * H * W * C; }
+};
+
+struct PlanStep {
+  ivx_conv_desc d;        // CONV: the descriptor handed to the conv entry point (Winograd: the transformed-axes view)
+  int tile = 0;           // 0: direct kernel, else F(tile x tile, 3x3)
+  int64_t ws = 0;
+};
+
+struct Plan {
+  std::vector<TInfo> t;
+  std::vector<PlanStep> ps;
+  int64_t arena = 0, ws_off = 0, ws_bytes = 0, tail_ws = 0, total = 0;
+  ivx_anchor_head_desc tail;
+};
+
+}  // namespace
+
+struct ivx_model {
+  ivx_model_cfg cfg;
+  std::vector<ConvLayer> layers;
+  std::vector<Step> steps;
+  int n_tensors = 0;
+  // step ranges [begin, end) and boundary tensors
+  int trunk0 = 0, trunk1 = 0, lift_step = -1, neck0 = 0, neck1 = 0, head_step = -1, tail_step = -1;
+  int t_img = -1, t_fpn0 = -1, t_volume = -1, t_valid = -1, t_neck = -1, t_head = -1;
+  std::map<std::string, HostTensor> weights;
+  bool finalized = false;
+  std::vector<float> anchors_host;     // [H*W*A, 7] for the (H, W) below; regenerated when the grid changes
+  int anchors_h = 0, anchors_w = 0;
+  float *anchors_dev = nullptr;
+  std::vector<float> anchors_given;    // supplied through ivx_weights_load("anchors", ...)
+  std::map<std::string, std::unique_ptr<Plan>> plans;
+  std::vector<void *> owned;           // device allocations (weights, filters, anchors)
+  // optional stage timing (ivx_model_trace): one record per launch group, events recorded on the caller's stream
+  bool trace_on = false;
+  struct TraceRec { int step, stage, is3d; double flops, bytes; hipEvent_t e0, e1; std::string name; };
+  std::vector<TraceRec> trace;
+  std::vector<hipEvent_t> event_pool;
+  size_t events_used = 0;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- graph construction
+int new_tensor(ivx_model *m) { return m->n_tensors++; }
+
+int add_conv(ivx_model *m, ConvLayer L, int in, int res = -1, int res_mode = 0) {
+  m->layers.push_back(std::move(L));
+  Step s;
+  s.kind = ST_CONV;
+  s.layer = (int)m->layers.size() - 1;
+  s.in = in;
+  s.res = res;
+  s.res_mode = res >= 0 ? (res_mode ? res_mode : 1) : 0;
+  s.out = new_tensor(m);
+  m->steps.push_back(s);
+  return s.out;
+}
+
+ConvLayer conv2d(const std::string &name, int cin, int cout, int k, int stride, int pad, bool relu, const std::string &w,
+                 const std::string &b, const std::string &bn) {
+  ConvLayer L;
+  L.name = name; L.dims = 2; L.cin = cin; L.cout = cout;
+  L.k[0] = 1; L.k[1] = k; L.k[2] = k;
+  L.s[0] = 1; L.s[1] = stride; L.s[2] = stride;
+  L.p[0] = 0; L.p[1] = pad; L.p[2] = pad;
+  L.relu = relu; L.w_keys = {w}; L.b_keys = {b}; L.bn = bn;
+  return L;
+}
+
+ConvLayer conv3d(const std::string &name, int cin, int cout, const int s[3], const int p[3], bool relu, const std::string &w,
+                 const std::string &b, const std::string &bn) {
+  ConvLayer L;
+  L.name = name; L.dims = 3; L.cin = cin; L.cout = cout;
+  for (int a = 0; a < 3; ++a) { L.k[a] = 3; L.s[a] = s[a]; L.p[a] = p[a]; }
+  L.relu = relu; L.w_keys = {w}; L.b_keys = {b}; L.bn = bn;
+  return L;
+}
+
+// ResNet-50 (style 'pytorch': stride on the 3x3) + FPN level 0 (lateral 1x1 -> nearest x2 top-down add -> 3x3).
+void build_trunk(ivx_model *m) {
+  m->trunk0 = (int)m->steps.size();
+  m->t_img = new_tensor(m);
+  Step a; a.kind = ST_IMG2CL; a.in = m->t_img; a.out = new_tensor(m);
+  m->steps.push_back(a);
+  int x = add_conv(m, conv2d("backbone.conv1", 3, 64, 7, 2, 3, true, "backbone.conv1.weight", "", "backbone.bn1"), a.out);
+  Step mp; mp.kind = ST_MAXPOOL; mp.in = x; mp.out = new_tensor(m);
+  m->steps.push_back(mp);
+  x = mp.out;
+  const int blocks[4] = {3, 4, 6, 3};
+  int cin = 64, feats[4];
+  for (int i = 0; i < 4; ++i) {
+    const int planes = 64 << i;
+    for (int j = 0; j < blocks[i]; ++j) {
+      const std::string pre = "backbone.layer" + std::to_string(i + 1) + "." + std::to_string(j) + ".";
+      const int stride = (j == 0 && i > 0) ? 2 : 1;
+      int idt = x;
+      if (j == 0)
+        idt = add_conv(m, conv2d(pre + "downsample", cin, planes * 4, 1, stride, 0, false, pre + "downsample.0.weight", "", pre + "downsample.1"), x);
+      int y = add_conv(m, conv2d(pre + "conv1", cin, planes, 1, 1, 0, true, pre + "conv1.weight", "", pre + "bn1"), x);
+      y = add_conv(m, conv2d(pre + "conv2", planes, planes, 3, stride, 1, true, pre + "conv2.weight", "", pre + "bn2"), y);
+      x = add_conv(m, conv2d(pre + "conv3", planes, planes * 4, 1, 1, 0, true, pre + "conv3.weight", "", pre + "bn3"), y, idt, 1);
+      cin = planes * 4;
+    }
+    feats[i] = x;
+  }
+  const int cf = m->cfg.fpn_channels, cins[4] = {256, 512, 1024, 2048};
+  int lat = -1;
+  for (int i = 3; i >= 0; --i) {
+    const std::string pre = "neck.lateral_convs." + std::to_string(i) + ".conv.";
+    lat = add_conv(m, conv2d("neck.lateral" + std::to_string(i), cins[i], cf, 1, 1, 0, false, pre + "weight", pre + "bias", ""), feats[i],
+                   i == 3 ? -1 : lat, 2);
+  }
+  m->t_fpn0 = add_conv(m, conv2d("neck.fpn_conv0", cf, cf, 3, 1, 1, false, "neck.fpn_convs.0.conv.weight", "neck.fpn_convs.0.conv.bias", ""), lat);
+  m->trunk1 = (int)m->steps.size();
+}
+
+// KittiImVoxelNeck / NuScenesImVoxelNeck: block, conv, block, conv, block, conv (necks/imvoxelnet.py:99-113, 131-145).
+void build_neck(ivx_model *m, int t_in) {
+  m->neck0 = (int)m->steps.size();
+  const int c = m->cfg.fpn_channels;
+  const int one[3] = {1, 1, 1};
+  int strides[3][3], pads[3][3];
+  if (m->cfg.neck_type == IVX_NECK_KITTI) {
+    const int s_[3][3] = {{1, 1, 2}, {1, 1, 2}, {1, 1, 1}}, p_[3][3] = {{1, 1, 1}, {1, 1, 1}, {0, 0, 0}};
+    memcpy(strides, s_, sizeof(s_)); memcpy(pads, p_, sizeof(p_));
+  } else {
+    const int s_[3][3] = {{2, 2, 2}, {1, 1, 2}, {1, 1, 1}}, p_[3][3] = {{1, 1, 1}, {1, 1, 1}, {1, 1, 0}};
+    memcpy(strides, s_, sizeof(s_)); memcpy(pads, p_, sizeof(p_));
+  }
+  const int chans[4] = {c, c * 2, c * 4, m->cfg.neck_out_channels};
+  int x = t_in;
+  for (int g = 0; g < 3; ++g) {
+    const std::string b = "neck_3d.model." + std::to_string(2 * g) + ".", d = "neck_3d.model." + std::to_string(2 * g + 1) + ".";
+    const int ch = chans[g];
+    int y = add_conv(m, conv3d(b + "conv1", ch, ch, one, one, true, b + "conv1.weight", "", b + "bn1"), x);
+    x = add_conv(m, conv3d(b + "conv2", ch, ch, one, one, true, b + "conv2.weight", "", b + "bn2"), y, x, 1);
+    x = add_conv(m, conv3d(d + "0", ch, chans[g + 1], strides[g], pads[g], true, d + "0.weight", d + "0.bias", d + "1"), x);
+  }
+  m->t_neck = x;
+  m->neck1 = (int)m->steps.size();
+}
+
+void build_graph(ivx_model *m) {
+  int t_feat;
+  if (m->cfg.with_trunk) {
+    build_trunk(m);
+    t_feat = m->t_fpn0;
+  } else {
+    m->t_fpn0 = t_feat = new_tensor(m);
+  }
+  Step lift; lift.kind = ST_LIFT; lift.in = t_feat; lift.out = m->t_volume = new_tensor(m); lift.out2 = m->t_valid = new_tensor(m);
+  m->lift_step = (int)m->steps.size();
+  m->steps.push_back(lift);
+  build_neck(m, m->t_volume);
+  // Anchor3DHead: conv_cls | conv_reg | conv_dir_cls as one 1x1 conv (anchor3d_head.py:122-130,138-153)
+  const int A = m->cfg.n_sizes * m->cfg.n_rotations, oc = m->cfg.neck_out_channels;
+  ConvLayer h = conv2d("bbox_head", oc, A * (m->cfg.num_classes + 7 + 2), 1, 1, 0, false, "", "", "");
+  h.w_keys = {"bbox_head.conv_cls.weight", "bbox_head.conv_reg.weight", "bbox_head.conv_dir_cls.weight"};
+  h.b_keys = {"bbox_head.conv_cls.bias", "bbox_head.conv_reg.bias", "bbox_head.conv_dir_cls.bias"};
+  m->head_step = (int)m->steps.size();
+  m->t_head = add_conv(m, h, m->t_neck);
+  Step tail; tail.kind = ST_TAIL; tail.in = m->t_head;
+  m->tail_step = (int)m->steps.size();
+  m->steps.push_back(tail);
+}
+
+// ---------------------------------------------------------------------------------------------- weights
+int dev_upload(ivx_model *m, const std::vector<float> &h, float **out, hipStream_t st) {
+  void *d = nullptr;
+  M_HIP(hipMalloc(&d, std::max<size_t>(h.size(), 1) * sizeof(float)), "hipMalloc (weights)");
+  m->owned.push_back(d);
+  M_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync (weights)");
+  *out = (float *)d;
+  return IVX_OK;
+}
+
+const HostTensor *find_w(const ivx_model *m, const std::string &key) {
+  auto it = m->weights.find(key);
+  return it == m->weights.end() ? nullptr : &it->second;
+}
+
+// Deploy form of one layer: imvoxelnet_amd/conv.py FusedConv.__init__ in C++ (same fp32 operations in the same order).
+int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing) {
+  const int kd = L.k[0], kh = L.k[1], kw = L.k[2], taps = kd * kh * kw;
+  L.cin_pad = (L.cin + 3) / 4 * 4;
+  L.layout = (L.cin_pad % 32 == 0) ? 1 : 0;
+  std::vector<float> wp((size_t)L.cout * taps * L.cin_pad, 0.f), w0;
+  std::vector<float> bias(L.cout, 0.f);
+  bool has_bias = false;
+  int co0 = 0;
+  for (size_t q = 0; q < L.w_keys.size(); ++q) {
+    const HostTensor *w = find_w(m, L.w_keys[q]);
+    if (!w) { *missing += L.w_keys[q] + " "; return IVX_OK; }
+    const size_t nd = w->shape.size();
+    M_REQUIRE(nd == (size_t)(L.dims + 2) && w->shape[1] == L.cin, "ivx_weights_finalize: %s has the wrong rank / input channels", L.w_keys[q].c_str());
+    const int co_n = (int)w->shape[0];
+    int64_t want = (int64_t)co_n * L.cin * taps;
+    M_REQUIRE((int64_t)w->data.size() == want && co0 + co_n <= L.cout, "ivx_weights_finalize: %s has the wrong shape", L.w_keys[q].c_str());
+    for (int co = 0; co < co_n; ++co)
+      for (int ci = 0; ci < L.cin; ++ci)
+        for (int t = 0; t < taps; ++t)      // torch [Cout,Cin,(kd,)kh,kw] -> [Cout,kd,kh,kw,Cin_pad]
+          wp[((size_t)(co0 + co) * taps + t) * L.cin_pad + ci] = w->data[((size_t)co * L.cin + ci) * taps + t];
+    if (!L.b_keys[q].empty()) {
+      const HostTensor *b = find_w(m, L.b_keys[q]);
+      if (!b) { *missing += L.b_keys[q] + " "; return IVX_OK; }
+      M_REQUIRE((int)b->data.size() == co_n, "ivx_weights_finalize: %s has the wrong size", L.b_keys[q].c_str());
+      for (int co = 0; co < co_n; ++co) bias[co0 + co] = b->data[co];
+      has_bias = true;
+    }
+    co0 += co_n;
+  }
+  M_REQUIRE(co0 == L.cout, "ivx_weights_finalize: layer %s: %d output channels loaded, %d expected", L.name.c_str(), co0, L.cout);
+  // Winograd candidate (FusedConv: 3x3 on the transformed axes with stride 1, fp32, unpadded Cin, >= 64 channels 3-D / 128 2-D)
+  L.wino2d = kd == 1 && kh == 3 && kw == 3 && L.s[0] == 1 && L.s[1] == 1 && L.s[2] == 1;
+  const bool wino3d = kd == 3 && kh == 3 && L.s[0] == 1 && L.s[1] == 1;
+  const int min_ch = L.wino2d ? 128 : 64;
+  L.wino_cand = (wino3d || L.wino2d) && L.cin_pad == L.cin && L.cout % 4 == 0 && std::max(L.cin, L.cout) >= min_ch && L.cin % 4 == 0;
+  if (L.wino_cand) w0 = wp;      // tap-major [Cout,kd,kh,kw,Cin]; a (1,3,3) kernel is the same memory as (3,3,1)
+  if (L.layout == 1) {           // chunk-major K: [Cout, Cin/32, kd,kh,kw, 32]
+    std::vector<float> wc(wp.size());
+    const int nch = L.cin_pad / 32;
+    for (int co = 0; co < L.cout; ++co)
+      for (int t = 0; t < taps; ++t)
+        for (int ci = 0; ci < L.cin_pad; ++ci)
+          wc[(((size_t)co * nch + ci / 32) * taps + t) * 32 + ci % 32] = wp[((size_t)co * taps + t) * L.cin_pad + ci];
+    wp.swap(wc);
+  }
+  M_TRY(dev_upload(m, wp, &L.w, st));
+  if (L.wino_cand) M_TRY(dev_upload(m, w0, &L.w0, st));
+  std::vector<float> scale(L.cout, 1.f), shift(bias);
+  if (!L.bn.empty()) {
+    const HostTensor *g = find_w(m, L.bn + ".weight"), *b = find_w(m, L.bn + ".bias"), *mu = find_w(m, L.bn + ".running_mean"),
+                     *var = find_w(m, L.bn + ".running_var");
+    if (!g || !b || !mu || !var) { *missing += L.bn + ".{weight,bias,running_mean,running_var} "; return IVX_OK; }
+    M_REQUIRE((int)g->data.size() == L.cout && (int)b->data.size() == L.cout && (int)mu->data.size() == L.cout && (int)var->data.size() == L.cout,
+              "ivx_weights_finalize: BatchNorm %s has the wrong size", L.bn.c_str());
+    const float eps = 1e-5f;
+    for (int c = 0; c < L.cout; ++c) {   // scale = gamma / sqrt(var + eps); shift = beta + (bias - mean) * scale
+      scale[c] = g->data[c] / sqrtf(var->data[c] + eps);
+      const float t = (shift[c] - mu->data[c]) * scale[c];
+      shift[c] = b->data[c] + t;
+    }
+  }
+  L.identity_epilogue = !has_bias && L.bn.empty();
+  if (!L.identity_epilogue) {
+    M_TRY(dev_upload(m, scale, &L.scale, st));
+    M_TRY(dev_upload(m, shift, &L.shift, st));
+  }
+  return IVX_OK;
+}
+
+// Anchor3DRangeGenerator.grid_anchors for one range per size (anchor_3d_generator.py:82-209): centres are
+// linspace(min, max, n) in fp32 (first half counted from the start, second half from the end, as torch.linspace),
+// flat order y (slow), x, size, rotation (fast).  A host may instead load the reference generator's own output
+// through ivx_weights_load("anchors", ...).
+void make_anchors(const ivx_model_cfg &c, int H, int W, std::vector<float> *out) {
+  const int S = c.n_sizes, R = c.n_rotations;
+  out->assign((size_t)H * W * S * R * 7, 0.f);
+  auto lin = [](float a, float b, int n, int i) {
+    if (n == 1) return a;
+    const float step = (b - a) / (float)(n - 1);
+    return i < n / 2 ? a + step * (float)i : b - step * (float)(n - 1 - i);
+  };
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x)
+      for (int s = 0; s < S; ++s)
+        for (int r = 0; r < R; ++r) {
+          float *a = out->data() + ((((size_t)y * W + x) * S + s) * R + r) * 7;
+          a[0] = lin(c.anchor_range[0], c.anchor_range[3], W, x);
+          a[1] = lin(c.anchor_range[1], c.anchor_range[4], H, y);
+          a[2] = c.anchor_range[2];      // one z level: linspace(z, z', 1) = z
+          a[3] = c.anchor_sizes[s * 3 + 0]; a[4] = c.anchor_sizes[s * 3 + 1]; a[5] = c.anchor_sizes[s * 3 + 2];
+          a[6] = c.anchor_rotations[r];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- planning
+struct Range { int s0, s1; };
+
+int conv_out(const ConvLayer &L, const TInfo &in, TInfo *o) {
+  const int dims[3] = {in.D, in.H, in.W};
+  int od[3];
+  for (int a = 0; a < 3; ++a) {
+    M_REQUIRE(dims[a] + 2 * L.p[a] >= L.k[a], "layer %s: kernel larger than the padded input", L.name.c_str());
+    od[a] = (dims[a] + 2 * L.p[a] - L.k[a]) / L.s[a] + 1;
+  }
+  o->B = in.B; o->D = od[0]; o->H = od[1]; o->W = od[2]; o->C = L.cout;
+  return IVX_OK;
+}
+
+// The Winograd decision of FusedConv.wino_tile (conv.py): returns the tile (0 = direct) and the descriptor to run.
+int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const TInfo *res, PlanStep *ps, hipStream_t stream) {
+  ivx_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.B = in.B; d.D = in.D; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L.cout;
+  d.KD = L.k[0]; d.KH = L.k[1]; d.KW = L.k[2];
+  d.sd = L.s[0]; d.sh = L.s[1]; d.sw = L.s[2];
+  d.pd = L.p[0]; d.ph = L.p[1]; d.pw = L.p[2];
+  d.relu = L.relu ? 1 : 0;
+  d.res_mode = st.res_mode;
+  if (st.res_mode == 2) { d.res_h = res->H; d.res_w = res->W; }
+  d.wgt_layout = L.layout; d.post_scale = 1.0f;
+  M_REQUIRE(in.C == L.cin_pad, "layer %s: input has %d channels, expected %d", L.name.c_str(), in.C, L.cin_pad);
+  int tile = 0;
+  ivx_conv_desc dw = d;
+  if (L.wino_cand && m->cfg.winograd && (st.res_mode == 0 || st.res_mode == 1) && (int64_t)in.B * in.D * in.H * in.W >= 2000) {
+    if (L.wino2d) {   // [B,1,H,W,C] as [B,H,W,1,C] with a 3x3x1 kernel
+      dw.D = in.H; dw.H = in.W; dw.W = 1;
+      dw.KD = 3; dw.KH = 3; dw.KW = 1; dw.sd = dw.sh = dw.sw = 1;
+      dw.pd = L.p[1]; dw.ph = L.p[2]; dw.pw = 0;
+    }
+    const int64_t plane = (int64_t)(dw.D + 2 * dw.pd - 2) * (dw.H + 2 * dw.ph - 2);
+    tile = m->cfg.winograd_tile ? m->cfg.winograd_tile : (plane >= 16384 ? 6 : 4);
+    ivx_conv_desc probe = dw;
+    probe.relu = 0; probe.res_mode = 0; probe.wgt_layout = 0;
+    if (!ivx_conv_winograd_supported(&probe, tile)) tile = 0;
+  }
+  if (tile) {
+    ps->d = dw;
+    ps->ws = ivx_conv_winograd_workspace_bytes(&dw, tile);
+    M_REQUIRE(ps->ws >= 0, "layer %s: %s", L.name.c_str(), ivx_last_error());
+    if (!L.u.count(tile)) {   // transformed filters for this tile, made once (ops.conv_winograd_weights)
+      ivx_conv_desc wd;
+      memset(&wd, 0, sizeof(wd));
+      wd.B = 1; wd.D = 4; wd.H = 4; wd.W = std::max(dw.KW, 1); wd.Cin = L.cin; wd.Cout = L.cout;
+      wd.KD = 3; wd.KH = 3; wd.KW = dw.KW; wd.sd = wd.sh = wd.sw = 1; wd.pd = wd.ph = 1; wd.pw = dw.KW / 2;
+      wd.wgt_layout = L.layout; wd.post_scale = 1.0f;
+      const int64_t n = ivx_conv_winograd_weight_elems(&wd, tile);
+      M_REQUIRE(n > 0, "layer %s: %s", L.name.c_str(), ivx_last_error());
+      void *u = nullptr;
+      M_HIP(hipMalloc(&u, (size_t)n * sizeof(float)), "hipMalloc (Winograd filters)");
+      m->owned.push_back(u);
+      M_TRY(ivx_conv_winograd_weights(&wd, tile, L.w0, (float *)u, stream));
+      L.u[tile] = (float *)u;
+    }
+  } else {
+    ps->d = d;
+    ps->ws = ivx_conv_workspace_bytes(&d);
+    M_REQUIRE(ps->ws >= 0, "layer %s: %s", L.name.c_str(), ivx_last_error());
+  }
+  ps->tile = tile;
+  return IVX_OK;
+}
+
+// Shapes, per-step descriptors and a liveness-based arena for the steps [r.s0, r.s1).  `ext` tensors are caller-owned.
+int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_views, Plan *pl, hipStream_t stream) {
+  pl->t.assign(m->n_tensors, TInfo());
+  pl->ps.assign(m->steps.size(), PlanStep());
+  for (auto &kv : inputs) { pl->t[kv.first] = kv.second; pl->t[kv.first].first = -2; }
+  const ivx_model_cfg &c = m->cfg;
+  for (int i = r.s0; i < r.s1; ++i) {
+    const Step &s = m->steps[i];
+    const TInfo &in = pl->t[s.in];
+    M_REQUIRE(in.B > 0, "internal: step %d reads an unplanned tensor", i);
+    TInfo o;
+    switch (s.kind) {
+      case ST_IMG2CL: o = in; o.C = 4; break;
+      case ST_MAXPOOL: o = in; o.H = (in.H + 2 - 3) / 2 + 1; o.W = (in.W + 2 - 3) / 2 + 1; break;
+      case ST_CONV: {
+        ConvLayer &L = m->layers[s.layer];
+        M_TRY(conv_out(L, in, &o));
+        M_TRY(plan_conv(m, L, in, s, s.res >= 0 ? &pl->t[s.res] : nullptr, &pl->ps[i], stream));
+        pl->ws_bytes = std::max(pl->ws_bytes, pl->ps[i].ws);
+        break;
+      }
+      case ST_LIFT: {
+        const int V = n_views;
+        M_REQUIRE(in.B % V == 0, "the %d feature maps do not divide into scenes of %d views", in.B, V);
+        o.B = in.B / V; o.D = c.n_voxels[0]; o.H = c.n_voxels[1]; o.W = c.n_voxels[2]; o.C = in.C;
+        TInfo v = o; v.C = 1;
+        v.bytes = align256(v.elems());          // u8 mask
+        v.first = i;
+        pl->t[s.out2] = v;
+        break;
+      }
+      case ST_TAIL: break;
+    }
+    if (s.kind == ST_TAIL) {
+      const TInfo &nk = pl->t[m->t_neck];      // [B, X', Y', 1, C]: the reference's H = Y', W = X' (necks/imvoxelnet.py:120)
+      ivx_anchor_head_desc &d = pl->tail;
+      memset(&d, 0, sizeof(d));
+      d.B = nk.B; d.H = nk.H; d.W = nk.D; d.CH = in.C;
+      d.num_anchors = c.n_sizes * c.n_rotations; d.num_classes = c.num_classes;
+      d.cls_off = 0; d.reg_off = d.num_anchors * c.num_classes; d.dir_off = d.reg_off + d.num_anchors * 7;
+      d.nms_pre = c.nms_pre; d.max_num = c.max_num; d.use_rotate_nms = c.use_rotate_nms; d.hw_transposed = 1;
+      d.score_thr = c.score_thr; d.nms_thr = c.nms_thr; d.dir_offset = c.dir_offset; d.dir_limit_offset = c.dir_limit_offset;
+      pl->tail_ws = ivx_anchor_head_workspace_bytes(&d);
+      M_REQUIRE(pl->tail_ws >= 0, "anchor tail: %s", ivx_last_error());
+      pl->ws_bytes = std::max(pl->ws_bytes, pl->tail_ws);
+      continue;
+    }
+    o.bytes = align256(o.elems() * 4);
+    o.first = i;
+    pl->t[s.out] = o;
+  }
+  // liveness
+  for (int i = r.s0; i < r.s1; ++i) {
+    const Step &s = m->steps[i];
+    for (int t : {s.in, s.res})
+      if (t >= 0) pl->t[t].last = std::max(pl->t[t].last, i);
+  }
+  for (int t : {m->t_fpn0, m->t_volume, m->t_valid, m->t_neck, m->t_head})
+    if (t >= 0 && pl->t[t].first >= r.s0) pl->t[t].last = r.s1;   // boundary tensors may be read back by the caller
+  // first-fit arena with coalescing free list
+  struct Blk { int64_t off, size; };
+  std::vector<Blk> free_list;
+  int64_t top = 0;
+  auto release = [&](int64_t off, int64_t size) {
+    free_list.push_back({off, size});
+    std::sort(free_list.begin(), free_list.end(), [](const Blk &a, const Blk &b) { return a.off < b.off; });
+    std::vector<Blk> merged;
+    for (const Blk &b : free_list) {
+      if (!merged.empty() && merged.back().off + merged.back().size == b.off) merged.back().size += b.size;
+      else merged.push_back(b);
+    }
+    free_list.swap(merged);
+  };
+  for (int i = r.s0; i < r.s1; ++i) {
+    const Step &s = m->steps[i];
+    for (int t : {s.out, s.out2}) {
+      if (t < 0 || pl->t[t].first != i) continue;
+      TInfo &ti = pl->t[t];
+      bool placed = false;
+      for (size_t f = 0; f < free_list.size(); ++f)
+        if (free_list[f].size >= ti.bytes) {
+          ti.off = free_list[f].off;
+          free_list[f].off += ti.bytes; free_list[f].size -= ti.bytes;
+          if (free_list[f].size == 0) free_list.erase(free_list.begin() + f);
+          placed = true;
+          break;
+        }
+      if (!placed) { ti.off = top; top += ti.bytes; }
+    }
+    for (int t = 0; t < m->n_tensors; ++t) {   // tensors whose last reader is this step die now
+      TInfo &ti = pl->t[t];
+      if (ti.off >= 0 && ti.first >= r.s0 && ti.last == i && ti.first != -2) release(ti.off, ti.bytes);
+    }
+    // an output nobody reads (should not happen) stays allocated
+  }
+  pl->arena = align256(top);
+  pl->ws_off = pl->arena;
+  pl->ws_bytes = align256(pl->ws_bytes);
+  pl->total = pl->arena + pl->ws_bytes;
+  return IVX_OK;
+}
+
+std::string plan_key(const char *what, int B, int V, int H, int W) {
+  char buf[96];
+  snprintf(buf, sizeof(buf), "%s:%d:%d:%d:%d", what, B, V, H, W);
+  return buf;
+}
+
+TInfo tinfo(int B, int D, int H, int W, int C) {
+  TInfo t; t.B = B; t.D = D; t.H = H; t.W = W; t.C = C; t.bytes = align256(t.elems() * 4);
+  return t;
+}
+
+int get_plan(ivx_model *m, const char *what, Range r, int B, int V, int H, int W, const std::map<int, TInfo> &inputs, Plan **out,
+             hipStream_t stream) {
+  M_REQUIRE(m->finalized, "%s: call ivx_weights_finalize first", what);
+  const std::string key = plan_key(what, B, V, H, W);
+  auto it = m->plans.find(key);
+  if (it == m->plans.end()) {
+    std::unique_ptr<Plan> pl(new Plan());
+    M_TRY(make_plan(m, r, inputs, V, pl.get(), stream));
+    it = m->plans.emplace(key, std::move(pl)).first;
+  }
+  *out = it->second.get();
+  return IVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- execution
+struct Bind {               // caller-owned buffers by tensor id
+  std::map<int, void *> ext;
+  const float *proj = nullptr, *new_origin = nullptr;
+  const int32_t *crop = nullptr;
+  int V = 1;
+  float *boxes = nullptr, *scores = nullptr;
+  int64_t *labels = nullptr;
+  int32_t *count = nullptr;
+};
+
+int trace_begin(ivx_model *m, int step, int stage, int is3d, double flops, double bytes, const std::string &name, hipStream_t st) {
+  if (!m->trace_on) return IVX_OK;
+  while (m->event_pool.size() < m->events_used + 2) {
+    hipEvent_t e;
+    M_HIP(hipEventCreate(&e), "hipEventCreate");
+    m->event_pool.push_back(e);
+  }
+  ivx_model::TraceRec r{step, stage, is3d, flops, bytes, m->event_pool[m->events_used], m->event_pool[m->events_used + 1], name};
+  m->events_used += 2;
+  M_HIP(hipEventRecord(r.e0, st), "hipEventRecord");
+  m->trace.push_back(r);
+  return IVX_OK;
+}
+
+int trace_end(ivx_model *m, hipStream_t st) {
+  if (!m->trace_on) return IVX_OK;
+  M_HIP(hipEventRecord(m->trace.back().e1, st), "hipEventRecord");
+  return IVX_OK;
+}
+
+int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *workspace, int64_t workspace_bytes, hipStream_t st,
+              const char *who) {
+  M_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, "%s: workspace must be non-null and 256-byte aligned", who);
+  if (workspace_bytes < pl.total) {
+    ivx_set_error("%s: workspace too small (%lld < %lld); size it with the matching *_workspace_bytes call", who, (long long)workspace_bytes,
+                  (long long)pl.total);
+    return IVX_ERR_WORKSPACE;
+  }
+  char *base = (char *)workspace;
+  void *ws = base + pl.ws_off;
+  auto ptr = [&](int t) -> void * {
+    auto it = bd.ext.find(t);
+    if (it != bd.ext.end()) return it->second;
+    return base + pl.t[t].off;
+  };
+  for (int i = r.s0; i < r.s1; ++i) {
+    const Step &s = m->steps[i];
+    const TInfo &in = pl.t[s.in];
+    switch (s.kind) {
+      case ST_IMG2CL:
+        M_TRY(ivx_nchw_to_nhwc((const float *)ptr(s.in), in.B, 3, (int64_t)in.H * in.W, 4, (float *)ptr(s.out), st));
+        break;
+      case ST_MAXPOOL:
+        M_TRY(ivx_maxpool2d_fwd((const float *)ptr(s.in), in.B, in.H, in.W, in.C, 3, 2, 1, (float *)ptr(s.out), st));
+        break;
+      case ST_CONV: {
+        const ConvLayer &L = m->layers[s.layer];
+        const PlanStep &ps = pl.ps[i];
+        const void *res = s.res >= 0 ? ptr(s.res) : nullptr;
+        const TInfo &o = pl.t[s.out];
+        const int is3d = in.D > 1;
+        if (ps.tile && m->trace_on) {   // the three stages as separate launches so each gets its own pair of events
+          const int n = ps.tile + 2, tiles = o.B * ((ps.d.D + 2 * ps.d.pd - 2 + ps.tile - 1) / ps.tile) * ((ps.d.H + 2 * ps.d.ph - 2 + ps.tile - 1) / ps.tile);
+          int32_t zo_d, zo_h, zo;
+          M_TRY(ivx_conv_out_dims(&ps.d, &zo_d, &zo_h, &zo));
+          const double vb = 4.0 * n * n * tiles * ps.d.W * ps.d.Cin, mb = 4.0 * n * n * tiles * zo * ps.d.Cout;
+          M_TRY(trace_begin(m, i, 1, is3d, 0.0, 4.0 * in.elems() + vb, L.name, st));
+          M_TRY(ivx_conv_winograd_input(&ps.d, ps.tile, ptr(s.in), ws, pl.ws_bytes, st));
+          M_TRY(trace_end(m, st));
+          M_TRY(trace_begin(m, i, 2, is3d, 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin, vb + mb, L.name, st));
+          M_TRY(ivx_conv_winograd_gemm(&ps.d, ps.tile, L.u.at(ps.tile), ws, pl.ws_bytes, st));
+          M_TRY(trace_end(m, st));
+          M_TRY(trace_begin(m, i, 3, is3d, 0.0, mb + 4.0 * o.elems() * (res ? 2 : 1), L.name, st));
+          M_TRY(ivx_conv_winograd_output(&ps.d, ps.tile, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
+          M_TRY(trace_end(m, st));
+          break;
+        }
+        M_TRY(trace_begin(m, i, 0, is3d, 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2], 0.0, L.name, st));
+        if (ps.tile)
+          M_TRY(ivx_conv_winograd_fwd(&ps.d, ps.tile, ptr(s.in), L.u.at(ps.tile), L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
+        else
+          M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.w, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
+        M_TRY(trace_end(m, st));
+        break;
+      }
+      case ST_LIFT: {
+        M_REQUIRE(bd.proj && bd.new_origin && bd.crop, "%s: proj / new_origin / crop_hw are required", who);
+        const TInfo &o = pl.t[s.out];
+        M_TRY(trace_begin(m, i, 4, 1, 0.0, 4.0 * in.elems() + 4.0 * o.elems() + (double)o.elems() / o.C, "unprojection", st));
+        M_TRY(ivx_backproject_mean_fwd((const float *)ptr(s.in), o.B, bd.V, in.H, in.W, in.C, bd.proj, bd.new_origin, bd.crop, m->cfg.voxel_size,
+                                       o.D, o.H, o.W, (float *)ptr(s.out), (uint8_t *)ptr(s.out2), st));
+        M_TRY(trace_end(m, st));
+        break;
+      }
+      case ST_TAIL: {
+        const ivx_anchor_head_desc &d = pl.tail;
+        if (m->anchors_h != d.H || m->anchors_w != d.W || !m->anchors_dev) {   // first use of this grid: not on the steady-state path
+          const size_t n = (size_t)d.H * d.W * d.num_anchors * 7;
+          if (!m->anchors_given.empty()) {
+            M_REQUIRE(m->anchors_given.size() == n, "%s: the loaded anchors have %zu values, the %d x %d grid needs %zu", who,
+                      m->anchors_given.size(), d.H, d.W, n);
+            m->anchors_host = m->anchors_given;
+          } else {
+            make_anchors(m->cfg, d.H, d.W, &m->anchors_host);
+          }
+          M_TRY(dev_upload(m, m->anchors_host, &m->anchors_dev, st));
+          m->anchors_h = d.H; m->anchors_w = d.W;
+        }
+        M_REQUIRE(bd.boxes && bd.scores && bd.labels && bd.count, "%s: output buffers are required", who);
+        M_TRY(trace_begin(m, i, 5, 0, 0.0, 0.0, "anchor tail", st));
+        M_TRY(ivx_anchor_head_get_bboxes(&d, (const float *)ptr(s.in), m->anchors_dev, ws, pl.ws_bytes, bd.boxes, bd.scores, bd.labels,
+                                         bd.count, nullptr, nullptr, nullptr, st));
+        M_TRY(trace_end(m, st));
+        break;
+      }
+    }
+  }
+  return IVX_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C-ABI
+extern "C" int ivx_create(const ivx_model_cfg *cfg, ivx_model **out) {
+  M_REQUIRE(cfg && out, "ivx_create: null argument");
+  M_REQUIRE(cfg->neck_type == IVX_NECK_KITTI || cfg->neck_type == IVX_NECK_NUSCENES, "ivx_create: neck_type must be IVX_NECK_KITTI or IVX_NECK_NUSCENES");
+  M_REQUIRE(cfg->fpn_channels > 0 && cfg->fpn_channels % 4 == 0 && cfg->neck_out_channels > 0 && cfg->neck_out_channels % 4 == 0,
+            "ivx_create: channel counts must be positive multiples of 4");
+  M_REQUIRE(cfg->n_voxels[0] > 0 && cfg->n_voxels[1] > 0 && cfg->n_voxels[2] > 0, "ivx_create: bad n_voxels");
+  M_REQUIRE(cfg->num_classes >= 1 && cfg->n_sizes >= 1 && cfg->n_sizes <= 4 && cfg->n_rotations >= 1 && cfg->n_rotations <= 4,
+            "ivx_create: 1..4 anchor sizes / rotations, >= 1 class");
+  M_REQUIRE(cfg->nms_pre > 0 && cfg->max_num > 0, "ivx_create: nms_pre and max_num must be positive");
+  M_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 2 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "ivx_create: winograd_tile 0 | 2 | 4 | 6");
+  ivx_model *m = new ivx_model();
+  m->cfg = *cfg;
+  build_graph(m);
+  *out = m;
+  return IVX_OK;
+}
+
+extern "C" int ivx_destroy(ivx_model *m) {
+  if (!m) return IVX_OK;
+  for (void *p : m->owned) (void)hipFree(p);
+  for (hipEvent_t e : m->event_pool) (void)hipEventDestroy(e);
+  delete m;
+  return IVX_OK;
+}
+
+extern "C" int ivx_weights_load(ivx_model *m, const char *key, const float *data, const int64_t *shape, int32_t ndim) {
+  M_REQUIRE(m && key && data && (shape || ndim == 0) && ndim >= 0 && ndim <= 6, "ivx_weights_load: bad argument");
+  M_REQUIRE(!m->finalized || !strcmp(key, "anchors"), "ivx_weights_load: the model is finalized; create a new handle to change weights");
+  HostTensor t;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    M_REQUIRE(shape[i] > 0, "ivx_weights_load: %s: non-positive dimension", key);
+    t.shape.push_back(shape[i]);
+    n *= shape[i];
+  }
+  t.data.assign(data, data + n);
+  if (!strcmp(key, "anchors")) {
+    M_REQUIRE(ndim == 2 && shape[1] == 7, "ivx_weights_load: anchors must be [n, 7]");
+    m->anchors_given = t.data;
+    m->anchors_h = m->anchors_w = 0;      // re-upload on the next forward
+    return IVX_OK;
+  }
+  std::string k = key;
+  if (k.rfind("module.", 0) == 0) k = k.substr(7);     // DataParallel prefix (mmcv load_checkpoint strips it)
+  m->weights[k] = std::move(t);
+  return IVX_OK;
+}
+
+extern "C" int ivx_weights_finalize(ivx_model *m, ivx_stream_t stream) {
+  M_REQUIRE(m, "ivx_weights_finalize: null handle");
+  M_REQUIRE(!m->finalized, "ivx_weights_finalize: already finalized");
+  std::string missing;
+  for (const ConvLayer &L : m->layers) {          // completeness first: no device work for an incomplete state dict
+    for (size_t q = 0; q < L.w_keys.size(); ++q) {
+      if (!find_w(m, L.w_keys[q])) missing += L.w_keys[q] + " ";
+      if (!L.b_keys[q].empty() && !find_w(m, L.b_keys[q])) missing += L.b_keys[q] + " ";
+    }
+    if (!L.bn.empty())
+      for (const char *sfx : {".weight", ".bias", ".running_mean", ".running_var"})
+        if (!find_w(m, L.bn + sfx)) missing += L.bn + sfx + " ";
+  }
+  if (missing.empty())
+    for (ConvLayer &L : m->layers) M_TRY(pack_layer(m, L, (hipStream_t)stream, &missing));
+  if (!missing.empty()) {
+    ivx_set_error("ivx_weights_finalize: missing state-dict keys: %.400s", missing.c_str());
+    return IVX_ERR_INVALID_ARG;
+  }
+  M_HIP(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");   // host staging vectors die here
+  m->weights.clear();
+  m->finalized = true;
+  return IVX_OK;
+}
+
+namespace {
+int check_img(const ivx_model *m, int B, int V, int H, int W, const char *who) {
+  M_REQUIRE(m, "%s: null handle", who);
+  M_REQUIRE(B > 0 && V > 0 && H > 0 && W > 0, "%s: non-positive dims", who);
+  M_REQUIRE(H % 32 == 0 && W % 32 == 0, "%s: the padded image must be a multiple of 32 (Pad(size_divisor=32)); got %d x %d", who, H, W);
+  return IVX_OK;
+}
+}  // namespace
+
+// ---- whole path
+static int plan_forward(ivx_model *m, int B, int V, int H, int W, Plan **pl, Range *r, hipStream_t st) {
+  std::map<int, TInfo> in;
+  if (m->cfg.with_trunk) {
+    in[m->t_img] = tinfo(B * V, 1, H, W, 3);
+    *r = {m->trunk0, (int)m->steps.size()};
+  } else {
+    in[m->t_fpn0] = tinfo(B * V, 1, H / 4, W / 4, m->cfg.fpn_channels);
+    *r = {m->lift_step, (int)m->steps.size()};
+  }
+  return get_plan(m, "forward", *r, B, V, H, W, in, pl, st);
+}
+
+extern "C" int64_t ivx_model_workspace_bytes(ivx_model *m, int32_t B, int32_t V, int32_t H, int32_t W) {
+  if (check_img(m, B, V, H, W, "ivx_model_workspace_bytes") != IVX_OK) return -1;
+  Plan *pl; Range r;
+  if (plan_forward(m, B, V, H, W, &pl, &r, nullptr) != IVX_OK) return -1;
+  return pl->total;
+}
+
+extern "C" int ivx_model_forward(ivx_model *m, const float *input, int32_t B, int32_t V, int32_t H, int32_t W, const float *proj,
+                                 const float *new_origin, const int32_t *crop_hw, void *workspace, int64_t workspace_bytes,
+                                 float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_count, uint8_t *out_valid,
+                                 ivx_stream_t stream) {
+  M_TRY(check_img(m, B, V, H, W, "ivx_model_forward"));
+  M_REQUIRE(input, "ivx_model_forward: null input");
+  Plan *pl; Range r;
+  M_TRY(plan_forward(m, B, V, H, W, &pl, &r, (hipStream_t)stream));
+  Bind bd;
+  bd.ext[m->cfg.with_trunk ? m->t_img : m->t_fpn0] = (void *)input;
+  if (out_valid) bd.ext[m->t_valid] = out_valid;
+  bd.proj = proj; bd.new_origin = new_origin; bd.crop = crop_hw; bd.V = V;
+  bd.boxes = out_boxes; bd.scores = out_scores; bd.labels = out_labels; bd.count = out_count;
+  return run_steps(m, *pl, r, bd, workspace, workspace_bytes, (hipStream_t)stream, "ivx_model_forward");
+}
+
+// ---- 2-D trunk alone
+static int plan_trunk(ivx_model *m, int BV, int H, int W, Plan **pl, hipStream_t st) {
+  M_REQUIRE(m->cfg.with_trunk, "ivx_backbone_fpn_fwd: the handle was created without the 2-D trunk (with_trunk = 0)");
+  std::map<int, TInfo> in;
+  in[m->t_img] = tinfo(BV, 1, H, W, 3);
+  return get_plan(m, "trunk", {m->trunk0, m->trunk1}, BV, 1, H, W, in, pl, st);
+}
+
+extern "C" int64_t ivx_backbone_fpn_workspace_bytes(ivx_model *m, int32_t BV, int32_t H, int32_t W) {
+  if (check_img(m, BV, 1, H, W, "ivx_backbone_fpn_workspace_bytes") != IVX_OK) return -1;
+  Plan *pl;
+  if (plan_trunk(m, BV, H, W, &pl, nullptr) != IVX_OK) return -1;
+  return pl->total;
+}
+
+extern "C" int ivx_backbone_fpn_fwd(ivx_model *m, const float *img, int32_t BV, int32_t H, int32_t W, float *fpn0, void *workspace,
+                                    int64_t workspace_bytes, ivx_stream_t stream) {
+  M_TRY(check_img(m, BV, 1, H, W, "ivx_backbone_fpn_fwd"));
+  M_REQUIRE(img && fpn0, "ivx_backbone_fpn_fwd: null argument");
+  Plan *pl;
+  M_TRY(plan_trunk(m, BV, H, W, &pl, (hipStream_t)stream));
+  Bind bd;
+  bd.ext[m->t_img] = (void *)img;
+  bd.ext[m->t_fpn0] = fpn0;
+  return run_steps(m, *pl, {m->trunk0, m->trunk1}, bd, workspace, workspace_bytes, (hipStream_t)stream, "ivx_backbone_fpn_fwd");
+}
+
+// ---- 3-D neck alone
+static int plan_neck(ivx_model *m, int B, Plan **pl, hipStream_t st) {
+  std::map<int, TInfo> in;
+  in[m->t_volume] = tinfo(B, m->cfg.n_voxels[0], m->cfg.n_voxels[1], m->cfg.n_voxels[2], m->cfg.fpn_channels);
+  return get_plan(m, "neck", {m->neck0, m->neck1}, B, 1, 0, 0, in, pl, st);
+}
+
+extern "C" int64_t ivx_neck3d_workspace_bytes(ivx_model *m, int32_t B) {
+  if (!m || B <= 0) { ivx_set_error("ivx_neck3d_workspace_bytes: bad argument"); return -1; }
+  Plan *pl;
+  if (plan_neck(m, B, &pl, nullptr) != IVX_OK) return -1;
+  return pl->total;
+}
+
+extern "C" int ivx_neck3d_out_dims(ivx_model *m, int32_t B, int32_t *X, int32_t *Y, int32_t *C) {
+  M_REQUIRE(m && X && Y && C && B > 0, "ivx_neck3d_out_dims: bad argument");
+  Plan *pl;
+  M_TRY(plan_neck(m, B, &pl, nullptr));
+  const TInfo &o = pl->t[m->t_neck];
+  M_REQUIRE(o.W == 1, "the z axis must collapse to 1 (got %d); necks/imvoxelnet.py:119,150", o.W);
+  *X = o.D; *Y = o.H; *C = o.C;
+  return IVX_OK;
+}
+
+static int neck_fwd(ivx_model *m, int want_type, const float *volume, int32_t B, float *out, void *workspace, int64_t workspace_bytes,
+                    ivx_stream_t stream, const char *who) {
+  M_REQUIRE(m && volume && out && B > 0, "%s: bad argument", who);
+  M_REQUIRE(m->cfg.neck_type == want_type, "%s: the handle holds the other stack neck", who);
+  Plan *pl;
+  M_TRY(plan_neck(m, B, &pl, (hipStream_t)stream));
+  M_REQUIRE(pl->t[m->t_neck].W == 1, "%s: the z axis must collapse to 1 (got %d); necks/imvoxelnet.py:119,150", who, pl->t[m->t_neck].W);
+  Bind bd;
+  bd.ext[m->t_volume] = (void *)volume;
+  bd.ext[m->t_neck] = out;
+  return run_steps(m, *pl, {m->neck0, m->neck1}, bd, workspace, workspace_bytes, (hipStream_t)stream, who);
+}
+
+extern "C" int ivx_neck3d_kitti_fwd(ivx_model *m, const float *volume, int32_t B, float *out, void *workspace, int64_t workspace_bytes,
+                                    ivx_stream_t stream) {
+  return neck_fwd(m, IVX_NECK_KITTI, volume, B, out, workspace, workspace_bytes, stream, "ivx_neck3d_kitti_fwd");
+}
+
+extern "C" int ivx_neck3d_nuscenes_fwd(ivx_model *m, const float *volume, int32_t B, float *out, void *workspace, int64_t workspace_bytes,
+                                       ivx_stream_t stream) {
+  return neck_fwd(m, IVX_NECK_NUSCENES, volume, B, out, workspace, workspace_bytes, stream, "ivx_neck3d_nuscenes_fwd");
+}
+
+// Host-only: the anchor grid this handle uses for an (H, W) map (n = H*W*A rows of 7); for hosts that want to inspect it.
+extern "C" int ivx_model_anchors(ivx_model *m, int32_t H, int32_t W, float *anchors_host, int64_t capacity) {
+  M_REQUIRE(m && anchors_host && H > 0 && W > 0, "ivx_model_anchors: bad argument");
+  std::vector<float> a;
+  make_anchors(m->cfg, H, W, &a);
+  M_REQUIRE(capacity >= (int64_t)a.size(), "ivx_model_anchors: capacity %lld < %zu values", (long long)capacity, a.size());
+  memcpy(anchors_host, a.data(), a.size() * sizeof(float));
+  return IVX_OK;
+}
+
+// ---- host-side camera set-up (no device work): detectors/imvoxelnet.py:114-129 and :139 in fixed fp32 operation order, so
+// the result does not depend on which BLAS kernel the host's matmul picks (the reference's `intrinsic @ extrinsic[:3]` is an
+// FMA chain over k on the CPUs it was pinned on; tests/golden/backproject_cases.npz holds its outputs).
+extern "C" int ivx_compute_projection(const float *intrinsic4x4, const float *extrinsics, int32_t V, double ratio, float *proj) {
+  M_REQUIRE(intrinsic4x4 && extrinsics && proj && V > 0, "ivx_compute_projection: bad argument");
+  float K[9];
+  const float r = (float)ratio;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float v = intrinsic4x4[i * 4 + j];
+      if (i < 2) v = v / r;                       // intrinsic[:2] /= ratio
+      K[i * 3 + j] = v;
+    }
+  for (int v = 0; v < V; ++v) {
+    const float *E = extrinsics + (size_t)v * 16;  // rows 0..2 of the 4x4 matrix
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 4; ++j) {
+        float acc = K[i * 3 + 0] * E[0 * 4 + j];
+        acc = fmaf(K[i * 3 + 1], E[1 * 4 + j], acc);
+        acc = fmaf(K[i * 3 + 2], E[2 * 4 + j], acc);
+        proj[(size_t)v * 12 + i * 4 + j] = acc;
+      }
+  }
+  return IVX_OK;
+}
+
+extern "C" int ivx_voxel_new_origin(const float *origin, const int32_t *n_voxels, const float *voxel_size, float *new_origin) {
+  M_REQUIRE(origin && n_voxels && voxel_size && new_origin, "ivx_voxel_new_origin: null argument");
+  for (int a = 0; a < 3; ++a) {                    // origin - n_voxels / 2. * voxel_size   (get_points, :139)
+    const float half = (float)n_voxels[a] / 2.0f;
+    const float ext = half * voxel_size[a];
+    new_origin[a] = origin[a] - ext;
+  }
+  return IVX_OK;
+}
+
+// ---- optional stage timing: events around every launch group of the forward calls made while enabled.  Stages: 0 direct
+// conv (or an un-split Winograd layer), 1 Winograd input transform, 2 grouped GEMM, 3 output transform, 4 unprojection,
+// 5 anchor tail.  Read the records after synchronising the stream; enabling clears them.
+extern "C" int ivx_model_trace(ivx_model *m, int32_t enable) {
+  M_REQUIRE(m, "ivx_model_trace: null handle");
+  m->trace_on = enable != 0;
+  m->trace.clear();
+  m->events_used = 0;
+  return IVX_OK;
+}
+
+extern "C" int32_t ivx_model_trace_count(ivx_model *m) { return m ? (int32_t)m->trace.size() : -1; }
+
+extern "C" int ivx_model_trace_read(ivx_model *m, int32_t i, ivx_trace_rec *rec) {
+  M_REQUIRE(m && rec && i >= 0 && i < (int32_t)m->trace.size(), "ivx_model_trace_read: bad index");
+  const ivx_model::TraceRec &r = m->trace[i];
+  float ms = 0.f, start = 0.f;
+  M_HIP(hipEventElapsedTime(&ms, r.e0, r.e1), "hipEventElapsedTime (synchronise the stream first)");
+  M_HIP(hipEventElapsedTime(&start, m->trace[0].e0, r.e0), "hipEventElapsedTime");
+  rec->step = r.step; rec->stage = r.stage; rec->is3d = r.is3d; rec->ms = ms; rec->start_ms = start; rec->flops = r.flops; rec->bytes = r.bytes;
+  snprintf(rec->name, sizeof(rec->name), "%s", r.name.c_str());
+  return IVX_OK;
+}

@@ -44,7 +44,7 @@ class ImVoxelNet(nn.Module):
         self.n_voxels = tuple(int(v) for v in n_voxels)
         self.voxel_size = tuple(float(v) for v in voxel_size)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
-        self.storage_dtype, self._prepared_device = None, None
+        self.storage_dtype, self._prepared_device, self._native = None, None, None
         # weights loaded AFTER prepare() (load_state_dict / data.load_checkpoint) must reach the packed device copies: the
         # sub-modules drop theirs (params.invalidate_packed_on_load), and the detector re-packs in the dtype it was prepared in
         self.register_load_state_dict_post_hook(
@@ -59,8 +59,11 @@ class ImVoxelNet(nn.Module):
         if self.head_2d is not None:
             self.head_2d.init_weights()
 
-    def prepare(self, device, dtype=torch.float32):
+    def prepare(self, device, dtype=torch.float32, native=None):
         """Pack every layer's parameters for the device kernels (call again after changing weights).
+        native (default: on unless IVX_NATIVE_MODEL=0): for the anchor-head families build the native model handle
+        (engine.NativeModel over csrc/model.cpp) and let simple_test run the whole device side through ONE C-ABI call;
+        the layer-by-layer composition below stays available (extract_feat, forward_cl, the other configurations).
         dtype: storage type of activations and weights between layers.  float32 (default) is the reference's precision
         and the one every parity claim is made for; bfloat16 is an optional reduced-precision mode (fp32 accumulate,
         fp32 epilogues, fp32 head output and detection tail) built for the single-view anchor-head configs."""
@@ -71,6 +74,15 @@ class ImVoxelNet(nn.Module):
             if self.head_2d is not None:
                 self.head_2d.prepare(device)
         self.storage_dtype, self._prepared_device = dtype, device
+        import os
+        from . import engine
+        if native is None:
+            native = os.environ.get('IVX_NATIVE_MODEL', '1') != '0'
+        if self._native is not None:
+            self._native.close()
+        self._native = None
+        if native and dtype == torch.float32 and engine.eligible(self):
+            self._native = engine.NativeModel(self, device)
         return self
 
     # ------------------------------------------------------------------ host-side camera set-up
@@ -80,13 +92,19 @@ class ImVoxelNet(nn.Module):
         of predicted (pitch, roll) the reference iterates as if they were views (:121-124; one entry at batch size 1)."""
         intrinsic = torch.tensor(img_meta['lidar2img']['intrinsic'][:3, :3])
         ratio = img_meta['ori_shape'][0] / (img_meta['img_shape'][0] / stride)
-        intrinsic[:2] /= ratio
         if angles is not None:
             from .heads_layout import get_extrinsics
             extrinsics = [get_extrinsics(a).to(intrinsic.device) for a in angles]
         else:
             extrinsics = [torch.tensor(e) for e in img_meta['lidar2img']['extrinsic']]
-        return torch.stack([intrinsic @ e[:3] for e in extrinsics])
+        if intrinsic.dtype != torch.float32 or any(e.dtype != torch.float32 for e in extrinsics):
+            intrinsic[:2] /= ratio                     # non-fp32 metas: the reference's own ops; _camera_setup rejects the result
+            return torch.stack([intrinsic @ e[:3] for e in extrinsics])
+        # fp32 (what the reference datasets produce): `intrinsic[:2] /= ratio; intrinsic @ extrinsic[:3]` in the library's
+        # fixed operation order -- a host matmul picks different fp32 summation orders on different CPUs (1 ulp, which
+        # flips the rounded pixel of a few voxels in a million); the fixed order is the one the golden vectors pin
+        from .engine import compute_projection
+        return compute_projection(intrinsic.numpy(), [e.numpy() for e in extrinsics], ratio)
 
     def _camera_setup(self, img_metas, stride, device, angles=None):
         proj, orig, crop = [], [], []
@@ -159,6 +177,19 @@ class ImVoxelNet(nn.Module):
         its slice of the batch and receives the detections of the WHOLE batch in rank order -- one all-gather of the
         fixed-size padded device tensors (dist.all_gather_detections) in place of mmdet's pickle-based collect_results
         after the loop (tools/test.py:131-136)."""
+        if self._prepared_device is None and self._native is None and img.is_cuda:
+            self.prepare(img.device)                             # first call: pack the weights (and build the native handle)
+        H, W = img.shape[-2:]
+        if self._native is not None and H % 32 == 0 and W % 32 == 0 and img.dtype == torch.float32:
+            # the whole device side in one native call (csrc/model.cpp); host work: the camera set-up, as the reference
+            B, V = img.shape[0], img.shape[1]
+            proj, new_origin, crop = self._camera_setup(img_metas, 4, img.device)
+            boxes, scores, labels, count = self._native.forward(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
+            if gather:
+                from .dist import all_gather_detections
+                boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)
+                img_metas = [img_metas[i % len(img_metas)] for i in range(boxes.shape[0])]
+            return self._results_one_copy(boxes, scores, labels, count, img_metas)
         p0, features_2d = self.features_2d_cl(img, img_metas, want_2d=True)
         volume, valid = self.lift_cl(p0, img_metas, features_2d[0] if features_2d is not None else None)
         if isinstance(self.bbox_head, Anchor3DHead):

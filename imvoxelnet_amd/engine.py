@@ -1,0 +1,195 @@
+"""Python caller of the native model handle (include/imvoxel.h "model handle", csrc/model.cpp).
+
+For the anchor-head families (KITTI / nuScenes with a plain ResNet-50) the whole device side of
+ImVoxelNet.simple_test -- layer sequence, weight packing, Winograd / tile selection, workspace planning, execution --
+lives in libimvoxel_hip.so; this module only feeds it the reference state dict, the per-batch camera set-up and
+caller-owned buffers.  The layer-by-layer Python composition (backbones.py / necks3d.py / heads.py over the op-level
+C-ABI) remains for the other configurations and as the cross-check: both run the same kernels with the same plans, so
+their results are bit-identical (tests/test_gpu_engine.py).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ModelCfg, TraceRec, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def eligible(model):
+    """The native handle covers: plain ResNet-50 + FPN, Kitti / NuScenes stack neck, Anchor3DHead with one anchor
+    range, no LayoutHead, fp32."""
+    from .backbones import ResNet, FPN
+    from .heads import Anchor3DHead
+    from .necks3d import KittiImVoxelNeck, NuScenesImVoxelNeck
+    bb = model.backbone
+    if not (isinstance(bb, ResNet) and isinstance(model.neck, FPN) and isinstance(model.bbox_head, Anchor3DHead)):
+        return False
+    if not isinstance(model.neck_3d, (KittiImVoxelNeck, NuScenesImVoxelNeck)) or model.head_2d is not None:
+        return False
+    if any(getattr(blk, 'dcn', False) for i in range(bb.num_stages) for blk in getattr(bb, f'layer{i + 1}')):
+        return False
+    if bb.num_stages != 4 or [len(getattr(bb, f'layer{i + 1}')) for i in range(4)] != [3, 4, 6, 3] or tuple(bb.out_indices) != (0, 1, 2, 3):
+        return False
+    g = model.bbox_head.anchor_generator
+    return len(g.ranges) == 1 and len(g.sizes) <= 4 and len(g.rotations) <= 4 and not g.custom_values and g.scales == [1]
+
+
+class NativeModel:
+    """ivx_model handle built from an ImVoxelNet module (its config and its state dict)."""
+
+    def __init__(self, model, device, with_trunk=True, winograd=None, winograd_tile=None):
+        from .conv import FusedConv
+        from .necks3d import KittiImVoxelNeck
+        if not eligible(model):
+            raise NotImplementedError('the native model handle covers ResNet-50 + FPN + Kitti/NuScenes neck + Anchor3DHead (fp32)')
+        self.device = torch.device(device)
+        L = self.L = _lib.lib()
+        head, tc = model.bbox_head, model.bbox_head.test_cfg
+        g = head.anchor_generator
+        cfg = ModelCfg()
+        cfg.neck_type = 0 if isinstance(model.neck_3d, KittiImVoxelNeck) else 1
+        cfg.with_trunk = int(bool(with_trunk))
+        cfg.fpn_channels = model.neck.out_channels
+        cfg.neck_out_channels = head.in_channels
+        cfg.n_voxels[:] = list(model.n_voxels)
+        cfg.voxel_size[:] = list(model.voxel_size)
+        cfg.num_classes = head.num_classes
+        cfg.n_sizes, cfg.n_rotations = len(g.sizes), len(g.rotations)
+        cfg.anchor_range[:] = [float(v) for v in g.ranges[0]]
+        for i, s in enumerate(g.sizes):
+            cfg.anchor_sizes[3 * i:3 * i + 3] = [float(v) for v in s]
+        cfg.anchor_rotations[:len(g.rotations)] = [float(v) for v in g.rotations]
+        cfg.nms_pre, cfg.max_num = int(tc['nms_pre']), int(tc['max_num'])
+        cfg.use_rotate_nms = int(bool(tc['use_rotate_nms']))
+        cfg.score_thr, cfg.nms_thr = float(tc.get('score_thr', 0)), float(tc['nms_thr'])
+        cfg.dir_offset, cfg.dir_limit_offset = float(head.dir_offset), float(head.dir_limit_offset)
+        cfg.winograd = int(FusedConv.winograd if winograd is None else winograd)
+        cfg.winograd_tile = int(FusedConv.winograd_tile if winograd_tile is None else winograd_tile)
+        self.cfg = cfg
+        self.max_num, self.n_voxels = cfg.max_num, tuple(model.n_voxels)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(L.ivx_create(C.byref(cfg), C.byref(h)), 'ivx_create')
+            self.h = h
+            for key, t in model.state_dict().items():
+                if not t.dtype.is_floating_point:
+                    continue                                   # num_batches_tracked
+                if not with_trunk and (key.startswith('backbone.') or key.startswith('neck.')):
+                    continue
+                a = t.detach().to('cpu', torch.float32).contiguous()
+                shape = (C.c_int64 * max(a.dim(), 1))(*a.shape)
+                check(L.ivx_weights_load(h, key.encode(), C.c_void_p(a.data_ptr()), shape, a.dim()), f'ivx_weights_load({key})')
+            check(L.ivx_weights_finalize(h, _stream()), 'ivx_weights_finalize')
+            # the anchor grid: the generator's own output (same torch ops as the reference's CPU path), not the built-in one
+            X, Y, Cn = C.c_int32(), C.c_int32(), C.c_int32()
+            check(L.ivx_neck3d_out_dims(h, 1, C.byref(X), C.byref(Y), C.byref(Cn)), 'ivx_neck3d_out_dims')
+            self.grid_hw = (Y.value, X.value)                  # the reference's (H, W) = (Y', X') (necks/imvoxelnet.py:120)
+            anc = g.grid_anchors([self.grid_hw], device='cpu')[0].reshape(-1, 7).contiguous().float()
+            shape = (C.c_int64 * 2)(*anc.shape)
+            check(L.ivx_weights_load(h, b'anchors', C.c_void_p(anc.data_ptr()), shape, 2), 'ivx_weights_load(anchors)')
+        self._ws = {}
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.L.ivx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ whole path
+    def _workspace(self, key, nbytes):
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = torch.empty((max(int(nbytes), 256),), device=self.device, dtype=torch.uint8)
+        return ws
+
+    def forward(self, x, B, V, H, W, proj, new_origin, crop_hw, want_valid=False):
+        """x: image batch [B*V,3,H,W] (with_trunk) or FPN level-0 maps [B*V,1,H/4,W/4,Cf]; -> (boxes [B,max_num,7], scores,
+        labels int64, count int32[, valid bool [B,X,Y,Z]]) device tensors."""
+        L = self.L
+        n = L.ivx_model_workspace_bytes(self.h, B, V, H, W)
+        if n < 0:
+            check(-1, 'ivx_model_workspace_bytes')
+        ws = self._workspace('fwd', n)
+        dev, M = x.device, self.max_num
+        boxes = torch.empty((B, M, 7), device=dev, dtype=torch.float32)
+        scores = torch.empty((B, M), device=dev, dtype=torch.float32)
+        labels = torch.empty((B, M), device=dev, dtype=torch.int64)
+        count = torch.empty((B,), device=dev, dtype=torch.int32)
+        valid = torch.empty((B,) + self.n_voxels, device=dev, dtype=torch.uint8) if want_valid else None
+        for t, nm in ((x, 'input'), (proj, 'proj'), (new_origin, 'new_origin')):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise ValueError(f'{nm} must be a contiguous float32 device tensor')
+        check(L.ivx_model_forward(self.h, C.c_void_p(x.data_ptr()), B, V, H, W, C.c_void_p(proj.data_ptr()), C.c_void_p(new_origin.data_ptr()),
+                                  C.c_void_p(crop_hw.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(boxes.data_ptr()),
+                                  C.c_void_p(scores.data_ptr()), C.c_void_p(labels.data_ptr()), C.c_void_p(count.data_ptr()),
+                                  C.c_void_p(valid.data_ptr()) if want_valid else None, _stream()), 'ivx_model_forward')
+        return (boxes, scores, labels, count, valid.view(torch.bool)) if want_valid else (boxes, scores, labels, count)
+
+    # ------------------------------------------------------------------ sub-paths
+    def backbone_fpn(self, img):
+        """img [BV,3,H,W] -> FPN level 0 [BV,1,H/4,W/4,Cf] channels-last."""
+        BV, _, H, W = img.shape
+        n = self.L.ivx_backbone_fpn_workspace_bytes(self.h, BV, H, W)
+        if n < 0:
+            check(-1, 'ivx_backbone_fpn_workspace_bytes')
+        ws = self._workspace('trunk', n)
+        out = torch.empty((BV, 1, H // 4, W // 4, self.cfg.fpn_channels), device=img.device, dtype=torch.float32)
+        check(self.L.ivx_backbone_fpn_fwd(self.h, C.c_void_p(img.data_ptr()), BV, H, W, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                          ws.numel(), _stream()), 'ivx_backbone_fpn_fwd')
+        return out
+
+    def neck3d(self, volume):
+        """volume [B,X,Y,Z,Cf] -> [B,X',Y',1,Cout]."""
+        B = volume.shape[0]
+        n = self.L.ivx_neck3d_workspace_bytes(self.h, B)
+        if n < 0:
+            check(-1, 'ivx_neck3d_workspace_bytes')
+        ws = self._workspace('neck', n)
+        out = torch.empty((B, self.grid_hw[1], self.grid_hw[0], 1, self.cfg.neck_out_channels), device=volume.device, dtype=torch.float32)
+        fn = self.L.ivx_neck3d_kitti_fwd if self.cfg.neck_type == 0 else self.L.ivx_neck3d_nuscenes_fwd
+        check(fn(self.h, C.c_void_p(volume.data_ptr()), B, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+              'ivx_neck3d_fwd')
+        return out
+
+    # ------------------------------------------------------------------ stage timing
+    def trace(self, enable=True):
+        check(self.L.ivx_model_trace(self.h, int(bool(enable))), 'ivx_model_trace')
+
+    def trace_records(self):
+        """After torch.cuda.synchronize(): list of dicts (step, stage, is3d, ms, flops, bytes, name) in launch order;
+        stage 0 direct conv, 1 Winograd input transform, 2 grouped GEMM, 3 output transform, 4 unprojection, 5 tail."""
+        out, rec = [], TraceRec()
+        for i in range(self.L.ivx_model_trace_count(self.h)):
+            check(self.L.ivx_model_trace_read(self.h, i, C.byref(rec)), 'ivx_model_trace_read')
+            out.append(dict(step=rec.step, stage=rec.stage, is3d=bool(rec.is3d), ms=rec.ms, start_ms=rec.start_ms, flops=rec.flops, bytes=rec.bytes,
+                            name=rec.name.decode()))
+        return out
+
+
+def compute_projection(intrinsic, extrinsics, ratio):
+    """(K[:3,:3] with rows 0,1 / ratio) @ E_v[:3] for every view, in the library's fixed fp32 operation order
+    (ivx_compute_projection; detectors/imvoxelnet.py:114-129).  numpy / torch in, float32 torch tensor [V,3,4] out."""
+    import numpy as np
+    K = np.ascontiguousarray(np.asarray(intrinsic, dtype=np.float32))
+    if K.shape != (4, 4):
+        K4 = np.eye(4, dtype=np.float32)
+        K4[:K.shape[0], :K.shape[1]] = K
+        K = K4
+    E = np.ascontiguousarray(np.stack([np.asarray(e, dtype=np.float32) for e in extrinsics]))
+    if E.shape[1:] != (4, 4):
+        E4 = np.zeros((E.shape[0], 4, 4), np.float32)
+        E4[:, :E.shape[1], :E.shape[2]] = E
+        E = E4
+    P = np.empty((E.shape[0], 3, 4), np.float32)
+    check(_lib.lib().ivx_compute_projection(K.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p), E.shape[0], float(ratio),
+                                            P.ctypes.data_as(C.c_void_p)), 'ivx_compute_projection')
+    return torch.from_numpy(P)

@@ -139,6 +139,9 @@ int ivx_conv_winograd_set_transform_blocks(int n);
 /* Per calling thread, A/B only: 1 = one-channel-per-lane epilogue stores in the LDS-DMA conv kernel; 0 (default) = the
  * LDS-transposed epilogue (a lane stores 4 consecutive channels as one 16-byte word) wherever it applies. */
 int ivx_conv_set_epilogue_mode(int narrow);
+/* Per calling thread, A/B only: start-up stagger of the LDS-DMA conv kernel in percent of (one workgroup's MFMA time /
+ * workgroups per CU): the first generation of workgroups on a CU starts spread out instead of in lock-step.  0 = off. */
+int ivx_conv_set_stagger(int percent);
 
 /* Modulated deformable convolution (DCNv2; mmcv ModulatedDeformConv2dPack, deform_groups = 1) -- nuScenes reference
  * backbone, configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14.  Builds the modulated, bilinearly sampled columns
@@ -337,6 +340,96 @@ int ivx_kitti_fused_statistics(const double *const *ov_ptrs, int32_t n_img, cons
                                const double *dontcares, const int64_t *ignored_gts, const int64_t *ignored_dets,
                                int32_t metric, double min_overlap, const double *thresholds, int32_t n_thr,
                                int32_t compute_aos, double *pr);
+
+/* ---------------------------------------------------------------------------------------
+ * Model handle -- the anchor-head ImVoxelNet forward path as one native object
+ * (ImVoxelNet.simple_test, mmdet3d/models/detectors/imvoxelnet.py:45-106, for the KITTI / nuScenes families:
+ * ResNet-50 -> FPN level 0 -> unprojection -> KittiImVoxelNeck | NuScenesImVoxelNeck (necks/imvoxelnet.py:94-154) ->
+ * Anchor3DHead forward (anchor3d_head.py:122-153) -> get_bboxes (:375-517)).  The layer sequence, weight packing
+ * (conv + eval BatchNorm -> scale/shift epilogue, chunk-major K, Winograd-domain filters), Winograd / tile selection and
+ * workspace planning live in the library; the caller owns the workspace and all input / output buffers.  The
+ * reference's only native precedent is the pybind op at ops/iou3d/src/iou3d.cpp:95-147,203-208 (caller-allocated
+ * outputs, int return); this keeps that convention.
+ *
+ *   ivx_create(&cfg, &m);
+ *   for every tensor of the reference state dict: ivx_weights_load(m, key, host_ptr, shape, ndim);
+ *       keys as in a released checkpoint: backbone.*, neck.lateral_convs.i.conv.*, neck.fpn_convs.0.conv.*,
+ *       neck_3d.model.{0,2,4}.{conv1,bn1,conv2,bn2}.*, neck_3d.model.{1,3,5}.{0,1}.*, bbox_head.conv_{cls,reg,dir_cls}.*
+ *       (a leading "module." is dropped; unused keys -- fpn_convs.1..3, num_batches_tracked -- are ignored);
+ *       optional pseudo-key "anchors" [H*W*A, 7]: the anchor grid to use instead of the built-in generator
+ *   ivx_weights_finalize(m, stream);                       packs and uploads; lists missing keys on error
+ *   n = ivx_model_workspace_bytes(m, B, V, H, W);          plans this shape (allocates transformed filters once)
+ *   ivx_model_forward(m, img, B, V, H, W, proj, new_origin, crop_hw, ws, n, boxes, scores, labels, count, valid, stream);
+ *   ivx_destroy(m);
+ * One handle per device and per host thread; calls are asynchronous on `stream`.                                  */
+#define IVX_NECK_KITTI 0
+#define IVX_NECK_NUSCENES 1
+typedef struct ivx_model ivx_model;
+typedef struct ivx_model_cfg {
+  int32_t neck_type;          /* IVX_NECK_KITTI | IVX_NECK_NUSCENES */
+  int32_t with_trunk;         /* 1: ResNet-50 + FPN inside the handle (input = image); 0: input = FPN level-0 map */
+  int32_t fpn_channels;       /* FPN out_channels = neck_3d in_channels (64 in the reference configs) */
+  int32_t neck_out_channels;  /* neck_3d out_channels = head in_channels (256) */
+  int32_t n_voxels[3];
+  float voxel_size[3];
+  int32_t num_classes;
+  int32_t n_sizes, n_rotations;        /* anchor generator: sizes x rotations base anchors, one range */
+  float anchor_range[6];               /* x0, y0, z0, x1, y1, z1 */
+  float anchor_sizes[12];              /* n_sizes x (w, l, h) */
+  float anchor_rotations[4];
+  int32_t nms_pre, max_num, use_rotate_nms;   /* test_cfg */
+  float score_thr, nms_thr;
+  float dir_offset, dir_limit_offset;         /* Anchor3DHead(dir_offset, dir_limit_offset) */
+  int32_t winograd;           /* 1: F(m x m, 3x3) form for the eligible layers (default of the Python host), 0: direct only */
+  int32_t winograd_tile;      /* 0: automatic (6 on planes >= 16384 positions, else 4) | 2 | 4 | 6 */
+} ivx_model_cfg;
+
+int ivx_create(const ivx_model_cfg *cfg, ivx_model **out);
+int ivx_destroy(ivx_model *m);
+int ivx_weights_load(ivx_model *m, const char *key, const float *data_host, const int64_t *shape, int32_t ndim);
+int ivx_weights_finalize(ivx_model *m, ivx_stream_t stream);
+/* Whole path.  input: image batch [B*V,3,H,W] NCHW fp32 (with_trunk) or FPN level-0 maps [B*V,1,H/4,W/4,Cf] channels-last;
+ * H, W = padded image size (multiples of 32).  proj [B,V,3,4], new_origin [B,3], crop_hw [B,2] int32 as for
+ * ivx_backproject_mean_fwd (device).  Outputs as ivx_anchor_head_get_bboxes; out_valid [B,X,Y,Z] u8 or NULL. */
+int64_t ivx_model_workspace_bytes(ivx_model *m, int32_t B, int32_t V, int32_t H, int32_t W);
+int ivx_model_forward(ivx_model *m, const float *input, int32_t B, int32_t V, int32_t H, int32_t W, const float *proj,
+                      const float *new_origin, const int32_t *crop_hw, void *workspace, int64_t workspace_bytes,
+                      float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_count, uint8_t *out_valid,
+                      ivx_stream_t stream);
+/* Sub-paths on the same handle: backbone(img) + neck(x)[0] (detectors/imvoxelnet.py:48,50) and neck_3d(x) (:79).
+ * fpn0 [BV,1,H/4,W/4,Cf]; volume [B,X,Y,Z,Cf] -> out [B,X',Y',1,Cout] (ivx_neck3d_out_dims). */
+int64_t ivx_backbone_fpn_workspace_bytes(ivx_model *m, int32_t BV, int32_t H, int32_t W);
+int ivx_backbone_fpn_fwd(ivx_model *m, const float *img, int32_t BV, int32_t H, int32_t W, float *fpn0, void *workspace,
+                         int64_t workspace_bytes, ivx_stream_t stream);
+int64_t ivx_neck3d_workspace_bytes(ivx_model *m, int32_t B);
+int ivx_neck3d_out_dims(ivx_model *m, int32_t B, int32_t *X, int32_t *Y, int32_t *C);
+int ivx_neck3d_kitti_fwd(ivx_model *m, const float *volume, int32_t B, float *out, void *workspace, int64_t workspace_bytes,
+                         ivx_stream_t stream);
+int ivx_neck3d_nuscenes_fwd(ivx_model *m, const float *volume, int32_t B, float *out, void *workspace,
+                            int64_t workspace_bytes, ivx_stream_t stream);
+/* Optional stage timing (measurement only): while enabled, every launch group of the forward calls is bracketed by a pair
+ * of HIP events on the caller's stream; the Winograd layers run as their three stages so each is timed.  stage: 0 direct
+ * conv, 1 Winograd input transform, 2 grouped GEMM, 3 output transform, 4 unprojection, 5 anchor tail.  flops = FLOPs the
+ * launch executes, bytes = algorithmic bytes of a transform / unprojection launch.  Read after synchronising the stream. */
+typedef struct ivx_trace_rec {
+  int32_t step, stage, is3d;
+  float ms;        /* duration of the launch group */
+  float start_ms;  /* its start, relative to the first record since tracing was enabled */
+  double flops, bytes;
+  char name[48];
+} ivx_trace_rec;
+int ivx_model_trace(ivx_model *m, int32_t enable);
+int32_t ivx_model_trace_count(ivx_model *m);
+int ivx_model_trace_read(ivx_model *m, int32_t i, ivx_trace_rec *rec);
+
+/* Host-only helpers (no device work, usable without a GPU): the built-in anchor grid for an (H, W) map
+ * (Anchor3DRangeGenerator, anchor_3d_generator.py:82-209), and the per-sample camera set-up of
+ * detectors/imvoxelnet.py:114-129 / :139 in a fixed fp32 operation order: proj[v] = (K[:3,:3] with rows 0,1 / ratio) @ E_v[:3]
+ * as an FMA chain over k; new_origin = origin - n_voxels / 2 * voxel_size. */
+int ivx_model_anchors(ivx_model *m, int32_t H, int32_t W, float *anchors_host, int64_t capacity);
+int ivx_compute_projection(const float *intrinsic4x4, const float *extrinsics /* [V,4,4] */, int32_t V, double ratio,
+                           float *proj /* [V,3,4] */);
+int ivx_voxel_new_origin(const float *origin, const int32_t *n_voxels, const float *voxel_size, float *new_origin);
 
 #ifdef __cplusplus
 }

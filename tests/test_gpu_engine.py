@@ -1,0 +1,161 @@
+"""-m gpu: the model-level C-ABI (csrc/model.cpp: ivx_create / ivx_weights_load / ivx_model_forward ...).
+
+The native handle and the layer-by-layer Python composition run the same kernels with the same plans, so their results
+must be BIT-identical; the handle is also driven by a C program with no Python in the process (tests/c/e2e_small.c) on
+the reference's end-to-end golden case."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import kitti_cfg as kc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def ia():
+    import imvoxelnet_amd
+    from imvoxelnet_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return imvoxelnet_amd
+
+
+def _kitti_model(ia, n_voxels, seed=21):
+    model = ia.build_detector(kc.kitti_model_cfg(n_voxels=n_voxels), test_cfg=kc.KITTI_TEST_CFG)
+    ia.randomize_(model, seed)
+    with torch.no_grad():
+        model.bbox_head.conv_cls.weight.normal_(0, 0.03, generator=torch.Generator().manual_seed(5))
+        model.bbox_head.conv_cls.bias.fill_(-1.5)
+        model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
+        model.bbox_head.conv_dir_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(7))
+    return model
+
+
+def _assert_same_detections(a, b):
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), f'{(x != y).sum().item()} values differ'
+
+
+@pytest.mark.parametrize('shape', ['small', 'full'])
+def test_native_model_equals_layerwise_kitti(ia, shape):
+    """ivx_model_forward == features_2d_cl -> lift_cl -> detect_cl, bit for bit (boxes, scores, labels, counts, valid mask),
+    and the sub-path entry points ivx_backbone_fpn_fwd / ivx_neck3d_kitti_fwd == backbone+FPN / neck_3d.forward_cl."""
+    if shape == 'small':
+        nv, hw, B = (104, 120, 12), (192, 640), 2
+    else:
+        nv, hw, B = (216, 248, 12), (384, 1280), 4      # BASELINE config 2 as benchmarked
+    model = _kitti_model(ia, nv)
+    model.prepare(torch.device('cuda'))
+    assert model._native is not None, 'the KITTI configuration must run on the native model handle'
+    img = torch.randn(B, 1, 3, *hw, generator=torch.Generator().manual_seed(3)).cuda()
+    metas = [kc.kitti_meta(img_hw=hw, t=(0.02 * b, 0.01 * b, 0.0), box_type=ia.LiDARInstance3DBoxes) for b in range(B)]
+    # layer by layer over the op-level C-ABI
+    p0 = model.features_2d_cl(img)
+    vol, valid = model.lift_cl(p0, metas)
+    y = model.neck_3d.forward_cl(vol)
+    ref = model.detect_cl(vol, metas)
+    # one native call
+    proj, new_origin, crop = model._camera_setup(metas, 4, img.device)
+    out = model._native.forward(img.reshape(B, 3, *hw).contiguous(), B, 1, hw[0], hw[1], proj, new_origin, crop, want_valid=True)
+    _assert_same_detections(out[:4], ref)
+    assert torch.equal(out[4], valid)
+    assert int(ref[3].sum()) > 0
+    # sub-paths
+    assert torch.equal(model._native.backbone_fpn(img.reshape(B, 3, *hw).contiguous()), p0)
+    assert torch.equal(model._native.neck3d(vol), y)
+    # and the public call goes through the handle
+    res = model.simple_test(img, metas)
+    for b in range(B):
+        n = int(ref[3][b])
+        assert len(res[b]['scores_3d']) == n
+        assert torch.equal(res[b]['scores_3d'], ref[1][b, :n].cpu()) and torch.equal(res[b]['boxes_3d'].tensor, ref[0][b, :n].cpu())
+        assert torch.equal(res[b]['labels_3d'], ref[2][b, :n].cpu())
+
+
+def test_native_model_nuscenes_plain_resnet(ia):
+    """NuScenesImVoxelNeck family (6 views, dir_offset pi/4, nms_pre 1000) on the handle; the reference's DCNv2 backbone is
+    outside it (engine.eligible) and keeps the layer-by-layer path."""
+    from imvoxelnet_amd import engine
+    cfg = kc.nuscenes_model_cfg(n_voxels=(104, 104, 12), dcn=False)
+    model = ia.build_detector(cfg, test_cfg=kc.NUSCENES_TEST_CFG)
+    ia.randomize_(model, 4)
+    with torch.no_grad():
+        model.bbox_head.conv_cls.weight.normal_(0, 0.03, generator=torch.Generator().manual_seed(5))
+        model.bbox_head.conv_cls.bias.fill_(-1.5)
+        model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
+    model.prepare(torch.device('cuda'))
+    assert model._native is not None
+    hw = (224, 416)
+    meta = kc.nuscenes_meta(img_hw=hw, box_type=ia.LiDARInstance3DBoxes)
+    for e in meta['lidar2img']['extrinsic']:       # the synthetic rig is built for 928 x 1600 images: rescale K to this size
+        e[0] *= np.float32(hw[1] / 1600.)
+        e[1] *= np.float32(hw[0] / 928.)
+    img = torch.randn(1, 6, 3, *hw, generator=torch.Generator().manual_seed(8)).cuda()
+    p0 = model.features_2d_cl(img)
+    vol, valid = model.lift_cl(p0, [meta])
+    ref = model.detect_cl(vol, [meta])
+    proj, new_origin, crop = model._camera_setup([meta], 4, img.device)
+    out = model._native.forward(img.reshape(6, 3, *hw).contiguous(), 1, 6, hw[0], hw[1], proj, new_origin, crop, want_valid=True)
+    _assert_same_detections(out[:4], ref)
+    assert torch.equal(out[4], valid) and 0.05 < float(valid.float().mean()) < 1.0
+    dcn_model = ia.build_detector(kc.nuscenes_model_cfg(n_voxels=(104, 104, 12)), test_cfg=kc.NUSCENES_TEST_CFG)
+    assert not engine.eligible(dcn_model)
+
+
+def test_native_model_trace_and_errors(ia):
+    """ivx_model_trace: one record per launch group with plausible durations; bad arguments fail loudly."""
+    import ctypes as C
+    from imvoxelnet_amd import _lib
+    model = _kitti_model(ia, (104, 120, 12))
+    model.prepare(torch.device('cuda'))
+    nat = model._native
+    hw, B = (192, 640), 2
+    img = torch.randn(B, 1, 3, *hw, generator=torch.Generator().manual_seed(3)).cuda()
+    metas = [kc.kitti_meta(img_hw=hw, box_type=ia.LiDARInstance3DBoxes) for _ in range(B)]
+    model.simple_test(img, metas)
+    nat.trace(True)
+    model.simple_test(img, metas)
+    torch.cuda.synchronize()
+    recs = nat.trace_records()
+    nat.trace(False)
+    stages = [r['stage'] for r in recs]
+    assert stages.count(4) == 1 and stages.count(5) == 1 and stages.count(2) >= 9, stages
+    assert stages.count(1) == stages.count(2) == stages.count(3)
+    assert all(r['ms'] > 0 for r in recs) and all(b['start_ms'] >= a['start_ms'] for a, b in zip(recs, recs[1:]))
+    neck_gemm = [r for r in recs if r['stage'] == 2 and r['is3d']]
+    assert len(neck_gemm) == 9 and all(r['flops'] > 0 for r in neck_gemm)
+    # errors: unpadded image size, too small a workspace, a handle without the trunk asked for the trunk
+    L = _lib.lib()
+    assert L.ivx_model_workspace_bytes(nat.h, 1, 1, 100, 640) == -1
+    proj, new_origin, crop = model._camera_setup(metas, 4, img.device)
+    x = img.reshape(B, 3, *hw).contiguous()
+    small = torch.empty(4096, device='cuda', dtype=torch.uint8)
+    rc = L.ivx_model_forward(nat.h, C.c_void_p(x.data_ptr()), B, 1, hw[0], hw[1], C.c_void_p(proj.data_ptr()), C.c_void_p(new_origin.data_ptr()),
+                             C.c_void_p(crop.data_ptr()), C.c_void_p(small.data_ptr()), small.numel(), None, None, None, None, None, None)
+    assert rc == -4 and b'workspace too small' in L.ivx_last_error()
+    from imvoxelnet_amd.engine import NativeModel
+    headless = NativeModel(model, torch.device('cuda'), with_trunk=False)
+    assert L.ivx_backbone_fpn_workspace_bytes(headless.h, 2, 192, 640) == -1
+    p0 = model.features_2d_cl(img)
+    out = headless.forward(p0, B, 1, hw[0], hw[1], proj, new_origin, crop)
+    ref = nat.forward(x, B, 1, hw[0], hw[1], proj, new_origin, crop)
+    _assert_same_detections(out, ref)
+
+
+def test_c_program_e2e_small_without_python(ia):
+    """tests/c/e2e_small.c: a C host (no Python in the process) drives ivx_create / ivx_weights_load / ivx_model_forward on
+    the reference's end-to-end golden case and checks detections and valid mask against the reference's outputs."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'c'))
+    import build as cbuild
+    exe = cbuild.build('e2e_small')
+    fx = os.path.join(ROOT, 'tests', 'golden', 'e2e_small.bin')
+    out = subprocess.run([exe, fx], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'C e2e_small OK' in out.stdout

@@ -532,3 +532,64 @@ def test_bench_launches_n_ranks(how):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['dry'] is True and rec['gathered_ok'] is True
     assert rec['config']['global_batch'] == 8 and rec['config']['parallelism'] == 'dp2'
+
+
+def test_projection_host_function_is_deterministic_and_pinned():
+    """ivx_compute_projection == the golden projections of the imported reference (bit-exact), whatever matmul kernel this
+    host's BLAS would have picked."""
+    from helpers import sub
+    from imvoxelnet_amd.engine import compute_projection
+    g = load_npz('backproject_cases.npz')
+    for case in 'ABCDE':
+        c = sub(g, case + '::')
+        ratio = float(c['ori_shape'][0]) / (float(c['img_shape'][0]) / 4)
+        P = compute_projection(c['intrinsic'], list(c['extrinsic']), ratio).numpy()
+        assert np.array_equal(P, c['projection']), case
+
+
+def test_model_cabi_host_side_without_gpu():
+    """The model-level C-ABI on a box without a GPU: ivx_create validates the configuration, the built-in anchor generator
+    agrees with Anchor3DRangeGenerator (to fp32 rounding of linspace: 1e-6), ivx_voxel_new_origin == the reference's
+    `origin - n_voxels / 2. * voxel_size` bit for bit, weights can be staged, and a forward without finalized weights
+    fails with a message instead of crashing."""
+    import ctypes as C
+    import imvoxelnet_amd as ia
+    from imvoxelnet_amd import _lib
+    from imvoxelnet_amd._lib import ModelCfg
+    L = _lib.lib()
+    cfg = ModelCfg()
+    cfg.neck_type, cfg.with_trunk, cfg.fpn_channels, cfg.neck_out_channels = 0, 1, 64, 256
+    cfg.n_voxels[:] = [216, 248, 12]
+    cfg.voxel_size[:] = [.32, .32, .32]
+    cfg.num_classes, cfg.n_sizes, cfg.n_rotations = 1, 1, 2
+    cfg.anchor_range[:] = [0, -39.68, -1.78, 69.12 - .32, 39.68 - .32, -1.78]
+    cfg.anchor_sizes[:3] = [1.6, 3.9, 1.56]
+    cfg.anchor_rotations[:2] = [0, 1.57]
+    cfg.nms_pre, cfg.max_num, cfg.use_rotate_nms, cfg.score_thr, cfg.nms_thr = 100, 50, 1, .1, .01
+    cfg.dir_limit_offset, cfg.winograd = 1.0, 1
+    h = C.c_void_p()
+    assert L.ivx_create(C.byref(cfg), C.byref(h)) == 0
+    H, W = 246, 214
+    got = np.empty((H * W * 2, 7), np.float32)
+    assert L.ivx_model_anchors(h, H, W, got.ctypes.data_as(C.c_void_p), got.size) == 0
+    gen = ia.Anchor3DRangeGenerator(ranges=[[0, -39.68, -1.78, 69.12 - .32, 39.68 - .32, -1.78]], sizes=[[1.6, 3.9, 1.56]], rotations=[0, 1.57])
+    want = gen.grid_anchors([(H, W)])[0].reshape(-1, 7).numpy()
+    assert got.shape == want.shape and np.abs(got - want).max() <= 4e-6 * 70
+    w = np.zeros((64, 3, 7, 7), np.float32)
+    shape = (C.c_int64 * 4)(*w.shape)
+    assert L.ivx_weights_load(h, b'module.backbone.conv1.weight', w.ctypes.data_as(C.c_void_p), shape, 4) == 0
+    assert L.ivx_model_workspace_bytes(h, 1, 1, 384, 1280) == -1 and b'finalize' in L.ivx_last_error()
+    assert L.ivx_weights_finalize(h, None) != 0 and b'missing state-dict keys' in L.ivx_last_error()   # only one tensor was staged
+    assert L.ivx_destroy(h) == 0
+    bad = ModelCfg()
+    assert L.ivx_create(C.byref(bad), C.byref(h)) == -1
+    for origin, nv, vs in (((34.56, 0, -1), (216, 248, 12), (.32, .32, .32)), ((0, 0, .5), (80, 80, 32), (.08, .08, .08)),
+                           ((0.4, -0.2, -0.8), (192, 192, 32), (.32, .32, .32))):
+        o = np.asarray(origin, np.float32)
+        out = np.empty(3, np.float32)
+        n32 = np.asarray(nv, np.int32)
+        v32 = np.asarray(vs, np.float32)
+        assert L.ivx_voxel_new_origin(o.ctypes.data_as(C.c_void_p), n32.ctypes.data_as(C.c_void_p), v32.ctypes.data_as(C.c_void_p),
+                                      out.ctypes.data_as(C.c_void_p)) == 0
+        ref = (torch.tensor(o) - torch.tensor(nv) / 2. * torch.tensor(vs)).numpy()
+        assert np.array_equal(out, ref), (out, ref)
