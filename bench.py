@@ -146,8 +146,6 @@ def bench_other(args, ia, kc, dev, rank, world):
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if native_trace:
-        model._native.trace(True)          # drop the warm-up records; the event pool they created is kept
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -371,6 +369,8 @@ def main():
             return int(out[:, -1].sum().item())
         step(0)
         torch.cuda.synchronize()
+    if native_trace:
+        model._native.trace(True)          # drop the warm-up records; the event pool they created is kept
     if multi:
         dist.barrier()
     torch.cuda.synchronize()

@@ -45,7 +45,7 @@ class TraceRec(C.Structure):
                 ('bytes', C.c_double), ('name', C.c_char * 48)]
 
 
-EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_winograd_set_transform_blocks', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_stagger', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
+EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_winograd_set_transform_blocks', 'ivx_conv_set_epilogue_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
            'ivx_conv_winograd_supported', 'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_weights', 'ivx_conv_winograd_workspace_bytes',
            'ivx_conv_winograd_input', 'ivx_conv_winograd_gemm', 'ivx_conv_winograd_output', 'ivx_conv_winograd_fwd',
            'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
@@ -54,7 +54,7 @@ EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd',
            'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms', 'ivx_multiclass_nms_workspace_bytes', 'ivx_multiclass_nms_bev',
            'ivx_create', 'ivx_destroy', 'ivx_weights_load', 'ivx_weights_finalize', 'ivx_model_workspace_bytes', 'ivx_model_forward',
            'ivx_backbone_fpn_workspace_bytes', 'ivx_backbone_fpn_fwd', 'ivx_neck3d_workspace_bytes', 'ivx_neck3d_out_dims',
-           'ivx_neck3d_kitti_fwd', 'ivx_neck3d_nuscenes_fwd', 'ivx_model_anchors', 'ivx_compute_projection', 'ivx_voxel_new_origin',
+           'ivx_neck3d_kitti_fwd', 'ivx_neck3d_nuscenes_fwd', 'ivx_model_anchors', 'ivx_compute_projection', 'ivx_voxel_new_origin', 'ivx_fold_batchnorm',
            'ivx_model_trace', 'ivx_model_trace_count', 'ivx_model_trace_read',
            'ivx_kitti_image_box_overlap', 'ivx_kitti_compute_statistics', 'ivx_kitti_collect_scores', 'ivx_kitti_fused_statistics']
 
@@ -77,7 +77,6 @@ def lib():
     L.ivx_conv_set_tile_override.argtypes = [C.c_int]
     L.ivx_conv_winograd_set_transform_blocks.argtypes = [C.c_int]
     L.ivx_conv_set_epilogue_mode.argtypes = [C.c_int]
-    L.ivx_conv_set_stagger.argtypes = [C.c_int]
     L.ivx_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
     L.ivx_conv_workspace_bytes.restype = i64
     L.ivx_conv_fwd_ws.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, i64, vp]
@@ -136,6 +135,7 @@ def lib():
     L.ivx_model_anchors.argtypes = [vp, i32, i32, vp, i64]
     L.ivx_compute_projection.argtypes = [vp, vp, i32, C.c_double, vp]
     L.ivx_voxel_new_origin.argtypes = [vp, vp, vp, vp]
+    L.ivx_fold_batchnorm.argtypes = [vp, vp, vp, vp, vp, f32, i32, vp, vp]
     L.ivx_model_trace.argtypes = [vp, i32]
     L.ivx_model_trace_count.argtypes = [vp]
     L.ivx_model_trace_count.restype = i32

@@ -25,6 +25,22 @@ def _spatial3(v, dims, fill):
     return v
 
 
+def fold_batchnorm(bn, bias, eps=1e-5):
+    """(gamma, beta, running_mean, running_var) [+ conv bias] -> (scale, shift) of the conv epilogue, through the library's
+    host function ivx_fold_batchnorm (IEEE fp32, fixed operation order), so every host of the kernels -- this module and
+    the native model handle (csrc/model.cpp) -- hands them identical bits."""
+    import ctypes as C
+    from . import _lib
+    g, b, m, v = (t.detach().to(torch.float32).cpu().contiguous() for t in bn)
+    n = g.numel()
+    bias_t = None if bias is None else bias.detach().to(torch.float32).cpu().contiguous()
+    scale, shift = torch.empty(n), torch.empty(n)
+    _lib.check(_lib.lib().ivx_fold_batchnorm(C.c_void_p(g.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()),
+                                             None if bias_t is None else C.c_void_p(bias_t.data_ptr()), float(eps), n,
+                                             C.c_void_p(scale.data_ptr()), C.c_void_p(shift.data_ptr())), 'ivx_fold_batchnorm')
+    return scale, shift
+
+
 _storage = [torch.float32]
 
 
@@ -126,9 +142,7 @@ class FusedConv:
         if bias is not None:
             shift = bias.detach().to(torch.float32).cpu().clone()
         if bn is not None:
-            g, b, m, v = (t.detach().to(torch.float32).cpu() for t in bn)
-            scale = g / torch.sqrt(v + eps)
-            shift = b + (shift - m) * scale
+            scale, shift = fold_batchnorm(bn, shift, eps)
         self._identity_epilogue = bias is None and bn is None
         self._scale_host, self._shift_host = scale.contiguous(), shift.contiguous()
         self.relu = relu
@@ -233,8 +247,6 @@ class FusedConvTranspose2x(FusedConv):
         self.cout_real = cout
         scale, shift = torch.ones(cout), torch.zeros(cout)
         if bn is not None:
-            g, b, m, v = (t.detach().to(torch.float32).cpu() for t in bn)
-            scale = g / torch.sqrt(v + eps)
-            shift = b - m * scale
+            scale, shift = fold_batchnorm(bn, None, eps)
             self._identity_epilogue = False
         self._scale_host, self._shift_host = scale.contiguous(), shift.contiguous()

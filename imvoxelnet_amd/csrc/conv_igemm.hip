@@ -51,9 +51,6 @@ struct ConvParams {
   long long g_in, g_w, g_out;
   int groups;
   int narrow_epilogue;  // A/B knob: 1 = the one-channel-per-lane epilogue everywhere (ivx_conv_set_epilogue_mode)
-  // start-up stagger (LDS-DMA kernel): workgroup b of the first stagger_wgs dispatched sleeps (b / 256) * stagger_sleeps x 8128
-  // cycles, so the workgroups sharing a CU do not run their prologues / epilogues in lock-step (ivx_conv_set_stagger)
-  int stagger_sleeps, stagger_wgs;
 };
 
 __device__ __forceinline__ float conv_ld_res(const ConvParams &p, size_t i) {
@@ -428,11 +425,6 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   if (mt * BM >= p.M) return;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
-  if (p.stagger_sleeps > 0) {
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (lin < (unsigned)p.stagger_wgs)
-      for (int i = (int)(lin >> 8) * p.stagger_sleeps; i > 0; --i) __builtin_amdgcn_s_sleep(127);
-  }
 
   const size_t gz = blockIdx.z;   // group of a grouped launch (strides are 0 otherwise)
   const __amdgpu_buffer_rsrc_t rs_in =
@@ -766,14 +758,6 @@ extern "C" int ivx_conv_set_epilogue_mode(int narrow) {
   return IVX_OK;
 }
 
-static thread_local int g_stagger_pct = 0;
-// Tuning knob (per calling thread): start-up stagger of the LDS-DMA kernel in percent of (tile time / workgroups per CU);
-// 0 = off (default).
-extern "C" int ivx_conv_set_stagger(int percent) {
-  g_stagger_pct = percent > 0 ? percent : 0;
-  return IVX_OK;
-}
-
 static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
                        const float *shift, const void *res, void *out, ConvParams *p) {
   IVX_REQUIRE(d && in && wgt && out, "ivx_conv_fwd: null argument");
@@ -814,7 +798,6 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   p->ksplit = 1; p->partial = nullptr; p->q_total = 0; p->q_begin = 0; p->q_count = 0; p->bm = 0;
   p->groups = 1; p->g_in = p->g_w = p->g_out = 0;
   p->narrow_epilogue = g_narrow_epilogue;
-  p->stagger_sleeps = 0; p->stagger_wgs = 0;
   return IVX_OK;
 }
 
@@ -851,14 +834,6 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
   }
   const long long g1 = 8LL * p.q_count * Nt;
   const dim3 grid((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1, p.groups > 1 ? p.groups : 1);
-  p.stagger_sleeps = 0;
-  if (g_stagger_pct > 0 && WPE > 1) {
-    // one workgroup's MFMA time on an otherwise idle CU = 2*BM*BN*K / 256 flop per clock; the WPE workgroups of a CU are
-    // spread over that interval (x percent / 100), in s_sleep(127) units of 8128 cycles
-    const double cyc = 2.0 * BM * BN * (double)p.K / (p.ksplit > 1 ? p.ksplit : 1) / 256.0 * (sizeof(T) == 2 ? 1.0 / 16 : 1.0);
-    p.stagger_sleeps = (int)(cyc * g_stagger_pct / 100.0 / 8128.0 + 0.5);
-    p.stagger_wgs = 256 * WPE;
-  }
   // every slab lies inside one filter tap -> uniform K-loop state
   const bool uni = p.kmode == 1 || p.Cin % BK == 0;
   auto kern = uni ? conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1> : conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 0>;
@@ -1166,7 +1141,10 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     // KW*Cin here (192 .. 768), so a workgroup's prologue and epilogue weigh more than in the direct form and one more
     // resident workgroup per CU pays: 128 x 64 at six per CU for Cout <= 64 (1.51 vs 1.85 ms at five), 128 x 128 at five
     // per CU up to K = 512 (2.50 vs 2.90 ms at four); at K = 768 four and five tie
-    else if (nblk >= 2500) pl.cfg = p.Cout > 64 ? (p.K <= 512 ? 55 : 54) : 56;
+    // re-measured with the LDS-transposed epilogue (profiles/r02_conv_layers.log): Cout <= 64 prefers 256 x 64 tiles at four per
+    // CU (1.12 vs 1.30 ms for 128 x 64 at six), Cout = 128 at K = 192 the 128 x 64 tile at six (1.07 vs 1.11), 256 output
+    // channels four 128 x 128 workgroups per CU also at K = 384 (1.82 vs 1.85)
+    else if (nblk >= 2500) pl.cfg = p.Cout > 64 ? (p.K <= 256 ? 56 : (p.K <= 512 && p.Cout < 256 ? 55 : 54)) : 57;
     else pl.cfg = p.K <= 640 ? 47 : 46;
   }
   TileInfo t;

@@ -320,12 +320,9 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
     if (!g || !b || !mu || !var) { *missing += L.bn + ".{weight,bias,running_mean,running_var} "; return IVX_OK; }
     M_REQUIRE((int)g->data.size() == L.cout && (int)b->data.size() == L.cout && (int)mu->data.size() == L.cout && (int)var->data.size() == L.cout,
               "ivx_weights_finalize: BatchNorm %s has the wrong size", L.bn.c_str());
-    const float eps = 1e-5f;
-    for (int c = 0; c < L.cout; ++c) {   // scale = gamma / sqrt(var + eps); shift = beta + (bias - mean) * scale
-      scale[c] = g->data[c] / sqrtf(var->data[c] + eps);
-      const float t = (shift[c] - mu->data[c]) * scale[c];
-      shift[c] = b->data[c] + t;
-    }
+    std::vector<float> bias_in(shift);
+    M_TRY(ivx_fold_batchnorm(g->data.data(), b->data.data(), mu->data.data(), var->data.data(), bias_in.data(), 1e-5f, L.cout, scale.data(),
+                             shift.data()));
   }
   L.identity_epilogue = !has_bias && L.bn.empty();
   if (!L.identity_epilogue) {
@@ -938,5 +935,21 @@ extern "C" int ivx_model_trace_read(ivx_model *m, int32_t i, ivx_trace_rec *rec)
   M_HIP(hipEventElapsedTime(&start, m->trace[0].e0, r.e0), "hipEventElapsedTime");
   rec->step = r.step; rec->stage = r.stage; rec->is3d = r.is3d; rec->ms = ms; rec->start_ms = start; rec->flops = r.flops; rec->bytes = r.bytes;
   snprintf(rec->name, sizeof(rec->name), "%s", r.name.c_str());
+  return IVX_OK;
+}
+
+// Host-only: eval-mode BatchNorm (and the conv bias) as the epilogue's per-channel affine, in IEEE fp32 with a fixed
+// operation order:  scale = gamma / sqrt(var + eps);  shift = beta + (bias - mean) * scale.   bias may be NULL (zeros).
+// Both hosts of the conv kernels (the native model handle and the Python FusedConv) call this, so they feed the kernels
+// the same bits whatever vector math library the host's tensor package uses.
+extern "C" int ivx_fold_batchnorm(const float *gamma, const float *beta, const float *mean, const float *var, const float *bias, float eps,
+                                  int32_t n, float *scale, float *shift) {
+  M_REQUIRE(gamma && beta && mean && var && scale && shift && n > 0, "ivx_fold_batchnorm: bad argument");
+  for (int c = 0; c < n; ++c) {
+    const float s = gamma[c] / sqrtf(var[c] + eps);
+    const float t = ((bias ? bias[c] : 0.0f) - mean[c]) * s;
+    scale[c] = s;
+    shift[c] = beta[c] + t;
+  }
   return IVX_OK;
 }

@@ -3,8 +3,11 @@ on-disk calibration -> `lidar2img` adapters.  Host-side numpy/torch; nothing her
 
 Reference: configs/imvoxelnet/imvoxelnet_kitti.py:66,94-105 (Resize keep_ratio -> Normalize -> Pad(size_divisor=32)),
 mmdet3d/datasets/{kitti,nuscenes,scannet,sunrgbd}_monocular_dataset.py (lidar2img), pipelines/multi_view.py:45-53
-(KittiSetOrigin).  mmcv/cv2 are not available here: the resize is torch bilinear (half-pixel centres, no anti-alias),
-which matches cv2.INTER_LINEAR up to its fixed-point rounding -- parity of the resize is UNPINNED.
+(KittiSetOrigin, SunRgbdSetOrigin), pipelines/multi_view.py:7-31 (MultiViewPipeline view sampling).
+mmcv / cv2 are not installed here: the resize restates cv2.resize(INTER_LINEAR) on uint8 images -- the 11-bit fixed-point
+coefficient tables, the int32 horizontal pass, the `>> 4 ... >> 16 ... + 2 >> 2` vertical pass and the exact-half
+INTER_AREA shortcut -- from OpenCV's published algorithm (imgproc/resize.cpp); it is checked against hand-derived vectors
+(tests/test_host_cpu.py), not against cv2 itself: parity of the resize stays UNPINNED.
 """
 import numpy as np
 import torch
@@ -50,17 +53,59 @@ def rescale_size(old_hw, scale):
     return int(h * float(f) + 0.5), int(w * float(f) + 0.5)
 
 
+def _linear_tables(src, dst):
+    """cv2 resize.cpp, INTER_LINEAR coefficient tables for one axis: source index and the two 11-bit weights per output
+    position.  fx = (d + 0.5) * (src / dst) - 0.5 in FLOAT, sx = floor(fx); clamped at both borders; weights =
+    round((1 - fx, fx) * 2048) as int16."""
+    scale = float(src) / float(dst)
+    d = np.arange(dst, dtype=np.float64)
+    fx = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    sx = np.floor(fx).astype(np.int64)
+    fx = (fx - sx.astype(np.float32)).astype(np.float32)
+    lo = sx < 0
+    sx[lo], fx[lo] = 0, 0.0
+    hi = sx >= src - 1
+    sx[hi], fx[hi] = src - 1, 0.0
+    a1 = np.rint(fx * np.float32(2048.0)).astype(np.int64)           # cvRound: round half to even
+    a0 = np.rint((np.float32(1.0) - fx) * np.float32(2048.0)).astype(np.int64)
+    return sx, np.minimum(sx + 1, src - 1), a0, a1
+
+
+def imresize_cv2_linear(img_u8, size_hw):
+    """cv2.resize(img, (w, h), interpolation=cv2.INTER_LINEAR) for an (H, W, C) uint8 image (what mmcv.imresize runs inside
+    mmdet's Resize: imvoxelnet_kitti.py:98), in integer arithmetic:
+      horizontal: D[x] = S[sx] * a0 + S[sx+1] * a1                                  (int32, weights sum to 2048)
+      vertical:   dst  = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2
+    An exact 2x down-scale on both axes takes OpenCV's INTER_AREA shortcut: (a + b + c + d + 2) >> 2."""
+    img = np.ascontiguousarray(img_u8)
+    if img.dtype != np.uint8 or img.ndim != 3:
+        raise TypeError('imresize_cv2_linear expects an (H, W, C) uint8 image')
+    h, w = img.shape[:2]
+    nh, nw = int(size_hw[0]), int(size_hw[1])
+    if (nh, nw) == (h, w):
+        return img.copy()
+    if h == 2 * nh and w == 2 * nw:
+        q = img.astype(np.int64).reshape(nh, 2, nw, 2, img.shape[2])
+        return ((q.sum(axis=(1, 3)) + 2) >> 2).astype(np.uint8)
+    sx, sx1, a0, a1 = _linear_tables(w, nw)
+    sy, sy1, b0, b1 = _linear_tables(h, nh)
+    src = img.astype(np.int64)
+    rows = src[:, sx] * a0[None, :, None] + src[:, sx1] * a1[None, :, None]        # [h, nw, C], up to 255 * 2048
+    d0, d1 = rows[sy] >> 4, rows[sy1] >> 4
+    out = (((b0[:, None, None] * d0) >> 16) + ((b1[:, None, None] * d1) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def prepare_image(img_bgr_u8, img_scale, img_norm_cfg=IMG_NORM_CFG, size_divisor=32, keep_ratio=True):
     """LoadImageFromFile -> Resize -> Normalize -> Pad for ONE image (H,W,3 uint8, BGR as cv2 loads it).
     Returns (tensor [3,Hp,Wp] fp32, meta dict with img_shape / ori_shape / pad_shape as the mmdet pipeline sets them)."""
-    img = torch.from_numpy(np.ascontiguousarray(img_bgr_u8)).float().permute(2, 0, 1)[None]
     ori_shape = tuple(img_bgr_u8.shape)
     if keep_ratio:
         nh, nw = rescale_size(ori_shape[:2], img_scale)
     else:
         nw, nh = img_scale
-    if (nh, nw) != ori_shape[:2]:
-        img = F.interpolate(img, size=(nh, nw), mode='bilinear', align_corners=False)
+    resized = imresize_cv2_linear(img_bgr_u8, (nh, nw))                    # uint8 in, uint8 out, as mmcv.imresize
+    img = torch.from_numpy(resized).float().permute(2, 0, 1)[None]
     mean = torch.tensor(img_norm_cfg['mean'], dtype=torch.float32).view(1, 3, 1, 1)
     std = torch.tensor(img_norm_cfg['std'], dtype=torch.float32).view(1, 3, 1, 1)
     if img_norm_cfg.get('to_rgb', True):
@@ -70,6 +115,77 @@ def prepare_image(img_bgr_u8, img_scale, img_norm_cfg=IMG_NORM_CFG, size_divisor
     pw = (nw + size_divisor - 1) // size_divisor * size_divisor
     img = F.pad(img, (0, pw - nw, 0, ph - nh))
     return img[0], dict(img_shape=(nh, nw, 3), ori_shape=ori_shape, pad_shape=(ph, pw, 3))
+
+
+# ------------------------------------------------------------------ multi-view pipeline
+class MultiViewPipeline:
+    """pipelines/multi_view.py:7-31: draw `n_images` of the scene's views with np.random.choice (with replacement only when
+    the scene has fewer views), run the per-view transforms on each drawn view, and re-order the extrinsics to the drawn
+    order.  `transforms`: one callable or a list of callables dict -> dict (mmdet's Compose of LoadImageFromFile / Resize /
+    Normalize / Pad; view_transform() below is that chain for an in-memory image).  Seed numpy's global generator as
+    the reference's training / test scripts do to reproduce a draw."""
+
+    def __init__(self, transforms, n_images):
+        self.transforms = list(transforms) if isinstance(transforms, (list, tuple)) else [transforms]
+        self.n_images = n_images
+
+    def _apply(self, res):
+        for t in self.transforms:
+            res = t(res)
+        return res
+
+    def __call__(self, results):
+        ids = np.arange(len(results['img_info']))
+        ids = np.random.choice(ids, self.n_images, replace=self.n_images > len(ids))
+        imgs, extrinsics, last = [], [], None
+        for i in ids.tolist():
+            last = self._apply({key: results[key][i] for key in ('img_prefix', 'img_info')})
+            imgs.append(last['img'])
+            extrinsics.append(results['lidar2img']['extrinsic'][i])
+        for key, val in last.items():          # per-view meta of the LAST drawn view becomes the sample's (img_shape, ...)
+            if key not in ('img', 'img_prefix', 'img_info'):
+                results[key] = val
+        results['img'] = imgs
+        results['lidar2img']['extrinsic'] = extrinsics
+        return results
+
+
+def view_transform(img_scale, img_norm_cfg=IMG_NORM_CFG, size_divisor=32, keep_ratio=True, loader=None):
+    """The per-view transform chain of the reference test pipelines (imvoxelnet_kitti.py:94-105) for MultiViewPipeline:
+    img_info['filename'] is loaded with `loader` (default: img_info['array'], an in-memory BGR uint8 image)."""
+    def run(res):
+        arr = loader(res['img_info']['filename']) if loader is not None else res['img_info']['array']
+        img, meta = prepare_image(arr, img_scale, img_norm_cfg, size_divisor, keep_ratio)
+        out = dict(res)
+        out.update(meta)
+        out['img'] = img
+        return out
+    return run
+
+
+class KittiSetOrigin:
+    """multi_view.py:45-53 (also the nuScenes configs): origin = centre of point_cloud_range, fp32."""
+
+    def __init__(self, point_cloud_range):
+        pcr = np.array(point_cloud_range, dtype=np.float32)
+        self.origin = (pcr[:3] + pcr[3:]) / 2.
+
+    def __call__(self, results):
+        results['lidar2img']['origin'] = self.origin.copy()
+        return results
+
+
+class SunRgbdSetOrigin:
+    """multi_view.py:84-94 (Total3D configs): the point 3 m along the ray through the image centre."""
+
+    def __call__(self, results):
+        l2i = results['lidar2img']
+        projection = l2i['intrinsic'][:3, :3] @ l2i['extrinsic'][0][:3, :3]
+        h, w, _ = results['ori_shape']
+        centre = np.array([w / 2, h / 2, 1], dtype=np.float32)
+        centre *= 3
+        l2i['origin'] = np.linalg.inv(projection) @ centre
+        return results
 
 
 # ------------------------------------------------------------------ calibration -> lidar2img

@@ -139,9 +139,6 @@ int ivx_conv_winograd_set_transform_blocks(int n);
 /* Per calling thread, A/B only: 1 = one-channel-per-lane epilogue stores in the LDS-DMA conv kernel; 0 (default) = the
  * LDS-transposed epilogue (a lane stores 4 consecutive channels as one 16-byte word) wherever it applies. */
 int ivx_conv_set_epilogue_mode(int narrow);
-/* Per calling thread, A/B only: start-up stagger of the LDS-DMA conv kernel in percent of (one workgroup's MFMA time /
- * workgroups per CU): the first generation of workgroups on a CU starts spread out instead of in lock-step.  0 = off. */
-int ivx_conv_set_stagger(int percent);
 
 /* Modulated deformable convolution (DCNv2; mmcv ModulatedDeformConv2dPack, deform_groups = 1) -- nuScenes reference
  * backbone, configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14.  Builds the modulated, bilinearly sampled columns
@@ -430,6 +427,10 @@ int ivx_model_anchors(ivx_model *m, int32_t H, int32_t W, float *anchors_host, i
 int ivx_compute_projection(const float *intrinsic4x4, const float *extrinsics /* [V,4,4] */, int32_t V, double ratio,
                            float *proj /* [V,3,4] */);
 int ivx_voxel_new_origin(const float *origin, const int32_t *n_voxels, const float *voxel_size, float *new_origin);
+/* Host-only: eval BatchNorm + conv bias as the conv epilogue's affine (all host pointers, n channels; bias may be NULL):
+ * scale = gamma / sqrt(var + eps), shift = beta + (bias - mean) * scale, IEEE fp32 in this order. */
+int ivx_fold_batchnorm(const float *gamma, const float *beta, const float *mean, const float *var, const float *bias, float eps,
+                       int32_t n, float *scale, float *shift);
 
 #ifdef __cplusplus
 }

@@ -814,6 +814,125 @@ def gen_layout_head(ns):
     print('layout_head angles', store['angles'].round(3).tolist())
 
 
+def gen_input_side(ns):
+    """Input side of the path: the reference's own get_data_info bodies of the four multi-view
+    datasets (datasets/{kitti,nuscenes,scannet,sunrgbd}_monocular_dataset.py) and its MultiViewPipeline / KittiSetOrigin /
+    SunRgbdSetOrigin (datasets/pipelines/multi_view.py) run on synthetic calibration records.  The dataset base classes
+    (mmdet / the LiDAR datasets: file loading, annotation parsing) are replaced by empty stand-ins -- the methods called
+    here touch only `self.data_infos`, `self.data_root`, `self.test_mode` and numpy."""
+    import types
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda c: c
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class NuBase:       # NuScenesDataset.get_data_info: returns the prepared per-sample record
+        def get_data_info(self, index):
+            return dict(self.data_infos[index])
+
+    stub('mmdet.datasets', DATASETS=_Reg())
+    stub('mmdet.datasets.builder', PIPELINES=_Reg(), DATASETS=_Reg())
+
+    class Compose:      # mmdet Compose: apply the callables in order
+        def __init__(self, transforms):
+            self.transforms = transforms
+
+        def __call__(self, data):
+            for t in self.transforms:
+                data = t(data)
+            return data
+    stub('mmdet.datasets.pipelines', Compose=Compose, RandomFlip=type('RandomFlip', (), {}), LoadImageFromFile=type('LoadImageFromFile', (), {}))
+    stub('mmcv.utils', print_log=lambda *a, **k: None)
+    stub('mmdet3d.datasets')
+    sys.modules['mmdet3d.datasets'].__path__ = []
+    stub('mmdet3d.datasets.kitti_dataset', KittiDataset=type('KittiDataset', (), {}))
+    stub('mmdet3d.datasets.nuscenes_dataset', NuScenesDataset=NuBase)
+    stub('mmdet3d.datasets.custom_3d', Custom3DDataset=type('Custom3DDataset', (), {}))
+    stub('mmdet3d.datasets.scannet_dataset', ScanNetDataset=type('ScanNetDataset', (), {'CLASSES': ('cabinet',)}))
+    stub('mmdet3d.datasets.sunrgbd_dataset', SUNRGBDDataset=type('SUNRGBDDataset', (), {}))
+    stub('mmdet3d.datasets.dataset_wrappers', MultiViewMixin=type('MultiViewMixin', (), {}))
+    sys.modules['mmdet3d.core.bbox'].DepthInstance3DBoxes = ns.depth.DepthInstance3DBoxes
+    kd = ref_import._load('mmdet3d.datasets.kitti_monocular_dataset', 'mmdet3d/datasets/kitti_monocular_dataset.py')
+    nd = ref_import._load('mmdet3d.datasets.nuscenes_monocular_dataset', 'mmdet3d/datasets/nuscenes_monocular_dataset.py')
+    sd = ref_import._load('mmdet3d.datasets.scannet_monocular_dataset', 'mmdet3d/datasets/scannet_monocular_dataset.py')
+    ud = ref_import._load('mmdet3d.datasets.sunrgbd_monocular_dataset', 'mmdet3d/datasets/sunrgbd_monocular_dataset.py')
+    mv = ref_import._load('mmdet3d.datasets.pipelines.multi_view', 'mmdet3d/datasets/pipelines/multi_view.py')
+
+    rng = np.random.RandomState(17)
+
+    def rot(seed):
+        q, _ = np.linalg.qr(np.random.RandomState(seed).randn(3, 3))
+        return q
+
+    def self_of(cls, infos):
+        o = cls.__new__(cls)
+        o.data_infos, o.data_root, o.test_mode = infos, '/data', True
+        return o
+
+    out = {}
+    # KITTI: P2 with a baseline term, rectification, velodyne -> camera (float64 on disk, as the info pkl holds them)
+    P2 = np.eye(4); P2[:3, :3] = [[721.5377, 0, 609.5593], [0, 721.5377, 172.854], [0, 0, 1]]; P2[:3, 3] = [44.85728, 0.2163791, 0.002745884]
+    R0 = np.eye(4); R0[:3, :3] = rot(1) @ np.diag([1, 1, 1.0])
+    Tr = np.eye(4); Tr[:3, :3] = rot(2); Tr[:3, 3] = [0.01, -0.07, -0.27]
+    info = dict(image=dict(image_idx=7, image_path='training/image_2/000007.png'), calib=dict(R0_rect=R0, Tr_velo_to_cam=Tr, P2=P2))
+    r = kd.KittiMultiViewDataset.get_data_info(self_of(kd.KittiMultiViewDataset, [info]), 0)
+    out.update({'kitti::P2': P2, 'kitti::R0_rect': R0, 'kitti::Tr_velo_to_cam': Tr, 'kitti::extrinsic': r['lidar2img']['extrinsic'][0],
+                'kitti::intrinsic': r['lidar2img']['intrinsic']})
+    pcr = [0, -39.68, -3, 69.12, 39.68, 1]
+    r = mv.KittiSetOrigin(pcr)(dict(lidar2img=dict(r['lidar2img'])))
+    out.update({'kitti::point_cloud_range': np.array(pcr, np.float64), 'kitti::origin': r['lidar2img']['origin']})
+    # nuScenes: six lidar2img matrices with K folded in
+    l2i = [rng.randn(4, 4) * 50 for _ in range(6)]
+    rec = dict(sample_idx='tok', img_filename=[f'cam{i}.jpg' for i in range(6)], lidar2img=l2i)
+    r = nd.NuScenesMultiViewDataset.get_data_info(self_of(nd.NuScenesMultiViewDataset, [rec]), 0)
+    out.update({'nuscenes::lidar2img': np.stack(l2i), 'nuscenes::extrinsic': np.stack(r['lidar2img']['extrinsic']),
+                'nuscenes::intrinsic': r['lidar2img']['intrinsic']})
+    # ScanNet: axis alignment, 5 camera-to-world poses, shared intrinsics
+    aam = np.eye(4); aam[:3, :3] = rot(3); aam[:3, 3] = [1.2, -0.7, 0.1]
+    poses = []
+    for i in range(5):
+        m = np.eye(4); m[:3, :3] = rot(10 + i); m[:3, 3] = rng.randn(3)
+        poses.append(m)
+    K = np.array([[577.87, 0, 319.5, 0], [0, 577.87, 239.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    info = dict(annos=dict(axis_align_matrix=aam), img_paths=[f'f{i}.jpg' for i in range(5)], extrinsics=poses, intrinsics=K)
+    r = sd.ScanNetMultiViewDataset.get_data_info(self_of(sd.ScanNetMultiViewDataset, [info]), 0)
+    out.update({'scannet::axis_align_matrix': aam, 'scannet::poses': np.stack(poses), 'scannet::K': K,
+                'scannet::extrinsic': np.stack(r['lidar2img']['extrinsic']), 'scannet::intrinsic': r['lidar2img']['intrinsic'],
+                'scannet::origin': r['lidar2img']['origin']})
+    # SUN RGB-D: K stored column-major, Rt
+    Ksun = np.array([[529.5, 0, 365.0], [0, 529.5, 265.0], [0, 0, 1.0]]).T.reshape(-1)
+    Rt = rot(4)
+    info = dict(image=dict(image_path='sunrgbd_trainval/image/000001.jpg'), calib=dict(K=Ksun, Rt=Rt))
+    r = ud.SunRgbdMultiViewDataset.get_data_info(self_of(ud.SunRgbdMultiViewDataset, [info]), 0)
+    out.update({'sunrgbd::K': Ksun, 'sunrgbd::Rt': Rt, 'sunrgbd::extrinsic': r['lidar2img']['extrinsic'][0],
+                'sunrgbd::intrinsic': r['lidar2img']['intrinsic'], 'sunrgbd::origin': r['lidar2img']['origin']})
+    res = dict(lidar2img=dict(intrinsic=r['lidar2img']['intrinsic'].copy(), extrinsic=[r['lidar2img']['extrinsic'][0].copy()]),
+               ori_shape=(530, 730, 3))
+    res = mv.SunRgbdSetOrigin()(res)
+    out['sunrgbd::set_origin'] = np.asarray(res['lidar2img']['origin'])
+    # MultiViewPipeline: 7 views; draw 4 (no replacement), 7, and 10 (with replacement); the transform tags each view
+    def tag(res):
+        i = res['img_info']['idx']
+        return dict(res, img=np.full((2, 2), i, np.float32), img_shape=(10 + i, 20 + i, 3), ori_shape=(100 + i, 200, 3), pad_shape=(32, 32, 3))
+    for n in (4, 7, 10):
+        results = dict(img_prefix=[None] * 7, img_info=[dict(idx=i) for i in range(7)],
+                       lidar2img=dict(extrinsic=[np.full((4, 4), i, np.float32) for i in range(7)], intrinsic=np.eye(4, dtype=np.float32)))
+        np.random.seed(100 + n)
+        r = mv.MultiViewPipeline([tag], n)(results)
+        out[f'mvp{n}::ids'] = np.array([int(e[0, 0]) for e in r['lidar2img']['extrinsic']], np.int64)
+        out[f'mvp{n}::img_ids'] = np.array([int(im[0, 0]) for im in r['img']], np.int64)
+        out[f'mvp{n}::img_shape'] = np.array(r['img_shape'], np.int64)
+        out[f'mvp{n}::ori_shape'] = np.array(r['ori_shape'], np.int64)
+    np.savez_compressed(os.path.join(GOLD, 'input_side.npz'), **out)
+
+
 def main():
     ns = ref_import.load()
     gen_backproject(ns)
@@ -828,6 +947,7 @@ def main():
     gen_kitti_eval(ns)
     gen_kitti_format(ns)
     gen_layout_head(ns)
+    gen_input_side(ns)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

@@ -593,3 +593,86 @@ def test_model_cabi_host_side_without_gpu():
                                       out.ctypes.data_as(C.c_void_p)) == 0
         ref = (torch.tensor(o) - torch.tensor(nv) / 2. * torch.tensor(vs)).numpy()
         assert np.array_equal(out, ref), (out, ref)
+
+
+def test_input_side_adapters_match_reference_dataset_code():
+    """the calibration -> lidar2img adapters and the SetOrigin transforms against the reference's own
+    get_data_info bodies / pipeline classes run on synthetic calibration records (tests/golden/input_side.npz,
+    oracle/gen_golden.py::gen_input_side) -- bit for bit, dtypes included."""
+    from imvoxelnet_amd import data
+    g = load_npz('input_side.npz')
+
+    def same(a, b):
+        a, b = np.asarray(a), np.asarray(b)
+        return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+
+    k = data.kitti_lidar2img(g['kitti::P2'], g['kitti::R0_rect'], g['kitti::Tr_velo_to_cam'], tuple(g['kitti::point_cloud_range']))
+    assert same(k['extrinsic'][0], g['kitti::extrinsic']) and same(k['intrinsic'], g['kitti::intrinsic']) and same(k['origin'], g['kitti::origin'])
+    r = data.KittiSetOrigin(list(g['kitti::point_cloud_range']))(dict(lidar2img={}))
+    assert same(r['lidar2img']['origin'], g['kitti::origin'])
+    n = data.nuscenes_lidar2img(list(g['nuscenes::lidar2img']))
+    assert same(np.stack(n['extrinsic']), g['nuscenes::extrinsic']) and same(n['intrinsic'], g['nuscenes::intrinsic'])
+    s = data.scannet_lidar2img(g['scannet::axis_align_matrix'], list(g['scannet::poses']), g['scannet::K'])
+    assert same(np.stack(s['extrinsic']), g['scannet::extrinsic']) and same(s['intrinsic'], g['scannet::intrinsic']) and same(s['origin'], g['scannet::origin'])
+    u = data.sunrgbd_lidar2img(g['sunrgbd::K'], g['sunrgbd::Rt'])
+    assert same(u['extrinsic'][0], g['sunrgbd::extrinsic']) and same(u['intrinsic'], g['sunrgbd::intrinsic']) and same(u['origin'], g['sunrgbd::origin'])
+    res = dict(lidar2img=dict(intrinsic=u['intrinsic'].copy(), extrinsic=[u['extrinsic'][0].copy()]), ori_shape=(530, 730, 3))
+    assert same(data.SunRgbdSetOrigin()(res)['lidar2img']['origin'], g['sunrgbd::set_origin'])
+
+
+def test_multi_view_pipeline_draws_the_reference_views():
+    """MultiViewPipeline (pipelines/multi_view.py:7-31): with numpy's global generator seeded as in the fixture, the drawn
+    view ids (without replacement for n <= views, with replacement beyond), the order of images and extrinsics, and the
+    per-sample meta (that of the LAST drawn view) equal the reference's."""
+    from imvoxelnet_amd import data
+    g = load_npz('input_side.npz')
+
+    def tag(res):
+        i = res['img_info']['idx']
+        return dict(res, img=np.full((2, 2), i, np.float32), img_shape=(10 + i, 20 + i, 3), ori_shape=(100 + i, 200, 3), pad_shape=(32, 32, 3))
+    for n in (4, 7, 10):
+        results = dict(img_prefix=[None] * 7, img_info=[dict(idx=i) for i in range(7)],
+                       lidar2img=dict(extrinsic=[np.full((4, 4), i, np.float32) for i in range(7)], intrinsic=np.eye(4, dtype=np.float32)))
+        np.random.seed(100 + n)
+        r = data.MultiViewPipeline([tag], n)(results)
+        assert [int(e[0, 0]) for e in r['lidar2img']['extrinsic']] == g[f'mvp{n}::ids'].tolist()
+        assert [int(im[0, 0]) for im in r['img']] == g[f'mvp{n}::img_ids'].tolist()
+        assert list(r['img_shape']) == g[f'mvp{n}::img_shape'].tolist() and list(r['ori_shape']) == g[f'mvp{n}::ori_shape'].tolist()
+        assert len(r['img']) == n
+    # with the real per-view chain: two in-memory views, images normalised and padded to 32
+    views = [np.random.RandomState(i).randint(0, 255, (60, 100, 3)).astype(np.uint8) for i in range(2)]
+    results = dict(img_prefix=[None, None], img_info=[dict(filename=None, array=v) for v in views],
+                   lidar2img=dict(extrinsic=[np.eye(4, dtype=np.float32)] * 2, intrinsic=np.eye(4, dtype=np.float32)))
+    np.random.seed(0)
+    r = data.MultiViewPipeline(data.view_transform((128, 64)), 2)(results)
+    assert r['img_shape'] == (64, 107, 3) and r['pad_shape'] == (64, 128, 3) and tuple(r['img'][0].shape) == (3, 64, 128)
+
+
+def test_imresize_cv2_linear_hand_derived_vectors():
+    """cv2.resize(INTER_LINEAR) on uint8 restated in fixed point (data.imresize_cv2_linear); cv2 is not installed, so the
+    vectors are derived by hand from OpenCV's algorithm (11-bit weights round((1-f, f) * 2048); horizontal int pass;
+    vertical ((b0*(D0>>4))>>16) + ((b1*(D1>>4))>>16) + 2 >> 2).  PARITY UNPINNED against cv2 itself.
+      1-D up-scale [0, 100] -> 4:   f = (-.25 -> clamp 0), .25, .75, (1.25 -> clamp)  => 0, 25, 75, 100
+      1-D up-scale [10, 20, 40] -> 5: scale .6; f_x = -.2->0 | .4 | 1.0 | 1.6 | 2.2->clamp
+          x=1: a = (1229, 819):  10*1229 + 20*819 = 28670 ; (2048*(28670>>4))>>16 = 55 ; (55+2)>>2 = 14
+          x=2: fx = 1.0 exactly in float? (2.5*.6-.5 = 1.0) -> sx=1, f=0 -> 20
+          x=3: f=.6 (float32 0.6 -> a1 = round(1228.8) = 1229, a0 = 819): 20*819 + 40*1229 = 65540; >>4 = 4096; *2048>>16 = 128; (128+2)>>2 = 32
+      exact half: a 2x2 block [[1, 2], [3, 5]] -> (11 + 2) >> 2 = 3   (INTER_AREA shortcut)"""
+    from imvoxelnet_amd.data import imresize_cv2_linear
+
+    def row(vals, n):
+        a = np.asarray(vals, np.uint8).reshape(1, -1, 1)
+        return imresize_cv2_linear(a, (1, n))[0, :, 0].tolist()
+    assert row([0, 100], 4) == [0, 25, 75, 100]
+    assert row([10, 20, 40], 5) == [10, 14, 20, 32, 40]
+    col = imresize_cv2_linear(np.asarray([0, 100], np.uint8).reshape(2, 1, 1), (4, 1))[:, 0, 0].tolist()
+    assert col == [0, 25, 75, 100]                       # the vertical pass gives the same values for a column
+    assert imresize_cv2_linear(np.asarray([[1, 2], [3, 5]], np.uint8).reshape(2, 2, 1), (1, 1))[0, 0, 0] == 3
+    img = np.random.RandomState(0).randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    assert np.array_equal(imresize_cv2_linear(img, (37, 53)), img)
+    up = imresize_cv2_linear(img, (74, 159))
+    ref = torch.nn.functional.interpolate(torch.from_numpy(img).float().permute(2, 0, 1)[None], size=(74, 159), mode='bilinear',
+                                          align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert up.dtype == np.uint8 and np.abs(up.astype(np.float32) - ref).max() <= 1.0    # fixed point vs float bilinear: within one grey level
+    const = imresize_cv2_linear(np.full((9, 7, 3), 200, np.uint8), (20, 31))
+    assert (const == 200).all()
