@@ -120,13 +120,17 @@ def bench_other(args, ia, kc, dev, rank, world):
 
     view_sharded = args.shard == 'views'
 
+    trunk_tr = [[] for _ in range(n)]        # per step: stage events of the 2-D trunk's conv launches
+
     def step(i):
+        FusedConv.trace = trunk_tr[i]
         if view_sharded:
             from imvoxelnet_amd.dist import view_sharded_lift
             vol, valid = view_sharded_lift(model, img, metas)       # 2-D trunk + partial lift on this rank's views, all-reduce
         else:
             p0 = model.features_2d_cl(img)
             vol, valid = model.lift_cl(p0, metas)
+        FusedConv.trace = None
         ev[i][0].record()
         FusedConv.flops, FusedConv.exec_flops, FusedConv.count_flops = 0.0, 0.0, True
         y = model.neck_3d.forward_cl(vol)
@@ -165,6 +169,10 @@ def bench_other(args, ia, kc, dev, rank, world):
             return
     neck_ms = sum(ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][1]) for i in range(args.steps)) / args.steps
     ach = neck_exec[0] / (neck_ms * 1e-3) / 1e12      # executed FLOPs over the whole neck time (transform kernels included)
+    t2d = [t for i in range(args.steps) for t in trunk_tr[args.warmup + i]]
+    t2d_ms = sum(t[1].elapsed_time(t[2]) for t in t2d) / args.steps
+    t2d_flops = sum(t[3] for t in t2d if t[0] in ('direct', 'wino_gemm')) / args.steps
+    pk = PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS
     rec = {'metric': f'images/sec/node ({args.config}: {V} view(s) 3x{H}x{W}, {"x".join(map(str, cfg["n_voxels"]))} vox)',
            'value': round(B * V * args.steps / dt, 3), 'unit': 'images/s', 'scenes_per_s': round(B * args.steps / dt, 3), 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
@@ -174,7 +182,13 @@ def bench_other(args, ia, kc, dev, rank, world):
                         'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS), 4), 'traffic': None,
                         'neck_gflop': round(neck_exec[0] / 1e9, 1), 'neck_direct_gflop': round(neck_flops[0] / 1e9, 1),
-                        'direct_equivalent_tflops': round(neck_flops[0] / (neck_ms * 1e-3) / 1e12, 2), 'neck_ms_per_step': round(neck_ms, 3)}}
+                        'direct_equivalent_tflops': round(neck_flops[0] / (neck_ms * 1e-3) / 1e12, 2), 'neck_ms_per_step': round(neck_ms, 3)},
+           'roofline_trunk_2d': None if not t2d else {
+               'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel (ResNet-50 + FPN level 0 over %d views, %d launches/step, event-bracketed incl. '
+                                          'their Winograd transform / split-K passes)' % (B * V, len(t2d) // args.steps),
+               'achieved': round(t2d_flops / (t2d_ms * 1e-3) / 1e12, 2), 'peak': pk, 'unit': 'TFLOP/s',
+               'frac': round(t2d_flops / (t2d_ms * 1e-3) / 1e12 / pk, 4), 'ms_per_step': round(t2d_ms, 3),
+               'executed_gflop_per_step': round(t2d_flops / 1e9, 1)}}
     print(json.dumps(rec))
 
 
@@ -318,9 +332,11 @@ def main():
     traces = [[] for _ in range(nsteps)]      # per step: the conv stage launches (FusedConv.trace)
     lifts = [[] for _ in range(nsteps)]       # per step: the unprojection launch (ops.stage_trace)
 
+    if args.graph:
+        args.api = 'composed'      # the graph replays the layer-by-layer launches; its eager warm-up steps carry the stage events
     native_trace = False
     if args.api == 'simple_test':
-        native_trace = model._native is not None and not args.graph      # stage events are recorded inside the native handle
+        native_trace = model._native is not None and os.environ.get('IVX_BENCH_TRACE', '1') != '0'   # stage events are recorded inside the native handle
         if native_trace:
             model._native.trace(True)
 
@@ -409,10 +425,15 @@ def main():
             per_step.append([(KIND[r['stage']], r['ms'], r['start_ms'], r['flops'], r['bytes'], r['is3d']) for r in recs[k * n_per:(k + 1) * n_per]])
     else:
         for i in ev_ids:
+            if not traces[i]:
+                continue
             first = traces[i][0][1]
             rows = [(t[0], t[1].elapsed_time(t[2]), first.elapsed_time(t[1]), t[3], t[4], t[5]) for t in traces[i]]
             rows += [('lift', l[1].elapsed_time(l[2]), first.elapsed_time(l[1]), 0.0, 0.0, True) for l in lifts[i]]
             per_step.append(rows)
+    untraced = not per_step or not per_step[0]
+    if untraced:          # IVX_BENCH_TRACE=0: throughput only (no stage events in the timed region)
+        per_step = [[('wino_gemm', 1e-9, 0.0, 0.0, 0.0, True), ('lift', 1e-9, 0.0, 0.0, 0.0, True), ('direct', 1e-9, 0.0, 0.0, 0.0, False)]]
     nst = len(per_step)
     neck_ms = []
     for rows in per_step:
@@ -491,6 +512,10 @@ def main():
                                   'frac': round(t2d_flops / (t2d_ms * 1e-3) / 1e12 / peak, 4) if t2d_ms > 0 else None,
                                   'ms_per_step': round(t2d_ms, 3), 'executed_gflop_per_step': round(t2d_flops / 1e9, 1)},
         }
+        if untraced:
+            for k in ('roofline', 'roofline_winograd_transforms', 'roofline_unprojection', 'roofline_trunk_2d'):
+                rec[k] = None
+            rec['note'] = 'IVX_BENCH_TRACE=0: stage events disabled, throughput only'
         if bf16:
             rec['note'] = 'reduced-precision storage mode (bf16 activations/weights, fp32 accumulate); NOT the headline metric, which is quoted at fp32'
         if world == 1 and not args.no_cpu_baseline:

@@ -21,4 +21,10 @@ from .evaluation import indoor_eval, average_precision, eval_det_cls, eval_map_r
 from .kitti_ap import kitti_eval, kitti_eval_coco_style, bbox2result_kitti  # noqa: F401
 from .params import randomize_                                              # noqa: F401
 
-__version__ = '0.1.0'
+from .data import (load_checkpoint, prepare_image, MultiViewPipeline, KittiSetOrigin, SunRgbdSetOrigin,  # noqa: F401
+                   imresize_cv2_linear)
+from .registry import maybe_register_into_mmdet as _reg_mmdet, register_into_mmdet  # noqa: F401
+
+_reg_mmdet()          # no-op unless mmdet is importable
+
+__version__ = '0.2.0'

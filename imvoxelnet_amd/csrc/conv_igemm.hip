@@ -872,6 +872,8 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 55: *t = {128, 128, 16, 5}; return true;
     case 56: *t = {128, 64, 16, 6}; return true;
     case 57: *t = {256, 64, 16, 4}; return true;
+    case 58: *t = {256, 128, 16, 2}; return true;
+    case 59: *t = {128, 256, 16, 2}; return true;
     case 47: *t = {64, 64, 16, 6}; return true;
     case 48: *t = {64, 128, 16, 5}; return true;
     case 49: *t = {128, 64, 16, 5}; return true;
@@ -997,6 +999,8 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 55: launch_v4<float, 2, 2, 2, 2, 16, 5>(p, st); break;  //    ... to 102 registers: 5 workgroups/CU (all 160 KB of LDS)
     case 56: launch_v4<float, 2, 1, 2, 2, 16, 6>(p, st); break;  // 53 at 6 workgroups/CU
     case 57: launch_v4<float, 2, 2, 4, 1, 16, 4>(p, st); break;  // 52 at 4 workgroups/CU
+    case 58: launch_v4<float, 2, 2, 4, 2, 16, 4>(p, st); break;  // 8 waves, 256 x 128: two workgroups per CU, half the tiles per FLOP
+    case 59: launch_v4<float, 2, 2, 2, 4, 16, 4>(p, st); break;  // 8 waves, 128 x 256
     case 47: launch_v4<float, 1, 1, 2, 2, 16, 6>(p, st); break;  // 64 x 64, 64-byte rows: 16 KB LDS, 6 workgroups/CU
     case 48: launch_v4<float, 1, 2, 2, 2, 16, 5>(p, st); break;  // 64 x 128
     case 49: launch_v4<float, 2, 1, 2, 2, 16, 5>(p, st); break;  // 128 x 64 at 5 workgroups/CU
@@ -1141,10 +1145,12 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     // KW*Cin here (192 .. 768), so a workgroup's prologue and epilogue weigh more than in the direct form and one more
     // resident workgroup per CU pays: 128 x 64 at six per CU for Cout <= 64 (1.51 vs 1.85 ms at five), 128 x 128 at five
     // per CU up to K = 512 (2.50 vs 2.90 ms at four); at K = 768 four and five tie
-    // re-measured with the LDS-transposed epilogue (profiles/r02_conv_layers.log): Cout <= 64 prefers 256 x 64 tiles at four per
-    // CU (1.12 vs 1.30 ms for 128 x 64 at six), Cout = 128 at K = 192 the 128 x 64 tile at six (1.07 vs 1.11), 256 output
-    // channels four 128 x 128 workgroups per CU also at K = 384 (1.82 vs 1.85)
-    else if (nblk >= 2500) pl.cfg = p.Cout > 64 ? (p.K <= 256 ? 56 : (p.K <= 512 && p.Cout < 256 ? 55 : 54)) : 57;
+    // re-measured with the LDS-transposed epilogue, configs interleaved inside one process (tools/gemm_ab.py,
+    // profiles/r02_gemm_ab.log; run-to-run spread exceeds most tile effects otherwise): the shorter epilogue removes the
+    // advantage of a fifth / sixth resident workgroup -- 128 x 128 at four per CU wins for every Cout >= 128 layer
+    // (K = 192: 1.05 vs 1.12 ms at five; K = 384: 1.79 vs 1.86; K = 768: 3.37 vs 3.40), 128 x 64 at five for Cout <= 64
+    // (1.08 vs 1.09 at six, 1.14 for 256 x 64)
+    else if (nblk >= 2500) pl.cfg = p.Cout > 64 ? 54 : 49;
     else pl.cfg = p.K <= 640 ? 47 : 46;
   }
   TileInfo t;

@@ -48,16 +48,36 @@ def unpack_detections(packed, max_num):
     return body[..., :7], body[..., 7], body[..., 8].to(torch.int64), packed[:, -1].to(torch.int32)
 
 
-def all_gather_detections(boxes, scores, labels, count, group=None):
-    """Every rank contributes its [B_local, ...] detections (same B_local and max_num on every rank) and
-    receives the detections of the whole batch in rank order."""
+def all_gather_detections(boxes, scores, labels, count, group=None, global_batch=None):
+    """Every rank contributes its [B_local, ...] detections (same max_num everywhere) and receives the detections of the
+    whole batch in rank order.  global_batch: size of the batch shard_batch() partitioned -- when it does not divide by
+    the world size the shards differ by one sample (shard_range), so every rank pads its slice to ceil(global / world)
+    rows with count 0 before the fixed-size all-gather and the padding rows are dropped afterwards (mmdet's
+    collect_results handles ragged shards the same way: pad to the longest, trim to len(dataset)).  Without
+    global_batch all ranks must hold the same B_local (checked)."""
     packed = pack_detections(boxes, scores, labels, count)
+    M = scores.shape[1]
     if not (dist.is_available() and dist.is_initialized()):
-        return unpack_detections(packed, scores.shape[1])
+        return unpack_detections(packed, M)
     world = dist.get_world_size(group)
-    out = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
-    return unpack_detections(out, scores.shape[1])
+    if global_batch is None:
+        sizes = torch.tensor([packed.shape[0], -packed.shape[0]], device=packed.device, dtype=torch.int64)
+        dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=group)          # max(B_local), -min(B_local)
+        if int(sizes[0]) != -int(sizes[1]):
+            raise ValueError(f'ranks hold between {-int(sizes[1])} and {int(sizes[0])} samples: pass global_batch= for ragged shards')
+        rows = packed.shape[0]
+    else:
+        rows = (int(global_batch) + world - 1) // world
+        if packed.shape[0] > rows:
+            raise ValueError(f'this rank holds {packed.shape[0]} samples, more than ceil({global_batch} / {world})')
+        if packed.shape[0] < rows:                                           # padding rows: all zeros, i.e. count 0
+            packed = torch.cat([packed, packed.new_zeros((rows - packed.shape[0], packed.shape[1]))])
+    out = torch.empty((world * rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
+    if global_batch is not None:
+        keep = [r * rows + i for r in range(world) for i in range(shard_range(int(global_batch), r, world)[1] - shard_range(int(global_batch), r, world)[0])]
+        out = out[torch.tensor(keep, device=out.device, dtype=torch.int64)]
+    return unpack_detections(out, M)
 
 
 def shard_views(img, img_metas, rank=None, world=None):

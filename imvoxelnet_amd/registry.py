@@ -1,8 +1,12 @@
 """Registries with the reference's names (mmdet registries re-exported by
 mmdet3d/models/builder.py:1-52): configs written for the reference (`dict(type='ImVoxelNet', ...)`,
-`type='KittiImVoxelNeck'`, ...) build the MI355X modules unchanged.  When mmdet is importable its own
-registries could be aliased here; it is absent from this image, so a minimal registry is built in.
+`type='KittiImVoxelNeck'`, ...) build the MI355X modules unchanged.  mmdet is absent from this image, so a minimal
+registry is built in; where mmdet IS importable, register_into_mmdet() (called on package import) puts the same classes
+into mmdet's own DETECTORS / NECKS / HEADS / BACKBONES / ANCHOR_GENERATORS / BBOX_CODERS under the same names
+(force=True, replacing the reference's CUDA-path classes), so `build_detector(cfg.model)` of an unmodified reference
+tools/test.py builds the MI355X modules.  IVX_REGISTER_MMDET=0 disables that.
 """
+import os
 
 
 class Registry:
@@ -80,3 +84,40 @@ class ConfigDict(dict):
 
     def __setattr__(self, k, v):
         self[k] = v
+
+
+# our registry -> (module path inside mmdet, attribute) of the registry the reference builds from
+_MMDET_REGISTRIES = (
+    (DETECTORS, 'mmdet.models', 'DETECTORS'), (NECKS, 'mmdet.models', 'NECKS'), (HEADS, 'mmdet.models', 'HEADS'),
+    (BACKBONES, 'mmdet.models', 'BACKBONES'), (ANCHOR_GENERATORS, 'mmdet.core.anchor', 'ANCHOR_GENERATORS'),
+    (BBOX_CODERS, 'mmdet.core.bbox.builder', 'BBOX_CODERS'),
+)
+
+
+def register_into_mmdet(force=True):
+    """Alias every class registered here into the mmdet registry of the same role (mmdet3d/models/builder.py:1-52 builds
+    from those).  Returns {registry name: [class names]} of what was registered; {} when mmdet is not importable."""
+    import importlib
+    done = {}
+    try:
+        importlib.import_module('mmdet')
+    except Exception:
+        return done
+    for ours, modname, attr in _MMDET_REGISTRIES:
+        try:
+            theirs = getattr(importlib.import_module(modname), attr)
+        except Exception:
+            continue
+        for name, cls in ours._modules.items():
+            try:
+                theirs.register_module(name=name, force=force, module=cls)
+            except TypeError:                       # older mmcv: register_module(cls) / _register_module(cls, name, force)
+                theirs._register_module(cls, module_name=name, force=force)
+            done.setdefault(attr, []).append(name)
+    return done
+
+
+def maybe_register_into_mmdet():
+    if os.environ.get('IVX_REGISTER_MMDET', '1') != '0':
+        return register_into_mmdet()
+    return {}

@@ -676,3 +676,86 @@ def test_imresize_cv2_linear_hand_derived_vectors():
     assert up.dtype == np.uint8 and np.abs(up.astype(np.float32) - ref).max() <= 1.0    # fixed point vs float bilinear: within one grey level
     const = imresize_cv2_linear(np.full((9, 7, 3), 200, np.uint8), (20, 31))
     assert (const == 200).all()
+
+
+def test_register_into_mmdet_when_importable(monkeypatch):
+    """where mmdet is importable the modules are aliased into ITS registries under the reference's
+    names, so an unmodified `build_detector(cfg.model)` (mmdet3d/models/builder.py:36-38) builds the MI355X classes.  mmdet
+    is not installed here: a stand-in package with mmcv-style registries is planted for the duration of the test."""
+    import sys
+    import types
+    import imvoxelnet_amd as ia
+    from imvoxelnet_amd import registry
+
+    class MMRegistry:
+        def __init__(self):
+            self.module_dict = {'ImVoxelNet': 'the reference CUDA-path class'}
+
+        def register_module(self, name=None, force=False, module=None):
+            if name in self.module_dict and not force:
+                raise KeyError(name)
+            self.module_dict[name] = module
+            return module
+    regs = {n: MMRegistry() for n in ('DETECTORS', 'NECKS', 'HEADS', 'BACKBONES', 'ANCHOR_GENERATORS', 'BBOX_CODERS')}
+    mods = {'mmdet': types.ModuleType('mmdet'), 'mmdet.models': types.ModuleType('mmdet.models'), 'mmdet.core': types.ModuleType('mmdet.core'),
+            'mmdet.core.anchor': types.ModuleType('mmdet.core.anchor'), 'mmdet.core.bbox': types.ModuleType('mmdet.core.bbox'),
+            'mmdet.core.bbox.builder': types.ModuleType('mmdet.core.bbox.builder')}
+    for n in ('DETECTORS', 'NECKS', 'HEADS', 'BACKBONES'):
+        setattr(mods['mmdet.models'], n, regs[n])
+    mods['mmdet.core.anchor'].ANCHOR_GENERATORS = regs['ANCHOR_GENERATORS']
+    mods['mmdet.core.bbox.builder'].BBOX_CODERS = regs['BBOX_CODERS']
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    assert registry.register_into_mmdet() != {}
+    assert regs['DETECTORS'].module_dict['ImVoxelNet'] is ia.ImVoxelNet
+    for n in ('KittiImVoxelNeck', 'NuScenesImVoxelNeck', 'FastIndoorImVoxelNeck', 'ImVoxelNeck', 'FPN'):
+        assert regs['NECKS'].module_dict[n] is getattr(ia, n)
+    for n in ('Anchor3DHead', 'ScanNetImVoxelHeadV2', 'SunRgbdImVoxelHeadV2', 'ScanNetImVoxelHead', 'SunRgbdImVoxelHead', 'LayoutHead'):
+        assert regs['HEADS'].module_dict[n] is getattr(ia, n)
+    assert regs['BACKBONES'].module_dict['ResNet'] is ia.ResNet
+    assert regs['ANCHOR_GENERATORS'].module_dict['Anchor3DRangeGenerator'] is ia.Anchor3DRangeGenerator
+    assert regs['BBOX_CODERS'].module_dict['DeltaXYZWLHRBBoxCoder'] is ia.DeltaXYZWLHRBBoxCoder
+    monkeypatch.setenv('IVX_REGISTER_MMDET', '0')
+    assert registry.maybe_register_into_mmdet() == {}
+
+
+def _ragged_gather_worker(rank, world, port, out_q):
+    import torch.distributed as dist
+    from imvoxelnet_amd import dist as ivd
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    G, M = 5, 3                                        # 5 samples over 2 ranks: shards of 3 and 2
+    g = torch.Generator().manual_seed(7)
+    boxes, scores = torch.randn(G, M, 7, generator=g), torch.rand(G, M, generator=g)
+    labels, count = torch.randint(0, 3, (G, M), generator=g), torch.tensor([3, 0, 2, 1, 3], dtype=torch.int32)
+    a, b = ivd.shard_range(G, rank, world)
+    gb, gs, gl, gc = ivd.all_gather_detections(boxes[a:b], scores[a:b], labels[a:b], count[a:b], global_batch=G)
+    ok = bool(torch.equal(gb, boxes) and torch.equal(gs, scores) and torch.equal(gl, labels) and torch.equal(gc, count))
+    err = ''
+    try:       # without global_batch the mismatch of B_local is detected on every rank instead of hanging / corrupting
+        ivd.all_gather_detections(boxes[a:b], scores[a:b], labels[a:b], count[a:b])
+    except ValueError as e:
+        err = str(e)
+    out_q.put((rank, ok, err))
+    dist.destroy_process_group()
+
+
+def test_all_gather_detections_ragged_shards_gloo_world2():
+    """shard_batch() gives shards that differ by one sample when the batch does not divide by the world size; the gather
+    pads every rank to ceil(B / world) rows (count 0) and trims afterwards, as mmdet's collect_results does for the
+    reference (tools/test.py:131-136).  Equal-size gathers without global_batch verify the sizes and raise otherwise."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, err in res:
+        assert ok, f'rank {rank}: reassembled batch differs'
+        assert 'global_batch' in err
