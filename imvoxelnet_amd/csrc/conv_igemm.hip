@@ -149,7 +149,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
   }
 }
 
-// Wide-store epilogue of the LDS-DMA kernel (fp32 output, plain layout, same-shape or no residual, Cout % 4 == 0).
+// Wide-store epilogue of the LDS-DMA kernel (fp32 output, plain layout, Cout % 4 == 0; residual: none, same shape, or the
+// nearest-upsampled coarser FPN level).
 // The MFMA accumulator layout gives a lane ONE channel of 16 rows, so the direct epilogue above issues 16 dword stores per
 // 32x32 tile and lane (64 per wave for a 64x64 quadrant): the store issue, not the bytes, sets its duration, and while a
 // wave sits in it its SIMD runs with one MFMA wave fewer.  With short K (the Winograd-domain GEMMs: K = 192 .. 768, the
@@ -183,7 +184,8 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams &p, f32x16 (
           const size_t o = (size_t)m * p.Cout + nb;
           v = v * sc + sf;
           f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-          if (p.res_mode) rr = *reinterpret_cast<const f32x4 *>(p.res + o);
+          if (p.res_mode == 2) rr = *reinterpret_cast<const f32x4 *>(p.res + res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + nb);
+          else if (p.res_mode) rr = *reinterpret_cast<const f32x4 *>(p.res + o);
           if (p.res_mode && !p.res_after_act) v += rr;
           if (p.relu) {
             v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
       }
     return;
   }
-  if (p.out_mode == 0 && !p.out_bf16 && p.res_mode != 2 && (p.Cout & 3) == 0 && !p.narrow_epilogue) {
+  if (p.out_mode == 0 && !p.out_bf16 && (p.Cout & 3) == 0 && !p.narrow_epilogue) {
     static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
     conv_epilogue_wide<TM, TN>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, gz * (size_t)p.g_out);
     return;
@@ -748,6 +750,13 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
     }
     conv_store_one(p, m, n, acc);
   }
+}
+
+static thread_local int g_plan_mode = 0;
+// Tuning knob (A/B; per calling thread): 1 = the round-1 tile rule of plan_conv, 0 (default) = the scored choice.
+extern "C" int ivx_conv_set_plan_mode(int mode) {
+  g_plan_mode = mode;
+  return IVX_OK;
 }
 
 static thread_local int g_narrow_epilogue = 0;
@@ -917,6 +926,28 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
   ConvPlan pl = {g_tile_override, 1, 1, 0, 0, 0, 0};
   const bool dma_ok = dma_applicable(p);
   bool small = false;
+  if (pl.cfg == 0 && dma_ok && !p.in_bf16 && p.Cout > 32 && g_plan_mode == 0) {
+    // fp32 LDS-DMA kernel: score the three tile shapes by (tile efficiency) x (useful fraction of the padded tile grid) x (fill
+    // of the last round of workgroup slots) and take the best.  The round-1 rule (128 x 128 from 2500 tiles on, else 64 x 64)
+    // left the mid-sized layers of the 2-D trunk -- 900 .. 2500 big tiles, i.e. 0.9 .. 2.4 rounds of 1024 slots -- on 64 x 64
+    // tiles at ~0.8 of the big tile's rate, or on a half-empty second round; 128 x 64 at five per CU sits in between.
+    // Efficiencies are the measured per-tile rates on long layers relative to 128 x 128 (141 / 131 / 113 TFLOP/s).
+    const int c64 = p.K <= 640 ? 47 : 46;
+    const int cand[3] = {54, 49, c64};
+    const double eff[3] = {1.00, 0.93, 0.80};
+    double best = -1.0;
+    for (int i = 0; i < 3; ++i) {
+      TileInfo ti;
+      tile_info(cand[i], &ti);
+      const double tiles = (double)((p.M + ti.bm - 1) / ti.bm) * ((p.Cout + ti.bn - 1) / ti.bn);
+      const double util = (double)p.M * p.Cout / (tiles * ti.bm * ti.bn);
+      const double rounds = tiles / (256.0 * ti.wg_per_cu);
+      const double fill = rounds >= 1.0 ? rounds / (double)(long long)(rounds + 0.999999) : rounds;
+      const double score = eff[i] * util * fill;
+      if (score > best) { best = score; pl.cfg = cand[i]; }
+    }
+    small = pl.cfg == c64;
+  }
   if (pl.cfg == 0) {
     const long long nblk = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (p.Cout <= 32) {

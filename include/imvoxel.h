@@ -139,6 +139,8 @@ int ivx_conv_winograd_set_transform_blocks(int n);
 /* Per calling thread, A/B only: 1 = one-channel-per-lane epilogue stores in the LDS-DMA conv kernel; 0 (default) = the
  * LDS-transposed epilogue (a lane stores 4 consecutive channels as one 16-byte word) wherever it applies. */
 int ivx_conv_set_epilogue_mode(int narrow);
+/* Per calling thread, A/B only: 1 = the round-1 tile rule of the direct convolution planner, 0 (default) = scored choice. */
+int ivx_conv_set_plan_mode(int mode);
 
 /* Modulated deformable convolution (DCNv2; mmcv ModulatedDeformConv2dPack, deform_groups = 1) -- nuScenes reference
  * backbone, configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14.  Builds the modulated, bilinearly sampled columns

@@ -81,9 +81,12 @@ def main():
     ap.add_argument('--winograd', action='store_true', help='also time the F(m x m, 3x3) form of each stride-1 layer')
     ap.add_argument('--wcfgs', default='0', help='tile overrides of the grouped GEMM to sweep')
     ap.add_argument('--tile', type=int, default=4, help='m of the Winograd form (2, 4 or 6)')
+    ap.add_argument('--plan1', action='store_true', help='A/B: the round-1 tile rule (ivx_conv_set_plan_mode(1))')
+    ap.add_argument('--hw', default='384,1280', help='image size of --set resnet')
     ap.add_argument('--narrow', action='store_true', help='A/B: one-channel-per-lane epilogue stores (ivx_conv_set_epilogue_mode(1))')
     a = ap.parse_args()
     _lib.lib().ivx_conv_set_epilogue_mode(1 if a.narrow else 0)
+    _lib.lib().ivx_conv_set_plan_mode(1 if a.plan1 else 0)
     if a.set == 'resnet':
         return run2d(a)
     L = _lib.lib()

@@ -18,14 +18,14 @@ IVX_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-no
 for c in nuscenes sunrgbd_fast scannet_fast scannet_v1 lift_nuscenes lift_scannet; do python bench.py --config $c --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT/other.jsonl; done
 for c in scannet_v1 scannet_fast sunrgbd_fast; do python bench.py --config $c --storage bf16 --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl; done
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $ROOT/$OUT/trace_bench.log 2>&1)
-tail -1 $OUT/trace_bench.log > $OUT/bench_profiled.json
+grep '^{"metric' $OUT/trace_bench.log | tail -1 > $OUT/bench_profiled.json
 DB=$(find $OUT/trace -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB 7 > $OUT/kernel_trace.md
 find $OUT/trace -name "*stats*.csv" | head -3 | while read f; do cp $f $OUT/; done
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace_scannet -o t -- python $ROOT/bench.py --config scannet_fast --steps 3 --warmup 1 > $ROOT/$OUT/trace_scannet.log 2>&1)
 DB=$(find $OUT/trace_scannet -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/kernel_trace_scannet_fast.md
-tail -1 $OUT/trace_scannet.log > $OUT/bench_profiled_scannet_fast.json
+grep '^{"metric' $OUT/trace_scannet.log | tail -1 > $OUT/bench_profiled_scannet_fast.json
 bash tools/pmc_bench.sh $OUT/pmc > $OUT/pmc.log 2>&1
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.5 --json $OUT/pmc.json > $OUT/pmc.md
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.1 --match wino_ --json $OUT/pmc_wino.json > $OUT/pmc_wino.md

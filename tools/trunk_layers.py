@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Per-launch table of the 2-D trunk (ResNet-50 + FPN level 0) as the model runs it (FusedConv.trace events):
+  python tools/trunk_layers.py [--config scannet_fast|kitti|scannet_v1] [--top 25]"""
+import argparse
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import imvoxelnet_amd as ia  # noqa: E402
+import kitti_cfg as kc  # noqa: E402
+from imvoxelnet_amd.conv import FusedConv  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default='scannet_fast')
+    ap.add_argument('--top', type=int, default=30)
+    a = ap.parse_args()
+    cfg, shape = {'kitti': (kc.kitti_model_cfg(), (4, 1, 3, 384, 1280)), 'scannet_fast': (kc.scannet_fast_model_cfg(), (1, 50, 3, 480, 640)),
+                  'scannet_v1': (kc.scannet_v1_model_cfg(), (1, 50, 3, 480, 640))}[a.config]
+    model = ia.build_detector(cfg, test_cfg=dict(nms_pre=100, max_num=50, use_rotate_nms=True, nms_thr=.1, score_thr=.1, iou_thr=.25))
+    ia.randomize_(model, 0)
+    model.backbone.prepare(torch.device('cuda'))
+    model.neck.prepare(torch.device('cuda'))
+    img = torch.randn(*shape, generator=torch.Generator().manual_seed(1)).cuda()
+    for _ in range(2):
+        model.features_2d_cl(img)
+    agg = collections.OrderedDict()
+    reps = 5
+    for _ in range(reps):
+        FusedConv.trace = []
+        model.features_2d_cl(img)
+        torch.cuda.synchronize()
+        tr, FusedConv.trace = FusedConv.trace, None
+        for t in tr:
+            key = (t[6], t[0])
+            d = agg.setdefault(key, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += t[1].elapsed_time(t[2])
+            d[2] += t[3]
+    rows = [(k, v[0] / reps, v[1] / reps, v[2] / reps) for k, v in agg.items()]
+    total = sum(r[2] for r in rows)
+    print(f'# {a.config}: trunk launches per step, {total:.3f} ms of conv-stage time per step, executed {sum(r[3] for r in rows) / 1e9:.1f} GFLOP')
+    print('| layer shape | stage | launches | ms/step | % | TFLOP/s executed |')
+    print('|---|---|---|---|---|---|')
+    for (desc, kind), n, ms, fl in sorted(rows, key=lambda r: -r[2])[:a.top]:
+        print(f'| {desc} | {kind} | {n:.0f} | {ms:.3f} | {100 * ms / total:.1f} | {fl / ms / 1e9 if fl else 0:.1f} |')
+
+
+if __name__ == '__main__':
+    main()
