@@ -678,239 +678,6 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane, gz * (size_t)p.g_out);
 }
 
-// ------------------------------------------------------------------------------------------------
-// v5, the persistent form of v4 for short-K problems (the Winograd-domain GEMMs: K = 192 .. 768; the 1x1 layers of the 2-D
-// trunk): the launch has one workgroup per resident slot (256 x WPE), and a workgroup walks over its tiles
-// (item i = blockIdx.x + k * gridDim.x of the v4 launch order, so a tile stays on the XCD v4 would give it) as ONE
-// stream of K-slabs: the LDS-DMA prefetch runs across the tile boundary, so the first slab of the next tile lands
-// while the last slabs of the current tile are multiplied and its outputs leave -- no pipeline drain / refill per tile, no
-// per-tile workgroup launch.  The wide-store epilogue stages through the slab buffer that has just become free; the
-// load that would have gone there is issued after it (one barrier), i.e. the look-ahead is one slab across a tile boundary
-// and two inside a tile.  Uniform-tap slabs only (UNI of v4), no split-K.
-template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE>
-__global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v5_kernel(const ConvParams p, const unsigned in_bytes, const unsigned w_bytes,
-                                                                         const unsigned grid_x, const unsigned n_items) {
-  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-  constexpr int EL = sizeof(T), EPC = 16 / EL, CK = 128 / EL, NCH = BK / EPC, NT = 64 * WR * WC, RP = NT / NCH;
-  constexpr int AR = BM / RP, BR = BN / RP;
-  constexpr int SW_SH = NCH == 8 ? 1 : 2, SW_MSK = NCH - 1;
-  constexpr int STG = (BM + BN) * BK;                       // elements of one stage: [A rows | B rows]
-  static_assert(NCH == 8 || NCH == 4, "BK: LDS rows are 128 or 64 bytes");
-  static_assert((size_t)STG * EL >= (size_t)NT / 64 * 4096, "a stage must hold 4 KB of epilogue staging per wave");
-  __shared__ __attribute__((aligned(16))) T smem[2 * STG];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid / WC, wc = wid % WC;
-  const int wid_u = __builtin_amdgcn_readfirstlane(wid);
-  const int lr = tid / NCH;
-  const int cc = (tid & (NCH - 1)) ^ ((lr >> SW_SH) & SW_MSK);
-  const unsigned OOB = 0x80000000u;
-  typedef __attribute__((address_space(3))) void *lds_ptr_t;
-  const int Nt = (p.Cout + BN - 1) / BN;
-  const int S = (p.K + BK - 1) / BK;
-  const int ntap = p.KD * p.KH * p.KW;
-  constexpr int HPS = CK / BK;
-
-  // ---- item -> tile
-  auto item_tile = [&](unsigned item, int &m0, int &n0, unsigned &gz) -> bool {
-    const unsigned bx = item % grid_x;
-    gz = item / grid_x;
-    const int xcd = bx & 7, idx = bx >> 3;
-    const int lt = idx / Nt;
-    const int nt = idx - lt * Nt;
-    const int mt = xcd * p.q_total + p.q_begin + lt;
-    m0 = mt * BM;
-    n0 = nt * BN;
-    return m0 < p.M;
-  };
-  auto next_valid = [&](unsigned item) -> unsigned {        // first item >= `item` of this workgroup that has rows
-    int m0, n0; unsigned gz;
-    while (item < n_items && !item_tile(item, m0, n0, gz)) item += gridDim.x;
-    return item;
-  };
-
-  // ---- load cursor: (item, slab) two slabs ahead of the multiply
-  unsigned l_item = next_valid(blockIdx.x);
-  if (l_item >= n_items) return;
-  int l_s = 0;
-  int a_base[AR];
-  unsigned a_msk[AR], b_base[BR];
-  __amdgpu_buffer_rsrc_t rs_in, rs_w;
-  int kc, ka, ke, kf, khalf;
-  unsigned kb;
-  auto load_begin_item = [&]() {
-    int m0, n0; unsigned gz;
-    item_tile(l_item, m0, n0, gz);
-    rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.in + (size_t)gz * (size_t)p.g_in * EL), 0, in_bytes, 0x00020000);
-    rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.wgt + (size_t)gz * (size_t)p.g_w * EL), 0, w_bytes, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < AR; ++j) {
-      const int m = m0 + lr + RP * j;
-      a_base[j] = 0;
-      a_msk[j] = 0;
-      if (m < p.M) {
-        const int ow = m % p.Wo;
-        int t = m / p.Wo;
-        const int oh = t % p.Ho;
-        t /= p.Ho;
-        const int od = t % p.Do;
-        const int b = t / p.Do;
-        const int id0 = od * p.sd - p.pd, ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
-        a_base[j] = (((b * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin + cc * EPC;
-        unsigned md = 0, mh = 0, mw = 0;
-        for (int a = 0; a < p.KD; ++a) md |= ((unsigned)(id0 + a) < (unsigned)p.D) ? (1u << a) : 0u;
-        for (int e = 0; e < p.KH; ++e) mh |= ((unsigned)(ih0 + e) < (unsigned)p.H) ? (1u << e) : 0u;
-        for (int f = 0; f < p.KW; ++f) mw |= ((unsigned)(iw0 + f) < (unsigned)p.W) ? (1u << f) : 0u;
-        a_msk[j] = md | (mh << 8) | (mw << 16);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      const int n = n0 + lr + RP * j;
-      b_base[j] = n < p.Cout ? (unsigned)(n * p.K + cc * EPC) * EL : OOB;
-    }
-    kc = 0; ka = ke = kf = 0; khalf = 0; kb = 0;
-  };
-  auto load_slab = [&](int buf) {                          // slab (l_item, l_s) -> stage `buf`, then advance the cursor
-    T *Ab = smem + buf * STG + wid_u * (64 / NCH) * BK;
-    T *Bb = smem + buf * STG + BM * BK + wid_u * (64 / NCH) * BK;
-    const int delta = ((ka * p.H + ke) * p.W + kf) * p.Cin + kc;
-    const unsigned tap = (1u << ka) | (1u << (8 + ke)) | (1u << (16 + kf));
-#pragma unroll
-    for (int j = 0; j < AR; ++j) {
-      const unsigned vo = ((a_msk[j] & tap) == tap) ? (unsigned)(a_base[j] + delta) * EL : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + RP * j * BK), 16, vo, 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      const unsigned vo = b_base[j] + kb;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bb + RP * j * BK), 16, vo, 0, 0, 0);
-    }
-    // advance: next slab of this item, or the first slab of this workgroup's next item
-    if (++l_s == S) {
-      l_s = 0;
-      l_item = next_valid(l_item + gridDim.x);
-      if (l_item < n_items) load_begin_item();
-      return;
-    }
-    kb += BK * EL;
-    if (p.kmode == 1) {
-      if (BK < CK) {
-        khalf ^= 1;
-        kc += khalf ? CK / 2 : -(CK / 2);
-        if (khalf) return;
-      }
-      if (++kf == p.KW) {
-        kf = 0;
-        if (++ke == p.KH) {
-          ke = 0;
-          if (++ka == p.KD) {
-            ka = 0;
-            kc += CK;
-          }
-        }
-      }
-      return;
-    }
-    kc += BK;
-    while (kc >= p.Cin) {
-      kc -= p.Cin;
-      if (++kf == p.KW) {
-        kf = 0;
-        if (++ke == p.KH) {
-          ke = 0;
-          ++ka;
-        }
-      }
-    }
-  };
-  (void)ntap; (void)HPS;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- prologue: two slabs in flight
-  unsigned c_item = l_item;                                 // multiply cursor
-  load_begin_item();
-  load_slab(0);
-  if (l_item < n_items) load_slab(1);
-  lds_dma_wait_all();
-  __syncthreads();
-
-  const int frow = (lane & 31) * BK, fsw = ((lane & 31) >> SW_SH) & SW_MSK, fh = lane >> 5;
-  int cur = 0, c_s = 0;
-  while (true) {
-    const T *Ac = smem + cur * STG + wr * TM * 32 * BK + frow;
-    const T *Bc = smem + cur * STG + BM * BK + wc * TN * 32 * BK + frow;
-    const bool tile_end = c_s == S - 1;
-    f32x4 fa[2][TM], fb[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + ((fh ^ fsw) * EPC));
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + ((fh ^ fsw) * EPC));
-#pragma unroll
-    for (int kk = 0; kk < NCH / 2; ++kk) {
-      const int cb = kk & 1, nb = cb ^ 1;
-      if (kk < NCH / 2 - 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
-      } else {
-        // every wave holds its last fragments of stage `cur`; the other stage must have landed
-        lds_dma_wait_all();
-        __syncthreads();
-        if (!tile_end && l_item < n_items) load_slab(cur);   // inside a tile: stage `cur` is free, prefetch two slabs ahead
-      }
-      if constexpr (EL == 4) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][i][q], fb[cb][j][q], acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cb][i]), __builtin_bit_cast(bf16x8, fb[cb][j]),
-                                                               acc[i][j], 0, 0, 0);
-      }
-    }
-    cur ^= 1;
-    if (!tile_end) {
-      ++c_s;
-      continue;
-    }
-    // ---- tile finished: outputs leave through the stage that has just become free (cur ^ 1), then the delayed prefetch
-    {
-      int m0, n0; unsigned gz;
-      item_tile(c_item, m0, n0, gz);
-      const size_t obase = (size_t)gz * (size_t)p.g_out;
-      // (the host launches v5 only where the wide-store epilogue applies: fp32 plain output, Cout % 4 == 0)
-      conv_epilogue_wide<TM, TN>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem + (cur ^ 1) * STG) + wid_u * 1024, obase);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    }
-    c_item = next_valid(c_item + gridDim.x);
-    if (c_item >= n_items) break;
-    c_s = 0;
-    __syncthreads();                                         // every wave is done with its staging slice
-    if (l_item < n_items) load_slab(cur ^ 1);
-  }
-}
-
 // Epilogue + store of one output element (row m, column n) from its finished accumulator: shared by the validation
 // kernel and the split-K reduction.
 __device__ __forceinline__ void conv_store_one(const ConvParams &p, int m, int n, float acc) {
@@ -1083,26 +850,6 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
 }
 
 
-// Persistent launch of the LDS-DMA kernel (v5): same tiles / order as launch_v4, one workgroup per resident slot.
-template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE>
-static void launch_v5(ConvParams &p, hipStream_t st) {
-  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-  const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * sizeof(T);
-  const int64_t w_bytes = (int64_t)p.Cout * p.K * sizeof(T);
-  const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
-  p.bm = BM;
-  if (p.q_total == 0) {
-    p.q_total = (int)((Mt + 7) / 8);
-    p.q_begin = 0;
-    p.q_count = p.q_total;
-  }
-  const long long gx = 8LL * p.q_count * Nt;
-  const long long items = gx * (p.groups > 1 ? p.groups : 1);
-  long long wgs = 256LL * WPE;
-  if (wgs > items) wgs = (items + 7) / 8 * 8;
-  hipLaunchKernelGGL((conv_igemm_v5_kernel<T, TM, TN, WR, WC, BK, WPE>), dim3((unsigned)wgs), dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes,
-                     (unsigned)w_bytes, (unsigned)gx, (unsigned)items);
-}
 
 static thread_local int g_tile_override = 0;
 // Tuning knob (A/B experiments, tools/conv_bench.py; per calling thread): 0 = automatic choice, else force a tile
@@ -1137,9 +884,6 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 56: *t = {128, 64, 16, 6}; return true;
     case 57: *t = {256, 64, 16, 4}; return true;
     case 58: *t = {256, 128, 16, 2}; return true;
-    case 84: *t = {128, 128, 16, 4}; return true;   // persistent (v5) twins
-    case 85: *t = {128, 128, 16, 3}; return true;
-    case 86: *t = {64, 64, 32, 4}; return true;
     case 59: *t = {128, 256, 16, 2}; return true;
     case 47: *t = {64, 64, 16, 6}; return true;
     case 48: *t = {64, 128, 16, 5}; return true;
@@ -1288,9 +1032,6 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 55: launch_v4<float, 2, 2, 2, 2, 16, 5>(p, st); break;  //    ... to 102 registers: 5 workgroups/CU (all 160 KB of LDS)
     case 56: launch_v4<float, 2, 1, 2, 2, 16, 6>(p, st); break;  // 53 at 6 workgroups/CU
     case 57: launch_v4<float, 2, 2, 4, 1, 16, 4>(p, st); break;  // 52 at 4 workgroups/CU
-    case 84: launch_v5<float, 2, 2, 2, 2, 16, 4>(p, st); break;  // persistent 128 x 128 (54)
-    case 85: launch_v5<float, 2, 2, 2, 2, 16, 3>(p, st); break;  //   ... at three workgroups per CU (168 registers)
-    case 86: launch_v5<float, 1, 1, 2, 2, 32, 4>(p, st); break;  // persistent 64 x 64, 128-byte rows (46)
     case 58: launch_v4<float, 2, 2, 4, 2, 16, 4>(p, st); break;  // 8 waves, 256 x 128: two workgroups per CU, half the tiles per FLOP
     case 59: launch_v4<float, 2, 2, 2, 4, 16, 4>(p, st); break;  // 8 waves, 128 x 256
     case 47: launch_v4<float, 1, 1, 2, 2, 16, 6>(p, st); break;  // 64 x 64, 64-byte rows: 16 KB LDS, 6 workgroups/CU
@@ -1446,7 +1187,7 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     else pl.cfg = p.K <= 640 ? 47 : 46;
   }
   TileInfo t;
-  if (!tile_info(pl.cfg, &t) || (pl.cfg >= 61 && pl.cfg < 84) || pl.cfg > 86) {
+  if (!tile_info(pl.cfg, &t) || pl.cfg >= 61) {
     ivx_set_error("ivx_conv_grouped_launch: tile %d is not an fp32 LDS-DMA tile", pl.cfg);
     return IVX_ERR_INVALID_ARG;
   }
