@@ -678,97 +678,6 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane, gz * (size_t)p.g_out);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Streaming 1x1 convolution for SHORT K (Cin = 64 or 128: ResNet stage-1 / stage-2 1x1 layers, 64 -> 256, 128 -> 512, ...).
-// Such a layer is HBM-bound (2*K*Cout flops per (K + Cout [+ Cout]) * 4 bytes: 14 .. 26 flop per byte), and the tiled kernel
-// above spends its time in per-tile prologues and epilogues (4 .. 8 K-slabs per tile): 2.3 TB/s on the 50-view ScanNet trunk.
-// Here a workgroup keeps its 128 filters in LDS for its whole life (loaded once, XOR-swizzled 16-byte chunks) and every
-// wave streams 32-row tiles on its own: the A rows go global -> registers directly in the MFMA fragment layout (lane
-// (r, h) loads the 16-byte chunks 2*kk + h of row r: same k permutation as the tiled kernel, so the sums are bit-identical),
-// double-buffered one tile ahead; no barrier after the filter load; the 32 x 128 outputs leave through the wave's
-// staging slice as 16-byte stores (conv_epilogue_wide).  K = 128 keeps one A buffer (register budget) at two workgroups
-// per CU, K = 64 two at three per CU.
-template <int K, int DB>
-__global__ __launch_bounds__(256, (DB ? 3 : 2)) void conv1x1_stream_kernel(const ConvParams p) {
-  constexpr int BN = 128, NC = K / 4, NKK = K / 8;       // 16-byte chunks per row, k-groups of 8
-  __shared__ __attribute__((aligned(16))) float Wl[BN * K];
-  __shared__ __attribute__((aligned(16))) float stage_all[4 * 1024];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int n0 = blockIdx.y * BN;
-  for (int idx = tid; idx < BN * NC; idx += 256) {        // filters of this N tile: slot c of row n holds chunk c ^ (n & 15)
-    const int n = idx / NC, c = idx - n * NC;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (n0 + n < p.Cout) v = *reinterpret_cast<const f32x4 *>(p.wgt + (size_t)(n0 + n) * K + c * 4);
-    *reinterpret_cast<f32x4 *>(Wl + n * K + ((c ^ (n & 15)) * 4)) = v;
-  }
-  __syncthreads();
-  float *stage = stage_all + __builtin_amdgcn_readfirstlane(wid) * 1024;
-  const int r = lane & 31, h = lane >> 5;
-  const int tiles = (p.M + 31) / 32;
-  const int GW = gridDim.x * 4;
-  int t = blockIdx.x * 4 + wid;
-  f32x4 a[DB ? 2 : 1][NKK];
-  auto load_a = [&](int tile, f32x4 (&dst)[NKK]) {
-    const int m = tile * 32 + r;
-    const float *row = p.in + (size_t)m * K + h * 4;
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < p.M) v = *reinterpret_cast<const f32x4 *>(row + kk * 8);
-      dst[kk] = v;
-    }
-  };
-  if (t < tiles) load_a(t, a[0]);
-  int cur = 0;
-  for (; t < tiles; t += GW) {
-    if constexpr (DB) {
-      if (t + GW < tiles) load_a(t + GW, a[cur ^ 1]);      // next tile of this wave, in flight during the MFMAs below
-    }
-    f32x16 acc[1][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[0][j][q] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-      f32x4 b[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = j * 32 + r;
-        b[j] = *reinterpret_cast<const f32x4 *>(Wl + n * K + (((2 * kk + h) ^ (n & 15)) * 4));
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[DB ? cur : 0][kk][q], b[j][q], acc[0][j], 0, 0, 0);
-    }
-    if constexpr (!DB) {
-      if (t + GW < tiles) load_a(t + GW, a[0]);            // single buffer: issue the next rows before the stores
-    }
-    conv_epilogue_wide<1, 4>(p, acc, t * 32, n0, 0, 0, lane, stage, 0);
-    if constexpr (DB) cur ^= 1;
-  }
-}
-
-static bool stream1x1_applicable(const ConvParams &p) {
-  return !p.in_bf16 && !p.out_bf16 && p.KD == 1 && p.KH == 1 && p.KW == 1 && p.sd == 1 && p.sh == 1 && p.sw == 1 && p.pd == 0 && p.ph == 0 &&
-         p.pw == 0 && p.out_mode == 0 && (p.Cin == 64 || p.Cin == 128) && p.K == p.Cin && (p.Cout & 3) == 0 && p.Cout >= 64 && p.M >= 16384 &&
-         p.groups <= 1 && !p.narrow_epilogue && (size_t)p.M * (size_t)(p.Cin > p.Cout ? p.Cin : p.Cout) < (1ull << 40);
-}
-
-static void launch_stream1x1(const ConvParams &p, hipStream_t st) {
-  const int Nt = (p.Cout + 127) / 128;
-  const int tiles = (p.M + 31) / 32;
-  const int per_cu = p.Cin == 64 ? 3 : 2;
-  int gx = 256 * per_cu / Nt;
-  if (gx < 1) gx = 1;
-  if (gx > (tiles + 3) / 4) gx = (tiles + 3) / 4;
-  if (p.Cin == 64)
-    hipLaunchKernelGGL((conv1x1_stream_kernel<64, 1>), dim3(gx, Nt), dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL((conv1x1_stream_kernel<128, 0>), dim3(gx, Nt), dim3(256), 0, st, p);
-}
-
 // Epilogue + store of one output element (row m, column n) from its finished accumulator: shared by the validation
 // kernel and the split-K reduction.
 __device__ __forceinline__ void conv_store_one(const ConvParams &p, int m, int n, float acc) {
@@ -1220,10 +1129,6 @@ static int conv_dispatch(const ConvParams &p, bool allow_ws, bool launch, void *
   *need = 0;
   for (int b0 = 0; b0 < p.B; b0 += nb) {
     ConvParams q = nb == p.B ? p : conv_slice_params(p, b0, (p.B - b0) < nb ? (p.B - b0) : nb);
-    if (g_tile_override == 0 && g_plan_mode == 0 && stream1x1_applicable(q)) {   // short-K 1x1 layer: the streaming kernel, no workspace
-      if (launch) launch_stream1x1(q, st);
-      continue;
-    }
     const ConvPlan pl = plan_conv(q, allow_ws);
     if (pl.ws_bytes > *need) *need = pl.ws_bytes;
     if (!launch) continue;

@@ -1002,32 +1002,3 @@ def test_pipelined_stack_equals_sequential(ia, neck_name):
         assert torch.equal(neck.forward_cl(x[:3].contiguous()), ref[:3])
     finally:
         pipeline.CHUNKS, pipeline.XF_BLOCKS, pipeline.XF_PRIORITY = old
-
-
-@pytest.mark.parametrize('cin,cout', [(64, 256), (64, 64), (128, 512), (128, 192), (64, 100)])
-def test_conv1x1_stream_kernel_equals_tiled_kernel(ia, cin, cout):
-    """Short-K 1x1 layers (Cin 64 / 128, >= 16384 rows) take the streaming kernel (filters resident in LDS, rows
-    global -> registers in the MFMA fragment layout): same k permutation as the tiled LDS-DMA kernel, so the two
-    agree BIT FOR BIT, with every epilogue variant (BN affine, ReLU, residual before / after the activation, a ragged
-    last 32-row tile, Cout not a multiple of 128)."""
-    from imvoxelnet_amd import ops, _lib
-    L = _lib.lib()
-    g = torch.Generator(device='cuda').manual_seed(cin + cout)
-    B, H, W = 3, 83, 97                                   # 24153 rows: not a multiple of 32
-    x = torch.randn(B, 1, H, W, cin, device='cuda', generator=g)
-    w = torch.randn(cout, 1, 1, 1, cin, device='cuda', generator=g) * 0.1
-    sc = torch.rand(cout, device='cuda', generator=g) + 0.5
-    sh = torch.randn(cout, device='cuda', generator=g)
-    res = torch.randn(B, 1, H, W, cout, device='cuda', generator=g)
-    for kw in (dict(), dict(relu=True), dict(relu=True, res=res), dict(relu=True, res=res, res_after_act=True, post_scale=0.5)):
-        sca, sha = (None, None) if not kw else (sc, sh)
-        L.ivx_conv_set_plan_mode(0)
-        y = ops.conv_fwd(x, w, sca, sha, (1, 1, 1), (1, 1, 1), (0, 0, 0), **kw)
-        L.ivx_conv_set_plan_mode(1)
-        try:
-            ref = ops.conv_fwd(x, w, sca, sha, (1, 1, 1), (1, 1, 1), (0, 0, 0), **kw)
-        finally:
-            L.ivx_conv_set_plan_mode(0)
-        naive = ops.conv_fwd(x, w, sca, sha, (1, 1, 1), (1, 1, 1), (0, 0, 0), naive=True, **kw)
-        assert torch.equal(y, ref), f'{kw.keys()}: {(y != ref).sum().item()} values differ from the tiled kernel'
-        assert_close('vs one-thread-per-output kernel', y, naive, 1e-4, 1e-4)
