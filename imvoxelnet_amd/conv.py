@@ -189,7 +189,7 @@ class FusedConv:
                 m_bytes = 4.0 * (m + 2) ** 2 * tiles * y.shape[3] * self.cout      # (m+2)^2 partial outputs [tiles, Zo, Cout]
                 by = {'input': 4.0 * x.numel() + v_bytes, 'gemm': v_bytes + m_bytes,
                       'output': m_bytes + 4.0 * y.numel() * (2 if res is not None else 1)}
-                FusedConv.trace += [('wino_' + n, e0, e1, fl, by[n], x.shape[1] > 1, self._describe(x, m)) for n, e0, e1, fl in ops.winograd_trace]
+                FusedConv.trace += [('wino_' + n, e0, e1, fl, by[n], x.shape[1] > 1 and x.shape[3] > 1, self._describe(x, m)) for n, e0, e1, fl in ops.winograd_trace]
                 ops.winograd_trace = None
             return y.view(B, 1, y.shape[1], y.shape[2], self.cout) if self._wino2d else y
         if FusedConv.trace is not None:
@@ -198,7 +198,7 @@ class FusedConv:
             y = self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
             e1.record()
             FusedConv.trace.append(('direct', e0, e1, 2.0 * y.numel() * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
-                                    if self.out_mode == 0 else 2.0 * x.numel() * self.cout, 0.0, x.shape[1] > 1, self._describe(x, 0)))
+                                    if self.out_mode == 0 else 2.0 * x.numel() * self.cout, 0.0, x.shape[1] > 1 and x.shape[3] > 1, self._describe(x, 0)))
             return y
         return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
 

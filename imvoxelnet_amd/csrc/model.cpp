@@ -613,7 +613,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         const PlanStep &ps = pl.ps[i];
         const void *res = s.res >= 0 ? ptr(s.res) : nullptr;
         const TInfo &o = pl.t[s.out];
-        const int is3d = in.D > 1;
+        const int is3d = in.D > 1 && in.W > 1;      // a 3-D neck layer (the head conv sees [B,X',Y',1,C])
         if (ps.tile && m->trace_on) {   // the three stages as separate launches so each gets its own pair of events
           const int n = ps.tile + 2, tiles = o.B * ((ps.d.D + 2 * ps.d.pd - 2 + ps.tile - 1) / ps.tile) * ((ps.d.H + 2 * ps.d.ph - 2 + ps.tile - 1) / ps.tile);
           int32_t zo_d, zo_h, zo;
