@@ -192,14 +192,23 @@ def test_conv_grid_tail_split(ia):
     r = torch.randn(1, 1, 672, 676, 64, device='cuda', generator=g)
     fc = FusedConv(w, bn=bn, padding=1, relu=True, dims=2).to('cuda')
     d = _lib.ConvDesc(1, 1, 672, 676, 128, 64, 1, 3, 3, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, fc.layout, 0, 0, 1.0)
-    assert _lib.lib().ivx_conv_workspace_bytes(C.byref(d)) > 0, 'expected the tail plan (2 full rounds + remainder)'
-    with direct_conv_only():
-        y = fc(x, res=r)
-        yn = fc(x, res=r, naive=True)
-        err = (y - yn).abs().max().item()
-        print('tail-split vs naive max err', err)
-        assert err < 1e-4
-        assert torch.equal(y, fc(x, res=r))
+    L = _lib.lib()
+    # the shape was built for the round-1 tile rule (128 x 64 at six per CU: 2 full rounds + a remainder); the scored choice
+    # of round 2 avoids such tails by picking another tile, so the rule is pinned here to keep the tail mechanism exercised
+    L.ivx_conv_set_plan_mode(1)
+    try:
+        assert L.ivx_conv_workspace_bytes(C.byref(d)) > 0, 'expected the tail plan (2 full rounds + remainder)'
+        with direct_conv_only():
+            y = fc(x, res=r)
+            yn = fc(x, res=r, naive=True)
+            err = (y - yn).abs().max().item()
+            print('tail-split vs naive max err', err)
+            assert err < 1e-4
+            assert torch.equal(y, fc(x, res=r))
+            L.ivx_conv_set_plan_mode(0)      # the scored plan: no K split here, so the sum order differs from the tail launch
+            assert (y - fc(x, res=r)).abs().max().item() < 1e-4
+    finally:
+        L.ivx_conv_set_plan_mode(0)
 
 
 def test_conv_fpn_upsample_residual(ia):
