@@ -344,7 +344,7 @@ def main():
     if args.api == 'simple_test':
         native_trace = model._native is not None and os.environ.get('IVX_BENCH_TRACE', '1') != '0'   # stage events are recorded inside the native handle
         if native_trace:
-            model._native.trace(True)
+            model._native.trace(1)     # coarse: neck stages, unprojection, tail individually; the 2-D trunk as one span
 
         def step(i):
             """The drop-in call, as tools/benchmark.py:74 times it: returns the list of result dicts on the host."""
@@ -392,7 +392,8 @@ def main():
         step(0)
         torch.cuda.synchronize()
     if native_trace:
-        model._native.trace(True)          # drop the warm-up records; the event pool they created is kept
+        model._native.trace(0)
+        model._native.trace(1)             # drop the warm-up records; the event pool they created is kept
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -422,12 +423,15 @@ def main():
     # neck time (it may exceed the MFMA peak).
     flops_step = neck_flops_per_sample((216, 248, 12), 64, 256) * B
     # uniform stage records (kind, ms, start_ms, flops, bytes, is_3d) per traced step, from either source
-    KIND = {0: 'direct', 1: 'wino_input', 2: 'wino_gemm', 3: 'wino_output', 4: 'lift', 5: 'tail'}
+    KIND = {0: 'direct', 1: 'wino_input', 2: 'wino_gemm', 3: 'wino_output', 4: 'lift', 5: 'tail', 6: 'trunk2d'}
     per_step = []
     if native_trace:
         recs = model._native.trace_records()
-        n_per = len(recs) // args.steps
-        for k in range(args.steps):
+        # graph replay (default): the stage events are nodes of the captured graph, re-recorded by every timed step; what is
+        # read back after the timed region are the event pairs of its LAST step.  Eager handle: one record list per step.
+        n_traced = 1 if model._native.graph else args.steps
+        n_per = len(recs) // n_traced
+        for k in range(n_traced):
             per_step.append([(KIND[r['stage']], r['ms'], r['start_ms'], r['flops'], r['bytes'], r['is3d']) for r in recs[k * n_per:(k + 1) * n_per]])
     else:
         for i in ev_ids:
@@ -460,7 +464,7 @@ def main():
     xf_bytes = sum(t[4] for t in xf) / nst
     t2d = [r for rows in per_step for r in rows if not r[5] and r[0] != 'tail']   # ResNet-50 + FPN level 0 + the head conv
     t2d_ms = sum(t[1] for t in t2d) / nst
-    t2d_flops = sum(t[3] for t in t2d if t[0] in ('direct', 'wino_gemm')) / nst
+    t2d_flops = sum(t[3] for t in t2d if t[0] in ('direct', 'wino_gemm', 'trunk2d')) / nst
 
     # HBM traffic of the neck conv launches: PMC counters cannot be read from inside the process, so the value comes
     # from the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh -> profiles/*_bench_pmc.json;
@@ -489,7 +493,8 @@ def main():
             'config': {'workload': 'kitti_mono_1x3x384x1280_vox216x248x12_resnet50_fpn64_kittineck_anchor3dhead',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'hip_graph': bool(args.graph),
                        'api': 'hipGraph replay' if args.graph else ('ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages'),
-                       'device_side': 'native model handle (ivx_model_forward)' if native_trace else 'layer-by-layer over the op-level C-ABI',
+                       'device_side': ('native model handle (ivx_model_forward%s)' % (', hipGraph replay per shape' if model._native.graph else '')) if model._native is not None and args.api == 'simple_test' else 'layer-by-layer over the op-level C-ABI',
+                       'stage_events': ('event-record nodes inside the replayed graph, read for the last timed step' if (native_trace and model._native.graph) else 'HIP event pairs around every launch of every timed step'),
                        'neck_pipeline_chunks': pipeline.CHUNKS if FusedConv.winograd else 0,
                        'detections_last_step': n_det(last)},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, %d launches/step)' % ('__bf16' if bf16 else 'float', n_launch),
@@ -512,8 +517,9 @@ def main():
                                       'achieved': round(lift_bytes / (lift_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
                                       'frac': round(lift_bytes / (lift_ms * 1e-3) / 8e12, 4), 'ms': round(lift_ms, 4),
                                       'algorithmic_MB': round(lift_bytes / 1e6, 1)},
-            'roofline_trunk_2d': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel (ResNet-50 + FPN level 0 + head conv, %d launches/step, '
-                                                             'event-bracketed incl. their transform / split-K passes)' % (len(t2d) // nst),
+            'roofline_trunk_2d': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel (ResNet-50 + FPN level 0 + head conv; %s)' % (
+                                      'one event pair around the whole trunk + one around the head conv' if native_trace else
+                                      '%d launches/step, event-bracketed incl. their transform / split-K passes' % (len(t2d) // nst)),
                                   'achieved': round(t2d_flops / (t2d_ms * 1e-3) / 1e12, 2) if t2d_ms > 0 else None, 'peak': peak, 'unit': 'TFLOP/s',
                                   'frac': round(t2d_flops / (t2d_ms * 1e-3) / 1e12 / peak, 4) if t2d_ms > 0 else None,
                                   'ms_per_step': round(t2d_ms, 3), 'executed_gflop_per_step': round(t2d_flops / 1e9, 1)},

@@ -116,8 +116,14 @@ struct ivx_model {
   std::vector<float> anchors_given;    // supplied through ivx_weights_load("anchors", ...)
   std::map<std::string, std::unique_ptr<Plan>> plans;
   std::vector<void *> owned;           // device allocations (weights, filters, anchors)
+  // hipGraph replay of ivx_model_forward (cfg.use_graph): one captured graph per distinct set of caller buffers
+  struct GraphEntry { std::vector<uintptr_t> key; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;
+  std::vector<std::vector<uintptr_t>> warmed;      // buffer sets that ran eagerly once (anchors uploaded, filters made)
   // optional stage timing (ivx_model_trace): one record per launch group, events recorded on the caller's stream
   bool trace_on = false;
+  int trace_level = 2;                 // 2: every launch group; 1: the 3-D neck stages, the unprojection and the tail individually,
+                                       //    the 2-D trunk (image layout change .. FPN level 0) as ONE span (stage 6)
   struct TraceRec { int step, stage, is3d; double flops, bytes; hipEvent_t e0, e1; std::string name; };
   std::vector<TraceRec> trace;
   std::vector<hipEvent_t> event_pool;
@@ -598,9 +604,32 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
     if (it != bd.ext.end()) return it->second;
     return base + pl.t[t].off;
   };
+  const bool span2d = m->trace_on && m->trace_level == 1 && m->cfg.with_trunk;     // coarse tracing: the trunk is one span
+  double span_flops = 0.0;
   for (int i = r.s0; i < r.s1; ++i) {
     const Step &s = m->steps[i];
     const TInfo &in = pl.t[s.in];
+    const bool in_span = span2d && i >= m->trunk0 && i < m->trunk1;
+    if (in_span && i == m->trunk0) M_TRY(trace_begin(m, i, 6, 0, 0.0, 0.0, "2-D trunk (ResNet-50 + FPN level 0)", st));
+    const bool was_on = m->trace_on;
+    if (in_span) {
+      m->trace_on = false;                       // no per-launch events inside the span
+      if (s.kind == ST_CONV) {
+        const PlanStep &ps = pl.ps[i];
+        const TInfo &o = pl.t[s.out];
+        const ConvLayer &L = m->layers[s.layer];
+        if (ps.tile) {
+          int32_t a_, b_, zo;
+          M_TRY(ivx_conv_out_dims(&ps.d, &a_, &b_, &zo));
+          const int n = ps.tile + 2;
+          const double tiles = (double)o.B * ((ps.d.D + 2 * ps.d.pd - 2 + ps.tile - 1) / ps.tile) * ((ps.d.H + 2 * ps.d.ph - 2 + ps.tile - 1) / ps.tile);
+          span_flops += 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin;
+        } else {
+          span_flops += 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2];
+        }
+      }
+    }
+    struct Restore { ivx_model *m; bool on; ~Restore() { m->trace_on = on; } } restore{m, was_on};   // also on an error return
     switch (s.kind) {
       case ST_IMG2CL:
         M_TRY(ivx_nchw_to_nhwc((const float *)ptr(s.in), in.B, 3, (int64_t)in.H * in.W, 4, (float *)ptr(s.out), st));
@@ -669,6 +698,15 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         break;
       }
     }
+    m->trace_on = was_on;
+    if (in_span && i == m->trunk1 - 1) {         // close the trunk span: its record is the last one opened at level 1
+      for (auto it = m->trace.rbegin(); it != m->trace.rend(); ++it)
+        if (it->stage == 6) {
+          it->flops = span_flops;
+          M_HIP(hipEventRecord(it->e1, st), "hipEventRecord");
+          break;
+        }
+    }
   }
   return IVX_OK;
 }
@@ -697,6 +735,7 @@ extern "C" int ivx_destroy(ivx_model *m) {
   if (!m) return IVX_OK;
   for (void *p : m->owned) (void)hipFree(p);
   for (hipEvent_t e : m->event_pool) (void)hipEventDestroy(e);
+  for (ivx_model::GraphEntry &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
   delete m;
   return IVX_OK;
 }
@@ -791,7 +830,46 @@ extern "C" int ivx_model_forward(ivx_model *m, const float *input, int32_t B, in
   if (out_valid) bd.ext[m->t_valid] = out_valid;
   bd.proj = proj; bd.new_origin = new_origin; bd.crop = crop_hw; bd.V = V;
   bd.boxes = out_boxes; bd.scores = out_scores; bd.labels = out_labels; bd.count = out_count;
-  return run_steps(m, *pl, r, bd, workspace, workspace_bytes, (hipStream_t)stream, "ivx_model_forward");
+  hipStream_t st = (hipStream_t)stream;
+  if (!m->cfg.use_graph || !st)      // (the legacy default stream cannot be captured)
+    return run_steps(m, *pl, r, bd, workspace, workspace_bytes, st, "ivx_model_forward");
+  // Graph replay: the ~150 launches of a forward are recorded once per set of caller buffers and replayed with one
+  // hipGraphLaunch.  First call with a buffer set: eager (settles one-time work: anchor upload); second: capture; then replay.
+  const std::vector<uintptr_t> key = {(uintptr_t)pl, (uintptr_t)input, (uintptr_t)proj, (uintptr_t)new_origin, (uintptr_t)crop_hw,
+                                      (uintptr_t)workspace, (uintptr_t)out_boxes, (uintptr_t)out_scores, (uintptr_t)out_labels,
+                                      (uintptr_t)out_count, (uintptr_t)out_valid, (uintptr_t)workspace_bytes};
+  for (const ivx_model::GraphEntry &g : m->graphs)
+    if (g.key == key) {
+      M_HIP(hipGraphLaunch(g.exec, st), "hipGraphLaunch");
+      return IVX_OK;
+    }
+  if (std::find(m->warmed.begin(), m->warmed.end(), key) == m->warmed.end()) {
+    m->warmed.push_back(key);
+    return run_steps(m, *pl, r, bd, workspace, workspace_bytes, st, "ivx_model_forward");
+  }
+  if (m->trace_on) {          // the stage events become event-record nodes of the graph: every replay re-records them, so the
+    m->trace.clear();         // records read back after a replay are those of the LAST step
+    m->events_used = 0;
+  }
+  M_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+  const int rc = run_steps(m, *pl, r, bd, workspace, workspace_bytes, st, "ivx_model_forward");
+  hipGraph_t graph = nullptr;
+  const hipError_t e_end = hipStreamEndCapture(st, &graph);
+  if (rc != IVX_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  M_HIP(e_end, "hipStreamEndCapture");
+  hipGraphExec_t exec = nullptr;
+  M_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+  (void)hipGraphDestroy(graph);
+  if (m->graphs.size() >= 8) {                      // callers with ever-changing buffers: keep the table small
+    (void)hipGraphExecDestroy(m->graphs.front().exec);
+    m->graphs.erase(m->graphs.begin());
+  }
+  m->graphs.push_back({key, exec});
+  M_HIP(hipGraphLaunch(exec, st), "hipGraphLaunch");
+  return IVX_OK;
 }
 
 // ---- 2-D trunk alone
@@ -919,9 +997,19 @@ extern "C" int ivx_voxel_new_origin(const float *origin, const int32_t *n_voxels
 // 5 anchor tail.  Read the records after synchronising the stream; enabling clears them.
 extern "C" int ivx_model_trace(ivx_model *m, int32_t enable) {
   M_REQUIRE(m, "ivx_model_trace: null handle");
+  if (m->trace_on != (enable != 0) || (enable && enable != m->trace_level)) {   // captured graphs hold (or lack) the event-record nodes: drop them on a change
+    for (ivx_model::GraphEntry &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    m->warmed.clear();
+    m->trace.clear();
+    m->events_used = 0;
+  }
   m->trace_on = enable != 0;
-  m->trace.clear();
-  m->events_used = 0;
+  if (enable == 1 || enable == 2) m->trace_level = enable;
+  if (m->graphs.empty()) {                 // eager mode (or nothing captured yet): start a fresh record list
+    m->trace.clear();
+    m->events_used = 0;
+  }
   return IVX_OK;
 }
 

@@ -41,7 +41,7 @@ def eligible(model):
 class NativeModel:
     """ivx_model handle built from an ImVoxelNet module (its config and its state dict)."""
 
-    def __init__(self, model, device, with_trunk=True, winograd=None, winograd_tile=None):
+    def __init__(self, model, device, with_trunk=True, winograd=None, winograd_tile=None, graph=None):
         from .conv import FusedConv
         from .necks3d import KittiImVoxelNeck
         if not eligible(model):
@@ -69,6 +69,12 @@ class NativeModel:
         cfg.dir_offset, cfg.dir_limit_offset = float(head.dir_offset), float(head.dir_limit_offset)
         cfg.winograd = int(FusedConv.winograd if winograd is None else winograd)
         cfg.winograd_tile = int(FusedConv.winograd_tile if winograd_tile is None else winograd_tile)
+        import os
+        # hipGraph replay inside the handle (one graph per set of caller buffers): opt-in (IVX_NATIVE_GRAPH=1).  Measured on
+        # KITTI batch 4: the handle issues its ~150 launches from C++ fast enough that the replay gains nothing (28.07 vs 27.86 ms
+        # eager), so it stays off by default; it helps a host that is slow to issue launches.
+        self.graph = (os.environ.get('IVX_NATIVE_GRAPH', '0') == '1') if graph is None else bool(graph)
+        cfg.use_graph = int(self.graph)
         self.cfg = cfg
         self.max_num, self.n_voxels = cfg.max_num, tuple(model.n_voxels)
         h = C.c_void_p()
@@ -92,6 +98,8 @@ class NativeModel:
             shape = (C.c_int64 * 2)(*anc.shape)
             check(L.ivx_weights_load(h, b'anchors', C.c_void_p(anc.data_ptr()), shape, 2), 'ivx_weights_load(anchors)')
         self._ws = {}
+        self._static = {}          # graph mode: stable input / output buffers per shape
+        self._gstream = torch.cuda.Stream(device=self.device) if self.graph else None   # the default stream cannot be captured
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -113,26 +121,51 @@ class NativeModel:
 
     def forward(self, x, B, V, H, W, proj, new_origin, crop_hw, want_valid=False):
         """x: image batch [B*V,3,H,W] (with_trunk) or FPN level-0 maps [B*V,1,H/4,W/4,Cf]; -> (boxes [B,max_num,7], scores,
-        labels int64, count int32[, valid bool [B,X,Y,Z]]) device tensors."""
+        labels int64, count int32[, valid bool [B,X,Y,Z]]) device tensors.
+        Graph mode (opt-in): inputs are copied into stable buffers, the handle replays one hipGraph per shape on its own
+        stream, and the returned tensors are the handle's stable output buffers -- consume (or clone) them before the next
+        forward of the same shape, as simple_test does."""
         L = self.L
+        for t, nm in ((x, 'input'), (proj, 'proj'), (new_origin, 'new_origin')):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise ValueError(f'{nm} must be a contiguous float32 device tensor')
         n = L.ivx_model_workspace_bytes(self.h, B, V, H, W)
         if n < 0:
             check(-1, 'ivx_model_workspace_bytes')
         ws = self._workspace('fwd', n)
         dev, M = x.device, self.max_num
-        boxes = torch.empty((B, M, 7), device=dev, dtype=torch.float32)
-        scores = torch.empty((B, M), device=dev, dtype=torch.float32)
-        labels = torch.empty((B, M), device=dev, dtype=torch.int64)
-        count = torch.empty((B,), device=dev, dtype=torch.int32)
-        valid = torch.empty((B,) + self.n_voxels, device=dev, dtype=torch.uint8) if want_valid else None
-        for t, nm in ((x, 'input'), (proj, 'proj'), (new_origin, 'new_origin')):
-            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
-                raise ValueError(f'{nm} must be a contiguous float32 device tensor')
-        check(L.ivx_model_forward(self.h, C.c_void_p(x.data_ptr()), B, V, H, W, C.c_void_p(proj.data_ptr()), C.c_void_p(new_origin.data_ptr()),
-                                  C.c_void_p(crop_hw.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(boxes.data_ptr()),
-                                  C.c_void_p(scores.data_ptr()), C.c_void_p(labels.data_ptr()), C.c_void_p(count.data_ptr()),
-                                  C.c_void_p(valid.data_ptr()) if want_valid else None, _stream()), 'ivx_model_forward')
-        return (boxes, scores, labels, count, valid.view(torch.bool)) if want_valid else (boxes, scores, labels, count)
+
+        def outputs():
+            return (torch.empty((B, M, 7), device=dev, dtype=torch.float32), torch.empty((B, M), device=dev, dtype=torch.float32),
+                    torch.empty((B, M), device=dev, dtype=torch.int64), torch.empty((B,), device=dev, dtype=torch.int32),
+                    torch.empty((B,) + self.n_voxels, device=dev, dtype=torch.uint8) if want_valid else None)
+
+        def call(xi, pj, no, cr, out, stream):
+            check(L.ivx_model_forward(self.h, C.c_void_p(xi.data_ptr()), B, V, H, W, C.c_void_p(pj.data_ptr()), C.c_void_p(no.data_ptr()),
+                                      C.c_void_p(cr.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(out[0].data_ptr()),
+                                      C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()), C.c_void_p(out[3].data_ptr()),
+                                      C.c_void_p(out[4].data_ptr()) if out[4] is not None else None, stream), 'ivx_model_forward')
+
+        if not self.graph:
+            out = outputs()
+            call(x, proj, new_origin, crop_hw, out, _stream())
+        else:
+            key = (tuple(x.shape), B, V, H, W, bool(want_valid))
+            st = self._static.get(key)
+            if st is None:
+                st = self._static[key] = (torch.empty_like(x), torch.empty_like(proj), torch.empty_like(new_origin), torch.empty_like(crop_hw),
+                                          outputs())
+            xs, ps, os_, cs, out = st
+            cur = torch.cuda.current_stream(dev)
+            self._gstream.wait_stream(cur)
+            with torch.cuda.stream(self._gstream):
+                xs.copy_(x, non_blocking=True)
+                ps.copy_(proj, non_blocking=True)
+                os_.copy_(new_origin, non_blocking=True)
+                cs.copy_(crop_hw, non_blocking=True)
+                call(xs, ps, os_, cs, out, C.c_void_p(self._gstream.cuda_stream))
+            cur.wait_stream(self._gstream)
+        return (out[0], out[1], out[2], out[3], out[4].view(torch.bool)) if want_valid else out[:4]
 
     # ------------------------------------------------------------------ sub-paths
     def backbone_fpn(self, img):
@@ -161,12 +194,16 @@ class NativeModel:
         return out
 
     # ------------------------------------------------------------------ stage timing
-    def trace(self, enable=True):
-        check(self.L.ivx_model_trace(self.h, int(bool(enable))), 'ivx_model_trace')
+    def trace(self, level=2):
+        """0 / False: off; 2 / True: an event pair around every launch group; 1: coarse -- the neck stages, the unprojection and
+        the tail individually, the 2-D trunk as one span (stage 6): a third of the events, for timed runs."""
+        level = 2 if level is True else int(level)
+        check(self.L.ivx_model_trace(self.h, level), 'ivx_model_trace')
 
     def trace_records(self):
         """After torch.cuda.synchronize(): list of dicts (step, stage, is3d, ms, flops, bytes, name) in launch order;
-        stage 0 direct conv, 1 Winograd input transform, 2 grouped GEMM, 3 output transform, 4 unprojection, 5 tail."""
+        stage 0 direct conv, 1 Winograd input transform, 2 grouped GEMM, 3 output transform, 4 unprojection, 5 tail, 6 the
+        2-D trunk as one span (coarse level)."""
         out, rec = [], TraceRec()
         for i in range(self.L.ivx_model_trace_count(self.h)):
             check(self.L.ivx_model_trace_read(self.h, i, C.byref(rec)), 'ivx_model_trace_read')

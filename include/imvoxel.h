@@ -381,6 +381,9 @@ typedef struct ivx_model_cfg {
   float dir_offset, dir_limit_offset;         /* Anchor3DHead(dir_offset, dir_limit_offset) */
   int32_t winograd;           /* 1: F(m x m, 3x3) form for the eligible layers (default of the Python host), 0: direct only */
   int32_t winograd_tile;      /* 0: automatic (6 on planes >= 16384 positions, else 4) | 2 | 4 | 6 */
+  int32_t use_graph;          /* 1: ivx_model_forward records its launches into a hipGraph per distinct set of caller buffers
+                                 (1st call eager, 2nd captured, then one hipGraphLaunch per call); needs a non-NULL stream and
+                                 stable buffers -- a host that passes new pointers every call gains nothing */
 } ivx_model_cfg;
 
 int ivx_create(const ivx_model_cfg *cfg, ivx_model **out);
@@ -409,7 +412,9 @@ int ivx_neck3d_nuscenes_fwd(ivx_model *m, const float *volume, int32_t B, float 
 /* Optional stage timing (measurement only): while enabled, every launch group of the forward calls is bracketed by a pair
  * of HIP events on the caller's stream; the Winograd layers run as their three stages so each is timed.  stage: 0 direct
  * conv, 1 Winograd input transform, 2 grouped GEMM, 3 output transform, 4 unprojection, 5 anchor tail.  flops = FLOPs the
- * launch executes, bytes = algorithmic bytes of a transform / unprojection launch.  Read after synchronising the stream. */
+ * launch executes, bytes = algorithmic bytes of a transform / unprojection launch.  Read after synchronising the stream.
+ * With use_graph the events are nodes of the captured graph: every replay re-records them and the records read back are
+ * those of the last forward. */
 typedef struct ivx_trace_rec {
   int32_t step, stage, is3d;
   float ms;        /* duration of the launch group */
@@ -417,7 +422,8 @@ typedef struct ivx_trace_rec {
   double flops, bytes;
   char name[48];
 } ivx_trace_rec;
-int ivx_model_trace(ivx_model *m, int32_t enable);
+int ivx_model_trace(ivx_model *m, int32_t level);   /* 0 off | 2 every launch group | 1 coarse: the 3-D neck stages, the
+                                                       unprojection and the tail individually, the 2-D trunk as one span (stage 6) */
 int32_t ivx_model_trace_count(ivx_model *m);
 int ivx_model_trace_read(ivx_model *m, int32_t i, ivx_trace_rec *rec);
 
