@@ -147,9 +147,23 @@ def bench_other(args, ia, kc, dev, rank, world):
     multi = dist.is_available() and dist.is_initialized()
     if multi and not view_sharded:
         raise SystemExit('--config other than kitti runs single-process, or with --shard views under torch.distributed.run')
+    # default: the public call.  model.simple_test runs trunk + unprojection + neck (+ the anchor head and tail for nuScenes)
+    # through the native model handle; stage times come from its coarse trace (neck stages individually, trunk as one span)
+    public = args.api == 'simple_test' and getattr(model, '_native', None) is not None and not view_sharded
+    traced_run = os.environ.get('IVX_BENCH_TRACE', '1') != '0'
+    if public:
+        step(0)                                  # one composed step: the neck's direct / executed FLOP counts
+
+        def step(i, traced=False):               # noqa: F811
+            res = model.simple_test(img, metas)
+            return [(r['boxes_3d'].tensor, r['scores_3d'], r['labels_3d']) for r in res]
+        model._native.trace(1 if traced_run else 0)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    if public and traced_run:
+        model._native.trace(0)
+        model._native.trace(1)                   # drop the warm-up records
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -167,31 +181,50 @@ def bench_other(args, ia, kc, dev, rank, world):
         dt = float(t.item())
         if rank != 0:
             return
-    neck_ms = sum(ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][1]) for i in range(args.steps)) / args.steps
+    trunk_note = ''
+    if public and not traced_run:                # throughput only
+        neck_ms, t2d, t2d_ms, t2d_flops, nt = 1e9, [], 0.0, 0.0, 0
+    elif public:
+        recs = model._native.trace_records()
+        model._native.trace(0)
+        n_per = len(recs) // args.steps
+        neck_ms = t2d_ms = t2d_flops = 0.0
+        for k in range(args.steps):
+            rows = recs[k * n_per:(k + 1) * n_per]
+            t3 = [r for r in rows if r['is3d'] and r['stage'] <= 3]
+            neck_ms += (max(r['start_ms'] + r['ms'] for r in t3) - min(r['start_ms'] for r in t3)) / args.steps
+            t2d_ms += sum(r['ms'] for r in rows if r['stage'] == 6) / args.steps
+            t2d_flops += sum(r['flops'] for r in rows if r['stage'] == 6) / args.steps
+        t2d, nt = [1], 1
+        trunk_note = 'one event pair around the whole trunk in every timed step (native coarse trace)'
+    else:
+        neck_ms = sum(ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][1]) for i in range(args.steps)) / args.steps
+        # 2-D trunk roofline: per-launch events would make these short, host-bound steps slower, so the trunk's launches are
+        # bracketed in `nt` EXTRA steps after the timed region (same inputs, same kernels)
+        nt = 0 if multi else min(3, args.steps)          # (the view-sharded step holds a collective: all ranks or none)
+        for k in range(nt):
+            step(k, traced=True)
+        torch.cuda.synchronize()
+        t2d = [t for k in range(nt) for t in trunk_tr[k]]
+        t2d_ms = sum(t[1].elapsed_time(t[2]) for t in t2d) / max(nt, 1)
+        t2d_flops = sum(t[3] for t in t2d if t[0] in ('direct', 'wino_gemm')) / max(nt, 1)
+        trunk_note = '%d launches/step, event-bracketed incl. their Winograd transform / split-K passes, in %d extra steps after the timed region' % (
+            len(t2d) // max(nt, 1), nt)
     ach = neck_exec[0] / (neck_ms * 1e-3) / 1e12      # executed FLOPs over the whole neck time (transform kernels included)
-    # 2-D trunk roofline: per-launch events would make these short, host-bound steps slower, so the trunk's launches are
-    # bracketed in `nt` EXTRA steps after the timed region (same inputs, same kernels)
-    nt = 0 if multi else min(3, args.steps)          # (the view-sharded step holds a collective: all ranks or none)
-    for k in range(nt):
-        step(k, traced=True)
-    torch.cuda.synchronize()
-    t2d = [t for k in range(nt) for t in trunk_tr[k]]
-    t2d_ms = sum(t[1].elapsed_time(t[2]) for t in t2d) / max(nt, 1)
-    t2d_flops = sum(t[3] for t in t2d if t[0] in ('direct', 'wino_gemm')) / max(nt, 1)
     pk = PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS
     rec = {'metric': f'images/sec/node ({args.config}: {V} view(s) 3x{H}x{W}, {"x".join(map(str, cfg["n_voxels"]))} vox)',
            'value': round(B * V * args.steps / dt, 3), 'unit': 'images/s', 'scenes_per_s': round(B * args.steps / dt, 3), 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
            'scaling': 'strong' if view_sharded else 'weak', 'vs_baseline': None, 'dtype': args.storage, 'data': 'synthetic',
-           'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'shard': args.shard, 'detections_last_step': int(sum(len(r[1]) for r in last))},
+           'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'shard': args.shard, 'api': 'simple_test (native handle)' if public else 'composed',
+                      'detections_last_step': int(sum(len(r[1]) for r in last))},
            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck)' % ('__bf16' if args.storage == 'bf16' else 'float'),
                         'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS), 4), 'traffic': None,
                         'neck_gflop': round(neck_exec[0] / 1e9, 1), 'neck_direct_gflop': round(neck_flops[0] / 1e9, 1),
                         'direct_equivalent_tflops': round(neck_flops[0] / (neck_ms * 1e-3) / 1e12, 2), 'neck_ms_per_step': round(neck_ms, 3)},
            'roofline_trunk_2d': None if not t2d else {
-               'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel (ResNet-50 + FPN level 0 over %d views, %d launches/step, event-bracketed incl. '
-                                          'their Winograd transform / split-K passes, in %d extra steps after the timed region)' % (B * V, len(t2d) // max(nt, 1), nt),
+               'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel (ResNet-50 + FPN level 0 over %d views; %s)' % (B * V, trunk_note),
                'achieved': round(t2d_flops / (t2d_ms * 1e-3) / 1e12, 2), 'peak': pk, 'unit': 'TFLOP/s',
                'frac': round(t2d_flops / (t2d_ms * 1e-3) / 1e12 / pk, 4), 'ms_per_step': round(t2d_ms, 3),
                'executed_gflop_per_step': round(t2d_flops / 1e9, 1)}}

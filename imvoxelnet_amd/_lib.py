@@ -36,7 +36,9 @@ class ModelCfg(C.Structure):
                 ('n_rotations', C.c_int32), ('anchor_range', C.c_float * 6), ('anchor_sizes', C.c_float * 12),
                 ('anchor_rotations', C.c_float * 4), ('nms_pre', C.c_int32), ('max_num', C.c_int32), ('use_rotate_nms', C.c_int32),
                 ('score_thr', C.c_float), ('nms_thr', C.c_float), ('dir_offset', C.c_float), ('dir_limit_offset', C.c_float),
-                ('winograd', C.c_int32), ('winograd_tile', C.c_int32), ('use_graph', C.c_int32)]
+                ('winograd', C.c_int32), ('winograd_tile', C.c_int32), ('use_graph', C.c_int32),
+                ('fast_n_blocks', C.c_int32 * 3), ('unet_channels', C.c_int32 * 4), ('unet_down_layers', C.c_int32 * 4),
+                ('unet_up_layers', C.c_int32 * 3)]
 
 
 class TraceRec(C.Structure):
@@ -54,7 +56,8 @@ EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd',
            'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms', 'ivx_multiclass_nms_workspace_bytes', 'ivx_multiclass_nms_bev',
            'ivx_create', 'ivx_destroy', 'ivx_weights_load', 'ivx_weights_finalize', 'ivx_model_workspace_bytes', 'ivx_model_forward',
            'ivx_backbone_fpn_workspace_bytes', 'ivx_backbone_fpn_fwd', 'ivx_neck3d_workspace_bytes', 'ivx_neck3d_out_dims',
-           'ivx_neck3d_kitti_fwd', 'ivx_neck3d_nuscenes_fwd', 'ivx_model_anchors', 'ivx_compute_projection', 'ivx_voxel_new_origin', 'ivx_fold_batchnorm',
+           'ivx_neck3d_kitti_fwd', 'ivx_neck3d_nuscenes_fwd', 'ivx_neck3d_levels', 'ivx_neck3d_fast_fwd', 'ivx_neck3d_unet_fwd',
+           'ivx_model_forward_levels', 'ivx_model_anchors', 'ivx_compute_projection', 'ivx_voxel_new_origin', 'ivx_fold_batchnorm',
            'ivx_model_trace', 'ivx_model_trace_count', 'ivx_model_trace_read',
            'ivx_kitti_image_box_overlap', 'ivx_kitti_compute_statistics', 'ivx_kitti_collect_scores', 'ivx_kitti_fused_statistics']
 
@@ -133,6 +136,10 @@ def lib():
     L.ivx_neck3d_out_dims.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.ivx_neck3d_kitti_fwd.argtypes = [vp, vp, i32, vp, vp, i64, vp]
     L.ivx_neck3d_nuscenes_fwd.argtypes = [vp, vp, i32, vp, vp, i64, vp]
+    L.ivx_neck3d_levels.argtypes = [vp, i32, vp]
+    L.ivx_neck3d_fast_fwd.argtypes = [vp, vp, i32, vp, vp, i64, vp]
+    L.ivx_neck3d_unet_fwd.argtypes = [vp, vp, i32, vp, vp, i64, vp]
+    L.ivx_model_forward_levels.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp]
     L.ivx_model_anchors.argtypes = [vp, i32, i32, vp, i64]
     L.ivx_compute_projection.argtypes = [vp, vp, i32, C.c_double, vp]
     L.ivx_voxel_new_origin.argtypes = [vp, vp, vp, vp]

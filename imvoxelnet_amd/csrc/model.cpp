@@ -59,6 +59,7 @@ struct ConvLayer {
   int cin = 0, cout = 0;
   int k[3] = {1, 1, 1}, s[3] = {1, 1, 1}, p[3] = {0, 0, 0};
   bool relu = false;
+  bool conv_t = false;                // nn.ConvTranspose3d(k2, s2) weights [Cin,Cout,2,2,2] run as a 1x1x1 GEMM with 8*Cout columns (out_mode 1)
   std::vector<std::string> w_keys;    // > 1: filter banks concatenated along Cout (the fused head conv)
   std::vector<std::string> b_keys;    // parallel to w_keys; "" = no bias
   std::string bn;                     // BatchNorm prefix or ""
@@ -69,13 +70,15 @@ struct ConvLayer {
   std::map<int, float *> u;           // tile -> transformed filters
 };
 
-enum StepKind { ST_IMG2CL, ST_CONV, ST_MAXPOOL, ST_LIFT, ST_TAIL };
+enum StepKind { ST_IMG2CL, ST_CONV, ST_MAXPOOL, ST_LIFT, ST_TAIL, ST_UPSAMPLE };
 
 struct Step {
   StepKind kind;
   int layer = -1;
   int in = -1, res = -1, out = -1, out2 = -1;   // tensor ids (out2: the valid mask of the lift)
   int res_mode = 0;
+  int res_after_act = 0;     // the residual is added after the ReLU (skip adds of the U-shaped necks)
+  float post_scale = 1.0f;   // Atlas decoder: (x + y) / 2
 };
 
 struct TInfo {
@@ -108,6 +111,7 @@ struct ivx_model {
   // step ranges [begin, end) and boundary tensors
   int trunk0 = 0, trunk1 = 0, lift_step = -1, neck0 = 0, neck1 = 0, head_step = -1, tail_step = -1;
   int t_img = -1, t_fpn0 = -1, t_volume = -1, t_valid = -1, t_neck = -1, t_head = -1;
+  std::vector<int> t_levels;           // indoor necks: the output levels, finest first
   std::map<std::string, HostTensor> weights;
   bool finalized = false;
   std::vector<float> anchors_host;     // [H*W*A, 7] for the (H, W) below; regenerated when the grid changes
@@ -232,6 +236,100 @@ void build_neck(ivx_model *m, int t_in) {
   m->neck1 = (int)m->steps.size();
 }
 
+
+ConvLayer conv3d_k(const std::string &name, int cin, int cout, int k, int stride, int pad, bool relu, const std::string &w, const std::string &b,
+                   const std::string &bn) {
+  const int s3[3] = {stride, stride, stride}, p3[3] = {pad, pad, pad};
+  ConvLayer L = conv3d(name, cin, cout, s3, p3, relu, w, b, bn);
+  for (int a = 0; a < 3; ++a) L.k[a] = k;
+  return L;
+}
+
+// BasicBlock3d (necks/imvoxelnet.py:191-230): conv3-BN-ReLU-conv3-BN-(+x)-ReLU
+int add_block3d(ivx_model *m, const std::string &pre, int ch, int x, const char *n1 = "bn1", const char *n2 = "bn2") {
+  int y = add_conv(m, conv3d_k(pre + "conv1", ch, ch, 3, 1, 1, true, pre + "conv1.weight", "", pre + n1), x);
+  return add_conv(m, conv3d_k(pre + "conv2", ch, ch, 3, 1, 1, true, pre + "conv2.weight", "", pre + n2), y, x, 1);
+}
+
+int add_upsample(ivx_model *m, int x) {
+  Step u; u.kind = ST_UPSAMPLE; u.in = x; u.out = new_tensor(m);
+  m->steps.push_back(u);
+  return u.out;
+}
+
+// FastIndoorImVoxelNeck (necks/imvoxelnet.py:8-67): BasicBlock3dV2 stacks (stride 2 from level 1 on, 1x1x1-BN shortcut when
+// strided), ConvTranspose(k2,s2)-BN-ReLU-conv3-BN-ReLU up-blocks with skip ADD after the activation, conv3-BN-ReLU out-blocks.
+void build_neck_fast(ivx_model *m, int t_in) {
+  m->neck0 = (int)m->steps.size();
+  int c = m->cfg.fpn_channels, x = t_in;
+  std::vector<int> down, chans;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < m->cfg.fast_n_blocks[i]; ++j) {
+      const std::string pre = "neck_3d.down_layer_" + std::to_string(i) + "." + std::to_string(j) + ".";
+      const int stride = (j == 0 && i > 0) ? 2 : 1, co = stride == 2 ? 2 * c : c;
+      int idt = x;
+      if (stride != 1) idt = add_conv(m, conv3d_k(pre + "downsample", c, co, 1, 2, 0, false, pre + "downsample.0.weight", "", pre + "downsample.1"), x);
+      int y = add_conv(m, conv3d_k(pre + "conv1", c, co, 3, stride, 1, true, pre + "conv1.weight", "", pre + "norm1"), x);
+      x = add_conv(m, conv3d_k(pre + "conv2", co, co, 3, 1, 1, true, pre + "conv2.weight", "", pre + "norm2"), y, idt, 1);
+      c = co;
+    }
+    down.push_back(x);
+    chans.push_back(c);
+  }
+  std::vector<int> outs(3, -1);
+  for (int i = 2; i >= 0; --i) {
+    if (i < 2) {
+      const std::string pre = "neck_3d.up_block_" + std::to_string(i + 1) + ".";
+      ConvLayer t = conv3d_k(pre + "0", chans[i + 1], 8 * chans[i], 1, 1, 0, true, pre + "0.weight", "", pre + "1");
+      t.conv_t = true;
+      x = add_conv(m, t, x);
+      x = add_conv(m, conv3d_k(pre + "3", chans[i], chans[i], 3, 1, 1, true, pre + "3.weight", "", pre + "4"), x, down[i], 1);
+      m->steps.back().res_after_act = 1;            // relu(bn(conv(.))) + skip   (:30-31)
+    }
+    const std::string po = "neck_3d.out_block_" + std::to_string(i) + ".";
+    outs[i] = add_conv(m, conv3d_k(po + "0", chans[i], m->cfg.neck_out_channels, 3, 1, 1, true, po + "0.weight", "", po + "1"), x);
+  }
+  m->t_levels = outs;
+  m->neck1 = (int)m->steps.size();
+}
+
+// ImVoxelNeck = Atlas EncoderDecoder + per-level conv3(bias)-BN-ReLU (necks/imvoxelnet.py:70-91, 297-372; cond_proj False)
+void build_neck_unet(ivx_model *m, int t_in) {
+  m->neck0 = (int)m->steps.size();
+  const int *ch = m->cfg.unet_channels, *dl = m->cfg.unet_down_layers, *ul = m->cfg.unet_up_layers;
+  int x = t_in;
+  std::vector<int> xs;
+  for (int i = 0; i < 4; ++i) {
+    const std::string pre = "neck_3d.model.layers_down." + std::to_string(i) + ".";
+    int k0 = 0;
+    if (i > 0) {
+      x = add_conv(m, conv3d_k(pre + "0", ch[i - 1], ch[i], 3, 2, 1, true, pre + "0.weight", "", pre + "1"), x);
+      k0 = 4;                                        // Sequential: conv, norm, dropout, relu precede the blocks
+    }
+    for (int j = 0; j < dl[i]; ++j) x = add_block3d(m, pre + std::to_string(k0 + j) + ".", ch[i], x);
+    xs.push_back(x);
+  }
+  std::vector<int> out;                              // coarse -> fine
+  for (int i = 0; i < 3; ++i) {
+    const int c_in = ch[3 - i], c_out = ch[2 - i];
+    const std::string pu = "neck_3d.model.layers_up_conv." + std::to_string(i) + ".", pp = "neck_3d.model.proj." + std::to_string(i) + ".";
+    x = add_upsample(m, x);
+    x = add_conv(m, conv3d_k(pu, c_in, c_out, 1, 1, 0, false, pu + "weight", "", ""), x);
+    x = add_conv(m, conv3d_k(pp + "conv", c_out, c_out, 1, 1, 0, true, pp + "conv.weight", "", pp + "norm"), xs[2 - i], x, 1);
+    m->steps.back().res_after_act = 1;               // (x + relu(bn(conv(skip)))) / 2   (:366-367)
+    m->steps.back().post_scale = 0.5f;
+    for (int j = 0; j < ul[i]; ++j) x = add_block3d(m, "neck_3d.model.layers_up_res." + std::to_string(i) + "." + std::to_string(j) + ".", c_out, x);
+    out.push_back(x);
+  }
+  std::vector<int> lv(3, -1);
+  for (int l = 0; l < 3; ++l) {                      // level l (finest first) = out[2 - l]
+    const std::string pb = "neck_3d.conv_blocks." + std::to_string(l) + ".";
+    lv[l] = add_conv(m, conv3d_k(pb + "0", ch[l], m->cfg.neck_out_channels, 3, 1, 1, true, pb + "0.weight", pb + "0.bias", pb + "1"), out[2 - l]);
+  }
+  m->t_levels = lv;
+  m->neck1 = (int)m->steps.size();
+}
+
 void build_graph(ivx_model *m) {
   int t_feat;
   if (m->cfg.with_trunk) {
@@ -243,6 +341,11 @@ void build_graph(ivx_model *m) {
   Step lift; lift.kind = ST_LIFT; lift.in = t_feat; lift.out = m->t_volume = new_tensor(m); lift.out2 = m->t_valid = new_tensor(m);
   m->lift_step = (int)m->steps.size();
   m->steps.push_back(lift);
+  if (m->cfg.neck_type == IVX_NECK_FAST || m->cfg.neck_type == IVX_NECK_UNET) {   // indoor families: the handle ends at the neck levels
+    if (m->cfg.neck_type == IVX_NECK_FAST) build_neck_fast(m, m->t_volume);
+    else build_neck_unet(m, m->t_volume);
+    return;
+  }
   build_neck(m, m->t_volume);
   // Anchor3DHead: conv_cls | conv_reg | conv_dir_cls as one 1x1 conv (anchor3d_head.py:122-130,138-153)
   const int A = m->cfg.n_sizes * m->cfg.n_rotations, oc = m->cfg.neck_out_channels;
@@ -284,6 +387,16 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
     const HostTensor *w = find_w(m, L.w_keys[q]);
     if (!w) { *missing += L.w_keys[q] + " "; return IVX_OK; }
     const size_t nd = w->shape.size();
+    if (L.conv_t) {   // [Cin, Cr, 2,2,2] -> columns n = ((a*2+e)*2+f)*Cr + co of a 1x1x1 GEMM (conv.py FusedConvTranspose2x)
+      const int cr = L.cout / 8;
+      M_REQUIRE(nd == 5 && w->shape[0] == L.cin && w->shape[1] == cr && w->shape[2] == 2 && w->shape[3] == 2 && w->shape[4] == 2,
+                "ivx_weights_finalize: %s must be [Cin, Cout, 2, 2, 2]", L.w_keys[q].c_str());
+      for (int ci = 0; ci < L.cin; ++ci)
+        for (int co = 0; co < cr; ++co)
+          for (int tap = 0; tap < 8; ++tap) wp[(size_t)(tap * cr + co) * L.cin_pad + ci] = w->data[((size_t)ci * cr + co) * 8 + tap];
+      co0 = L.cout;
+      continue;
+    }
     M_REQUIRE(nd == (size_t)(L.dims + 2) && w->shape[1] == L.cin, "ivx_weights_finalize: %s has the wrong rank / input channels", L.w_keys[q].c_str());
     const int co_n = (int)w->shape[0];
     int64_t want = (int64_t)co_n * L.cin * taps;
@@ -319,15 +432,16 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
   }
   M_TRY(dev_upload(m, wp, &L.w, st));
   if (L.wino_cand) M_TRY(dev_upload(m, w0, &L.w0, st));
-  std::vector<float> scale(L.cout, 1.f), shift(bias);
+  const int n_aff = L.conv_t ? L.cout / 8 : L.cout;     // the transposed conv's BN has the REAL channel count (epilogue indexes n % Cr)
+  std::vector<float> scale(n_aff, 1.f), shift(bias.begin(), bias.begin() + n_aff);
   if (!L.bn.empty()) {
     const HostTensor *g = find_w(m, L.bn + ".weight"), *b = find_w(m, L.bn + ".bias"), *mu = find_w(m, L.bn + ".running_mean"),
                      *var = find_w(m, L.bn + ".running_var");
     if (!g || !b || !mu || !var) { *missing += L.bn + ".{weight,bias,running_mean,running_var} "; return IVX_OK; }
-    M_REQUIRE((int)g->data.size() == L.cout && (int)b->data.size() == L.cout && (int)mu->data.size() == L.cout && (int)var->data.size() == L.cout,
+    M_REQUIRE((int)g->data.size() == n_aff && (int)b->data.size() == n_aff && (int)mu->data.size() == n_aff && (int)var->data.size() == n_aff,
               "ivx_weights_finalize: BatchNorm %s has the wrong size", L.bn.c_str());
     std::vector<float> bias_in(shift);
-    M_TRY(ivx_fold_batchnorm(g->data.data(), b->data.data(), mu->data.data(), var->data.data(), bias_in.data(), 1e-5f, L.cout, scale.data(),
+    M_TRY(ivx_fold_batchnorm(g->data.data(), b->data.data(), mu->data.data(), var->data.data(), bias_in.data(), 1e-5f, n_aff, scale.data(),
                              shift.data()));
   }
   L.identity_epilogue = !has_bias && L.bn.empty();
@@ -374,6 +488,7 @@ int conv_out(const ConvLayer &L, const TInfo &in, TInfo *o) {
     od[a] = (dims[a] + 2 * L.p[a] - L.k[a]) / L.s[a] + 1;
   }
   o->B = in.B; o->D = od[0]; o->H = od[1]; o->W = od[2]; o->C = L.cout;
+  if (L.conv_t) { o->D = 2 * in.D; o->H = 2 * in.H; o->W = 2 * in.W; o->C = L.cout / 8; }
   return IVX_OK;
 }
 
@@ -388,11 +503,13 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
   d.relu = L.relu ? 1 : 0;
   d.res_mode = st.res_mode;
   if (st.res_mode == 2) { d.res_h = res->H; d.res_w = res->W; }
-  d.wgt_layout = L.layout; d.post_scale = 1.0f;
+  d.wgt_layout = L.layout; d.post_scale = st.post_scale;
+  d.res_after_act = st.res_after_act;
+  d.out_mode = L.conv_t ? 1 : 0;
   M_REQUIRE(in.C == L.cin_pad, "layer %s: input has %d channels, expected %d", L.name.c_str(), in.C, L.cin_pad);
   int tile = 0;
   ivx_conv_desc dw = d;
-  if (L.wino_cand && m->cfg.winograd && (st.res_mode == 0 || st.res_mode == 1) && (int64_t)in.B * in.D * in.H * in.W >= 2000) {
+  if (L.wino_cand && !L.conv_t && m->cfg.winograd && (st.res_mode == 0 || st.res_mode == 1) && (int64_t)in.B * in.D * in.H * in.W >= 2000) {
     if (L.wino2d) {   // [B,1,H,W,C] as [B,H,W,1,C] with a 3x3x1 kernel
       dw.D = in.H; dw.H = in.W; dw.W = 1;
       dw.KD = 3; dw.KH = 3; dw.KW = 1; dw.sd = dw.sh = dw.sw = 1;
@@ -445,6 +562,7 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
     switch (s.kind) {
       case ST_IMG2CL: o = in; o.C = 4; break;
       case ST_MAXPOOL: o = in; o.H = (in.H + 2 - 3) / 2 + 1; o.W = (in.W + 2 - 3) / 2 + 1; break;
+      case ST_UPSAMPLE: o = in; o.D = 2 * in.D; o.H = 2 * in.H; o.W = 2 * in.W; break;
       case ST_CONV: {
         ConvLayer &L = m->layers[s.layer];
         M_TRY(conv_out(L, in, &o));
@@ -488,7 +606,9 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
     for (int t : {s.in, s.res})
       if (t >= 0) pl->t[t].last = std::max(pl->t[t].last, i);
   }
-  for (int t : {m->t_fpn0, m->t_volume, m->t_valid, m->t_neck, m->t_head})
+  std::vector<int> keep = {m->t_fpn0, m->t_volume, m->t_valid, m->t_neck, m->t_head};
+  keep.insert(keep.end(), m->t_levels.begin(), m->t_levels.end());
+  for (int t : keep)
     if (t >= 0 && pl->t[t].first >= r.s0) pl->t[t].last = r.s1;   // boundary tensors may be read back by the caller
   // first-fit arena with coalescing free list
   struct Blk { int64_t off, size; };
@@ -637,6 +757,9 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
       case ST_MAXPOOL:
         M_TRY(ivx_maxpool2d_fwd((const float *)ptr(s.in), in.B, in.H, in.W, in.C, 3, 2, 1, (float *)ptr(s.out), st));
         break;
+      case ST_UPSAMPLE:
+        M_TRY(ivx_upsample_trilinear2x_fwd((const float *)ptr(s.in), in.B, in.D, in.H, in.W, in.C, (float *)ptr(s.out), st));
+        break;
       case ST_CONV: {
         const ConvLayer &L = m->layers[s.layer];
         const PlanStep &ps = pl.ps[i];
@@ -716,13 +839,21 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
 // ================================================================================================ C-ABI
 extern "C" int ivx_create(const ivx_model_cfg *cfg, ivx_model **out) {
   M_REQUIRE(cfg && out, "ivx_create: null argument");
-  M_REQUIRE(cfg->neck_type == IVX_NECK_KITTI || cfg->neck_type == IVX_NECK_NUSCENES, "ivx_create: neck_type must be IVX_NECK_KITTI or IVX_NECK_NUSCENES");
+  M_REQUIRE(cfg->neck_type >= IVX_NECK_KITTI && cfg->neck_type <= IVX_NECK_UNET, "ivx_create: neck_type must be IVX_NECK_KITTI | NUSCENES | FAST | UNET");
+  const bool indoor = cfg->neck_type == IVX_NECK_FAST || cfg->neck_type == IVX_NECK_UNET;
+  if (cfg->neck_type == IVX_NECK_FAST)
+    M_REQUIRE(cfg->fast_n_blocks[0] >= 1 && cfg->fast_n_blocks[1] >= 1 && cfg->fast_n_blocks[2] >= 1, "ivx_create: fast_n_blocks must be >= 1 per level");
+  if (cfg->neck_type == IVX_NECK_UNET) {
+    M_REQUIRE(cfg->unet_channels[0] == cfg->fpn_channels, "ivx_create: unet_channels[0] must equal fpn_channels");
+    for (int i = 0; i < 4; ++i) M_REQUIRE(cfg->unet_channels[i] > 0 && cfg->unet_channels[i] % 4 == 0 && cfg->unet_down_layers[i] >= 0, "ivx_create: bad unet_channels / unet_down_layers");
+    for (int i = 0; i < 3; ++i) M_REQUIRE(cfg->unet_up_layers[i] >= 0, "ivx_create: bad unet_up_layers");
+  }
   M_REQUIRE(cfg->fpn_channels > 0 && cfg->fpn_channels % 4 == 0 && cfg->neck_out_channels > 0 && cfg->neck_out_channels % 4 == 0,
             "ivx_create: channel counts must be positive multiples of 4");
   M_REQUIRE(cfg->n_voxels[0] > 0 && cfg->n_voxels[1] > 0 && cfg->n_voxels[2] > 0, "ivx_create: bad n_voxels");
-  M_REQUIRE(cfg->num_classes >= 1 && cfg->n_sizes >= 1 && cfg->n_sizes <= 4 && cfg->n_rotations >= 1 && cfg->n_rotations <= 4,
+  M_REQUIRE(indoor || (cfg->num_classes >= 1 && cfg->n_sizes >= 1 && cfg->n_sizes <= 4 && cfg->n_rotations >= 1 && cfg->n_rotations <= 4),
             "ivx_create: 1..4 anchor sizes / rotations, >= 1 class");
-  M_REQUIRE(cfg->nms_pre > 0 && cfg->max_num > 0, "ivx_create: nms_pre and max_num must be positive");
+  M_REQUIRE(indoor || (cfg->nms_pre > 0 && cfg->max_num > 0), "ivx_create: nms_pre and max_num must be positive");
   M_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 2 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "ivx_create: winograd_tile 0 | 2 | 4 | 6");
   ivx_model *m = new ivx_model();
   m->cfg = *cfg;
@@ -823,6 +954,7 @@ extern "C" int ivx_model_forward(ivx_model *m, const float *input, int32_t B, in
                                  ivx_stream_t stream) {
   M_TRY(check_img(m, B, V, H, W, "ivx_model_forward"));
   M_REQUIRE(input, "ivx_model_forward: null input");
+  M_REQUIRE(m->t_head >= 0, "ivx_model_forward: the handle holds an indoor neck (no anchor head); use ivx_model_forward_levels");
   Plan *pl; Range r;
   M_TRY(plan_forward(m, B, V, H, W, &pl, &r, (hipStream_t)stream));
   Bind bd;
@@ -916,6 +1048,7 @@ extern "C" int64_t ivx_neck3d_workspace_bytes(ivx_model *m, int32_t B) {
 extern "C" int ivx_neck3d_out_dims(ivx_model *m, int32_t B, int32_t *X, int32_t *Y, int32_t *C) {
   M_REQUIRE(m && X && Y && C && B > 0, "ivx_neck3d_out_dims: bad argument");
   Plan *pl;
+  M_REQUIRE(m->t_neck >= 0, "ivx_neck3d_out_dims: the handle holds an indoor neck; use ivx_neck3d_levels");
   M_TRY(plan_neck(m, B, &pl, nullptr));
   const TInfo &o = pl->t[m->t_neck];
   M_REQUIRE(o.W == 1, "the z axis must collapse to 1 (got %d); necks/imvoxelnet.py:119,150", o.W);
@@ -947,6 +1080,57 @@ extern "C" int ivx_neck3d_nuscenes_fwd(ivx_model *m, const float *volume, int32_
 }
 
 // Host-only: the anchor grid this handle uses for an (H, W) map (n = H*W*A rows of 7); for hosts that want to inspect it.
+// ---- indoor necks: three levels
+extern "C" int ivx_neck3d_levels(ivx_model *m, int32_t B, int32_t dims[3][4]) {
+  M_REQUIRE(m && dims && B > 0, "ivx_neck3d_levels: bad argument");
+  M_REQUIRE(m->t_levels.size() == 3, "ivx_neck3d_levels: the handle holds a stack neck; use ivx_neck3d_out_dims");
+  Plan *pl;
+  M_TRY(plan_neck(m, B, &pl, nullptr));
+  for (int l = 0; l < 3; ++l) {
+    const TInfo &o = pl->t[m->t_levels[l]];
+    dims[l][0] = o.D; dims[l][1] = o.H; dims[l][2] = o.W; dims[l][3] = o.C;
+  }
+  return IVX_OK;
+}
+
+static int neck_levels_fwd(ivx_model *m, int want_type, const float *volume, int32_t B, float *const out_levels[3], void *workspace,
+                           int64_t workspace_bytes, ivx_stream_t stream, const char *who) {
+  M_REQUIRE(m && volume && out_levels && out_levels[0] && out_levels[1] && out_levels[2] && B > 0, "%s: bad argument", who);
+  M_REQUIRE(m->cfg.neck_type == want_type, "%s: the handle holds another neck", who);
+  Plan *pl;
+  M_TRY(plan_neck(m, B, &pl, (hipStream_t)stream));
+  Bind bd;
+  bd.ext[m->t_volume] = (void *)volume;
+  for (int l = 0; l < 3; ++l) bd.ext[m->t_levels[l]] = out_levels[l];
+  return run_steps(m, *pl, {m->neck0, m->neck1}, bd, workspace, workspace_bytes, (hipStream_t)stream, who);
+}
+
+extern "C" int ivx_neck3d_fast_fwd(ivx_model *m, const float *volume, int32_t B, float *const out_levels[3], void *workspace,
+                                   int64_t workspace_bytes, ivx_stream_t stream) {
+  return neck_levels_fwd(m, IVX_NECK_FAST, volume, B, out_levels, workspace, workspace_bytes, stream, "ivx_neck3d_fast_fwd");
+}
+
+extern "C" int ivx_neck3d_unet_fwd(ivx_model *m, const float *volume, int32_t B, float *const out_levels[3], void *workspace,
+                                   int64_t workspace_bytes, ivx_stream_t stream) {
+  return neck_levels_fwd(m, IVX_NECK_UNET, volume, B, out_levels, workspace, workspace_bytes, stream, "ivx_neck3d_unet_fwd");
+}
+
+extern "C" int ivx_model_forward_levels(ivx_model *m, const float *input, int32_t B, int32_t V, int32_t H, int32_t W, const float *proj,
+                                        const float *new_origin, const int32_t *crop_hw, void *workspace, int64_t workspace_bytes,
+                                        float *const out_levels[3], uint8_t *out_valid, ivx_stream_t stream) {
+  M_TRY(check_img(m, B, V, H, W, "ivx_model_forward_levels"));
+  M_REQUIRE(input && out_levels && out_levels[0] && out_levels[1] && out_levels[2], "ivx_model_forward_levels: null argument");
+  M_REQUIRE(m->t_levels.size() == 3, "ivx_model_forward_levels: the handle holds a stack neck + anchor head; use ivx_model_forward");
+  Plan *pl; Range r;
+  M_TRY(plan_forward(m, B, V, H, W, &pl, &r, (hipStream_t)stream));
+  Bind bd;
+  bd.ext[m->cfg.with_trunk ? m->t_img : m->t_fpn0] = (void *)input;
+  if (out_valid) bd.ext[m->t_valid] = out_valid;
+  for (int l = 0; l < 3; ++l) bd.ext[m->t_levels[l]] = out_levels[l];
+  bd.proj = proj; bd.new_origin = new_origin; bd.crop = crop_hw; bd.V = V;
+  return run_steps(m, *pl, r, bd, workspace, workspace_bytes, (hipStream_t)stream, "ivx_model_forward_levels");
+}
+
 extern "C" int ivx_model_anchors(ivx_model *m, int32_t H, int32_t W, float *anchors_host, int64_t capacity) {
   M_REQUIRE(m && anchors_host && H > 0 && W > 0, "ivx_model_anchors: bad argument");
   std::vector<float> a;

@@ -180,7 +180,15 @@ class ImVoxelNet(nn.Module):
         if self._prepared_device is None and self._native is None and img.is_cuda:
             self.prepare(img.device)                             # first call: pack the weights (and build the native handle)
         H, W = img.shape[-2:]
-        if self._native is not None and H % 32 == 0 and W % 32 == 0 and img.dtype == torch.float32:
+        native_ok = self._native is not None and H % 32 == 0 and W % 32 == 0 and img.dtype == torch.float32
+        if native_ok and self._native.family == 'levels':
+            # indoor families: extract_feat (trunk + unprojection + neck_3d) in one native call, the anchor-free head on the op-level ABI
+            B, V = img.shape[0], img.shape[1]
+            proj, new_origin, crop = self._camera_setup(img_metas, 4, img.device)
+            levels, valid = self._native.forward_levels(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
+            dets = self.bbox_head.get_bboxes_cl(self.bbox_head.forward_cl(levels), valid, img_metas)
+            return [bbox3d2result(b, s, l) for b, s, l in dets]
+        if native_ok:
             # the whole device side in one native call (csrc/model.cpp); host work: the camera set-up, as the reference
             B, V = img.shape[0], img.shape[1]
             proj, new_origin, crop = self._camera_setup(img_metas, 4, img.device)

@@ -3,7 +3,9 @@
 For the anchor-head families (KITTI / nuScenes with a plain ResNet-50) the whole device side of
 ImVoxelNet.simple_test -- layer sequence, weight packing, Winograd / tile selection, workspace planning, execution --
 lives in libimvoxel_hip.so; this module only feeds it the reference state dict, the per-batch camera set-up and
-caller-owned buffers.  The layer-by-layer Python composition (backbones.py / necks3d.py / heads.py over the op-level
+caller-owned buffers.  For the indoor families (FastIndoorImVoxelNeck / ImVoxelNeck without a LayoutHead) the handle
+covers extract_feat (trunk + unprojection + neck_3d -> three levels); the anchor-free head and its tail stay on the
+op-level C-ABI.  The layer-by-layer Python composition (backbones.py / necks3d.py / heads.py over the op-level
 C-ABI) remains for the other configurations and as the cross-check: both run the same kernels with the same plans, so
 their results are bit-identical (tests/test_gpu_engine.py).
 """
@@ -19,44 +21,54 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def eligible(model):
-    """The native handle covers: plain ResNet-50 + FPN, Kitti / NuScenes stack neck, Anchor3DHead with one anchor
-    range, no LayoutHead, fp32."""
+def family(model):
+    """Which native handle covers this module: 'anchor' (plain ResNet-50 + FPN, Kitti / NuScenes stack neck, Anchor3DHead
+    with one anchor range: the whole simple_test device side), 'levels' (plain ResNet-50 + FPN + FastIndoorImVoxelNeck /
+    ImVoxelNeck, no LayoutHead: trunk + unprojection + neck_3d, the anchor-free head stays layer-by-layer), or None."""
     from .backbones import ResNet, FPN
     from .heads import Anchor3DHead
-    from .necks3d import KittiImVoxelNeck, NuScenesImVoxelNeck
+    from .necks3d import KittiImVoxelNeck, NuScenesImVoxelNeck, FastIndoorImVoxelNeck, ImVoxelNeck
     bb = model.backbone
-    if not (isinstance(bb, ResNet) and isinstance(model.neck, FPN) and isinstance(model.bbox_head, Anchor3DHead)):
-        return False
-    if not isinstance(model.neck_3d, (KittiImVoxelNeck, NuScenesImVoxelNeck)) or model.head_2d is not None:
-        return False
+    if not (isinstance(bb, ResNet) and isinstance(model.neck, FPN)) or model.head_2d is not None:
+        return None
     if any(getattr(blk, 'dcn', False) for i in range(bb.num_stages) for blk in getattr(bb, f'layer{i + 1}')):
-        return False
+        return None
     if bb.num_stages != 4 or [len(getattr(bb, f'layer{i + 1}')) for i in range(4)] != [3, 4, 6, 3] or tuple(bb.out_indices) != (0, 1, 2, 3):
-        return False
+        return None
+    n3 = model.neck_3d
+    if isinstance(n3, FastIndoorImVoxelNeck):
+        return 'levels' if n3.n_scales == 3 else None
+    if isinstance(n3, ImVoxelNeck):
+        return 'levels' if len(n3.model.channels) == 4 else None
+    if not isinstance(n3, (KittiImVoxelNeck, NuScenesImVoxelNeck)) or not isinstance(model.bbox_head, Anchor3DHead):
+        return None
     g = model.bbox_head.anchor_generator
-    return len(g.ranges) == 1 and len(g.sizes) <= 4 and len(g.rotations) <= 4 and not g.custom_values and g.scales == [1]
+    ok = len(g.ranges) == 1 and len(g.sizes) <= 4 and len(g.rotations) <= 4 and not g.custom_values and g.scales == [1]
+    return 'anchor' if ok else None
 
 
-class NativeModel:
-    """ivx_model handle built from an ImVoxelNet module (its config and its state dict)."""
+def eligible(model):
+    return family(model) is not None
 
-    def __init__(self, model, device, with_trunk=True, winograd=None, winograd_tile=None, graph=None):
-        from .conv import FusedConv
-        from .necks3d import KittiImVoxelNeck
-        if not eligible(model):
-            raise NotImplementedError('the native model handle covers ResNet-50 + FPN + Kitti/NuScenes neck + Anchor3DHead (fp32)')
-        self.device = torch.device(device)
-        L = self.L = _lib.lib()
-        head, tc = model.bbox_head, model.bbox_head.test_cfg
-        g = head.anchor_generator
-        cfg = ModelCfg()
-        cfg.neck_type = 0 if isinstance(model.neck_3d, KittiImVoxelNeck) else 1
-        cfg.with_trunk = int(bool(with_trunk))
-        cfg.fpn_channels = model.neck.out_channels
+
+def model_cfg(model, with_trunk=True, winograd=None, winograd_tile=None):
+    """ivx_model_cfg of an ImVoxelNet module (host-only: no device or library call)."""
+    from .conv import FusedConv
+    from .necks3d import KittiImVoxelNeck, FastIndoorImVoxelNeck, BasicBlock3d
+    fam = family(model)
+    if fam is None:
+        raise NotImplementedError('the native model handle covers plain ResNet-50 + FPN with a Kitti / NuScenes neck + Anchor3DHead, or '
+                                  'with FastIndoorImVoxelNeck / ImVoxelNeck (no LayoutHead), fp32')
+    head, n3 = model.bbox_head, model.neck_3d
+    cfg = ModelCfg()
+    cfg.with_trunk = int(bool(with_trunk))
+    cfg.fpn_channels = model.neck.out_channels
+    cfg.n_voxels[:] = list(model.n_voxels)
+    cfg.voxel_size[:] = list(model.voxel_size)
+    if fam == 'anchor':
+        tc, g = head.test_cfg, head.anchor_generator
+        cfg.neck_type = 0 if isinstance(n3, KittiImVoxelNeck) else 1
         cfg.neck_out_channels = head.in_channels
-        cfg.n_voxels[:] = list(model.n_voxels)
-        cfg.voxel_size[:] = list(model.voxel_size)
         cfg.num_classes = head.num_classes
         cfg.n_sizes, cfg.n_rotations = len(g.sizes), len(g.rotations)
         cfg.anchor_range[:] = [float(v) for v in g.ranges[0]]
@@ -67,8 +79,31 @@ class NativeModel:
         cfg.use_rotate_nms = int(bool(tc['use_rotate_nms']))
         cfg.score_thr, cfg.nms_thr = float(tc.get('score_thr', 0)), float(tc['nms_thr'])
         cfg.dir_offset, cfg.dir_limit_offset = float(head.dir_offset), float(head.dir_limit_offset)
-        cfg.winograd = int(FusedConv.winograd if winograd is None else winograd)
-        cfg.winograd_tile = int(FusedConv.winograd_tile if winograd_tile is None else winograd_tile)
+    elif isinstance(n3, FastIndoorImVoxelNeck):
+        cfg.neck_type = 2
+        cfg.neck_out_channels = n3.out_block_0[0].weight.shape[0]
+        cfg.fast_n_blocks[:] = [len(getattr(n3, f'down_layer_{i}')) for i in range(3)]
+    else:
+        cfg.neck_type = 3
+        cfg.neck_out_channels = n3.conv_blocks[0][0].weight.shape[0]
+        cfg.unet_channels[:] = list(n3.model.channels)
+        cfg.unet_down_layers[:] = [sum(isinstance(b, BasicBlock3d) for b in layer) for layer in n3.model.layers_down]
+        cfg.unet_up_layers[:] = [len(seq) for seq in n3.model.layers_up_res]
+    cfg.winograd = int(FusedConv.winograd if winograd is None else winograd)
+    cfg.winograd_tile = int(FusedConv.winograd_tile if winograd_tile is None else winograd_tile)
+    return cfg
+
+
+class NativeModel:
+    """ivx_model handle built from an ImVoxelNet module (its config and its state dict)."""
+
+    def __init__(self, model, device, with_trunk=True, winograd=None, winograd_tile=None, graph=None):
+        self.family = family(model)
+        cfg = model_cfg(model, with_trunk, winograd, winograd_tile)
+        self.device = torch.device(device)
+        L = self.L = _lib.lib()
+        head = model.bbox_head
+        g = getattr(head, 'anchor_generator', None)
         import os
         # hipGraph replay inside the handle (one graph per set of caller buffers): opt-in (IVX_NATIVE_GRAPH=1).  Measured on
         # KITTI batch 4: the handle issues its ~150 launches from C++ fast enough that the replay gains nothing (28.07 vs 27.86 ms
@@ -77,6 +112,10 @@ class NativeModel:
         cfg.use_graph = int(self.graph)
         self.cfg = cfg
         self.max_num, self.n_voxels = cfg.max_num, tuple(model.n_voxels)
+        if graph and self.family != 'anchor':
+            raise NotImplementedError('graph replay is wired for ivx_model_forward (anchor-head families) only')
+        if self.family != 'anchor':
+            self.graph, cfg.use_graph = False, 0
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(L.ivx_create(C.byref(cfg), C.byref(h)), 'ivx_create')
@@ -90,13 +129,18 @@ class NativeModel:
                 shape = (C.c_int64 * max(a.dim(), 1))(*a.shape)
                 check(L.ivx_weights_load(h, key.encode(), C.c_void_p(a.data_ptr()), shape, a.dim()), f'ivx_weights_load({key})')
             check(L.ivx_weights_finalize(h, _stream()), 'ivx_weights_finalize')
-            # the anchor grid: the generator's own output (same torch ops as the reference's CPU path), not the built-in one
-            X, Y, Cn = C.c_int32(), C.c_int32(), C.c_int32()
-            check(L.ivx_neck3d_out_dims(h, 1, C.byref(X), C.byref(Y), C.byref(Cn)), 'ivx_neck3d_out_dims')
-            self.grid_hw = (Y.value, X.value)                  # the reference's (H, W) = (Y', X') (necks/imvoxelnet.py:120)
-            anc = g.grid_anchors([self.grid_hw], device='cpu')[0].reshape(-1, 7).contiguous().float()
-            shape = (C.c_int64 * 2)(*anc.shape)
-            check(L.ivx_weights_load(h, b'anchors', C.c_void_p(anc.data_ptr()), shape, 2), 'ivx_weights_load(anchors)')
+            if self.family == 'anchor':
+                # the anchor grid: the generator's own output (same torch ops as the reference's CPU path), not the built-in one
+                X, Y, Cn = C.c_int32(), C.c_int32(), C.c_int32()
+                check(L.ivx_neck3d_out_dims(h, 1, C.byref(X), C.byref(Y), C.byref(Cn)), 'ivx_neck3d_out_dims')
+                self.grid_hw = (Y.value, X.value)                  # the reference's (H, W) = (Y', X') (necks/imvoxelnet.py:120)
+                anc = g.grid_anchors([self.grid_hw], device='cpu')[0].reshape(-1, 7).contiguous().float()
+                shape = (C.c_int64 * 2)(*anc.shape)
+                check(L.ivx_weights_load(h, b'anchors', C.c_void_p(anc.data_ptr()), shape, 2), 'ivx_weights_load(anchors)')
+            else:
+                dims = ((C.c_int32 * 4) * 3)()
+                check(L.ivx_neck3d_levels(h, 1, dims), 'ivx_neck3d_levels')
+                self.level_dims = [tuple(d) for d in dims]         # (X, Y, Z, C) per level, finest first
         self._ws = {}
         self._static = {}          # graph mode: stable input / output buffers per shape
         self._gstream = torch.cuda.Stream(device=self.device) if self.graph else None   # the default stream cannot be captured
@@ -166,6 +210,40 @@ class NativeModel:
                 call(xs, ps, os_, cs, out, C.c_void_p(self._gstream.cuda_stream))
             cur.wait_stream(self._gstream)
         return (out[0], out[1], out[2], out[3], out[4].view(torch.bool)) if want_valid else out[:4]
+
+    def _level_buffers(self, B, dev):
+        outs = [torch.empty((B, X, Y, Z, Cn), device=dev, dtype=torch.float32) for X, Y, Z, Cn in self.level_dims]
+        return outs, (C.c_void_p * 3)(*[o.data_ptr() for o in outs])
+
+    def forward_levels(self, x, B, V, H, W, proj, new_origin, crop_hw):
+        """Indoor families: x as for forward -> ([level0, level1, level2] channels-last [B,X_l,Y_l,Z_l,Cout] finest first,
+        valid bool [B,X,Y,Z]) -- extract_feat of detectors/imvoxelnet.py:43-88 in one native call."""
+        L = self.L
+        for t, nm in ((x, 'input'), (proj, 'proj'), (new_origin, 'new_origin')):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise ValueError(f'{nm} must be a contiguous float32 device tensor')
+        n = L.ivx_model_workspace_bytes(self.h, B, V, H, W)
+        if n < 0:
+            check(-1, 'ivx_model_workspace_bytes')
+        ws = self._workspace('fwd', n)
+        outs, ptrs = self._level_buffers(B, x.device)
+        valid = torch.empty((B,) + self.n_voxels, device=x.device, dtype=torch.uint8)
+        check(L.ivx_model_forward_levels(self.h, C.c_void_p(x.data_ptr()), B, V, H, W, C.c_void_p(proj.data_ptr()), C.c_void_p(new_origin.data_ptr()),
+                                         C.c_void_p(crop_hw.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), ptrs, C.c_void_p(valid.data_ptr()),
+                                         _stream()), 'ivx_model_forward_levels')
+        return outs, valid.view(torch.bool)
+
+    def neck3d_levels(self, volume):
+        """volume [B,X,Y,Z,Cf] -> the three neck levels (channels-last, finest first)."""
+        B = volume.shape[0]
+        n = self.L.ivx_neck3d_workspace_bytes(self.h, B)
+        if n < 0:
+            check(-1, 'ivx_neck3d_workspace_bytes')
+        ws = self._workspace('neck', n)
+        outs, ptrs = self._level_buffers(B, volume.device)
+        fn = self.L.ivx_neck3d_fast_fwd if self.cfg.neck_type == 2 else self.L.ivx_neck3d_unet_fwd
+        check(fn(self.h, C.c_void_p(volume.data_ptr()), B, ptrs, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), 'ivx_neck3d_levels_fwd')
+        return outs
 
     # ------------------------------------------------------------------ sub-paths
     def backbone_fpn(self, img):

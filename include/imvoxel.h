@@ -363,9 +363,11 @@ int ivx_kitti_fused_statistics(const double *const *ov_ptrs, int32_t n_img, cons
  * One handle per device and per host thread; calls are asynchronous on `stream`.                                  */
 #define IVX_NECK_KITTI 0
 #define IVX_NECK_NUSCENES 1
+#define IVX_NECK_FAST 2      /* FastIndoorImVoxelNeck (necks/imvoxelnet.py:8-67): the handle ends at the 3 neck levels */
+#define IVX_NECK_UNET 3      /* ImVoxelNeck = Atlas EncoderDecoder + conv blocks (necks/imvoxelnet.py:70-91, 297-372) */
 typedef struct ivx_model ivx_model;
 typedef struct ivx_model_cfg {
-  int32_t neck_type;          /* IVX_NECK_KITTI | IVX_NECK_NUSCENES */
+  int32_t neck_type;          /* IVX_NECK_KITTI | IVX_NECK_NUSCENES | IVX_NECK_FAST | IVX_NECK_UNET */
   int32_t with_trunk;         /* 1: ResNet-50 + FPN inside the handle (input = image); 0: input = FPN level-0 map */
   int32_t fpn_channels;       /* FPN out_channels = neck_3d in_channels (64 in the reference configs) */
   int32_t neck_out_channels;  /* neck_3d out_channels = head in_channels (256) */
@@ -384,6 +386,11 @@ typedef struct ivx_model_cfg {
   int32_t use_graph;          /* 1: ivx_model_forward records its launches into a hipGraph per distinct set of caller buffers
                                  (1st call eager, 2nd captured, then one hipGraphLaunch per call); needs a non-NULL stream and
                                  stable buffers -- a host that passes new pointers every call gains nothing */
+  /* indoor necks (zero for the outdoor ones; the anchor / test_cfg fields above are ignored for them) */
+  int32_t fast_n_blocks[3];        /* FastIndoorImVoxelNeck(n_blocks) */
+  int32_t unet_channels[4];        /* ImVoxelNeck(channels); [0] = fpn_channels */
+  int32_t unet_down_layers[4];     /* ImVoxelNeck(n_blocks, "down"), e.g. 1,2,3,4 */
+  int32_t unet_up_layers[3];       /* ImVoxelNeck(n_blocks, "up") in decode order (coarse first), e.g. 3,2,1 */
 } ivx_model_cfg;
 
 int ivx_create(const ivx_model_cfg *cfg, ivx_model **out);
@@ -409,6 +416,22 @@ int ivx_neck3d_kitti_fwd(ivx_model *m, const float *volume, int32_t B, float *ou
                          ivx_stream_t stream);
 int ivx_neck3d_nuscenes_fwd(ivx_model *m, const float *volume, int32_t B, float *out, void *workspace,
                             int64_t workspace_bytes, ivx_stream_t stream);
+/* Indoor necks: three output levels, finest first, channels-last [B, X_l, Y_l, Z_l, Cout] (neck_3d(x) of
+ * detectors/imvoxelnet.py:79 for FastIndoorImVoxelNeck / ImVoxelNeck).  dims[l] = {X, Y, Z, C} of level l.
+ * State-dict keys: neck_3d.down_layer_{i}.{j}.{conv1,norm1,conv2,norm2,downsample.0,downsample.1}.*,
+ * neck_3d.up_block_{1,2}.{0,1,3,4}.*, neck_3d.out_block_{i}.{0,1}.* (fast); neck_3d.model.layers_down.*,
+ * neck_3d.model.proj.{k}.{conv,norm}.*, neck_3d.model.layers_up_conv.{k}.weight, neck_3d.model.layers_up_res.{k}.{j}.*,
+ * neck_3d.conv_blocks.{l}.{0,1}.* (unet). */
+int ivx_neck3d_levels(ivx_model *m, int32_t B, int32_t dims[3][4]);
+int ivx_neck3d_fast_fwd(ivx_model *m, const float *volume, int32_t B, float *const out_levels[3], void *workspace,
+                        int64_t workspace_bytes, ivx_stream_t stream);
+int ivx_neck3d_unet_fwd(ivx_model *m, const float *volume, int32_t B, float *const out_levels[3], void *workspace,
+                        int64_t workspace_bytes, ivx_stream_t stream);
+/* Whole indoor path up to the head: backbone + FPN level 0 + unprojection + neck_3d (extract_feat,
+ * detectors/imvoxelnet.py:43-88).  Arguments as ivx_model_forward; workspace from ivx_model_workspace_bytes. */
+int ivx_model_forward_levels(ivx_model *m, const float *input, int32_t B, int32_t V, int32_t H, int32_t W, const float *proj,
+                             const float *new_origin, const int32_t *crop_hw, void *workspace, int64_t workspace_bytes,
+                             float *const out_levels[3], uint8_t *out_valid, ivx_stream_t stream);
 /* Optional stage timing (measurement only): while enabled, every launch group of the forward calls is bracketed by a pair
  * of HIP events on the caller's stream; the Winograd layers run as their three stages so each is timed.  stage: 0 direct
  * conv, 1 Winograd input transform, 2 grouped GEMM, 3 output transform, 4 unprojection, 5 anchor tail.  flops = FLOPs the

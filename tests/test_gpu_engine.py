@@ -187,3 +187,45 @@ def test_c_program_e2e_small_without_python(ia):
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'C e2e_small OK' in out.stdout
+
+
+@pytest.mark.parametrize('cfg_name,views', [('scannet_fast', 5), ('sunrgbd_fast', 1), ('scannet_v1', 4)])
+def test_native_levels_equal_layerwise_indoor(ia, cfg_name, views):
+    """Indoor families on the handle (IVX_NECK_FAST / IVX_NECK_UNET): ivx_model_forward_levels == features_2d_cl -> lift_cl
+    -> neck_3d.forward_cl bit for bit on every level and on the valid mask, ivx_neck3d_{fast,unet}_fwd == neck_3d.forward_cl,
+    and simple_test (which routes extract_feat through the handle) returns the layer-by-layer detections."""
+    mcfg = getattr(kc, f'{cfg_name}_model_cfg')()
+    tcfg = dict(getattr(kc, f'{cfg_name.upper()}_TEST_CFG'))
+    model = ia.build_detector(mcfg, test_cfg=tcfg)
+    ia.randomize_(model, 33)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        model.bbox_head.cls_conv.weight.normal_(0, 0.01, generator=g)
+        model.bbox_head.cls_conv.bias.fill_(-2.0)
+        model.bbox_head.centerness_conv.weight.normal_(0, 0.005, generator=g)
+        model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)       # keeps exp(reg) finite: NaN != NaN would fail torch.equal
+    model.prepare(torch.device('cuda'))
+    assert model._native is not None and model._native.family == 'levels'
+    B, hw = 1, (480, 640)
+    img = torch.randn(B, views, 3, *hw, generator=torch.Generator().manual_seed(9)).cuda()
+    box_type = ia.DepthInstance3DBoxes
+    metas = [kc.indoor_meta(views, img_hw=hw, box_type=box_type)]
+    p0 = model.features_2d_cl(img)
+    vol, valid = model.lift_cl(p0, metas)
+    ref_levels = model.neck_3d.forward_cl(vol)
+    proj, new_origin, crop = model._camera_setup(metas, 4, img.device)
+    levels, ok = model._native.forward_levels(img.reshape(B * views, 3, *hw).contiguous(), B, views, hw[0], hw[1], proj, new_origin, crop)
+    assert torch.equal(ok, valid)
+    assert len(levels) == len(ref_levels) == 3
+    for l, (a, b) in enumerate(zip(levels, ref_levels)):
+        assert a.shape == b.shape, (l, a.shape, b.shape)
+        assert torch.equal(a, b), f'level {l}: {(a != b).sum().item()} of {a.numel()} differ, max {(a - b).abs().max().item():.3e}'
+    for l, (a, b) in enumerate(zip(model._native.neck3d_levels(vol), ref_levels)):
+        assert torch.equal(a, b), f'neck-only level {l} differs'
+    ref = model.detect_indoor_cl(vol, valid, metas)
+    res = model.simple_test(img, metas)
+    for (rb, rs, rl), r in zip(ref, res):
+        assert torch.equal(r['scores_3d'], rs.cpu()) and torch.equal(r['labels_3d'], rl.cpu()) and torch.equal(r['boxes_3d'].tensor, rb.tensor.cpu())
+    # the anchor entry points refuse an indoor handle, loudly
+    with pytest.raises(ValueError, match='ivx_model_forward_levels'):
+        model._native.forward(img.reshape(B * views, 3, *hw).contiguous(), B, views, hw[0], hw[1], proj, new_origin, crop)

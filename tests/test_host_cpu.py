@@ -595,6 +595,38 @@ def test_model_cabi_host_side_without_gpu():
         assert np.array_equal(out, ref), (out, ref)
 
 
+@pytest.mark.parametrize('cfg_name', ['scannet_fast', 'sunrgbd_fast', 'scannet_v1'])
+def test_indoor_handle_expects_the_reference_state_dict_keys(cfg_name):
+    """IVX_NECK_FAST / IVX_NECK_UNET handles (csrc/model.cpp build_neck_fast / build_neck_unet) name their parameters as the
+    reference checkpoints do: staged with the module's full state dict minus ONE tensor per sub-module family, the
+    completeness check (which runs before any device work, so also on a box without a GPU) lists exactly the withheld keys."""
+    import ctypes as C
+    import imvoxelnet_amd as ia
+    import kitti_cfg as kc
+    from imvoxelnet_amd import _lib, engine
+    model = ia.build_detector(getattr(kc, f'{cfg_name}_model_cfg')(), test_cfg=dict(getattr(kc, f'{cfg_name.upper()}_TEST_CFG')))
+    assert engine.family(model) == 'levels'
+    sd = {k: v for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    neck_keys = sorted(k for k in sd if k.startswith('neck_3d.'))
+    withheld = {neck_keys[0], neck_keys[len(neck_keys) // 2], neck_keys[-1], 'backbone.layer3.4.bn2.running_var', 'neck.lateral_convs.2.conv.bias'}
+    # build the cfg the way engine.NativeModel does, without touching the device
+    L = _lib.lib()
+    cfg = engine.model_cfg(model, with_trunk=True)
+    h = C.c_void_p()
+    assert L.ivx_create(C.byref(cfg), C.byref(h)) == 0, L.ivx_last_error()
+    for k, t in sd.items():
+        if k in withheld:
+            continue
+        a = t.detach().float().contiguous()
+        shape = (C.c_int64 * max(a.dim(), 1))(*a.shape)
+        assert L.ivx_weights_load(h, k.encode(), C.c_void_p(a.data_ptr()), shape, a.dim()) == 0
+    assert L.ivx_weights_finalize(h, None) != 0
+    msg = L.ivx_last_error().decode()
+    listed = set(msg.split('missing state-dict keys:')[1].split())
+    assert listed == withheld, (listed ^ withheld, msg)
+    assert L.ivx_destroy(h) == 0
+
+
 def test_input_side_adapters_match_reference_dataset_code():
     """the calibration -> lidar2img adapters and the SetOrigin transforms against the reference's own
     get_data_info bodies / pipeline classes run on synthetic calibration records (tests/golden/input_side.npz,
