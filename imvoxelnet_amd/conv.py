@@ -198,7 +198,10 @@ class FusedConv:
             y = self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
             e1.record()
             FusedConv.trace.append(('direct', e0, e1, 2.0 * y.numel() * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
-                                    if self.out_mode == 0 else 2.0 * x.numel() * self.cout, 0.0, x.shape[1] > 1 and x.shape[3] > 1, self._describe(x, 0)))
+                                    if self.out_mode == 0 else 2.0 * x.numel() * self.cout,
+                                    float(x.numel() * x.element_size() + y.numel() * y.element_size() + self.w.numel() * self.w.element_size()
+                                          + (res.numel() * res.element_size() if res is not None else 0)),     # algorithmic bytes
+                                    x.shape[1] > 1 and x.shape[3] > 1, self._describe(x, 0)))
             return y
         return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
 

@@ -200,6 +200,70 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams &p, f32x16 (
   }
 }
 
+// bf16-output variant of the wide epilogue (Cout % 8 == 0).  The one-channel-per-lane epilogue stores 2 bytes per lane --
+// sub-dword writes, which the memory side handles as read-modify-write: the Cout-expanding 1x1 layers of the bf16 trunk ran
+// at ~1.1 TB/s of algorithmic traffic.  Here NJ (2 when TN is even, else 1) 32x32 tiles are transposed through the wave's LDS
+// slice so that a lane owns 8 consecutive channels of a row: the tile pair leaves as 16-byte stores (8 bf16), 8 lanes to a
+// 128-byte row segment; the residual arrives as 16-byte loads.  Rounding is the same round-to-nearest-even conversion.
+template <int TM, int TN, int NJ>
+__device__ __forceinline__ void conv_epilogue_wide_bf16(const ConvParams &p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
+                                                        int lane, float *stage, size_t obase) {
+  static_assert(TN % NJ == 0, "tile pairs");
+  constexpr int LPR = 4 * NJ;        // lanes per row: 8 channels each over NJ*32 channels
+  constexpr int RPP = 64 / LPR;      // rows per pass
+  const int col_l = lane & 31, hh = lane >> 5;
+  const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
+  const float *rd = stage + (c8 >> 5) * 1024 + (c8 & 31);
+  __bf16 *outp = reinterpret_cast<__bf16 *>(p.out);
+  const __bf16 *resp = reinterpret_cast<const __bf16 *>(p.res);
+#pragma unroll
+  for (int j = 0; j < TN; j += NJ) {
+    const int nb = n0 + (wc * TN + j) * 32 + c8;
+    const bool nok = nb < p.Cout;                        // Cout % 8 == 0: an 8-channel chunk is inside or outside as a whole
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sf0 = {0.f, 0.f, 0.f, 0.f}, sf1 = sf0;
+    if (nok && p.scale) { sc0 = *reinterpret_cast<const f32x4 *>(p.scale + nb); sc1 = *reinterpret_cast<const f32x4 *>(p.scale + nb + 4); }
+    if (nok && p.shift) { sf0 = *reinterpret_cast<const f32x4 *>(p.shift + nb); sf1 = *reinterpret_cast<const f32x4 *>(p.shift + nb + 4); }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[jj * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col_l] = acc[i][j + jj][r];
+      const int mb = m0 + (wr * TM + i) * 32 + rrow;
+#pragma unroll
+      for (int q = 0; q < 32 / RPP; ++q) {
+        f32x4 v0 = *reinterpret_cast<const f32x4 *>(rd + (rrow + RPP * q) * 32);
+        f32x4 v1 = *reinterpret_cast<const f32x4 *>(rd + (rrow + RPP * q) * 32 + 4);
+        const int m = mb + RPP * q;
+        if (m < p.M && nok) {
+          const size_t o = (size_t)m * p.Cout + nb;
+          v0 = v0 * sc0 + sf0;
+          v1 = v1 * sc1 + sf1;
+          f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+          if (p.res_mode) {
+            const size_t ro = p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + nb : o;
+            const bf16x8 rb = *reinterpret_cast<const bf16x8 *>(resp + ro);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { r0[e] = (float)rb[e]; r1[e] = (float)rb[e + 4]; }
+          }
+          if (p.res_mode && !p.res_after_act) { v0 += r0; v1 += r1; }
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = v0[e] > 0.f ? v0[e] : 0.f; v1[e] = v1[e] > 0.f ? v1[e] : 0.f; }
+          }
+          if (p.res_mode && p.res_after_act) { v0 += r0; v1 += r1; }
+          v0 *= p.post_scale;
+          v1 *= p.post_scale;
+          bf16x8 ob;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ob[e] = (__bf16)v0[e]; ob[e + 4] = (__bf16)v1[e]; }
+          *reinterpret_cast<bf16x8 *>(outp + obase + o) = ob;
+        }
+      }
+    }
+  }
+}
+
 template <int TM, int TN, int WR, int WC>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
@@ -675,6 +739,12 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
     conv_epilogue_wide<TM, TN>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, gz * (size_t)p.g_out);
     return;
   }
+  if (p.out_mode == 0 && p.out_bf16 && (p.Cout & 7) == 0 && !p.narrow_epilogue) {
+    constexpr int NJ = (TN % 2 == 0 && sizeof(smem) >= (size_t)NT / 64 * 8192) ? 2 : 1;
+    static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096 * NJ, "staging LDS for the transposed bf16 epilogue");
+    conv_epilogue_wide_bf16<TM, TN, NJ>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024 * NJ, gz * (size_t)p.g_out);
+    return;
+  }
   conv_epilogue<TM, TN>(p, acc, m0, n0, wr, wc, lane, gz * (size_t)p.g_out);
 }
 
@@ -962,6 +1032,21 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
       pl.cfg = dma_ok ? (p.K <= 640 ? 47 : 46) : 6;
       small = true;
     }
+  }
+  if (p.in_bf16 && g_tile_override == 0 && dma_ok && p.Cout > 32 && g_plan_mode == 0) {
+    // bf16: interleaved A/B over the layers of the 2-D trunk at 50 views (tools/conv_ab.py, profiles/r02_conv_ab_bf16.log).
+    // At 8x the MFMA rate every 1x1 layer and most 3x3 layers are bound by HBM / staging latency, and what matters is how
+    // many workgroups a CU holds to overlap one tile's epilogue with another's loads: 128 x 128 with 64-byte LDS rows at four
+    // per CU (74) is the best or within 5 % of it on all of them (the 1 / 2 per CU of 82 / 81 / 61 lose 20-40 % on short K);
+    // Cout <= 64 takes 128 x 64 (63).  The 8- / 16-wave tiles keep the long-K layers with many tiles (the 3-D necks), and
+    // layers that would leave most workgroup slots empty keep the 64 x 64 + split-K path below.
+    const long long t128 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    if (p.Cout <= 64) {
+      if ((long long)((p.M + 127) / 128) * 2 > 256 * 3) pl.cfg = 63;
+    } else if (t128 * 2 > 1024 && !(t128 >= 2500 && p.K >= 1024)) {
+      pl.cfg = 74;
+    }
+    if (pl.cfg == 63 || pl.cfg == 74) small = false;
   }
   if (p.in_bf16 && pl.cfg >= 41 && pl.cfg <= 57) {
     // same tile, bf16 instantiation -- except for the big layers: at 8x the MFMA rate the kernel is bound by the

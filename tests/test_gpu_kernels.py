@@ -156,6 +156,14 @@ def test_conv_bf16_storage(ia, case):
             assert_close(name + ' f32-out mfma-vs-torch', uncl(y), full, 2e-4, 2e-4)
             assert_close(name + ' f32-out mfma-vs-naive', uncl(y), uncl(yn), 2e-4, 1e-4)
         assert torch.equal(y, fc(xc, res=rr))
+        # the transposed wide-store epilogue (16-byte bf16 stores) == the one-channel-per-lane epilogue, bit for bit
+        from imvoxelnet_amd import _lib
+        _lib.lib().ivx_conv_set_epilogue_mode(1)
+        try:
+            y_narrow = fc(xc, res=rr)
+        finally:
+            _lib.lib().ivx_conv_set_epilogue_mode(0)
+        assert torch.equal(y, y_narrow)
 
 
 def test_conv_bf16_tile_variants(ia):

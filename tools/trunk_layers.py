@@ -20,13 +20,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', default='scannet_fast')
     ap.add_argument('--top', type=int, default=30)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     a = ap.parse_args()
     cfg, shape = {'kitti': (kc.kitti_model_cfg(), (4, 1, 3, 384, 1280)), 'scannet_fast': (kc.scannet_fast_model_cfg(), (1, 50, 3, 480, 640)),
                   'scannet_v1': (kc.scannet_v1_model_cfg(), (1, 50, 3, 480, 640))}[a.config]
     model = ia.build_detector(cfg, test_cfg=dict(nms_pre=100, max_num=50, use_rotate_nms=True, nms_thr=.1, score_thr=.1, iou_thr=.25))
     ia.randomize_(model, 0)
-    model.backbone.prepare(torch.device('cuda'))
-    model.neck.prepare(torch.device('cuda'))
+    from imvoxelnet_amd.conv import storage_dtype
+    with storage_dtype(torch.bfloat16 if a.dtype == 'bf16' else torch.float32):
+        model.backbone.prepare(torch.device('cuda'))
+        model.neck.prepare(torch.device('cuda'))
     img = torch.randn(*shape, generator=torch.Generator().manual_seed(1)).cuda()
     for _ in range(2):
         model.features_2d_cl(img)
@@ -39,17 +42,20 @@ def main():
         tr, FusedConv.trace = FusedConv.trace, None
         for t in tr:
             key = (t[6], t[0])
-            d = agg.setdefault(key, [0, 0.0, 0.0])
+            d = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += t[1].elapsed_time(t[2])
             d[2] += t[3]
-    rows = [(k, v[0] / reps, v[1] / reps, v[2] / reps) for k, v in agg.items()]
+            d[3] += t[4]
+    rows = [(k, v[0] / reps, v[1] / reps, v[2] / reps, v[3] / reps) for k, v in agg.items()]
     total = sum(r[2] for r in rows)
-    print(f'# {a.config}: trunk launches per step, {total:.3f} ms of conv-stage time per step, executed {sum(r[3] for r in rows) / 1e9:.1f} GFLOP')
-    print('| layer shape | stage | launches | ms/step | % | TFLOP/s executed |')
-    print('|---|---|---|---|---|---|')
-    for (desc, kind), n, ms, fl in sorted(rows, key=lambda r: -r[2])[:a.top]:
-        print(f'| {desc} | {kind} | {n:.0f} | {ms:.3f} | {100 * ms / total:.1f} | {fl / ms / 1e9 if fl else 0:.1f} |')
+    floor = sum(max(r[4] / 5.5e12, r[3] / ((1500e12 if a.dtype == 'bf16' else 140e12))) for r in rows) * 1e3
+    print(f'# floor at 5.5 TB/s / {"1500" if a.dtype == "bf16" else "140"} TFLOP/s per launch: {floor:.3f} ms; algorithmic bytes {sum(r[4] for r in rows) / 1e9:.2f} GB')
+    print(f'# {a.config} {a.dtype}: trunk launches per step, {total:.3f} ms of conv-stage time per step, executed {sum(r[3] for r in rows) / 1e9:.1f} GFLOP')
+    print('| layer shape | stage | launches | ms/step | % | TFLOP/s executed | GB/s algorithmic |')
+    print('|---|---|---|---|---|---|---|')
+    for (desc, kind), n, ms, fl, by in sorted(rows, key=lambda r: -r[2])[:a.top]:
+        print(f'| {desc} | {kind} | {n:.0f} | {ms:.3f} | {100 * ms / total:.1f} | {fl / ms / 1e9 if fl else 0:.1f} | {by / ms / 1e6:.0f} |')
 
 
 if __name__ == '__main__':
