@@ -1004,9 +1004,14 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     // left the mid-sized layers of the 2-D trunk -- 900 .. 2500 big tiles, i.e. 0.9 .. 2.4 rounds of 1024 slots -- on 64 x 64
     // tiles at ~0.8 of the big tile's rate, or on a half-empty second round; 128 x 64 at five per CU sits in between.
     // Efficiencies are the measured per-tile rates on long layers relative to 128 x 128 (141 / 131 / 113 TFLOP/s).
+    // Short K (the 1x1 layers up to 512 input channels): one or two K slabs per tile, the tile's time is its epilogue and the
+    // latency of its loads, and six 128 x 64 workgroups per CU (56) overlap those better than four 128 x 128: interleaved A/B
+    // at 50 views (tools/conv_ab.py, profiles/r02_conv_ab_f32.log) 64->256 0.547 vs 0.640 ms, 128->512 0.378 vs 0.417,
+    // 256->1024 0.293 vs 0.310, 512->2048 0.269 vs 0.290; from K = 1024 on the 128 x 128 tile is ahead again.
+    const bool short_k = p.K <= 512;
     const int c64 = p.K <= 640 ? 47 : 46;
-    const int cand[3] = {54, 49, c64};
-    const double eff[3] = {1.00, 0.93, 0.80};
+    const int cand[3] = {54, short_k ? 56 : 49, c64};
+    const double eff[3] = {short_k ? 0.93 : 1.00, short_k ? 1.00 : 0.93, short_k ? 0.85 : 0.80};
     double best = -1.0;
     for (int i = 0; i < 3; ++i) {
       TileInfo ti;

@@ -482,13 +482,22 @@ def boxes_overlap_bev(a, b, iou=False):
     return out
 
 
-def aligned_3d_nms_dev(boxes, scores, classes, thresh):
+def aligned_3d_nms_dev(boxes, scores, classes, thresh, single_workgroup=False):
     _chk(boxes, 'boxes')
     _chk(scores, 'scores')
     _chk(classes, 'classes', torch.int64)
     n = boxes.shape[0]
     pick = torch.empty((max(n, 1),), device=boxes.device, dtype=torch.int64)
     num = torch.empty((1,), device=boxes.device, dtype=torch.int32)
-    check(_lib.lib().ivx_aligned_3d_nms(_ptr(boxes), _ptr(scores), _ptr(classes), n, float(thresh), _ptr(pick), _ptr(num),
-                                        _stream()), 'ivx_aligned_3d_nms')
+    L = _lib.lib()
+    if single_workgroup:
+        check(L.ivx_aligned_3d_nms(_ptr(boxes), _ptr(scores), _ptr(classes), n, float(thresh), _ptr(pick), _ptr(num), _stream()),
+              'ivx_aligned_3d_nms')
+        return pick, num
+    wsb = L.ivx_aligned_3d_nms_workspace_bytes(n)
+    if wsb < 0:
+        raise ValueError(f'ivx_aligned_3d_nms_ws: at most 4096 boxes (got {n})')
+    ws = torch.empty((wsb,), device=boxes.device, dtype=torch.uint8)
+    check(L.ivx_aligned_3d_nms_ws(_ptr(boxes), _ptr(scores), _ptr(classes), n, float(thresh), _ptr(ws), wsb, _ptr(pick), _ptr(num),
+                                  _stream()), 'ivx_aligned_3d_nms_ws')
     return pick, num

@@ -141,6 +141,10 @@ int ivx_conv_winograd_set_transform_blocks(int n);
 int ivx_conv_set_epilogue_mode(int narrow);
 /* Per calling thread, A/B only: 1 = the round-1 tile rule of the direct convolution planner, 0 (default) = scored choice. */
 int ivx_conv_set_plan_mode(int mode);
+/* Per calling thread, A/B and tests only: 1 = the candidate top-k of the detection tails (ivx_anchor_head_get_bboxes,
+ * ivx_fcos_head_level_candidates) always runs as the one-workgroup radix select; 0 (default) = lists of >= 16 384 scores take
+ * the chip-wide histogram / compaction form.  Both return the same indices in the same order. */
+int ivx_topk_set_mode(int32_t single_workgroup);
 
 /* Modulated deformable convolution (DCNv2; mmcv ModulatedDeformConv2dPack, deform_groups = 1) -- nuScenes reference
  * backbone, configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14.  Builds the modulated, bilinearly sampled columns
@@ -288,9 +292,15 @@ int ivx_boxes_overlap_bev(const float *a, int32_t na, const float *b, int32_t nb
 
 /* aligned_3d_nms (mmdet3d/core/post_processing/box3d_nms.py:91-138) on the device.
  * boxes [n,6] corners, scores [n], classes [n] int64; pick [n] int64 receives the kept box
- * indices in descending score order, num_out [1] int32.  One workgroup; n <= 16384.           */
+ * indices in descending score order, num_out [1] int32.  One workgroup; n <= 4096.            */
 int ivx_aligned_3d_nms(const float *boxes, const float *scores, const int64_t *classes, int32_t n,
                        float thresh, int64_t *pick, int32_t *num_out, ivx_stream_t stream);
+/* The same result with a workspace (n <= 4096): the greedy chain runs per class on 64 workgroups in parallel (boxes of
+ * different classes never suppress each other); inputs with degenerate boxes (non-finite corners, an extent outside
+ * (0, 1e6)), where the reference's NaN IoU suppresses ACROSS classes, take the one-workgroup form inside the call. */
+int64_t ivx_aligned_3d_nms_workspace_bytes(int32_t n);
+int ivx_aligned_3d_nms_ws(const float *boxes, const float *scores, const int64_t *classes, int32_t n, float thresh,
+                          void *workspace, int64_t workspace_bytes, int64_t *pick, int32_t *num_out, ivx_stream_t stream);
 
 /* Global average pool of a channels-last map: in [B,S,C] -> out [B,C]; `x.mean(dim=(2,3))` of LayoutHead.forward
  * (mmdet3d/models/dense_heads/layout_head.py:42, SUN RGB-D Total configs).                                        */

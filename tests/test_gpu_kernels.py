@@ -1019,3 +1019,77 @@ def test_pipelined_stack_equals_sequential(ia, neck_name):
         assert torch.equal(neck.forward_cl(x[:3].contiguous()), ref[:3])
     finally:
         pipeline.CHUNKS, pipeline.XF_BLOCKS, pipeline.XF_PRIORITY = old
+
+
+def test_topk_chipwide_equals_single_workgroup(ia):
+    """The candidate top-k of the detection tails on long score lists (histogram of the top 16 key bits -> threshold bin ->
+    compaction -> LDS sort, csrc/anchor_tail.hip launch_topk) against the one-workgroup radix select it replaces there:
+    identical candidate indices in identical order, boxes and scores bit for bit -- on random logits, and on logits quantised
+    to a few values (tens of thousands of equal scores: the threshold bin overflows the candidate list and the kernel falls
+    back to the exact select; ties resolve to the lower index either way)."""
+    import kitti_cfg as kc
+    from imvoxelnet_amd import _lib
+    L = _lib.lib()
+    model = ia.build_detector(kc.scannet_fast_model_cfg(), test_cfg=dict(kc.SCANNET_FAST_TEST_CFG))
+    head = model.bbox_head
+    head.prepare(torch.device('cuda'))
+    meta = kc.indoor_meta(1, box_type=ia.DepthInstance3DBoxes)
+    g = torch.Generator().manual_seed(77)
+    CH = 1 + head.n_reg_outs + head.n_classes
+    for quant in (0.0, 0.5, 4.0):
+        fused = []
+        for lvl, (nx, ny, nz) in enumerate(((80, 80, 32), (40, 40, 16), (20, 20, 8))):
+            f = torch.randn(2, nx, ny, nz, CH, generator=g)
+            f[..., 1 + head.n_reg_outs:] -= 2.0
+            if quant:
+                f = torch.round(f / quant) * quant
+            f[..., 1:1 + head.n_reg_outs] *= 0.1
+            fused.append(f.cuda().contiguous())
+        valid = (torch.rand(2, 80, 80, 32, generator=g) > 0.2).cuda()
+        out = {}
+        for mode in (0, 1):
+            L.ivx_topk_set_mode(mode)
+            try:
+                out[mode] = head.get_candidates_cl(fused, valid, [meta, meta], want_index=True)
+            finally:
+                L.ivx_topk_set_mode(0)
+        for (b0, s0, i0), (b1, s1, i1) in zip(out[0], out[1]):
+            assert torch.equal(i0, i1), f'quant {quant}: {(i0 != i1).sum().item()} candidate indices differ'
+            assert torch.equal(b0, b1) and torch.equal(s0, s1)
+
+
+def test_aligned_nms_class_parallel_equals_single_workgroup(ia):
+    """ivx_aligned_3d_nms_ws (per-class greedy chains on 64 workgroups) == ivx_aligned_3d_nms (one chain) == the C oracle:
+    3 000 boxes over 18 classes (a ScanNet scene), one dominant class (its chain does not fit the LDS stage), class ids
+    beyond 64 and negative, equal scores, and degenerate boxes -- zero / negative extents and NaN corners, whose NaN IoU
+    suppresses across classes in the reference (box3d_nms.py:131-137), which the call detects and runs as one chain."""
+    from oracle import c_oracle
+    from imvoxelnet_amd import ops
+    g = torch.Generator().manual_seed(123)
+
+    def boxes(n, spread):
+        c = (torch.rand(n, 3, generator=g) - .5) * spread
+        s = torch.rand(n, 3, generator=g) * 1.5 + 0.1
+        return torch.cat([c - s / 2, c + s / 2], 1)
+
+    cases = []
+    b = boxes(3000, 8.0)
+    cases.append(('scannet-like', b, torch.rand(3000, generator=g), torch.randint(0, 18, (3000,), generator=g), 0.25))
+    cls = torch.where(torch.rand(2500, generator=g) < 0.8, torch.tensor(3), torch.randint(0, 18, (2500,), generator=g))
+    cases.append(('dominant class', boxes(2500, 6.0), torch.rand(2500, generator=g), cls, 0.15))
+    cases.append(('wide class ids + ties', boxes(700, 3.0), torch.round(torch.rand(700, generator=g) * 20) / 20,
+                  torch.randint(-70, 200, (700,), generator=g), 0.25))
+    bd = boxes(400, 3.0)
+    bd[5, 3:] = bd[5, :3]                       # zero volume
+    bd[17, 3] = bd[17, 0] - 0.5                 # negative extent
+    bd[40, 1] = float('nan')
+    cases.append(('degenerate', bd, torch.rand(400, generator=g), torch.randint(0, 6, (400,), generator=g), 0.25))
+    cases.append(('tiny', boxes(3, 1.0), torch.rand(3, generator=g), torch.zeros(3, dtype=torch.long), 0.25))
+    for name, bx, sc, cl_, thr in cases:
+        bx, sc, cl_ = bx.contiguous().float(), sc.contiguous().float(), cl_.contiguous().long()
+        desc = np.lexsort((np.arange(len(sc)), -sc.numpy()))       # descending score, ties: lower index first (the device's key)
+        want = c_oracle.aligned_3d_nms(bx.numpy(), sc.numpy(), cl_.numpy(), desc[::-1].copy(), thr)
+        for single in (False, True):
+            pick, num = ops.aligned_3d_nms_dev(bx.cuda(), sc.cuda(), cl_.cuda(), thr, single_workgroup=single)
+            got = pick[:int(num.item())].cpu().numpy()
+            assert np.array_equal(got, want), f'{name} single={single}: {len(got)} vs {len(want)} picks'
