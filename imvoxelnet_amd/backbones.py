@@ -114,17 +114,40 @@ class ResNet(nn.Module):
 
     def prepare(self, device):
         self.stem = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), stride=2, padding=3, relu=True, dims=2).to(device)
+        # bf16 mode: the 7x7 stride-2 stem as a 4x4 stride-1 convolution over 2x2 space-to-depth blocks of the image
+        # (ops.image_s2d_bf16): bf16 MFMA with K = 256 instead of the fp32 kernel on 3 (padded to 4) channels
+        self.stem_s2d = None
+        from .conv import current_storage_dtype
+        w = self.conv1.weight.detach()
+        if current_storage_dtype() == torch.bfloat16 and tuple(w.shape[1:]) == (3, 7, 7):
+            w8 = torch.zeros(w.shape[0], 3, 8, 8, dtype=torch.float32)
+            w8[:, :, :7, :7] = w.float().cpu()
+            # [co, c, th, a, tw, e] -> [co, (a, e, c), th, tw], 12 real + 4 zero input channels
+            w2 = w8.reshape(-1, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(-1, 12, 4, 4)
+            w2 = torch.cat([w2, torch.zeros(w2.shape[0], 4, 4, 4)], 1)
+            self.stem_s2d = FusedConv(w2, bn=self.bn1.tensors(), stride=1, padding=1, relu=True, dims=2).to(device)
         for i in range(self.num_stages):
             for blk in getattr(self, f'layer{i + 1}'):
                 blk.prepare(device)
         self._device = device
         return self
 
+    def forward_image(self, img):
+        """img [N,3,H,W] (reference layout, fp32) -> tuple of channels-last stage outputs."""
+        if self._device is None:
+            self.prepare(img.device)
+        if self.stem_s2d is not None and img.shape[-1] % 2 == 0 and img.shape[-2] % 2 == 0 and img.dtype == torch.float32:
+            return self._stages(self.stem_s2d(ops.image_s2d_bf16(img.contiguous())))
+        return self.forward_cl(ops.to_channels_last(img.contiguous(), pad_to=4))
+
     def forward_cl(self, x):
         """x [N,1,H,W,4] channels-last image (3 channels zero-padded to 4) -> tuple of stage outputs."""
         if self._device is None:
             self.prepare(x.device)
-        x = ops.maxpool2d(self.stem(x), 3, 2, 1)
+        return self._stages(self.stem(x))
+
+    def _stages(self, x):
+        x = ops.maxpool2d(x, 3, 2, 1)
         outs = []
         for i in range(self.num_stages):
             for blk in getattr(self, f'layer{i + 1}'):
@@ -135,8 +158,7 @@ class ResNet(nn.Module):
 
     def forward(self, img):
         """img [N,3,H,W] -> tuple of [N,C,h,w] (reference layout)."""
-        outs = self.forward_cl(ops.to_channels_last(img.contiguous(), pad_to=4))
-        return tuple(ops.from_channels_last(o, 2) for o in outs)
+        return tuple(ops.from_channels_last(o, 2) for o in self.forward_image(img))
 
 
 @NECKS.register_module()

@@ -102,6 +102,50 @@ extern "C" int ivx_nchw_to_nhwc(const float *in, int32_t B, int32_t C, int64_t S
   return IVX_OK;
 }
 
+// Image -> space-to-depth blocks for the bf16 stem (optional reduced-precision mode).  The 7x7 stride-2 pad-3 stem reads, for
+// output (oh, ow), the pixels 2*oh-3 .. 2*oh+3: exactly the four 2x2 blocks oh-1 .. oh+2 of a block grid whose block p holds
+// the pixels (2p-1, 2p).  So the stem is a 4x4 stride-1 pad-1 convolution over out[b][ph][pw][(a*2+e)*3 + c] =
+// img[b][c][2*ph-1+a][2*pw-1+e] (zero outside the image; channels 12..15 zero): K = 4*4*16 = 256 bf16 values per output, of
+// which 147 are real taps, instead of 7*7*8 = 392 with the 3 channels padded to one 16-byte chunk -- and no strided gather.
+__global__ __launch_bounds__(256) void image_s2d_bf16_kernel(const float *img, int H, int W, int PH, int PW, __bf16 *out) {
+  const int b = blockIdx.z;
+  const int pw = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ph = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (pw >= PW || ph >= PH) return;
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  bf16x8_t lo, hi;
+  const float *base = img + (size_t)b * 3 * H * W;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int y = 2 * ph - 1 + a, x = 2 * pw - 1 + e;
+      const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = in ? base[((size_t)c * H + y) * W + x] : 0.f;
+        const int k = (a * 2 + e) * 3 + c;
+        if (k < 8) lo[k] = (__bf16)v; else hi[k - 8] = (__bf16)v;
+      }
+    }
+#pragma unroll
+  for (int k = 4; k < 8; ++k) hi[k] = (__bf16)0.f;
+  bf16x8_t *o = reinterpret_cast<bf16x8_t *>(out + (((size_t)b * PH + ph) * PW + pw) * 16);
+  o[0] = lo;
+  o[1] = hi;
+}
+
+extern "C" int ivx_image_s2d_bf16(const float *img, int32_t B, int32_t H, int32_t W, void *out, ivx_stream_t stream) {
+  IVX_REQUIRE(img && out && B > 0 && H > 0 && W > 0, "ivx_image_s2d_bf16: bad argument");
+  IVX_REQUIRE(H % 2 == 0 && W % 2 == 0, "ivx_image_s2d_bf16: H and W must be even (got %d x %d)", H, W);
+  IVX_REQUIRE(B <= 65535, "ivx_image_s2d_bf16: batch too large");
+  const int PH = H / 2 + 1, PW = W / 2 + 1;
+  dim3 grid((PW + 63) / 64, (PH + 3) / 4, B);
+  hipLaunchKernelGGL(image_s2d_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, H, W, PH, PW, (__bf16 *)out);
+  IVX_CHECK_LAUNCH("ivx_image_s2d_bf16");
+  return IVX_OK;
+}
+
 // [B,S,C] -> [B,C,S]
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *in, long long S, int C, float *out) {
   __shared__ float tile[32][33];

@@ -133,7 +133,7 @@ class ImVoxelNet(nn.Module):
         """img [B,V,3,H,W] -> FPN level 0, channels-last [B*V,1,H/4,W/4,Cf]
         (with want_2d: also the LayoutHead output (angles, layouts) computed from C5, or None without a head_2d)."""
         x = img.reshape([-1] + list(img.shape)[2:]).contiguous()
-        feats = self.backbone.forward_cl(ops.to_channels_last(x, pad_to=4))
+        feats = self.backbone.forward_image(x) if hasattr(self.backbone, 'forward_image') else self.backbone.forward_cl(ops.to_channels_last(x, pad_to=4))
         features_2d = self.head_2d.forward_cl(feats[-1], img_metas) if (want_2d and self.head_2d is not None) else None
         p0 = self.neck.forward_cl(list(feats))[0]
         stride = x.shape[-1] / p0.shape[3]

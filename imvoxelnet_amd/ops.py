@@ -37,6 +37,18 @@ def _ptr(t):
 
 
 # ------------------------------------------------------------------ layout
+def image_s2d_bf16(img):
+    """bf16 mode: image [N,3,H,W] fp32 -> 2x2 space-to-depth blocks [N,1,H/2+1,W/2+1,16] bf16 (ivx_image_s2d_bf16): the input of
+    the stem in its 4x4 stride-1 form (backbones.ResNet)."""
+    _chk(img, 'img')
+    N, Cn, H, W = img.shape
+    if Cn != 3:
+        raise ValueError('image_s2d_bf16 takes a 3-channel image')
+    out = torch.empty((N, 1, H // 2 + 1, W // 2 + 1, 16), device=img.device, dtype=torch.bfloat16)
+    check(_lib.lib().ivx_image_s2d_bf16(_ptr(img), N, H, W, _ptr(out), _stream()), 'ivx_image_s2d_bf16')
+    return out
+
+
 def to_channels_last(x, pad_to=None):
     """[B,C,*spatial] (reference layout) -> [B,D,H,W,Cpad] channels-last (D=1 for 2-D input)."""
     _chk(x, 'x')

@@ -172,6 +172,10 @@ int ivx_upsample_trilinear2x_fwd(const float *in, int32_t B, int32_t D, int32_t 
  * ([B,S,C] -> [B,C,S] with S = product of the spatial dims). */
 int ivx_nchw_to_nhwc(const float *in, int32_t B, int32_t C, int64_t S, int32_t Cpad, float *out,
                      ivx_stream_t stream);
+/* bf16 mode only: image [B,3,H,W] fp32 NCHW (H, W even) -> 2x2 space-to-depth blocks [B, H/2+1, W/2+1, 16] bf16 with
+ * out[b][ph][pw][(a*2+e)*3+c] = img[b][c][2ph-1+a][2pw-1+e] (zero outside, channels 12..15 zero): the 7x7 stride-2 pad-3 stem
+ * (mmdet ResNet.conv1) becomes a 4x4 stride-1 pad-1 convolution over it (weights re-indexed kh = 2*th + a, kw = 2*tw + e). */
+int ivx_image_s2d_bf16(const float *img, int32_t B, int32_t H, int32_t W, void *out, ivx_stream_t stream);
 int ivx_nhwc_to_nchw(const float *in, int32_t B, int64_t S, int32_t C, float *out, ivx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -1093,3 +1093,33 @@ def test_aligned_nms_class_parallel_equals_single_workgroup(ia):
             pick, num = ops.aligned_3d_nms_dev(bx.cuda(), sc.cuda(), cl_.cuda(), thr, single_workgroup=single)
             got = pick[:int(num.item())].cpu().numpy()
             assert np.array_equal(got, want), f'{name} single={single}: {len(got)} vs {len(want)} picks'
+
+
+def test_bf16_stem_space_to_depth(ia):
+    """bf16 mode: the 7x7 stride-2 stem as a 4x4 stride-1 convolution over 2x2 space-to-depth blocks (ivx_image_s2d_bf16 +
+    re-indexed weights, backbones.ResNet.prepare) against torch's conv2d on the bf16-rounded image and weights (products of
+    bf16 values are exact in fp32, so only the summation order differs): one bf16 ulp of the output."""
+    from imvoxelnet_amd import ops
+    from imvoxelnet_amd.conv import storage_dtype
+    from imvoxelnet_amd.backbones import ResNet
+    bf = torch.bfloat16
+    net = ResNet(depth=50, num_stages=1, out_indices=(0,), frozen_stages=-1, norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='pytorch')
+    ia.randomize_(net, 3)
+    with storage_dtype(bf):
+        net.prepare(torch.device('cuda'))
+    assert net.stem_s2d is not None
+    for hw in ((64, 96), (30, 52)):
+        img = torch.randn(3, 3, *hw, generator=torch.Generator().manual_seed(hw[0]))
+        blocks = ops.image_s2d_bf16(img.cuda())
+        assert blocks.shape == (3, 1, hw[0] // 2 + 1, hw[1] // 2 + 1, 16)
+        # the block layout itself
+        pad = F.pad(img.to(bf).float(), (1, 1, 1, 1))
+        want = torch.stack([pad[:, :, a::2, e::2][:, :, :hw[0] // 2 + 1, :hw[1] // 2 + 1] for a in (0, 1) for e in (0, 1)], 1)   # [N,4,3,PH,PW]
+        want = want.reshape(3, 12, hw[0] // 2 + 1, hw[1] // 2 + 1).permute(0, 2, 3, 1)
+        assert torch.equal(blocks[:, 0, :, :, :12].float().cpu(), want) and not blocks[..., 12:].any()
+        y = net.stem_s2d(blocks)
+        w = net.conv1.weight.detach().to(bf).float()
+        ref = F.conv2d(img.to(bf).float(), w, None, 2, 3)
+        ref = F.relu(F.batch_norm(ref, net.bn1.running_mean, net.bn1.running_var, net.bn1.weight, net.bn1.bias, False, 0.0, 1e-5))
+        assert y.dtype == bf and y.shape == (3, 1, hw[0] // 2, hw[1] // 2, 64)
+        assert_close(f'stem s2d {hw}', uncl(y.float())[:, :, 0], ref, 2 ** -7, 2e-3)

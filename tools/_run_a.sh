@@ -1,11 +1,11 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "aligned or nms or topk" 2>&1 | tail -15
-timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_engine.py tests/test_gpu_configs.py -x -q -m gpu -k "indoor or scannet or sunrgbd" 2>&1 | tail -5
-ROOT=$GRAFT_REPO_ROOT; OUT=gpurun_out/bf16prof; rm -rf $OUT; mkdir -p $OUT
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --config scannet_fast --storage bf16 --steps 5 --warmup 2 --no-cpu-baseline > $ROOT/$OUT/trace.log 2>&1)
-DB=$(find $OUT/trace -name "*.db" | head -1)
-[ -n "$DB" ] && python tools/rocpd_summary.py $DB 7 > $OUT/kernel_trace_scannet_fast_bf16.md
-rm -rf $OUT/trace
-grep -v "conv_igemm" $OUT/kernel_trace_scannet_fast_bf16.md | head -24 | cut -c1-150
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -x -q -m gpu -k "bf16" 2>&1 | tail -15
+for c in scannet_v1 scannet_fast sunrgbd_fast; do
+for s in bf16 f32; do
+timeout 300 python bench.py --config $c --storage $s --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys
+r=json.loads(sys.stdin.read()); t=r.get('roofline_trunk_2d') or {}
+print(r['config']['workload'], r['dtype'], r['value'], r['ms_per_step'], 'neck', r['roofline']['neck_ms_per_step'], 'trunk', t.get('ms_per_step'), t.get('achieved'))"
+done; done
+timeout 300 python bench.py --storage bf16 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-300
