@@ -26,8 +26,14 @@ find $OUT/trace -name "*stats*.csv" | head -3 | while read f; do cp $f $OUT/; do
 DB=$(find $OUT/trace_scannet -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/kernel_trace_scannet_fast.md
 grep '^{"metric' $OUT/trace_scannet.log | tail -1 > $OUT/bench_profiled_scannet_fast.json
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace_v1bf16 -o t -- python $ROOT/bench.py --config scannet_v1 --storage bf16 --steps 3 --warmup 1 > $ROOT/$OUT/trace_v1bf16.log 2>&1)
+DB=$(find $OUT/trace_v1bf16 -name "*.db" | head -1)
+[ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/kernel_trace_scannet_v1_bf16.md
+for d in f32 bf16; do python tools/trunk_layers.py --config scannet_v1 --dtype $d --top 40 > $OUT/trunk_layers_scannet_v1_$d.md 2>/dev/null; done
+python tools/trunk_layers.py --config kitti --top 40 > $OUT/trunk_layers_kitti.md 2>/dev/null
+python tools/trunk_ab.py > $OUT/trunk_ab.log 2>/dev/null
 bash tools/pmc_bench.sh $OUT/pmc > $OUT/pmc.log 2>&1
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.5 --json $OUT/pmc.json > $OUT/pmc.md
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.1 --match wino_ --json $OUT/pmc_wino.json > $OUT/pmc_wino.md
-rm -rf $OUT/trace/*/*.db.bak $OUT/trace $OUT/trace_scannet 2>/dev/null
+rm -rf $OUT/trace/*/*.db.bak $OUT/trace $OUT/trace_scannet $OUT/trace_v1bf16 2>/dev/null
 du -sh $OUT
