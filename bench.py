@@ -111,9 +111,15 @@ def bench_other(args, ia, kc, dev, rank, world):
             model.bbox_head.cls_conv.bias.fill_(-2.0)
             model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
     model.prepare(dev, dtype=torch.bfloat16 if args.storage == 'bf16' else torch.float32)
+    fp8_note = None
     # view sharding: every rank holds the same scene(s) and works on its slice of the views
     img = torch.randn(B, V, 3, H, W, generator=torch.Generator().manual_seed(1000 + (0 if args.shard == 'views' else rank))).to(dev)
     metas = [mk() for _ in range(B)]
+    if args.trunk_fp8:
+        if args.storage != 'bf16':
+            raise SystemExit('--trunk-fp8 goes on top of --storage bf16 (BASELINE config 5: "bf16 with fp8 2D-conv MFMA")')
+        model.calibrate_fp8(img)               # one bf16 pass over the batch: per-tensor activation scales
+        fp8_note = 'ResNet-50 activations and weights stored as e4m3 (calibrated per-tensor / per-channel scales), v_mfma_f32_32x32x16_fp8_fp8'
     n = args.steps + args.warmup
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     neck_flops, neck_exec = [0.0], [0.0]    # direct-convolution FLOPs / FLOPs executed (fewer for Winograd-form layers)
@@ -217,8 +223,8 @@ def bench_other(args, ia, kc, dev, rank, world):
     rec = {'metric': f'images/sec/node ({args.config}: {V} view(s) 3x{H}x{W}, {"x".join(map(str, cfg["n_voxels"]))} vox)',
            'value': round(B * V * args.steps / dt, 3), 'unit': 'images/s', 'scenes_per_s': round(B * args.steps / dt, 3), 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-           'scaling': 'strong' if view_sharded else 'weak', 'vs_baseline': None, 'dtype': args.storage, 'data': 'synthetic',
-           'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'shard': args.shard, 'api': 'simple_test (native handle)' if public else 'composed',
+           'scaling': 'strong' if view_sharded else 'weak', 'vs_baseline': None, 'dtype': args.storage + ('+fp8 trunk' if args.trunk_fp8 else ''), 'data': 'synthetic',
+           'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'shard': args.shard, 'trunk_fp8': fp8_note, 'api': 'simple_test (native handle)' if public else 'composed',
                       'detections_last_step': int(sum(len(r[1]) for r in last))},
            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck)' % ('__bf16' if args.storage == 'bf16' else 'float'),
                         'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS,
@@ -291,6 +297,7 @@ def main():
     ap.add_argument('--shard', default='samples', choices=['samples', 'views'],
                     help="multi-GPU partition: 'samples' (default; weak scaling, the headline mode) or 'views' (indoor multi-view "
                          "configs: the views of each scene are split over the ranks, one RCCL all-reduce of the partial volume; strong scaling)")
+    ap.add_argument('--trunk-fp8', action='store_true', help='with --storage bf16 and an indoor --config: e4m3 storage of the 2-D trunk (calibrated on the bench batch)')
     ap.add_argument('--graph', action='store_true',
                     help='replay the device side of the step as one captured hipGraph (kitti config); the roofline entry is then '
                          'taken from the eager warm-up steps, which run the same kernels with HIP events around the neck')

@@ -63,6 +63,17 @@ class _Bottleneck(nn.Module):
         return self.f3(y, res=idt)
 
 
+def stem_s2d_weights(w):
+    """[Cout, 3, 7, 7] stem filters -> [Cout, 16, 4, 4]: the same convolution as a 4x4 stride-1 pad-1 one over the 2x2
+    space-to-depth blocks of ops.image_s2d_bf16 (block p holds the pixels (2p-1, 2p); input channel (a*2+e)*3 + c is pixel
+    (2*ph-1+a, 2*pw-1+e), colour c; tap kh = 2*th + a, kw = 2*tw + e, the eighth row / column and channels 12..15 are zero)."""
+    w8 = torch.zeros(w.shape[0], 3, 8, 8, dtype=torch.float32)
+    w8[:, :, :7, :7] = w.detach().float().cpu()
+    # [co, c, th, a, tw, e] -> [co, (a, e, c), th, tw]
+    w2 = w8.reshape(-1, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(-1, 12, 4, 4)
+    return torch.cat([w2, torch.zeros(w2.shape[0], 4, 4, 4)], 1)
+
+
 @BACKBONES.register_module()
 class ResNet(nn.Module):
     arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
@@ -113,19 +124,21 @@ class ResNet(nn.Module):
         self.load_state_dict(sd.get('state_dict', sd) if isinstance(sd, dict) else sd, strict=False)
 
     def prepare(self, device):
-        self.stem = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), stride=2, padding=3, relu=True, dims=2).to(device)
+        from .conv import current_storage_dtype, FP8
+        fp8 = current_storage_dtype() == FP8       # optional: e4m3 storage of the trunk's activations (detector.calibrate_fp8)
+        self.stem = None
+        if not fp8:
+            self.stem = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), stride=2, padding=3, relu=True, dims=2).to(device)
         # bf16 mode: the 7x7 stride-2 stem as a 4x4 stride-1 convolution over 2x2 space-to-depth blocks of the image
         # (ops.image_s2d_bf16): bf16 MFMA with K = 256 instead of the fp32 kernel on 3 (padded to 4) channels
         self.stem_s2d = None
-        from .conv import current_storage_dtype
         w = self.conv1.weight.detach()
-        if current_storage_dtype() == torch.bfloat16 and tuple(w.shape[1:]) == (3, 7, 7):
-            w8 = torch.zeros(w.shape[0], 3, 8, 8, dtype=torch.float32)
-            w8[:, :, :7, :7] = w.float().cpu()
-            # [co, c, th, a, tw, e] -> [co, (a, e, c), th, tw], 12 real + 4 zero input channels
-            w2 = w8.reshape(-1, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(-1, 12, 4, 4)
-            w2 = torch.cat([w2, torch.zeros(w2.shape[0], 4, 4, 4)], 1)
-            self.stem_s2d = FusedConv(w2, bn=self.bn1.tensors(), stride=1, padding=1, relu=True, dims=2).to(device)
+        if fp8 and tuple(w.shape[1:]) != (3, 7, 7):
+            raise NotImplementedError('fp8 trunk storage is built for the 3-channel 7x7 stem')
+        if current_storage_dtype() in (torch.bfloat16, FP8) and tuple(w.shape[1:]) == (3, 7, 7):
+            w2 = stem_s2d_weights(w)
+            self.stem_s2d = FusedConv(w2, bn=self.bn1.tensors(), stride=1, padding=1, relu=True, dims=2, dtype=torch.bfloat16,
+                                      out_dtype=FP8 if fp8 else torch.bfloat16, key=id(self.conv1.weight)).to(device)
         for i in range(self.num_stages):
             for blk in getattr(self, f'layer{i + 1}'):
                 blk.prepare(device)
@@ -138,6 +151,8 @@ class ResNet(nn.Module):
             self.prepare(img.device)
         if self.stem_s2d is not None and img.shape[-1] % 2 == 0 and img.shape[-2] % 2 == 0 and img.dtype == torch.float32:
             return self._stages(self.stem_s2d(ops.image_s2d_bf16(img.contiguous())))
+        if self.stem is None:
+            raise ValueError('the fp8 trunk takes float32 images with even height and width')
         return self.forward_cl(ops.to_channels_last(img.contiguous(), pad_to=4))
 
     def forward_cl(self, x):
@@ -147,7 +162,8 @@ class ResNet(nn.Module):
         return self._stages(self.stem(x))
 
     def _stages(self, x):
-        x = ops.maxpool2d(x, 3, 2, 1)
+        from .conv import QTensor
+        x = QTensor(ops.maxpool2d(x.data, 3, 2, 1), x.scale) if isinstance(x, QTensor) else ops.maxpool2d(x, 3, 2, 1)
         outs = []
         for i in range(self.num_stages):
             for blk in getattr(self, f'layer{i + 1}'):
@@ -158,7 +174,8 @@ class ResNet(nn.Module):
 
     def forward(self, img):
         """img [N,3,H,W] -> tuple of [N,C,h,w] (reference layout)."""
-        return tuple(ops.from_channels_last(o, 2) for o in self.forward_image(img))
+        from .conv import QTensor
+        return tuple(ops.from_channels_last(o.float() if isinstance(o, QTensor) else o, 2) for o in self.forward_image(img))
 
 
 @NECKS.register_module()
@@ -188,8 +205,12 @@ class FPN(nn.Module):
     def init_weights(self):
         pass
 
-    def prepare(self, device):
-        self.flat = [FusedConv(m.conv.weight, m.conv.bias, dims=2).to(device) for m in self.lateral_convs]
+    def prepare(self, device, in_dtype=None):
+        """in_dtype: storage type of the backbone's stage outputs when it differs from the FPN's own (the fp8 trunk: e4m3 in,
+        the FPN's storage type -- bf16 -- out)."""
+        from .conv import current_storage_dtype
+        od = current_storage_dtype()
+        self.flat = [FusedConv(m.conv.weight, m.conv.bias, dims=2, dtype=in_dtype or od, out_dtype=od).to(device) for m in self.lateral_convs]
         self.fout = [FusedConv(m.conv.weight, m.conv.bias, padding=1, dims=2).to(device) for m in self.fpn_convs]
         self._device = device
         return self

@@ -49,8 +49,8 @@ class storage_dtype:
     reduced-precision mode; the default and the reference's precision is float32).  Accumulation stays fp32."""
 
     def __init__(self, dtype):
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise TypeError('storage dtype must be torch.float32 or torch.bfloat16')
+        if dtype not in (torch.float32, torch.bfloat16, torch.float8_e4m3fn):
+            raise TypeError('storage dtype must be torch.float32, torch.bfloat16 or torch.float8_e4m3fn')
         self.dtype = dtype
 
     def __enter__(self):
@@ -64,6 +64,32 @@ class storage_dtype:
 
 def current_storage_dtype():
     return _storage[-1]
+
+
+FP8 = torch.float8_e4m3fn
+FP8_MAX = 448.0
+
+
+class QTensor:
+    """An e4m3 activation with its per-tensor scale: value = data.float() * scale (optional fp8 storage of the 2-D trunk in
+    the bf16 mode).  Produced and consumed by FusedConv / ops.maxpool2d; `scale` is a Python float fixed at calibration."""
+    __slots__ = ('data', 'scale')
+
+    def __init__(self, data, scale):
+        self.data, self.scale = data, float(scale)
+
+    shape = property(lambda self: self.data.shape)
+    device = property(lambda self: self.data.device)
+    dtype = property(lambda self: self.data.dtype)
+
+    def numel(self):
+        return self.data.numel()
+
+    def element_size(self):
+        return 1
+
+    def float(self):
+        return self.data.float() * self.scale
 
 
 class FusedConv:
@@ -93,18 +119,37 @@ class FusedConv:
     # 'wino_output'; the events bracket exactly the launches of that stage on the stream they run on; is_3d tells the 3-D
     # neck layers from the 2-D trunk
     trace = None
+    # fp8 calibration (optional fp8 storage of the 2-D trunk): while `calib` is a dict, every call records the running
+    # max |output| under the layer's key (id of its weight parameter); layers built later with out_dtype FP8 read their output
+    # scale from it: scale = amax * calib_margin / 448
+    calib = None
+    calib_margin = 1.0
 
     def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, relu=False, dims=3, eps=1e-5, layout=None,
-                 dtype=None, out_dtype=None):
+                 dtype=None, out_dtype=None, key=None):
         """weight: [Cout,Cin,kh,kw] (dims=2) or [Cout,Cin,kd,kh,kw] (dims=3) tensor (any device).
         bn: None or (gamma, beta, running_mean, running_var).
         dtype: storage type of the input and the packed weights (float32 = the reference's precision; bfloat16 is the
         optional reduced-precision mode); out_dtype: storage type of the output / residual (default: dtype)."""
         dtype = _storage[-1] if dtype is None else dtype
         out_dtype = dtype if out_dtype is None else out_dtype
+        self.key = id(weight) if key is None else key
         w = weight.detach().to(torch.float32)
         if dtype == torch.bfloat16 and w.shape[1] % 8 != 0:
             dtype = torch.float32      # e.g. the 3-channel stem: fp32 image in, reduced-precision map out
+        if dtype == FP8 and w.shape[1] % 16 != 0:
+            raise ValueError('fp8 input needs a multiple of 16 input channels')
+        self.w_scale = None            # fp8 weights: per-output-channel scale, folded into the epilogue scale
+        if dtype == FP8:
+            self.w_scale = (w.reshape(w.shape[0], -1).abs().amax(1).clamp_min(1e-12) / FP8_MAX).cpu()
+            w = w / self.w_scale.view(-1, *([1] * (w.dim() - 1))).to(w.device)
+        self.out_scale = 1.0
+        if out_dtype == FP8:
+            if FusedConv.calib is None or self.key not in FusedConv.calib:
+                raise RuntimeError('fp8 output needs a calibration record for this layer (FusedConv.calib; see ImVoxelNet.calibrate_fp8)')
+            self.out_scale = max(float(FusedConv.calib[self.key]), 1e-12) * FusedConv.calib_margin / FP8_MAX
+        self._qvec = {}                # (in_scale, out_scale) -> device (scale, shift) with the tensor scales folded in
+        self._res_scale = 1.0
         self.dtype, self.out_dtype = dtype, out_dtype
         if dims == 2:
             w = w.unsqueeze(2)
@@ -112,8 +157,8 @@ class FusedConv:
         self.padding = _spatial3(padding, dims, 0)
         self.cout, self.cin = w.shape[0], w.shape[1]
         self.kernel = tuple(w.shape[2:])
-        epc = 8 if dtype == torch.bfloat16 else 4          # elements per 16-byte chunk
-        ck = 64 if dtype == torch.bfloat16 else 32         # channels per 128-byte chunk (layout 1)
+        epc = {torch.float32: 4, torch.bfloat16: 8, FP8: 16}[dtype]       # elements per 16-byte chunk
+        ck = {torch.float32: 32, torch.bfloat16: 64, FP8: 128}[dtype]     # channels per 128-byte chunk (layout 1)
         self.cin_pad = (self.cin + epc - 1) // epc * epc
         wp = w.permute(0, 2, 3, 4, 1).contiguous()
         if self.cin_pad != self.cin:
@@ -164,6 +209,36 @@ class FusedConv:
     def __call__(self, x, res=None, res_mode=0, relu=None, naive=False, res_after_act=False, post_scale=1.0):
         if self.w is None:
             raise RuntimeError('FusedConv.to(device) must be called before use')
+        if self.dtype == FP8 or self.out_dtype == FP8 or isinstance(res, QTensor):
+            return self._call_quantized(x, res, res_mode, relu, naive, res_after_act, post_scale)
+        y = self._call(x, res, res_mode, relu, naive, res_after_act, post_scale)
+        if FusedConv.calib is not None:
+            FusedConv.calib[self.key] = max(FusedConv.calib.get(self.key, 0.0), float(y.float().abs().max()))
+        return y
+
+    def _call_quantized(self, x, res, res_mode, relu, naive, res_after_act, post_scale):
+        """fp8 storage: x / res may be QTensors (e4m3 bytes + scale); the tensors' scales are folded into the epilogue vectors
+        (scale = bn_scale * s_w[co] * s_in / s_out, shift = bn_shift / s_out, residual multiplier s_res / s_out)."""
+        s_in = x.scale if isinstance(x, QTensor) else 1.0
+        xd = x.data if isinstance(x, QTensor) else x
+        if (self.dtype == FP8) != isinstance(x, QTensor):
+            raise TypeError('an fp8 layer takes a QTensor (and only an fp8 layer does)')
+        s_out = self.out_scale
+        vec = self._qvec.get((s_in, s_out))
+        if vec is None:
+            sc = self._scale_host * (self.w_scale if self.w_scale is not None else 1.0) * (s_in / s_out)
+            vec = self._qvec[(s_in, s_out)] = (sc.float().contiguous().to(self.w.device), (self._shift_host / s_out).float().contiguous().to(self.w.device))
+        rd = res.data if isinstance(res, QTensor) else res
+        keep = (self.scale, self.shift, self._res_scale)
+        self.scale, self.shift = vec
+        self._res_scale = ((res.scale if isinstance(res, QTensor) else 1.0) / s_out) if res is not None else 1.0
+        try:
+            y = self._call(xd, rd, res_mode, relu, naive, res_after_act, post_scale)
+        finally:
+            self.scale, self.shift, self._res_scale = keep
+        return QTensor(y, s_out) if self.out_dtype == FP8 else y
+
+    def _call(self, x, res, res_mode, relu, naive, res_after_act, post_scale):
         B = x.shape[0]
         m, xs, wk, wst, wpad = self.wino_tile(tuple(x.shape), x.dtype, res_mode, naive)
         wino = m > 0
@@ -234,7 +309,7 @@ class FusedConv:
         return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,
                             self.relu if relu is None else relu, res, res_mode, naive=naive, wgt_layout=self.layout,
                             out_mode=self.out_mode, res_after_act=res_after_act, post_scale=post_scale,
-                            out_dtype=self.out_dtype)
+                            out_dtype=self.out_dtype, res_scale=self._res_scale)
 
 
 

@@ -23,6 +23,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvParams {
@@ -51,13 +52,30 @@ struct ConvParams {
   long long g_in, g_w, g_out;
   int groups;
   int narrow_epilogue;  // A/B knob: 1 = the one-channel-per-lane epilogue everywhere (ivx_conv_set_epilogue_mode)
+  int in_fp8;         // in / wgt are OCP e4m3 bytes (v_mfma_f32_32x32x16_fp8_fp8); dequantisation is folded into scale[]
+  int out_fp8;        // out / res are e4m3 bytes (saturating round-to-nearest-even at the store)
+  float res_scale;    // multiplier of the residual (fp8 storage: res_scale_of_tensor / out_scale); 1 otherwise
 };
 
+struct fp8_t { unsigned char v; };       // storage element of the fp8 instantiation (size 1)
+typedef long i64_t;
+
+__device__ __forceinline__ float fp8_to_f32(unsigned char b) { return __builtin_amdgcn_cvt_f32_fp8((int)b, 0); }
+// saturating e4m3 conversion of two floats -> low / high byte pair (NaN stays NaN)
+__device__ __forceinline__ unsigned int f32x2_to_fp8(float a, float b) {
+  a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
+  b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+  return (unsigned int)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+
 __device__ __forceinline__ float conv_ld_res(const ConvParams &p, size_t i) {
+  if (p.out_fp8) return fp8_to_f32(reinterpret_cast<const unsigned char *>(p.res)[i]);
   return p.out_bf16 ? (float)reinterpret_cast<const __bf16 *>(p.res)[i] : p.res[i];
 }
 __device__ __forceinline__ void conv_st_out(const ConvParams &p, size_t i, float v) {
-  if (p.out_bf16)
+  if (p.out_fp8)
+    reinterpret_cast<unsigned char *>(p.out)[i] = (unsigned char)(f32x2_to_fp8(v, 0.f) & 0xffu);
+  else if (p.out_bf16)
     reinterpret_cast<__bf16 *>(p.out)[i] = (__bf16)v;
   else
     p.out[i] = v;
@@ -83,9 +101,9 @@ __device__ __noinline__ size_t res2_row_base(int m, int Ho, int Wo, int rH, int 
 // y = act(acc*scale + shift [+ res]) [+ res] [* post_scale] for one output element; `oidx` is its flat offset.
 __device__ __forceinline__ float conv_finish(const ConvParams &p, float acc, float sc, float sf, size_t ridx) {
   float v = acc * sc + sf;
-  if (p.res_mode && !p.res_after_act) v += conv_ld_res(p, ridx);
+  if (p.res_mode && !p.res_after_act) v += conv_ld_res(p, ridx) * p.res_scale;     // res_scale is 1 outside the fp8 mode (exact)
   if (p.relu) v = v > 0.f ? v : 0.f;
-  if (p.res_mode && p.res_after_act) v += conv_ld_res(p, ridx);
+  if (p.res_mode && p.res_after_act) v += conv_ld_res(p, ridx) * p.res_scale;
   return v * p.post_scale;
 }
 
@@ -244,7 +262,7 @@ __device__ __forceinline__ void conv_epilogue_wide_bf16(const ConvParams &p, f32
             const size_t ro = p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + nb : o;
             const bf16x8 rb = *reinterpret_cast<const bf16x8 *>(resp + ro);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { r0[e] = (float)rb[e]; r1[e] = (float)rb[e + 4]; }
+            for (int e = 0; e < 4; ++e) { r0[e] = (float)rb[e] * p.res_scale; r1[e] = (float)rb[e + 4] * p.res_scale; }
           }
           if (p.res_mode && !p.res_after_act) { v0 += r0; v1 += r1; }
           if (p.relu) {
@@ -259,6 +277,68 @@ __device__ __forceinline__ void conv_epilogue_wide_bf16(const ConvParams &p, f32
           for (int e = 0; e < 4; ++e) { ob[e] = (__bf16)v0[e]; ob[e + 4] = (__bf16)v1[e]; }
           *reinterpret_cast<bf16x8 *>(outp + obase + o) = ob;
         }
+      }
+    }
+  }
+}
+
+// e4m3-output variant (Cout % 16 == 0): a lane owns 16 consecutive channels of a row -- one 16-byte store of 16 fp8 values,
+// 4 lanes to a 64-byte row segment of a tile pair; the residual (e4m3, its own scale) arrives as one 16-byte load.
+template <int TM, int TN, int NJ>
+__device__ __forceinline__ void conv_epilogue_wide_fp8(const ConvParams &p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
+                                                       int lane, float *stage, size_t obase) {
+  static_assert(TN % NJ == 0, "tile pairs");
+  constexpr int LPR = 2 * NJ;        // lanes per row: 16 channels each over NJ*32 channels
+  constexpr int RPP = 64 / LPR;      // rows per pass
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int col_l = lane & 31, hh = lane >> 5;
+  const int rrow = lane / LPR, c16 = (lane % LPR) * 16;
+  const float *rd = stage + (c16 >> 5) * 1024 + (c16 & 31);
+  unsigned char *outp = reinterpret_cast<unsigned char *>(p.out);
+  const unsigned char *resp = reinterpret_cast<const unsigned char *>(p.res);
+#pragma unroll
+  for (int j = 0; j < TN; j += NJ) {
+    const int nb = n0 + (wc * TN + j) * 32 + c16;
+    const bool nok = nb < p.Cout;                        // Cout % 16 == 0
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[jj * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col_l] = acc[i][j + jj][r];
+      const int mb = m0 + (wr * TM + i) * 32 + rrow;
+#pragma unroll
+      for (int q = 0; q < 32 / RPP; ++q) {
+        const int m = mb + RPP * q;
+        if (!(m < p.M && nok)) continue;
+        const size_t o = (size_t)m * p.Cout + nb;
+        u32x4 rb = {0u, 0u, 0u, 0u};
+        if (p.res_mode) rb = *reinterpret_cast<const u32x4 *>(resp + (p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + nb : o));
+        u32x4 ob;
+        // four channels at a time (scale / shift come from the cache again for every row: keeps the live registers low -- the
+        // first version held 16 scales + 16 shifts + 16 values + 16 residuals beside the 64 accumulators and spilled 75 VGPRs)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          f32x4 v = *reinterpret_cast<const f32x4 *>(rd + (rrow + RPP * q) * 32 + 4 * w);
+          f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+          if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + nb + 4 * w);
+          if (p.shift) sf = *reinterpret_cast<const f32x4 *>(p.shift + nb + 4 * w);
+          v = v * sc + sf;
+          f32x4 r = {0.f, 0.f, 0.f, 0.f};
+          if (p.res_mode) {
+            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)rb[w], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)rb[w], true);
+            r[0] = lo[0] * p.res_scale; r[1] = lo[1] * p.res_scale; r[2] = hi[0] * p.res_scale; r[3] = hi[1] * p.res_scale;
+          }
+          if (p.res_mode && !p.res_after_act) v += r;
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          if (p.res_mode && p.res_after_act) v += r;
+          v *= p.post_scale;
+          ob[w] = f32x2_to_fp8(v[0], v[1]) | (f32x2_to_fp8(v[2], v[3]) << 16);
+        }
+        *reinterpret_cast<u32x4 *>(outp + obase + o) = ob;
       }
     }
   }
@@ -706,13 +786,23 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][i][q], fb[cb][j][q], acc[i][j], 0, 0, 0);
-      } else {
+      } else if constexpr (EL == 2) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cb][i]), __builtin_bit_cast(bf16x8, fb[cb][j]),
                                                                acc[i][j], 0, 0, 0);
+      } else {   // e4m3: the lane's 16-byte chunk holds 16 k -> two MFMAs 32x32x16 (8 bytes per operand each)
+        typedef i64_t i64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(i64x2, fa[cb][i])[q], __builtin_bit_cast(i64x2, fb[cb][j])[q],
+                                                                    acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -734,9 +824,16 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
       }
     return;
   }
-  if (p.out_mode == 0 && !p.out_bf16 && (p.Cout & 3) == 0 && !p.narrow_epilogue) {
+  if (p.out_mode == 0 && !p.out_bf16 && !p.out_fp8 && (p.Cout & 3) == 0 && !p.narrow_epilogue) {
     static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
     conv_epilogue_wide<TM, TN>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, gz * (size_t)p.g_out);
+    return;
+  }
+  if constexpr (EL < 4)    // e4m3 outputs come from bf16 (the stem) or e4m3 inputs only: keeps the fp32 instantiations as they were
+  if (p.out_mode == 0 && p.out_fp8 && (p.Cout & 15) == 0 && !p.narrow_epilogue) {
+    constexpr int NJ = (TN % 2 == 0 && sizeof(smem) >= (size_t)NT / 64 * 8192) ? 2 : 1;
+    static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096 * NJ, "staging LDS for the transposed fp8 epilogue");
+    conv_epilogue_wide_fp8<TM, TN, NJ>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024 * NJ, gz * (size_t)p.g_out);
     return;
   }
   if (p.out_mode == 0 && p.out_bf16 && (p.Cout & 7) == 0 && !p.narrow_epilogue) {
@@ -808,11 +905,13 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
           const int tap = (a * p.KH + e) * p.KW + f;
           const int ntap = p.KD * p.KH * p.KW;
           const size_t wo = (size_t)n * p.K;
-          const int ck = p.in_bf16 ? 64 : 32;   // channels per 128-byte chunk of the chunk-major order
+          const int ck = p.in_fp8 ? 128 : (p.in_bf16 ? 64 : 32);   // channels per 128-byte chunk of the chunk-major order
           for (int c = 0; c < p.Cin; ++c) {
             const size_t wi = wo + (p.kmode == 1 ? (size_t)((c / ck) * ntap + tap) * ck + (c % ck) : (size_t)tap * p.Cin + c);
-            const float xv = p.in_bf16 ? (float)reinterpret_cast<const __bf16 *>(p.in)[xo + c] : p.in[xo + c];
-            const float wv = p.in_bf16 ? (float)reinterpret_cast<const __bf16 *>(p.wgt)[wi] : p.wgt[wi];
+            const float xv = p.in_fp8 ? fp8_to_f32(reinterpret_cast<const unsigned char *>(p.in)[xo + c])
+                                      : (p.in_bf16 ? (float)reinterpret_cast<const __bf16 *>(p.in)[xo + c] : p.in[xo + c]);
+            const float wv = p.in_fp8 ? fp8_to_f32(reinterpret_cast<const unsigned char *>(p.wgt)[wi])
+                                      : (p.in_bf16 ? (float)reinterpret_cast<const __bf16 *>(p.wgt)[wi] : p.wgt[wi]);
             acc = fmaf(xv, wv, acc);
           }
         }
@@ -854,9 +953,11 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   IVX_REQUIRE(d->out_mode == 0 || (d->out_mode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 1 && d->sd == 1 && d->sh == 1 && d->sw == 1 &&
                                      d->pd == 0 && d->ph == 0 && d->pw == 0 && d->Cout % 8 == 0 && d->res_mode != 2),
               "ivx_conv_fwd: out_mode 1 (ConvTranspose k2 s2) needs a 1x1x1 stride-1 GEMM with Cout = 8 * real channels");
-  IVX_REQUIRE((d->in_dtype == IVX_F32 || d->in_dtype == IVX_BF16) && (d->out_dtype == IVX_F32 || d->out_dtype == IVX_BF16),
-              "ivx_conv_fwd: dtypes are IVX_F32 (0) or IVX_BF16 (1)");
-  const int ck = d->in_dtype == IVX_BF16 ? 64 : 32;
+  IVX_REQUIRE(d->in_dtype >= IVX_F32 && d->in_dtype <= IVX_FP8 && d->out_dtype >= IVX_F32 && d->out_dtype <= IVX_FP8,
+              "ivx_conv_fwd: dtypes are IVX_F32 (0), IVX_BF16 (1) or IVX_FP8 (2)");
+  IVX_REQUIRE(d->in_dtype != IVX_FP8 || d->Cin % 16 == 0, "ivx_conv_fwd: fp8 input needs Cin %% 16 == 0");
+  IVX_REQUIRE((d->in_dtype != IVX_FP8 && d->out_dtype != IVX_FP8) || d->out_mode == 0, "ivx_conv_fwd: fp8 is built for out_mode 0 only");
+  const int ck = d->in_dtype == IVX_FP8 ? 128 : (d->in_dtype == IVX_BF16 ? 64 : 32);
   IVX_REQUIRE(d->wgt_layout == 0 || (d->wgt_layout == 1 && d->Cin % ck == 0),
               "ivx_conv_fwd: wgt_layout 1 needs Cin %% %d == 0 (128-byte channel chunks)", ck);
   IVX_REQUIRE(d->in_dtype == IVX_F32 || d->Cin % 8 == 0, "ivx_conv_fwd: bf16 input needs Cin %% 8 == 0");
@@ -867,6 +968,8 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   p->in = (const float *)in; p->wgt = (const float *)wgt; p->scale = scale; p->shift = shift;
   p->res = d->res_mode ? (const float *)res : nullptr; p->out = (float *)out;
   p->in_bf16 = d->in_dtype == IVX_BF16; p->out_bf16 = d->out_dtype == IVX_BF16;
+  p->in_fp8 = d->in_dtype == IVX_FP8; p->out_fp8 = d->out_dtype == IVX_FP8;
+  p->res_scale = d->res_scale == 0.f ? 1.0f : d->res_scale;
   p->B = d->B; p->D = d->D; p->H = d->H; p->W = d->W; p->Cin = d->Cin;
   p->Cout = d->Cout; p->KD = d->KD; p->KH = d->KH; p->KW = d->KW;
   p->sd = d->sd; p->sh = d->sh; p->sw = d->sw; p->pd = d->pd; p->ph = d->ph; p->pw = d->pw;
@@ -959,6 +1062,10 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 48: *t = {64, 128, 16, 5}; return true;
     case 49: *t = {128, 64, 16, 5}; return true;
     case 74: *t = {128, 128, 32, 4}; return true;
+    case 91: *t = {128, 128, 64, 4}; return true;
+    case 92: *t = {128, 64, 64, 5}; return true;
+    case 93: *t = {64, 64, 64, 6}; return true;
+    case 94: *t = {128, 128, 128, 2}; return true;
     case 81: *t = {256, 128, 32, 2}; return true;
     case 82: *t = {256, 256, 32, 1}; return true;
     case 83: *t = {256, 128, 64, 1}; return true;
@@ -976,7 +1083,7 @@ static bool tile_info(int cfg, TileInfo *t) {
 }
 
 static bool dma_applicable(const ConvParams &p) {
-  const int el = p.in_bf16 ? 2 : 4;
+  const int el = p.in_fp8 ? 1 : (p.in_bf16 ? 2 : 4);
   const int64_t in_b = (int64_t)p.B * p.D * p.H * p.W * p.Cin * el, w_b = (int64_t)p.Cout * p.K * el;
   return in_b < (1LL << 31) && w_b < (1LL << 31) && p.KD <= 8 && p.KH <= 8 && p.KW <= 8;
 }
@@ -1036,6 +1143,18 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
       // variant at six workgroups per CU keeps more loads in flight; long-K layers prefer the 128-byte rows
       pl.cfg = dma_ok ? (p.K <= 640 ? 47 : 46) : 6;
       small = true;
+    }
+  }
+  if (p.in_fp8) {
+    // e4m3 storage (2-D trunk of the bf16 + fp8 mode): HBM / latency-bound like the bf16 trunk, same rule: 128 x 128 at four per
+    // CU, 128 x 64 for Cout <= 64, 64 x 64 (+ split K) when the tiles would not fill the workgroup slots
+    if (g_tile_override >= 91 && g_tile_override <= 94) {
+      pl.cfg = g_tile_override;
+    } else {
+      const long long t128 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+      if (p.Cout <= 64) pl.cfg = ((long long)((p.M + 127) / 128) * 2 > 256 * 5) ? 92 : 93;
+      else pl.cfg = t128 * 2 > 1024 ? 91 : 93;
+      small = pl.cfg == 93;
     }
   }
   if (p.in_bf16 && g_tile_override == 0 && dma_ok && p.Cout > 32 && g_plan_mode == 0) {
@@ -1128,6 +1247,10 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 48: launch_v4<float, 1, 2, 2, 2, 16, 5>(p, st); break;  // 64 x 128
     case 49: launch_v4<float, 2, 1, 2, 2, 16, 5>(p, st); break;  // 128 x 64 at 5 workgroups/CU
     case 74: launch_v4<__bf16, 2, 2, 2, 2, 32, 4>(p, st); break; // 71 at 4 workgroups/CU
+    case 91: launch_v4<fp8_t, 2, 2, 2, 2, 64, 4>(p, st); break;  // e4m3 operands, v_mfma_f32_32x32x16_fp8_fp8: 128 x 128, 64-byte rows
+    case 92: launch_v4<fp8_t, 2, 1, 2, 2, 64, 5>(p, st); break;  //   128 x 64
+    case 93: launch_v4<fp8_t, 1, 1, 2, 2, 64, 6>(p, st); break;  //   64 x 64
+    case 94: launch_v4<fp8_t, 2, 2, 2, 2, 128, 2>(p, st); break; //   128 x 128, 128-byte rows
     case 81: launch_v4<__bf16, 2, 2, 4, 2, 32, 4>(p, st); break; // 8 waves, 256 x 128: 25 % less L2->LDS traffic per flop
     case 82: launch_v4<__bf16, 2, 2, 4, 4, 32, 4>(p, st); break; // 16 waves, 256 x 256: half the traffic per flop
     case 83: launch_v4<__bf16, 2, 2, 4, 2, 64, 2>(p, st); break; // 8 waves, 256 x 128, 128-byte rows
@@ -1155,7 +1278,11 @@ static void launch_reduce(const ConvParams &p, hipStream_t st) {
 
 static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStream_t st) {
   TileInfo ti;
-  if (p.in_bf16 && (!dma_applicable(p) || !(tile_info(pl.cfg, &ti) && pl.cfg >= 61))) {
+  if (p.in_fp8 && (!dma_applicable(p) || pl.cfg < 91 || pl.cfg > 94)) {
+    ivx_set_error("ivx_conv_fwd: fp8 input is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
+    return IVX_ERR_UNSUPPORTED;
+  }
+  if (p.in_bf16 && (!dma_applicable(p) || !(tile_info(pl.cfg, &ti) && pl.cfg >= 61 && pl.cfg < 91))) {
     ivx_set_error("ivx_conv_fwd: bf16 input is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;
   }
@@ -1189,7 +1316,7 @@ static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStrea
 // pointer offset.  Returns the number of samples per slice (B = no slicing needed or not possible).
 static int conv_batch_slice(const ConvParams &p) {
   if (dma_applicable(p) || p.B == 1 || p.KD > 8 || p.KH > 8 || p.KW > 8) return p.B;
-  const int el = p.in_bf16 ? 2 : 4;
+  const int el = p.in_fp8 ? 1 : (p.in_bf16 ? 2 : 4);
   const int64_t in_s = (int64_t)p.D * p.H * p.W * p.Cin * el;
   if ((int64_t)p.Cout * p.K * el >= (1LL << 31) || in_s >= (1LL << 31)) return p.B;
   const int64_t nb = ((1LL << 31) - 1) / in_s;
@@ -1198,7 +1325,7 @@ static int conv_batch_slice(const ConvParams &p) {
 
 static ConvParams conv_slice_params(const ConvParams &p, int b0, int nb) {
   ConvParams q = p;
-  const size_t in_el = p.in_bf16 ? 2 : 4, out_el = p.out_bf16 ? 2 : 4;
+  const size_t in_el = p.in_fp8 ? 1 : (p.in_bf16 ? 2 : 4), out_el = p.out_fp8 ? 1 : (p.out_bf16 ? 2 : 4);
   const size_t in_s = (size_t)p.D * p.H * p.W * p.Cin;
   const size_t out_s = p.out_mode == 1 ? (size_t)8 * p.D * p.H * p.W * p.Cr : (size_t)p.Do * p.Ho * p.Wo * p.Cout;
   q.B = nb;

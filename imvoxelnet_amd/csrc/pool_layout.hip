@@ -72,6 +72,67 @@ extern "C" int ivx_maxpool2d_fwd_bf16(const void *in, int32_t B, int32_t H, int3
   return maxpool2d_launch<__bf16>((const __bf16 *)in, B, H, W, C, k, s, p, (__bf16 *)out, stream);
 }
 
+// The same pool on e4m3 bytes (C % 16 == 0): one thread per (output pixel, 16 channels), one 16-byte load per tap.  The
+// maximum of representable values is representable, so decode -> max -> encode is exact; the per-tensor scale is unchanged.
+__global__ __launch_bounds__(256) void maxpool2d_nhwc_fp8_kernel(const unsigned char *in, int B, int H, int W, int C, int k, int s,
+                                                                 int pd, int Ho, int Wo, unsigned char *out) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int C16 = C >> 4;
+  const size_t total = (size_t)B * Ho * Wo * C16;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c16 = (int)(idx % C16);
+    size_t t = idx / C16;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float m[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m[q] = -INFINITY;
+    for (int e = 0; e < k; ++e) {
+      const int ih = oh * s - pd + e;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int f = 0; f < k; ++f) {
+        const int iw = ow * s - pd + f;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(in + (((size_t)b * H + ih) * W + iw) * C + c16 * 16);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], true);
+          const float x[4] = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) m[4 * w + q] = (x[q] > m[4 * w + q] || x[q] != x[q]) ? x[q] : m[4 * w + q];
+        }
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      int pk = __builtin_amdgcn_cvt_pk_fp8_f32(m[4 * w], m[4 * w + 1], 0, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(m[4 * w + 2], m[4 * w + 3], pk, true);
+      o[w] = (unsigned int)pk;
+    }
+    *reinterpret_cast<u32x4 *>(out + idx * 16) = o;
+  }
+}
+
+extern "C" int ivx_maxpool2d_fwd_fp8(const void *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s,
+                                     int32_t p, void *out, ivx_stream_t stream) {
+  IVX_REQUIRE(in && out, "ivx_maxpool2d_fwd_fp8: null argument");
+  IVX_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0, "ivx_maxpool2d_fwd_fp8: bad dims (C %% 16 must be 0)");
+  IVX_REQUIRE(k > 0 && s > 0 && p >= 0 && 2 * p <= k, "ivx_maxpool2d_fwd_fp8: bad window");
+  const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  IVX_REQUIRE(Ho > 0 && Wo > 0, "ivx_maxpool2d_fwd_fp8: empty output");
+  const size_t total = (size_t)B * Ho * Wo * (C / 16);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(maxpool2d_nhwc_fp8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char *)in, B, H, W,
+                     C, k, s, p, Ho, Wo, (unsigned char *)out);
+  IVX_CHECK_LAUNCH("ivx_maxpool2d_fwd_fp8");
+  return IVX_OK;
+}
+
 // [B,C,S] -> [B,S,Cpad] through a 32x33 LDS tile so both sides are coalesced.
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *in, int C, long long S, int Cpad, float *out) {
   __shared__ float tile[32][33];

@@ -45,6 +45,7 @@ class ImVoxelNet(nn.Module):
         self.voxel_size = tuple(float(v) for v in voxel_size)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.storage_dtype, self._prepared_device, self._native = None, None, None
+        self.trunk_fp8 = False
         # weights loaded AFTER prepare() (load_state_dict / data.load_checkpoint) must reach the packed device copies: the
         # sub-modules drop theirs (params.invalidate_packed_on_load), and the detector re-packs in the dtype it was prepared in
         self.register_load_state_dict_post_hook(
@@ -73,7 +74,7 @@ class ImVoxelNet(nn.Module):
                 m.prepare(device)
             if self.head_2d is not None:
                 self.head_2d.prepare(device)
-        self.storage_dtype, self._prepared_device = dtype, device
+        self.storage_dtype, self._prepared_device, self.trunk_fp8 = dtype, device, False
         import os
         from . import engine
         if native is None:
@@ -84,6 +85,37 @@ class ImVoxelNet(nn.Module):
         if native and dtype == torch.float32 and engine.eligible(self):
             self._native = engine.NativeModel(self, device)
         return self
+
+    def calibrate_fp8(self, img, margin=1.0):
+        """Optional, on top of prepare(device, dtype=torch.bfloat16) (BASELINE config 5: "bf16 with fp8 2D-conv MFMA"): store
+        the 2-D trunk's activations and weights as OCP e4m3 bytes.  One bf16 pass over `img` ([B,V,3,H,W] or [N,3,H,W], a
+        representative batch) records max |output| of every trunk layer; the layers are then rebuilt with per-tensor activation
+        scales amax * margin / 448 and per-output-channel weight scales folded into their epilogues (v_mfma_f32_32x32x16_fp8_fp8,
+        fp32 accumulate).  The FPN laterals read the e4m3 stage outputs and produce bf16; everything after the trunk is unchanged.
+        Weights loaded afterwards need a new calibration.  Returns {layer key: amax}."""
+        from .conv import FusedConv, storage_dtype, FP8
+        if self._prepared_device is None or self.storage_dtype != torch.bfloat16:
+            raise RuntimeError('calibrate_fp8 needs prepare(device, dtype=torch.bfloat16) first')
+        if self.head_2d is not None or not hasattr(self.backbone, 'forward_image'):
+            raise NotImplementedError('the fp8 trunk is built for the plain ResNet + FPN configurations without a LayoutHead')
+        dev = self._prepared_device
+        x = img.reshape([-1] + list(img.shape)[-3:]).contiguous().to(dev)
+        with storage_dtype(torch.bfloat16):          # a fresh bf16 trunk (a second calibration starts from bf16 again)
+            self.backbone.prepare(dev)
+        FusedConv.calib = {}
+        try:
+            self.backbone.forward_image(x)
+            torch.cuda.synchronize()
+            FusedConv.calib_margin = float(margin)
+            with storage_dtype(FP8):
+                self.backbone.prepare(dev)
+            with storage_dtype(torch.bfloat16):
+                self.neck.prepare(dev, in_dtype=FP8)
+            calib = dict(FusedConv.calib)
+        finally:
+            FusedConv.calib, FusedConv.calib_margin = None, 1.0
+        self.trunk_fp8 = True
+        return calib
 
     # ------------------------------------------------------------------ host-side camera set-up
     @staticmethod

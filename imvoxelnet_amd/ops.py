@@ -17,7 +17,8 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_DT = {torch.float32: 0, torch.bfloat16: 1}   # IVX_F32 / IVX_BF16
+FP8 = torch.float8_e4m3fn      # OCP e4m3 bytes with a per-tensor scale kept by the caller (conv.QTensor)
+_DT = {torch.float32: 0, torch.bfloat16: 1, FP8: 2}   # IVX_F32 / IVX_BF16 / IVX_FP8
 
 
 def _chk(t, name, dtype=torch.float32):
@@ -81,26 +82,27 @@ def from_channels_last(x, ndim_spatial=3):
 # ------------------------------------------------------------------ conv
 def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0), relu=False,
              res=None, res_mode=0, naive=False, out=None, wgt_layout=0, out_mode=0, res_after_act=False, post_scale=1.0,
-             out_dtype=None):
+             out_dtype=None, res_scale=1.0):
     """x [B,D,H,W,Cin], wgt [Cout,KD,KH,KW,Cin] (packed), scale/shift [Cout] -> [B,Do,Ho,Wo,Cout].
-    x and wgt are fp32 (the reference's precision) or both bf16; out_dtype (default: x.dtype) is the storage type of
+    x and wgt are fp32 (the reference's precision), both bf16, or both e4m3 bytes (torch.float8_e4m3fn; the caller folds the
+    tensors' scales into scale / shift / res_scale, see ivx_conv_desc); out_dtype (default: x.dtype) is the storage type of
     the output and of the residual.  Accumulation and the epilogue are fp32 in every case."""
     if x.dtype not in _DT:
-        raise TypeError(f'x must be float32 or bfloat16, got {x.dtype}')
+        raise TypeError(f'x must be float32, bfloat16 or float8_e4m3fn, got {x.dtype}')
     out_dtype = x.dtype if out_dtype is None else out_dtype
     if out_dtype not in _DT:
-        raise TypeError(f'out_dtype must be float32 or bfloat16, got {out_dtype}')
+        raise TypeError(f'out_dtype must be float32, bfloat16 or float8_e4m3fn, got {out_dtype}')
     _chk(x, 'x', x.dtype)
     _chk(wgt, 'wgt', x.dtype)
     B, D, H, W, Cin = x.shape
     Cout = wgt.shape[0]
-    ck = 64 if x.dtype == torch.bfloat16 else 32
+    ck = {torch.float32: 32, torch.bfloat16: 64, FP8: 128}[x.dtype]
     want = (kernel[0], kernel[1], kernel[2], Cin) if wgt_layout == 0 else (Cin // ck, kernel[0], kernel[1], kernel[2], ck)
     if tuple(wgt.shape[1:]) != want:
         raise ValueError(f'weight shape {tuple(wgt.shape)} does not match kernel {kernel} / Cin {Cin} / layout {wgt_layout}')
     d = ConvDesc(B, D, H, W, Cin, Cout, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
                  padding[0], padding[1], padding[2], int(bool(relu)), 0, 0, 0, int(wgt_layout), int(out_mode), int(bool(res_after_act)), float(post_scale),
-                 _DT[x.dtype], _DT[out_dtype])
+                 _DT[x.dtype], _DT[out_dtype], float(res_scale))
     do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
     L = _lib.lib()
     check(L.ivx_conv_out_dims(C.byref(d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')
@@ -273,14 +275,15 @@ def winograd_set_transform_blocks(n):
 
 def maxpool2d(x, k=3, s=2, p=1):
     if x.dtype not in _DT:
-        raise TypeError(f'x must be float32 or bfloat16, got {x.dtype}')
+        raise TypeError(f'x must be float32, bfloat16 or float8_e4m3fn, got {x.dtype}')
     _chk(x, 'x', x.dtype)
     B, D, H, W, Cn = x.shape
     if D != 1:
         raise ValueError('maxpool2d expects a 2-D map (D == 1)')
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     out = torch.empty((B, 1, Ho, Wo, Cn), device=x.device, dtype=x.dtype)
-    fn = _lib.lib().ivx_maxpool2d_fwd if x.dtype == torch.float32 else _lib.lib().ivx_maxpool2d_fwd_bf16
+    L = _lib.lib()
+    fn = {torch.float32: L.ivx_maxpool2d_fwd, torch.bfloat16: L.ivx_maxpool2d_fwd_bf16, FP8: L.ivx_maxpool2d_fwd_fp8}[x.dtype]
     check(fn(_ptr(x), B, H, W, Cn, k, s, p, _ptr(out), _stream()), 'ivx_maxpool2d_fwd')
     return out
 

@@ -68,6 +68,7 @@ const char *ivx_last_error(void);
  *   out_dtype IVX_BF16: out and res are bf16 (epilogue in fp32, one round-to-nearest-even at the store).  */
 #define IVX_F32 0
 #define IVX_BF16 1
+#define IVX_FP8 2      /* OCP e4m3 bytes (gfx950) with a per-tensor scale kept by the caller: see res_scale below */
 typedef struct ivx_conv_desc {
   int32_t B, D, H, W, Cin;
   int32_t Cout, KD, KH, KW;
@@ -81,8 +82,12 @@ typedef struct ivx_conv_desc {
                             (out is [B,2D,2H,2W,C]; scale/shift have C entries; res, if any, has the out shape) */
   int32_t res_after_act; /* 1: the residual is added after the ReLU (skip adds of the U-shaped necks) */
   float post_scale;      /* final multiplier, 0 or 1 = none (Atlas neck: (x + y) / 2) */
-  int32_t in_dtype;      /* IVX_F32 (default) or IVX_BF16: element type of in and wgt */
-  int32_t out_dtype;     /* IVX_F32 (default) or IVX_BF16: element type of out and res */
+  int32_t in_dtype;      /* IVX_F32 (default), IVX_BF16 or IVX_FP8: element type of in and wgt */
+  int32_t out_dtype;     /* IVX_F32 (default), IVX_BF16 or IVX_FP8: element type of out and res */
+  float res_scale;       /* multiplier of the residual before it is added, 0 or 1 = none.  IVX_FP8 tensors are e4m3 bytes with a
+                            per-tensor scale kept by the caller (x = byte_value * s_x): the caller folds s_in * s_wgt[co] / s_out
+                            into scale[], 1 / s_out into shift[] and passes res_scale = s_res / s_out; the store saturates at
+                            +-448 and rounds to nearest even.  fp8 input needs Cin % 16 == 0 (wgt_layout 1: Cin % 128 == 0). */
 } ivx_conv_desc;
 
 int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *Ho, int32_t *Wo);
@@ -162,6 +167,9 @@ int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t 
 /* Same on bf16 storage (optional reduced-precision mode; a max of bf16 values is exact). */
 int ivx_maxpool2d_fwd_bf16(const void *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
                            int32_t s, int32_t p, void *out, ivx_stream_t stream);
+/* The same pool on e4m3 bytes (IVX_FP8 storage; C % 16 == 0): exact, the tensor's scale is unchanged. */
+int ivx_maxpool2d_fwd_fp8(const void *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p,
+                          void *out, ivx_stream_t stream);
 
 /* F.interpolate(scale_factor=2, mode='trilinear', align_corners=False) on NDHWC [B,D,H,W,C] -> [B,2D,2H,2W,C]
  * (Atlas decoder of ImVoxelNeck, mmdet3d/models/necks/imvoxelnet.py:359).  C % 4 == 0. */

@@ -1123,3 +1123,94 @@ def test_bf16_stem_space_to_depth(ia):
         ref = F.relu(F.batch_norm(ref, net.bn1.running_mean, net.bn1.running_var, net.bn1.weight, net.bn1.bias, False, 0.0, 1e-5))
         assert y.dtype == bf and y.shape == (3, 1, hw[0] // 2, hw[1] // 2, 64)
         assert_close(f'stem s2d {hw}', uncl(y.float())[:, :, 0], ref, 2 ** -7, 2e-3)
+
+
+FP8_CASES = [
+    # name, B, Cin, H, W, Cout, k, stride, res, relu
+    ('f8_1x1_64_256_res', 2, 64, 24, 40, 256, 1, 1, True, True),
+    ('f8_1x1_256_64', 2, 256, 24, 40, 64, 1, 1, False, True),
+    ('f8_3x3_128_128', 1, 128, 20, 28, 128, 3, 1, False, True),
+    ('f8_3x3_64_64_s2', 1, 64, 30, 44, 64, 3, 2, False, False),
+    ('f8_1x1_512_2048_splitk', 1, 512, 6, 10, 2048, 1, 1, True, True),
+    ('f8_1x1_16_48', 1, 16, 9, 13, 48, 1, 1, False, False),
+]
+
+
+@pytest.mark.parametrize('case', FP8_CASES, ids=[c[0] for c in FP8_CASES])
+def test_conv_fp8_storage(ia, case):
+    """Optional e4m3 storage (BASELINE config 5 "fp8 2D-conv MFMA"; not the reference's precision): activations and weights as
+    OCP e4m3 bytes with per-tensor / per-output-channel scales (conv.QTensor), v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulate
+    and epilogue.  Reference = torch conv2d on the DEQUANTISED operands (products of e4m3 values are exact in fp32, so only
+    the summation order differs): 2e-4 with a bf16/fp32 output; with an e4m3 output the reference is quantised the same way
+    and at most a rounding boundary apart (one e4m3 ulp = 2^-3 relative, on < 2 % of the elements).  Also: MFMA kernel ==
+    validation kernel, wide 16-byte-store epilogue == one-byte-per-lane epilogue bit for bit, fp8 max-pool == torch."""
+    from imvoxelnet_amd import _lib, ops
+    from imvoxelnet_amd.conv import FusedConv, QTensor, FP8, FP8_MAX
+
+    def to_dev(q):          # e4m3 [B,C,H,W] (host) -> channels-last [B,1,H,W,C] e4m3 on the device
+        return q.view(torch.uint8).unsqueeze(2).permute(0, 2, 3, 4, 1).contiguous().cuda().view(FP8)
+
+    def to_host(d):         # channels-last e4m3 device [B,1,H,W,C] -> float [B,C,H,W] of the raw e4m3 values
+        return d.view(torch.uint8).permute(0, 4, 1, 2, 3).contiguous().cpu().view(FP8).float()[:, :, 0]
+    name, B, Cin, H, W, Cout, k, st, has_res, relu = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))      # (hash() of a str changes per process)
+    x = torch.randn(B, Cin, H, W, generator=g).abs() * 2.0
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    bnp = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1, torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5)
+    s_x = float(x.abs().max()) / FP8_MAX
+    xq = (x / s_x).to(FP8)
+    s_w = w.reshape(Cout, -1).abs().amax(1) / FP8_MAX
+    wq = (w / s_w.view(-1, 1, 1, 1)).to(FP8)
+    xd, wd = xq.float() * s_x, wq.float() * s_w.view(-1, 1, 1, 1)
+    ref = F.batch_norm(F.conv2d(xd, wd, None, st, k // 2), bnp[2], bnp[3], bnp[0], bnp[1], False, 0.0, 1e-5)
+    r = s_r = rq = None
+    if has_res:
+        r = torch.randn(ref.shape, generator=g).abs()
+        s_r = float(r.abs().max()) / FP8_MAX
+        rq = (r / s_r).to(FP8)
+        ref = ref + rq.float() * s_r
+    if relu:
+        ref = F.relu(ref)
+    xin = QTensor(to_dev(xq), s_x)
+    L = _lib.lib()
+    for out_dtype in (torch.bfloat16, FP8):
+        FusedConv.calib = {'k': float(ref.abs().max())}
+        try:
+            fc = FusedConv(w, None, bnp, stride=st, padding=k // 2, relu=relu, dims=2, dtype=FP8, out_dtype=out_dtype, key='k').to('cuda')
+        finally:
+            FusedConv.calib = None
+        assert torch.equal(fc._w_host.view(torch.uint8).reshape(-1).sort()[0], wq.view(torch.uint8).reshape(-1).sort()[0]), 'weight quantisation'
+        res = None
+        if has_res:
+            res = QTensor(to_dev(rq), s_r) if out_dtype == FP8 else None
+            if res is None:
+                continue                    # the residual has the output's storage type; the bf16-out + fp8-res mix is not a trunk case
+        y = fc(xin, res=res)
+        yn = fc(xin, res=res, naive=True)
+        if out_dtype == FP8:
+            assert isinstance(y, QTensor) and y.data.dtype == FP8
+            got, gotn = to_host(y.data) * y.scale, to_host(yn.data) * y.scale
+            want = (ref / y.scale).clamp(-FP8_MAX, FP8_MAX).to(FP8).float() * y.scale
+            for nm, a, b in (('mfma-vs-torch', got, want), ('mfma-vs-naive', got, gotn)):
+                diff = (a - b).abs()
+                ulp = torch.maximum(a.abs(), b.abs()) * 2 ** -3 + y.scale * 2 ** -9
+                if not bool((diff <= ulp).all()):
+                    i = int((diff / ulp).argmax())
+                    raise AssertionError(f'{name} {nm}: beyond one e4m3 ulp: {float(a.reshape(-1)[i]) / y.scale} vs {float(b.reshape(-1)[i]) / y.scale} '
+                                         f'(pre-rounding reference {float(ref.reshape(-1)[i]) / y.scale}), {int((diff > ulp).sum())} elements')
+                assert float((diff > 0).float().mean()) < 0.02, f'{name} {nm}: {float((diff > 0).float().mean()):.4f} of the elements differ'
+            L.ivx_conv_set_epilogue_mode(1)
+            try:
+                y_narrow = fc(xin, res=res)
+            finally:
+                L.ivx_conv_set_epilogue_mode(0)
+            assert torch.equal(y.data.view(torch.uint8), y_narrow.data.view(torch.uint8))
+        else:
+            assert y.dtype == torch.bfloat16
+            assert_close(name + ' bf16-out mfma-vs-torch', uncl(y.float())[:, :, 0], ref, 2 ** -7, 2e-3)
+            assert_close(name + ' bf16-out mfma-vs-naive', uncl(y.float()), uncl(yn.float()), 2 ** -7, 1e-3)
+    # max-pool on e4m3 bytes
+    if Cin % 16 == 0:
+        mp = ops.maxpool2d(xin.data, 3, 2, 1)
+        want = F.max_pool2d(xq.float(), 3, 2, 1)
+        assert torch.equal(to_host(mp), want)

@@ -449,3 +449,50 @@ def test_indoor_bf16_storage_mode_tracks_fp32(ia, cfg_name):
     print(cfg_name, 'detections', na, nb)
     assert na > 0 and abs(na - nb) <= max(5, na // 4)
     assert abs(float(a[3][0]['scores_3d'].max()) - float(b[3][0]['scores_3d'].max())) < 0.05
+
+
+@pytest.mark.parametrize('cfg_name,views', [('scannet_v1', 4), ('scannet_fast', 3)])
+def test_fp8_trunk_tracks_bf16(ia, cfg_name, views):
+    import kitti_cfg as kc
+    """BASELINE config 5's "bf16 with fp8 2D-conv MFMA": ImVoxelNet.calibrate_fp8 stores the ResNet-50 activations and weights
+    as e4m3 (per-tensor / per-output-channel scales from one calibration pass) on top of the bf16 mode.  Not the reference's
+    precision -- the check is that the FPN level-0 map and the detections track the bf16 mode of the same weights: FPN map
+    within 6 % of its max magnitude (rms within 1.5 %), the lifted volume likewise, and most detections shared."""
+    mcfg = getattr(kc, f'{cfg_name}_model_cfg')()
+    model = ia.build_detector(mcfg, test_cfg=dict(getattr(kc, f'{cfg_name.upper()}_TEST_CFG')))
+    ia.randomize_(model, 41)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        model.bbox_head.cls_conv.weight.normal_(0, 0.01, generator=g)
+        model.bbox_head.cls_conv.bias.fill_(-2.0)
+        model.bbox_head.centerness_conv.weight.normal_(0, 0.005, generator=g)
+        model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
+    img = torch.randn(1, views, 3, 480, 640, generator=torch.Generator().manual_seed(2)).cuda()
+    metas = [kc.indoor_meta(views, box_type=ia.DepthInstance3DBoxes)]
+    model.prepare(torch.device('cuda'), dtype=torch.bfloat16)
+    p0_bf = model.features_2d_cl(img).float()
+    vol_bf, valid_bf = model.lift_cl(model.features_2d_cl(img), metas)
+    calib = model.calibrate_fp8(img)
+    assert model.trunk_fp8 and len(calib) >= 53
+    p0 = model.features_2d_cl(img)
+    assert p0.dtype == torch.bfloat16
+    vol, valid = model.lift_cl(p0, metas)
+    assert torch.equal(valid, valid_bf)
+    for nm, a, b in (('fpn0', p0.float(), p0_bf), ('volume', vol.float(), vol_bf.float())):
+        mx = float(b.abs().max())
+        err, rms = float((a - b).abs().max()) / mx, float((a - b).pow(2).mean().sqrt()) / mx
+        rel = float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+        print(f'{cfg_name} fp8 trunk vs bf16: {nm} max err {err:.4f} of max, rms {rms:.5f} of max, {rel:.4f} of the signal rms')
+        assert err < 0.25 and rms < 0.04 and rel < 0.2, (nm, err, rms, rel)
+    res = model.simple_test(img, metas)
+    assert len(res) == 1 and len(res[0]['scores_3d']) > 0
+    # the image generator of a second, different batch runs through the calibrated trunk as well (scales are static)
+    img2 = torch.randn(1, views, 3, 480, 640, generator=torch.Generator().manual_seed(3)).cuda()
+    p0_2 = model.features_2d_cl(img2).float()
+    model.prepare(torch.device('cuda'), dtype=torch.bfloat16)
+    assert not model.trunk_fp8
+    ref2 = model.features_2d_cl(img2).float()
+    mx = float(ref2.abs().max())
+    rel2 = float((p0_2 - ref2).pow(2).mean().sqrt() / ref2.pow(2).mean().sqrt())
+    print(f'{cfg_name} fp8 trunk, second batch with the first batch\'s scales: {rel2:.4f} of the signal rms')
+    assert rel2 < 0.25

@@ -28,7 +28,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) <= declared
     assert L.ivx_version() >= 100
     # struct layouts used by the ctypes binding match the header field counts
-    assert ctypes.sizeof(_lib.ConvDesc) == 25 * 4     # ivx_conv_desc: 22 int32 + float + 2 int32 dtypes
+    assert ctypes.sizeof(_lib.ConvDesc) == 26 * 4     # ivx_conv_desc: 22 int32 + float + 2 int32 dtypes + float res_scale
     assert ctypes.sizeof(_lib.AnchorHeadDesc) == 17 * 4
 
 
@@ -791,3 +791,46 @@ def test_all_gather_detections_ragged_shards_gloo_world2():
     for rank, ok, err in res:
         assert ok, f'rank {rank}: reassembled batch differs'
         assert 'global_batch' in err
+
+
+def test_stem_space_to_depth_weights_are_the_same_convolution():
+    """bf16 / fp8 modes: backbones.stem_s2d_weights re-indexes the 7x7 stride-2 pad-3 stem as a 4x4 stride-1 pad-1 convolution
+    over 2x2 space-to-depth blocks (block p = pixels 2p-1, 2p; the layout ivx_image_s2d_bf16 writes).  In fp32 on the host the
+    two convolutions agree to rounding on even-sized images."""
+    import torch.nn.functional as F
+    from imvoxelnet_amd.backbones import stem_s2d_weights
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(8, 3, 7, 7, generator=g)
+    for hw in ((12, 18), (30, 22)):
+        img = torch.randn(2, 3, *hw, generator=g)
+        ref = F.conv2d(img, w, None, 2, 3)
+        pad = F.pad(img, (1, 1, 1, 1))
+        PH, PW = hw[0] // 2 + 1, hw[1] // 2 + 1
+        blocks = torch.stack([pad[:, :, a::2, e::2][:, :, :PH, :PW] for a in (0, 1) for e in (0, 1)], 1).reshape(2, 12, PH, PW)
+        blocks = torch.cat([blocks, torch.zeros(2, 4, PH, PW)], 1)
+        got = F.conv2d(blocks, stem_s2d_weights(w), None, 1, 1)
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-4
+
+
+def test_fp8_weight_quantisation_and_qtensor_host_side():
+    """Optional e4m3 storage: FusedConv(dtype=FP8) quantises its filters per output channel (max |w| -> 448, round to nearest)
+    and packs them in 16-byte chunks of 16 channels (128-channel chunk-major order when Cin % 128 == 0); a layer with an e4m3
+    output refuses to be built without a calibration record.  No device needed."""
+    from imvoxelnet_amd.conv import FusedConv, QTensor, FP8, FP8_MAX
+    g = torch.Generator().manual_seed(4)
+    for cin, layout in ((128, 1), (64, 0)):
+        w = torch.randn(32, cin, 3, 3, generator=g) * 0.1
+        fc = FusedConv(w, dims=2, padding=1, dtype=FP8, out_dtype=torch.bfloat16)
+        assert fc.layout == layout and fc._w_host.dtype == FP8 and fc.w_scale.shape == (32,)
+        wp = fc._w_host.float()
+        if layout == 1:      # [co, chunk, kd, kh, kw, 128] -> [co, kd, kh, kw, cin]
+            wp = wp.permute(0, 2, 3, 4, 1, 5).reshape(32, 1, 3, 3, cin)
+        deq = wp.permute(0, 4, 1, 2, 3)[:, :, 0] * fc.w_scale.view(-1, 1, 1, 1)
+        assert float(((deq - w).abs() / w.abs().amax(dim=(1, 2, 3), keepdim=True)).max()) <= 2 ** -4 + 1e-6     # half an e4m3 ulp of the row maximum
+        assert torch.allclose(fc.w_scale, w.reshape(32, -1).abs().amax(1) / FP8_MAX)
+    with pytest.raises(RuntimeError, match='calibration'):
+        FusedConv(torch.randn(32, 64, 1, 1, generator=g), dims=2, dtype=FP8, out_dtype=FP8)
+    with pytest.raises(ValueError, match='multiple of 16'):
+        FusedConv(torch.randn(32, 24, 1, 1, generator=g), dims=2, dtype=FP8, out_dtype=torch.bfloat16)
+    q = QTensor(torch.tensor([1.0, 2.0]).to(FP8), 0.5)
+    assert torch.equal(q.float(), torch.tensor([0.5, 1.0])) and q.shape == (2,)

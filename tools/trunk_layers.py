@@ -20,17 +20,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', default='scannet_fast')
     ap.add_argument('--top', type=int, default=30)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'fp8'])
     a = ap.parse_args()
     cfg, shape = {'kitti': (kc.kitti_model_cfg(), (4, 1, 3, 384, 1280)), 'scannet_fast': (kc.scannet_fast_model_cfg(), (1, 50, 3, 480, 640)),
                   'scannet_v1': (kc.scannet_v1_model_cfg(), (1, 50, 3, 480, 640))}[a.config]
     model = ia.build_detector(cfg, test_cfg=dict(nms_pre=100, max_num=50, use_rotate_nms=True, nms_thr=.1, score_thr=.1, iou_thr=.25))
     ia.randomize_(model, 0)
     from imvoxelnet_amd.conv import storage_dtype
-    with storage_dtype(torch.bfloat16 if a.dtype == 'bf16' else torch.float32):
-        model.backbone.prepare(torch.device('cuda'))
-        model.neck.prepare(torch.device('cuda'))
+    if a.dtype == 'fp8':
+        model.prepare(torch.device('cuda'), dtype=torch.bfloat16)
+    else:
+        with storage_dtype(torch.bfloat16 if a.dtype == 'bf16' else torch.float32):
+            model.backbone.prepare(torch.device('cuda'))
+            model.neck.prepare(torch.device('cuda'))
     img = torch.randn(*shape, generator=torch.Generator().manual_seed(1)).cuda()
+    if a.dtype == 'fp8':
+        model.calibrate_fp8(img)
     for _ in range(2):
         model.features_2d_cl(img)
     agg = collections.OrderedDict()
@@ -49,7 +54,7 @@ def main():
             d[3] += t[4]
     rows = [(k, v[0] / reps, v[1] / reps, v[2] / reps, v[3] / reps) for k, v in agg.items()]
     total = sum(r[2] for r in rows)
-    floor = sum(max(r[4] / 5.5e12, r[3] / ((1500e12 if a.dtype == 'bf16' else 140e12))) for r in rows) * 1e3
+    floor = sum(max(r[4] / 5.5e12, r[3] / ((1500e12 if a.dtype != 'f32' else 140e12))) for r in rows) * 1e3
     print(f'# floor at 5.5 TB/s / {"1500" if a.dtype == "bf16" else "140"} TFLOP/s per launch: {floor:.3f} ms; algorithmic bytes {sum(r[4] for r in rows) / 1e9:.2f} GB')
     print(f'# {a.config} {a.dtype}: trunk launches per step, {total:.3f} ms of conv-stage time per step, executed {sum(r[3] for r in rows) / 1e9:.1f} GFLOP')
     print('| layer shape | stage | launches | ms/step | % | TFLOP/s executed | GB/s algorithmic |')
