@@ -118,8 +118,8 @@ def bench_other(args, ia, kc, dev, rank, world):
     if args.trunk_fp8:
         if args.storage != 'bf16':
             raise SystemExit('--trunk-fp8 goes on top of --storage bf16 (BASELINE config 5: "bf16 with fp8 2D-conv MFMA")')
-        model.calibrate_fp8(img)               # one bf16 pass over the batch: per-tensor activation scales
-        fp8_note = 'ResNet-50 activations and weights stored as e4m3 (calibrated per-tensor / per-channel scales), v_mfma_f32_32x32x16_fp8_fp8'
+        model.calibrate_fp8(img, stages=args.fp8_stages)   # one bf16 pass over the batch: per-tensor activation scales
+        fp8_note = 'ResNet-50 activations and weights stored as e4m3 (calibrated per-tensor / per-channel scales; stages: %s), v_mfma_f32_32x32x16_fp8_fp8' % ('all' if args.fp8_stages is None else args.fp8_stages)
     n = args.steps + args.warmup
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     neck_flops, neck_exec = [0.0], [0.0]    # direct-convolution FLOPs / FLOPs executed (fewer for Winograd-form layers)
@@ -297,6 +297,7 @@ def main():
     ap.add_argument('--shard', default='samples', choices=['samples', 'views'],
                     help="multi-GPU partition: 'samples' (default; weak scaling, the headline mode) or 'views' (indoor multi-view "
                          "configs: the views of each scene are split over the ranks, one RCCL all-reduce of the partial volume; strong scaling)")
+    ap.add_argument('--fp8-stages', type=int, default=None, help='--trunk-fp8: how many leading ResNet stages store e4m3 (default: all four)')
     ap.add_argument('--trunk-fp8', action='store_true', help='with --storage bf16 and an indoor --config: e4m3 storage of the 2-D trunk (calibrated on the bench batch)')
     ap.add_argument('--graph', action='store_true',
                     help='replay the device side of the step as one captured hipGraph (kitti config); the roofline entry is then '

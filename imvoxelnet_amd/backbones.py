@@ -34,9 +34,13 @@ class _Bottleneck(nn.Module):
         else:
             self.downsample = None
 
-    def prepare(self, device):
+    def prepare(self, device, in_dtype=None):
+        """in_dtype: storage type of the block's INPUT when it differs from the block's own (the first bf16 block after the e4m3
+        stages of the fp8 trunk): conv1 and the shortcut conv read it."""
+        from .conv import current_storage_dtype
+        sd = current_storage_dtype()
         # style='pytorch': the stride sits on the 3x3 conv
-        self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2).to(device)
+        self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2, dtype=in_dtype or sd, out_dtype=sd).to(device)
         if self.dcn:
             from .conv import current_storage_dtype
             if current_storage_dtype() != torch.float32:
@@ -51,7 +55,10 @@ class _Bottleneck(nn.Module):
         self.f3 = FusedConv(self.conv3.weight, bn=self.bn3.tensors(), relu=True, dims=2).to(device)  # relu after the add
         self.fd = None
         if self.downsample is not None:
-            self.fd = FusedConv(self.downsample[0].weight, bn=self.downsample[1].tensors(), stride=self.stride, dims=2).to(device)
+            self.fd = FusedConv(self.downsample[0].weight, bn=self.downsample[1].tensors(), stride=self.stride, dims=2,
+                                dtype=in_dtype or sd, out_dtype=sd).to(device)
+        elif in_dtype is not None and in_dtype != sd:
+            raise ValueError('a block without a shortcut conv keeps the storage type of its input')
 
     def forward_cl(self, x):
         idt = x if self.fd is None else self.fd(x)
@@ -77,6 +84,7 @@ def stem_s2d_weights(w):
 @BACKBONES.register_module()
 class ResNet(nn.Module):
     arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+    fp8_stages = None      # fp8 trunk (detector.calibrate_fp8): how many leading stages store e4m3 (None: all)
 
     def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_cfg=None, norm_eval=True,
                  style='pytorch', in_channels=3, dcn=None, stage_with_dcn=(False, False, False, False), **kwargs):
@@ -139,9 +147,19 @@ class ResNet(nn.Module):
             w2 = stem_s2d_weights(w)
             self.stem_s2d = FusedConv(w2, bn=self.bn1.tensors(), stride=1, padding=1, relu=True, dims=2, dtype=torch.bfloat16,
                                       out_dtype=FP8 if fp8 else torch.bfloat16, key=id(self.conv1.weight)).to(device)
+        # fp8 trunk: the first `fp8_stages` stages store e4m3, the rest bf16 (their residual streams carry 8 mantissa bits
+        # again; the first block of the first bf16 stage reads e4m3).  stage_dtypes: storage type of every stage's OUTPUT.
+        from .conv import storage_dtype
+        n8 = self.num_stages if fp8 and ResNet.fp8_stages is None else (ResNet.fp8_stages if fp8 else 0)
+        self.stage_dtypes = []
+        prev = current_storage_dtype()
         for i in range(self.num_stages):
-            for blk in getattr(self, f'layer{i + 1}'):
-                blk.prepare(device)
+            sd = current_storage_dtype() if not fp8 else (FP8 if i < n8 else torch.bfloat16)
+            with storage_dtype(sd):
+                for j, blk in enumerate(getattr(self, f'layer{i + 1}')):
+                    blk.prepare(device, in_dtype=prev if (j == 0 and prev != sd) else None)
+            self.stage_dtypes.append(sd)
+            prev = sd
         self._device = device
         return self
 
@@ -206,11 +224,13 @@ class FPN(nn.Module):
         pass
 
     def prepare(self, device, in_dtype=None):
-        """in_dtype: storage type of the backbone's stage outputs when it differs from the FPN's own (the fp8 trunk: e4m3 in,
-        the FPN's storage type -- bf16 -- out)."""
+        """in_dtype: storage type(s) of the backbone's stage outputs when they differ from the FPN's own (the fp8 trunk: e4m3 in,
+        the FPN's storage type -- bf16 -- out); one type or a list per level."""
         from .conv import current_storage_dtype
         od = current_storage_dtype()
-        self.flat = [FusedConv(m.conv.weight, m.conv.bias, dims=2, dtype=in_dtype or od, out_dtype=od).to(device) for m in self.lateral_convs]
+        ind = list(in_dtype) if isinstance(in_dtype, (list, tuple)) else [in_dtype] * len(self.lateral_convs)
+        self.flat = [FusedConv(m.conv.weight, m.conv.bias, dims=2, dtype=ind[i] or od, out_dtype=od).to(device)
+                     for i, m in enumerate(self.lateral_convs)]
         self.fout = [FusedConv(m.conv.weight, m.conv.bias, padding=1, dims=2).to(device) for m in self.fpn_convs]
         self._device = device
         return self

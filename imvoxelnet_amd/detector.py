@@ -86,7 +86,7 @@ class ImVoxelNet(nn.Module):
             self._native = engine.NativeModel(self, device)
         return self
 
-    def calibrate_fp8(self, img, margin=1.0):
+    def calibrate_fp8(self, img, margin=1.0, stages=None):
         """Optional, on top of prepare(device, dtype=torch.bfloat16) (BASELINE config 5: "bf16 with fp8 2D-conv MFMA"): store
         the 2-D trunk's activations and weights as OCP e4m3 bytes.  One bf16 pass over `img` ([B,V,3,H,W] or [N,3,H,W], a
         representative batch) records max |output| of every trunk layer; the layers are then rebuilt with per-tensor activation
@@ -107,13 +107,15 @@ class ImVoxelNet(nn.Module):
             self.backbone.forward_image(x)
             torch.cuda.synchronize()
             FusedConv.calib_margin = float(margin)
+            type(self.backbone).fp8_stages = stages       # None: all four stages; n: the first n (the rest keep a bf16 residual stream)
             with storage_dtype(FP8):
                 self.backbone.prepare(dev)
             with storage_dtype(torch.bfloat16):
-                self.neck.prepare(dev, in_dtype=FP8)
+                self.neck.prepare(dev, in_dtype=[self.backbone.stage_dtypes[i] for i in self.backbone.out_indices])
             calib = dict(FusedConv.calib)
         finally:
             FusedConv.calib, FusedConv.calib_margin = None, 1.0
+            type(self.backbone).fp8_stages = None
         self.trunk_fp8 = True
         return calib
 
