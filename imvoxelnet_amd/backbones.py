@@ -84,7 +84,6 @@ def stem_s2d_weights(w):
 @BACKBONES.register_module()
 class ResNet(nn.Module):
     arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
-    fp8_stages = None      # fp8 trunk (detector.calibrate_fp8): how many leading stages store e4m3 (None: all)
 
     def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_cfg=None, norm_eval=True,
                  style='pytorch', in_channels=3, dcn=None, stage_with_dcn=(False, False, False, False), **kwargs):
@@ -150,7 +149,8 @@ class ResNet(nn.Module):
         # fp8 trunk: the first `fp8_stages` stages store e4m3, the rest bf16 (their residual streams carry 8 mantissa bits
         # again; the first block of the first bf16 stage reads e4m3).  stage_dtypes: storage type of every stage's OUTPUT.
         from .conv import storage_dtype
-        n8 = self.num_stages if fp8 and ResNet.fp8_stages is None else (ResNet.fp8_stages if fp8 else 0)
+        n_req = getattr(self, 'fp8_stages', None)      # set by detector.calibrate_fp8(stages=...); None: all stages
+        n8 = 0 if not fp8 else (self.num_stages if n_req is None else max(0, min(int(n_req), self.num_stages)))
         self.stage_dtypes = []
         prev = current_storage_dtype()
         for i in range(self.num_stages):

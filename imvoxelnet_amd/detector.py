@@ -107,7 +107,7 @@ class ImVoxelNet(nn.Module):
             self.backbone.forward_image(x)
             torch.cuda.synchronize()
             FusedConv.calib_margin = float(margin)
-            type(self.backbone).fp8_stages = stages       # None: all four stages; n: the first n (the rest keep a bf16 residual stream)
+            self.backbone.fp8_stages = stages             # None: all four stages; n: the first n (the rest keep a bf16 residual stream)
             with storage_dtype(FP8):
                 self.backbone.prepare(dev)
             with storage_dtype(torch.bfloat16):
@@ -115,7 +115,6 @@ class ImVoxelNet(nn.Module):
             calib = dict(FusedConv.calib)
         finally:
             FusedConv.calib, FusedConv.calib_margin = None, 1.0
-            type(self.backbone).fp8_stages = None
         self.trunk_fp8 = True
         return calib
 
