@@ -229,3 +229,62 @@ def test_native_levels_equal_layerwise_indoor(ia, cfg_name, views):
     # the anchor entry points refuse an indoor handle, loudly
     with pytest.raises(ValueError, match='ivx_model_forward_levels'):
         model._native.forward(img.reshape(B * views, 3, *hw).contiguous(), B, views, hw[0], hw[1], proj, new_origin, crop)
+
+
+def test_edge_cases_no_detections_and_no_valid_voxels(ia):
+    """Edge cases of the whole path through the public call: (a) no anchor above score_thr -> empty results ([0, 7] boxes, empty
+    scores / labels) for every sample, on the native handle and layer by layer alike; (b) a camera that sees none of the voxels ->
+    valid mask all False, a zero volume, and the indoor tail still returns (every score is 0: the candidate top-k degenerates to
+    204 800 ties, taken in index order by both top-k forms); (c) samples of one batch with different un-padded image sizes (crop)."""
+    from imvoxelnet_amd import _lib
+    # (a)
+    model = _kitti_model(ia, (104, 120, 12))
+    with torch.no_grad():
+        model.bbox_head.conv_cls.bias.fill_(-30.0)
+    model.prepare(torch.device('cuda'))
+    hw = (192, 640)
+    img = torch.randn(2, 1, 3, *hw, generator=torch.Generator().manual_seed(3)).cuda()
+    metas = [kc.kitti_meta(img_hw=hw, box_type=ia.LiDARInstance3DBoxes) for _ in range(2)]
+    assert model._native is not None
+    res = model.simple_test(img, metas)
+    p0 = model.features_2d_cl(img)
+    vol, valid = model.lift_cl(p0, metas)
+    ref = model.detect_cl(vol, metas)
+    assert int(ref[3].sum()) == 0
+    for r in res:
+        assert tuple(r['boxes_3d'].tensor.shape) == (0, 7) and r['scores_3d'].numel() == 0 and r['labels_3d'].numel() == 0
+    # (c) the second sample's image is smaller inside the same padded batch
+    metas_c = [kc.kitti_meta(img_hw=hw, box_type=ia.LiDARInstance3DBoxes), kc.kitti_meta(img_hw=(160, 608), box_type=ia.LiDARInstance3DBoxes)]
+    metas_c[1]['pad_shape'] = (hw[0], hw[1], 3)
+    with torch.no_grad():
+        model.bbox_head.conv_cls.bias.fill_(-1.5)
+    model.prepare(torch.device('cuda'))
+    proj, new_origin, crop = model._camera_setup(metas_c, 4, img.device)
+    assert crop.tolist() == [[48, 160], [40, 152]]
+    out = model._native.forward(img.reshape(2, 3, *hw).contiguous(), 2, 1, hw[0], hw[1], proj, new_origin, crop, want_valid=True)
+    vol_c, valid_c = model.lift_cl(model.features_2d_cl(img), metas_c)
+    _assert_same_detections(out[:4], model.detect_cl(vol_c, metas_c))
+    assert torch.equal(out[4], valid_c) and int(valid_c[1].sum()) < int(valid_c[0].sum())
+    # (b)
+    m2 = ia.build_detector(kc.scannet_fast_model_cfg(), test_cfg=dict(kc.SCANNET_FAST_TEST_CFG))
+    ia.randomize_(m2, 12)
+    m2.prepare(torch.device('cuda'))
+    V = 2
+    img2 = torch.randn(1, V, 3, 480, 640, generator=torch.Generator().manual_seed(4)).cuda()
+    meta = kc.indoor_meta(V, box_type=ia.DepthInstance3DBoxes)
+    far = np.eye(4, dtype=np.float32)
+    far[2, 3] = -100.0                        # every voxel ends up behind the camera (z < 0): nothing projects
+    meta['lidar2img']['extrinsic'] = [far.copy() for _ in range(V)]
+    out = {}
+    for mode in (0, 1):
+        _lib.lib().ivx_topk_set_mode(mode)
+        try:
+            out[mode] = m2.simple_test(img2, [meta])
+        finally:
+            _lib.lib().ivx_topk_set_mode(0)
+    p0 = m2.features_2d_cl(img2)
+    vol2, valid2 = m2.lift_cl(p0, [meta])
+    assert not bool(valid2.any()) and float(vol2.abs().max()) == 0.0
+    a, b = out[0][0], out[1][0]
+    assert torch.equal(a['scores_3d'], b['scores_3d']) and torch.equal(a['boxes_3d'].tensor, b['boxes_3d'].tensor) and torch.equal(a['labels_3d'], b['labels_3d'])
+    assert bool(torch.isfinite(a['boxes_3d'].tensor).all())
