@@ -101,9 +101,11 @@ __device__ __noinline__ size_t res2_row_base(int m, int Ho, int Wo, int rH, int 
 // y = act(acc*scale + shift [+ res]) [+ res] [* post_scale] for one output element; `oidx` is its flat offset.
 __device__ __forceinline__ float conv_finish(const ConvParams &p, float acc, float sc, float sf, size_t ridx) {
   float v = acc * sc + sf;
-  if (p.res_mode && !p.res_after_act) v += conv_ld_res(p, ridx) * p.res_scale;     // res_scale is 1 outside the fp8 mode (exact)
+  // one fused multiply-add, spelled out so that every epilogue variant rounds the same way; res_scale is 1 outside the fp8 mode,
+  // where fma(r, 1, v) == v + r exactly
+  if (p.res_mode && !p.res_after_act) v = __builtin_fmaf(conv_ld_res(p, ridx), p.res_scale, v);
   if (p.relu) v = v > 0.f ? v : 0.f;
-  if (p.res_mode && p.res_after_act) v += conv_ld_res(p, ridx) * p.res_scale;
+  if (p.res_mode && p.res_after_act) v = __builtin_fmaf(conv_ld_res(p, ridx), p.res_scale, v);
   return v * p.post_scale;
 }
 
@@ -327,14 +329,20 @@ __device__ __forceinline__ void conv_epilogue_wide_fp8(const ConvParams &p, f32x
           f32x4 r = {0.f, 0.f, 0.f, 0.f};
           if (p.res_mode) {
             const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)rb[w], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)rb[w], true);
-            r[0] = lo[0] * p.res_scale; r[1] = lo[1] * p.res_scale; r[2] = hi[0] * p.res_scale; r[3] = hi[1] * p.res_scale;
+            r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
           }
-          if (p.res_mode && !p.res_after_act) v += r;
+          if (p.res_mode && !p.res_after_act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(r[e], p.res_scale, v[e]);     // as conv_finish
+          }
           if (p.relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
-          if (p.res_mode && p.res_after_act) v += r;
+          if (p.res_mode && p.res_after_act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(r[e], p.res_scale, v[e]);
+          }
           v *= p.post_scale;
           ob[w] = f32x2_to_fp8(v[0], v[1]) | (f32x2_to_fp8(v[2], v[3]) << 16);
         }

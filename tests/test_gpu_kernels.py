@@ -2,6 +2,8 @@
 import hashlib
 import json
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1142,7 +1144,8 @@ def test_conv_fp8_storage(ia, case):
     OCP e4m3 bytes with per-tensor / per-output-channel scales (conv.QTensor), v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulate
     and epilogue.  Reference = torch conv2d on the DEQUANTISED operands (products of e4m3 values are exact in fp32, so only
     the summation order differs): 2e-4 with a bf16/fp32 output; with an e4m3 output the reference is quantised the same way
-    and at most a rounding boundary apart (one e4m3 ulp = 2^-3 relative, on < 2 % of the elements).  Also: MFMA kernel ==
+    and at most a rounding boundary apart (one e4m3 ulp = 2^-3 relative, on < 3 % of the elements; plus 1e-4 of the output range
+    for the fp8 MFMA's own accumulation error).  Also: MFMA kernel ==
     validation kernel, wide 16-byte-store epilogue == one-byte-per-lane epilogue bit for bit, fp8 max-pool == torch."""
     from imvoxelnet_amd import _lib, ops
     from imvoxelnet_amd.conv import FusedConv, QTensor, FP8, FP8_MAX
@@ -1153,7 +1156,7 @@ def test_conv_fp8_storage(ia, case):
     def to_host(d):         # channels-last e4m3 device [B,1,H,W,C] -> float [B,C,H,W] of the raw e4m3 values
         return d.view(torch.uint8).permute(0, 4, 1, 2, 3).contiguous().cpu().view(FP8).float()[:, :, 0]
     name, B, Cin, H, W, Cout, k, st, has_res, relu = case
-    g = torch.Generator().manual_seed(sum(map(ord, name)))      # (hash() of a str changes per process)
+    g = torch.Generator().manual_seed(sum(map(ord, name)) + int(os.environ.get('IVX_TEST_SEED_OFFSET', '0')))   # (hash() of a str changes per process)
     x = torch.randn(B, Cin, H, W, generator=g).abs() * 2.0
     w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
     bnp = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1, torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5)
@@ -1193,12 +1196,16 @@ def test_conv_fp8_storage(ia, case):
             want = (ref / y.scale).clamp(-FP8_MAX, FP8_MAX).to(FP8).float() * y.scale
             for nm, a, b in (('mfma-vs-torch', got, want), ('mfma-vs-naive', got, gotn)):
                 diff = (a - b).abs()
-                ulp = torch.maximum(a.abs(), b.abs()) * 2 ** -3 + y.scale * 2 ** -9
+                # one e4m3 step (2^-3 relative; 2^-9 of the scale among the subnormals) + the accumulation error of the fp8 MFMA
+                # itself: the instruction sums a k-block's products to ~2^-15 of their magnitude, not to fp32 precision (measured:
+                # 3.7e-5 of max |out| against 1.1e-7 for an fp32 fma chain, tools/fp8_mfma_precision.py) -- visible only where the
+                # output nearly cancels, i.e. among the subnormals
+                ulp = torch.maximum(a.abs(), b.abs()) * 2 ** -3 + y.scale * 2 ** -9 + 1e-4 * float(ref.abs().max())
                 if not bool((diff <= ulp).all()):
                     i = int((diff / ulp).argmax())
                     raise AssertionError(f'{name} {nm}: beyond one e4m3 ulp: {float(a.reshape(-1)[i]) / y.scale} vs {float(b.reshape(-1)[i]) / y.scale} '
                                          f'(pre-rounding reference {float(ref.reshape(-1)[i]) / y.scale}), {int((diff > ulp).sum())} elements')
-                assert float((diff > 0).float().mean()) < 0.02, f'{name} {nm}: {float((diff > 0).float().mean()):.4f} of the elements differ'
+                assert float((diff > 0).float().mean()) < 0.03, f'{name} {nm}: {float((diff > 0).float().mean()):.4f} of the elements differ'
             L.ivx_conv_set_epilogue_mode(1)
             try:
                 y_narrow = fc(xin, res=res)
