@@ -149,7 +149,6 @@ class FusedConv:
                 raise RuntimeError('fp8 output needs a calibration record for this layer (FusedConv.calib; see ImVoxelNet.calibrate_fp8)')
             self.out_scale = max(float(FusedConv.calib[self.key]), 1e-12) * FusedConv.calib_margin / FP8_MAX
         self._qvec = {}                # (in_scale, out_scale) -> device (scale, shift) with the tensor scales folded in
-        self._res_scale = 1.0
         self.dtype, self.out_dtype = dtype, out_dtype
         if dims == 2:
             w = w.unsqueeze(2)
@@ -229,16 +228,13 @@ class FusedConv:
             sc = self._scale_host * (self.w_scale if self.w_scale is not None else 1.0) * (s_in / s_out)
             vec = self._qvec[(s_in, s_out)] = (sc.float().contiguous().to(self.w.device), (self._shift_host / s_out).float().contiguous().to(self.w.device))
         rd = res.data if isinstance(res, QTensor) else res
-        keep = (self.scale, self.shift, self._res_scale)
-        self.scale, self.shift = vec
-        self._res_scale = ((res.scale if isinstance(res, QTensor) else 1.0) / s_out) if res is not None else 1.0
-        try:
-            y = self._call(xd, rd, res_mode, relu, naive, res_after_act, post_scale)
-        finally:
-            self.scale, self.shift, self._res_scale = keep
+        res_scale = ((res.scale if isinstance(res, QTensor) else 1.0) / s_out) if res is not None else 1.0
+        y = self._call(xd, rd, res_mode, relu, naive, res_after_act, post_scale, epi=(vec[0], vec[1], res_scale))
         return QTensor(y, s_out) if self.out_dtype == FP8 else y
 
-    def _call(self, x, res, res_mode, relu, naive, res_after_act, post_scale):
+    def _call(self, x, res, res_mode, relu, naive, res_after_act, post_scale, epi=None):
+        """epi: (scale, shift, res_scale) of this call when they differ from the layer's own (the quantised modes: the tensors'
+        scales folded in); the direct kernel only -- the Winograd form is fp32."""
         B = x.shape[0]
         m, xs, wk, wst, wpad = self.wino_tile(tuple(x.shape), x.dtype, res_mode, naive)
         wino = m > 0
@@ -270,7 +266,7 @@ class FusedConv:
         if FusedConv.trace is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
+            y = self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale, epi)
             e1.record()
             FusedConv.trace.append(('direct', e0, e1, 2.0 * y.numel() * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
                                     if self.out_mode == 0 else 2.0 * x.numel() * self.cout,
@@ -278,7 +274,7 @@ class FusedConv:
                                           + (res.numel() * res.element_size() if res is not None else 0)),     # algorithmic bytes
                                     x.shape[1] > 1 and x.shape[3] > 1, self._describe(x, 0)))
             return y
-        return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale)
+        return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale, epi)
 
     def wino_tile(self, x_shape, dtype=torch.float32, res_mode=0, naive=False):
         """-> (m, xs, wk, wst, wpad): m = tile of the F(m x m, 3x3) form this layer takes for an input of shape x_shape
@@ -305,11 +301,12 @@ class FusedConv:
             self.u[tile] = ops.conv_winograd_weights(self._w0, self.layout, tile)
         return self.u[tile]
 
-    def _direct(self, x, res, res_mode, relu, naive, res_after_act, post_scale):
-        return ops.conv_fwd(x, self.w, self.scale, self.shift, self.kernel, self.stride, self.padding,
+    def _direct(self, x, res, res_mode, relu, naive, res_after_act, post_scale, epi=None):
+        scale, shift, res_scale = epi if epi is not None else (self.scale, self.shift, 1.0)
+        return ops.conv_fwd(x, self.w, scale, shift, self.kernel, self.stride, self.padding,
                             self.relu if relu is None else relu, res, res_mode, naive=naive, wgt_layout=self.layout,
                             out_mode=self.out_mode, res_after_act=res_after_act, post_scale=post_scale,
-                            out_dtype=self.out_dtype, res_scale=self._res_scale)
+                            out_dtype=self.out_dtype, res_scale=res_scale)
 
 
 
