@@ -297,9 +297,10 @@ void build_neck_fast(ivx_model *m, int t_in) {
 void build_neck_unet(ivx_model *m, int t_in) {
   m->neck0 = (int)m->steps.size();
   const int *ch = m->cfg.unet_channels, *dl = m->cfg.unet_down_layers, *ul = m->cfg.unet_up_layers;
+  const int n = ch[3] > 0 ? 4 : 3;                   // encoder scales (the reference configs use 4; 3 = a two-level decoder)
   int x = t_in;
   std::vector<int> xs;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < n; ++i) {
     const std::string pre = "neck_3d.model.layers_down." + std::to_string(i) + ".";
     int k0 = 0;
     if (i > 0) {
@@ -310,21 +311,21 @@ void build_neck_unet(ivx_model *m, int t_in) {
     xs.push_back(x);
   }
   std::vector<int> out;                              // coarse -> fine
-  for (int i = 0; i < 3; ++i) {
-    const int c_in = ch[3 - i], c_out = ch[2 - i];
+  for (int i = 0; i < n - 1; ++i) {
+    const int c_in = ch[n - 1 - i], c_out = ch[n - 2 - i];
     const std::string pu = "neck_3d.model.layers_up_conv." + std::to_string(i) + ".", pp = "neck_3d.model.proj." + std::to_string(i) + ".";
     x = add_upsample(m, x);
     x = add_conv(m, conv3d_k(pu, c_in, c_out, 1, 1, 0, false, pu + "weight", "", ""), x);
-    x = add_conv(m, conv3d_k(pp + "conv", c_out, c_out, 1, 1, 0, true, pp + "conv.weight", "", pp + "norm"), xs[2 - i], x, 1);
+    x = add_conv(m, conv3d_k(pp + "conv", c_out, c_out, 1, 1, 0, true, pp + "conv.weight", "", pp + "norm"), xs[n - 2 - i], x, 1);
     m->steps.back().res_after_act = 1;               // (x + relu(bn(conv(skip)))) / 2   (:366-367)
     m->steps.back().post_scale = 0.5f;
     for (int j = 0; j < ul[i]; ++j) x = add_block3d(m, "neck_3d.model.layers_up_res." + std::to_string(i) + "." + std::to_string(j) + ".", c_out, x);
     out.push_back(x);
   }
-  std::vector<int> lv(3, -1);
-  for (int l = 0; l < 3; ++l) {                      // level l (finest first) = out[2 - l]
+  std::vector<int> lv(n - 1, -1);
+  for (int l = 0; l < n - 1; ++l) {                  // level l (finest first) = out[n - 2 - l]
     const std::string pb = "neck_3d.conv_blocks." + std::to_string(l) + ".";
-    lv[l] = add_conv(m, conv3d_k(pb + "0", ch[l], m->cfg.neck_out_channels, 3, 1, 1, true, pb + "0.weight", pb + "0.bias", pb + "1"), out[2 - l]);
+    lv[l] = add_conv(m, conv3d_k(pb + "0", ch[l], m->cfg.neck_out_channels, 3, 1, 1, true, pb + "0.weight", pb + "0.bias", pb + "1"), out[n - 2 - l]);
   }
   m->t_levels = lv;
   m->neck1 = (int)m->steps.size();
@@ -845,8 +846,9 @@ extern "C" int ivx_create(const ivx_model_cfg *cfg, ivx_model **out) {
     M_REQUIRE(cfg->fast_n_blocks[0] >= 1 && cfg->fast_n_blocks[1] >= 1 && cfg->fast_n_blocks[2] >= 1, "ivx_create: fast_n_blocks must be >= 1 per level");
   if (cfg->neck_type == IVX_NECK_UNET) {
     M_REQUIRE(cfg->unet_channels[0] == cfg->fpn_channels, "ivx_create: unet_channels[0] must equal fpn_channels");
-    for (int i = 0; i < 4; ++i) M_REQUIRE(cfg->unet_channels[i] > 0 && cfg->unet_channels[i] % 4 == 0 && cfg->unet_down_layers[i] >= 0, "ivx_create: bad unet_channels / unet_down_layers");
-    for (int i = 0; i < 3; ++i) M_REQUIRE(cfg->unet_up_layers[i] >= 0, "ivx_create: bad unet_up_layers");
+    const int nu = cfg->unet_channels[3] > 0 ? 4 : 3;     // 4 scales (the reference configs) or 3 (unet_channels[3] = 0)
+    for (int i = 0; i < nu; ++i) M_REQUIRE(cfg->unet_channels[i] > 0 && cfg->unet_channels[i] % 4 == 0 && cfg->unet_down_layers[i] >= 0, "ivx_create: bad unet_channels / unet_down_layers");
+    for (int i = 0; i < nu - 1; ++i) M_REQUIRE(cfg->unet_up_layers[i] >= 0, "ivx_create: bad unet_up_layers");
   }
   M_REQUIRE(cfg->fpn_channels > 0 && cfg->fpn_channels % 4 == 0 && cfg->neck_out_channels > 0 && cfg->neck_out_channels % 4 == 0,
             "ivx_create: channel counts must be positive multiples of 4");
@@ -1083,10 +1085,12 @@ extern "C" int ivx_neck3d_nuscenes_fwd(ivx_model *m, const float *volume, int32_
 // ---- indoor necks: three levels
 extern "C" int ivx_neck3d_levels(ivx_model *m, int32_t B, int32_t dims[3][4]) {
   M_REQUIRE(m && dims && B > 0, "ivx_neck3d_levels: bad argument");
-  M_REQUIRE(m->t_levels.size() == 3, "ivx_neck3d_levels: the handle holds a stack neck; use ivx_neck3d_out_dims");
+  M_REQUIRE(!m->t_levels.empty(), "ivx_neck3d_levels: the handle holds a stack neck; use ivx_neck3d_out_dims");
   Plan *pl;
   M_TRY(plan_neck(m, B, &pl, nullptr));
   for (int l = 0; l < 3; ++l) {
+    dims[l][0] = dims[l][1] = dims[l][2] = dims[l][3] = 0;      // a 3-scale U-Net has two levels: the third entry stays 0
+    if (l >= (int)m->t_levels.size()) continue;
     const TInfo &o = pl->t[m->t_levels[l]];
     dims[l][0] = o.D; dims[l][1] = o.H; dims[l][2] = o.W; dims[l][3] = o.C;
   }
@@ -1095,13 +1099,14 @@ extern "C" int ivx_neck3d_levels(ivx_model *m, int32_t B, int32_t dims[3][4]) {
 
 static int neck_levels_fwd(ivx_model *m, int want_type, const float *volume, int32_t B, float *const out_levels[3], void *workspace,
                            int64_t workspace_bytes, ivx_stream_t stream, const char *who) {
-  M_REQUIRE(m && volume && out_levels && out_levels[0] && out_levels[1] && out_levels[2] && B > 0, "%s: bad argument", who);
+  M_REQUIRE(m && volume && out_levels && B > 0, "%s: bad argument", who);
   M_REQUIRE(m->cfg.neck_type == want_type, "%s: the handle holds another neck", who);
+  for (size_t l = 0; l < m->t_levels.size(); ++l) M_REQUIRE(out_levels[l], "%s: null output level %d", who, (int)l);
   Plan *pl;
   M_TRY(plan_neck(m, B, &pl, (hipStream_t)stream));
   Bind bd;
   bd.ext[m->t_volume] = (void *)volume;
-  for (int l = 0; l < 3; ++l) bd.ext[m->t_levels[l]] = out_levels[l];
+  for (size_t l = 0; l < m->t_levels.size(); ++l) bd.ext[m->t_levels[l]] = out_levels[l];
   return run_steps(m, *pl, {m->neck0, m->neck1}, bd, workspace, workspace_bytes, (hipStream_t)stream, who);
 }
 
@@ -1119,14 +1124,15 @@ extern "C" int ivx_model_forward_levels(ivx_model *m, const float *input, int32_
                                         const float *new_origin, const int32_t *crop_hw, void *workspace, int64_t workspace_bytes,
                                         float *const out_levels[3], uint8_t *out_valid, ivx_stream_t stream) {
   M_TRY(check_img(m, B, V, H, W, "ivx_model_forward_levels"));
-  M_REQUIRE(input && out_levels && out_levels[0] && out_levels[1] && out_levels[2], "ivx_model_forward_levels: null argument");
-  M_REQUIRE(m->t_levels.size() == 3, "ivx_model_forward_levels: the handle holds a stack neck + anchor head; use ivx_model_forward");
+  M_REQUIRE(input && out_levels, "ivx_model_forward_levels: null argument");
+  M_REQUIRE(!m->t_levels.empty(), "ivx_model_forward_levels: the handle holds a stack neck + anchor head; use ivx_model_forward");
+  for (size_t l = 0; l < m->t_levels.size(); ++l) M_REQUIRE(out_levels[l], "ivx_model_forward_levels: null output level %d", (int)l);
   Plan *pl; Range r;
   M_TRY(plan_forward(m, B, V, H, W, &pl, &r, (hipStream_t)stream));
   Bind bd;
   bd.ext[m->cfg.with_trunk ? m->t_img : m->t_fpn0] = (void *)input;
   if (out_valid) bd.ext[m->t_valid] = out_valid;
-  for (int l = 0; l < 3; ++l) bd.ext[m->t_levels[l]] = out_levels[l];
+  for (size_t l = 0; l < m->t_levels.size(); ++l) bd.ext[m->t_levels[l]] = out_levels[l];
   bd.proj = proj; bd.new_origin = new_origin; bd.crop = crop_hw; bd.V = V;
   return run_steps(m, *pl, r, bd, workspace, workspace_bytes, (hipStream_t)stream, "ivx_model_forward_levels");
 }

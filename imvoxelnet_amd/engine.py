@@ -39,7 +39,7 @@ def family(model):
     if isinstance(n3, FastIndoorImVoxelNeck):
         return 'levels' if n3.n_scales == 3 else None
     if isinstance(n3, ImVoxelNeck):
-        return 'levels' if len(n3.model.channels) == 4 else None
+        return 'levels' if len(n3.model.channels) in (3, 4) else None
     if not isinstance(n3, (KittiImVoxelNeck, NuScenesImVoxelNeck)) or not isinstance(model.bbox_head, Anchor3DHead):
         return None
     g = model.bbox_head.anchor_generator
@@ -86,9 +86,10 @@ def model_cfg(model, with_trunk=True, winograd=None, winograd_tile=None):
     else:
         cfg.neck_type = 3
         cfg.neck_out_channels = n3.conv_blocks[0][0].weight.shape[0]
-        cfg.unet_channels[:] = list(n3.model.channels)
-        cfg.unet_down_layers[:] = [sum(isinstance(b, BasicBlock3d) for b in layer) for layer in n3.model.layers_down]
-        cfg.unet_up_layers[:] = [len(seq) for seq in n3.model.layers_up_res]
+        pad = lambda v, n: list(v) + [0] * (n - len(v))        # a 3-scale U-Net leaves the last entries 0
+        cfg.unet_channels[:] = pad(n3.model.channels, 4)
+        cfg.unet_down_layers[:] = pad([sum(isinstance(b, BasicBlock3d) for b in layer) for layer in n3.model.layers_down], 4)
+        cfg.unet_up_layers[:] = pad([len(seq) for seq in n3.model.layers_up_res], 3)
     cfg.winograd = int(FusedConv.winograd if winograd is None else winograd)
     cfg.winograd_tile = int(FusedConv.winograd_tile if winograd_tile is None else winograd_tile)
     return cfg
@@ -140,7 +141,7 @@ class NativeModel:
             else:
                 dims = ((C.c_int32 * 4) * 3)()
                 check(L.ivx_neck3d_levels(h, 1, dims), 'ivx_neck3d_levels')
-                self.level_dims = [tuple(d) for d in dims]         # (X, Y, Z, C) per level, finest first
+                self.level_dims = [tuple(d) for d in dims if d[3] > 0]    # (X, Y, Z, C) per level, finest first
         self._ws = {}
         self._static = {}          # graph mode: stable input / output buffers per shape
         self._gstream = torch.cuda.Stream(device=self.device) if self.graph else None   # the default stream cannot be captured
@@ -213,7 +214,7 @@ class NativeModel:
 
     def _level_buffers(self, B, dev):
         outs = [torch.empty((B, X, Y, Z, Cn), device=dev, dtype=torch.float32) for X, Y, Z, Cn in self.level_dims]
-        return outs, (C.c_void_p * 3)(*[o.data_ptr() for o in outs])
+        return outs, (C.c_void_p * 3)(*([o.data_ptr() for o in outs] + [None] * (3 - len(outs))))
 
     def forward_levels(self, x, B, V, H, W, proj, new_origin, crop_hw):
         """Indoor families: x as for forward -> ([level0, level1, level2] channels-last [B,X_l,Y_l,Z_l,Cout] finest first,

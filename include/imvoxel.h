@@ -410,7 +410,7 @@ typedef struct ivx_model_cfg {
                                  stable buffers -- a host that passes new pointers every call gains nothing */
   /* indoor necks (zero for the outdoor ones; the anchor / test_cfg fields above are ignored for them) */
   int32_t fast_n_blocks[3];        /* FastIndoorImVoxelNeck(n_blocks) */
-  int32_t unet_channels[4];        /* ImVoxelNeck(channels); [0] = fpn_channels */
+  int32_t unet_channels[4];        /* ImVoxelNeck(channels); [0] = fpn_channels; [3] = 0: three scales (two output levels) */
   int32_t unet_down_layers[4];     /* ImVoxelNeck(n_blocks, "down"), e.g. 1,2,3,4 */
   int32_t unet_up_layers[3];       /* ImVoxelNeck(n_blocks, "up") in decode order (coarse first), e.g. 3,2,1 */
 } ivx_model_cfg;
@@ -438,7 +438,7 @@ int ivx_neck3d_kitti_fwd(ivx_model *m, const float *volume, int32_t B, float *ou
                          ivx_stream_t stream);
 int ivx_neck3d_nuscenes_fwd(ivx_model *m, const float *volume, int32_t B, float *out, void *workspace,
                             int64_t workspace_bytes, ivx_stream_t stream);
-/* Indoor necks: three output levels, finest first, channels-last [B, X_l, Y_l, Z_l, Cout] (neck_3d(x) of
+/* Indoor necks: three output levels (two for a 3-scale ImVoxelNeck: the unused entry is ignored / zero), finest first, channels-last [B, X_l, Y_l, Z_l, Cout] (neck_3d(x) of
  * detectors/imvoxelnet.py:79 for FastIndoorImVoxelNeck / ImVoxelNeck).  dims[l] = {X, Y, Z, C} of level l.
  * State-dict keys: neck_3d.down_layer_{i}.{j}.{conv1,norm1,conv2,norm2,downsample.0,downsample.1}.*,
  * neck_3d.up_block_{1,2}.{0,1,3,4}.*, neck_3d.out_block_{i}.{0,1}.* (fast); neck_3d.model.layers_down.*,

@@ -288,3 +288,81 @@ def test_edge_cases_no_detections_and_no_valid_voxels(ia):
     a, b = out[0][0], out[1][0]
     assert torch.equal(a['scores_3d'], b['scores_3d']) and torch.equal(a['boxes_3d'].tensor, b['boxes_3d'].tensor) and torch.equal(a['labels_3d'], b['labels_3d'])
     assert bool(torch.isfinite(a['boxes_3d'].tensor).all())
+
+
+@pytest.mark.parametrize('name', ['kitti', 'nuscenes', 'fast', 'atlas'])
+def test_native_handle_necks_vs_reference_golden(ia, name):
+    """The four neck builders of the native handle (csrc/model.cpp) driven through the C-ABI alone -- ivx_create, the reference's
+    state-dict keys via ivx_weights_load, ivx_neck3d_{kitti,nuscenes,fast,unet}_fwd -- against the imported reference modules'
+    outputs (tests/golden/necks.npz): the same 1e-3 / 1e-4 bar as the Python composition's test_neck_golden."""
+    import ctypes as C
+    from helpers import load_npz
+    from gpu_util import assert_close
+    from imvoxelnet_amd import _lib
+    from imvoxelnet_amd._lib import ModelCfg, check
+    L = _lib.lib()
+    g = load_npz('necks.npz')
+    x = torch.from_numpy(g[name + '::x']).cuda()                                   # [B, C, X, Y, Z]
+    B, Cin, X, Y, Z = x.shape
+    cfg = ModelCfg()
+    cfg.neck_type = {'kitti': 0, 'nuscenes': 1, 'fast': 2, 'atlas': 3}[name]
+    cfg.with_trunk, cfg.fpn_channels, cfg.winograd = 0, Cin, 1
+    cfg.neck_out_channels = 4 if name == 'atlas' else 8
+    cfg.n_voxels[:] = [X, Y, Z]
+    cfg.voxel_size[:] = [.1, .1, .1]
+    if name in ('kitti', 'nuscenes'):           # the anchor head of these handles is not exercised here: any valid settings
+        cfg.num_classes, cfg.n_sizes, cfg.n_rotations, cfg.nms_pre, cfg.max_num = 1, 1, 2, 10, 5
+        cfg.anchor_range[:] = [0, 0, 0, 1, 1, 0]
+        cfg.anchor_sizes[:3] = [1, 1, 1]
+        cfg.anchor_rotations[:2] = [0, 1.57]
+    if name == 'fast':
+        cfg.fast_n_blocks[:] = [1, 1, 1]
+    if name == 'atlas':
+        cfg.unet_channels[:] = [4, 8, 16, 0]
+        cfg.unet_down_layers[:] = [1, 2, 2, 0]
+        cfg.unet_up_layers[:] = [2, 1, 0]
+    h = C.c_void_p()
+    check(L.ivx_create(C.byref(cfg), C.byref(h)), 'ivx_create')
+    try:
+        keep = []
+        for k in g.files:
+            if not k.startswith(name + '::sd::') or 'num_batches_tracked' in k:
+                continue
+            a = np.ascontiguousarray(g[k], dtype=np.float32)
+            keep.append(a)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            check(L.ivx_weights_load(h, ('neck_3d.' + k.split('::sd::')[1]).encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim), k)
+        if name in ('kitti', 'nuscenes'):       # the fused head conv of the handle wants its three tensors: zeros
+            for key, co in (('bbox_head.conv_cls', 2), ('bbox_head.conv_reg', 14), ('bbox_head.conv_dir_cls', 4)):
+                for sfx, shp in (('.weight', (co, 8, 1, 1)), ('.bias', (co,))):
+                    a = np.zeros(shp, np.float32)
+                    keep.append(a)
+                    check(L.ivx_weights_load(h, (key + sfx).encode(), a.ctypes.data_as(C.c_void_p), (C.c_int64 * len(shp))(*shp), len(shp)), key)
+        check(L.ivx_weights_finalize(h, None), 'ivx_weights_finalize')
+        vol = x.permute(0, 2, 3, 4, 1).contiguous()                                  # channels-last [B, X, Y, Z, C]
+        n = L.ivx_neck3d_workspace_bytes(h, B)
+        assert n > 0, L.ivx_last_error()
+        ws = torch.empty((n,), device='cuda', dtype=torch.uint8)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if name in ('kitti', 'nuscenes'):
+            Xo, Yo, Co = C.c_int32(), C.c_int32(), C.c_int32()
+            check(L.ivx_neck3d_out_dims(h, B, C.byref(Xo), C.byref(Yo), C.byref(Co)), 'ivx_neck3d_out_dims')
+            out = torch.empty((B, Xo.value, Yo.value, 1, Co.value), device='cuda')
+            fn = L.ivx_neck3d_kitti_fwd if name == 'kitti' else L.ivx_neck3d_nuscenes_fwd
+            check(fn(h, C.c_void_p(vol.data_ptr()), B, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), n, st), 'neck fwd')
+            got = [out[:, :, :, 0].permute(0, 3, 2, 1)]                              # the reference returns [B, C, Y', X'] (necks/imvoxelnet.py:120)
+        else:
+            dims = ((C.c_int32 * 4) * 3)()
+            check(L.ivx_neck3d_levels(h, B, dims), 'ivx_neck3d_levels')
+            outs = [torch.empty((B, d[0], d[1], d[2], d[3]), device='cuda') for d in dims if d[3] > 0]
+            ptrs = (C.c_void_p * 3)(*([o.data_ptr() for o in outs] + [None] * (3 - len(outs))))
+            fn = L.ivx_neck3d_fast_fwd if name == 'fast' else L.ivx_neck3d_unet_fwd
+            check(fn(h, C.c_void_p(vol.data_ptr()), B, ptrs, C.c_void_p(ws.data_ptr()), n, st), 'neck fwd')
+            got = [o.permute(0, 4, 1, 2, 3) for o in outs]
+        torch.cuda.synchronize()
+        n_out = len([k for k in g.files if k.startswith(name + '::y')])
+        assert len(got) == n_out
+        for i, y in enumerate(got):
+            assert_close(f'{name} native neck level {i}', y.contiguous().cpu().numpy(), g[f'{name}::y{i}'], 1e-3, 1e-4)
+    finally:
+        L.ivx_destroy(h)
