@@ -358,6 +358,8 @@ def main():
         if world > 1 or force_dist:
             dist.destroy_process_group()
         return
+    if args.trunk_fp8:
+        raise SystemExit('--trunk-fp8 is wired for the multi-view indoor configs (--config scannet_v1 | scannet_fast), where the 2-D trunk is the step')
     model = ia.build_detector(kitti_model_cfg(), test_cfg=KITTI_TEST_CFG)
     ia.randomize_(model, 0)
     with torch.no_grad():   # trained-net-like head statistics so the NMS tail has real work
