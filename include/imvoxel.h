@@ -39,7 +39,7 @@ typedef void *ivx_stream_t; /* hipStream_t */
 
 /* Library version (major*10000 + minor*100 + patch) and the message of the last failing
  * call on this thread (never NULL). */
-int ivx_version(void);
+int ivx_version(void);   /* major*1000 + minor*100 + patch: 200 = 0.2.0 (struct layouts of this header) */
 const char *ivx_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
