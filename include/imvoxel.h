@@ -37,9 +37,9 @@ extern "C" {
 
 typedef void *ivx_stream_t; /* hipStream_t */
 
-/* Library version (major*10000 + minor*100 + patch) and the message of the last failing
- * call on this thread (never NULL). */
-int ivx_version(void);   /* major*1000 + minor*100 + patch: 200 = 0.2.0 (struct layouts of this header) */
+/* Library version (major*10000 + minor*100 + patch; 200 = 0.2.0, the struct layouts of this header) and the message of
+ * the last failing call on this thread (never NULL). */
+int ivx_version(void);
 const char *ivx_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
