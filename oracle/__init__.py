@@ -21,6 +21,11 @@ Pinning status (see DESIGN.md "Oracle"):
              imported reference + the reference's own test vectors)
   partial  : rotated-BEV overlap (reference test_box3d.py known answers,
              rtol 1e-4); nms_gpu greedy scan (restated, CUDA op cannot run here)
+  cpu_abi/  : the SAME C-ABI as the product (include/imvoxel.h) served by a CPU restatement -- cpu_ops.cpp (op-level
+             entry points on host memory) under the product's csrc/model.cpp compiled unchanged against a host-memory stand-in
+             of the HIP runtime (cpu_abi/hip/); built into oracle/_cpuabi/libimvoxel_cpu.so by cpu_abi/build.py.  The CPU
+             tests run the model-level handle and the Python-free C host (tests/c/e2e_small.c) on it against the reference's
+             goldens.  Loaded by tests/ only.
   UNPINNED : ResNet-50 / FPN (mmdet 2.10.0 + torchvision, absent from the
              reference tree and this image) -- restated from the public
              architecture; DCNv2 (mmcv-full 1.2.7) not built.

@@ -1,0 +1,380 @@
+// TEST INFRASTRUCTURE (oracle/).  A CPU restatement of the op-level entry points of include/imvoxel.h -- the SAME C-ABI
+// (names, argument meaning, status codes) served from host memory, so that csrc/model.cpp (the model-level handle: layer graph,
+// weight packing, planning) and tests/c/e2e_small.c can be built and run WITHOUT a GPU: SURVEY 8d "same ABI served by the CPU
+// restatement".  Built by oracle/cpu_abi/build.py into oracle/_cpuabi/libimvoxel_cpu.so; only tests/ load it.  The product
+// (imvoxelnet_amd/_lib.py) loads csrc/libimvoxel_hip.so and nothing else -- there is no CPU fallback.
+//
+// Each function restates the HIP kernel of the same name (file cited per function), which in turn cites the reference lines it
+// replaces.  fp32 only; plain loops + OpenMP, separate multiply and add (-ffp-contract=off), so results differ from the MFMA
+// kernels by summation order only; the geometry (unprojection, decoding, rotated NMS) uses the same operation order as the HIP
+// kernels and the C oracle (oracle/ivx_oracle.c, linked in for the rotated-box geometry).
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/imvoxel.h"
+
+void ivx_set_error(const char *fmt, ...);          // csrc/api_common.cpp
+
+extern "C" {                                      // oracle/ivx_oracle.c
+int ivxo_nms_rotated_sorted(const float *boxes, int n, float thr, int64_t *keep);
+int ivxo_nms_normal_sorted(const float *boxes, int n, float thr, int64_t *keep);
+void ivxo_boxes_overlap_bev(const float *a, int na, const float *b, int nb, float *out);
+void ivxo_boxes_iou_bev(const float *a, int na, const float *b, int nb, float *out);
+int ivxo_aligned_3d_nms(const float *boxes, const float *scores, const int64_t *classes, const int64_t *order, int n, float thresh,
+                        int64_t *pick);
+}
+
+#define C_REQUIRE(cond, ...)      \
+  do {                            \
+    if (!(cond)) {                \
+      ivx_set_error(__VA_ARGS__); \
+      return IVX_ERR_INVALID_ARG; \
+    }                             \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------- convolution (csrc/conv_igemm.hip)
+extern "C" int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *Ho, int32_t *Wo) {
+  C_REQUIRE(d && Do && Ho && Wo, "ivx_conv_out_dims: null argument");
+  const int od = (d->D + 2 * d->pd - d->KD) / d->sd + 1, oh = (d->H + 2 * d->ph - d->KH) / d->sh + 1, ow = (d->W + 2 * d->pw - d->KW) / d->sw + 1;
+  C_REQUIRE(d->D + 2 * d->pd >= d->KD && d->H + 2 * d->ph >= d->KH && d->W + 2 * d->pw >= d->KW && od > 0 && oh > 0 && ow > 0,
+            "ivx_conv_out_dims: kernel larger than padded input");
+  *Do = od; *Ho = oh; *Wo = ow;
+  return IVX_OK;
+}
+
+extern "C" int64_t ivx_conv_workspace_bytes(const ivx_conv_desc *d) { return d ? 0 : -1; }
+
+// nearest-upsampled residual row (res_mode 2), as res2_row_base of the HIP kernel
+static size_t res2_row(int m, int Ho, int Wo, int rH, int rW, int Cout) {
+  const int ow = m % Wo, t = m / Wo, oh = t % Ho, b = t / Ho;
+  int sh_ = (Ho == rH) ? oh : (Ho == 2 * rH ? (oh >> 1) : (int)floorf(oh * ((float)rH / Ho)));
+  int sw_ = (Wo == rW) ? ow : (Wo == 2 * rW ? (ow >> 1) : (int)floorf(ow * ((float)rW / Wo)));
+  sh_ = sh_ < rH - 1 ? sh_ : rH - 1;
+  sw_ = sw_ < rW - 1 ? sw_ : rW - 1;
+  return (((size_t)b * rH + sh_) * rW + sw_) * Cout;
+}
+
+extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in_, const void *wgt_, const float *scale, const float *shift,
+                               const void *res_, void *out_, void *workspace, int64_t workspace_bytes, ivx_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  C_REQUIRE(d && in_ && wgt_ && out_, "ivx_conv_fwd: null argument");
+  C_REQUIRE(d->in_dtype == IVX_F32 && d->out_dtype == IVX_F32, "ivx_conv_fwd (CPU restatement): fp32 only");
+  C_REQUIRE(d->Cin % 4 == 0, "ivx_conv_fwd: Cin (%d) must be a multiple of 4 (pad the input channels)", d->Cin);
+  C_REQUIRE(d->wgt_layout == 0 || (d->wgt_layout == 1 && d->Cin % 32 == 0), "ivx_conv_fwd: wgt_layout 1 needs Cin %% 32 == 0");
+  C_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2 && (d->res_mode == 0 || res_), "ivx_conv_fwd: bad res_mode / null res");
+  int32_t Do, Ho, Wo;
+  if (ivx_conv_out_dims(d, &Do, &Ho, &Wo) != IVX_OK) return IVX_ERR_INVALID_ARG;
+  const float *in = (const float *)in_, *wgt = (const float *)wgt_, *res = (const float *)res_;
+  float *out = (float *)out_;
+  const int Cin = d->Cin, Cout = d->Cout, ntap = d->KD * d->KH * d->KW;
+  const int64_t K = (int64_t)ntap * Cin, M = (int64_t)d->B * Do * Ho * Wo;
+  const int Cr = d->out_mode == 1 ? Cout / 8 : Cout;
+  const float post = d->post_scale == 0.f ? 1.0f : d->post_scale, rs = d->res_scale == 0.f ? 1.0f : d->res_scale;
+#pragma omp parallel for schedule(static)
+  for (int64_t m = 0; m < M; ++m) {
+    const int ow = (int)(m % Wo);
+    int64_t t = m / Wo;
+    const int oh = (int)(t % Ho);
+    t /= Ho;
+    const int od = (int)(t % Do), b = (int)(t / Do);
+    std::vector<float> acc(Cout, 0.f);
+    for (int a = 0; a < d->KD; ++a) {
+      const int id = od * d->sd - d->pd + a;
+      if ((unsigned)id >= (unsigned)d->D) continue;
+      for (int e = 0; e < d->KH; ++e) {
+        const int ih = oh * d->sh - d->ph + e;
+        if ((unsigned)ih >= (unsigned)d->H) continue;
+        for (int f = 0; f < d->KW; ++f) {
+          const int iw = ow * d->sw - d->pw + f;
+          if ((unsigned)iw >= (unsigned)d->W) continue;
+          const float *x = in + ((((size_t)b * d->D + id) * d->H + ih) * d->W + iw) * Cin;
+          const int tap = (a * d->KH + e) * d->KW + f;
+          for (int n = 0; n < Cout; ++n) {
+            const float *w = wgt + (size_t)n * K;
+            float s = acc[n];
+            if (d->wgt_layout == 1) {
+              for (int c0 = 0; c0 < Cin; c0 += 32) {
+                const float *wc = w + ((size_t)(c0 / 32) * ntap + tap) * 32;
+                for (int c = 0; c < 32; ++c) s += x[c0 + c] * wc[c];
+              }
+            } else {
+              const float *wc = w + (size_t)tap * Cin;
+              for (int c = 0; c < Cin; ++c) s += x[c] * wc[c];
+            }
+            acc[n] = s;
+          }
+        }
+      }
+    }
+    for (int n = 0; n < Cout; ++n) {          // conv_finish / conv_store_one of the HIP kernel
+      size_t o = (size_t)m * Cout + n, ridx = o;
+      int ch = n;
+      if (d->out_mode == 1) {                 // ConvTranspose3d(k2, s2): column n = ((a*2+e)*2+f)*Cr + co
+        const int tapn = n / Cr, a2 = tapn >> 2, e2 = (tapn >> 1) & 1, f2 = tapn & 1;
+        ch = n - tapn * Cr;
+        const int w_ = (int)(m % d->W);
+        int64_t q = m / d->W;
+        const int h_ = (int)(q % d->H);
+        q /= d->H;
+        const int d_ = (int)(q % d->D), b_ = (int)(q / d->D);
+        o = ridx = ((((size_t)b_ * 2 * d->D + 2 * d_ + a2) * 2 * d->H + 2 * h_ + e2) * 2 * d->W + 2 * w_ + f2) * Cr + ch;
+      } else if (d->res_mode == 2) {
+        ridx = res2_row((int)m, Ho, Wo, d->res_h, d->res_w, Cout) + n;
+      }
+      float v = acc[n] * (scale ? scale[ch] : 1.0f) + (shift ? shift[ch] : 0.0f);
+      if (d->res_mode && !d->res_after_act) v = res[ridx] * rs + v;
+      if (d->relu) v = v > 0.f ? v : 0.f;
+      if (d->res_mode && d->res_after_act) v = res[ridx] * rs + v;
+      out[o] = v * post;
+    }
+  }
+  return IVX_OK;
+}
+
+extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale, const float *shift, const void *res,
+                            void *out, ivx_stream_t stream) {
+  return ivx_conv_fwd_ws(d, in, wgt, scale, shift, res, out, nullptr, 0, stream);
+}
+
+// The minimal-filtering form is a device-side optimisation: the CPU restatement reports "not supported" and the handle
+// (csrc/model.cpp plan_conv) falls back to the direct convolution, as it does for any layer the Winograd entry points refuse.
+extern "C" int ivx_conv_winograd_supported(const ivx_conv_desc *, int32_t) { return 0; }
+extern "C" int64_t ivx_conv_winograd_weight_elems(const ivx_conv_desc *, int32_t) { return -1; }
+extern "C" int64_t ivx_conv_winograd_workspace_bytes(const ivx_conv_desc *, int32_t) { return -1; }
+static int no_wino(const char *who) {
+  ivx_set_error("%s: the CPU restatement has no Winograd form (ivx_conv_winograd_supported returns 0)", who);
+  return IVX_ERR_UNSUPPORTED;
+}
+extern "C" int ivx_conv_winograd_weights(const ivx_conv_desc *, int32_t, const float *, float *, ivx_stream_t) { return no_wino("ivx_conv_winograd_weights"); }
+extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *, int32_t, const void *, void *, int64_t, ivx_stream_t) { return no_wino("ivx_conv_winograd_input"); }
+extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *, int32_t, const float *, void *, int64_t, ivx_stream_t) { return no_wino("ivx_conv_winograd_gemm"); }
+extern "C" int ivx_conv_winograd_output(const ivx_conv_desc *, int32_t, const float *, const float *, const void *, void *, void *, int64_t,
+                                        ivx_stream_t) { return no_wino("ivx_conv_winograd_output"); }
+extern "C" int ivx_conv_winograd_fwd(const ivx_conv_desc *, int32_t, const void *, const float *, const float *, const float *, const void *,
+                                     void *, void *, int64_t, ivx_stream_t) { return no_wino("ivx_conv_winograd_fwd"); }
+
+// ---------------------------------------------------------------------------------------------- pool / layout (csrc/pool_layout.hip)
+extern "C" int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p, float *out,
+                                 ivx_stream_t) {
+  C_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && s > 0 && p >= 0 && 2 * p <= k, "ivx_maxpool2d_fwd: bad argument");
+  const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int oh = 0; oh < Ho; ++oh)
+      for (int ow = 0; ow < Wo; ++ow)
+        for (int c = 0; c < C; ++c) {
+          float m = -INFINITY;                       // -inf padding semantics of torch
+          for (int e = 0; e < k; ++e) {
+            const int ih = oh * s - p + e;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int f = 0; f < k; ++f) {
+              const int iw = ow * s - p + f;
+              if ((unsigned)iw >= (unsigned)W) continue;
+              const float x = in[(((size_t)b * H + ih) * W + iw) * C + c];
+              m = (x > m || x != x) ? x : m;
+            }
+          }
+          out[(((size_t)b * Ho + oh) * Wo + ow) * C + c] = m;
+        }
+  return IVX_OK;
+}
+
+extern "C" int ivx_nchw_to_nhwc(const float *in, int32_t B, int32_t C, int64_t S, int32_t Cpad, float *out, ivx_stream_t) {
+  C_REQUIRE(in && out && B > 0 && C > 0 && S > 0 && Cpad >= C, "ivx_nchw_to_nhwc: bad argument");
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)B * S; ++i) {
+    const int64_t b = i / S, s = i % S;
+    for (int c = 0; c < Cpad; ++c) out[i * Cpad + c] = c < C ? in[((size_t)b * C + c) * S + s] : 0.f;
+  }
+  return IVX_OK;
+}
+
+extern "C" int ivx_nhwc_to_nchw(const float *in, int32_t B, int64_t S, int32_t C, float *out, ivx_stream_t) {
+  C_REQUIRE(in && out && B > 0 && C > 0 && S > 0, "ivx_nhwc_to_nchw: bad argument");
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)B * S; ++i) {
+    const int64_t b = i / S, s = i % S;
+    for (int c = 0; c < C; ++c) out[((size_t)b * C + c) * S + s] = in[i * C + c];
+  }
+  return IVX_OK;
+}
+
+// F.interpolate(scale_factor=2, mode='trilinear', align_corners=False), the blend order of upsample_trilinear2x_kernel
+extern "C" int ivx_upsample_trilinear2x_fwd(const float *in, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, float *out, ivx_stream_t) {
+  C_REQUIRE(in && out && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "ivx_upsample_trilinear2x_fwd: bad argument");
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)B * Do * Ho * Wo; ++i) {
+    const int ow = (int)(i % Wo);
+    int64_t t = i / Wo;
+    const int oh = (int)(t % Ho);
+    t /= Ho;
+    const int od = (int)(t % Do), b = (int)(t / Do);
+    float sd = 0.5f * (od + 0.5f) - 0.5f, sh = 0.5f * (oh + 0.5f) - 0.5f, sw = 0.5f * (ow + 0.5f) - 0.5f;
+    sd = sd < 0.f ? 0.f : sd; sh = sh < 0.f ? 0.f : sh; sw = sw < 0.f ? 0.f : sw;
+    const int d0 = (int)sd, h0 = (int)sh, w0 = (int)sw;
+    const int d1 = d0 + (d0 < D - 1 ? 1 : 0), h1 = h0 + (h0 < H - 1 ? 1 : 0), w1 = w0 + (w0 < W - 1 ? 1 : 0);
+    const float ld1 = sd - d0, lh1 = sh - h0, lw1 = sw - w0, ld0 = 1.f - ld1, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+    auto at = [&](int dd, int hh, int ww) { return in + ((((size_t)b * D + dd) * H + hh) * W + ww) * C; };
+    const float *v000 = at(d0, h0, w0), *v001 = at(d0, h0, w1), *v010 = at(d0, h1, w0), *v011 = at(d0, h1, w1);
+    const float *v100 = at(d1, h0, w0), *v101 = at(d1, h0, w1), *v110 = at(d1, h1, w0), *v111 = at(d1, h1, w1);
+    for (int c = 0; c < C; ++c)
+      out[i * C + c] = ld0 * (lh0 * (lw0 * v000[c] + lw1 * v001[c]) + lh1 * (lw0 * v010[c] + lw1 * v011[c])) +
+                       ld1 * (lh0 * (lw0 * v100[c] + lw1 * v101[c]) + lh1 * (lw0 * v110[c] + lw1 * v111[c]));
+  }
+  return IVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- unprojection (csrc/backproject.hip)
+// detectors/imvoxelnet.py:58-76, 132-160: voxel centre -> P @ [x, y, z, 1] -> round(u / d), round(v / d) -> in-crop and d > 0
+// -> mean of the hit views; the operation order of backproject_mean_kernel (fmul, 3 fma, IEEE divide, rintf).
+extern "C" int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C, const float *proj,
+                                        const float *new_origin, const int32_t *crop_hw, const float *voxel_size, int32_t X, int32_t Y,
+                                        int32_t Z, float *volume, uint8_t *valid, ivx_stream_t) {
+  C_REQUIRE(feat && proj && new_origin && crop_hw && voxel_size && volume && valid, "ivx_backproject_mean_fwd: null argument");
+  C_REQUIRE(B > 0 && V > 0 && FH > 0 && FW > 0 && C > 0 && X > 0 && Y > 0 && Z > 0, "ivx_backproject_mean_fwd: non-positive dims");
+  const int64_t N = (int64_t)X * Y * Z;
+#pragma omp parallel for schedule(static)
+  for (int64_t bn = 0; bn < (int64_t)B * N; ++bn) {
+    const int b = (int)(bn / N);
+    const int64_t n = bn % N;
+    const int k = (int)(n % Z), j = (int)((n / Z) % Y), i = (int)(n / ((int64_t)Z * Y));
+    const float *no = new_origin + b * 3;
+    const float px = (float)i * voxel_size[0] + no[0], py = (float)j * voxel_size[1] + no[1], pz = (float)k * voxel_size[2] + no[2];
+    const int hc = std::min(crop_hw[b * 2], FH), wc = std::min(crop_hw[b * 2 + 1], FW);
+    float *dst = volume + bn * C;
+    for (int c = 0; c < C; ++c) dst[c] = 0.f;
+    int cnt = 0;
+    for (int v = 0; v < V; ++v) {
+      const float *P = proj + ((size_t)b * V + v) * 12;
+      float u = P[0] * px; u = fmaf(P[1], py, u); u = fmaf(P[2], pz, u); u = fmaf(P[3], 1.0f, u);
+      float w = P[4] * px; w = fmaf(P[5], py, w); w = fmaf(P[6], pz, w); w = fmaf(P[7], 1.0f, w);
+      float dd = P[8] * px; dd = fmaf(P[9], py, dd); dd = fmaf(P[10], pz, dd); dd = fmaf(P[11], 1.0f, dd);
+      const float xr = rintf(u / dd), yr = rintf(w / dd);
+      if (!((xr >= 0.f) && (yr >= 0.f) && (xr < (float)wc) && (yr < (float)hc) && (dd > 0.f))) continue;
+      ++cnt;
+      const float *src = feat + ((((size_t)b * V + v) * FH + (int)yr) * FW + (int)xr) * C;
+      for (int c = 0; c < C; ++c) dst[c] = dst[c] + src[c];
+    }
+    const float dn = (float)cnt;
+    for (int c = 0; c < C; ++c) dst[c] = cnt ? dst[c] / dn : 0.f;
+    valid[bn] = cnt > 0 ? 1 : 0;
+  }
+  return IVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- anchor tail (csrc/anchor_tail.hip)
+static int next_pow2(int v) { int r = 1; while (r < v) r <<= 1; return r; }
+
+extern "C" int64_t ivx_anchor_head_workspace_bytes(const ivx_anchor_head_desc *d) { return d ? 256 : -1; }
+
+// Anchor3DHead.get_bboxes_single (anchor3d_head.py:420-520): sigmoid scores, top nms_pre (ties -> lower index), box decoding,
+// direction argmax, BEV boxes, rotated / axis-aligned NMS over the candidates above score_thr, first max_num, yaw fix-up.
+extern "C" int ivx_anchor_head_get_bboxes(const ivx_anchor_head_desc *d, const float *head_out, const float *anchors, void *workspace,
+                                          int64_t workspace_bytes, float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_count,
+                                          int64_t *cand_idx, float *cand_boxes, float *cand_scores, ivx_stream_t) {
+  (void)workspace; (void)workspace_bytes;
+  C_REQUIRE(d && head_out && anchors && out_boxes && out_scores && out_labels && out_count, "ivx_anchor_head_get_bboxes: null argument");
+  C_REQUIRE(d->num_classes == 1, "ivx_anchor_head: only num_classes == 1 is built; got %d", d->num_classes);
+  const int HW = d->H * d->W, A = d->num_anchors, n = HW * A;
+  const int k = (d->nms_pre > 0 && d->nms_pre < n) ? d->nms_pre : n;
+  C_REQUIRE(k <= 4096 && d->max_num > 0 && d->max_num <= 4096 && d->nms_pre > 0, "ivx_anchor_head: nms_pre / max_num out of range");
+  (void)next_pow2;
+  const float PI = 3.14159265358979323846f;
+  for (int b = 0; b < d->B; ++b) {
+    auto mem = [&](int hw) { if (!d->hw_transposed) return hw; const int y = hw / d->W, x = hw - y * d->W; return x * d->H + y; };
+    std::vector<float> key(n);
+    for (int i = 0; i < n; ++i) {
+      const float *src = head_out + ((size_t)b * HW + mem(i / A)) * d->CH + d->cls_off + (i % A) * d->num_classes;
+      key[i] = 1.0f / (1.0f + expf(-src[0]));
+    }
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::partial_sort(order.begin(), order.begin() + k, order.end(), [&](int a, int c) { return key[a] > key[c] || (key[a] == key[c] && a < c); });
+    std::vector<float> boxes((size_t)k * 7), bev((size_t)k * 5), sc(k);
+    std::vector<int> dir(k);
+    int n1 = 0;
+    for (int j = 0; j < k; ++j) {
+      const int idx = order[j], hw = idx / A, a = idx % A;
+      const float *row = head_out + ((size_t)b * HW + mem(hw)) * d->CH, *an = anchors + (size_t)idx * 7, *dl = row + d->reg_off + a * 7;
+      const float xa = an[0], ya = an[1], wa = an[3], la = an[4], ha = an[5], ra = an[6];
+      float za = an[2];
+      za = za + ha / 2;
+      const float diag = sqrtf(la * la + wa * wa);
+      const float xg = dl[0] * diag + xa, yg = dl[1] * diag + ya;
+      float zg = dl[2] * ha + za;
+      const float lg = expf(dl[4]) * la, wg = expf(dl[3]) * wa, hg = expf(dl[5]) * ha, rg = dl[6] + ra;
+      zg = zg - hg / 2;
+      float *ob = &boxes[(size_t)j * 7];
+      ob[0] = xg; ob[1] = yg; ob[2] = zg; ob[3] = wg; ob[4] = lg; ob[5] = hg; ob[6] = rg;
+      const float hwid = wg / 2, hlen = lg / 2;
+      float *bv = &bev[(size_t)j * 5];
+      bv[0] = xg - hwid; bv[1] = yg - hlen; bv[2] = xg + hwid; bv[3] = yg + hlen; bv[4] = rg;
+      dir[j] = row[d->dir_off + a * 2 + 1] > row[d->dir_off + a * 2] ? 1 : 0;
+      sc[j] = key[idx];
+      if (sc[j] > d->score_thr) ++n1;          // a prefix: the candidates are sorted
+    }
+    std::vector<int64_t> keep(n1 > 0 ? n1 : 1);
+    int nk = 0;
+    if (n1 > 0) nk = d->use_rotate_nms ? ivxo_nms_rotated_sorted(bev.data(), n1, d->nms_thr, keep.data()) : ivxo_nms_normal_sorted(bev.data(), n1, d->nms_thr, keep.data());
+    if (nk > d->max_num) nk = d->max_num;
+    for (int j = 0; j < d->max_num; ++j) {
+      float *ob = out_boxes + ((size_t)b * d->max_num + j) * 7;
+      if (j < nk) {
+        const int i = (int)keep[j];
+        for (int q = 0; q < 6; ++q) ob[q] = boxes[(size_t)i * 7 + q];
+        const float val = boxes[(size_t)i * 7 + 6] - d->dir_offset;
+        const float t = floorf(val / PI + d->dir_limit_offset);
+        const float dir_rot = val - t * PI;
+        ob[6] = (dir_rot + d->dir_offset) + PI * (float)dir[i];
+        out_scores[(size_t)b * d->max_num + j] = sc[i];
+      } else {
+        for (int q = 0; q < 7; ++q) ob[q] = 0.f;
+        out_scores[(size_t)b * d->max_num + j] = 0.f;
+      }
+      out_labels[(size_t)b * d->max_num + j] = 0;
+    }
+    out_count[b] = nk;
+    for (int j = 0; j < d->nms_pre; ++j) {
+      const bool in = j < k;
+      if (cand_idx) cand_idx[(size_t)b * d->nms_pre + j] = in ? order[j] : -1;
+      if (cand_boxes) for (int q = 0; q < 7; ++q) cand_boxes[((size_t)b * d->nms_pre + j) * 7 + q] = in ? boxes[(size_t)j * 7 + q] : 0.f;
+      if (cand_scores) cand_scores[(size_t)b * d->nms_pre + j] = in ? sc[j] : 0.f;
+    }
+  }
+  return IVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- NMS entry points (via oracle/ivx_oracle.c)
+extern "C" int64_t ivx_nms_workspace_bytes(int32_t n) { return n < 0 ? -1 : 256; }
+
+extern "C" int ivx_nms_bev(const float *boxes_sorted, int32_t n, float thresh, int32_t rotated, void *, int64_t, int64_t *keep, int32_t *num_out,
+                           ivx_stream_t) {
+  C_REQUIRE(n >= 0 && n <= 4096 && keep && num_out && (n == 0 || boxes_sorted), "ivx_nms_bev: bad argument");
+  *num_out = n == 0 ? 0 : (rotated ? ivxo_nms_rotated_sorted(boxes_sorted, n, thresh, keep) : ivxo_nms_normal_sorted(boxes_sorted, n, thresh, keep));
+  return IVX_OK;
+}
+
+extern "C" int ivx_boxes_overlap_bev(const float *a, int32_t na, const float *b, int32_t nb, int32_t iou, float *out, ivx_stream_t) {
+  C_REQUIRE(na >= 0 && nb >= 0, "ivx_boxes_overlap_bev: bad sizes");
+  if (na == 0 || nb == 0) return IVX_OK;
+  C_REQUIRE(a && b && out, "ivx_boxes_overlap_bev: null argument");
+  if (iou) ivxo_boxes_iou_bev(a, na, b, nb, out); else ivxo_boxes_overlap_bev(a, na, b, nb, out);
+  return IVX_OK;
+}
+
+extern "C" int ivx_aligned_3d_nms(const float *boxes, const float *scores, const int64_t *classes, int32_t n, float thresh, int64_t *pick,
+                                  int32_t *num_out, ivx_stream_t) {
+  C_REQUIRE(n >= 0 && n <= 4096 && pick && num_out && (n == 0 || (boxes && scores && classes)), "ivx_aligned_3d_nms: bad argument");
+  std::vector<int64_t> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  // ascending score for the oracle's scan from the back; among equal scores the LOWER index is processed first (the device's key)
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return scores[a] < scores[c] || (scores[a] == scores[c] && a > c); });
+  *num_out = n == 0 ? 0 : ivxo_aligned_3d_nms(boxes, scores, classes, order.data(), n, thresh, pick);
+  return IVX_OK;
+}

@@ -834,3 +834,110 @@ def test_fp8_weight_quantisation_and_qtensor_host_side():
         FusedConv(torch.randn(32, 24, 1, 1, generator=g), dims=2, dtype=FP8, out_dtype=torch.bfloat16)
     q = QTensor(torch.tensor([1.0, 2.0]).to(FP8), 0.5)
     assert torch.equal(q.float(), torch.tensor([0.5, 1.0])) and q.shape == (2,)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the SAME C-ABI served by the CPU restatement (oracle/cpu_abi: test infrastructure).  The product's model-level
+# handle (csrc/model.cpp, compiled unchanged) runs over CPU versions of the op-level entry points, so its layer graphs, weight
+# packing and planning are checked against the reference's goldens WITHOUT a GPU.  The product itself never loads this library.
+def _cpu_abi():
+    import ctypes as C
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ivx_cpu_abi_build', os.path.join(ROOT, 'oracle', 'cpu_abi', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib_path, exe = mod.build()
+    L = C.CDLL(lib_path)
+    L.ivx_last_error.restype = C.c_char_p
+    L.ivx_neck3d_workspace_bytes.restype = C.c_int64
+    return L, exe
+
+
+def test_c_host_program_runs_the_e2e_golden_on_the_cpu_abi():
+    """tests/c/e2e_small.c -- the Python-free host of the model-level C-ABI -- linked against libimvoxel_cpu.so: unprojection ->
+    KittiImVoxelNeck -> Anchor3DHead -> NMS of the reference's end-to-end golden case on the CPU, detections within the program's
+    own 1e-5 / 1e-4 bars and the valid mask exact."""
+    import subprocess
+    _, exe = _cpu_abi()
+    r = subprocess.run([exe, os.path.join(ROOT, 'tests', 'golden', 'e2e_small.bin')], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'C e2e_small OK' in r.stdout and 'no Python involved' in r.stdout
+
+
+@pytest.mark.parametrize('name', ['kitti', 'nuscenes', 'fast', 'atlas'])
+def test_cpu_abi_necks_vs_reference_golden(name):
+    """The four neck builders of csrc/model.cpp through the C-ABI on the CPU restatement (ivx_create, the golden's state dict
+    via ivx_weights_load, ivx_neck3d_{kitti,nuscenes,fast,unet}_fwd on host buffers) against the imported reference modules'
+    outputs (tests/golden/necks.npz): 1e-3 / 1e-4, the bar of the GPU twin tests/test_gpu_engine.py::
+    test_native_handle_necks_vs_reference_golden."""
+    import ctypes as C
+    from imvoxelnet_amd._lib import ModelCfg            # the ctypes struct only; the HIP library is not loaded
+    L, _ = _cpu_abi()
+    g = load_npz('necks.npz')
+    x = np.ascontiguousarray(g[name + '::x'], np.float32)                         # [B, C, X, Y, Z]
+    B, Cin, X, Y, Z = x.shape
+    cfg = ModelCfg()
+    cfg.neck_type = {'kitti': 0, 'nuscenes': 1, 'fast': 2, 'atlas': 3}[name]
+    cfg.with_trunk, cfg.fpn_channels, cfg.winograd = 0, Cin, 1
+    cfg.neck_out_channels = 4 if name == 'atlas' else 8
+    cfg.n_voxels[:] = [X, Y, Z]
+    cfg.voxel_size[:] = [.1, .1, .1]
+    if name in ('kitti', 'nuscenes'):
+        cfg.num_classes, cfg.n_sizes, cfg.n_rotations, cfg.nms_pre, cfg.max_num = 1, 1, 2, 10, 5
+        cfg.anchor_range[:] = [0, 0, 0, 1, 1, 0]
+        cfg.anchor_sizes[:3] = [1, 1, 1]
+        cfg.anchor_rotations[:2] = [0, 1.57]
+    if name == 'fast':
+        cfg.fast_n_blocks[:] = [1, 1, 1]
+    if name == 'atlas':
+        cfg.unet_channels[:] = [4, 8, 16, 0]
+        cfg.unet_down_layers[:] = [1, 2, 2, 0]
+        cfg.unet_up_layers[:] = [2, 1, 0]
+    vp = C.c_void_p
+    h = vp()
+
+    def ok(rc, what):
+        assert rc == 0, f'{what}: {L.ivx_last_error().decode()}'
+
+    ok(L.ivx_create(C.byref(cfg), C.byref(h)), 'ivx_create')
+    try:
+        def load(key, a):
+            a = np.ascontiguousarray(a, np.float32)
+            ok(L.ivx_weights_load(h, key.encode(), a.ctypes.data_as(vp), (C.c_int64 * max(a.ndim, 1))(*a.shape), a.ndim), key)
+
+        for k in g.files:
+            if k.startswith(name + '::sd::') and 'num_batches_tracked' not in k:
+                load('neck_3d.' + k.split('::sd::')[1], g[k])
+        if name in ('kitti', 'nuscenes'):
+            for key, co in (('bbox_head.conv_cls', 2), ('bbox_head.conv_reg', 14), ('bbox_head.conv_dir_cls', 4)):
+                load(key + '.weight', np.zeros((co, 8, 1, 1), np.float32))
+                load(key + '.bias', np.zeros((co,), np.float32))
+        ok(L.ivx_weights_finalize(h, None), 'ivx_weights_finalize')
+        vol = np.ascontiguousarray(x.transpose(0, 2, 3, 4, 1))                     # channels-last [B, X, Y, Z, C]
+        n = L.ivx_neck3d_workspace_bytes(h, B)
+        assert n > 0, L.ivx_last_error()
+        raw = np.empty(n + 256, np.uint8)
+        ws = raw.ctypes.data + (-raw.ctypes.data % 256)                            # 256-byte aligned, as the entry points require
+        if name in ('kitti', 'nuscenes'):
+            Xo, Yo, Co = C.c_int32(), C.c_int32(), C.c_int32()
+            ok(L.ivx_neck3d_out_dims(h, B, C.byref(Xo), C.byref(Yo), C.byref(Co)), 'ivx_neck3d_out_dims')
+            out = np.empty((B, Xo.value, Yo.value, 1, Co.value), np.float32)
+            fn = L.ivx_neck3d_kitti_fwd if name == 'kitti' else L.ivx_neck3d_nuscenes_fwd
+            ok(fn(h, vol.ctypes.data_as(vp), B, out.ctypes.data_as(vp), vp(ws), C.c_int64(n), None), 'neck fwd')
+            got = [out[:, :, :, 0].transpose(0, 3, 2, 1)]                          # the reference returns [B, C, Y', X']
+        else:
+            dims = ((C.c_int32 * 4) * 3)()
+            ok(L.ivx_neck3d_levels(h, B, dims), 'ivx_neck3d_levels')
+            outs = [np.empty((B, d[0], d[1], d[2], d[3]), np.float32) for d in dims if d[3] > 0]
+            ptrs = (vp * 3)(*([o.ctypes.data for o in outs] + [None] * (3 - len(outs))))
+            fn = L.ivx_neck3d_fast_fwd if name == 'fast' else L.ivx_neck3d_unet_fwd
+            ok(fn(h, vol.ctypes.data_as(vp), B, ptrs, vp(ws), C.c_int64(n), None), 'neck fwd')
+            got = [o.transpose(0, 4, 1, 2, 3) for o in outs]
+        n_out = len([k for k in g.files if k.startswith(name + '::y')])
+        assert len(got) == n_out
+        for i, y in enumerate(got):
+            ref = g[f'{name}::y{i}']
+            assert y.shape == ref.shape
+            assert np.allclose(y, ref, rtol=1e-3, atol=1e-4), f'{name} level {i}: max |d| {np.abs(y - ref).max():.3e}'
+    finally:
+        L.ivx_destroy(h)
