@@ -13,6 +13,10 @@ Contents
   ref_import.py       imports the REAL reference from /root/reference (build
                       container only) -- used to generate tests/golden/
   gen_golden.py       the script that generated tests/golden/*.npz
+  cpu_abi/            the SAME C-ABI as the product (include/imvoxel.h) served by a CPU restatement: cpu_ops.cpp
+                      (op-level entry points on host memory) under the product's csrc/model.cpp compiled unchanged
+                      against a host-memory stand-in of the HIP runtime (cpu_abi/hip/); build.py ->
+                      oracle/_cpuabi/libimvoxel_cpu.so + tests/c/e2e_small_cpu.  Loaded by tests/ only.
 
 Pinning status (see DESIGN.md "Oracle"):
   pinned   : get_points, _compute_projection, backproject(+mean), 3-D necks,
@@ -21,11 +25,6 @@ Pinning status (see DESIGN.md "Oracle"):
              imported reference + the reference's own test vectors)
   partial  : rotated-BEV overlap (reference test_box3d.py known answers,
              rtol 1e-4); nms_gpu greedy scan (restated, CUDA op cannot run here)
-  cpu_abi/  : the SAME C-ABI as the product (include/imvoxel.h) served by a CPU restatement -- cpu_ops.cpp (op-level
-             entry points on host memory) under the product's csrc/model.cpp compiled unchanged against a host-memory stand-in
-             of the HIP runtime (cpu_abi/hip/); built into oracle/_cpuabi/libimvoxel_cpu.so by cpu_abi/build.py.  The CPU
-             tests run the model-level handle and the Python-free C host (tests/c/e2e_small.c) on it against the reference's
-             goldens.  Loaded by tests/ only.
   UNPINNED : ResNet-50 / FPN (mmdet 2.10.0 + torchvision, absent from the
              reference tree and this image) -- restated from the public
              architecture; DCNv2 (mmcv-full 1.2.7) not built.
