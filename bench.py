@@ -290,6 +290,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='samples per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-cabi', action='store_true', help='skip the second CPU leg (the C-ABI over the CPU restatement, oracle/cpu_abi)')
     ap.add_argument('--cpu-repeats', type=int, default=3, help='timed images of the cpu_baseline leg (after one warm-up image)')
     ap.add_argument('--config', default='kitti', choices=['kitti', 'nuscenes', 'scannet_fast', 'sunrgbd_fast', 'scannet_v1', 'lift_nuscenes', 'lift_scannet'],
                     help='BASELINE.json workload; the headline metric is quoted on kitti (configs[1]), the default')
@@ -593,6 +594,29 @@ def main():
                                    'sample': '%d images (1x3x384x1280 -> 216x248x12 each, one at a time) through the oracle port (torch-CPU fp32 '
                                              'convs + C unprojection/NMS) after one untimed warm-up image: %s s, mean %.2f s'
                                              % (len(ts), ' / '.join('%.2f' % t for t in ts), tc)}
+            if not args.no_cpu_cabi:
+                # SURVEY 8d baseline (ii): the build's own CPU restatement behind the SAME C-ABI (oracle/cpu_abi: csrc/model.cpp over
+                # plain-loop OpenMP ops), same weights, same image, through ivx_model_forward on host memory
+                import importlib.util
+                os.environ.setdefault('OMP_NUM_THREADS', str(torch.get_num_threads()))
+                spec = importlib.util.spec_from_file_location('ivx_cpu_abi_host', os.path.join(ROOT, 'oracle', 'cpu_abi', 'host.py'))
+                host = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(host)
+                cm = host.CpuModel(model)
+                try:
+                    tcs = []
+                    for k in range(1 + max(1, args.cpu_repeats - 1)):       # one untimed warm-up image, then cpu_repeats - 1 timed ones
+                        tc0 = time.perf_counter()
+                        cdet = cm.forward(img_host[k % B:k % B + 1], metas[k % B:k % B + 1])
+                        tcs.append(time.perf_counter() - tc0)
+                finally:
+                    cm.close()
+                tcs = tcs[1:]
+                rec['cpu_baseline_cabi'] = {'value': round(len(tcs) / sum(tcs), 4), 'unit': 'images/s', 'cores': int(os.environ['OMP_NUM_THREADS']),
+                                            'kind': 'port', 'host_cpus': os.cpu_count(), 'detections_last_image': int(len(cdet[0][1])),
+                                            'sample': '%d images through ivx_model_forward of oracle/_cpuabi/libimvoxel_cpu.so (the model-level C-ABI '
+                                                      'over the CPU restatement: direct convolutions, no Winograd form) after one untimed warm-up '
+                                                      'image: %s s' % (len(tcs), ' / '.join('%.2f' % t for t in tcs))}
         print(json.dumps(rec))
     if world > 1 or force_dist:
         dist.destroy_process_group()

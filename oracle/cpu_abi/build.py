@@ -25,7 +25,7 @@ def build(force=False):
     if force or _stale(LIB, deps):
         obj = os.path.join(OUT, 'ivx_oracle.o')
         subprocess.check_call(['gcc', '-O2', '-fPIC', '-std=c11', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', '-c', oracle_c, '-o', obj])
-        subprocess.check_call(['g++', '-O2', '-fPIC', '-shared', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', f'-I{HERE}'] + srcs +
+        subprocess.check_call(['g++', '-O3', '-mavx2', '-fPIC', '-shared', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', f'-I{HERE}'] + srcs +
                               [obj, '-o', LIB, '-lm', '-Wl,--no-undefined'])
     c_src = os.path.join(ROOT, 'tests', 'c', 'e2e_small.c')
     if force or _stale(EXE, [c_src, LIB]):

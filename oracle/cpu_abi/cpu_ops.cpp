@@ -75,6 +75,16 @@ extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in_, const vo
   const int64_t K = (int64_t)ntap * Cin, M = (int64_t)d->B * Do * Ho * Wo;
   const int Cr = d->out_mode == 1 ? Cout / 8 : Cout;
   const float post = d->post_scale == 0.f ? 1.0f : d->post_scale, rs = d->res_scale == 0.f ? 1.0f : d->res_scale;
+  // filters re-laid [tap][ci][co] once per call: the inner loop then runs over the output channels (contiguous, no reduction
+  // dependency -> vectorises); the sum over (tap, ci) of every output element keeps the tap-major, channel-ascending order
+  std::vector<float> wt((size_t)ntap * Cin * Cout);
+#pragma omp parallel for schedule(static)
+  for (int n = 0; n < Cout; ++n)
+    for (int tap = 0; tap < ntap; ++tap)
+      for (int c = 0; c < Cin; ++c) {
+        const size_t src = d->wgt_layout == 1 ? ((size_t)(c / 32) * ntap + tap) * 32 + (c % 32) : (size_t)tap * Cin + c;
+        wt[((size_t)tap * Cin + c) * Cout + n] = wgt[(size_t)n * K + src];
+      }
 #pragma omp parallel for schedule(static)
   for (int64_t m = 0; m < M; ++m) {
     const int ow = (int)(m % Wo);
@@ -83,6 +93,7 @@ extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in_, const vo
     t /= Ho;
     const int od = (int)(t % Do), b = (int)(t / Do);
     std::vector<float> acc(Cout, 0.f);
+    float *ap = acc.data();
     for (int a = 0; a < d->KD; ++a) {
       const int id = od * d->sd - d->pd + a;
       if ((unsigned)id >= (unsigned)d->D) continue;
@@ -93,20 +104,12 @@ extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in_, const vo
           const int iw = ow * d->sw - d->pw + f;
           if ((unsigned)iw >= (unsigned)d->W) continue;
           const float *x = in + ((((size_t)b * d->D + id) * d->H + ih) * d->W + iw) * Cin;
-          const int tap = (a * d->KH + e) * d->KW + f;
-          for (int n = 0; n < Cout; ++n) {
-            const float *w = wgt + (size_t)n * K;
-            float s = acc[n];
-            if (d->wgt_layout == 1) {
-              for (int c0 = 0; c0 < Cin; c0 += 32) {
-                const float *wc = w + ((size_t)(c0 / 32) * ntap + tap) * 32;
-                for (int c = 0; c < 32; ++c) s += x[c0 + c] * wc[c];
-              }
-            } else {
-              const float *wc = w + (size_t)tap * Cin;
-              for (int c = 0; c < Cin; ++c) s += x[c] * wc[c];
-            }
-            acc[n] = s;
+          const float *wtap = wt.data() + (size_t)((a * d->KH + e) * d->KW + f) * Cin * Cout;
+          for (int c = 0; c < Cin; ++c) {
+            const float xc = x[c];
+            const float *wr = wtap + (size_t)c * Cout;
+#pragma omp simd
+            for (int n = 0; n < Cout; ++n) ap[n] += xc * wr[n];
           }
         }
       }

@@ -941,3 +941,50 @@ def test_cpu_abi_necks_vs_reference_golden(name):
             assert np.allclose(y, ref, rtol=1e-3, atol=1e-4), f'{name} level {i}: max |d| {np.abs(y - ref).max():.3e}'
     finally:
         L.ivx_destroy(h)
+
+
+def test_cpu_abi_whole_path_with_trunk_matches_the_oracle_port():
+    """ivx_model_forward on the CPU restatement -- ResNet-50 + FPN + unprojection + KittiImVoxelNeck + Anchor3DHead + NMS built by
+    csrc/model.cpp from the module's state dict -- against the oracle's torch / C port of the same path on a small case: the same
+    detections (count, boxes to 1e-4, scores to 1e-5).  Checks the handle's 2-D trunk builder (state-dict keys, strides, the FPN
+    top-down adds) without a GPU."""
+    import importlib.util
+    import imvoxelnet_amd as ia
+    from oracle import imvoxel_oracle as orc
+    spec = importlib.util.spec_from_file_location('ivx_cpu_abi_host', os.path.join(ROOT, 'oracle', 'cpu_abi', 'host.py'))
+    host = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(host)
+    nv = (24, 28, 12)
+    cfg = kitti_model_cfg(n_voxels=nv, in_ch=16, out_ch=32)
+    ox = 0.5 + nv[0] * .32 / 2
+    rng = [ox - nv[0] * .16, -nv[1] * .16, -1.78, ox + nv[0] * .16 - .32, nv[1] * .16 - .32, -1.78]
+    cfg['bbox_head']['anchor_generator']['ranges'] = [rng]
+    test_cfg = dict(KITTI_TEST_CFG, score_thr=0.05)
+    model = ia.build_detector(cfg, test_cfg=test_cfg)
+    ia.randomize_(model, 7)
+    with torch.no_grad():
+        model.bbox_head.conv_cls.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(1))
+        model.bbox_head.conv_cls.bias.fill_(-1.5)
+        model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(3))   # keeps exp(size deltas) tame
+    H, W = 96, 160
+    K = np.array([[36., 0, 40, 0], [0, 36., 22, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    metas = []
+    for b in range(2):
+        E = np.array([[0, -1, 0, 0.03 * b], [0, 0, -1, 0.2], [1, 0, 0, 0.1], [0, 0, 0, 1]], np.float32)
+        metas.append(dict(img_shape=(H, W, 3), ori_shape=(H // 2, W // 2, 3), box_type_3d=ia.LiDARInstance3DBoxes,
+                          lidar2img=dict(intrinsic=K, extrinsic=[E], origin=np.array([ox, 0, -1.0], np.float32))))
+    img = torch.randn(2, 1, 3, H, W, generator=torch.Generator().manual_seed(2))
+    cm = host.CpuModel(model)
+    try:
+        got = cm.forward(img, metas)
+    finally:
+        cm.close()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ocfg = dict(n_voxels=nv, voxel_size=(.32, .32, .32), neck='kitti', num_classes=1, test_cfg=test_cfg,
+                anchor=dict(ranges=[rng], sizes=[[1.6, 3.9, 1.56]], rotations=[0, 1.57]))
+    ref, _ = orc.simple_test_anchor(img, metas, sd, ocfg)
+    assert sum(len(r[1]) for r in ref) > 0
+    for (gb, gs, gl), (rb, rs, rl) in zip(got, ref):
+        rb, rs = np.asarray(rb, np.float32).reshape(-1, 7), np.asarray(rs, np.float32)
+        assert len(gs) == len(rs), (len(gs), len(rs))
+        assert np.allclose(gs, rs, atol=1e-5) and np.allclose(gb, rb, atol=1e-4, rtol=1e-4) and not gl.any()
