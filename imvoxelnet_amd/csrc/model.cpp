@@ -120,6 +120,7 @@ struct ivx_model {
   std::vector<float> anchors_given;    // supplied through ivx_weights_load("anchors", ...)
   std::map<std::string, std::unique_ptr<Plan>> plans;
   std::vector<void *> owned;           // device allocations (weights, filters, anchors)
+  std::vector<float> pack_a, pack_b;   // host staging of ivx_weights_finalize (released there)
   // hipGraph replay of ivx_model_forward (cfg.use_graph): one captured graph per distinct set of caller buffers
   struct GraphEntry { std::vector<uintptr_t> key; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
@@ -370,6 +371,17 @@ int dev_upload(ivx_model *m, const std::vector<float> &h, float **out, hipStream
   return IVX_OK;
 }
 
+// ... from a staging buffer that is about to be reused: the copy has completed when this returns
+int dev_upload_sync(ivx_model *m, const float *h, size_t n, float **out, hipStream_t st) {
+  void *d = nullptr;
+  M_HIP(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(float)), "hipMalloc (weights)");
+  m->owned.push_back(d);
+  M_HIP(hipMemcpyAsync(d, h, n * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync (weights)");
+  M_HIP(hipStreamSynchronize(st), "hipStreamSynchronize (weights)");
+  *out = (float *)d;
+  return IVX_OK;
+}
+
 const HostTensor *find_w(const ivx_model *m, const std::string &key) {
   auto it = m->weights.find(key);
   return it == m->weights.end() ? nullptr : &it->second;
@@ -380,7 +392,12 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
   const int kd = L.k[0], kh = L.k[1], kw = L.k[2], taps = kd * kh * kw;
   L.cin_pad = (L.cin + 3) / 4 * 4;
   L.layout = (L.cin_pad % 32 == 0) ? 1 : 0;
-  std::vector<float> wp((size_t)L.cout * taps * L.cin_pad, 0.f), w0;
+  // staging buffers live in the handle and are reused by every layer (fresh 100 MB vectors per layer cost seconds of first-touch
+  // page faults in a sandboxed container); only channel padding needs the zero fill
+  std::vector<float> &wp = m->pack_a, &wc = m->pack_b;
+  const size_t n_w = (size_t)L.cout * taps * L.cin_pad;
+  if (wp.size() < n_w) wp.resize(n_w);
+  if (L.cin_pad != L.cin) std::fill(wp.begin(), wp.begin() + n_w, 0.f);
   std::vector<float> bias(L.cout, 0.f);
   bool has_bias = false;
   int co0 = 0;
@@ -402,10 +419,12 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
     const int co_n = (int)w->shape[0];
     int64_t want = (int64_t)co_n * L.cin * taps;
     M_REQUIRE((int64_t)w->data.size() == want && co0 + co_n <= L.cout, "ivx_weights_finalize: %s has the wrong shape", L.w_keys[q].c_str());
-    for (int co = 0; co < co_n; ++co)
-      for (int ci = 0; ci < L.cin; ++ci)
-        for (int t = 0; t < taps; ++t)      // torch [Cout,Cin,(kd,)kh,kw] -> [Cout,kd,kh,kw,Cin_pad]
-          wp[((size_t)(co0 + co) * taps + t) * L.cin_pad + ci] = w->data[((size_t)co * L.cin + ci) * taps + t];
+    for (int co = 0; co < co_n; ++co) {      // torch [Cout,Cin,(kd,)kh,kw] -> [Cout,kd,kh,kw,Cin_pad]; contiguous writes (the filter
+      const float *src = w->data.data() + (size_t)co * L.cin * taps;                  // block of one output channel stays in L2)
+      float *dst = wp.data() + (size_t)(co0 + co) * taps * L.cin_pad;
+      for (int t = 0; t < taps; ++t)
+        for (int ci = 0; ci < L.cin; ++ci) dst[(size_t)t * L.cin_pad + ci] = src[(size_t)ci * taps + t];
+    }
     if (!L.b_keys[q].empty()) {
       const HostTensor *b = find_w(m, L.b_keys[q]);
       if (!b) { *missing += L.b_keys[q] + " "; return IVX_OK; }
@@ -421,18 +440,18 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
   const bool wino3d = kd == 3 && kh == 3 && L.s[0] == 1 && L.s[1] == 1;
   const int min_ch = L.wino2d ? 128 : 64;
   L.wino_cand = (wino3d || L.wino2d) && L.cin_pad == L.cin && L.cout % 4 == 0 && std::max(L.cin, L.cout) >= min_ch && L.cin % 4 == 0;
-  if (L.wino_cand) w0 = wp;      // tap-major [Cout,kd,kh,kw,Cin]; a (1,3,3) kernel is the same memory as (3,3,1)
+  if (L.wino_cand) M_TRY(dev_upload_sync(m, wp.data(), n_w, &L.w0, st));   // tap-major [Cout,kd,kh,kw,Cin]; (1,3,3) is the same memory as (3,3,1)
   if (L.layout == 1) {           // chunk-major K: [Cout, Cin/32, kd,kh,kw, 32]
-    std::vector<float> wc(wp.size());
+    if (wc.size() < n_w) wc.resize(n_w);
     const int nch = L.cin_pad / 32;
     for (int co = 0; co < L.cout; ++co)
-      for (int t = 0; t < taps; ++t)
-        for (int ci = 0; ci < L.cin_pad; ++ci)
-          wc[(((size_t)co * nch + ci / 32) * taps + t) * 32 + ci % 32] = wp[((size_t)co * taps + t) * L.cin_pad + ci];
-    wp.swap(wc);
+      for (int ch = 0; ch < nch; ++ch)
+        for (int t = 0; t < taps; ++t)
+          memcpy(&wc[(((size_t)co * nch + ch) * taps + t) * 32], &wp[((size_t)co * taps + t) * L.cin_pad + ch * 32], 32 * sizeof(float));
+    M_TRY(dev_upload_sync(m, wc.data(), n_w, &L.w, st));
+  } else {
+    M_TRY(dev_upload_sync(m, wp.data(), n_w, &L.w, st));
   }
-  M_TRY(dev_upload(m, wp, &L.w, st));
-  if (L.wino_cand) M_TRY(dev_upload(m, w0, &L.w0, st));
   const int n_aff = L.conv_t ? L.cout / 8 : L.cout;     // the transposed conv's BN has the REAL channel count (epilogue indexes n % Cr)
   std::vector<float> scale(n_aff, 1.f), shift(bias.begin(), bias.begin() + n_aff);
   if (!L.bn.empty()) {
@@ -917,6 +936,8 @@ extern "C" int ivx_weights_finalize(ivx_model *m, ivx_stream_t stream) {
   }
   M_HIP(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");   // host staging vectors die here
   m->weights.clear();
+  std::vector<float>().swap(m->pack_a);
+  std::vector<float>().swap(m->pack_b);
   m->finalized = true;
   return IVX_OK;
 }

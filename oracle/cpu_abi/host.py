@@ -31,18 +31,20 @@ class CpuModel:
         self.L = L = load()
         self.model = model
         self.cfg = cfg = engine.model_cfg(model, with_trunk=True)
-        if engine.family(model) != 'anchor':
-            raise NotImplementedError('CpuModel drives ivx_model_forward (anchor-head families)')
+        self.family = engine.family(model)
+        if self.family is None:
+            raise NotImplementedError('the model-level handle does not cover this module (engine.family)')
         self.h = C.c_void_p()
         self._ok(L.ivx_create(C.byref(cfg), C.byref(self.h)), 'ivx_create')
         for key, t in model.state_dict().items():
             if t.dtype.is_floating_point:
                 self._load(key, t.detach().cpu().numpy())
         self._ok(L.ivx_weights_finalize(self.h, None), 'ivx_weights_finalize')
-        X, Y, Cn = C.c_int32(), C.c_int32(), C.c_int32()
-        self._ok(L.ivx_neck3d_out_dims(self.h, 1, C.byref(X), C.byref(Y), C.byref(Cn)), 'ivx_neck3d_out_dims')
-        anc = model.bbox_head.anchor_generator.grid_anchors([(Y.value, X.value)], device='cpu')[0].reshape(-1, 7).contiguous().float().numpy()
-        self._load('anchors', anc)
+        if self.family == 'anchor':
+            X, Y, Cn = C.c_int32(), C.c_int32(), C.c_int32()
+            self._ok(L.ivx_neck3d_out_dims(self.h, 1, C.byref(X), C.byref(Y), C.byref(Cn)), 'ivx_neck3d_out_dims')
+            anc = model.bbox_head.anchor_generator.grid_anchors([(Y.value, X.value)], device='cpu')[0].reshape(-1, 7).contiguous().float().numpy()
+            self._load('anchors', anc)
 
     def _ok(self, rc, what):
         if rc != 0:
@@ -71,6 +73,29 @@ class CpuModel:
                                           crop.ctypes.data_as(vp), vp(ws), C.c_int64(n), boxes.ctypes.data_as(vp), scores.ctypes.data_as(vp),
                                           labels.ctypes.data_as(vp), count.ctypes.data_as(vp), None, None), 'ivx_model_forward')
         return [(boxes[b, :count[b]].copy(), scores[b, :count[b]].copy(), labels[b, :count[b]].copy()) for b in range(B)]
+
+    def forward_levels(self, img, img_metas):
+        """Indoor families: img [B, V, 3, H, W] -> ([levels, channels-last [B, X_l, Y_l, Z_l, C], finest first], valid [B, X, Y, Z] bool)
+        = extract_feat through ivx_model_forward_levels."""
+        vp = C.c_void_p
+        x = np.ascontiguousarray(np.asarray(img, dtype=np.float32))
+        B, V, _, H, W = x.shape
+        proj, new_origin, crop = self.model._camera_setup(img_metas, 4, 'cpu')
+        proj, new_origin, crop = (np.ascontiguousarray(t.numpy()) for t in (proj, new_origin, crop))
+        n = self.L.ivx_model_workspace_bytes(self.h, B, V, H, W)
+        if n < 0:
+            raise RuntimeError(self.L.ivx_last_error().decode())
+        raw = np.empty(n + 256, np.uint8)
+        ws = raw.ctypes.data + (-raw.ctypes.data % 256)
+        dims = ((C.c_int32 * 4) * 3)()
+        self._ok(self.L.ivx_neck3d_levels(self.h, B, dims), 'ivx_neck3d_levels')
+        outs = [np.empty((B, d[0], d[1], d[2], d[3]), np.float32) for d in dims if d[3] > 0]
+        ptrs = (vp * 3)(*([o.ctypes.data for o in outs] + [None] * (3 - len(outs))))
+        valid = np.empty((B,) + tuple(self.model.n_voxels), np.uint8)
+        self._ok(self.L.ivx_model_forward_levels(self.h, x.ctypes.data_as(vp), B, V, H, W, proj.ctypes.data_as(vp), new_origin.ctypes.data_as(vp),
+                                                 crop.ctypes.data_as(vp), vp(ws), C.c_int64(n), ptrs, valid.ctypes.data_as(vp), None),
+                 'ivx_model_forward_levels')
+        return outs, valid.astype(bool)
 
     def close(self):
         if self.h:

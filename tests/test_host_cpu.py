@@ -988,3 +988,47 @@ def test_cpu_abi_whole_path_with_trunk_matches_the_oracle_port():
         rb, rs = np.asarray(rb, np.float32).reshape(-1, 7), np.asarray(rs, np.float32)
         assert len(gs) == len(rs), (len(gs), len(rs))
         assert np.allclose(gs, rs, atol=1e-5) and np.allclose(gb, rb, atol=1e-4, rtol=1e-4) and not gl.any()
+
+
+@pytest.mark.parametrize('cfg_name', ['scannet_fast', 'scannet_v1'])
+def test_cpu_abi_indoor_extract_feat_matches_the_oracle_port(cfg_name):
+    """ivx_model_forward_levels on the CPU restatement (ResNet-50 + FPN + multi-view unprojection + FastIndoorImVoxelNeck /
+    ImVoxelNeck as csrc/model.cpp builds them from the module's state dict) against the oracle's torch / C port on a small
+    multi-view case: valid mask exact, every neck level within 2e-4 of its range."""
+    import importlib.util
+    import imvoxelnet_amd as ia
+    import kitti_cfg as kc
+    from oracle import imvoxel_oracle as orc
+    spec = importlib.util.spec_from_file_location('ivx_cpu_abi_host', os.path.join(ROOT, 'oracle', 'cpu_abi', 'host.py'))
+    host = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(host)
+    mcfg = getattr(kc, f'{cfg_name}_model_cfg')()
+    mcfg['n_voxels'] = (16, 16, 8)                         # a small volume: the CPU suite must stay fast
+    model = ia.build_detector(mcfg, test_cfg=dict(getattr(kc, f'{cfg_name.upper()}_TEST_CFG')))
+    ia.randomize_(model, 19)
+    V, hw = 2, (64, 96)
+    img = torch.randn(1, V, 3, *hw, generator=torch.Generator().manual_seed(6))
+    meta = kc.indoor_meta(V, img_hw=hw)
+    meta['lidar2img']['intrinsic'] = meta['lidar2img']['intrinsic'].copy()
+    meta['lidar2img']['intrinsic'][:2] *= hw[0] / 480.0    # the synthetic K is for 480 x 640
+    cm = host.CpuModel(model)
+    try:
+        levels, valid = cm.forward_levels(img, [meta])
+    finally:
+        cm.close()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        f0 = orc.fpn_level0(orc.resnet50(img[0], sd), sd)
+        vol, ok = orc.extract_volume(f0.numpy(), meta, mcfg['n_voxels'], mcfg['voxel_size'])
+        sdn = {k[len('neck_3d.'):]: v for k, v in sd.items() if k.startswith('neck_3d.')}
+        nk = mcfg['neck_3d']
+        if cfg_name == 'scannet_fast':
+            ref = orc.fast_indoor_neck(torch.from_numpy(vol)[None], sdn, tuple(nk['n_blocks']))
+        else:
+            ref = orc.atlas_neck(torch.from_numpy(vol)[None], sdn, nk['channels'], nk['down_layers'], nk['up_layers'])
+    assert np.array_equal(valid[0], ok.reshape(valid[0].shape).astype(bool)) and valid.any()
+    assert len(levels) == len(ref)
+    for l, (a, r) in enumerate(zip(levels, ref)):
+        r = r.numpy().transpose(0, 2, 3, 4, 1)
+        assert a.shape == r.shape, (l, a.shape, r.shape)
+        assert float(np.abs(a - r).max()) <= 2e-4 * float(np.abs(r).max()), (l, float(np.abs(a - r).max()), float(np.abs(r).max()))
