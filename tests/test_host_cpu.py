@@ -1032,3 +1032,52 @@ def test_cpu_abi_indoor_extract_feat_matches_the_oracle_port(cfg_name):
         r = r.numpy().transpose(0, 2, 3, 4, 1)
         assert a.shape == r.shape, (l, a.shape, r.shape)
         assert float(np.abs(a - r).max()) <= 2e-4 * float(np.abs(r).max()), (l, float(np.abs(a - r).max()), float(np.abs(r).max()))
+
+
+def test_cpu_abi_stage_trace_levels():
+    """ivx_model_trace on the CPU restatement (events are wall-clock stamps there): level 2 brackets every launch group of a
+    forward (one record per conv layer, the unprojection and the tail), level 1 folds the 2-D trunk into ONE span (stage 6) and
+    keeps the neck layers, the unprojection and the tail; records carry the layer names and non-negative durations."""
+    import ctypes as C
+    import importlib.util
+    import imvoxelnet_amd as ia
+    from imvoxelnet_amd._lib import TraceRec
+    spec = importlib.util.spec_from_file_location('ivx_cpu_abi_host', os.path.join(ROOT, 'oracle', 'cpu_abi', 'host.py'))
+    host = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(host)
+    nv = (24, 28, 12)
+    cfg = kitti_model_cfg(n_voxels=nv, in_ch=16, out_ch=32)
+    ox = 0.5 + nv[0] * .32 / 2
+    cfg['bbox_head']['anchor_generator']['ranges'] = [[ox - nv[0] * .16, -nv[1] * .16, -1.78, ox + nv[0] * .16 - .32, nv[1] * .16 - .32, -1.78]]
+    model = ia.build_detector(cfg, test_cfg=dict(KITTI_TEST_CFG))
+    ia.randomize_(model, 7)
+    H, W = 64, 96
+    K = np.array([[36., 0, 40, 0], [0, 36., 22, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    E = np.array([[0, -1, 0, 0.0], [0, 0, -1, 0.2], [1, 0, 0, 0.1], [0, 0, 0, 1]], np.float32)
+    metas = [dict(img_shape=(H, W, 3), ori_shape=(H // 2, W // 2, 3), box_type_3d=ia.LiDARInstance3DBoxes,
+                  lidar2img=dict(intrinsic=K, extrinsic=[E], origin=np.array([ox, 0, -1.0], np.float32)))]
+    img = torch.randn(1, 1, 3, H, W, generator=torch.Generator().manual_seed(2))
+    cm = host.CpuModel(model)
+    try:
+        recs = {}
+        for level in (2, 1):
+            assert cm.L.ivx_model_trace(cm.h, level) == 0
+            cm.forward(img, metas)
+            n = cm.L.ivx_model_trace_count(cm.h)
+            out, rec = [], TraceRec()
+            for i in range(n):
+                assert cm.L.ivx_model_trace_read(cm.h, i, C.byref(rec)) == 0
+                out.append((rec.stage, rec.is3d, rec.ms, rec.name.decode()))
+            recs[level] = out
+            assert cm.L.ivx_model_trace(cm.h, 0) == 0
+    finally:
+        cm.close()
+    full, coarse = recs[2], recs[1]
+    assert all(r[2] >= 0 for r in full + coarse)
+    assert sum(r[0] == 4 for r in full) == 1 and sum(r[0] == 5 for r in full) == 1          # unprojection, tail
+    trunk_full = [r for r in full if r[0] == 0 and not r[1]]
+    assert len(trunk_full) >= 53 + 4 + 1 and any('backbone.layer3.5.conv2' in r[3] for r in trunk_full)   # ResNet-50 convs + FPN + head conv
+    assert sum(r[0] == 6 for r in coarse) == 1 and 'trunk' in [r for r in coarse if r[0] == 6][0][3]
+    neck_full, neck_coarse = [r for r in full if r[1] and r[0] <= 3], [r for r in coarse if r[1] and r[0] <= 3]
+    assert len(neck_full) == len(neck_coarse) == 9                                            # direct convs on the CPU restatement (no Winograd stages)
+    assert len(coarse) < len(full) / 3
