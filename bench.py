@@ -461,9 +461,7 @@ def main():
         ev_ids = range(1, args.warmup)       # skip the very first (cold) step
     ev_ids = list(ev_ids)
     # The nine conv layers of KittiImVoxelNeck run in the F(6x6,3x3) minimal-filtering form (csrc/winograd.hip): input
-    # transform -> ONE grouped launch of the implicit-GEMM kernel -> output transform, and (pipeline.py) the batch is cut
-    # into slices so the transform kernels of one slice stream through HBM on a second stream while the matrix cores work
-    # on the other slice.  The roofline entry is the implicit-GEMM kernel over its launches on the 3-D neck with the
+    # transform -> ONE grouped launch of the implicit-GEMM kernel -> output transform.  The roofline entry is the implicit-GEMM kernel over its launches on the 3-D neck with the
     # FLOPs the kernel EXECUTES (64/324 of the direct count for an F(6x6,3x3) layer) over the event-bracketed duration of
     # exactly those launches; direct_equivalent_tflops divides the direct-convolution FLOPs of the whole neck by the whole
     # neck time (it may exceed the MFMA peak).
@@ -530,7 +528,6 @@ def main():
 
     if rank == 0:
         total_images = B * world * args.steps
-        from imvoxelnet_amd import pipeline
         rec = {
             'metric': 'images/sec/node (KITTI 3x384x1280, 216x248x12 vox)',
             'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
@@ -541,7 +538,6 @@ def main():
                        'api': 'hipGraph replay' if args.graph else ('ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages'),
                        'device_side': ('native model handle (ivx_model_forward%s)' % (', hipGraph replay per shape' if model._native.graph else '')) if model._native is not None and args.api == 'simple_test' else 'layer-by-layer over the op-level C-ABI',
                        'stage_events': ('event-record nodes inside the replayed graph, read for the last timed step' if (native_trace and model._native.graph) else 'HIP event pairs around every launch of every timed step'),
-                       'neck_pipeline_chunks': pipeline.CHUNKS if FusedConv.winograd else 0,
                        'detections_last_step': n_det(last)},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, %d launches/step)' % ('__bf16' if bf16 else 'float', n_launch),
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
@@ -554,8 +550,7 @@ def main():
                          'direct_equivalent_tflops': round(flops_step / (neck_ms_avg * 1e-3) / 1e12, 2),
                          'winograd_gemm_launches_per_step': len([t for t in tr if t[0] == 'wino_gemm']) // nst},
             'roofline_winograd_transforms': None if not xf else {
-                'bound': 'hbm', 'kernel': 'wino_input_kernel + wino_output_kernel (%d launches/step, event-bracketed; they run beside '
-                                          'the GEMM of the other batch slice when pipelined)' % (len(xf) // nst),
+                'bound': 'hbm', 'kernel': 'wino_input_kernel + wino_output_kernel (%d launches/step, event-bracketed)' % (len(xf) // nst),
                 'achieved': round(xf_bytes / (xf_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
                 'frac': round(xf_bytes / (xf_ms * 1e-3) / 8e12, 4), 'ms_per_step': round(xf_ms, 3),
                 'algorithmic_GB_per_step': round(xf_bytes / 1e9, 2)},

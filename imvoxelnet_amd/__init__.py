@@ -1,6 +1,7 @@
 """imvoxelnet_amd -- MI355X-native ImVoxelNet forward path (hand-written HIP for gfx950 behind a C-ABI).
 
-Importing the package registers the modules under the reference's registry names; it does NOT load the
+Importing the package registers the modules under the reference's registry names in its OWN registries (aliasing them
+into mmdet's is an explicit register_into_mmdet() call or IVX_REGISTER_MMDET=1); it does NOT load the
 HIP library (that happens on first use and fails loudly if libimvoxel_hip.so is missing).
 """
 from .registry import (BACKBONES, NECKS, HEADS, DETECTORS, ANCHOR_GENERATORS, BBOX_CODERS, ConfigDict,  # noqa: F401
@@ -25,6 +26,6 @@ from .data import (load_checkpoint, prepare_image, MultiViewPipeline, KittiSetOr
                    imresize_cv2_linear)
 from .registry import maybe_register_into_mmdet as _reg_mmdet, register_into_mmdet  # noqa: F401
 
-_reg_mmdet()          # no-op unless mmdet is importable
+_reg_mmdet()          # opt-in (IVX_REGISTER_MMDET=1); otherwise call register_into_mmdet() explicitly
 
 __version__ = '0.2.0'

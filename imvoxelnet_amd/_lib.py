@@ -47,7 +47,7 @@ class TraceRec(C.Structure):
                 ('bytes', C.c_double), ('name', C.c_char * 48)]
 
 
-EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_winograd_set_transform_blocks', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
+EXPORTS = ['ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
            'ivx_conv_winograd_supported', 'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_weights', 'ivx_conv_winograd_workspace_bytes',
            'ivx_conv_winograd_input', 'ivx_conv_winograd_gemm', 'ivx_conv_winograd_output', 'ivx_conv_winograd_fwd',
            'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_maxpool2d_fwd_fp8', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_image_s2d_bf16', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
@@ -78,7 +78,6 @@ def lib():
     for name in ('ivx_conv_fwd', 'ivx_conv_fwd_naive'):
         getattr(L, name).argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
     L.ivx_conv_set_tile_override.argtypes = [C.c_int]
-    L.ivx_conv_winograd_set_transform_blocks.argtypes = [C.c_int]
     L.ivx_conv_set_epilogue_mode.argtypes = [C.c_int]
     L.ivx_conv_set_plan_mode.argtypes = [C.c_int]
     L.ivx_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
@@ -153,12 +152,10 @@ def lib():
     L.ivx_model_trace_count.argtypes = [vp]
     L.ivx_model_trace_count.restype = i32
     L.ivx_model_trace_read.argtypes = [vp, i32, C.POINTER(TraceRec)]
-    for name in EXPORTS:
-        if name not in ('ivx_last_error', 'ivx_anchor_head_workspace_bytes', 'ivx_nms_workspace_bytes',
-                        'ivx_fcos_head_workspace_bytes', 'ivx_conv_workspace_bytes', 'ivx_multiclass_nms_workspace_bytes',
-                        'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_workspace_bytes', 'ivx_model_workspace_bytes',
-                        'ivx_backbone_fpn_workspace_bytes', 'ivx_neck3d_workspace_bytes', 'ivx_model_trace_count'):
-            getattr(L, name).restype = C.c_int
+    # ctypes' default restype (c_int) is the int status every other entry point returns; the 64-bit queries must have been
+    # declared explicitly above (a missing one would silently truncate)
+    wide = [n for n in EXPORTS if n.endswith(('_workspace_bytes', '_weight_elems')) and getattr(L, n).restype is not C.c_int64]
+    assert not wide, f'int64-returning entry points without an explicit restype: {wide}'
     _lib = L
     return L
 

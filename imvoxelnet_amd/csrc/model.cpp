@@ -117,6 +117,7 @@ struct ivx_model {
   std::vector<float> anchors_host;     // [H*W*A, 7] for the (H, W) below; regenerated when the grid changes
   int anchors_h = 0, anchors_w = 0;
   float *anchors_dev = nullptr;
+  size_t anchors_cap = 0;              // floats anchors_dev holds
   std::vector<float> anchors_given;    // supplied through ivx_weights_load("anchors", ...)
   std::map<std::string, std::unique_ptr<Plan>> plans;
   std::vector<void *> owned;           // device allocations (weights, filters, anchors)
@@ -557,6 +558,10 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
       M_HIP(hipMalloc(&u, (size_t)n * sizeof(float)), "hipMalloc (Winograd filters)");
       m->owned.push_back(u);
       M_TRY(ivx_conv_winograd_weights(&wd, tile, L.w0, (float *)u, stream));
+      // One-time work of planning a new shape.  The *_workspace_bytes / *_dims queries plan on the NULL stream and the forward
+      // that follows may run on a non-blocking stream: the transformed filters must be complete before this returns, whatever
+      // stream later reads them.
+      M_HIP(hipStreamSynchronize(stream), "hipStreamSynchronize (Winograd filters)");
       L.u[tile] = (float *)u;
     }
   } else {
@@ -729,6 +734,38 @@ int trace_end(ivx_model *m, hipStream_t st) {
   return IVX_OK;
 }
 
+// The anchor grid of the tail for this (H, W): generated (or taken from ivx_weights_load("anchors")) and uploaded on first use of
+// a grid; the previous grid's device buffer is reused when it is large enough, freed otherwise.  Not on the steady-state path.
+int ensure_anchors(ivx_model *m, const ivx_anchor_head_desc &d, hipStream_t st, const char *who) {
+  if (m->anchors_h == d.H && m->anchors_w == d.W && m->anchors_dev) return IVX_OK;
+  const size_t n = (size_t)d.H * d.W * d.num_anchors * 7;
+  if (!m->anchors_given.empty()) {
+    M_REQUIRE(m->anchors_given.size() == n, "%s: the loaded anchors have %zu values, the %d x %d grid needs %zu", who, m->anchors_given.size(),
+              d.H, d.W, n);
+    m->anchors_host = m->anchors_given;
+  } else {
+    make_anchors(m->cfg, d.H, d.W, &m->anchors_host);
+  }
+  M_HIP(hipStreamSynchronize(st), "hipStreamSynchronize (anchors)");     // a forward in flight may still read the old grid
+  if (m->anchors_dev && m->anchors_cap < n) {
+    auto it = std::find(m->owned.begin(), m->owned.end(), (void *)m->anchors_dev);
+    if (it != m->owned.end()) m->owned.erase(it);
+    (void)hipFree(m->anchors_dev);
+    m->anchors_dev = nullptr;
+  }
+  if (!m->anchors_dev) {
+    void *p = nullptr;
+    M_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)), "hipMalloc (anchors)");
+    m->owned.push_back(p);
+    m->anchors_dev = (float *)p;
+    m->anchors_cap = n;
+  }
+  M_HIP(hipMemcpyAsync(m->anchors_dev, m->anchors_host.data(), n * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync (anchors)");
+  M_HIP(hipStreamSynchronize(st), "hipStreamSynchronize (anchors)");     // anchors_host may be rewritten by the next grid
+  m->anchors_h = d.H; m->anchors_w = d.W;
+  return IVX_OK;
+}
+
 int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *workspace, int64_t workspace_bytes, hipStream_t st,
               const char *who) {
   M_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, "%s: workspace must be non-null and 256-byte aligned", who);
@@ -821,18 +858,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
       }
       case ST_TAIL: {
         const ivx_anchor_head_desc &d = pl.tail;
-        if (m->anchors_h != d.H || m->anchors_w != d.W || !m->anchors_dev) {   // first use of this grid: not on the steady-state path
-          const size_t n = (size_t)d.H * d.W * d.num_anchors * 7;
-          if (!m->anchors_given.empty()) {
-            M_REQUIRE(m->anchors_given.size() == n, "%s: the loaded anchors have %zu values, the %d x %d grid needs %zu", who,
-                      m->anchors_given.size(), d.H, d.W, n);
-            m->anchors_host = m->anchors_given;
-          } else {
-            make_anchors(m->cfg, d.H, d.W, &m->anchors_host);
-          }
-          M_TRY(dev_upload(m, m->anchors_host, &m->anchors_dev, st));
-          m->anchors_h = d.H; m->anchors_w = d.W;
-        }
+        M_TRY(ensure_anchors(m, d, st, who));          // no-op on the steady-state path
         M_REQUIRE(bd.boxes && bd.scores && bd.labels && bd.count, "%s: output buffers are required", who);
         M_TRY(trace_begin(m, i, 5, 0, 0.0, 0.0, "anchor tail", st));
         M_TRY(ivx_anchor_head_get_bboxes(&d, (const float *)ptr(s.in), m->anchors_dev, ws, pl.ws_bytes, bd.boxes, bd.scores, bd.labels,
@@ -892,6 +918,12 @@ extern "C" int ivx_destroy(ivx_model *m) {
   return IVX_OK;
 }
 
+static void drop_graphs(ivx_model *m) {
+  for (ivx_model::GraphEntry &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+  m->graphs.clear();
+  m->warmed.clear();
+}
+
 extern "C" int ivx_weights_load(ivx_model *m, const char *key, const float *data, const int64_t *shape, int32_t ndim) {
   M_REQUIRE(m && key && data && (shape || ndim == 0) && ndim >= 0 && ndim <= 6, "ivx_weights_load: bad argument");
   M_REQUIRE(!m->finalized || !strcmp(key, "anchors"), "ivx_weights_load: the model is finalized; create a new handle to change weights");
@@ -907,6 +939,7 @@ extern "C" int ivx_weights_load(ivx_model *m, const char *key, const float *data
     M_REQUIRE(ndim == 2 && shape[1] == 7, "ivx_weights_load: anchors must be [n, 7]");
     m->anchors_given = t.data;
     m->anchors_h = m->anchors_w = 0;      // re-upload on the next forward
+    drop_graphs(m);                       // captured graphs replay the old grid (and possibly an old device pointer)
     return IVX_OK;
   }
   std::string k = key;
@@ -998,7 +1031,9 @@ extern "C" int ivx_model_forward(ivx_model *m, const float *input, int32_t B, in
       M_HIP(hipGraphLaunch(g.exec, st), "hipGraphLaunch");
       return IVX_OK;
     }
+  M_TRY(ensure_anchors(m, pl->tail, st, "ivx_model_forward"));    // allocation + H2D copy: never inside a capture
   if (std::find(m->warmed.begin(), m->warmed.end(), key) == m->warmed.end()) {
+    if (m->warmed.size() >= 8) m->warmed.erase(m->warmed.begin());     // a host that passes new buffers every call: bounded
     m->warmed.push_back(key);
     return run_steps(m, *pl, r, bd, workspace, workspace_bytes, st, "ivx_model_forward");
   }
@@ -1209,9 +1244,7 @@ extern "C" int ivx_voxel_new_origin(const float *origin, const int32_t *n_voxels
 extern "C" int ivx_model_trace(ivx_model *m, int32_t enable) {
   M_REQUIRE(m, "ivx_model_trace: null handle");
   if (m->trace_on != (enable != 0) || (enable && enable != m->trace_level)) {   // captured graphs hold (or lack) the event-record nodes: drop them on a change
-    for (ivx_model::GraphEntry &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
-    m->graphs.clear();
-    m->warmed.clear();
+    drop_graphs(m);
     m->trace.clear();
     m->events_used = 0;
   }

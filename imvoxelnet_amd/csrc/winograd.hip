@@ -320,23 +320,12 @@ ivx_conv_desc wino_group_desc(const ivx_conv_desc *d, const WinoDims &w) {
   return g;
 }
 
-// Tuning knob (per calling thread): > 0 caps the grid of the transform kernels (they are grid-stride loops), so that a
-// transform launch occupies only a fraction of the workgroup slots and can run BESIDE the MFMA-bound grouped GEMM of another
-// sample on a second stream (ivx_conv_winograd_set_transform_blocks).  0 = one workgroup per 256 items.
-thread_local int g_xf_blocks = 0;
-
 unsigned wino_blocks(int64_t items) {
-  int64_t b = (items + 255) / 256;
-  const int64_t cap = g_xf_blocks > 0 ? g_xf_blocks : (1 << 20);
-  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+  const int64_t b = (items + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > (1 << 20) ? (1 << 20) : b));
 }
 
 }  // namespace
-
-extern "C" int ivx_conv_winograd_set_transform_blocks(int n) {
-  g_xf_blocks = n > 0 ? n : 0;
-  return IVX_OK;
-}
 
 extern "C" int ivx_conv_winograd_supported(const ivx_conv_desc *d, int32_t tile) {
   WinoDims w;

@@ -17,21 +17,32 @@ IMG_NORM_CFG = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375],
 
 
 # ------------------------------------------------------------------ checkpoints
-def torch_load_trusted(filename, map_location='cpu'):
-    """torch.load for mmcv-style .pth files.  They are pickled dicts with 'meta' (strings, config text) and possibly
-    optimizer state next to 'state_dict', which torch >= 2.6's default weights_only=True refuses with an opaque
-    unpickling error; the caller vouches for the file, as mmcv.runner.load_checkpoint does."""
+def torch_load_trusted(filename, map_location='cpu', trusted=None):
+    """torch.load for mmcv-style .pth files: `weights_only=True` first (tensors, dicts, strings and numbers -- what a released
+    ImVoxelNet checkpoint holds -- load under it; nothing in the file is executed).  Files that carry other pickled objects
+    (an optimizer's param-group classes, numpy scalars in 'meta') need the full unpickler, which can run arbitrary code from
+    the file: that fallback is taken only when the caller vouches for the file -- `trusted=True`, or IVX_TRUST_CHECKPOINT=1
+    in the environment (what mmcv.runner.load_checkpoint does unconditionally)."""
+    import os
+    import pickle
     try:
-        return torch.load(filename, map_location=map_location, weights_only=False)
+        return torch.load(filename, map_location=map_location, weights_only=True)
     except TypeError:           # torch < 1.13: no weights_only argument
         return torch.load(filename, map_location=map_location)
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        if trusted is None:
+            trusted = os.environ.get('IVX_TRUST_CHECKPOINT', '0') == '1'
+        if not trusted:
+            raise RuntimeError(f'{filename}: not loadable with weights_only=True ({str(e).splitlines()[0][:160]}); if you trust the '
+                               'file, pass trusted=True (or set IVX_TRUST_CHECKPOINT=1) to unpickle it fully') from e
+        return torch.load(filename, map_location=map_location, weights_only=False)
 
 
-def load_checkpoint(model, filename, map_location='cpu', strict=False):
+def load_checkpoint(model, filename, map_location='cpu', strict=False, trusted=None):
     """mmcv.runner.load_checkpoint for the released ImVoxelNet .pth files: a dict with 'state_dict' (and 'meta'),
     keys optionally prefixed with 'module.'.  Returns the checkpoint dict.  A model that was already prepared is re-packed for
-    the device by its load_state_dict hook; otherwise call model.prepare(device) (or just run it)."""
-    ckpt = torch_load_trusted(filename, map_location=map_location)
+    the device by its load_state_dict hook; otherwise call model.prepare(device) (or just run it).  trusted: see torch_load_trusted."""
+    ckpt = torch_load_trusted(filename, map_location=map_location, trusted=trusted)
     sd = ckpt.get('state_dict', ckpt) if isinstance(ckpt, dict) else ckpt
     sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
     res = model.load_state_dict(sd, strict=False)

@@ -63,18 +63,6 @@ class _StackNeck(nn.Module):
                 k = len(self.fconv)
                 self.fconv.append(FusedConv(m[0].weight, m[0].bias, bn=m[1].tensors(), stride=self.strides[k],
                                             padding=self.paddings[k], relu=True).to(device))
-        # the chain as a flat list for the two-stream pipeline (pipeline.py): layer i adds activation res_from[i] (0 = the
-        # input, j + 1 = output of layer j) before its ReLU
-        self._chain, self._res_from = [], []
-        k = 0
-        for m in self.model:
-            if isinstance(m, BasicBlock3d):
-                self._res_from += [None, len(self._chain)]
-                self._chain += [m.f1, m.f2]
-            else:
-                self._res_from.append(None)
-                self._chain.append(self.fconv[k])
-                k += 1
         self._device = device
         return self
 
@@ -82,21 +70,6 @@ class _StackNeck(nn.Module):
         """x [B,X,Y,Z,C] -> [B,X',Y',1,Cout]."""
         if self._device is None:
             self.prepare(x.device)
-        from . import pipeline
-        if pipeline.CHUNKS >= 2 and pipeline.pipelined_ok(self._chain, x, pipeline.CHUNKS):
-            if FusedConv.count_flops:
-                shape = tuple(x.shape)
-                for f in self._chain:
-                    m, xs, wk, wst, wpad = f.wino_tile(shape)
-                    o = tuple((shape[1 + a] + 2 * f.padding[a] - f.kernel[a]) // f.stride[a] + 1 for a in range(3))
-                    FusedConv.flops += 2.0 * shape[0] * o[0] * o[1] * o[2] * f.cout * f.cin * 27
-                    FusedConv.exec_flops += (2.0 * (m + 2) ** 2 * shape[0] * ((o[0] + m - 1) // m) * ((o[1] + m - 1) // m) * o[2] *
-                                             f.cout * f.cin * 3)
-                    shape = (shape[0],) + o + (f.cout,)
-            x = pipeline.stack_forward_pipelined(self._chain, self._res_from, x, trace=FusedConv.trace)
-            if x.shape[3] != 1:
-                raise AssertionError(f'the z axis must collapse to 1 (got {x.shape[3]}); necks/imvoxelnet.py:119,150')
-            return x
         k = 0
         for m in self.model:
             if isinstance(m, BasicBlock3d):

@@ -232,8 +232,7 @@ def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1
 
 class WinogradLayerPlan:
     """One fp32 3x3xkw layer in the F(m x m, 3x3) form for a fixed input shape: descriptor, output shape and workspace
-    size, with the three stages as separate calls on caller-owned buffers (pipeline.py runs the transform stages of one
-    batch chunk beside the grouped GEMM of another on a second stream)."""
+    size, with the three stages as separate calls on caller-owned buffers (tools/gemm_ab.py times them one by one)."""
 
     def __init__(self, x_shape, Cout, kw, stride_w, padding, relu, wgt_layout, tile, has_res=False, res_after_act=False,
                  post_scale=1.0):
@@ -266,11 +265,6 @@ class WinogradLayerPlan:
     def output(self, scale, shift, res, out, ws):
         check(_lib.lib().ivx_conv_winograd_output(C.byref(self.d), self.tile, _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _ptr(ws),
                                                   ws.numel(), _stream()), 'ivx_conv_winograd_output')
-
-
-def winograd_set_transform_blocks(n):
-    """n > 0: cap the grid of the Winograd transform kernels at n workgroups (this thread); 0 = default."""
-    check(_lib.lib().ivx_conv_winograd_set_transform_blocks(int(n)), 'ivx_conv_winograd_set_transform_blocks')
 
 
 def maxpool2d(x, k=3, s=2, p=1):

@@ -1,10 +1,11 @@
 """Registries with the reference's names (mmdet registries re-exported by
 mmdet3d/models/builder.py:1-52): configs written for the reference (`dict(type='ImVoxelNet', ...)`,
 `type='KittiImVoxelNeck'`, ...) build the MI355X modules unchanged.  mmdet is absent from this image, so a minimal
-registry is built in; where mmdet IS importable, register_into_mmdet() (called on package import) puts the same classes
-into mmdet's own DETECTORS / NECKS / HEADS / BACKBONES / ANCHOR_GENERATORS / BBOX_CODERS under the same names
-(force=True, replacing the reference's CUDA-path classes), so `build_detector(cfg.model)` of an unmodified reference
-tools/test.py builds the MI355X modules.  IVX_REGISTER_MMDET=0 disables that.
+registry is built in; where mmdet IS importable, register_into_mmdet() -- an explicit call, or IVX_REGISTER_MMDET=1 to have
+the package import do it -- puts the same classes into mmdet's own DETECTORS / NECKS / HEADS / BACKBONES /
+ANCHOR_GENERATORS / BBOX_CODERS under the same names (force=True, replacing the reference's CUDA-path classes AND mmdet's
+generic ResNet / FPN for the process), so `build_detector(cfg.model)` of the reference's tools/test.py builds the MI355X
+modules.  Call it after mmdet3d has been imported: mmdet3d's own non-forced registrations would otherwise collide.
 """
 import os
 
@@ -118,6 +119,10 @@ def register_into_mmdet(force=True):
 
 
 def maybe_register_into_mmdet():
-    if os.environ.get('IVX_REGISTER_MMDET', '1') != '0':
+    """Opt-in at import time: IVX_REGISTER_MMDET=1 aliases the classes into mmdet's registries while the package is imported
+    (replacing mmdet's own 'ResNet' / 'FPN' / 'Anchor3DHead' for the whole process, and -- if mmdet3d is imported afterwards --
+    colliding with its non-forced registration of 'ImVoxelNet').  Without it nothing outside this package is touched; a host
+    that wants the aliases calls register_into_mmdet() itself, after importing mmdet3d."""
+    if os.environ.get('IVX_REGISTER_MMDET', '0') == '1':
         return register_into_mmdet()
     return {}

@@ -137,10 +137,6 @@ int ivx_conv_winograd_fwd(const ivx_conv_desc *d, int32_t tile, const void *in, 
 /* Tuning knob for A/B experiments only (per calling thread): 0 = automatic tile choice (default); 1..7 force a tile
  * of the generic kernel, 41..53 of the LDS-DMA fp32 kernel, 61..73 of its bf16 instantiation. */
 int ivx_conv_set_tile_override(int cfg);
-/* Per calling thread: n > 0 caps the grid of the Winograd transform kernels (grid-stride loops) at n workgroups, so a
- * transform launch leaves most workgroup slots free and can run beside the MFMA-bound grouped GEMM of another sample on a
- * second stream; 0 (default) = one workgroup per 256 work items. */
-int ivx_conv_winograd_set_transform_blocks(int n);
 /* Per calling thread, A/B only: 1 = one-channel-per-lane epilogue stores in the LDS-DMA conv kernel; 0 (default) = the
  * LDS-transposed epilogue (a lane stores 4 consecutive channels as one 16-byte word) wherever it applies. */
 int ivx_conv_set_epilogue_mode(int narrow);

@@ -990,39 +990,6 @@ def test_conv_winograd_fullsize_kitti_layers(ia, shape):
     assert torch.equal(b, a * 2.0)
 
 
-@pytest.mark.parametrize('neck_name', ['kitti', 'nuscenes'])
-def test_pipelined_stack_equals_sequential(ia, neck_name):
-    """pipeline.py: the two-stream software pipeline (transform stages of one batch slice beside the grouped GEMM of
-    another) runs exactly the kernels of the layer-by-layer path on exactly the same data -> bit-identical output,
-    for 2 and 4 slices, with and without a grid cap on the transform kernels."""
-    from imvoxelnet_amd import pipeline
-    neck = (ia.KittiImVoxelNeck if neck_name == 'kitti' else ia.NuScenesImVoxelNeck)(64, 256)
-    ia.randomize_(neck, 5)
-    neck.prepare(torch.device('cuda'))
-    x = torch.randn(4, 60, 66, 12, 64, device='cuda', generator=torch.Generator(device='cuda').manual_seed(2))
-    old = (pipeline.CHUNKS, pipeline.XF_BLOCKS, pipeline.XF_PRIORITY)
-    try:
-        pipeline.CHUNKS = 0
-        ref = neck.forward_cl(x).clone()
-        if neck_name == 'nuscenes':      # its first down-conv has stride 2 on the transformed axes: no Winograd form, no pipeline
-            assert not pipeline.pipelined_ok(neck._chain, x, 2)
-            pipeline.CHUNKS = 2
-            assert torch.equal(neck.forward_cl(x), ref)
-            return
-        assert pipeline.pipelined_ok(neck._chain, x, 2)
-        for chunks, cap, prio in ((2, 512, -1), (4, 0, 0), (2, 64, 0)):
-            pipeline.CHUNKS, pipeline.XF_BLOCKS, pipeline.XF_PRIORITY = chunks, cap, prio
-            for _ in range(3):      # repeated: a missing cross-stream dependency shows up as a race, not every time
-                y = neck.forward_cl(x)
-                torch.cuda.synchronize()
-                assert torch.equal(y, ref), f'chunks {chunks} cap {cap}: {(y != ref).sum().item()} values differ'
-        pipeline.CHUNKS = 2       # batch not divisible / tiny layer -> falls back to the sequential path
-        assert not pipeline.pipelined_ok(neck._chain, x[:3], 2)
-        assert torch.equal(neck.forward_cl(x[:3].contiguous()), ref[:3])
-    finally:
-        pipeline.CHUNKS, pipeline.XF_BLOCKS, pipeline.XF_PRIORITY = old
-
-
 def test_topk_chipwide_equals_single_workgroup(ia):
     """The candidate top-k of the detection tails on long score lists (histogram of the top 16 key bits -> threshold bin ->
     compaction -> LDS sort, csrc/anchor_tail.hip launch_topk) against the one-workgroup radix select it replaces there:

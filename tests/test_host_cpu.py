@@ -307,6 +307,14 @@ def test_input_side_adapters(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(neck.state_dict().values(), neck2.state_dict().values()))
     with pytest.raises(RuntimeError):
         data.load_checkpoint(ia.NuScenesImVoxelNeck(8, 8), str(f), strict=True)
+    # a file that needs the full unpickler (an arbitrary object next to the tensors) is refused unless the caller vouches for it
+    import argparse
+    f2 = tmp_path / 'ckpt_obj.pth'
+    torch.save(dict(meta=dict(CLASSES=('Car',), cfg=argparse.Namespace(a=1)), state_dict=neck.state_dict()), f2)
+    with pytest.raises(RuntimeError, match='trusted=True'):
+        data.load_checkpoint(ia.KittiImVoxelNeck(4, 8), str(f2))
+    ck2 = data.load_checkpoint(ia.KittiImVoxelNeck(4, 8), str(f2), trusted=True)
+    assert ck2['meta']['cfg'].a == 1
     # KITTI: 375 x 1242 -> Resize((1280, 384), keep_ratio) -> 384 x 1272 -> Pad 32 -> 384 x 1280   
     img = (np.random.RandomState(0).rand(375, 1242, 3) * 255).astype(np.uint8)
     t, meta = data.prepare_image(img, (1280, 384))
@@ -747,8 +755,11 @@ def test_register_into_mmdet_when_importable(monkeypatch):
     assert regs['BACKBONES'].module_dict['ResNet'] is ia.ResNet
     assert regs['ANCHOR_GENERATORS'].module_dict['Anchor3DRangeGenerator'] is ia.Anchor3DRangeGenerator
     assert regs['BBOX_CODERS'].module_dict['DeltaXYZWLHRBBoxCoder'] is ia.DeltaXYZWLHRBBoxCoder
-    monkeypatch.setenv('IVX_REGISTER_MMDET', '0')
+    # the import-time hook is opt-in: without IVX_REGISTER_MMDET=1 importing the package touches nothing outside it
+    monkeypatch.delenv('IVX_REGISTER_MMDET', raising=False)
     assert registry.maybe_register_into_mmdet() == {}
+    monkeypatch.setenv('IVX_REGISTER_MMDET', '1')
+    assert registry.maybe_register_into_mmdet() != {}
 
 
 def _ragged_gather_worker(rank, world, port, out_q):
