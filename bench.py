@@ -21,9 +21,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, 'tests')):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -31,6 +30,29 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
 BATCH_PER_GPU = 4
+
+
+def measured_ceilings(dev, bf16=False):
+    """Device ceilings measured on this box at start-up (csrc/ubench.hip): the dense issue rate of the MFMA form the conv kernel
+    uses and the HBM streaming copy rate over 2 x 1 GiB buffers.  ~0.3 s; the buffers are freed before the model is built."""
+    import ctypes as C
+    from imvoxelnet_amd import _lib
+    L = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    v = C.c_double()
+    scratch = torch.empty((1 << 20,), device=dev, dtype=torch.uint8)
+    for name, dt in (('mfma_f32_tflops', 0),) + ((('mfma_bf16_tflops', 1),) if bf16 else ()):
+        _lib.check(L.ivx_ubench_mfma(dt, C.c_void_p(scratch.data_ptr()), scratch.numel(), C.byref(v), st), 'ivx_ubench_mfma')
+        out[name] = round(v.value, 1)
+    n = 1 << 30
+    a, b = torch.empty((n,), device=dev, dtype=torch.uint8), torch.empty((n,), device=dev, dtype=torch.uint8)
+    a.zero_()
+    _lib.check(L.ivx_ubench_copy(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), n, C.byref(v), st), 'ivx_ubench_copy')
+    out['hbm_copy_gbps'] = round(v.value, 1)
+    del a, b, scratch
+    torch.cuda.empty_cache()
+    return out
 
 
 def neck_flops_per_sample(nv, c_in, c_out):
@@ -118,8 +140,10 @@ def bench_other(args, ia, kc, dev, rank, world):
     if args.trunk_fp8:
         if args.storage != 'bf16':
             raise SystemExit('--trunk-fp8 goes on top of --storage bf16 (BASELINE config 5: "bf16 with fp8 2D-conv MFMA")')
-        model.calibrate_fp8(img, stages=args.fp8_stages)   # one bf16 pass over the batch: per-tensor activation scales
-        fp8_note = 'ResNet-50 activations and weights stored as e4m3 (calibrated per-tensor / per-channel scales; stages: %s), v_mfma_f32_32x32x16_fp8_fp8' % ('all' if args.fp8_stages is None else args.fp8_stages)
+        model.calibrate_fp8(img, stages=args.fp8_stages, residual=args.fp8_residual)   # one bf16 pass over the batch: per-tensor activation scales
+        fp8_note = ('ResNet-50 %s stored as e4m3 (calibrated per-tensor / per-channel scales; stages: %s; residual stream: %s), v_mfma_f32_32x32x16_fp8_fp8'
+                    % ('activations and weights' if args.fp8_residual == 'fp8' else 'bottleneck interiors (conv1 / conv2 outputs, conv2 / conv3 weights)',
+                       'all' if args.fp8_stages is None else args.fp8_stages, args.fp8_residual))
     n = args.steps + args.warmup
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     neck_flops, neck_exec = [0.0], [0.0]    # direct-convolution FLOPs / FLOPs executed (fewer for Winograd-form layers)
@@ -223,7 +247,7 @@ def bench_other(args, ia, kc, dev, rank, world):
     rec = {'metric': f'images/sec/node ({args.config}: {V} view(s) 3x{H}x{W}, {"x".join(map(str, cfg["n_voxels"]))} vox)',
            'value': round(B * V * args.steps / dt, 3), 'unit': 'images/s', 'scenes_per_s': round(B * args.steps / dt, 3), 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-           'scaling': 'strong' if view_sharded else 'weak', 'vs_baseline': None, 'dtype': args.storage + ('+fp8 trunk' if args.trunk_fp8 else ''), 'data': 'synthetic',
+           'scaling': 'strong' if view_sharded else 'weak', 'vs_baseline': None, 'dtype': args.storage + ((' + fp8 2-D conv (bf16 residual stream)' if args.fp8_residual == 'bf16' else ' + fp8 trunk storage') if args.trunk_fp8 else ''), 'data': 'synthetic',
            'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'shard': args.shard, 'trunk_fp8': fp8_note, 'api': 'simple_test (native handle)' if public else 'composed',
                       'detections_last_step': int(sum(len(r[1]) for r in last))},
            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck)' % ('__bf16' if args.storage == 'bf16' else 'float'),
@@ -299,6 +323,7 @@ def main():
                     help="multi-GPU partition: 'samples' (default; weak scaling, the headline mode) or 'views' (indoor multi-view "
                          "configs: the views of each scene are split over the ranks, one RCCL all-reduce of the partial volume; strong scaling)")
     ap.add_argument('--fp8-stages', type=int, default=None, help='--trunk-fp8: how many leading ResNet stages store e4m3 (default: all four)')
+    ap.add_argument('--fp8-residual', default='bf16', choices=['bf16', 'fp8'], help="--trunk-fp8: 'bf16' (default) keeps the residual stream in bf16 and stores the bottleneck interiors as e4m3; 'fp8' stores every trunk activation as e4m3 (bandwidth stress mode, ~10 %% feature noise)")
     ap.add_argument('--trunk-fp8', action='store_true', help='with --storage bf16 and an indoor --config: e4m3 storage of the 2-D trunk (calibrated on the bench batch)')
     ap.add_argument('--graph', action='store_true',
                     help='replay the device side of the step as one captured hipGraph (kitti config); the roofline entry is then '
@@ -345,8 +370,8 @@ def main():
 
     import imvoxelnet_amd as ia
     from imvoxelnet_amd import dist as ivx_dist, ops
-    import kitti_cfg as kc
-    from kitti_cfg import kitti_model_cfg, KITTI_TEST_CFG, kitti_meta
+    from imvoxelnet_amd import workloads as kc
+    from imvoxelnet_amd.workloads import kitti_model_cfg, KITTI_TEST_CFG, kitti_meta
     from imvoxelnet_amd.conv import FusedConv
 
     if os.environ.get('IVX_NARROW_EPILOGUE') == '1':       # A/B of the conv epilogue (default: LDS-transposed wide stores)
@@ -369,8 +394,11 @@ def main():
         model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
         model.bbox_head.conv_dir_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(7))
     bf16 = args.storage == 'bf16'
+    ceil = measured_ceilings(dev, bf16) if os.environ.get('IVX_BENCH_UBENCH', '1') != '0' else {}
     model.prepare(dev, dtype=torch.bfloat16 if bf16 else torch.float32)
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    peak_meas = ceil.get('mfma_bf16_tflops' if bf16 else 'mfma_f32_tflops')
+    hbm_meas = ceil.get('hbm_copy_gbps')
     esz = 2 if bf16 else 4
 
     B = args.batch
@@ -401,7 +429,7 @@ def main():
                 FusedConv.trace, ops.stage_trace = None, None
 
         def n_det(out):
-            return int(sum(len(r['scores_3d']) for r in out))
+            return int(sum(len(r['scores_3d']) for r in out)) if out is not None else 0
     else:
         def step(i):
             FusedConv.trace, ops.stage_trace = traces[i], lifts[i]
@@ -451,7 +479,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    rank_ms, rccl_ranks = [round(dt / args.steps * 1e3, 3)], 1
     if multi:
+        # self-check of the N > 1 line: every rank's own step time (all-gather) and the rank count an actual RCCL all-reduce sees
+        tl = torch.tensor([dt], device=dev, dtype=torch.float64)
+        allt = torch.empty((dist.get_world_size(),), device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, tl)
+        rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in allt.cpu()]
+        ones = torch.ones((1,), device=dev, dtype=torch.float32)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(ones.item())
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -514,7 +551,7 @@ def main():
     # from the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh -> profiles/*_bench_pmc.json;
     # FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as reported), averaged per launch; null if absent.
     traffic, traffic_src = None, None
-    for name in ('r02_bench_pmc.json', 'r01_bench_pmc.json'):
+    for name in ('r03_bench_pmc.json', 'r02_bench_pmc.json', 'r01_bench_pmc.json'):
         pj = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pj) and not bf16:
             try:   # the summary covers the main launch of every neck layer: HBM bytes averaged per launch
@@ -538,10 +575,17 @@ def main():
                        'api': 'hipGraph replay' if args.graph else ('ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages'),
                        'device_side': ('native model handle (ivx_model_forward%s)' % (', hipGraph replay per shape' if model._native.graph else '')) if model._native is not None and args.api == 'simple_test' else 'layer-by-layer over the op-level C-ABI',
                        'stage_events': ('event-record nodes inside the replayed graph, read for the last timed step' if (native_trace and model._native.graph) else 'HIP event pairs around every launch of every timed step'),
-                       'detections_last_step': n_det(last)},
+                       'detections_last_step': n_det(last), 'rccl_ranks': rccl_ranks, 'ms_per_step_by_rank': rank_ms,
+                       'collective': 'one all_gather_into_tensor of padded detections per step (RCCL)' if multi else None},
+            'measured_ceilings': dict(ceil, note='csrc/ubench.hip at start-up: MFMA issue rate of the conv kernel\'s instruction, HBM copy rate '
+                                                 '(read + written bytes) over 2 x 1 GiB') if ceil else None,
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, %d launches/step)' % ('__bf16' if bf16 else 'float', n_launch),
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': f'GB/launch (rocprofv3 PMC, {traffic_src})',
+                         'frac': round(achieved / peak, 4),
+                         'peak_measured': peak_meas, 'frac_of_measured': round(achieved / peak_meas, 4) if peak_meas else None,
+                         'frac_whole_neck': round(mfma_flops / (neck_ms_avg * 1e-3) / 1e12 / peak, 4),
+                         'traffic': traffic, 'traffic_unit': 'GB/launch', 'traffic_source': f'committed profile {traffic_src} (rocprofv3 --pmc pass of this command; '
+                                                                                             'PMC counters cannot be read in-process)' if traffic is not None else None,
                          'algorithmic_gflop_per_launch': round(mfma_flops / n_launch / 1e9, 2),
                          'avg_launch_ms': round(mfma_ms / n_launch, 4), 'launches_per_step': n_launch,
                          'mfma_launch_ms_per_step': round(mfma_ms, 3),
@@ -552,11 +596,14 @@ def main():
             'roofline_winograd_transforms': None if not xf else {
                 'bound': 'hbm', 'kernel': 'wino_input_kernel + wino_output_kernel (%d launches/step, event-bracketed)' % (len(xf) // nst),
                 'achieved': round(xf_bytes / (xf_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                'frac': round(xf_bytes / (xf_ms * 1e-3) / 8e12, 4), 'ms_per_step': round(xf_ms, 3),
+                'frac': round(xf_bytes / (xf_ms * 1e-3) / 8e12, 4), 'peak_measured': hbm_meas,
+                'frac_of_measured': round(xf_bytes / (xf_ms * 1e-3) / 1e9 / hbm_meas, 4) if hbm_meas else None, 'ms_per_step': round(xf_ms, 3),
                 'algorithmic_GB_per_step': round(xf_bytes / 1e9, 2)},
             'roofline_unprojection': {'bound': 'hbm', 'kernel': 'backproject_single_view_kernel (1 launch/step, event-bracketed)',
                                       'achieved': round(lift_bytes / (lift_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                                      'frac': round(lift_bytes / (lift_ms * 1e-3) / 8e12, 4), 'ms': round(lift_ms, 4),
+                                      'frac': round(lift_bytes / (lift_ms * 1e-3) / 8e12, 4), 'peak_measured': hbm_meas,
+                                      'frac_of_measured': round(lift_bytes / (lift_ms * 1e-3) / 1e9 / hbm_meas, 4) if hbm_meas else None,
+                                      'ms': round(lift_ms, 4),
                                       'algorithmic_MB': round(lift_bytes / 1e6, 1)},
             'roofline_trunk_2d': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel (ResNet-50 + FPN level 0 + head conv; %s)' % (
                                       'one event pair around the whole trunk + one around the head conv' if native_trace else

@@ -15,6 +15,7 @@ SOURCES = [
     ('backproject.hip', ['-ffp-contract=off']),
     ('anchor_tail.hip', ['-ffp-contract=off']),
     ('dcn.hip', []),
+    ('ubench.hip', []),
     ('api_common.cpp', []),
     ('kitti_eval.cpp', []),
     ('model.cpp', ['-ffp-contract=off']),

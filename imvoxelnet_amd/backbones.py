@@ -34,16 +34,20 @@ class _Bottleneck(nn.Module):
         else:
             self.downsample = None
 
-    def prepare(self, device, in_dtype=None):
+    def prepare(self, device, in_dtype=None, stream_dtype=None):
         """in_dtype: storage type of the block's INPUT when it differs from the block's own (the first bf16 block after the e4m3
-        stages of the fp8 trunk): conv1 and the shortcut conv read it."""
+        stages of the fp8 trunk): conv1 and the shortcut conv read it.
+        stream_dtype (fp8 trunk, residual='bf16'): storage type of the RESIDUAL STREAM -- the block's input, its shortcut and its
+        output -- while the branch (conv1 -> conv2 -> conv3 inputs) uses the current storage type (e4m3): the stream is never
+        re-quantised, so the e4m3 rounding noise of one block does not ride on into the next ones."""
         from .conv import current_storage_dtype
         sd = current_storage_dtype()
+        xd = stream_dtype or in_dtype or sd            # what conv1 / the shortcut read
+        od = stream_dtype or sd                        # what conv3 / the shortcut write
         # style='pytorch': the stride sits on the 3x3 conv
-        self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2, dtype=in_dtype or sd, out_dtype=sd).to(device)
+        self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2, dtype=xd, out_dtype=sd).to(device)
         if self.dcn:
-            from .conv import current_storage_dtype
-            if current_storage_dtype() != torch.float32:
+            if sd != torch.float32:
                 raise NotImplementedError('the DCNv2 stages are built for float32 storage only')
             co = self.conv2.conv_offset
             self.f_off = FusedConv(co.weight, co.bias, stride=self.stride, padding=1, dims=2).to(device)
@@ -52,12 +56,12 @@ class _Bottleneck(nn.Module):
             self.f2 = FusedConv(w_col, bn=self.bn2.tensors(), relu=True, dims=2).to(device)
         else:
             self.f2 = FusedConv(self.conv2.weight, bn=self.bn2.tensors(), stride=self.stride, padding=1, relu=True, dims=2).to(device)
-        self.f3 = FusedConv(self.conv3.weight, bn=self.bn3.tensors(), relu=True, dims=2).to(device)  # relu after the add
+        self.f3 = FusedConv(self.conv3.weight, bn=self.bn3.tensors(), relu=True, dims=2, dtype=sd, out_dtype=od).to(device)  # relu after the add
         self.fd = None
         if self.downsample is not None:
             self.fd = FusedConv(self.downsample[0].weight, bn=self.downsample[1].tensors(), stride=self.stride, dims=2,
-                                dtype=in_dtype or sd, out_dtype=sd).to(device)
-        elif in_dtype is not None and in_dtype != sd:
+                                dtype=xd, out_dtype=od).to(device)
+        elif in_dtype is not None and in_dtype != sd and stream_dtype is None:
             raise ValueError('a block without a shortcut conv keeps the storage type of its input')
 
     def forward_cl(self, x):
@@ -142,24 +146,30 @@ class ResNet(nn.Module):
         w = self.conv1.weight.detach()
         if fp8 and tuple(w.shape[1:]) != (3, 7, 7):
             raise NotImplementedError('fp8 trunk storage is built for the 3-channel 7x7 stem')
+        # fp8 trunk, residual='bf16' (detector.calibrate_fp8): only the inside of every bottleneck is e4m3 -- the stem, the
+        # max-pool and every block output (the residual stream) stay bf16
+        res_bf16 = fp8 and getattr(self, 'fp8_residual', 'fp8') == 'bf16'
         if current_storage_dtype() in (torch.bfloat16, FP8) and tuple(w.shape[1:]) == (3, 7, 7):
             w2 = stem_s2d_weights(w)
             self.stem_s2d = FusedConv(w2, bn=self.bn1.tensors(), stride=1, padding=1, relu=True, dims=2, dtype=torch.bfloat16,
-                                      out_dtype=FP8 if fp8 else torch.bfloat16, key=id(self.conv1.weight)).to(device)
+                                      out_dtype=FP8 if (fp8 and not res_bf16) else torch.bfloat16, key=id(self.conv1.weight)).to(device)
         # fp8 trunk: the first `fp8_stages` stages store e4m3, the rest bf16 (their residual streams carry 8 mantissa bits
         # again; the first block of the first bf16 stage reads e4m3).  stage_dtypes: storage type of every stage's OUTPUT.
         from .conv import storage_dtype
         n_req = getattr(self, 'fp8_stages', None)      # set by detector.calibrate_fp8(stages=...); None: all stages
         n8 = 0 if not fp8 else (self.num_stages if n_req is None else max(0, min(int(n_req), self.num_stages)))
         self.stage_dtypes = []
-        prev = current_storage_dtype()
+        prev = torch.bfloat16 if res_bf16 else current_storage_dtype()
         for i in range(self.num_stages):
             sd = current_storage_dtype() if not fp8 else (FP8 if i < n8 else torch.bfloat16)
             with storage_dtype(sd):
                 for j, blk in enumerate(getattr(self, f'layer{i + 1}')):
-                    blk.prepare(device, in_dtype=prev if (j == 0 and prev != sd) else None)
-            self.stage_dtypes.append(sd)
-            prev = sd
+                    if res_bf16:
+                        blk.prepare(device, stream_dtype=torch.bfloat16 if sd == FP8 else None)
+                    else:
+                        blk.prepare(device, in_dtype=prev if (j == 0 and prev != sd) else None)
+            self.stage_dtypes.append(torch.bfloat16 if res_bf16 else sd)
+            prev = self.stage_dtypes[-1]
         self._device = device
         return self
 

@@ -179,6 +179,61 @@ __device__ int greedy_scan_wave(const unsigned long long *mask, int n, int cb_st
   return nk;
 }
 
+// ---- General N (> 4096 candidates; the reference op takes any N, iou3d.cpp:95-147 with col_blocks = DIVUP(N, 64)).
+// The removal set no longer fits one word per lane, so it lives in the scanning wave's LDS (IVX_NMS_MAX_N / 64 words); the
+// visiting order is either the row order (triangular mask over score-sorted boxes: only the words >= the row's own are
+// defined) or an explicit order over a FULL hit matrix indexed by original box (order != NULL; the next 64 entries are
+// prefetched into the lanes).  One wave, one dependent step per visited box, as in the 64-word form above -- same kept
+// sequence by construction.  Kept entries go straight to global memory: out[nk] = remap ? remap[i] : i.
+#define IVX_NMS_MAX_N 65536
+template <typename OutT>
+__device__ int greedy_scan_big(const unsigned long long *mask, const int *order, int n, int cb, int max_keep, const int *remap,
+                               unsigned long long *remv /* LDS, cb words */, OutT *out) {
+  const int lane = threadIdx.x & 63;
+  for (int w = lane; w < cb; w += 64) remv[w] = 0ULL;
+  __syncthreads();                                  // (a one-wave workgroup: orders the LDS accesses)
+  int nk = 0, chunk = 0;
+  for (int i = 0; i < n && nk < max_keep; ++i) {
+    if (order && (i & 63) == 0) chunk = (i + lane < n) ? order[i + lane] : 0;
+    const int a = order ? __shfl(chunk, i & 63, 64) : i;
+    const unsigned long long rw = remv[a >> 6];
+    if (!((rw >> (a & 63)) & 1ULL)) {
+      if (lane == 0) out[nk] = (OutT)(remap ? remap[i] : i);
+      ++nk;
+      const unsigned long long *row = mask + (size_t)a * cb;
+      for (int w = (order ? 0 : (a >> 6)) + lane; w < cb; w += 64) remv[w] |= row[w];
+      __syncthreads();
+    }
+  }
+  return nk;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_big_kernel(const unsigned long long *mask, const int *order, int n, int cb, const int *remap,
+                                                          long long *keep, int *num_out) {
+  __shared__ unsigned long long remv[IVX_NMS_MAX_N / 64];
+  const int nk = greedy_scan_big(mask, order, n, cb, n, remap, remv, keep);
+  if (threadIdx.x == 0) *num_out = nk;
+}
+
+// Rank sort of n 64-bit keys, descending, for lists beyond one workgroup's LDS sort: rank[i] = #{j : key[j] > key[i]} (the keys
+// are unique -- their low word is ~index).  O(n^2) compares, n^2 / 256 per workgroup from LDS tiles: 0.4 G compares at n = 20 000.
+// grid (ceil(n / 256), lists); keys [lists][stride].
+__global__ __launch_bounds__(256) void rank_sort_kernel(const unsigned long long *keys, int n, int stride, int *rank) {
+  __shared__ unsigned long long tile[1024];
+  const unsigned long long *k = keys + (size_t)blockIdx.y * stride;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long mine = i < n ? k[i] : 0ULL;
+  int r = 0;
+  for (int base = 0; base < n; base += 1024) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = base + t < n ? k[base + t] : 0ULL;
+    __syncthreads();
+    const int lim = n - base < 1024 ? n - base : 1024;
+    for (int t = 0; t < lim; ++t) r += tile[t] > mine ? 1 : 0;
+  }
+  if (i < n) rank[(size_t)blockIdx.y * stride + i] = r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Anchor head: scores
 struct HeadP {
@@ -745,14 +800,14 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long *
 }
 
 extern "C" int64_t ivx_nms_workspace_bytes(int32_t n) {
-  if (n < 0) return -1;
+  if (n < 0 || n > IVX_NMS_MAX_N) return -1;
   const int64_t cb = (n + 63) / 64;
   return ivx_align_up((int64_t)(n > 0 ? n : 1) * (cb > 0 ? cb : 1) * 8, 256);
 }
 
 extern "C" int ivx_nms_bev(const float *boxes_sorted, int32_t n, float thresh, int32_t rotated, void *workspace,
                            int64_t workspace_bytes, int64_t *keep, int32_t *num_out, ivx_stream_t stream) {
-  IVX_REQUIRE(n >= 0 && n <= 4096, "ivx_nms_bev: n must be in 0..4096 (got %d)", n);
+  IVX_REQUIRE(n >= 0 && n <= IVX_NMS_MAX_N, "ivx_nms_bev: n must be in 0..%d (got %d)", IVX_NMS_MAX_N, n);
   IVX_REQUIRE(keep && num_out, "ivx_nms_bev: null output");
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) {
@@ -771,7 +826,11 @@ extern "C" int ivx_nms_bev(const float *boxes_sorted, int32_t n, float thresh, i
   const int cb = (n + 63) / 64;
   unsigned long long *mask = (unsigned long long *)workspace;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, n, 1), dim3(64), 0, st, boxes_sorted, (const int *)nullptr, n, n, cb, thresh, rotated, mask);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, mask, n, cb, (long long *)keep, num_out);
+  if (n <= 4096)
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, mask, n, cb, (long long *)keep, num_out);
+  else       // removal words in LDS instead of one per lane: same kept sequence
+    hipLaunchKernelGGL(nms_scan_big_kernel, dim3(1), dim3(64), 0, st, mask, (const int *)nullptr, n, cb, (const int *)nullptr, (long long *)keep,
+                       num_out);
   IVX_CHECK_LAUNCH("ivx_nms_bev");
   return IVX_OK;
 }
@@ -950,8 +1009,42 @@ __global__ __launch_bounds__(256) void mc_finalize_kernel(const McP p, long long
   out_label[rank] = c;
 }
 
-static int mc_layout(int32_t n, int32_t num_classes, McP *p, int64_t *total) {
-  IVX_REQUIRE(n >= 0 && n <= 4096, "ivx_multiclass_nms_bev: n must be in 0..4096 (got %d)", n);
+// ---- n > 4096: the per-class LDS sort becomes keys + rank sort + scatter, the hit matrix is always the shared one (full rows over
+// the original indices) and the per-class scan keeps its removal bits in LDS (greedy_scan_big with an explicit order).
+__global__ __launch_bounds__(256) void mc_keys_big_kernel(const McP p, unsigned long long *keys) {
+  const int c = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const float sc = p.scores[(size_t)i * p.score_stride + c];
+  // below the threshold: high word 0 (below every kept key: f2key of a score > thr >= -inf is > 0 ... f2key(x) >= 1 for any
+  // non-NaN x except -max; a filtered entry still gets a unique key, so the ranks form a permutation)
+  const bool ok = sc > p.score_thr;
+  keys[(size_t)c * p.ns + i] = ((unsigned long long)(ok ? f2key(sc) : 0u) << 32) | (unsigned int)(~(unsigned int)i);
+  if (ok) atomicAdd(&p.n_arr[c], 1);
+}
+
+__global__ __launch_bounds__(256) void mc_scatter_big_kernel(const McP p, const unsigned long long *keys, const int *rank) {
+  const int c = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const unsigned long long k = keys[(size_t)c * p.ns + i];
+  if ((k >> 32) == 0ULL) return;                      // filtered
+  const int j = rank[(size_t)c * p.ns + i];
+  p.sidx[(size_t)c * p.ns + j] = i;
+  p.sscore[(size_t)c * p.ns + j] = key2f((unsigned int)(k >> 32));
+}
+
+__global__ __launch_bounds__(64) void mc_scan_big_kernel(const McP p) {
+  __shared__ unsigned long long remv[IVX_NMS_MAX_N / 64];
+  const int c = blockIdx.x;
+  const int n = p.n_arr[c];
+  int *kept = p.kept + (size_t)c * p.ns;
+  const int nk = greedy_scan_big(p.mask, p.sidx + (size_t)c * p.ns, n, p.ns >> 6, n, (const int *)nullptr, remv, kept);
+  __syncthreads();
+  for (int j = threadIdx.x; j < nk; j += 64) p.kscore[(size_t)c * p.ns + j] = p.sscore[(size_t)c * p.ns + kept[j]];
+  if (threadIdx.x == 0) p.nk[c] = nk;
+}
+
+static int mc_layout(int32_t n, int32_t num_classes, McP *p, int64_t *total, int64_t *o_keys_out = nullptr, int64_t *o_rank_out = nullptr) {
+  IVX_REQUIRE(n >= 0 && n <= IVX_NMS_MAX_N, "ivx_multiclass_nms_bev: n must be in 0..%d (got %d)", IVX_NMS_MAX_N, n);
   IVX_REQUIRE(num_classes >= 1 && num_classes <= 64, "ivx_multiclass_nms_bev: num_classes must be in 1..64 (got %d)", num_classes);
   const int ns = n > 0 ? (n + 63) / 64 * 64 : 64;
   int64_t off = 0;
@@ -960,7 +1053,11 @@ static int mc_layout(int32_t n, int32_t num_classes, McP *p, int64_t *total) {
   const int64_t o_cb = take((int64_t)num_classes * ns * 5 * 4), o_na = take((int64_t)num_classes * 4);
   const int64_t o_kept = take((int64_t)num_classes * ns * 4), o_nk = take((int64_t)num_classes * 4);
   const int64_t o_ks = take((int64_t)num_classes * ns * 4);
-  const int64_t o_mask = take((int64_t)num_classes * ns * (ns / 64) * 8);
+  const bool big = n > 4096;
+  const int64_t o_mask = take((int64_t)(big ? 1 : num_classes) * ns * (ns / 64) * 8);     // big: one shared hit matrix
+  const int64_t o_keys = big ? take((int64_t)num_classes * ns * 8) : 0, o_rank = big ? take((int64_t)num_classes * ns * 4) : 0;
+  if (o_keys_out) *o_keys_out = o_keys;
+  if (o_rank_out) *o_rank_out = o_rank;
   if (p) {
     p->ns = ns;
     p->npad = next_pow2(n > 1 ? n : 2);
@@ -982,8 +1079,8 @@ extern "C" int ivx_multiclass_nms_bev(const float *boxes, const float *scores, i
                                       int64_t workspace_bytes, int64_t *out_idx, int64_t *out_label, int32_t *out_count,
                                       ivx_stream_t stream) {
   McP p;
-  int64_t need = 0;
-  if (mc_layout(n, num_classes, &p, &need) != IVX_OK) return IVX_ERR_INVALID_ARG;
+  int64_t need = 0, o_keys = 0, o_rank = 0;
+  if (mc_layout(n, num_classes, &p, &need, &o_keys, &o_rank) != IVX_OK) return IVX_ERR_INVALID_ARG;
   IVX_REQUIRE(out_idx && out_label && out_count, "ivx_multiclass_nms_bev: null output");
   IVX_REQUIRE(score_stride >= num_classes && max_num > 0, "ivx_multiclass_nms_bev: bad score_stride / max_num");
   hipStream_t st = (hipStream_t)stream;
@@ -1008,6 +1105,25 @@ extern "C" int ivx_multiclass_nms_bev(const float *boxes, const float *scores, i
   p.boxes = boxes; p.scores = scores; p.n = n; p.score_stride = score_stride; p.num_classes = num_classes; p.max_num = max_num;
   p.rotated = rotated; p.score_thr = score_thr; p.nms_thr = nms_thr;
   const int cb = p.ns / 64;
+  if (n > 4096) {
+    unsigned long long *keys = (unsigned long long *)(w + o_keys);
+    int *rank = (int *)(w + o_rank);
+    if (hipMemsetAsync(p.n_arr, 0, (size_t)num_classes * 4, st) != hipSuccess) {
+      ivx_set_error("ivx_multiclass_nms_bev: memset failed");
+      return IVX_ERR_HIP;
+    }
+    const dim3 g((n + 255) / 256, num_classes);
+    hipLaunchKernelGGL(mc_keys_big_kernel, g, dim3(256), 0, st, p, keys);
+    hipLaunchKernelGGL(rank_sort_kernel, g, dim3(256), 0, st, keys, n, p.ns, rank);
+    hipLaunchKernelGGL(mc_scatter_big_kernel, g, dim3(256), 0, st, p, keys, rank);
+    hipLaunchKernelGGL(nms_hit_full_kernel, dim3(cb, n), dim3(64), 0, st, boxes, n, cb, nms_thr, rotated, p.mask);
+    hipLaunchKernelGGL(mc_scan_big_kernel, dim3(num_classes), dim3(64), 0, st, p);
+    const int cap = p.ns < max_num ? p.ns : max_num;
+    const unsigned blocks = (unsigned)(((long long)num_classes * cap + 255) / 256);
+    hipLaunchKernelGGL(mc_finalize_kernel, dim3(blocks), dim3(256), 0, st, p, (long long *)out_idx, (long long *)out_label, out_count);
+    IVX_CHECK_LAUNCH("ivx_multiclass_nms_bev");
+    return IVX_OK;
+  }
   hipLaunchKernelGGL(mc_select_sort_kernel, dim3(num_classes), dim3(1024), (size_t)p.npad * 8, st, p);
   const int shared = num_classes >= 3;
   if (shared)
@@ -1251,15 +1367,69 @@ __global__ __launch_bounds__(1024) void aligned_collect_kernel(const float *boxe
   if (tid == 1023) *num_out = cnt[1023];
 }
 
+// ---- n > 4096: score order by keys + rank sort, suppression mask over the sorted candidates (bit = NOT (iou * same_class <= thresh),
+// the reference's own predicate, box3d_nms.py:131-137: NaN IoUs suppress across classes without any special case), greedy scan with
+// the removal bits in LDS; pick[j] = original index of the j-th kept candidate.
+__global__ __launch_bounds__(256) void aligned_keys_big_kernel(const float *scores, int n, unsigned long long *keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keys[i] = ((unsigned long long)f2key(scores[i]) << 32) | (unsigned int)(~(unsigned int)i);
+}
+
+__global__ __launch_bounds__(256) void aligned_scatter_big_kernel(const float *boxes, const long long *classes, int n, const int *rank,
+                                                                  AnmsScratch w) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int j = rank[i];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) w.sbox[(size_t)j * 6 + q] = boxes[(size_t)i * 6 + q];
+  w.scls[j] = classes[i];
+  w.sidx[j] = i;
+}
+
+__global__ __launch_bounds__(64) void aligned_mask_big_kernel(int n, int cb, float thresh, AnmsScratch w, unsigned long long *mask) {
+  const int row = blockIdx.y, col_start = blockIdx.x;
+  if (col_start < (row >> 6)) return;
+  const int col = col_start * 64 + threadIdx.x;
+  bool hit = false;
+  if (col < n && col > row) {
+    const float *B1 = w.sbox + (size_t)row * 6, *B2 = w.sbox + (size_t)col * 6;
+    const float x1 = B1[0], y1 = B1[1], z1 = B1[2], x2 = B1[3], y2 = B1[4], z2 = B1[5];
+    const float ai = (x2 - x1) * (y2 - y1) * (z2 - z1);
+    const float xx1 = fmaxf(x1, B2[0]), yy1 = fmaxf(y1, B2[1]), zz1 = fmaxf(z1, B2[2]);
+    const float xx2 = fminf(x2, B2[3]), yy2 = fminf(y2, B2[4]), zz2 = fminf(z2, B2[5]);
+    const float il = fmaxf(0.f, xx2 - xx1), iw = fmaxf(0.f, yy2 - yy1), ih = fmaxf(0.f, zz2 - zz1);
+    const float inter = il * iw * ih;
+    const float aj = (B2[3] - B2[0]) * (B2[4] - B2[1]) * (B2[5] - B2[2]);
+    float iou = inter / (ai + aj - inter);
+    iou = iou * (w.scls[row] == w.scls[col] ? 1.0f : 0.0f);
+    hit = !(iou <= thresh);
+  }
+  const unsigned long long m = __ballot(hit);
+  if (threadIdx.x == 0) mask[(size_t)row * cb + col_start] = m;
+}
+
+static int64_t anms_big_bytes(int64_t n, int64_t *o_keys, int64_t *o_rank, int64_t *o_mask) {
+  const int64_t cb = (n + 63) / 64;
+  int64_t off = ivx_align_up(n * 24, 256) + ivx_align_up(n * 8, 256) + ivx_align_up(n * 4, 256);
+  if (o_keys) *o_keys = off;
+  off += ivx_align_up(n * 8, 256);
+  if (o_rank) *o_rank = off;
+  off += ivx_align_up(n * 4, 256);
+  if (o_mask) *o_mask = off;
+  off += ivx_align_up(n * cb * 8, 256);
+  return off;
+}
+
 extern "C" int64_t ivx_aligned_3d_nms_workspace_bytes(int32_t n) {
-  if (n < 0 || n > 4096) return -1;
+  if (n < 0 || n > IVX_NMS_MAX_N) return -1;
+  if (n > 4096) return anms_big_bytes(n, nullptr, nullptr, nullptr);
   const int64_t npad = next_pow2(n < 64 ? 64 : n);
   return ivx_align_up(npad * 24, 256) + ivx_align_up(npad * 8, 256) + ivx_align_up(npad * 4, 256) + ivx_align_up(npad, 256) + 256;
 }
 
 extern "C" int ivx_aligned_3d_nms_ws(const float *boxes, const float *scores, const int64_t *classes, int32_t n, float thresh,
                                      void *workspace, int64_t workspace_bytes, int64_t *pick, int32_t *num_out, ivx_stream_t stream) {
-  IVX_REQUIRE(n >= 0 && n <= 4096, "ivx_aligned_3d_nms_ws: n must be in 0..4096 (got %d)", n);
+  IVX_REQUIRE(n >= 0 && n <= IVX_NMS_MAX_N, "ivx_aligned_3d_nms_ws: n must be in 0..%d (got %d)", IVX_NMS_MAX_N, n);
   IVX_REQUIRE(pick && num_out, "ivx_aligned_3d_nms_ws: null output");
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) {
@@ -1275,6 +1445,28 @@ extern "C" int ivx_aligned_3d_nms_ws(const float *boxes, const float *scores, co
   if (workspace_bytes < ivx_aligned_3d_nms_workspace_bytes(n)) {
     ivx_set_error("ivx_aligned_3d_nms_ws: workspace too small");
     return IVX_ERR_WORKSPACE;
+  }
+  if (n > 4096) {
+    int64_t o_keys, o_rank, o_mask;
+    anms_big_bytes(n, &o_keys, &o_rank, &o_mask);
+    char *b = (char *)workspace;
+    AnmsScratch w;
+    w.sbox = (float *)b;
+    w.scls = (long long *)(b + ivx_align_up((int64_t)n * 24, 256));
+    w.sidx = (int *)(b + ivx_align_up((int64_t)n * 24, 256) + ivx_align_up((int64_t)n * 8, 256));
+    w.keep = nullptr; w.irregular = nullptr;
+    unsigned long long *keys = (unsigned long long *)(b + o_keys), *mask = (unsigned long long *)(b + o_mask);
+    int *rank = (int *)(b + o_rank);
+    const int cb = (n + 63) / 64;
+    const dim3 g((n + 255) / 256);
+    hipLaunchKernelGGL(aligned_keys_big_kernel, g, dim3(256), 0, st, scores, n, keys);
+    hipLaunchKernelGGL(rank_sort_kernel, dim3(g.x, 1), dim3(256), 0, st, keys, n, n, rank);
+    hipLaunchKernelGGL(aligned_scatter_big_kernel, g, dim3(256), 0, st, boxes, (const long long *)classes, n, rank, w);
+    hipLaunchKernelGGL(aligned_mask_big_kernel, dim3(cb, n), dim3(64), 0, st, n, cb, thresh, w, mask);
+    hipLaunchKernelGGL(nms_scan_big_kernel, dim3(1), dim3(64), 0, st, mask, (const int *)nullptr, n, cb, (const int *)w.sidx, (long long *)pick,
+                       num_out);
+    IVX_CHECK_LAUNCH("ivx_aligned_3d_nms_ws");
+    return IVX_OK;
   }
   const int npad = next_pow2(n < 64 ? 64 : n);
   AnmsScratch w;

@@ -86,12 +86,16 @@ class ImVoxelNet(nn.Module):
             self._native = engine.NativeModel(self, device)
         return self
 
-    def calibrate_fp8(self, img, margin=1.0, stages=None):
+    def calibrate_fp8(self, img, margin=1.0, stages=None, residual='bf16'):
         """Optional, on top of prepare(device, dtype=torch.bfloat16) (BASELINE config 5: "bf16 with fp8 2D-conv MFMA"): store
         the 2-D trunk's activations and weights as OCP e4m3 bytes.  One bf16 pass over `img` ([B,V,3,H,W] or [N,3,H,W], a
         representative batch) records max |output| of every trunk layer; the layers are then rebuilt with per-tensor activation
         scales amax * margin / 448 and per-output-channel weight scales folded into their epilogues (v_mfma_f32_32x32x16_fp8_fp8,
         fp32 accumulate).  The FPN laterals read the e4m3 stage outputs and produce bf16; everything after the trunk is unchanged.
+        residual: 'bf16' (default) keeps the residual stream -- stem, max-pool, every bottleneck's input / shortcut / output -- in
+        bf16 and stores only the inside of each bottleneck (conv1 / conv2 outputs, all conv weights of conv2 / conv3) as e4m3, so
+        the rounding noise of a block does not ride on through the later ones (FPN level 0 within a few % rms of fp32);
+        'fp8' stores every trunk activation as e4m3 (half the bf16 traffic; FPN level 0 ~10 % rms away: a bandwidth stress mode).
         Weights loaded afterwards need a new calibration.  Returns {layer key: amax}."""
         from .conv import FusedConv, storage_dtype, FP8
         if self._prepared_device is None or self.storage_dtype != torch.bfloat16:
@@ -108,6 +112,9 @@ class ImVoxelNet(nn.Module):
             torch.cuda.synchronize()
             FusedConv.calib_margin = float(margin)
             self.backbone.fp8_stages = stages             # None: all four stages; n: the first n (the rest keep a bf16 residual stream)
+            if residual not in ('bf16', 'fp8'):
+                raise ValueError("residual must be 'bf16' or 'fp8'")
+            self.backbone.fp8_residual = residual
             with storage_dtype(FP8):
                 self.backbone.prepare(dev)
             with storage_dtype(torch.bfloat16):
@@ -115,7 +122,7 @@ class ImVoxelNet(nn.Module):
             calib = dict(FusedConv.calib)
         finally:
             FusedConv.calib, FusedConv.calib_margin = None, 1.0
-        self.trunk_fp8 = True
+        self.trunk_fp8 = 'fp8' if residual == 'fp8' else 'fp8-branches'
         return calib
 
     # ------------------------------------------------------------------ host-side camera set-up
@@ -207,9 +214,10 @@ class ImVoxelNet(nn.Module):
 
     def simple_test(self, img, img_metas, gather=False):
         """detectors/imvoxelnet.py:93-106.  gather (anchor-head configs, torch.distributed initialised): every rank passes
-        its slice of the batch and receives the detections of the WHOLE batch in rank order -- one all-gather of the
-        fixed-size padded device tensors (dist.all_gather_detections) in place of mmdet's pickle-based collect_results
-        after the loop (tools/test.py:131-136)."""
+        its slice of the batch; ONE all-gather of the fixed-size padded device tensors (dist.all_gather_detections) replaces
+        mmdet's pickle-based collect_results after the loop (tools/test.py:131-136), and -- as there -- the collected result list
+        (whole batch, rank order) is built and returned on rank 0 only; the other ranks return None, so the host work of a step
+        does not grow with the number of ranks."""
         if self._prepared_device is None and self._native is None and img.is_cuda:
             self.prepare(img.device)                             # first call: pack the weights (and build the native handle)
         H, W = img.shape[-2:]
@@ -227,8 +235,10 @@ class ImVoxelNet(nn.Module):
             proj, new_origin, crop = self._camera_setup(img_metas, 4, img.device)
             boxes, scores, labels, count = self._native.forward(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
             if gather:
-                from .dist import all_gather_detections
+                from .dist import all_gather_detections, is_collecting_rank
                 boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)
+                if not is_collecting_rank():
+                    return None                  # as collect_results (tools/test.py:131-136): the collected list exists on rank 0 only
                 img_metas = [img_metas[i % len(img_metas)] for i in range(boxes.shape[0])]
             return self._results_one_copy(boxes, scores, labels, count, img_metas)
         p0, features_2d = self.features_2d_cl(img, img_metas, want_2d=True)
@@ -236,8 +246,10 @@ class ImVoxelNet(nn.Module):
         if isinstance(self.bbox_head, Anchor3DHead):
             boxes, scores, labels, count = self.detect_cl(volume, img_metas)
             if gather:
-                from .dist import all_gather_detections
+                from .dist import all_gather_detections, is_collecting_rank
                 boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)
+                if not is_collecting_rank():
+                    return None
                 img_metas = [img_metas[i % len(img_metas)] for i in range(boxes.shape[0])]     # box type of the other ranks' samples
             if features_2d is None:
                 return self._results_one_copy(boxes, scores, labels, count, img_metas)

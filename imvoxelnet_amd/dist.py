@@ -28,6 +28,11 @@ def _rank_world(rank, world):
     return ((dist.get_rank() if on else 0) if rank is None else rank, (dist.get_world_size() if on else 1) if world is None else world)
 
 
+def is_collecting_rank(group=None):
+    """True on the rank that builds the collected result list (rank 0 of the group, or any single process)."""
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == 0
+
+
 def shard_batch(img, img_metas, rank=None, world=None):
     rank, world = _rank_world(rank, world)
     a, b = shard_range(len(img_metas), rank, world)

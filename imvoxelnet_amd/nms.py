@@ -41,12 +41,12 @@ def boxes_overlap_bev(boxes_a, boxes_b):
 def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg, mlvl_dir_scores=None):
     """post_processing/box3d_nms.py:8-88 as ONE fused device call (ivx_multiclass_nms_bev: per-class filter + sort +
     rotated/normal NMS for all classes concurrently, class-major concat, final top-max_num) followed by gathers; the
-    only host round trip is the survivor count.  Falls back to the per-class loop over the same device NMS for
-    n > 4096 candidates or > 64 classes (each class's own NMS call is still limited to 4096 boxes above score_thr: the
-    device scan keeps 64 removal words per wave -- larger sets raise, see INTEGRATION.md "Limits").  (The single-class anchor-head configs use ops.anchor_head_get_bboxes.)"""
+    only host round trip is the survivor count.  Any n up to 65536 candidates (beyond 4096 the library sorts by rank and keeps
+    the removal bits in LDS: same kept order); more than 64 classes fall back to the per-class loop over the same device NMS.
+    (The single-class anchor-head configs use ops.anchor_head_get_bboxes.)"""
     num_classes = mlvl_scores.shape[1] - 1
     n = mlvl_bboxes.shape[0]
-    if n > 4096 or num_classes > 64:
+    if n > 65536 or num_classes > 64:
         return _box3d_multiclass_nms_loop(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg, mlvl_dir_scores)
     if n == 0 or num_classes == 0:
         z = mlvl_scores.new_zeros
@@ -65,7 +65,7 @@ def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_th
 
 def _box3d_multiclass_nms_loop(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg, mlvl_dir_scores=None):
     """The reference's control flow (host loop over classes) on the device NMS: used when the fused op does not apply (more than
-    4096 candidates in total or more than 64 classes); every per-class call still needs <= 4096 boxes above score_thr."""
+    64 classes, or more than 65536 candidates in total; every per-class call takes up to 65536 boxes above score_thr)."""
     num_classes = mlvl_scores.shape[1] - 1
     bboxes, scores, labels, dir_scores = [], [], [], []
     fn = nms_gpu if cfg['use_rotate_nms'] else nms_normal_gpu

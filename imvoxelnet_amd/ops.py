@@ -505,7 +505,7 @@ def aligned_3d_nms_dev(boxes, scores, classes, thresh, single_workgroup=False):
         return pick, num
     wsb = L.ivx_aligned_3d_nms_workspace_bytes(n)
     if wsb < 0:
-        raise ValueError(f'ivx_aligned_3d_nms_ws: at most 4096 boxes (got {n})')
+        raise ValueError(f'ivx_aligned_3d_nms_ws: at most 65536 boxes (got {n})')
     ws = torch.empty((wsb,), device=boxes.device, dtype=torch.uint8)
     check(L.ivx_aligned_3d_nms_ws(_ptr(boxes), _ptr(scores), _ptr(classes), n, float(thresh), _ptr(ws), wsb, _ptr(pick), _ptr(num),
                                   _stream()), 'ivx_aligned_3d_nms_ws')

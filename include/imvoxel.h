@@ -289,7 +289,9 @@ int ivx_fcos_head_level_candidates(const float *head_out, const uint8_t *valid0,
  * reference op except that nothing is copied to the host: boxes [n,5] (x1,y1,x2,y2,ry) must
  * already be sorted by descending score (as iou3d_utils.py:39-47 does before the call);
  * keep [n] int64 receives indices into that order, num_out [1] int32 their count.
- * workspace >= ivx_nms_workspace_bytes(n).                                                   */
+ * workspace >= ivx_nms_workspace_bytes(n) (the n x ceil(n/64) mask words, as the reference's cudaMalloc at iou3d.cpp:110).
+ * Any n up to 65536, like the reference op (col_blocks = DIVUP(N, 64)): up to 4096 boxes the scanning wave keeps one removal
+ * word per lane, beyond that the words live in its LDS -- same kept sequence.                  */
 int64_t ivx_nms_workspace_bytes(int32_t n);
 int ivx_nms_bev(const float *boxes_sorted, int32_t n, float thresh, int32_t rotated, void *workspace,
                 int64_t workspace_bytes, int64_t *keep, int32_t *num_out, ivx_stream_t stream);
@@ -300,12 +302,14 @@ int ivx_boxes_overlap_bev(const float *a, int32_t na, const float *b, int32_t nb
 
 /* aligned_3d_nms (mmdet3d/core/post_processing/box3d_nms.py:91-138) on the device.
  * boxes [n,6] corners, scores [n], classes [n] int64; pick [n] int64 receives the kept box
- * indices in descending score order, num_out [1] int32.  One workgroup; n <= 4096.            */
+ * indices in descending score order, num_out [1] int32.  One workgroup, no workspace: n <= 4096 (use the _ws form beyond). */
 int ivx_aligned_3d_nms(const float *boxes, const float *scores, const int64_t *classes, int32_t n,
                        float thresh, int64_t *pick, int32_t *num_out, ivx_stream_t stream);
-/* The same result with a workspace (n <= 4096): the greedy chain runs per class on 64 workgroups in parallel (boxes of
- * different classes never suppress each other); inputs with degenerate boxes (non-finite corners, an extent outside
- * (0, 1e6)), where the reference's NaN IoU suppresses ACROSS classes, take the one-workgroup form inside the call. */
+/* The same result with a workspace, n <= 65536.  Up to 4096 boxes the greedy chain runs per class on 64 workgroups in
+ * parallel (boxes of different classes never suppress each other); inputs with degenerate boxes (non-finite corners, an extent
+ * outside (0, 1e6)), where the reference's NaN IoU suppresses ACROSS classes, take the one-workgroup form inside the call.
+ * Beyond 4096: rank sort by score, a suppression mask over the sorted boxes with the reference's own predicate
+ * NOT(iou * same_class <= thresh), greedy scan with the removal bits in LDS -- same picks, any input. */
 int64_t ivx_aligned_3d_nms_workspace_bytes(int32_t n);
 int ivx_aligned_3d_nms_ws(const float *boxes, const float *scores, const int64_t *classes, int32_t n, float thresh,
                           void *workspace, int64_t workspace_bytes, int64_t *pick, int32_t *num_out, ivx_stream_t stream);
@@ -315,8 +319,8 @@ int ivx_aligned_3d_nms_ws(const float *boxes, const float *scores, const int64_t
 int ivx_global_avgpool_fwd(const float *in, int32_t B, int64_t S, int32_t C, float *out, ivx_stream_t stream);
 
 /* Fused multi-class BEV NMS -- replaces box3d_multiclass_nms (mmdet3d/core/post_processing/box3d_nms.py:8-88), i.e.
- * the host loop over classes around nms_gpu / nms_normal_gpu with its per-class D2H, for n <= 4096 candidates and
- * num_classes <= 64.  boxes [n,5] (x1,y1,x2,y2,ry); scores [n,score_stride], class c in column c.  Per class the
+ * the host loop over classes around nms_gpu / nms_normal_gpu with its per-class D2H, for n <= 65536 candidates and
+ * num_classes <= 64 (beyond 4096 candidates: per-class rank sort, one shared hit matrix, removal bits in LDS; same output).  boxes [n,5] (x1,y1,x2,y2,ry); scores [n,score_stride], class c in column c.  Per class the
  * candidates with score > score_thr are sorted by score (descending, ties -> lower index) and greedily suppressed at
  * IoU > nms_thr; the survivors are concatenated class-major, or, when more than max_num survive, cut to the max_num
  * best by score (descending; ties -> lower class).  out_idx (index into the n candidates) and out_label hold
@@ -480,6 +484,15 @@ int ivx_voxel_new_origin(const float *origin, const int32_t *n_voxels, const flo
  * scale = gamma / sqrt(var + eps), shift = beta + (bias - mean) * scale, IEEE fp32 in this order. */
 int ivx_fold_batchnorm(const float *gamma, const float *beta, const float *mean, const float *var, const float *bias, float eps,
                        int32_t n, float *scale, float *shift);
+
+/* ---------------------------------------------------------------------------------------
+ * Device ceilings measured on the box (measurement only; bench.py prices its roofline fractions against the data-sheet
+ * peaks AND these): the dense issue rate of the MFMA form the conv kernel uses for `dtype` (IVX_F32:
+ * v_mfma_f32_32x32x2_f32, IVX_BF16: v_mfma_f32_32x32x16_bf16; scratch >= 512 KiB of device memory), and the streaming
+ * copy rate of HBM (read + written bytes per second over `bytes` from src to dst; use buffers well past the 256 MiB
+ * Infinity Cache).  Both synchronise the stream and return the best of a few repetitions. */
+int ivx_ubench_mfma(int32_t dtype, void *scratch, int64_t scratch_bytes, double *tflops, ivx_stream_t stream);
+int ivx_ubench_copy(const void *src, void *dst, int64_t bytes, double *gbps, ivx_stream_t stream);
 
 #ifdef __cplusplus
 }

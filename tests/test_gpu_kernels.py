@@ -1064,6 +1064,57 @@ def test_aligned_nms_class_parallel_equals_single_workgroup(ia):
             assert np.array_equal(got, want), f'{name} single={single}: {len(got)} vs {len(want)} picks'
 
 
+@pytest.mark.parametrize('n', [5000, 10000])
+def test_nms_general_n_vs_oracle(ia, n):
+    """N > 4096 candidates (the reference op takes any N: iou3d.cpp:95-147, col_blocks = DIVUP(N, 64)): ivx_nms_bev (rotated and
+    axis-aligned), ivx_aligned_3d_nms_ws and ivx_multiclass_nms_bev on the rank-sort / LDS-removal-words path against the C
+    oracle -- identical kept indices in identical order -- and a 4096 / 4097 pair around the switch between the two forms."""
+    from oracle import c_oracle as co, imvoxel_oracle as orc
+    from imvoxelnet_amd import ops, nms
+    g = torch.Generator().manual_seed(900 + n)
+    for m in (n, 4096, 4097):
+        ctr = torch.rand(m, 2, generator=g) * 60
+        wh = torch.rand(m, 2, generator=g) * 3 + 0.5
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2, (torch.rand(m, 1, generator=g) - 0.5) * 6], 1)
+        scores = torch.rand(m, generator=g)
+        scores[::7] = scores[3::7][:len(scores[::7])]                 # ties: equal scores at different indices
+        for rot in (True, False):
+            keep = (ia.nms_gpu if rot else ia.nms_normal_gpu)(boxes.cuda(), scores.cuda(), 0.1)
+            order_dev = scores.cuda().sort(0, descending=True)[1].cpu()    # nms_gpu sorts with torch on the device, as the reference
+            ref = order_dev[torch.from_numpy(co.nms_sorted(boxes[order_dev].numpy(), 0.1, rot))]
+            assert torch.equal(keep.cpu(), ref), f'nms_bev n={m} rotated={rot}: {len(keep)} vs {len(ref)} kept'
+            assert 10 < len(ref) < m
+    # aligned 3-D NMS: 18 classes, ties, a NaN corner and a zero-volume box (their NaN IoU suppresses across classes)
+    c = (torch.rand(n, 3, generator=g) - .5) * 14
+    sz = torch.rand(n, 3, generator=g) * 1.5 + 0.1
+    bx = torch.cat([c - sz / 2, c + sz / 2], 1)
+    bx[123, 3:] = bx[123, :3]
+    bx[4500, 1] = float('nan')
+    sc = torch.round(torch.rand(n, generator=g) * 2000) / 2000
+    cl_ = torch.randint(0, 18, (n,), generator=g)
+    desc = np.lexsort((np.arange(n), -sc.numpy()))                    # descending score, ties: lower index first (the device's key)
+    want = co.aligned_3d_nms(bx.numpy(), sc.numpy(), cl_.numpy(), desc[::-1].copy(), 0.25)
+    pick, num = ops.aligned_3d_nms_dev(bx.cuda(), sc.cuda(), cl_.cuda(), 0.25)
+    got = pick[:int(num.item())].cpu().numpy()
+    assert np.array_equal(got, want), f'aligned n={n}: {len(got)} vs {len(want)} picks'
+    assert 50 < len(want) < n
+    # multi-class: 10 classes, score_thr 0 (SUN RGB-D: every candidate enters every class), both cuts of max_num
+    ctr = torch.rand(n, 2, generator=g) * 25
+    wl = torch.rand(n, 2, generator=g) * 2 + 0.5
+    bev = torch.cat([ctr - wl / 2, ctr + wl / 2, (torch.rand(n, 1, generator=g) - 0.5) * 6], 1)
+    b3 = torch.cat([ctr, torch.rand(n, 5, generator=g)], 1)
+    # globally distinct scores (a host sort and the device's composite key order equal scores differently; ties are covered above)
+    ms = torch.stack([(torch.randperm(n, generator=g).float() + (c + 1) / 16.0) / (n + 1) for c in range(10)], 1)
+    ms[:, 3] *= 0.05
+    ms[:, 4] = 0
+    ms = torch.cat([ms, torch.zeros(n, 1)], 1)
+    for thr, max_num in ((0.0, 1000), (0.04, 100000)):
+        rb, rs, rl, _ = orc.box3d_multiclass_nms(b3, bev, ms, thr, max_num, True, 0.15)
+        gb, gs, gl, _ = nms.box3d_multiclass_nms(b3.cuda(), bev.cuda(), ms.cuda(), thr, max_num, dict(use_rotate_nms=True, nms_thr=0.15))
+        assert len(gs) == len(rs) > 100, (len(gs), len(rs))
+        assert torch.equal(gl.cpu(), rl) and torch.equal(gs.cpu(), rs) and torch.equal(gb.cpu(), rb), f'multiclass n={n} max_num={max_num}'
+
+
 def test_bf16_stem_space_to_depth(ia):
     """bf16 mode: the 7x7 stride-2 stem as a 4x4 stride-1 convolution over 2x2 space-to-depth blocks (ivx_image_s2d_bf16 +
     re-indexed weights, backbones.ResNet.prepare) against torch's conv2d on the bf16-rounded image and weights (products of

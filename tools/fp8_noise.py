@@ -1,6 +1,7 @@
 import sys, torch
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
-import imvoxelnet_amd as ia, kitti_cfg as kc
+import imvoxelnet_amd as ia
+from imvoxelnet_amd import workloads as kc
 model = ia.build_detector(kc.scannet_v1_model_cfg(), test_cfg=dict(kc.SCANNET_V1_TEST_CFG))
 ia.randomize_(model, 41)
 img = torch.randn(1, 4, 3, 480, 640, generator=torch.Generator().manual_seed(2)).cuda()

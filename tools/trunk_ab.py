@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 import imvoxelnet_amd as ia  # noqa: E402
-import kitti_cfg as kc  # noqa: E402
+from imvoxelnet_amd import workloads as kc  # noqa: E402
 from imvoxelnet_amd import _lib  # noqa: E402
 from imvoxelnet_amd.conv import FusedConv  # noqa: E402
 
