@@ -38,7 +38,22 @@ class ModelCfg(C.Structure):
                 ('score_thr', C.c_float), ('nms_thr', C.c_float), ('dir_offset', C.c_float), ('dir_limit_offset', C.c_float),
                 ('winograd', C.c_int32), ('winograd_tile', C.c_int32), ('use_graph', C.c_int32),
                 ('fast_n_blocks', C.c_int32 * 3), ('unet_channels', C.c_int32 * 4), ('unet_down_layers', C.c_int32 * 4),
-                ('unet_up_layers', C.c_int32 * 3)]
+                ('unet_up_layers', C.c_int32 * 3),
+                ('head_type', C.c_int32), ('head_classes', C.c_int32), ('head_nms_pre', C.c_int32), ('head_use_rotate_nms', C.c_int32),
+                ('head_score_thr', C.c_float), ('head_nms_thr', C.c_float), ('dcn_stages', C.c_int32 * 4), ('layout_head', C.c_int32),
+                ('layout_linear_size', C.c_int32)]
+
+
+class SampleMeta(C.Structure):
+    """ivx_sample_meta."""
+    _fields_ = [('intrinsic', C.c_float * 16), ('extrinsics', C.c_void_p), ('origin', C.c_float * 3), ('img_h', C.c_int32), ('img_w', C.c_int32),
+                ('ori_h', C.c_int32)]
+
+
+class IndoorTailDesc(C.Structure):
+    """ivx_indoor_tail_desc."""
+    _fields_ = [('B', C.c_int32), ('n_levels', C.c_int32), ('k', C.c_int32 * 4), ('n_classes', C.c_int32), ('n_reg', C.c_int32),
+                ('use_rotate_nms', C.c_int32), ('max_num', C.c_int32), ('score_thr', C.c_float), ('nms_thr', C.c_float)]
 
 
 class TraceRec(C.Structure):
@@ -47,7 +62,7 @@ class TraceRec(C.Structure):
                 ('bytes', C.c_double), ('name', C.c_char * 48)]
 
 
-EXPORTS = ['ivx_ubench_mfma', 'ivx_ubench_copy', 'ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
+EXPORTS = ['ivx_conv_winograd_set_variant', 'ivx_ubench_mfma', 'ivx_ubench_copy', 'ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws',
            'ivx_conv_winograd_supported', 'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_weights', 'ivx_conv_winograd_workspace_bytes',
            'ivx_conv_winograd_input', 'ivx_conv_winograd_gemm', 'ivx_conv_winograd_output', 'ivx_conv_winograd_fwd',
            'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_maxpool2d_fwd_fp8', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_image_s2d_bf16', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
@@ -59,6 +74,8 @@ EXPORTS = ['ivx_ubench_mfma', 'ivx_ubench_copy', 'ivx_version', 'ivx_last_error'
            'ivx_neck3d_kitti_fwd', 'ivx_neck3d_nuscenes_fwd', 'ivx_neck3d_levels', 'ivx_neck3d_fast_fwd', 'ivx_neck3d_unet_fwd',
            'ivx_model_forward_levels', 'ivx_model_anchors', 'ivx_compute_projection', 'ivx_voxel_new_origin', 'ivx_fold_batchnorm',
            'ivx_model_trace', 'ivx_model_trace_count', 'ivx_model_trace_read',
+           'ivx_model_detect_workspace_bytes', 'ivx_model_max_detections', 'ivx_model_detect', 'ivx_layout_head_decode', 'ivx_layout_extrinsics',
+           'ivx_indoor_tail_workspace_bytes', 'ivx_indoor_tail_get_bboxes',
            'ivx_kitti_image_box_overlap', 'ivx_kitti_compute_statistics', 'ivx_kitti_collect_scores', 'ivx_kitti_fused_statistics']
 
 
@@ -149,6 +166,17 @@ def lib():
     L.ivx_voxel_new_origin.argtypes = [vp, vp, vp, vp]
     L.ivx_fold_batchnorm.argtypes = [vp, vp, vp, vp, vp, f32, i32, vp, vp]
     L.ivx_model_trace.argtypes = [vp, i32]
+    L.ivx_model_detect_workspace_bytes.argtypes = [vp, i32, i32, i32, i32]
+    L.ivx_model_detect_workspace_bytes.restype = i64
+    L.ivx_model_max_detections.argtypes = [vp, i32, i32, i32, i32]
+    L.ivx_model_max_detections.restype = i32
+    L.ivx_model_detect.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ivx_layout_head_decode.argtypes = [vp, vp, vp, vp]
+    L.ivx_layout_extrinsics.argtypes = [vp, vp]
+    L.ivx_indoor_tail_workspace_bytes.argtypes = [vp]
+    L.ivx_indoor_tail_workspace_bytes.restype = i64
+    L.ivx_indoor_tail_get_bboxes.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.ivx_conv_winograd_set_variant.argtypes = [i32, i32]
     L.ivx_ubench_mfma.argtypes = [i32, vp, i64, C.POINTER(C.c_double), vp]
     L.ivx_ubench_copy.argtypes = [vp, vp, i64, C.POINTER(C.c_double), vp]
     L.ivx_model_trace_count.argtypes = [vp]

@@ -1622,3 +1622,211 @@ extern "C" int ivx_fcos_head_level_candidates(const float *head_out, const uint8
   IVX_CHECK_LAUNCH("ivx_fcos_head_level_candidates");
   return IVX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Indoor head tail after the per-level candidates: the cross-level NMS and the result rows of
+// ImVoxelHeadV2._get_bboxes_single / _nms (mmdet3d/models/dense_heads/imvoxel_head_v2.py:258-277 torch.cat over levels,
+// ScanNet _nms :528-545, SUN RGB-D _nms :397-417) on the device for a batch, nothing returned to the host in between.
+//   ScanNet (n_reg 6):  class maximum + label per candidate, `score > score_thr` filter, class-aware aligned 3-D NMS, corners ->
+//                       (centre, size), fake yaw 0;  candidates under the threshold enter the NMS with score -inf -- they sort
+//                       behind every real candidate, so they can neither suppress one nor be picked before one, and the
+//                       picks that are real form a prefix: same result as filtering first (box3d_nms.py:91-138 is greedy in
+//                       descending score), with a host-known problem size
+//   SUN RGB-D (n_reg 7): BEV boxes (x -+ dx/2, y -+ dy/2, alpha), fused multi-class NMS (ivx_multiclass_nms_bev), gather
+// Output rows are the box object's tensor: (x, y, z_bottom, dx, dy, dz, yaw) -- the gravity-centre z moved to the bottom face
+// exactly as BaseInstance3DBoxes.__init__(origin=(.5,.5,.5)) does (base_box3d.py:63-66: z += dz * (0 - 0.5)).
+struct IndoorP {
+  const float *cb[4];      // per level [B, k_l, R]
+  const float *cs[4];      // per level [B, k_l, ncls]
+  int k[4], koff[5];
+  int B, L, K, R, ncls, max_num;
+  float score_thr;
+};
+
+// ScanNet: concatenated corner boxes [B,K,6], class maximum (first maximum, as torch.max(dim=1)) as score (-inf when <= thr) + label
+__global__ __launch_bounds__(256) void indoor_prep_scannet_kernel(const IndoorP p, float *boxes, float *scores, float *raw_scores,
+                                                                  long long *labels) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p.K) return;
+  int l = 0;
+  while (l + 1 < p.L && j >= p.koff[l + 1]) ++l;
+  const int r = j - p.koff[l];
+  const float *sb = p.cb[l] + ((size_t)b * p.k[l] + r) * 6;
+  const float *ss = p.cs[l] + ((size_t)b * p.k[l] + r) * p.ncls;
+  float best = ss[0];
+  int lab = 0;
+  for (int c = 1; c < p.ncls; ++c)
+    if (ss[c] > best) { best = ss[c]; lab = c; }
+  float *ob = boxes + ((size_t)b * p.K + j) * 6;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) ob[q] = sb[q];
+  raw_scores[(size_t)b * p.K + j] = best;
+  scores[(size_t)b * p.K + j] = best > p.score_thr ? best : -__builtin_inff();
+  labels[(size_t)b * p.K + j] = lab;
+}
+
+__global__ __launch_bounds__(256) void indoor_finish_scannet_kernel(const IndoorP p, const float *boxes, const float *raw_scores,
+                                                                    const long long *labels, const long long *pick, const int *npick,
+                                                                    float *out_boxes, float *out_scores, long long *out_labels, int *out_count) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p.max_num) return;
+  const int np = npick[b];
+  float *ob = out_boxes + ((size_t)b * p.max_num + j) * 7;
+  bool real = false;
+  int i = 0;
+  if (j < np) {
+    i = (int)pick[(size_t)b * p.K + j];
+    real = raw_scores[(size_t)b * p.K + i] > p.score_thr;
+  }
+  if (real) {
+    const float *c = boxes + ((size_t)b * p.K + i) * 6;
+    const float dz = c[5] - c[2];
+    ob[0] = (c[0] + c[3]) / 2.f; ob[1] = (c[1] + c[4]) / 2.f;
+    ob[2] = (c[2] + c[5]) / 2.f + dz * -0.5f;
+    ob[3] = c[3] - c[0]; ob[4] = c[4] - c[1]; ob[5] = dz; ob[6] = 0.f;
+    out_scores[(size_t)b * p.max_num + j] = raw_scores[(size_t)b * p.K + i];
+    out_labels[(size_t)b * p.max_num + j] = labels[(size_t)b * p.K + i];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 7; ++q) ob[q] = 0.f;
+    out_scores[(size_t)b * p.max_num + j] = 0.f;
+    out_labels[(size_t)b * p.max_num + j] = 0;
+  }
+  // the real picks are a prefix of the pick list (descending score): count them once per sample
+  if (j == 0) {
+    int lo = 0, hi = np;            // first pick that is not real
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (raw_scores[(size_t)b * p.K + (int)pick[(size_t)b * p.K + mid]] > p.score_thr) lo = mid + 1; else hi = mid;
+    }
+    out_count[b] = lo < p.max_num ? lo : p.max_num;
+  }
+}
+
+// SUN RGB-D: concatenated boxes [B,K,7], BEV boxes [B,K,5], scores [B,K,ncls]
+__global__ __launch_bounds__(256) void indoor_prep_sunrgbd_kernel(const IndoorP p, float *boxes, float *bev, float *scores) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p.K) return;
+  int l = 0;
+  while (l + 1 < p.L && j >= p.koff[l + 1]) ++l;
+  const int r = j - p.koff[l];
+  const float *sb = p.cb[l] + ((size_t)b * p.k[l] + r) * 7;
+  const float *ss = p.cs[l] + ((size_t)b * p.k[l] + r) * p.ncls;
+  float *ob = boxes + ((size_t)b * p.K + j) * 7;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) ob[q] = sb[q];
+  float *v = bev + ((size_t)b * p.K + j) * 5;
+  v[0] = sb[0] - sb[3] / 2.f; v[1] = sb[1] - sb[4] / 2.f; v[2] = sb[0] + sb[3] / 2.f; v[3] = sb[1] + sb[4] / 2.f; v[4] = sb[6];
+  for (int c = 0; c < p.ncls; ++c) scores[((size_t)b * p.K + j) * p.ncls + c] = ss[c];
+}
+
+__global__ __launch_bounds__(256) void indoor_finish_sunrgbd_kernel(const IndoorP p, const float *boxes, const float *scores, const long long *idx,
+                                                                    const long long *lab, const int *cnt, float *out_boxes, float *out_scores,
+                                                                    long long *out_labels, int *out_count) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p.max_num) return;
+  const int n = cnt[b];
+  float *ob = out_boxes + ((size_t)b * p.max_num + j) * 7;
+  if (j < n) {
+    const int i = (int)idx[(size_t)b * p.max_num + j], c = (int)lab[(size_t)b * p.max_num + j];
+    const float *s = boxes + ((size_t)b * p.K + i) * 7;
+    ob[0] = s[0]; ob[1] = s[1]; ob[2] = s[2] + s[5] * -0.5f; ob[3] = s[3]; ob[4] = s[4]; ob[5] = s[5]; ob[6] = s[6];
+    out_scores[(size_t)b * p.max_num + j] = scores[((size_t)b * p.K + i) * p.ncls + c];
+    out_labels[(size_t)b * p.max_num + j] = c;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 7; ++q) ob[q] = 0.f;
+    out_scores[(size_t)b * p.max_num + j] = 0.f;
+    out_labels[(size_t)b * p.max_num + j] = 0;
+  }
+  if (j == 0) out_count[b] = n;
+}
+
+struct IndoorWs { int64_t boxes, bev, scores, raw, labels, pick, npick, nms, nms_bytes, total; };
+
+static int indoor_layout(const ivx_indoor_tail_desc *d, IndoorP *p, IndoorWs *w) {
+  IVX_REQUIRE(d, "ivx_indoor_tail: null descriptor");
+  IVX_REQUIRE(d->B > 0 && d->n_levels >= 1 && d->n_levels <= 4 && d->n_classes >= 1 && (d->n_reg == 6 || d->n_reg == 7), "ivx_indoor_tail: bad dims");
+  IVX_REQUIRE(d->n_reg == 6 || d->n_classes <= 64, "ivx_indoor_tail: the multi-class NMS takes at most 64 classes");
+  p->B = d->B; p->L = d->n_levels; p->R = d->n_reg; p->ncls = d->n_classes; p->score_thr = d->score_thr;
+  int K = 0;
+  for (int l = 0; l < d->n_levels; ++l) {
+    IVX_REQUIRE(d->k[l] > 0, "ivx_indoor_tail: level %d has no candidates", l);
+    p->k[l] = d->k[l]; p->koff[l] = K; K += d->k[l];
+  }
+  p->koff[d->n_levels] = K;
+  IVX_REQUIRE(K <= 65536, "ivx_indoor_tail: at most 65536 candidates per sample (got %d)", K);
+  p->K = K;
+  p->max_num = d->max_num;
+  IVX_REQUIRE(d->max_num > 0, "ivx_indoor_tail: max_num must be positive (ScanNet: the total number of candidates; SUN RGB-D: test_cfg.nms_pre)");
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) { const int64_t at = o; o += ivx_align_up(bytes, 256); return at; };
+  w->boxes = take((int64_t)d->B * K * d->n_reg * 4);
+  w->bev = d->n_reg == 7 ? take((int64_t)d->B * K * 5 * 4) : 0;
+  w->scores = take((int64_t)d->B * K * (d->n_reg == 7 ? d->n_classes : 1) * 4);
+  w->raw = d->n_reg == 6 ? take((int64_t)d->B * K * 4) : 0;
+  w->labels = take((int64_t)d->B * (d->n_reg == 6 ? K : d->max_num) * 8);
+  w->pick = take((int64_t)d->B * (d->n_reg == 6 ? K : d->max_num) * 8);
+  w->npick = take((int64_t)d->B * 4);
+  w->nms_bytes = d->n_reg == 6 ? ivx_aligned_3d_nms_workspace_bytes(K) : ivx_multiclass_nms_workspace_bytes(K, d->n_classes);
+  IVX_REQUIRE(w->nms_bytes >= 0, "ivx_indoor_tail: %s", ivx_last_error());
+  w->nms = take(w->nms_bytes);
+  w->total = o;
+  return IVX_OK;
+}
+
+extern "C" int64_t ivx_indoor_tail_workspace_bytes(const ivx_indoor_tail_desc *d) {
+  IndoorP p;
+  IndoorWs w;
+  if (indoor_layout(d, &p, &w) != IVX_OK) return -1;
+  return w.total;
+}
+
+extern "C" int ivx_indoor_tail_get_bboxes(const ivx_indoor_tail_desc *d, const float *const *cand_boxes, const float *const *cand_scores,
+                                          void *workspace, int64_t workspace_bytes, float *out_boxes, float *out_scores, int64_t *out_labels,
+                                          int32_t *out_count, ivx_stream_t stream) {
+  IndoorP p;
+  IndoorWs w;
+  int rc = indoor_layout(d, &p, &w);
+  if (rc != IVX_OK) return rc;
+  IVX_REQUIRE(cand_boxes && cand_scores && workspace && out_boxes && out_scores && out_labels && out_count, "ivx_indoor_tail_get_bboxes: null argument");
+  for (int l = 0; l < p.L; ++l) {
+    IVX_REQUIRE(cand_boxes[l] && cand_scores[l], "ivx_indoor_tail_get_bboxes: null candidates of level %d", l);
+    p.cb[l] = cand_boxes[l]; p.cs[l] = cand_scores[l];
+  }
+  IVX_REQUIRE(((uintptr_t)workspace & 255) == 0, "ivx_indoor_tail_get_bboxes: workspace must be 256-byte aligned");
+  if (workspace_bytes < w.total) {
+    ivx_set_error("ivx_indoor_tail_get_bboxes: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)w.total);
+    return IVX_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char *ws = (char *)workspace;
+  float *boxes = (float *)(ws + w.boxes), *scores = (float *)(ws + w.scores);
+  long long *labels = (long long *)(ws + w.labels), *pick = (long long *)(ws + w.pick);
+  int *npick = (int *)(ws + w.npick);
+  const dim3 gk((p.K + 255) / 256, p.B), gm((p.max_num + 255) / 256, p.B);
+  if (p.R == 6) {
+    float *raw = (float *)(ws + w.raw);
+    hipLaunchKernelGGL(indoor_prep_scannet_kernel, gk, dim3(256), 0, st, p, boxes, scores, raw, labels);
+    for (int b = 0; b < p.B; ++b) {       // indoor batches are small (the reference tests them at batch 1)
+      rc = ivx_aligned_3d_nms_ws(boxes + (size_t)b * p.K * 6, scores + (size_t)b * p.K, (const int64_t *)(labels + (size_t)b * p.K), p.K, d->nms_thr,
+                                 ws + w.nms, w.nms_bytes, (int64_t *)(pick + (size_t)b * p.K), npick + b, stream);
+      if (rc != IVX_OK) return rc;
+    }
+    hipLaunchKernelGGL(indoor_finish_scannet_kernel, gm, dim3(256), 0, st, p, boxes, raw, labels, pick, npick, out_boxes, out_scores,
+                       (long long *)out_labels, out_count);
+  } else {
+    float *bev = (float *)(ws + w.bev);
+    hipLaunchKernelGGL(indoor_prep_sunrgbd_kernel, gk, dim3(256), 0, st, p, boxes, bev, scores);
+    for (int b = 0; b < p.B; ++b) {
+      rc = ivx_multiclass_nms_bev(bev + (size_t)b * p.K * 5, scores + (size_t)b * p.K * p.ncls, p.K, p.ncls, p.ncls, d->score_thr, d->nms_thr,
+                                  d->use_rotate_nms, p.max_num, ws + w.nms, w.nms_bytes, (int64_t *)(pick + (size_t)b * p.max_num),
+                                  (int64_t *)(labels + (size_t)b * p.max_num), npick + b, stream);
+      if (rc != IVX_OK) return rc;
+    }
+    hipLaunchKernelGGL(indoor_finish_sunrgbd_kernel, gm, dim3(256), 0, st, p, boxes, scores, pick, labels, npick, out_boxes, out_scores,
+                       (long long *)out_labels, out_count);
+  }
+  IVX_CHECK_LAUNCH("ivx_indoor_tail_get_bboxes");
+  return IVX_OK;
+}

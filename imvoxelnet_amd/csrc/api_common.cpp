@@ -13,5 +13,5 @@ void ivx_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int ivx_version(void) { return 200; /* 0.2.0: ivx_conv_desc gained res_scale, ivx_model_cfg the indoor-neck fields */ }
+extern "C" int ivx_version(void) { return 300; /* 0.3.0: ivx_model_cfg gained the head / DCNv2 / LayoutHead fields; ivx_model_detect, ivx_indoor_tail_* */ }
 extern "C" const char *ivx_last_error(void) { return g_err; }

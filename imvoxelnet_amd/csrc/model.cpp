@@ -60,6 +60,8 @@ struct ConvLayer {
   int k[3] = {1, 1, 1}, s[3] = {1, 1, 1}, p[3] = {0, 0, 0};
   bool relu = false;
   bool conv_t = false;                // nn.ConvTranspose3d(k2, s2) weights [Cin,Cout,2,2,2] run as a 1x1x1 GEMM with 8*Cout columns (out_mode 1)
+  bool dcn_cols = false;              // DCNv2 main conv: weights [Cout,C,3,3] run as a 1x1 conv over the 9*C columns of ivx_dcn_im2col_fwd
+  bool linear = false;                // nn.Linear weights [Cout,Cin] run as a 1x1 conv on a [B,1,1,1,Cin] tensor (LayoutHead MLPs)
   std::vector<std::string> w_keys;    // > 1: filter banks concatenated along Cout (the fused head conv)
   std::vector<std::string> b_keys;    // parallel to w_keys; "" = no bias
   std::string bn;                     // BatchNorm prefix or ""
@@ -70,7 +72,7 @@ struct ConvLayer {
   std::map<int, float *> u;           // tile -> transformed filters
 };
 
-enum StepKind { ST_IMG2CL, ST_CONV, ST_MAXPOOL, ST_LIFT, ST_TAIL, ST_UPSAMPLE };
+enum StepKind { ST_IMG2CL, ST_CONV, ST_MAXPOOL, ST_LIFT, ST_TAIL, ST_UPSAMPLE, ST_DCN_COL, ST_AVGPOOL, ST_LAYOUT, ST_FCOS, ST_INDOOR_TAIL };
 
 struct Step {
   StepKind kind;
@@ -79,12 +81,14 @@ struct Step {
   int res_mode = 0;
   int res_after_act = 0;     // the residual is added after the ReLU (skip adds of the U-shaped necks)
   float post_scale = 1.0f;   // Atlas decoder: (x + y) / 2
+  int aux = 0;               // ST_DCN_COL: stride of the deformable conv; ST_FCOS: the level
 };
 
 struct TInfo {
   int B = 0, D = 0, H = 0, W = 0, C = 0;
   int64_t bytes = 0, off = -1;
   int first = -1, last = -1;
+  bool raw = false;          // a byte buffer (candidate lists): `bytes` is set explicitly
   int64_t elems() const { return (int64_t)B * D * H * W * C; }
 };
 
@@ -99,6 +103,11 @@ struct Plan {
   std::vector<PlanStep> ps;
   int64_t arena = 0, ws_off = 0, ws_bytes = 0, tail_ws = 0, total = 0;
   ivx_anchor_head_desc tail;
+  // camera block at the start of the arena (ivx_model_detect: the host-built per-batch set-up is uploaded there)
+  int64_t cam_bytes = 0, cam_proj = 0, cam_origin = 0, cam_crop = 0, cam_lvl_vs[3] = {0, 0, 0}, cam_lvl_no[3] = {0, 0, 0};
+  int n_views = 1;
+  ivx_indoor_tail_desc itail;          // indoor families with a head
+  int max_det = 0;                     // rows per sample of the detection outputs
 };
 
 }  // namespace
@@ -112,6 +121,13 @@ struct ivx_model {
   int trunk0 = 0, trunk1 = 0, lift_step = -1, neck0 = 0, neck1 = 0, head_step = -1, tail_step = -1;
   int t_img = -1, t_fpn0 = -1, t_volume = -1, t_valid = -1, t_neck = -1, t_head = -1;
   std::vector<int> t_levels;           // indoor necks: the output levels, finest first
+  // anchor-free head (cfg.head_type): per level the fused head conv output and the candidate buffers; the LayoutHead's tensors
+  int head0 = -1;                      // first step after the neck (head convs, candidates, cross-level tail)
+  std::vector<int> t_headout, t_cb, t_cs, t_cc;
+  float head_scales[3] = {1.f, 1.f, 1.f};   // bbox_head.scales.{l}.scale (mmcv Scale)
+  int t_c5 = -1, t_angle = -1, t_layout = -1, layout_step = -1;
+  std::vector<std::vector<char>> cam_ring;   // host staging of the camera block (ring: a forward may still be reading the previous one)
+  size_t cam_next = 0;
   std::map<std::string, HostTensor> weights;
   bool finalized = false;
   std::vector<float> anchors_host;     // [H*W*A, 7] for the (H, W) below; regenerated when the grid changes
@@ -195,11 +211,47 @@ void build_trunk(ivx_model *m) {
       if (j == 0)
         idt = add_conv(m, conv2d(pre + "downsample", cin, planes * 4, 1, stride, 0, false, pre + "downsample.0.weight", "", pre + "downsample.1"), x);
       int y = add_conv(m, conv2d(pre + "conv1", cin, planes, 1, 1, 0, true, pre + "conv1.weight", "", pre + "bn1"), x);
-      y = add_conv(m, conv2d(pre + "conv2", planes, planes, 3, stride, 1, true, pre + "conv2.weight", "", pre + "bn2"), y);
+      if (m->cfg.dcn_stages[i]) {
+        // ModulatedDeformConv2dPack (mmcv; configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14): conv_offset (3x3, bias) -> 27 raw channels,
+        // ivx_dcn_im2col_fwd builds the modulated, bilinearly sampled columns, the main conv is a 1x1 over K = 9 * C
+        const int off = add_conv(m, conv2d(pre + "conv2.conv_offset", planes, 27, 3, stride, 1, false, pre + "conv2.conv_offset.weight",
+                                           pre + "conv2.conv_offset.bias", ""), y);
+        Step dc; dc.kind = ST_DCN_COL; dc.in = y; dc.res = off; dc.out = new_tensor(m); dc.aux = stride;
+        m->steps.push_back(dc);
+        ConvLayer c2 = conv2d(pre + "conv2", 9 * planes, planes, 1, 1, 0, true, pre + "conv2.weight", "", pre + "bn2");
+        c2.dcn_cols = true;
+        y = add_conv(m, c2, dc.out);
+      } else {
+        y = add_conv(m, conv2d(pre + "conv2", planes, planes, 3, stride, 1, true, pre + "conv2.weight", "", pre + "bn2"), y);
+      }
       x = add_conv(m, conv2d(pre + "conv3", planes, planes * 4, 1, 1, 0, true, pre + "conv3.weight", "", pre + "bn3"), y, idt, 1);
       cin = planes * 4;
     }
     feats[i] = x;
+  }
+  if (m->cfg.layout_head) {
+    // LayoutHead (dense_heads/layout_head.py:8-50): x.mean(dim=(2,3)) of C5, two MLPs Linear-ReLU-(Dropout)-Linear-ReLU-(Dropout)-Linear
+    m->t_c5 = feats[3];
+    Step ap; ap.kind = ST_AVGPOOL; ap.in = feats[3]; ap.out = new_tensor(m);
+    m->steps.push_back(ap);
+    const int ls = m->cfg.layout_linear_size;
+    auto mlp = [&](const std::string &name, int n_out) {
+      int t = ap.out, ci = 2048;
+      const int idx[3] = {0, 3, 6}, co[3] = {ls, ls, n_out};
+      for (int q = 0; q < 3; ++q) {
+        const std::string pre = "head_2d." + name + "." + std::to_string(idx[q]) + ".";
+        ConvLayer L = conv2d(pre, ci, co[q], 1, 1, 0, q < 2, pre + "weight", pre + "bias", "");
+        L.linear = true;
+        t = add_conv(m, L, t);
+        ci = co[q];
+      }
+      return t;
+    };
+    m->t_angle = mlp("angle_mlp", 2);
+    m->t_layout = mlp("layout_mlp", 7);
+    Step ly; ly.kind = ST_LAYOUT; ly.in = m->t_angle; ly.res = m->t_layout;
+    m->layout_step = (int)m->steps.size();
+    m->steps.push_back(ly);
   }
   const int cf = m->cfg.fpn_channels, cins[4] = {256, 512, 1024, 2048};
   int lat = -1;
@@ -347,6 +399,31 @@ void build_graph(ivx_model *m) {
   if (m->cfg.neck_type == IVX_NECK_FAST || m->cfg.neck_type == IVX_NECK_UNET) {   // indoor families: the handle ends at the neck levels
     if (m->cfg.neck_type == IVX_NECK_FAST) build_neck_fast(m, m->t_volume);
     else build_neck_unet(m, m->t_volume);
+    m->head0 = (int)m->steps.size();
+    if (m->cfg.head_type != IVX_HEAD_NONE) {
+      // ImVoxelHeadV2 / ImVoxelHead with n_convs = 0 (dense_heads/imvoxel_head_v2.py:64-80, 305-313): centerness | reg | cls 3x3x3 convs
+      // as ONE conv shared by the levels, then per level the candidate kernel and ONE cross-level tail
+      const int R = m->cfg.head_type == IVX_HEAD_SCANNET ? 6 : 7, nc = m->cfg.head_classes, oc = m->cfg.neck_out_channels;
+      ConvLayer h = conv3d_k("bbox_head", oc, 1 + R + nc, 3, 1, 1, false, "", "", "");
+      h.w_keys = {"bbox_head.centerness_conv.weight", "bbox_head.reg_conv.weight", "bbox_head.cls_conv.weight"};
+      h.b_keys = {"", "", "bbox_head.cls_conv.bias"};
+      m->layers.push_back(h);
+      const int hl = (int)m->layers.size() - 1;
+      for (size_t l = 0; l < m->t_levels.size(); ++l) {
+        Step c; c.kind = ST_CONV; c.layer = hl; c.in = m->t_levels[l]; c.out = new_tensor(m);
+        m->steps.push_back(c);
+        m->t_headout.push_back(c.out);
+      }
+      for (size_t l = 0; l < m->t_levels.size(); ++l) {
+        Step f; f.kind = ST_FCOS; f.in = m->t_headout[l]; f.res = m->t_valid; f.aux = (int)l;
+        f.out = new_tensor(m); f.out2 = new_tensor(m);
+        m->t_cb.push_back(f.out); m->t_cs.push_back(f.out2); m->t_cc.push_back(new_tensor(m));
+        m->steps.push_back(f);
+      }
+      Step t; t.kind = ST_INDOOR_TAIL; t.in = m->t_cb[0];
+      m->tail_step = (int)m->steps.size();
+      m->steps.push_back(t);
+    }
     return;
   }
   build_neck(m, m->t_volume);
@@ -416,7 +493,18 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
       co0 = L.cout;
       continue;
     }
-    M_REQUIRE(nd == (size_t)(L.dims + 2) && w->shape[1] == L.cin, "ivx_weights_finalize: %s has the wrong rank / input channels", L.w_keys[q].c_str());
+    if (L.dcn_cols) {   // [Cout, C, 3, 3] -> the 1x1 filter over the (tap, c) columns of ivx_dcn_im2col_fwd: k = tap * C + c
+      const int C9 = L.cin / 9;
+      M_REQUIRE(nd == 4 && w->shape[0] == L.cout && w->shape[1] == C9 && w->shape[2] == 3 && w->shape[3] == 3,
+                "ivx_weights_finalize: %s must be [Cout, C, 3, 3]", L.w_keys[q].c_str());
+      for (int co = 0; co < L.cout; ++co)
+        for (int c = 0; c < C9; ++c)
+          for (int t = 0; t < 9; ++t) wp[(size_t)co * L.cin_pad + (size_t)t * C9 + c] = w->data[((size_t)co * C9 + c) * 9 + t];
+      co0 = L.cout;
+      continue;
+    }
+    M_REQUIRE((L.linear ? nd == 2 : nd == (size_t)(L.dims + 2)) && w->shape[1] == L.cin, "ivx_weights_finalize: %s has the wrong rank / input channels",
+              L.w_keys[q].c_str());
     const int co_n = (int)w->shape[0];
     int64_t want = (int64_t)co_n * L.cin * taps;
     M_REQUIRE((int64_t)w->data.size() == want && co0 + co_n <= L.cout, "ivx_weights_finalize: %s has the wrong shape", L.w_keys[q].c_str());
@@ -606,7 +694,42 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
         break;
       }
       case ST_TAIL: break;
+      case ST_DCN_COL: {
+        const TInfo &om = pl->t[s.res];          // the conv_offset output fixes the output grid
+        o = om; o.C = 9 * in.C;
+        break;
+      }
+      case ST_AVGPOOL: o = in; o.D = 1; o.H = 1; o.W = 1; break;
+      case ST_LAYOUT: break;
+      case ST_FCOS: {
+        const int n = in.D * in.H * in.W, k = (c.head_nms_pre > 0 && c.head_nms_pre < n) ? c.head_nms_pre : n;
+        const int R = c.head_type == IVX_HEAD_SCANNET ? 6 : 7;
+        const int64_t fw = ivx_fcos_head_workspace_bytes(in.B, n, c.head_nms_pre);
+        M_REQUIRE(fw >= 0, "indoor head level %d: more than 4096 candidates per level (nms_pre %d)", s.aux, c.head_nms_pre);
+        pl->ws_bytes = std::max(pl->ws_bytes, fw);
+        pl->itail.k[s.aux] = k;
+        TInfo cb; cb.B = in.B; cb.D = cb.H = 1; cb.W = k; cb.C = R; cb.raw = true; cb.bytes = align256((int64_t)in.B * k * R * 4); cb.first = i;
+        TInfo cs = cb; cs.C = c.head_classes; cs.bytes = align256((int64_t)in.B * k * c.head_classes * 4);
+        TInfo cc = cb; cc.W = 1; cc.C = 1; cc.bytes = align256((int64_t)in.B * 4);
+        pl->t[s.out] = cb; pl->t[s.out2] = cs; pl->t[m->t_cc[s.aux]] = cc;
+        break;
+      }
+      case ST_INDOOR_TAIL: {
+        ivx_indoor_tail_desc &d = pl->itail;
+        d.B = in.B; d.n_levels = (int)m->t_cb.size(); d.n_classes = c.head_classes; d.n_reg = c.head_type == IVX_HEAD_SCANNET ? 6 : 7;
+        d.use_rotate_nms = c.head_use_rotate_nms; d.score_thr = c.head_score_thr; d.nms_thr = c.head_nms_thr;
+        int K = 0;
+        for (int l = 0; l < d.n_levels; ++l) K += d.k[l];
+        // ScanNet: nothing is cut after the NMS (imvoxel_head_v2.py:528-545); SUN RGB-D: max_num = nms_pre (:411-413)
+        d.max_num = c.head_type == IVX_HEAD_SCANNET ? K : std::min<int64_t>(c.head_nms_pre > 0 ? c.head_nms_pre : K, (int64_t)K * c.head_classes);
+        pl->max_det = d.max_num;
+        const int64_t tw = ivx_indoor_tail_workspace_bytes(&d);
+        M_REQUIRE(tw >= 0, "indoor tail: %s", ivx_last_error());
+        pl->ws_bytes = std::max(pl->ws_bytes, tw);
+        break;
+      }
     }
+    if (s.kind == ST_LAYOUT || s.kind == ST_FCOS || s.kind == ST_INDOOR_TAIL) continue;
     if (s.kind == ST_TAIL) {
       const TInfo &nk = pl->t[m->t_neck];      // [B, X', Y', 1, C]: the reference's H = Y', W = X' (necks/imvoxelnet.py:120)
       ivx_anchor_head_desc &d = pl->tail;
@@ -619,6 +742,7 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       pl->tail_ws = ivx_anchor_head_workspace_bytes(&d);
       M_REQUIRE(pl->tail_ws >= 0, "anchor tail: %s", ivx_last_error());
       pl->ws_bytes = std::max(pl->ws_bytes, pl->tail_ws);
+      pl->max_det = c.max_num;
       continue;
     }
     o.bytes = align256(o.elems() * 4);
@@ -630,15 +754,30 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
     const Step &s = m->steps[i];
     for (int t : {s.in, s.res})
       if (t >= 0) pl->t[t].last = std::max(pl->t[t].last, i);
+    if (s.kind == ST_INDOOR_TAIL)            // reads every level's candidate buffers
+      for (size_t l = 0; l < m->t_cb.size(); ++l)
+        for (int t : {m->t_cb[l], m->t_cs[l], m->t_cc[l]}) pl->t[t].last = std::max(pl->t[t].last, i);
   }
-  std::vector<int> keep = {m->t_fpn0, m->t_volume, m->t_valid, m->t_neck, m->t_head};
+  std::vector<int> keep = {m->t_fpn0, m->t_volume, m->t_valid, m->t_neck, m->t_head, m->t_angle, m->t_layout};
   keep.insert(keep.end(), m->t_levels.begin(), m->t_levels.end());
   for (int t : keep)
     if (t >= 0 && pl->t[t].first >= r.s0) pl->t[t].last = r.s1;   // boundary tensors may be read back by the caller
   // first-fit arena with coalescing free list
   struct Blk { int64_t off, size; };
   std::vector<Blk> free_list;
+  // camera block (ivx_model_detect): proj [B,V,3,4] | new_origin [B,3] | crop [B,2] i32 | per head level: voxel size [B,3], origin [B,3]
   int64_t top = 0;
+  {
+    const TInfo &vol = pl->t[m->t_volume];
+    const int Bs = vol.B > 0 ? vol.B : 1;
+    auto take = [&](int64_t bytes) { const int64_t at = top; top += align256(bytes); return at; };
+    pl->n_views = n_views;
+    pl->cam_proj = take((int64_t)Bs * n_views * 12 * 4);
+    pl->cam_origin = take((int64_t)Bs * 3 * 4);
+    pl->cam_crop = take((int64_t)Bs * 2 * 4);
+    for (int l = 0; l < 3; ++l) { pl->cam_lvl_vs[l] = take((int64_t)Bs * 3 * 4); pl->cam_lvl_no[l] = take((int64_t)Bs * 3 * 4); }
+    pl->cam_bytes = top;
+  }
   auto release = [&](int64_t off, int64_t size) {
     free_list.push_back({off, size});
     std::sort(free_list.begin(), free_list.end(), [](const Blk &a, const Blk &b) { return a.off < b.off; });
@@ -651,7 +790,8 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
   };
   for (int i = r.s0; i < r.s1; ++i) {
     const Step &s = m->steps[i];
-    for (int t : {s.out, s.out2}) {
+    const int extra = s.kind == ST_FCOS ? m->t_cc[s.aux] : -1;
+    for (int t : {s.out, s.out2, extra}) {
       if (t < 0 || pl->t[t].first != i) continue;
       TInfo &ti = pl->t[t];
       bool placed = false;
@@ -712,6 +852,12 @@ struct Bind {               // caller-owned buffers by tensor id
   float *boxes = nullptr, *scores = nullptr;
   int64_t *labels = nullptr;
   int32_t *count = nullptr;
+  // ivx_model_detect: per-level geometry of the anchor-free head (device), the host metas (LayoutHead: the projection is built
+  // from the predicted angles in the middle of the forward) and the host outputs of the LayoutHead
+  const float *lvl_vs[3] = {nullptr, nullptr, nullptr}, *lvl_no[3] = {nullptr, nullptr, nullptr};
+  const ivx_sample_meta *metas = nullptr;
+  float *proj_dev = nullptr;           // writable alias of proj inside the camera block
+  float *angles_host = nullptr, *layout_host = nullptr;
 };
 
 int trace_begin(ivx_model *m, int step, int stage, int is3d, double flops, double bytes, const std::string &name, hipStream_t st) {
@@ -856,6 +1002,60 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         M_TRY(trace_end(m, st));
         break;
       }
+      case ST_DCN_COL: {
+        const TInfo &om = pl.t[s.res];
+        M_TRY(trace_begin(m, i, 0, 0, 0.0, 4.0 * pl.t[s.out].elems(), "dcn columns", st));
+        M_TRY(ivx_dcn_im2col_fwd((const float *)ptr(s.in), (const float *)ptr(s.res), in.B, in.H, in.W, in.C, 3, 3, s.aux, 1, 1, om.C,
+                                 (float *)ptr(s.out), st));
+        M_TRY(trace_end(m, st));
+        break;
+      }
+      case ST_AVGPOOL:
+        M_TRY(ivx_global_avgpool_fwd((const float *)ptr(s.in), in.B, (int64_t)in.D * in.H * in.W, in.C, (float *)ptr(s.out), st));
+        break;
+      case ST_LAYOUT: {
+        // LayoutHead._forward_single (layout_head.py:52-74) + the projection from the PREDICTED angles (detectors/imvoxelnet.py:59-61,
+        // 121-124, 164-187).  The one place where the forward returns to the host: 9 numbers per sample, as in the reference (its
+        // extrinsics are built from `angles` with CPU ops).
+        M_REQUIRE(bd.metas && bd.proj_dev, "%s: a handle with a LayoutHead runs through ivx_model_detect (the projection is built from its angles)", who);
+        const int B = in.B;
+        std::vector<float> a((size_t)B * 2), l((size_t)B * 7), pj((size_t)B * 12);
+        M_HIP(hipMemcpyAsync(a.data(), ptr(s.in), a.size() * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (angles)");
+        M_HIP(hipMemcpyAsync(l.data(), ptr(s.res), l.size() * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (layout)");
+        M_HIP(hipStreamSynchronize(st), "hipStreamSynchronize (LayoutHead)");
+        for (int b = 0; b < B; ++b) {
+          float ang[2], E[16];
+          M_TRY(ivx_layout_head_decode(&a[(size_t)b * 2], &l[(size_t)b * 7], ang, bd.layout_host ? bd.layout_host + (size_t)b * 7 : nullptr));
+          if (bd.angles_host) { bd.angles_host[(size_t)b * 2] = ang[0]; bd.angles_host[(size_t)b * 2 + 1] = ang[1]; }
+          M_TRY(ivx_layout_extrinsics(ang, E));
+          const ivx_sample_meta &mt = bd.metas[b];
+          M_TRY(ivx_compute_projection(mt.intrinsic, E, 1, (double)mt.ori_h / ((double)mt.img_h / 4.0), &pj[(size_t)b * 12]));
+        }
+        M_HIP(hipMemcpyAsync(bd.proj_dev, pj.data(), pj.size() * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync (projection)");
+        M_HIP(hipStreamSynchronize(st), "hipStreamSynchronize (projection)");      // pj dies at the end of this block
+        break;
+      }
+      case ST_FCOS: {
+        const ivx_model_cfg &c = m->cfg;
+        const int l = s.aux, R = c.head_type == IVX_HEAD_SCANNET ? 6 : 7;
+        const TInfo &vol = pl.t[m->t_volume];
+        M_REQUIRE(bd.lvl_vs[l] && bd.lvl_no[l], "%s: the head levels need their geometry (ivx_model_detect)", who);
+        M_TRY(trace_begin(m, i, 5, 0, 0.0, 0.0, "indoor head candidates", st));
+        M_TRY(ivx_fcos_head_level_candidates((const float *)ptr(s.in), (const uint8_t *)ptr(s.res), bd.lvl_vs[l], bd.lvl_no[l], m->head_scales[l], in.B,
+                                             in.D, in.H, in.W, in.C, c.head_classes, R, l, vol.D, vol.H, vol.W, c.head_nms_pre, ws, pl.ws_bytes,
+                                             (float *)ptr(s.out), (float *)ptr(s.out2), (int32_t *)ptr(m->t_cc[l]), st));
+        M_TRY(trace_end(m, st));
+        break;
+      }
+      case ST_INDOOR_TAIL: {
+        M_REQUIRE(bd.boxes && bd.scores && bd.labels && bd.count, "%s: output buffers are required", who);
+        const float *cb[4] = {nullptr, nullptr, nullptr, nullptr}, *cs[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (size_t l = 0; l < m->t_cb.size(); ++l) { cb[l] = (const float *)ptr(m->t_cb[l]); cs[l] = (const float *)ptr(m->t_cs[l]); }
+        M_TRY(trace_begin(m, i, 5, 0, 0.0, 0.0, "indoor tail", st));
+        M_TRY(ivx_indoor_tail_get_bboxes(&pl.itail, cb, cs, ws, pl.ws_bytes, bd.boxes, bd.scores, bd.labels, bd.count, st));
+        M_TRY(trace_end(m, st));
+        break;
+      }
       case ST_TAIL: {
         const ivx_anchor_head_desc &d = pl.tail;
         M_TRY(ensure_anchors(m, d, st, who));          // no-op on the steady-state path
@@ -902,6 +1102,14 @@ extern "C" int ivx_create(const ivx_model_cfg *cfg, ivx_model **out) {
             "ivx_create: 1..4 anchor sizes / rotations, >= 1 class");
   M_REQUIRE(indoor || (cfg->nms_pre > 0 && cfg->max_num > 0), "ivx_create: nms_pre and max_num must be positive");
   M_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 2 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "ivx_create: winograd_tile 0 | 2 | 4 | 6");
+  M_REQUIRE(cfg->head_type >= IVX_HEAD_NONE && cfg->head_type <= IVX_HEAD_SUNRGBD, "ivx_create: head_type 0 (none) | IVX_HEAD_SCANNET | IVX_HEAD_SUNRGBD");
+  if (cfg->head_type != IVX_HEAD_NONE) {
+    M_REQUIRE(indoor, "ivx_create: the anchor-free heads sit on the FAST / UNET necks (the stack necks end in the Anchor3DHead)");
+    M_REQUIRE(cfg->head_classes >= 1 && (cfg->head_type == IVX_HEAD_SCANNET || cfg->head_classes <= 64), "ivx_create: bad head_classes");
+    M_REQUIRE(cfg->head_nms_pre > 0 && cfg->head_nms_pre <= 4096, "ivx_create: head_nms_pre must be in 1..4096");
+  }
+  M_REQUIRE(!cfg->layout_head || (cfg->with_trunk && cfg->layout_linear_size > 0), "ivx_create: the LayoutHead needs the trunk and a positive layout_linear_size");
+  for (int i = 0; i < 4; ++i) M_REQUIRE(cfg->dcn_stages[i] == 0 || cfg->with_trunk, "ivx_create: dcn_stages without the trunk");
   ivx_model *m = new ivx_model();
   m->cfg = *cfg;
   build_graph(m);
@@ -967,6 +1175,14 @@ extern "C" int ivx_weights_finalize(ivx_model *m, ivx_stream_t stream) {
     ivx_set_error("ivx_weights_finalize: missing state-dict keys: %.400s", missing.c_str());
     return IVX_ERR_INVALID_ARG;
   }
+  for (size_t l = 0; l < m->t_headout.size() && l < 3; ++l) {     // mmcv Scale of the anchor-free heads (imvoxel_head_v2.py:78-80): exp(scale * reg)
+    const HostTensor *sc = find_w(m, "bbox_head.scales." + std::to_string(l) + ".scale");
+    if (!sc || sc->data.size() != 1) {
+      ivx_set_error("ivx_weights_finalize: missing state-dict keys: bbox_head.scales.%d.scale", (int)l);
+      return IVX_ERR_INVALID_ARG;
+    }
+    m->head_scales[l] = sc->data[0];
+  }
   M_HIP(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");   // host staging vectors die here
   m->weights.clear();
   std::vector<float>().swap(m->pack_a);
@@ -985,16 +1201,19 @@ int check_img(const ivx_model *m, int B, int V, int H, int W, const char *who) {
 }  // namespace
 
 // ---- whole path
-static int plan_forward(ivx_model *m, int B, int V, int H, int W, Plan **pl, Range *r, hipStream_t st) {
+// whole = false: up to the anchor tail (stack necks) or the neck levels (indoor necks) -- ivx_model_forward / _forward_levels;
+// whole = true: every step, i.e. including the anchor-free head and its tail -- ivx_model_detect
+static int plan_forward(ivx_model *m, int B, int V, int H, int W, Plan **pl, Range *r, hipStream_t st, bool whole = false) {
   std::map<int, TInfo> in;
+  const int end = (!whole && m->head0 >= 0) ? m->head0 : (int)m->steps.size();
   if (m->cfg.with_trunk) {
     in[m->t_img] = tinfo(B * V, 1, H, W, 3);
-    *r = {m->trunk0, (int)m->steps.size()};
+    *r = {m->trunk0, end};
   } else {
     in[m->t_fpn0] = tinfo(B * V, 1, H / 4, W / 4, m->cfg.fpn_channels);
-    *r = {m->lift_step, (int)m->steps.size()};
+    *r = {m->lift_step, end};
   }
-  return get_plan(m, "forward", *r, B, V, H, W, in, pl, st);
+  return get_plan(m, whole ? "detect" : "forward", *r, B, V, H, W, in, pl, st);
 }
 
 extern "C" int64_t ivx_model_workspace_bytes(ivx_model *m, int32_t B, int32_t V, int32_t H, int32_t W) {
@@ -1010,7 +1229,8 @@ extern "C" int ivx_model_forward(ivx_model *m, const float *input, int32_t B, in
                                  ivx_stream_t stream) {
   M_TRY(check_img(m, B, V, H, W, "ivx_model_forward"));
   M_REQUIRE(input, "ivx_model_forward: null input");
-  M_REQUIRE(m->t_head >= 0, "ivx_model_forward: the handle holds an indoor neck (no anchor head); use ivx_model_forward_levels");
+  M_REQUIRE(m->t_head >= 0, "ivx_model_forward: the handle holds an indoor neck (no anchor head); use ivx_model_forward_levels or ivx_model_detect");
+  M_REQUIRE(!m->cfg.layout_head, "ivx_model_forward: a handle with a LayoutHead runs through ivx_model_detect");
   Plan *pl; Range r;
   M_TRY(plan_forward(m, B, V, H, W, &pl, &r, (hipStream_t)stream));
   Bind bd;
@@ -1182,6 +1402,7 @@ extern "C" int ivx_model_forward_levels(ivx_model *m, const float *input, int32_
   M_TRY(check_img(m, B, V, H, W, "ivx_model_forward_levels"));
   M_REQUIRE(input && out_levels, "ivx_model_forward_levels: null argument");
   M_REQUIRE(!m->t_levels.empty(), "ivx_model_forward_levels: the handle holds a stack neck + anchor head; use ivx_model_forward");
+  M_REQUIRE(!m->cfg.layout_head, "ivx_model_forward_levels: a handle with a LayoutHead runs through ivx_model_detect");
   for (size_t l = 0; l < m->t_levels.size(); ++l) M_REQUIRE(out_levels[l], "ivx_model_forward_levels: null output level %d", (int)l);
   Plan *pl; Range r;
   M_TRY(plan_forward(m, B, V, H, W, &pl, &r, (hipStream_t)stream));
@@ -1191,6 +1412,117 @@ extern "C" int ivx_model_forward_levels(ivx_model *m, const float *input, int32_
   for (size_t l = 0; l < m->t_levels.size(); ++l) bd.ext[m->t_levels[l]] = out_levels[l];
   bd.proj = proj; bd.new_origin = new_origin; bd.crop = crop_hw; bd.V = V;
   return run_steps(m, *pl, r, bd, workspace, workspace_bytes, (hipStream_t)stream, "ivx_model_forward_levels");
+}
+
+// ---- the whole of simple_test in one call, every family: the per-batch camera set-up is computed here (host), uploaded into the
+// camera block of the workspace, and the handle runs trunk -> unprojection -> neck -> head -> tail.
+static int plan_detect(ivx_model *m, int B, int V, int H, int W, Plan **pl, Range *r, hipStream_t st) {
+  M_REQUIRE(m->t_head >= 0 || m->cfg.head_type != IVX_HEAD_NONE,
+            "ivx_model_detect: the handle was created without a head (head_type 0): it ends at the neck levels, use ivx_model_forward_levels");
+  M_REQUIRE(!m->cfg.layout_head || V == 1, "ivx_model_detect: the LayoutHead predicts ONE camera per sample (V must be 1, got %d)", V);
+  return plan_forward(m, B, V, H, W, pl, r, st, true);
+}
+
+extern "C" int64_t ivx_model_detect_workspace_bytes(ivx_model *m, int32_t B, int32_t V, int32_t H, int32_t W) {
+  if (check_img(m, B, V, H, W, "ivx_model_detect_workspace_bytes") != IVX_OK) return -1;
+  Plan *pl; Range r;
+  if (plan_detect(m, B, V, H, W, &pl, &r, nullptr) != IVX_OK) return -1;
+  return pl->total;
+}
+
+extern "C" int32_t ivx_model_max_detections(ivx_model *m, int32_t B, int32_t V, int32_t H, int32_t W) {
+  if (check_img(m, B, V, H, W, "ivx_model_max_detections") != IVX_OK) return -1;
+  Plan *pl; Range r;
+  if (plan_detect(m, B, V, H, W, &pl, &r, nullptr) != IVX_OK) return -1;
+  return pl->max_det;
+}
+
+extern "C" int ivx_model_detect(ivx_model *m, const float *img, int32_t B, int32_t V, int32_t H, int32_t W, const ivx_sample_meta *metas,
+                                void *workspace, int64_t workspace_bytes, float *out_boxes, float *out_scores, int64_t *out_labels,
+                                int32_t *out_count, uint8_t *out_valid, float *out_angles, float *out_layout, ivx_stream_t stream) {
+  M_TRY(check_img(m, B, V, H, W, "ivx_model_detect"));
+  M_REQUIRE(img && metas, "ivx_model_detect: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  Plan *pl; Range r;
+  M_TRY(plan_detect(m, B, V, H, W, &pl, &r, st));
+  M_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, "ivx_model_detect: workspace must be non-null and 256-byte aligned");
+  if (workspace_bytes < pl->total) {
+    ivx_set_error("ivx_model_detect: workspace too small (%lld < %lld); size it with ivx_model_detect_workspace_bytes", (long long)workspace_bytes,
+                  (long long)pl->total);
+    return IVX_ERR_WORKSPACE;
+  }
+  // host camera set-up (detectors/imvoxelnet.py:114-129, :139, :67-68; imvoxel_head_v2.py:206-214 for the head levels), in the library's
+  // fixed fp32 operation order
+  if (m->cam_ring.empty()) m->cam_ring.resize(8);
+  std::vector<char> &hs = m->cam_ring[m->cam_next++ % m->cam_ring.size()];
+  hs.assign((size_t)pl->cam_bytes, 0);
+  const ivx_model_cfg &c = m->cfg;
+  for (int b = 0; b < B; ++b) {
+    const ivx_sample_meta &mt = metas[b];
+    M_REQUIRE(mt.img_h > 0 && mt.img_w > 0 && mt.ori_h > 0 && mt.img_h <= H && mt.img_w <= W, "ivx_model_detect: sample %d: bad img_shape / ori_shape", b);
+    if (!c.layout_head) {
+      M_REQUIRE(mt.extrinsics, "ivx_model_detect: sample %d: null extrinsics", b);
+      M_TRY(ivx_compute_projection(mt.intrinsic, mt.extrinsics, V, (double)mt.ori_h / ((double)mt.img_h / 4.0),
+                                   (float *)(hs.data() + pl->cam_proj) + (size_t)b * V * 12));
+    }
+    M_TRY(ivx_voxel_new_origin(mt.origin, c.n_voxels, c.voxel_size, (float *)(hs.data() + pl->cam_origin) + (size_t)b * 3));
+    int32_t *crop = (int32_t *)(hs.data() + pl->cam_crop) + (size_t)b * 2;
+    crop[0] = mt.img_h / 4; crop[1] = mt.img_w / 4;
+    for (size_t l = 0; l < m->t_headout.size(); ++l) {
+      const TInfo &ho = pl->t[m->t_headout[l]];
+      const int32_t nl[3] = {ho.D, ho.H, ho.W};
+      float *vs = (float *)(hs.data() + pl->cam_lvl_vs[l]) + (size_t)b * 3;
+      for (int a = 0; a < 3; ++a) vs[a] = c.voxel_size[a] * (float)(1 << l);       // voxel_size * 2^level (exact)
+      M_TRY(ivx_voxel_new_origin(mt.origin, nl, vs, (float *)(hs.data() + pl->cam_lvl_no[l]) + (size_t)b * 3));
+    }
+  }
+  char *base = (char *)workspace;
+  M_HIP(hipMemcpyAsync(base, hs.data(), (size_t)pl->cam_bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync (camera block)");
+  Bind bd;
+  bd.ext[m->cfg.with_trunk ? m->t_img : m->t_fpn0] = (void *)img;     // (with_trunk = 0: the FPN level-0 maps, channels-last)
+  if (out_valid) bd.ext[m->t_valid] = out_valid;
+  bd.proj = (const float *)(base + pl->cam_proj); bd.proj_dev = (float *)(base + pl->cam_proj);
+  bd.new_origin = (const float *)(base + pl->cam_origin); bd.crop = (const int32_t *)(base + pl->cam_crop); bd.V = V;
+  for (int l = 0; l < 3; ++l) { bd.lvl_vs[l] = (const float *)(base + pl->cam_lvl_vs[l]); bd.lvl_no[l] = (const float *)(base + pl->cam_lvl_no[l]); }
+  bd.metas = metas; bd.angles_host = out_angles; bd.layout_host = out_layout;
+  bd.boxes = out_boxes; bd.scores = out_scores; bd.labels = out_labels; bd.count = out_count;
+  return run_steps(m, *pl, r, bd, workspace, workspace_bytes, st, "ivx_model_detect");
+}
+
+// ---- LayoutHead host arithmetic (no device work), fixed fp32 operation order shared by every host of the library.
+// angle = limit_period(angle) (layout_head.py:53, structures/utils.py:5-18: val - floor(val / pi + 0.5) * pi); layout = (centre, exp(size), yaw) (:70-74)
+extern "C" int ivx_layout_head_decode(const float *angle_raw, const float *layout_raw, float *angle, float *layout) {
+  M_REQUIRE(angle_raw && layout_raw && angle, "ivx_layout_head_decode: null argument");
+  const float PI = 3.14159265358979323846f;
+  for (int q = 0; q < 2; ++q) {
+    const float t = floorf(angle_raw[q] / PI + 0.5f);
+    angle[q] = angle_raw[q] - t * PI;
+  }
+  if (layout) {
+    for (int q = 0; q < 3; ++q) layout[q] = layout_raw[q];
+    for (int q = 3; q < 6; ++q) layout[q] = expf(layout_raw[q]);
+    layout[6] = layout_raw[6];
+  }
+  return IVX_OK;
+}
+
+// get_extrinsics (detectors/imvoxelnet.py:164-187): camera extrinsic [4,4] from the predicted (pitch, roll), yaw = 0; the rotation in
+// Total3DUnderstanding axes, moved to the depth-box axes (column order 2, 0, 1; third row negated).
+extern "C" int ivx_layout_extrinsics(const float *angles, float *extrinsic4x4) {
+  M_REQUIRE(angles && extrinsic4x4, "ivx_layout_extrinsics: null argument");
+  const float cp = cosf(angles[0]), sp = sinf(angles[0]), cr = cosf(angles[1]), sr = sinf(angles[1]);
+  float r[3][3];                                  // yaw = 0: cos = 1, sin = 0 (the products with them are exact)
+  r[0][0] = cp;       r[0][1] = -(cr * sp);  r[0][2] = sp * sr;
+  r[1][0] = sp;       r[1][1] = cp * cr;     r[1][2] = -(cp * sr);
+  r[2][0] = 0.0f;     r[2][1] = sr;          r[2][2] = cr;
+  float q[3][3];                                  // t @ r.T with t = [[0,0,1],[0,-1,0],[-1,0,0]]
+  for (int j = 0; j < 3; ++j) { q[0][j] = r[j][2]; q[1][j] = -r[j][1]; q[2][j] = -r[j][0]; }
+  const int perm[3] = {2, 0, 1};
+  for (int i = 0; i < 16; ++i) extrinsic4x4[i] = 0.0f;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) extrinsic4x4[i * 4 + j] = (i == 2 ? -1.0f : 1.0f) * q[i][perm[j]];
+  extrinsic4x4[15] = 1.0f;
+  return IVX_OK;
 }
 
 extern "C" int ivx_model_anchors(ivx_model *m, int32_t H, int32_t W, float *anchors_host, int64_t capacity) {

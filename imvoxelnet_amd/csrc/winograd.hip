@@ -27,6 +27,7 @@ struct WinoP {
   const float *in, *scale, *shift, *res;
   float *out;
   float *V, *Mw;
+  long long vs, ms;         // xi-plane strides of V / M in floats (>= the plane size: see wino_plane_stride)
   int B, X, Y, Z, C;        // input volume
   int Xo, Yo, Zo, Co;       // output volume
   int TX, TY;               // m x m output tiles
@@ -39,6 +40,9 @@ struct WinoP {
 template <int W> struct VecT;
 template <> struct VecT<4> { typedef float4 T; };
 template <> struct VecT<2> { typedef float2 T; };
+template <> struct VecT<1> { typedef float T; };
+__device__ __forceinline__ float vzero(float *) { return 0.f; }
+__device__ __forceinline__ float vone(float *) { return 1.f; }
 __device__ __forceinline__ float4 vzero(float4 *) { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float2 vzero(float2 *) { return make_float2(0.f, 0.f); }
 __device__ __forceinline__ float4 vone(float4 *) { return make_float4(1.f, 1.f, 1.f, 1.f); }
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
       V v[N];
       Wino1D<MT, V>::in(w[i], v);
 #pragma unroll
-      for (int j = 0; j < N; ++j) Vw[(long long)(N * i + j) * total + t] = v[j];
+      for (int j = 0; j < N; ++j) Vw[(long long)(N * i + j) * (p.vs / VW) + t] = v[j];
     }
   }
 }
@@ -198,6 +202,7 @@ __device__ __forceinline__ float4 wino_finish_v(const WinoP &p, float4 a, float4
   return make_float4(wino_finish(p, a.x, sc.x, sf.x, r.x), wino_finish(p, a.y, sc.y, sf.y, r.y), wino_finish(p, a.z, sc.z, sf.z, r.z),
                      wino_finish(p, a.w, sc.w, sf.w, r.w));
 }
+__device__ __forceinline__ float wino_finish_v(const WinoP &p, float a, float sc, float sf, float r) { return wino_finish(p, a, sc, sf, r); }
 __device__ __forceinline__ float2 wino_finish_v(const WinoP &p, float2 a, float2 sc, float2 sf, float2 r) {
   return make_float2(wino_finish(p, a.x, sc.x, sf.x, r.x), wino_finish(p, a.y, sc.y, sf.y, r.y));
 }
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
     for (int j = 0; j < N; ++j) {
       V m[N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) m[i] = Mw[(long long)(N * i + j) * total + t];
+      for (int i = 0; i < N; ++i) m[i] = Mw[(long long)(N * i + j) * (p.ms / VW) + t];
       V y[MT];
       Wino1D<MT, V>::out(m, y);
 #pragma unroll
@@ -249,6 +254,150 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
         if (p.res_mode) rr = res[o];
         out[o] = wino_finish_v(p, yy[e], sc, sf, rr);
       }
+    }
+  }
+}
+
+// Coefficients of At for the column-accumulate form of the output transform (wino_output_buf_kernel below).
+template <int MT> struct WinoAt;
+template <> struct WinoAt<6> {
+  static __device__ __forceinline__ float c(int e, int j) {
+    constexpr float A[6][8] = {{1, 1, 1, 1, 1, 1, 1, 0},          {0, 1, -1, 2, -2, 0.5f, -0.5f, 0},
+                               {0, 1, 1, 4, 4, 0.25f, 0.25f, 0},   {0, 1, -1, 8, -8, 0.125f, -0.125f, 0},
+                               {0, 1, 1, 16, 16, 0.0625f, 0.0625f, 0}, {0, 1, -1, 32, -32, 0.03125f, -0.03125f, 1}};
+    return A[e][j];
+  }
+};
+template <> struct WinoAt<4> {
+  static __device__ __forceinline__ float c(int e, int j) {
+    constexpr float A[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    return A[e][j];
+  }
+};
+__device__ __forceinline__ float vfma(float s, float a, float c) { return fmaf(s, a, c); }
+__device__ __forceinline__ float2 vfma(float s, float2 a, float2 c) { return make_float2(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y)); }
+__device__ __forceinline__ float4 vfma(float s, float4 a, float4 c) {
+  return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+
+// Output transform, default form for F(6x6, 3x3): buffer addressing + column accumulation.
+//  * ONE 32-bit lane offset per thread; the plane / output-position offsets are wave-uniform SGPR operands of buffer_load /
+//    buffer_store (the pointer form above spends two VGPRs and a 64-bit add per access on 64 + 36 + 36 addresses);
+//  * the columns of M are consumed one at a time -- 8 loads, the 1-D transform down the column, its contribution At[e][j] * r[a]
+//    added to the m x m accumulators -- with the next column's loads issued one step ahead and fenced (sched_barrier), so a thread
+//    holds 36 accumulators + two columns instead of the whole 8 x 8 tile: 164 VGPRs / 3 waves per SIMD with 2 channels per lane
+//    (the whole-tile form: 211 / 2) -- and the residual loads of one output row overlap the stores of the previous one;
+//  * the epilogue is branch-free (border positions get an out-of-range lane offset: the buffer hardware drops those stores and
+//    returns 0 for those loads), which keeps the loop body one basic block -- otherwise LLVM sinks the column arithmetic into the
+//    conditional store blocks and every load is hoisted to the top again.
+// Measured on the KITTI neck at batch 4 (tools/wino_ab.py, profiles/r03_wino_ab.log): with residual 0.63 -> 0.52 ms per launch
+// (3.95 -> 4.8 TB/s), without 0.37 -> 0.35.  Needs the (m+2)^2 planes of M below 4 GiB and the output tensor below 2 GiB (the
+// launcher falls back to the pointer kernel otherwise).  The sums are accumulated in another order than in the whole-tile form:
+// same fp32 arithmetic, results differ by rounding only.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int VW> struct BufIO;
+template <> struct BufIO<2> {
+  static __device__ __forceinline__ float2 load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+  }
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 f) {
+    u32x2 v;
+    v.x = __float_as_uint(f.x);
+    v.y = __float_as_uint(f.y);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+  }
+};
+template <> struct BufIO<1> {
+  static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  }
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float f) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(f), r, voff, soff, 0);
+  }
+};
+
+// acc[e] += At[e][J] * y for one column J of F(6,3)'s At (coefficients 0 / +-1 become nothing / plain adds).
+template <int J, typename V>
+__device__ __forceinline__ void wino6_acc_column(V (&acc)[6], const V y) {
+#pragma unroll
+  for (int e = 0; e < 6; ++e) {
+    const float cf = WinoAt<6>::c(e, J);
+    if (cf == 1.0f) acc[e] = acc[e] + y;
+    else if (cf == -1.0f) acc[e] = acc[e] - y;
+    else if (cf != 0.0f) acc[e] = vfma(cf, y, acc[e]);
+  }
+}
+
+// The column loop as a compile-time recursion (J is a template constant, so every array index is static): consume column J
+// (already loaded), issue column J + 1, fence, transform + accumulate, fence.
+template <int J, int VW> struct Wino6Columns {
+  typedef typename VecT<VW>::T V;
+  static __device__ __forceinline__ void run(V (&acc)[6][6], const V (&col)[8], const __amdgpu_buffer_rsrc_t rm, const unsigned vo,
+                                             const unsigned ps) {
+    V nxt[8];
+    if (J + 1 < 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) nxt[i] = BufIO<VW>::load(rm, vo, (unsigned)(8 * i + J + 1) * ps);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    V y[6];
+    Wino1D<6, V>::out(col, y);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) wino6_acc_column<J>(acc[a], y[a]);
+    __builtin_amdgcn_sched_barrier(0);
+    Wino6Columns<J + 1, VW>::run(acc, nxt, rm, vo, ps);
+  }
+};
+template <int VW> struct Wino6Columns<8, VW> {
+  typedef typename VecT<VW>::T V;
+  static __device__ __forceinline__ void run(V (&)[6][6], const V (&)[8], const __amdgpu_buffer_rsrc_t, const unsigned, const unsigned) {}
+};
+
+template <int VW, int WPE>
+__global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p, const unsigned m_bytes, const unsigned out_bytes) {
+  typedef typename VecT<VW>::T V;
+  constexpr int MT = 6, N = 8, EB = VW * 4;     // bytes per lane item
+  const int CV = p.Co / VW;
+  const long long per_tile = (long long)p.Zo * CV;
+  const long long total = (long long)p.B * p.TX * p.TY * per_tile;
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)p.Mw, 0, m_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), 0, p.res ? out_bytes : 0u, 0x00020000);
+  const unsigned ps = (unsigned)(p.ms * 4);                 // plane stride in bytes
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long zc = t % per_tile;
+    const int cv = (int)(zc % CV);
+    long long q = t / per_tile;
+    const int ty = (int)(q % p.TY);
+    q /= p.TY;
+    const int tx = (int)(q % p.TX);
+    const int b = (int)(q / p.TX);
+    const unsigned vo = (unsigned)(t * EB);
+    const V sc = p.scale ? reinterpret_cast<const V *>(p.scale)[cv] : vone((V *)nullptr);     // (uniform branches BEFORE the column loop)
+    const V sf = p.shift ? reinterpret_cast<const V *>(p.shift)[cv] : vzero((V *)nullptr);
+    V acc[MT][MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int e = 0; e < MT; ++e) acc[a][e] = vzero((V *)nullptr);
+    V col[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) col[i] = BufIO<VW>::load(rm, vo, (unsigned)(N * i) * ps);
+    Wino6Columns<0, VW>::run(acc, col, rm, vo, ps);
+    const int xb = MT * tx, yb = MT * ty;
+    const unsigned o00 = (unsigned)(((((long long)b * p.Xo + xb) * p.Yo + yb) * per_tile + zc) * EB);
+    const unsigned row = (unsigned)(p.Yo * per_tile * EB), colb = (unsigned)(per_tile * EB);
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+#pragma unroll
+      for (int e = 0; e < MT; ++e) {
+        const unsigned vo_ae = (xb + a < p.Xo && yb + e < p.Yo) ? o00 : 0x80000000u;
+        const unsigned so = (unsigned)a * row + (unsigned)e * colb;
+        const V rv = BufIO<VW>::load(rr, vo_ae, so);        // no residual: rr has zero records -> 0
+        BufIO<VW>::store(ro, vo_ae, so, wino_finish_v(p, acc[a][e], sc, sf, rv));
+      }
+      __builtin_amdgcn_sched_barrier(0);       // one output row's residual loads in flight at a time (else all 36 are hoisted)
     }
   }
 }
@@ -289,7 +438,15 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restric
 struct WinoDims {
   int Xo, Yo, Zo, TX, TY, n2;
   int64_t v_elems, m_elems;   // elements of one xi plane of V / M
+  int64_t v_stride, m_stride; // distance between consecutive xi planes in floats (= the plane size; padding the stride to break
+                              // a possible channel-interleave alignment of the 64 concurrent plane streams measured nothing: r03_wino_ab.log)
 };
+
+// A/B knob (per calling thread; ivx_conv_winograd_set_variant): the F(6x6,3x3) output transform kernel.
+//  -1 default rule (2 with a residual, 1 without) | 0 whole tile, 2 channels per lane (the round-2 kernel) | 1 whole tile, 1 channel
+//  per lane | 2 buffer addressing + column accumulation, 2 channels per lane | 3 the same, 1 channel per lane
+thread_local int g_wino_out_variant = -1;
+thread_local int g_wino_in_variant = -1;     // input transform of F(6x6,3x3): -1 default (0) | 0: 2 channels per lane | 1: 1 channel per lane
 
 int wino_dims(const ivx_conv_desc *d, int tile, WinoDims *w, const char *who) {
   IVX_REQUIRE(d, "%s: null descriptor", who);
@@ -308,6 +465,8 @@ int wino_dims(const ivx_conv_desc *d, int tile, WinoDims *w, const char *who) {
   w->n2 = (tile + 2) * (tile + 2);
   w->v_elems = (int64_t)d->B * w->TX * w->TY * d->W * d->Cin;
   w->m_elems = (int64_t)d->B * w->TX * w->TY * Zo * d->Cout;
+  w->v_stride = w->v_elems;
+  w->m_stride = w->m_elems;
   return IVX_OK;
 }
 
@@ -327,11 +486,17 @@ unsigned wino_blocks(int64_t items) {
 
 }  // namespace
 
+extern "C" int ivx_conv_winograd_set_variant(int32_t output_variant, int32_t input_variant) {
+  g_wino_out_variant = output_variant;
+  g_wino_in_variant = input_variant;
+  return IVX_OK;
+}
+
 extern "C" int ivx_conv_winograd_supported(const ivx_conv_desc *d, int32_t tile) {
   WinoDims w;
   if (wino_dims(d, tile, &w, "ivx_conv_winograd_supported") != IVX_OK) return 0;
   // one xi plane is one group of the grouped launch: 31-bit buffer offsets
-  if (w.v_elems * 4 >= (1LL << 31) || w.m_elems >= (1LL << 31) - 512 * (int64_t)d->Cout) return 0;
+  if (w.v_stride * 4 >= (1LL << 31) || w.m_stride >= (1LL << 31) - 512 * (int64_t)d->Cout) return 0;
   if ((int64_t)d->Cout * d->KW * d->Cin * 4 >= (1LL << 31)) return 0;
   return 1;
 }
@@ -362,7 +527,7 @@ extern "C" int ivx_conv_winograd_weights(const ivx_conv_desc *d, int32_t tile, c
 extern "C" int64_t ivx_conv_winograd_workspace_bytes(const ivx_conv_desc *d, int32_t tile) {
   WinoDims w;
   if (wino_dims(d, tile, &w, "ivx_conv_winograd_workspace_bytes") != IVX_OK) return -1;
-  return ivx_align_up(w.n2 * w.v_elems * 4, 256) + ivx_align_up(w.n2 * w.m_elems * 4, 256);
+  return ivx_align_up(w.n2 * w.v_stride * 4, 256) + ivx_align_up(w.n2 * w.m_stride * 4, 256);
 }
 
 namespace {
@@ -384,7 +549,8 @@ int wino_setup(const ivx_conv_desc *d, int tile, const void *in, const float *sc
   p->in = (const float *)in; p->scale = scale; p->shift = shift; p->res = d->res_mode ? (const float *)res : nullptr;
   p->out = (float *)out;
   p->V = (float *)workspace;
-  p->Mw = (float *)((char *)workspace + ivx_align_up(w->n2 * w->v_elems * 4, 256));
+  p->Mw = (float *)((char *)workspace + ivx_align_up(w->n2 * w->v_stride * 4, 256));
+  p->vs = w->v_stride; p->ms = w->m_stride;
   p->B = d->B; p->X = d->D; p->Y = d->H; p->Z = d->W; p->C = d->Cin;
   p->Xo = w->Xo; p->Yo = w->Yo; p->Zo = w->Zo; p->Co = d->Cout;
   p->TX = w->TX; p->TY = w->TY; p->px = d->pd; p->py = d->ph;
@@ -407,6 +573,8 @@ extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *d, int32_t tile, con
     hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wino_blocks(w.v_elems / 4)), dim3(256), 0, (hipStream_t)stream, p);
   else if (tile == 4)
     hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
+  else if (g_wino_in_variant == 1)
+    hipLaunchKernelGGL((wino_input_kernel<6, 1>), dim3(wino_blocks(w.v_elems)), dim3(256), 0, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL((wino_input_kernel<6, 2>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
   IVX_CHECK_LAUNCH("ivx_conv_winograd_input");
@@ -422,7 +590,7 @@ extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *d, int32_t tile, cons
   int rc = wino_setup(d, tile, &dummy, nullptr, nullptr, &dummy, &dummy, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_gemm");
   if (rc != IVX_OK) return rc;
   const ivx_conv_desc g = wino_group_desc(d, w);
-  rc = ivx_conv_grouped_launch(&g, w.n2, p.V, w.v_elems, u, (long long)d->Cout * d->KW * d->Cin, p.Mw, w.m_elems, (hipStream_t)stream);
+  rc = ivx_conv_grouped_launch(&g, w.n2, p.V, w.v_stride, u, (long long)d->Cout * d->KW * d->Cin, p.Mw, w.m_stride, (hipStream_t)stream);
   if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_winograd_gemm");
   return IVX_OK;
@@ -441,8 +609,20 @@ extern "C" int ivx_conv_winograd_output(const ivx_conv_desc *d, int32_t tile, co
     hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wino_blocks(w.m_elems / 4)), dim3(256), 0, (hipStream_t)stream, p);
   else if (tile == 4)
     hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
+  else {
+    const bool buf_ok = (int64_t)w.n2 * w.m_stride * 4 < (1LL << 32) && (int64_t)d->B * w.Xo * w.Yo * w.Zo * d->Cout * 4 < (1LL << 31);
+    int v = g_wino_out_variant >= 0 ? g_wino_out_variant : (d->res_mode ? 2 : 1);
+    if (v >= 2 && !buf_ok) v = 0;
+    const unsigned mb = (unsigned)((int64_t)w.n2 * w.m_stride * 4), ob = (unsigned)((int64_t)d->B * w.Xo * w.Yo * w.Zo * d->Cout * 4);
+    if (v == 2)
+      hipLaunchKernelGGL((wino_output_buf_kernel<2, 3>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p, mb, ob);
+    else if (v == 3)
+      hipLaunchKernelGGL((wino_output_buf_kernel<1, 5>), dim3(wino_blocks(w.m_elems)), dim3(256), 0, (hipStream_t)stream, p, mb, ob);
+    else if (v == 1)
+      hipLaunchKernelGGL((wino_output_kernel<6, 1>), dim3(wino_blocks(w.m_elems)), dim3(256), 0, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
+  }
   IVX_CHECK_LAUNCH("ivx_conv_winograd_output");
   return IVX_OK;
 }

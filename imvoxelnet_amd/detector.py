@@ -62,8 +62,8 @@ class ImVoxelNet(nn.Module):
 
     def prepare(self, device, dtype=torch.float32, native=None):
         """Pack every layer's parameters for the device kernels (call again after changing weights).
-        native (default: on unless IVX_NATIVE_MODEL=0): for the anchor-head families build the native model handle
-        (engine.NativeModel over csrc/model.cpp) and let simple_test run the whole device side through ONE C-ABI call;
+        native (default: on unless IVX_NATIVE_MODEL=0): build the native model handle (engine.NativeModel over csrc/model.cpp) for every
+        family it covers (engine.family) and let simple_test run the whole device side through ONE C-ABI call;
         the layer-by-layer composition below stays available (extract_feat, forward_cl, the other configurations).
         dtype: storage type of activations and weights between layers.  float32 (default) is the reference's precision
         and the one every parity claim is made for; bfloat16 is an optional reduced-precision mode (fp32 accumulate,
@@ -133,8 +133,8 @@ class ImVoxelNet(nn.Module):
         intrinsic = torch.tensor(img_meta['lidar2img']['intrinsic'][:3, :3])
         ratio = img_meta['ori_shape'][0] / (img_meta['img_shape'][0] / stride)
         if angles is not None:
-            from .heads_layout import get_extrinsics
-            extrinsics = [get_extrinsics(a).to(intrinsic.device) for a in angles]
+            from .heads_layout import layout_extrinsics
+            extrinsics = [layout_extrinsics(a).to(intrinsic.device) for a in angles]
         else:
             extrinsics = [torch.tensor(e) for e in img_meta['lidar2img']['extrinsic']]
         if intrinsic.dtype != torch.float32 or any(e.dtype != torch.float32 for e in extrinsics):
@@ -222,8 +222,21 @@ class ImVoxelNet(nn.Module):
             self.prepare(img.device)                             # first call: pack the weights (and build the native handle)
         H, W = img.shape[-2:]
         native_ok = self._native is not None and H % 32 == 0 and W % 32 == 0 and img.dtype == torch.float32
+        if native_ok and self._native.family == 'indoor':
+            # the whole of simple_test in ONE native call (ivx_model_detect): trunk [+ LayoutHead -> predicted angles -> projection]
+            # -> unprojection -> neck_3d -> anchor-free head -> per-level candidates -> cross-level NMS; camera set-up inside the library
+            out = self._native.detect(img.contiguous(), img_metas)
+            boxes, scores, labels, count = out[:4]
+            results = self._results_one_copy(boxes, scores, labels, count, img_metas, with_yaw=self.bbox_head.n_reg_outs == 7, indoor=True)
+            if self.head_2d is not None:                           # detectors/imvoxelnet.py:101-105
+                ang, lay = out[-1]
+                angles, layouts = self.head_2d.get_bboxes(list(ang), list(lay), img_metas)
+                for i in range(len(results)):
+                    results[i]['angles'] = angles[i]
+                    results[i]['layout'] = layouts[i]
+            return results
         if native_ok and self._native.family == 'levels':
-            # indoor families: extract_feat (trunk + unprojection + neck_3d) in one native call, the anchor-free head on the op-level ABI
+            # indoor necks with a head the handle does not hold: extract_feat in one native call, the head on the op-level ABI
             B, V = img.shape[0], img.shape[1]
             proj, new_origin, crop = self._camera_setup(img_metas, 4, img.device)
             levels, valid = self._native.forward_levels(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
@@ -265,19 +278,19 @@ class ImVoxelNet(nn.Module):
         return results
 
     @staticmethod
-    def _results_one_copy(boxes, scores, labels, count, img_metas):
+    def _results_one_copy(boxes, scores, labels, count, img_metas, with_yaw=True, indoor=False):
         """bbox3d2result (core/bbox/transforms.py:49-67) for the fixed-size padded device tensors of the anchor tail: ONE
         packed D2H copy for the whole batch instead of three copies (and syncs) per sample; the box objects are built
         on the host from it."""
-        from .boxes import LiDARInstance3DBoxes
+        from .boxes import LiDARInstance3DBoxes, DepthInstance3DBoxes
         from .dist import pack_detections, unpack_detections
         packed = pack_detections(boxes, scores, labels, count).cpu()         # the one sync of the step
         b, s, l, c = unpack_detections(packed, scores.shape[1])
         res = []
         for i, meta in enumerate(img_metas):
             n = int(c[i])
-            box_type = meta.get('box_type_3d', LiDARInstance3DBoxes)
-            res.append(dict(boxes_3d=box_type(b[i, :n], box_dim=7), scores_3d=s[i, :n].clone(), labels_3d=l[i, :n].clone()))
+            box_type = meta.get('box_type_3d', DepthInstance3DBoxes if indoor else LiDARInstance3DBoxes)
+            res.append(dict(boxes_3d=box_type(b[i, :n], box_dim=7, with_yaw=bool(with_yaw)), scores_3d=s[i, :n].clone(), labels_3d=l[i, :n].clone()))
         return res
 
     def simple_test_view_sharded(self, img, img_metas, group=None):

@@ -22,24 +22,41 @@ def _stream():
 
 
 def family(model):
-    """Which native handle covers this module: 'anchor' (plain ResNet-50 + FPN, Kitti / NuScenes stack neck, Anchor3DHead
-    with one anchor range: the whole simple_test device side), 'levels' (plain ResNet-50 + FPN + FastIndoorImVoxelNeck /
-    ImVoxelNeck, no LayoutHead: trunk + unprojection + neck_3d, the anchor-free head stays layer-by-layer), or None."""
+    """Which native handle covers this module, or None:
+      'anchor'  ResNet-50 (plain or DCNv2 stages) + FPN, Kitti / NuScenes stack neck, Anchor3DHead with one anchor range: the whole
+                simple_test device side (ivx_model_forward / ivx_model_detect);
+      'indoor'  ResNet-50 + FPN + FastIndoorImVoxelNeck / ImVoxelNeck + an anchor-free head without conv towers (n_convs = 0, every
+                reference config), optionally a LayoutHead: the whole simple_test (ivx_model_detect), or extract_feat alone
+                (ivx_model_forward_levels);
+      'levels'  the same necks with a head the handle does not hold (V1 heads with towers): trunk + unprojection + neck_3d only."""
     from .backbones import ResNet, FPN
     from .heads import Anchor3DHead
+    from .heads_indoor import _ImVoxelHeadBase
+    from .heads_layout import LayoutHead
     from .necks3d import KittiImVoxelNeck, NuScenesImVoxelNeck, FastIndoorImVoxelNeck, ImVoxelNeck
     bb = model.backbone
-    if not (isinstance(bb, ResNet) and isinstance(model.neck, FPN)) or model.head_2d is not None:
+    if not (isinstance(bb, ResNet) and isinstance(model.neck, FPN)):
         return None
-    if any(getattr(blk, 'dcn', False) for i in range(bb.num_stages) for blk in getattr(bb, f'layer{i + 1}')):
+    if model.head_2d is not None and not (isinstance(model.head_2d, LayoutHead) and model.head_2d.angle_mlp[0].weight.shape[1] == 2048):
         return None
     if bb.num_stages != 4 or [len(getattr(bb, f'layer{i + 1}')) for i in range(4)] != [3, 4, 6, 3] or tuple(bb.out_indices) != (0, 1, 2, 3):
         return None
     n3 = model.neck_3d
-    if isinstance(n3, FastIndoorImVoxelNeck):
-        return 'levels' if n3.n_scales == 3 else None
-    if isinstance(n3, ImVoxelNeck):
-        return 'levels' if len(n3.model.channels) in (3, 4) else None
+    if isinstance(n3, (FastIndoorImVoxelNeck, ImVoxelNeck)):
+        if isinstance(n3, FastIndoorImVoxelNeck) and n3.n_scales != 3:
+            return None
+        if isinstance(n3, ImVoxelNeck) and len(n3.model.channels) not in (3, 4):
+            return None
+        h = model.bbox_head
+        tc = getattr(h, 'test_cfg', None)
+        n_levels = 3 if isinstance(n3, FastIndoorImVoxelNeck) else len(n3.model.channels) - 1
+        ok = (isinstance(h, _ImVoxelHeadBase) and h.n_convs == 0 and tc is not None and 0 < int(tc.get('nms_pre', 0)) <= 4096
+              and h.n_scales >= n_levels and (h.n_reg_outs == 6 or h.n_classes <= 64))
+        if ok:
+            return 'indoor'
+        return 'levels' if model.head_2d is None else None
+    if model.head_2d is not None:
+        return None
     if not isinstance(n3, (KittiImVoxelNeck, NuScenesImVoxelNeck)) or not isinstance(model.bbox_head, Anchor3DHead):
         return None
     g = model.bbox_head.anchor_generator
@@ -57,14 +74,18 @@ def model_cfg(model, with_trunk=True, winograd=None, winograd_tile=None):
     from .necks3d import KittiImVoxelNeck, FastIndoorImVoxelNeck, BasicBlock3d
     fam = family(model)
     if fam is None:
-        raise NotImplementedError('the native model handle covers plain ResNet-50 + FPN with a Kitti / NuScenes neck + Anchor3DHead, or '
-                                  'with FastIndoorImVoxelNeck / ImVoxelNeck (no LayoutHead), fp32')
-    head, n3 = model.bbox_head, model.neck_3d
+        raise NotImplementedError('the native model handle covers ResNet-50 (+ DCNv2 stages) + FPN with a Kitti / NuScenes neck + Anchor3DHead, or '
+                                  'with FastIndoorImVoxelNeck / ImVoxelNeck + an anchor-free head without towers (+ LayoutHead), fp32')
+    head, n3, bb = model.bbox_head, model.neck_3d, model.backbone
     cfg = ModelCfg()
     cfg.with_trunk = int(bool(with_trunk))
     cfg.fpn_channels = model.neck.out_channels
     cfg.n_voxels[:] = list(model.n_voxels)
     cfg.voxel_size[:] = list(model.voxel_size)
+    if with_trunk:
+        cfg.dcn_stages[:] = [int(any(getattr(blk, 'dcn', False) for blk in getattr(bb, f'layer{i + 1}'))) for i in range(4)]
+        if model.head_2d is not None:
+            cfg.layout_head, cfg.layout_linear_size = 1, int(model.head_2d.angle_mlp[0].weight.shape[0])
     if fam == 'anchor':
         tc, g = head.test_cfg, head.anchor_generator
         cfg.neck_type = 0 if isinstance(n3, KittiImVoxelNeck) else 1
@@ -79,17 +100,25 @@ def model_cfg(model, with_trunk=True, winograd=None, winograd_tile=None):
         cfg.use_rotate_nms = int(bool(tc['use_rotate_nms']))
         cfg.score_thr, cfg.nms_thr = float(tc.get('score_thr', 0)), float(tc['nms_thr'])
         cfg.dir_offset, cfg.dir_limit_offset = float(head.dir_offset), float(head.dir_limit_offset)
-    elif isinstance(n3, FastIndoorImVoxelNeck):
-        cfg.neck_type = 2
-        cfg.neck_out_channels = n3.out_block_0[0].weight.shape[0]
-        cfg.fast_n_blocks[:] = [len(getattr(n3, f'down_layer_{i}')) for i in range(3)]
     else:
-        cfg.neck_type = 3
-        cfg.neck_out_channels = n3.conv_blocks[0][0].weight.shape[0]
-        pad = lambda v, n: list(v) + [0] * (n - len(v))        # a 3-scale U-Net leaves the last entries 0
-        cfg.unet_channels[:] = pad(n3.model.channels, 4)
-        cfg.unet_down_layers[:] = pad([sum(isinstance(b, BasicBlock3d) for b in layer) for layer in n3.model.layers_down], 4)
-        cfg.unet_up_layers[:] = pad([len(seq) for seq in n3.model.layers_up_res], 3)
+        if isinstance(n3, FastIndoorImVoxelNeck):
+            cfg.neck_type = 2
+            cfg.neck_out_channels = n3.out_block_0[0].weight.shape[0]
+            cfg.fast_n_blocks[:] = [len(getattr(n3, f'down_layer_{i}')) for i in range(3)]
+        else:
+            cfg.neck_type = 3
+            cfg.neck_out_channels = n3.conv_blocks[0][0].weight.shape[0]
+            pad = lambda v, n: list(v) + [0] * (n - len(v))        # a 3-scale U-Net leaves the last entries 0
+            cfg.unet_channels[:] = pad(n3.model.channels, 4)
+            cfg.unet_down_layers[:] = pad([sum(isinstance(b, BasicBlock3d) for b in layer) for layer in n3.model.layers_down], 4)
+            cfg.unet_up_layers[:] = pad([len(seq) for seq in n3.model.layers_up_res], 3)
+        if fam == 'indoor':
+            tc = head.test_cfg
+            cfg.head_type = 1 if head.n_reg_outs == 6 else 2
+            cfg.head_classes, cfg.head_nms_pre = int(head.n_classes), int(tc['nms_pre'])
+            cfg.head_score_thr = float(tc.get('score_thr', 0))
+            cfg.head_nms_thr = float(tc['iou_thr'] if head.n_reg_outs == 6 else tc['nms_thr'])
+            cfg.head_use_rotate_nms = int(bool(tc.get('use_rotate_nms', False)))
     cfg.winograd = int(FusedConv.winograd if winograd is None else winograd)
     cfg.winograd_tile = int(FusedConv.winograd_tile if winograd_tile is None else winograd_tile)
     return cfg
@@ -117,6 +146,8 @@ class NativeModel:
             raise NotImplementedError('graph replay is wired for ivx_model_forward (anchor-head families) only')
         if self.family != 'anchor':
             self.graph, cfg.use_graph = False, 0
+        self.has_head = self.family == 'anchor' or cfg.head_type != 0          # ivx_model_detect runs the whole simple_test
+        self.layout = bool(cfg.layout_head)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(L.ivx_create(C.byref(cfg), C.byref(h)), 'ivx_create')
@@ -211,6 +242,56 @@ class NativeModel:
                 call(xs, ps, os_, cs, out, C.c_void_p(self._gstream.cuda_stream))
             cur.wait_stream(self._gstream)
         return (out[0], out[1], out[2], out[3], out[4].view(torch.bool)) if want_valid else out[:4]
+
+    def detect(self, img, img_metas, want_valid=False):
+        """simple_test in ONE native call (ivx_model_detect), every family with a head: img [B,V,3,H,W] device tensor + the reference's
+        img_metas -> (boxes [B,M,7] rows of the box object's tensor, scores [B,M], labels int64 [B,M], count int32 [B]) device
+        tensors [+ valid bool [B,X,Y,Z]] [+ (angles [B,2], layouts [B,7]) host tensors with a LayoutHead].  The camera set-up is
+        computed inside the library from the metas' intrinsic / extrinsic / origin / img_shape / ori_shape."""
+        import numpy as np
+        from ._lib import SampleMeta
+        L = self.L
+        B, V, _, H, W = img.shape
+        x = img.reshape(B * V, 3, H, W)
+        if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32):
+            raise ValueError('img must be a contiguous float32 device tensor')
+        metas = (SampleMeta * B)()
+        keep = []
+        for b, meta in enumerate(img_metas):
+            K = np.zeros((4, 4), np.float32)
+            Ki = np.asarray(meta['lidar2img']['intrinsic'])
+            if Ki.dtype != np.float32:
+                raise TypeError('lidar2img intrinsic/extrinsic must be float32 (as the reference datasets produce)')
+            K[:Ki.shape[0], :Ki.shape[1]] = Ki
+            metas[b].intrinsic[:] = K.reshape(-1).tolist()
+            if not self.layout:
+                ex = list(meta['lidar2img']['extrinsic'])
+                if len(ex) != V or any(np.asarray(e).dtype != np.float32 for e in ex):
+                    raise ValueError('every sample needs V float32 extrinsics')
+                E = np.zeros((V, 4, 4), np.float32)
+                for v, e in enumerate(ex):
+                    e = np.asarray(e)
+                    E[v, :e.shape[0], :e.shape[1]] = e
+                keep.append(E)
+                metas[b].extrinsics = E.ctypes.data
+            metas[b].origin[:] = [float(v) for v in np.asarray(meta['lidar2img']['origin'], np.float32)]
+            metas[b].img_h, metas[b].img_w, metas[b].ori_h = int(meta['img_shape'][0]), int(meta['img_shape'][1]), int(meta['ori_shape'][0])
+        n = L.ivx_model_detect_workspace_bytes(self.h, B, V, H, W)
+        M = L.ivx_model_max_detections(self.h, B, V, H, W)
+        if n < 0 or M < 0:
+            check(-1, 'ivx_model_detect_workspace_bytes')
+        ws = self._workspace('fwd', n)
+        dev = x.device
+        out = (torch.empty((B, M, 7), device=dev, dtype=torch.float32), torch.empty((B, M), device=dev, dtype=torch.float32),
+               torch.empty((B, M), device=dev, dtype=torch.int64), torch.empty((B,), device=dev, dtype=torch.int32))
+        valid = torch.empty((B,) + self.n_voxels, device=dev, dtype=torch.uint8) if want_valid else None
+        ang = torch.empty((B, 2), dtype=torch.float32) if self.layout else None
+        lay = torch.empty((B, 7), dtype=torch.float32) if self.layout else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(L.ivx_model_detect(self.h, p(x), B, V, H, W, C.cast(metas, C.c_void_p), p(ws), ws.numel(), p(out[0]), p(out[1]), p(out[2]), p(out[3]),
+                                 p(valid), p(ang), p(lay), _stream()), 'ivx_model_detect')
+        res = out + ((valid.view(torch.bool),) if want_valid else ())
+        return res + ((ang, lay),) if self.layout else res
 
     def _level_buffers(self, B, dev):
         outs = [torch.empty((B, X, Y, Z, Cn), device=dev, dtype=torch.float32) for X, Y, Z, Cn in self.level_dims]

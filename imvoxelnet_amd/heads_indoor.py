@@ -15,7 +15,6 @@ from . import ops, _lib
 from .boxes import DepthInstance3DBoxes
 from .conv import FusedConv
 from .heads import bias_init_with_prob
-from .nms import aligned_3d_nms, box3d_multiclass_nms
 from .params import ConvParams, BNParams, ScaleParams, invalidate_packed_on_load
 from .registry import HEADS, ConfigDict
 
@@ -147,6 +146,18 @@ class _ImVoxelHeadBase(nn.Module):
     def get_bboxes_cl(self, fused, valid, img_metas, scales=None):
         return [self._nms(b, s, m) for (b, s), m in zip(self.get_candidates_cl(fused, valid, img_metas, scales), img_metas)]
 
+    def _nms(self, bboxes, scores, img_meta):
+        """The cross-level tail on the device (ivx_indoor_tail_get_bboxes) for ONE sample's concatenated candidates [K,R] / [K,ncls]:
+        ScanNet (imvoxel_head_v2.py:528-545): class maximum, score threshold, class-aware aligned 3-D NMS, corner -> centre / size;
+        SUN RGB-D (:397-417): BEV boxes, per-class rotated NMS, max_num = nms_pre.  One host round trip: the count."""
+        tc = self.test_cfg
+        sun = self.n_reg_outs == 7
+        b7, s, l, cnt = ops.indoor_tail([bboxes.unsqueeze(0).contiguous()], [scores.unsqueeze(0).contiguous()], self.n_classes, tc.score_thr,
+                                        tc.nms_thr if sun else tc.iou_thr, tc.use_rotate_nms if sun else False, tc.nms_pre if sun else None)
+        n = int(cnt[0])
+        box_type = img_meta.get('box_type_3d', DepthInstance3DBoxes)
+        return box_type(b7[0, :n], box_dim=7, with_yaw=sun), s[0, :n], l[0, :n]
+
     def get_bboxes(self, centernesses, bbox_preds, cls_scores, valid, img_metas):
         """Reference signature (inputs as returned by forward).  The decoded distances are fed back through the
         fused-layout tail with scale 1 (exp(log d) == d to 1 ulp)."""
@@ -158,30 +169,11 @@ class _ImVoxelHeadBase(nn.Module):
 
 
 class _ScanNetMixin:
-    def _nms(self, bboxes, scores, img_meta):
-        """imvoxel_head_v2.py:528-545: class maximum, score threshold, class-aware aligned 3-D NMS, corner -> centre/size."""
-        scores, labels = scores.max(dim=1)
-        ids = scores > self.test_cfg.score_thr
-        bboxes, scores, labels = bboxes[ids], scores[ids], labels[ids]
-        ids = aligned_3d_nms(bboxes, scores, labels, self.test_cfg.iou_thr)
-        bboxes = bboxes[ids]
-        bboxes = torch.stack(((bboxes[:, 0] + bboxes[:, 3]) / 2., (bboxes[:, 1] + bboxes[:, 4]) / 2.,
-                              (bboxes[:, 2] + bboxes[:, 5]) / 2., bboxes[:, 3] - bboxes[:, 0],
-                              bboxes[:, 4] - bboxes[:, 1], bboxes[:, 5] - bboxes[:, 2]), dim=1)
-        box_type = img_meta.get('box_type_3d', DepthInstance3DBoxes)
-        return box_type(bboxes, origin=(.5, .5, .5), box_dim=6, with_yaw=False), scores[ids], labels[ids]
+    """n_reg_outs 6: axis-aligned corner boxes, aligned 3-D NMS (the tail lives in _ImVoxelHeadBase._nms)."""
 
 
 class _SunRgbdMixin:
-    def _nms(self, bboxes, scores, img_meta):
-        """imvoxel_head_v2.py:397-417: per-class rotated BEV NMS, max_num = nms_pre."""
-        scores = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1)
-        for_nms = torch.stack((bboxes[:, 0] - bboxes[:, 3] / 2, bboxes[:, 1] - bboxes[:, 4] / 2,
-                               bboxes[:, 0] + bboxes[:, 3] / 2, bboxes[:, 1] + bboxes[:, 4] / 2, bboxes[:, 6]), dim=1)
-        bboxes, scores, labels, _ = box3d_multiclass_nms(bboxes, for_nms, scores, self.test_cfg.score_thr,
-                                                         self.test_cfg.nms_pre, self.test_cfg)
-        box_type = img_meta.get('box_type_3d', DepthInstance3DBoxes)
-        return box_type(bboxes, origin=(.5, .5, .5)), scores, labels
+    """n_reg_outs 7: rotated boxes, multi-class BEV NMS (the tail lives in _ImVoxelHeadBase._nms)."""
 
 
 @HEADS.register_module()

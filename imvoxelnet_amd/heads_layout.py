@@ -11,7 +11,6 @@ import torch
 from torch import nn
 
 from . import ops
-from .boxes import limit_period
 from .conv import FusedConv
 from .params import invalidate_packed_on_load
 from .registry import HEADS
@@ -80,8 +79,17 @@ class LayoutHead(nn.Module):
 
     @staticmethod
     def _forward_single(angle, layout, img_meta):
-        angle = limit_period(angle)                                   # layout_head.py:53
-        return angle, torch.cat((layout[:3], torch.exp(layout[3:6]), layout[6:7]))      # :54,:70-74
+        """layout_head.py:52-74: angle = limit_period(angle); layout = (centre, exp(size), yaw) -- through the library's host
+        function (ivx_layout_head_decode: fixed fp32 order, libm expf), so this host and the native model handle return the same
+        bits; the reference's torch ops (limit_period, torch.exp) agree with it to 1 ulp."""
+        import ctypes as C
+        from . import _lib
+        a = angle.detach().to('cpu', torch.float32).contiguous()
+        l_ = layout.detach().to('cpu', torch.float32).contiguous()
+        oa, ol = torch.empty(2), torch.empty(7)
+        _lib.check(_lib.lib().ivx_layout_head_decode(C.c_void_p(a.data_ptr()), C.c_void_p(l_.data_ptr()), C.c_void_p(oa.data_ptr()),
+                                                     C.c_void_p(ol.data_ptr())), 'ivx_layout_head_decode')
+        return oa, ol
 
     def get_bboxes(self, angles, layouts, img_metas):
         """layout_head.py:106-115: -> (angles, layout boxes of the sample's box type, gravity-centre origin)."""
@@ -90,6 +98,18 @@ class LayoutHead(nn.Module):
             out_a.append(angle.cpu())
             out_l.append(meta['box_type_3d'](layout.unsqueeze(0), origin=(.5, .5, .5)))
         return out_a, out_l
+
+
+def layout_extrinsics(angles):
+    """get_extrinsics through the library's host function (ivx_layout_extrinsics: the same products in a fixed order, libm cosf / sinf):
+    what the detector feeds the unprojection, on both hosts of the library.  Equal to get_extrinsics (the reference's torch ops) to 1 ulp
+    of the four trigonometric values."""
+    import ctypes as C
+    from . import _lib
+    a = angles.detach().to('cpu', torch.float32).contiguous()
+    e = torch.empty(4, 4)
+    _lib.check(_lib.lib().ivx_layout_extrinsics(C.c_void_p(a.data_ptr()), C.c_void_p(e.data_ptr())), 'ivx_layout_extrinsics')
+    return e
 
 
 def get_extrinsics(angles):

@@ -482,6 +482,40 @@ def multiclass_nms_bev(boxes, scores, num_classes, score_thr, nms_thr, rotated, 
     return idx, lab, cnt
 
 
+def indoor_tail(cand_boxes, cand_scores, n_classes, score_thr, nms_thr, use_rotate_nms=False, max_num=None):
+    """Cross-level tail of the anchor-free indoor heads (ivx_indoor_tail_get_bboxes): cand_boxes / cand_scores = per-level lists of
+    [B, k_l, R] / [B, k_l, n_classes] device tensors (R = 6 ScanNet corners, 7 SUN RGB-D boxes) -> (boxes [B,M,7] rows of the box
+    object's tensor (bottom-face z), scores [B,M], labels int64 [B,M], count int32 [B]); M = sum(k_l) for ScanNet, max_num (the
+    reference passes test_cfg.nms_pre) capped at sum(k_l) * n_classes for SUN RGB-D."""
+    from ._lib import IndoorTailDesc
+    L = _lib.lib()
+    B, R = cand_boxes[0].shape[0], cand_boxes[0].shape[2]
+    d = IndoorTailDesc()
+    d.B, d.n_levels, d.n_classes, d.n_reg = B, len(cand_boxes), int(n_classes), R
+    K = 0
+    for l, (cb, cs) in enumerate(zip(cand_boxes, cand_scores)):
+        _chk(cb, 'cand_boxes')
+        _chk(cs, 'cand_scores')
+        if cb.shape[0] != B or cs.shape[:2] != cb.shape[:2] or cs.shape[2] != n_classes or cb.shape[2] != R:
+            raise ValueError('candidate lists must be [B, k, R] / [B, k, n_classes] per level')
+        d.k[l] = cb.shape[1]
+        K += cb.shape[1]
+    M = K if R == 6 else max(1, min(int(max_num if max_num is not None else K), K * int(n_classes)))
+    d.use_rotate_nms, d.max_num, d.score_thr, d.nms_thr = int(bool(use_rotate_nms)), M, float(score_thr), float(nms_thr)
+    wsb = L.ivx_indoor_tail_workspace_bytes(C.byref(d))
+    if wsb < 0:
+        check(-1, 'ivx_indoor_tail_workspace_bytes')
+    dev = cand_boxes[0].device
+    ws = torch.empty((max(int(wsb), 256),), device=dev, dtype=torch.uint8)
+    boxes, scores = torch.empty((B, M, 7), device=dev, dtype=torch.float32), torch.empty((B, M), device=dev, dtype=torch.float32)
+    labels, count = torch.empty((B, M), device=dev, dtype=torch.int64), torch.empty((B,), device=dev, dtype=torch.int32)
+    pb = (C.c_void_p * 4)(*([t.data_ptr() for t in cand_boxes] + [None] * (4 - len(cand_boxes))))
+    ps = (C.c_void_p * 4)(*([t.data_ptr() for t in cand_scores] + [None] * (4 - len(cand_scores))))
+    check(L.ivx_indoor_tail_get_bboxes(C.byref(d), pb, ps, _ptr(ws), ws.numel(), _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(count), _stream()),
+          'ivx_indoor_tail_get_bboxes')
+    return boxes, scores, labels, count
+
+
 def boxes_overlap_bev(a, b, iou=False):
     _chk(a, 'a')
     _chk(b, 'b')

@@ -37,7 +37,7 @@ extern "C" {
 
 typedef void *ivx_stream_t; /* hipStream_t */
 
-/* Library version (major*10000 + minor*100 + patch; 200 = 0.2.0, the struct layouts of this header) and the message of
+/* Library version (major*10000 + minor*100 + patch; 300 = 0.3.0, the struct layouts of this header) and the message of
  * the last failing call on this thread (never NULL). */
 int ivx_version(void);
 const char *ivx_last_error(void);
@@ -137,6 +137,11 @@ int ivx_conv_winograd_fwd(const ivx_conv_desc *d, int32_t tile, const void *in, 
 /* Tuning knob for A/B experiments only (per calling thread): 0 = automatic tile choice (default); 1..7 force a tile
  * of the generic kernel, 41..53 of the LDS-DMA fp32 kernel, 61..73 of its bf16 instantiation. */
 int ivx_conv_set_tile_override(int cfg);
+/* Per calling thread, A/B only (tools/wino_ab.py): kernel of the F(6x6,3x3) output transform.  -1 = the library's rule (2 with a
+ * residual, 1 without); 0 whole 8x8 tile per thread, 2 channels per lane (the round-2 kernel); 1 the same with 1 channel per lane;
+ * 2 buffer addressing + column accumulation, 2 channels per lane; 3 the same with 1 channel per lane.  input_variant: -1 / 0 two
+ * channels per lane, 1 one channel per lane. */
+int ivx_conv_winograd_set_variant(int32_t output_variant, int32_t input_variant);
 /* Per calling thread, A/B only: 1 = one-channel-per-lane epilogue stores in the LDS-DMA conv kernel; 0 (default) = the
  * LDS-transposed epilogue (a lane stores 4 consecutive channels as one 16-byte word) wherever it applies. */
 int ivx_conv_set_epilogue_mode(int narrow);
@@ -283,6 +288,28 @@ int ivx_fcos_head_level_candidates(const float *head_out, const uint8_t *valid0,
                                    int32_t Y, int32_t Z, int32_t nms_pre, void *workspace, int64_t workspace_bytes,
                                    float *cand_boxes, float *cand_scores, int32_t *cand_count, ivx_stream_t stream);
 
+/* Cross-level tail of the anchor-free indoor heads: replaces the torch.cat over levels and `_nms` of
+ * ImVoxelHeadV2._get_bboxes_single (mmdet3d/models/dense_heads/imvoxel_head_v2.py:258-277; ScanNet _nms :528-545 = class
+ * maximum, score threshold, class-aware aligned_3d_nms, corners -> centre / size; SUN RGB-D _nms :397-417 = BEV boxes +
+ * box3d_multiclass_nms with max_num = nms_pre) for a batch, without a host round trip.
+ *   cand_boxes[l] [B, k[l], n_reg], cand_scores[l] [B, k[l], n_classes]   outputs of ivx_fcos_head_level_candidates per level
+ *   n_reg 6 (ScanNet): nms_thr = test_cfg.iou_thr, max_num >= sum(k) (nothing is cut); n_reg 7 (SUN RGB-D): nms_thr / use_rotate_nms
+ *   of test_cfg, max_num = test_cfg.nms_pre.
+ *   out_boxes [B, max_num, 7] = the rows of the returned box object's tensor (x, y, z of the BOTTOM face, dx, dy, dz, yaw; yaw 0 for
+ *   ScanNet) -- BaseInstance3DBoxes(origin=(.5,.5,.5)) applied (core/bbox/structures/base_box3d.py:63-66); out_scores, out_labels
+ *   int64 [B, max_num], out_count [B]; rows >= count are zero. */
+typedef struct ivx_indoor_tail_desc {
+  int32_t B, n_levels;
+  int32_t k[4];              /* candidates per level (min(nms_pre, level voxels)) */
+  int32_t n_classes, n_reg;
+  int32_t use_rotate_nms, max_num;
+  float score_thr, nms_thr;
+} ivx_indoor_tail_desc;
+int64_t ivx_indoor_tail_workspace_bytes(const ivx_indoor_tail_desc *d);
+int ivx_indoor_tail_get_bboxes(const ivx_indoor_tail_desc *d, const float *const *cand_boxes, const float *const *cand_scores,
+                               void *workspace, int64_t workspace_bytes, float *out_boxes, float *out_scores, int64_t *out_labels,
+                               int32_t *out_count, ivx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * BEV NMS -- device-side replacement of iou3d_cuda.nms_gpu / nms_normal_gpu
  * (mmdet3d/ops/iou3d/src/iou3d.cpp:95-201, iou3d_kernel.cu:284-396).  Same contract as the
@@ -387,6 +414,9 @@ int ivx_kitti_fused_statistics(const double *const *ov_ptrs, int32_t n_img, cons
 #define IVX_NECK_NUSCENES 1
 #define IVX_NECK_FAST 2      /* FastIndoorImVoxelNeck (necks/imvoxelnet.py:8-67): the handle ends at the 3 neck levels */
 #define IVX_NECK_UNET 3      /* ImVoxelNeck = Atlas EncoderDecoder + conv blocks (necks/imvoxelnet.py:70-91, 297-372) */
+#define IVX_HEAD_NONE 0
+#define IVX_HEAD_SCANNET 1
+#define IVX_HEAD_SUNRGBD 2
 typedef struct ivx_model ivx_model;
 typedef struct ivx_model_cfg {
   int32_t neck_type;          /* IVX_NECK_KITTI | IVX_NECK_NUSCENES | IVX_NECK_FAST | IVX_NECK_UNET */
@@ -413,6 +443,19 @@ typedef struct ivx_model_cfg {
   int32_t unet_channels[4];        /* ImVoxelNeck(channels); [0] = fpn_channels; [3] = 0: three scales (two output levels) */
   int32_t unet_down_layers[4];     /* ImVoxelNeck(n_blocks, "down"), e.g. 1,2,3,4 */
   int32_t unet_up_layers[3];       /* ImVoxelNeck(n_blocks, "up") in decode order (coarse first), e.g. 3,2,1 */
+  /* (0.3.0) the rest of the path inside the handle; all zero = the 0.2.0 behaviour */
+  int32_t head_type;               /* IVX_HEAD_NONE: the indoor handle ends at the neck levels | IVX_HEAD_SCANNET (n_reg 6: ScanNetImVoxelHead /
+                                      HeadV2, aligned 3-D NMS) | IVX_HEAD_SUNRGBD (n_reg 7: SunRgbdImVoxelHead / HeadV2, multi-class BEV NMS);
+                                      n_convs = 0 as in every reference config (dense_heads/imvoxel_head_v2.py, imvoxel_head.py) */
+  int32_t head_classes;            /* n_classes */
+  int32_t head_nms_pre;            /* test_cfg.nms_pre (candidates per level; also max_num of the SUN RGB-D NMS) */
+  int32_t head_use_rotate_nms;     /* SUN RGB-D test_cfg.use_rotate_nms */
+  float head_score_thr, head_nms_thr;   /* test_cfg.score_thr; iou_thr (ScanNet) / nms_thr (SUN RGB-D) */
+  int32_t dcn_stages[4];           /* ResNet stage_with_dcn: DCNv2 (ModulatedDeformConv2dPack, deform_groups 1) as conv2 of every bottleneck of
+                                      the stage (configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14); keys backbone.layerS.B.conv2.conv_offset.* */
+  int32_t layout_head;             /* 1: LayoutHead(n_channels 2048, linear_size) on C5 (SUN RGB-D Total configs, dense_heads/layout_head.py);
+                                      its predicted angles replace the extrinsics of the metas at test time; keys head_2d.{angle,layout}_mlp.* */
+  int32_t layout_linear_size;
 } ivx_model_cfg;
 
 int ivx_create(const ivx_model_cfg *cfg, ivx_model **out);
@@ -454,6 +497,34 @@ int ivx_neck3d_unet_fwd(ivx_model *m, const float *volume, int32_t B, float *con
 int ivx_model_forward_levels(ivx_model *m, const float *input, int32_t B, int32_t V, int32_t H, int32_t W, const float *proj,
                              const float *new_origin, const int32_t *crop_hw, void *workspace, int64_t workspace_bytes,
                              float *const out_levels[3], uint8_t *out_valid, ivx_stream_t stream);
+/* simple_test as ONE call for every family (detectors/imvoxelnet.py:93-106): image batch [B*V,3,H,W] (with_trunk = 0: the FPN level-0
+ * maps [B*V,1,H/4,W/4,Cf] channels-last) -> detections, the per-sample camera
+ * set-up of :114-129 / :139 / :67-68 included (computed on the host in the library's fixed fp32 order and uploaded into the
+ * workspace).  One ivx_sample_meta per sample = the fields of img_meta the path reads.
+ *   anchor families (KITTI / nuScenes, DCNv2 stages included): outputs as ivx_model_forward, max_num rows per sample
+ *   indoor families with head_type != 0: out_boxes [B, M, 7] rows of the returned box object's tensor (x, y, z of the bottom face,
+ *     dx, dy, dz, yaw), M = ivx_model_max_detections(...): ScanNet the total number of candidates (nothing is cut), SUN RGB-D nms_pre
+ *   LayoutHead (layout_head = 1, V = 1): the predicted (pitch, roll) replace metas[b].extrinsics (may be NULL); out_angles host [B,2],
+ *     out_layout host [B,7] (centre, exp(size), yaw) or NULL -- the forward synchronises the stream once to read them, as the
+ *     reference does.
+ * Asynchronous on `stream` otherwise; `metas` and what it points to are consumed before the call returns. */
+typedef struct ivx_sample_meta {
+  float intrinsic[16];         /* img_meta['lidar2img']['intrinsic'], 4x4 row-major (rows 0..2 x cols 0..2 are used) */
+  const float *extrinsics;     /* host [V,4,4] row-major: img_meta['lidar2img']['extrinsic'] */
+  float origin[3];             /* img_meta['lidar2img']['origin'] */
+  int32_t img_h, img_w;        /* img_meta['img_shape'][:2] (before padding to H x W) */
+  int32_t ori_h;               /* img_meta['ori_shape'][0] */
+} ivx_sample_meta;
+int64_t ivx_model_detect_workspace_bytes(ivx_model *m, int32_t B, int32_t V, int32_t H, int32_t W);
+int32_t ivx_model_max_detections(ivx_model *m, int32_t B, int32_t V, int32_t H, int32_t W);
+int ivx_model_detect(ivx_model *m, const float *img, int32_t B, int32_t V, int32_t H, int32_t W, const ivx_sample_meta *metas /*host [B]*/,
+                     void *workspace, int64_t workspace_bytes, float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_count,
+                     uint8_t *out_valid, float *out_angles /*host*/, float *out_layout /*host*/, ivx_stream_t stream);
+/* Host-only LayoutHead arithmetic in a fixed fp32 order (both hosts of the library use it): angle = limit_period(raw) and layout =
+ * (centre, exp(size), yaw) (layout_head.py:52-74); the camera extrinsic of detectors/imvoxelnet.py:164-187 from (pitch, roll). */
+int ivx_layout_head_decode(const float *angle_raw /*[2]*/, const float *layout_raw /*[7]*/, float *angle /*[2]*/, float *layout /*[7] or NULL*/);
+int ivx_layout_extrinsics(const float *angles /*[2]*/, float *extrinsic4x4);
+
 /* Optional stage timing (measurement only): while enabled, every launch group of the forward calls is bracketed by a pair
  * of HIP events on the caller's stream; the Winograd layers run as their three stages so each is timed.  stage: 0 direct
  * conv, 1 Winograd input transform, 2 grouped GEMM, 3 output transform, 4 unprojection, 5 anchor tail.  flops = FLOPs the

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE.  Build oracle/_cpuabi/libimvoxel_cpu.so: the model-level handle of the product (csrc/model.cpp, compiled
 UNCHANGED against the host-memory stand-in of the HIP runtime in oracle/cpu_abi/hip/) over the CPU restatement of the op-level
-entry points (cpu_ops.cpp + oracle/ivx_oracle.c), and tests/c/e2e_small_cpu: the same C host program as tests/c/e2e_small.c,
-linked against it.  Only tests/ use the result; the product loads csrc/libimvoxel_hip.so and has no CPU fallback."""
+entry points (cpu_ops.cpp + oracle/ivx_oracle.c), and tests/c/e2e_small_cpu / e2e_indoor_cpu: the same C host programs as
+tests/c/e2e_small.c / e2e_indoor.c, linked against it.  Only tests/ use the result; the product loads csrc/libimvoxel_hip.so and has no CPU fallback."""
 import os
 import subprocess
 
@@ -27,10 +27,11 @@ def build(force=False):
         subprocess.check_call(['gcc', '-O2', '-fPIC', '-std=c11', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', '-c', oracle_c, '-o', obj])
         subprocess.check_call(['g++', '-O3', '-mavx2', '-fPIC', '-shared', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', f'-I{HERE}'] + srcs +
                               [obj, '-o', LIB, '-lm', '-Wl,--no-undefined'])
-    c_src = os.path.join(ROOT, 'tests', 'c', 'e2e_small.c')
-    if force or _stale(EXE, [c_src, LIB]):
-        subprocess.check_call(['gcc', '-std=gnu11', '-O1', f'-I{HERE}', c_src, '-o', EXE, f'-L{OUT}', '-limvoxel_cpu', '-lm', f'-Wl,-rpath,{OUT}',
-                               '-Wl,-rpath,$ORIGIN/../../oracle/_cpuabi'])
+    for name in ('e2e_small', 'e2e_indoor'):         # the Python-free C hosts of tests/c, linked against the CPU restatement
+        c_src, exe = os.path.join(ROOT, 'tests', 'c', name + '.c'), os.path.join(ROOT, 'tests', 'c', name + '_cpu')
+        if force or _stale(exe, [c_src, LIB]):
+            subprocess.check_call(['gcc', '-std=gnu11', '-O1', f'-I{HERE}', c_src, '-o', exe, f'-L{OUT}', '-limvoxel_cpu', '-lm', f'-Wl,-rpath,{OUT}',
+                                   '-Wl,-rpath,$ORIGIN/../../oracle/_cpuabi'])
     return LIB, EXE
 
 

@@ -381,3 +381,255 @@ extern "C" int ivx_aligned_3d_nms(const float *boxes, const float *scores, const
   *num_out = n == 0 ? 0 : ivxo_aligned_3d_nms(boxes, scores, classes, order.data(), n, thresh, pick);
   return IVX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- general-N and fused NMS forms
+extern "C" int64_t ivx_aligned_3d_nms_workspace_bytes(int32_t n) { return n < 0 || n > 65536 ? -1 : 256; }
+
+extern "C" int ivx_aligned_3d_nms_ws(const float *boxes, const float *scores, const int64_t *classes, int32_t n, float thresh, void *, int64_t,
+                                     int64_t *pick, int32_t *num_out, ivx_stream_t) {
+  C_REQUIRE(n >= 0 && n <= 65536 && pick && num_out && (n == 0 || (boxes && scores && classes)), "ivx_aligned_3d_nms_ws: bad argument");
+  std::vector<int64_t> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return scores[a] < scores[c] || (scores[a] == scores[c] && a > c); });
+  *num_out = n == 0 ? 0 : ivxo_aligned_3d_nms(boxes, scores, classes, order.data(), n, thresh, pick);
+  return IVX_OK;
+}
+
+extern "C" int64_t ivx_multiclass_nms_workspace_bytes(int32_t n, int32_t num_classes) {
+  return (n < 0 || n > 65536 || num_classes < 1 || num_classes > 64) ? -1 : 256;
+}
+
+// box3d_multiclass_nms (core/post_processing/box3d_nms.py:8-88) as csrc/anchor_tail.hip ivx_multiclass_nms_bev orders it: per class
+// the candidates above score_thr by descending score (ties: lower index), greedy NMS, class-major concatenation, or -- beyond max_num --
+// the max_num best by score (ties: lower class, then earlier position).
+extern "C" int ivx_multiclass_nms_bev(const float *boxes, const float *scores, int32_t n, int32_t score_stride, int32_t num_classes, float score_thr,
+                                      float nms_thr, int32_t rotated, int32_t max_num, void *, int64_t, int64_t *out_idx, int64_t *out_label,
+                                      int32_t *out_count, ivx_stream_t) {
+  C_REQUIRE(n >= 0 && n <= 65536 && num_classes >= 1 && num_classes <= 64 && out_idx && out_label && out_count && max_num > 0 &&
+                score_stride >= num_classes,
+            "ivx_multiclass_nms_bev: bad argument");
+  struct Det { float s; int c, pos, idx; };
+  std::vector<Det> all;
+  for (int c = 0; c < num_classes; ++c) {
+    std::vector<int> cand;
+    for (int i = 0; i < n; ++i)
+      if (scores[(size_t)i * score_stride + c] > score_thr) cand.push_back(i);
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) {
+      const float sa = scores[(size_t)a * score_stride + c], sb = scores[(size_t)b * score_stride + c];
+      return sa > sb || (sa == sb && a < b);
+    });
+    const int m = (int)cand.size();
+    if (!m) continue;
+    std::vector<float> sorted((size_t)m * 5);
+    for (int j = 0; j < m; ++j) memcpy(&sorted[(size_t)j * 5], boxes + (size_t)cand[j] * 5, 5 * sizeof(float));
+    std::vector<int64_t> keep(m);
+    const int nk = rotated ? ivxo_nms_rotated_sorted(sorted.data(), m, nms_thr, keep.data()) : ivxo_nms_normal_sorted(sorted.data(), m, nms_thr, keep.data());
+    for (int j = 0; j < nk; ++j) all.push_back({scores[(size_t)cand[keep[j]] * score_stride + c], c, j, cand[keep[j]]});
+  }
+  if ((int)all.size() > max_num) {
+    std::stable_sort(all.begin(), all.end(), [](const Det &a, const Det &b) { return a.s > b.s; });   // class-major input: ties keep lower class first
+    all.resize(max_num);
+  }
+  for (size_t j = 0; j < all.size(); ++j) { out_idx[j] = all[j].idx; out_label[j] = all[j].c; }
+  *out_count = (int32_t)all.size();
+  return IVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- indoor heads (csrc/anchor_tail.hip)
+extern "C" int64_t ivx_fcos_head_workspace_bytes(int32_t B, int32_t n, int32_t nms_pre) {
+  if (B <= 0 || n <= 0) return -1;
+  const int k = (nms_pre > 0 && nms_pre < n) ? nms_pre : n;
+  return k > 4096 ? -1 : 256;
+}
+
+static inline float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ImVoxelHeadV2._get_bboxes_single per level (imvoxel_head_v2.py:245-277): as fcos_scores_kernel / topk / fcos_decode_kernel.
+extern "C" int ivx_fcos_head_level_candidates(const float *head_out, const uint8_t *valid0, const float *level_vs, const float *level_new_origin,
+                                              float scale, int32_t B, int32_t nx, int32_t ny, int32_t nz, int32_t CH, int32_t n_classes, int32_t n_reg,
+                                              int32_t level, int32_t X, int32_t Y, int32_t Z, int32_t nms_pre, void *, int64_t, float *cand_boxes,
+                                              float *cand_scores, int32_t *cand_count, ivx_stream_t) {
+  C_REQUIRE(head_out && valid0 && level_vs && level_new_origin && cand_boxes && cand_scores && cand_count, "ivx_fcos_head_level_candidates: null argument");
+  C_REQUIRE(B > 0 && nx > 0 && ny > 0 && nz > 0 && n_classes > 0 && (n_reg == 6 || n_reg == 7) && CH >= 1 + n_reg + n_classes &&
+                level >= 0 && level < 8 && (nx << level) == X && (ny << level) == Y && (nz << level) == Z,
+            "ivx_fcos_head_level_candidates: bad dims");
+  const int n = nx * ny * nz, k = (nms_pre > 0 && nms_pre < n) ? nms_pre : n;
+  C_REQUIRE(k <= 4096, "ivx_fcos_head_level_candidates: at most 4096 candidates per level (got %d)", k);
+  auto validf = [&](int b, int i) -> float {
+    const int iz = i % nz, t = i / nz, iy = t % ny, ix = t / ny;
+    const uint8_t *v = valid0 + (size_t)b * X * Y * Z;
+    if (level == 0) return v[((size_t)ix * Y + iy) * Z + iz] ? 1.0f : 0.0f;
+    const int h = (1 << (level - 1)) - 1, x0 = (ix << level) + h, y0 = (iy << level) + h, z0 = (iz << level) + h;
+    int cnt = 0;
+    for (int a = 0; a < 2; ++a)
+      for (int e = 0; e < 2; ++e)
+        for (int f = 0; f < 2; ++f) cnt += v[((size_t)(x0 + a) * Y + (y0 + e)) * Z + (z0 + f)] ? 1 : 0;
+    return cnt >= 5 ? 1.0f : 0.0f;
+  };
+  for (int b = 0; b < B; ++b) {
+    std::vector<float> key(n);
+#pragma omp parallel for
+    for (int i = 0; i < n; ++i) {
+      const float *row = head_out + ((size_t)b * n + i) * CH;
+      const float ctr = sigmoid_ref(row[0]), vf = validf(b, i);
+      float m = -1.0f;
+      for (int c = 0; c < n_classes; ++c) {
+        const float s = (sigmoid_ref(row[1 + n_reg + c]) * ctr) * vf;
+        m = s > m ? s : m;
+      }
+      key[i] = m;
+    }
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::partial_sort(order.begin(), order.begin() + k, order.end(), [&](int a, int c) { return key[a] > key[c] || (key[a] == key[c] && a < c); });
+    const float *vs = level_vs + b * 3, *no = level_new_origin + b * 3;
+    for (int j = 0; j < k; ++j) {
+      const int i = order[j], iz = i % nz, t = i / nz, iy = t % ny, ix = t / ny;
+      const float px = (float)ix * vs[0] + no[0], py = (float)iy * vs[1] + no[1], pz = (float)iz * vs[2] + no[2];
+      const float *row = head_out + ((size_t)b * n + i) * CH;
+      float d[6];
+      for (int q = 0; q < 6; ++q) d[q] = expf(row[1 + q] * scale);
+      float *ob = cand_boxes + ((size_t)b * k + j) * n_reg, *os = cand_scores + ((size_t)b * k + j) * n_classes;
+      if (n_reg == 6) {
+        ob[0] = px - d[0]; ob[1] = py - d[2]; ob[2] = pz - d[4];
+        ob[3] = px + d[1]; ob[4] = py + d[3]; ob[5] = pz + d[5];
+      } else {
+        const float alpha = row[1 + 6];
+        const float sx = (d[1] - d[0]) / 2, sy = (d[3] - d[2]) / 2, sz = (d[5] - d[4]) / 2;
+        const float c = cosf(alpha), s = sinf(alpha);
+        ob[0] = px + (sx * c + sy * s);
+        ob[1] = py + (-sx * s + sy * c);
+        ob[2] = pz + sz;
+        ob[3] = d[0] + d[1]; ob[4] = d[2] + d[3]; ob[5] = d[4] + d[5];
+        ob[6] = alpha;
+      }
+      const float ctr = sigmoid_ref(row[0]), vf = validf(b, i);
+      for (int c = 0; c < n_classes; ++c) os[c] = (sigmoid_ref(row[1 + n_reg + c]) * ctr) * vf;
+    }
+    cand_count[b] = k;
+  }
+  return IVX_OK;
+}
+
+extern "C" int64_t ivx_indoor_tail_workspace_bytes(const ivx_indoor_tail_desc *d) { return d ? 256 : -1; }
+
+// Cross-level tail (csrc/anchor_tail.hip ivx_indoor_tail_get_bboxes; imvoxel_head_v2.py:258-277, :528-545, :397-417).
+extern "C" int ivx_indoor_tail_get_bboxes(const ivx_indoor_tail_desc *d, const float *const *cand_boxes, const float *const *cand_scores, void *, int64_t,
+                                          float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_count, ivx_stream_t st) {
+  C_REQUIRE(d && cand_boxes && cand_scores && out_boxes && out_scores && out_labels && out_count, "ivx_indoor_tail_get_bboxes: null argument");
+  C_REQUIRE(d->B > 0 && d->n_levels >= 1 && d->n_levels <= 4 && d->n_classes >= 1 && (d->n_reg == 6 || d->n_reg == 7) && d->max_num > 0,
+            "ivx_indoor_tail: bad dims");
+  int K = 0;
+  for (int l = 0; l < d->n_levels; ++l) K += d->k[l];
+  const int R = d->n_reg, nc = d->n_classes, M = d->max_num;
+  for (int b = 0; b < d->B; ++b) {
+    std::vector<float> boxes((size_t)K * R), sc((size_t)K * nc);
+    int o = 0;
+    for (int l = 0; l < d->n_levels; ++l) {
+      memcpy(&boxes[(size_t)o * R], cand_boxes[l] + (size_t)b * d->k[l] * R, (size_t)d->k[l] * R * sizeof(float));
+      memcpy(&sc[(size_t)o * nc], cand_scores[l] + (size_t)b * d->k[l] * nc, (size_t)d->k[l] * nc * sizeof(float));
+      o += d->k[l];
+    }
+    float *ob = out_boxes + (size_t)b * M * 7, *os = out_scores + (size_t)b * M;
+    int64_t *ol = out_labels + (size_t)b * M;
+    memset(ob, 0, (size_t)M * 7 * sizeof(float));
+    memset(os, 0, (size_t)M * sizeof(float));
+    memset(ol, 0, (size_t)M * sizeof(int64_t));
+    int cnt = 0;
+    if (R == 6) {
+      std::vector<float> best(K), masked(K);
+      std::vector<int64_t> lab(K), pick(K);
+      for (int j = 0; j < K; ++j) {
+        float m = sc[(size_t)j * nc];
+        int c0 = 0;
+        for (int c = 1; c < nc; ++c)
+          if (sc[(size_t)j * nc + c] > m) { m = sc[(size_t)j * nc + c]; c0 = c; }
+        best[j] = m; lab[j] = c0;
+        masked[j] = m > d->score_thr ? m : -INFINITY;
+      }
+      int32_t np = 0;
+      int rc = ivx_aligned_3d_nms_ws(boxes.data(), masked.data(), lab.data(), K, d->nms_thr, nullptr, 0, pick.data(), &np, st);
+      if (rc != IVX_OK) return rc;
+      for (int j = 0; j < np && cnt < M; ++j) {
+        const int i = (int)pick[j];
+        if (!(best[i] > d->score_thr)) break;          // the real picks are a prefix
+        const float *c = &boxes[(size_t)i * 6];
+        const float dz = c[5] - c[2];
+        float *r = ob + (size_t)cnt * 7;
+        r[0] = (c[0] + c[3]) / 2.f; r[1] = (c[1] + c[4]) / 2.f; r[2] = (c[2] + c[5]) / 2.f + dz * -0.5f;
+        r[3] = c[3] - c[0]; r[4] = c[4] - c[1]; r[5] = dz; r[6] = 0.f;
+        os[cnt] = best[i]; ol[cnt] = lab[i];
+        ++cnt;
+      }
+    } else {
+      std::vector<float> bev((size_t)K * 5);
+      for (int j = 0; j < K; ++j) {
+        const float *s = &boxes[(size_t)j * 7];
+        float *v = &bev[(size_t)j * 5];
+        v[0] = s[0] - s[3] / 2.f; v[1] = s[1] - s[4] / 2.f; v[2] = s[0] + s[3] / 2.f; v[3] = s[1] + s[4] / 2.f; v[4] = s[6];
+      }
+      std::vector<int64_t> idx(M), lab(M);
+      int32_t n = 0;
+      int rc = ivx_multiclass_nms_bev(bev.data(), sc.data(), K, nc, nc, d->score_thr, d->nms_thr, d->use_rotate_nms, M, nullptr, 0, idx.data(), lab.data(), &n, st);
+      if (rc != IVX_OK) return rc;
+      for (int j = 0; j < n; ++j) {
+        const float *s = &boxes[(size_t)idx[j] * 7];
+        float *r = ob + (size_t)j * 7;
+        r[0] = s[0]; r[1] = s[1]; r[2] = s[2] + s[5] * -0.5f; r[3] = s[3]; r[4] = s[4]; r[5] = s[5]; r[6] = s[6];
+        os[j] = sc[(size_t)idx[j] * nc + lab[j]]; ol[j] = lab[j];
+      }
+      cnt = n;
+    }
+    out_count[b] = cnt;
+  }
+  return IVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- DCNv2 columns, global pool
+// csrc/dcn.hip dcn_im2col_kernel (mmcv ModulatedDeformConv2d, deform_groups 1): col[b,ho,wo,k,c] = sigmoid(m_k) * bilinear(x[..., c])
+extern "C" int ivx_dcn_im2col_fwd(const float *x, const float *offset_mask, int32_t B, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw,
+                                  int32_t stride, int32_t pad, int32_t dil, int32_t om_channels, float *col, ivx_stream_t) {
+  C_REQUIRE(x && offset_mask && col && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && kh > 0 && kw > 0 && stride > 0 && om_channels >= 3 * kh * kw,
+            "ivx_dcn_im2col_fwd: bad argument");
+  const int K = kh * kw, Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+#pragma omp parallel for collapse(2)
+  for (int b = 0; b < B; ++b)
+    for (int ho = 0; ho < Ho; ++ho)
+      for (int wo = 0; wo < Wo; ++wo) {
+        const float *om = offset_mask + (((size_t)b * Ho + ho) * Wo + wo) * om_channels;
+        for (int k = 0; k < K; ++k) {
+          const int i = k / kw, j = k % kw;
+          const float hh = (float)(ho * stride - pad + i * dil) + om[2 * k], ww = (float)(wo * stride - pad + j * dil) + om[2 * k + 1];
+          const float m = 1.0f / (1.0f + expf(-om[2 * K + k]));
+          float *dst = col + ((((size_t)b * Ho + ho) * Wo + wo) * K + k) * C;
+          if (!(hh > -1.0f && ww > -1.0f && hh < (float)H && ww < (float)W)) {
+            for (int c = 0; c < C; ++c) dst[c] = 0.f;
+            continue;
+          }
+          const int h0 = (int)floorf(hh), w0 = (int)floorf(ww), h1 = h0 + 1, w1 = w0 + 1;
+          const float lh = hh - (float)h0, lw = ww - (float)w0, uh = 1.0f - lh, uw = 1.0f - lw;
+          const float w00 = uh * uw, w01 = uh * lw, w10 = lh * uw, w11 = lh * lw;
+          const float *xb = x + (size_t)b * H * W * C;
+          for (int c = 0; c < C; ++c) {
+            const float v00 = (h0 >= 0 && w0 >= 0) ? xb[((size_t)h0 * W + w0) * C + c] : 0.f;
+            const float v01 = (h0 >= 0 && w1 <= W - 1) ? xb[((size_t)h0 * W + w1) * C + c] : 0.f;
+            const float v10 = (h1 <= H - 1 && w0 >= 0) ? xb[((size_t)h1 * W + w0) * C + c] : 0.f;
+            const float v11 = (h1 <= H - 1 && w1 <= W - 1) ? xb[((size_t)h1 * W + w1) * C + c] : 0.f;
+            dst[c] = (((w00 * v00 + w01 * v01) + w10 * v10) + w11 * v11) * m;
+          }
+        }
+      }
+  return IVX_OK;
+}
+
+// csrc/pool_layout.hip global_avgpool: in [B,S,C] -> out [B,C] (LayoutHead, layout_head.py:42)
+extern "C" int ivx_global_avgpool_fwd(const float *in, int32_t B, int64_t S, int32_t C, float *out, ivx_stream_t) {
+  C_REQUIRE(in && out && B > 0 && S > 0 && C > 0, "ivx_global_avgpool_fwd: bad argument");
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      double acc = 0.0;
+      for (int64_t s = 0; s < S; ++s) acc += in[((size_t)b * S + s) * C + c];
+      out[(size_t)b * C + c] = (float)(acc / (double)S);
+    }
+  return IVX_OK;
+}

@@ -18,7 +18,7 @@ def load():
     lib_path, _ = mod.build()
     L = C.CDLL(lib_path)
     L.ivx_last_error.restype = C.c_char_p
-    for f in ('ivx_model_workspace_bytes', 'ivx_neck3d_workspace_bytes'):
+    for f in ('ivx_model_workspace_bytes', 'ivx_neck3d_workspace_bytes', 'ivx_model_detect_workspace_bytes'):
         getattr(L, f).restype = C.c_int64
     return L
 
@@ -96,6 +96,46 @@ class CpuModel:
                                                  crop.ctypes.data_as(vp), vp(ws), C.c_int64(n), ptrs, valid.ctypes.data_as(vp), None),
                  'ivx_model_forward_levels')
         return outs, valid.astype(bool)
+
+    def detect(self, img, img_metas):
+        """simple_test through ivx_model_detect (every family with a head): img [B, V, 3, H, W] host array + the reference's img_metas ->
+        list of (boxes [n, 7], scores [n], labels [n]) [, (angles [B,2], layouts [B,7]) with a LayoutHead]; valid mask in self.last_valid."""
+        from imvoxelnet_amd._lib import SampleMeta
+        vp = C.c_void_p
+        x = np.ascontiguousarray(np.asarray(img, dtype=np.float32))
+        B, V, _, H, W = x.shape
+        metas, keep = (SampleMeta * B)(), []
+        layout = bool(self.cfg.layout_head)
+        for b, meta in enumerate(img_metas):
+            K = np.zeros((4, 4), np.float32)
+            Ki = np.asarray(meta['lidar2img']['intrinsic'], np.float32)
+            K[:Ki.shape[0], :Ki.shape[1]] = Ki
+            metas[b].intrinsic[:] = K.reshape(-1).tolist()
+            if not layout:
+                E = np.zeros((V, 4, 4), np.float32)
+                for v, e in enumerate(meta['lidar2img']['extrinsic']):
+                    e = np.asarray(e, np.float32)
+                    E[v, :e.shape[0], :e.shape[1]] = e
+                keep.append(E)
+                metas[b].extrinsics = E.ctypes.data
+            metas[b].origin[:] = [float(v) for v in np.asarray(meta['lidar2img']['origin'], np.float32)]
+            metas[b].img_h, metas[b].img_w, metas[b].ori_h = int(meta['img_shape'][0]), int(meta['img_shape'][1]), int(meta['ori_shape'][0])
+        n = self.L.ivx_model_detect_workspace_bytes(self.h, B, V, H, W)
+        M = self.L.ivx_model_max_detections(self.h, B, V, H, W)
+        if n < 0 or M < 0:
+            raise RuntimeError(self.L.ivx_last_error().decode())
+        raw = np.empty(n + 256, np.uint8)
+        ws = raw.ctypes.data + (-raw.ctypes.data % 256)
+        boxes, scores = np.empty((B, M, 7), np.float32), np.empty((B, M), np.float32)
+        labels, count = np.empty((B, M), np.int64), np.empty((B,), np.int32)
+        valid = np.empty((B,) + tuple(self.model.n_voxels), np.uint8)
+        ang, lay = np.zeros((B, 2), np.float32), np.zeros((B, 7), np.float32)
+        self._ok(self.L.ivx_model_detect(self.h, x.ctypes.data_as(vp), B, V, H, W, C.cast(metas, vp), vp(ws), C.c_int64(n), boxes.ctypes.data_as(vp),
+                                         scores.ctypes.data_as(vp), labels.ctypes.data_as(vp), count.ctypes.data_as(vp), valid.ctypes.data_as(vp),
+                                         ang.ctypes.data_as(vp) if layout else None, lay.ctypes.data_as(vp) if layout else None, None), 'ivx_model_detect')
+        self.last_valid = valid.astype(bool)
+        dets = [(boxes[b, :count[b]].copy(), scores[b, :count[b]].copy(), labels[b, :count[b]].copy()) for b in range(B)]
+        return (dets, (ang, lay)) if layout else dets
 
     def close(self):
         if self.h:

@@ -508,6 +508,85 @@ def gen_indoor_heads(ns):
     np.savez_compressed(os.path.join(GOLD, 'indoor_heads.npz'), **out)
 
 
+def gen_e2e_indoor(ns):
+    """Reference ImVoxelNet.simple_test end to end on the two INDOOR families (orchestration pin of the anchor-free path): the toy
+    stride-4 trunk of gen_e2e_small feeds the REAL extract_feat (multi-view unprojection, detectors/imvoxelnet.py:45-80) ->
+    FastIndoorImVoxelNeck -> ScanNetImVoxelHeadV2 / SunRgbdImVoxelHeadV2 forward + get_bboxes (aligned 3-D NMS / rotated multi-class
+    NMS) -> bbox3d2result.  The trunk's level-0 output is stored as the input of the handle (ivx_model_cfg.with_trunk = 0).
+    Written LAST by main() so the other fixtures' random streams are untouched."""
+    from torch import nn
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+    ns.nms.nms_gpu = orc.nms_gpu
+    ns.nms.nms_normal_gpu = orc.nms_normal_gpu
+    ns.head_v2.box3d_multiclass_nms = ns.nms.box3d_multiclass_nms
+    out = {}
+    cases = {
+        'scannet': ('ScanNetImVoxelHeadV2', dict(n_classes=5, n_channels=16, n_reg_outs=6, n_scales=3, limit=27, centerness_topk=18),
+                    dict(nms_pre=50, iou_thr=.25, score_thr=.01), 3, (0.0, 0.0, 0.5)),
+        'sunrgbd': ('SunRgbdImVoxelHeadV2', dict(n_classes=4, n_channels=16, n_reg_outs=7, n_scales=3, limit=27, centerness_topk=18),
+                    dict(nms_pre=50, nms_thr=.15, use_rotate_nms=True, score_thr=.0), 1, (0.0, 3.0, -1.0)),
+    }
+    n_voxels, vs = (16, 16, 8), (.16, .16, .16)
+    for name, (head_type, hkw, tcfg, V, origin) in cases.items():
+        torch.manual_seed({'scannet': 70, 'sunrgbd': 71}[name])
+
+        def super_init(self, pretrained=None):
+            return None
+        nn.Module.init_weights = super_init            # BaseDetector.init_weights stand-in (mmdet, logging only)
+        model = ns.detector.ImVoxelNet(
+            backbone=dict(type='ToyBackbone'), neck=dict(type='ToyFPN'),
+            neck_3d=dict(type='FastIndoorImVoxelNeck', in_channels=8, out_channels=16, n_blocks=[1, 1, 1]),
+            bbox_head=dict(type=head_type, **hkw), n_voxels=n_voxels, voxel_size=vs, train_cfg=None, test_cfg=Cfg(tcfg))
+        del nn.Module.init_weights
+        g = torch.Generator().manual_seed(72)
+        randomize_bn(model, g)
+        with torch.no_grad():
+            model.bbox_head.centerness_conv.weight.normal_(0, 0.1)
+            model.bbox_head.reg_conv.weight.normal_(0, 0.02)
+            model.bbox_head.cls_conv.weight.normal_(0, 0.1)
+            model.bbox_head.cls_conv.bias.fill_(-1.0)
+            for i, sc in enumerate(model.bbox_head.scales):
+                sc.scale.fill_(1.0 + 0.25 * i)
+        model.eval()
+        B, H, W = 2, 96, 128
+        img = torch.randn(B, V, 3, H, W, generator=g)
+        K = np.array([[70., 0, 63.5, 0], [0, 70., 47.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+        metas = []
+        for b in range(B):
+            E = [look_at((2.0 * np.cos(2 * np.pi * (i + 0.3 * b) / max(V, 3)) + origin[0], 2.0 * np.sin(2 * np.pi * (i + 0.3 * b) / max(V, 3)) + origin[1],
+                          origin[2] + 0.9), origin) for i in range(V)]
+            metas.append(dict(img_shape=(H - 8 * b, W - 12 * b, 3), ori_shape=((H - 8 * b) // 2, (W - 12 * b) // 2, 3),
+                              box_type_3d=ns.depth.DepthInstance3DBoxes,
+                              lidar2img=dict(intrinsic=K, extrinsic=E, origin=np.array(origin, np.float32))))
+        with torch.no_grad():
+            x, valids, _ = model.extract_feat(img, metas, 'test')
+            res = model.simple_test(img, metas)
+            f = model.backbone(img.reshape(-1, 3, H, W))
+            fpn0 = model.neck(f)[0]
+        pre = name + '::'
+        out.update(sd_to_np(model.state_dict(), pre + 'sd::'))
+        out.update({pre + 'fpn0': fpn0.numpy(), pre + 'valids': valids.numpy(), pre + 'n_voxels': np.array(n_voxels),
+                    pre + 'voxel_size': np.array(vs, np.float32), pre + 'test_cfg': np.array(json.dumps(tcfg)),
+                    pre + 'head_kw': np.array(json.dumps(hkw)), pre + 'views': np.array(V), pre + 'hw': np.array([H, W]),
+                    pre + 'nms_source': np.array('reference aligned_3d_nms' if hkw['n_reg_outs'] == 6 else 'oracle/ivx_oracle.c rotated NMS')})
+        for l in range(3):
+            out[pre + f'level{l}'] = x[l].numpy()
+        for b in range(B):
+            m = metas[b]
+            out[pre + f'meta{b}::img_shape'] = np.array(m['img_shape'])
+            out[pre + f'meta{b}::ori_shape'] = np.array(m['ori_shape'])
+            out[pre + f'meta{b}::intrinsic'] = m['lidar2img']['intrinsic']
+            out[pre + f'meta{b}::extrinsic'] = np.stack(m['lidar2img']['extrinsic'])
+            out[pre + f'meta{b}::origin'] = m['lidar2img']['origin']
+            out[pre + f'res{b}::boxes'] = res[b]['boxes_3d'].tensor.numpy()
+            out[pre + f'res{b}::scores'] = res[b]['scores_3d'].numpy()
+            out[pre + f'res{b}::labels'] = res[b]['labels_3d'].numpy()
+            print('e2e indoor', name, 'sample', b, 'valid frac', float(valids[b].float().mean()), 'dets', len(res[b]['scores_3d']))
+    np.savez_compressed(os.path.join(GOLD, 'e2e_indoor.npz'), **out)
+
+
 def gen_indoor_eval(ns):
     """Reference indoor_eval (core/evaluation/indoor_eval.py) on synthetic scenes.  Its 3-D IoU goes through
     BaseInstance3DBoxes.overlaps -> iou3d_cuda.boxes_overlap_bev_gpu (CUDA): the C restatement is injected and
@@ -948,6 +1027,7 @@ def main():
     gen_kitti_format(ns)
     gen_layout_head(ns)
     gen_input_side(ns)
+    gen_e2e_indoor(ns)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

@@ -33,7 +33,7 @@ def _cpu_sd(model):
     return {k: v.detach().cpu() for k, v in model.state_dict().items()}
 
 
-def _indoor_case(ia, cfg_name, V, head_seed=5):
+def _indoor_case(ia, cfg_name, V, head_seed=5, cls_gain=1.0, cls_bias=-2.0):
     """Model + inputs + the oracle's stage outputs and detections (torch-CPU fp32 / C restatement) of one indoor config."""
     from oracle import imvoxel_oracle as orc
     if cfg_name == 'scannet_fast':
@@ -49,8 +49,8 @@ def _indoor_case(ia, cfg_name, V, head_seed=5):
     ia.randomize_(model, 77 if cfg_name != 'scannet_v1' else 78)
     with torch.no_grad():
         g = torch.Generator().manual_seed(head_seed)
-        model.bbox_head.cls_conv.weight.normal_(0, w[0], generator=g)
-        model.bbox_head.cls_conv.bias.fill_(-2.0)
+        model.bbox_head.cls_conv.weight.normal_(0, w[0] * cls_gain, generator=g)
+        model.bbox_head.cls_conv.bias.fill_(cls_bias)
         model.bbox_head.centerness_conv.weight.normal_(0, w[1], generator=g)
         model.bbox_head.reg_conv.weight.normal_(0, w[2], generator=g)
     img = torch.randn(1, V, 3, 480, 640, generator=torch.Generator().manual_seed(13))
@@ -260,6 +260,10 @@ if __name__ == '__main__':           # tools-style use on the GPU box: print the
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import imvoxelnet_amd as _ia
-    case = _indoor_case(_ia, 'scannet_v1', int(sys.argv[1]) if len(sys.argv) > 1 else 50)
-    for mode in ('bf16', 'bf16+fp8conv', 'bf16+fp8storage'):
-        print(json.dumps(measure_config5(_ia, case, mode)))
+    V = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    for gain, bias in [(float(a.split(',')[0]), float(a.split(',')[1])) for a in (sys.argv[2:] or ['1,-2'])]:
+        case = _indoor_case(_ia, 'scannet_v1', V, cls_gain=gain, cls_bias=bias)
+        for mode in ('bf16', 'bf16+fp8conv', 'bf16+fp8storage'):
+            m = measure_config5(_ia, case, mode)
+            m['head'] = (gain, bias)
+            print(json.dumps(m))

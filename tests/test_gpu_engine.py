@@ -189,6 +189,75 @@ def test_c_program_e2e_small_without_python(ia):
     assert 'C e2e_small OK' in out.stdout
 
 
+def test_c_program_e2e_indoor_without_python(ia):
+    """tests/c/e2e_indoor.c: a C host (no Python in the process) drives ivx_create / ivx_weights_load / ivx_model_detect on the
+    reference's end-to-end INDOOR golden cases (ScanNet head + aligned NMS, SUN RGB-D head + rotated multi-class NMS; camera set-up
+    inside the library) and checks detections and valid masks against the reference's outputs."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'c'))
+    import build as cbuild
+    exe = cbuild.build('e2e_indoor')
+    fx = os.path.join(ROOT, 'tests', 'golden', 'e2e_indoor.bin')
+    out = subprocess.run([exe, fx], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'C e2e_indoor OK' in out.stdout
+
+
+@pytest.mark.parametrize('cfg_name,views', [('scannet_fast', 5), ('sunrgbd_fast', 1), ('scannet_v1', 4), ('sunrgbd_total', 1), ('nuscenes_dcn', 6)])
+def test_native_detect_equals_layerwise(ia, cfg_name, views):
+    """The WHOLE of simple_test inside the native handle (round 3): the anchor-free heads + per-level candidates + cross-level NMS
+    (ScanNet fast / SUN RGB-D fast / ScanNet v1), the LayoutHead with its predicted angles feeding the unprojection (SUN RGB-D Total),
+    and the DCNv2 trunk stages (the reference nuScenes backbone) -- one C-ABI call (ivx_model_detect / ivx_model_forward) against the
+    layer-by-layer Python composition over the op-level ABI: identical detections bit for bit."""
+    total = cfg_name == 'sunrgbd_total'
+    if cfg_name == 'nuscenes_dcn':
+        mcfg, tcfg = kc.nuscenes_model_cfg(dcn=True), dict(kc.NUSCENES_TEST_CFG)
+        hw, metas = (928, 1600), [kc.nuscenes_meta(box_type=ia.LiDARInstance3DBoxes)]
+    else:
+        base = 'sunrgbd_fast' if total else cfg_name
+        mcfg, tcfg = getattr(kc, f'{base}_model_cfg')(), dict(getattr(kc, f'{base.upper()}_TEST_CFG'))
+        if total:
+            mcfg['head_2d'] = dict(type='LayoutHead', n_channels=2048, linear_size=256, dropout=0.0)
+        hw = (480, 640)
+        metas = [kc.indoor_meta(views, img_hw=hw, origin=(0, 3, -1) if base == 'sunrgbd_fast' else (0, 0, .5), box_type=ia.DepthInstance3DBoxes)]
+    model = ia.build_detector(mcfg, test_cfg=tcfg)
+    ia.randomize_(model, 33)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        if cfg_name == 'nuscenes_dcn':
+            for name, m in model.backbone.named_modules():
+                if name.endswith('conv_offset'):
+                    m.weight.normal_(0, 0.02, generator=g)
+                    m.bias.normal_(0, 0.5, generator=g)
+            model.bbox_head.conv_cls.weight.normal_(0, 0.02, generator=g)
+            model.bbox_head.conv_cls.bias.fill_(-2.0)
+            model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=g)
+        else:
+            model.bbox_head.cls_conv.weight.normal_(0, 0.01, generator=g)
+            model.bbox_head.cls_conv.bias.fill_(-2.0)
+            model.bbox_head.centerness_conv.weight.normal_(0, 0.005, generator=g)
+            model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
+            for i, sc in enumerate(model.bbox_head.scales):
+                sc.scale.fill_(1.0 + 0.125 * i)
+            if total:                                       # predicted (pitch, roll) near a pose that sees the volume
+                model.head_2d.angle_mlp[6].weight.mul_(0.02)
+                model.head_2d.angle_mlp[6].bias.copy_(torch.tensor([-0.26, 0.43]))
+    img = torch.randn(1, views, 3, *hw, generator=torch.Generator().manual_seed(9)).cuda()
+    model.prepare(torch.device('cuda'), native=False)
+    ref = model.simple_test(img, metas)                       # layer by layer over the op-level ABI
+    model.prepare(torch.device('cuda'))
+    assert model._native is not None and model._native.family == ('anchor' if cfg_name == 'nuscenes_dcn' else 'indoor')
+    res = model.simple_test(img, metas)                       # one native call
+    assert len(res) == len(ref) == 1 and len(ref[0]['scores_3d']) > 5
+    for a, b in zip(res, ref):
+        assert torch.equal(a['scores_3d'], b['scores_3d']) and torch.equal(a['labels_3d'], b['labels_3d'])
+        assert torch.equal(a['boxes_3d'].tensor, b['boxes_3d'].tensor)
+        assert a['boxes_3d'].with_yaw == b['boxes_3d'].with_yaw and type(a['boxes_3d']) is type(b['boxes_3d'])
+        if total:
+            assert torch.equal(a['angles'], b['angles']) and torch.equal(a['layout'].tensor, b['layout'].tensor)
+    print(cfg_name, 'detections', len(res[0]['scores_3d']))
+
+
 @pytest.mark.parametrize('cfg_name,views', [('scannet_fast', 5), ('sunrgbd_fast', 1), ('scannet_v1', 4)])
 def test_native_levels_equal_layerwise_indoor(ia, cfg_name, views):
     """Indoor families on the handle (IVX_NECK_FAST / IVX_NECK_UNET): ivx_model_forward_levels == features_2d_cl -> lift_cl
@@ -205,7 +274,7 @@ def test_native_levels_equal_layerwise_indoor(ia, cfg_name, views):
         model.bbox_head.centerness_conv.weight.normal_(0, 0.005, generator=g)
         model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)       # keeps exp(reg) finite: NaN != NaN would fail torch.equal
     model.prepare(torch.device('cuda'))
-    assert model._native is not None and model._native.family == 'levels'
+    assert model._native is not None and model._native.family == 'indoor'
     B, hw = 1, (480, 640)
     img = torch.randn(B, views, 3, *hw, generator=torch.Generator().manual_seed(9)).cuda()
     box_type = ia.DepthInstance3DBoxes

@@ -1077,7 +1077,8 @@ def test_nms_general_n_vs_oracle(ia, n):
         wh = torch.rand(m, 2, generator=g) * 3 + 0.5
         boxes = torch.cat([ctr - wh / 2, ctr + wh / 2, (torch.rand(m, 1, generator=g) - 0.5) * 6], 1)
         scores = torch.rand(m, generator=g)
-        scores[::7] = scores[3::7][:len(scores[::7])]                 # ties: equal scores at different indices
+        k7 = len(scores[3::7])
+        scores[0:7 * k7:7] = scores[3::7]                             # ties: equal scores at different indices
         for rot in (True, False):
             keep = (ia.nms_gpu if rot else ia.nms_normal_gpu)(boxes.cuda(), scores.cuda(), 0.1)
             order_dev = scores.cuda().sort(0, descending=True)[1].cpu()    # nms_gpu sorts with torch on the device, as the reference

@@ -613,10 +613,11 @@ def test_indoor_handle_expects_the_reference_state_dict_keys(cfg_name):
     import kitti_cfg as kc
     from imvoxelnet_amd import _lib, engine
     model = ia.build_detector(getattr(kc, f'{cfg_name}_model_cfg')(), test_cfg=dict(getattr(kc, f'{cfg_name.upper()}_TEST_CFG')))
-    assert engine.family(model) == 'levels'
+    assert engine.family(model) == 'indoor'             # trunk + unprojection + neck + the anchor-free head and its tail
     sd = {k: v for k, v in model.state_dict().items() if v.dtype.is_floating_point}
     neck_keys = sorted(k for k in sd if k.startswith('neck_3d.'))
-    withheld = {neck_keys[0], neck_keys[len(neck_keys) // 2], neck_keys[-1], 'backbone.layer3.4.bn2.running_var', 'neck.lateral_convs.2.conv.bias'}
+    withheld = {neck_keys[0], neck_keys[len(neck_keys) // 2], neck_keys[-1], 'backbone.layer3.4.bn2.running_var', 'neck.lateral_convs.2.conv.bias',
+                'bbox_head.reg_conv.weight', 'bbox_head.cls_conv.bias'}
     # build the cfg the way engine.NativeModel does, without touching the device
     L = _lib.lib()
     cfg = engine.model_cfg(model, with_trunk=True)
@@ -875,6 +876,43 @@ def test_c_host_program_runs_the_e2e_golden_on_the_cpu_abi():
     assert 'C e2e_small OK' in r.stdout and 'no Python involved' in r.stdout
 
 
+def test_c_host_program_runs_the_indoor_e2e_golden_on_the_cpu_abi():
+    """tests/c/e2e_indoor.c -- the Python-free host of ivx_model_detect -- linked against libimvoxel_cpu.so: the reference's own
+    end-to-end ScanNet (3 views, aligned NMS) and SUN RGB-D (rotated multi-class NMS) cases (tests/golden/e2e_indoor.npz, generated by
+    oracle/gen_golden.py::gen_e2e_indoor from the imported reference's simple_test): detections within the program's 1e-5 / 1e-3 bars,
+    valid masks exact, camera set-up computed inside the library from the metas."""
+    import subprocess
+    _cpu_abi()
+    exe = os.path.join(ROOT, 'tests', 'c', 'e2e_indoor_cpu')
+    r = subprocess.run([exe, os.path.join(ROOT, 'tests', 'golden', 'e2e_indoor.bin')], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'C e2e_indoor OK' in r.stdout and 'no Python involved' in r.stdout
+
+
+def test_c_fixtures_are_reencodings_of_the_golden_npz():
+    """tests/golden/e2e_{small,indoor}.bin hold exactly the arrays of the .npz files (tools/make_c_fixture.py is a pure re-encoding)."""
+    import struct
+    for name in ('e2e_small', 'e2e_indoor'):
+        g = load_npz(name + '.npz')
+        with open(os.path.join(ROOT, 'tests', 'golden', name + '.bin'), 'rb') as f:
+            assert f.read(8) == b'IVXF0001'
+            n, = struct.unpack('<i', f.read(4))
+            seen = 0
+            for _ in range(n):
+                ln, = struct.unpack('<i', f.read(4))
+                key = f.read(ln).decode()
+                code, nd = struct.unpack('<ii', f.read(8))
+                shape = struct.unpack('<%dq' % nd, f.read(8 * nd))
+                dt = [np.float32, np.int64, np.uint8][code]
+                a = np.frombuffer(f.read(int(np.prod(shape, dtype=np.int64)) * np.dtype(dt).itemsize), dt).reshape(shape)
+                if key in g.files:
+                    ref = g[key]
+                    ref = ref.astype(np.float32) if ref.dtype == np.float64 else ref.astype(np.uint8) if ref.dtype == np.bool_ else ref
+                    assert np.array_equal(a.reshape(-1), ref.reshape(-1)) and a.size == ref.size, key      # (0-d arrays are stored as 1 element)
+                    seen += 1
+            assert seen >= 60 and f.read(1) == b''
+
+
 @pytest.mark.parametrize('name', ['kitti', 'nuscenes', 'fast', 'atlas'])
 def test_cpu_abi_necks_vs_reference_golden(name):
     """The four neck builders of csrc/model.cpp through the C-ABI on the CPU restatement (ivx_create, the golden's state dict
@@ -1043,6 +1081,177 @@ def test_cpu_abi_indoor_extract_feat_matches_the_oracle_port(cfg_name):
         r = r.numpy().transpose(0, 2, 3, 4, 1)
         assert a.shape == r.shape, (l, a.shape, r.shape)
         assert float(np.abs(a - r).max()) <= 2e-4 * float(np.abs(r).max()), (l, float(np.abs(a - r).max()), float(np.abs(r).max()))
+
+
+def _load_cpu_host():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ivx_cpu_abi_host', os.path.join(ROOT, 'oracle', 'cpu_abi', 'host.py'))
+    host = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(host)
+    return host
+
+
+@pytest.mark.parametrize('cfg_name', ['scannet_fast', 'sunrgbd_fast', 'scannet_v1'])
+def test_cpu_abi_indoor_detect_matches_the_oracle_port(cfg_name):
+    """ivx_model_detect on the CPU restatement -- the WHOLE indoor simple_test as csrc/model.cpp builds it (trunk, host camera set-up
+    inside the library, multi-view unprojection, neck, the anchor-free head as one fused conv per level, per-level candidates with the
+    head's Scale parameters, cross-level aligned / multi-class NMS, bottom-face box rows) -- against the oracle's port of the
+    reference chain on a small case: same number of detections, same labels, boxes / scores to 1e-4."""
+    import imvoxelnet_amd as ia
+    import kitti_cfg as kc
+    from oracle import imvoxel_oracle as orc
+    host = _load_cpu_host()
+    mcfg = getattr(kc, f'{cfg_name}_model_cfg')()
+    mcfg['n_voxels'] = (16, 16, 8)
+    tcfg = dict(getattr(kc, f'{cfg_name.upper()}_TEST_CFG'), nms_pre=60)
+    model = ia.build_detector(mcfg, test_cfg=tcfg)
+    ia.randomize_(model, 23)
+    n_reg = model.bbox_head.n_reg_outs
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        model.bbox_head.cls_conv.weight.normal_(0, 0.01, generator=g)
+        model.bbox_head.cls_conv.bias.fill_(-1.0)
+        model.bbox_head.centerness_conv.weight.normal_(0, 0.005, generator=g)
+        model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
+        for i, sc in enumerate(model.bbox_head.scales):
+            sc.scale.fill_(1.0 + 0.25 * i)                  # non-trivial Scale parameters: the handle must read them
+    V, hw = (1 if cfg_name == 'sunrgbd_fast' else 2), (64, 96)
+    img = torch.randn(1, V, 3, *hw, generator=torch.Generator().manual_seed(6))
+    meta = kc.indoor_meta(V, img_hw=hw, origin=(0, 3, -1) if cfg_name == 'sunrgbd_fast' else (0, 0, .5))
+    meta['lidar2img']['intrinsic'] = meta['lidar2img']['intrinsic'].copy()
+    meta['lidar2img']['intrinsic'][:2] *= hw[0] / 480.0
+    cm = host.CpuModel(model)
+    try:
+        assert cm.family == 'indoor'
+        (boxes, scores, labels), = cm.detect(img, [meta])
+        valid = cm.last_valid
+    finally:
+        cm.close()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        f0 = orc.fpn_level0(orc.resnet50(img[0], sd), sd)
+        vol, ok = orc.extract_volume(f0.numpy(), meta, mcfg['n_voxels'], mcfg['voxel_size'])
+        sdn = {k[len('neck_3d.'):]: v for k, v in sd.items() if k.startswith('neck_3d.')}
+        sdh = {k[len('bbox_head.'):]: v for k, v in sd.items() if k.startswith('bbox_head.')}
+        nk = mcfg['neck_3d']
+        if cfg_name == 'scannet_v1':
+            lv = orc.atlas_neck(torch.from_numpy(vol)[None], sdn, nk['channels'], nk['down_layers'], nk['up_layers'])
+            cs, bs, ss = orc.fcos_head_forward(lv, sdh, n_reg, n_convs=0)
+        else:
+            lv = orc.fast_indoor_neck(torch.from_numpy(vol)[None], sdn, tuple(nk['n_blocks']))
+            cs, bs, ss = orc.fcos_head_forward(lv, sdh, n_reg)
+        rb, rs, rl = orc.fcos_get_bboxes_single([c[0] for c in cs], [b[0] for b in bs], [s[0] for s in ss], torch.from_numpy(ok).float(),
+                                                meta['lidar2img']['origin'], mcfg['voxel_size'], n_reg, tcfg)
+    assert np.array_equal(valid[0], ok.reshape(valid[0].shape).astype(bool))
+    print(cfg_name, 'detections', len(scores), 'oracle', len(rs))
+    assert len(scores) == len(rs) and len(rs) >= 5
+    # same detections; the ORDER may differ among scores that agree to ~1e-6 (two fp32 summation orders), so rows are paired by box
+    d = (np.abs(boxes[:, None, :] - rb.numpy()[None, :, :]) / (1.0 + np.abs(rb.numpy()[None, :, :]))).max(-1) + 10.0 * (labels[:, None] != rl.numpy()[None, :])
+    j = d.argmin(1)
+    assert len(set(j.tolist())) == len(j), 'two detections pair with the same oracle detection'
+    assert float(d.min(1).max()) <= 1e-4, float(d.min(1).max())
+    assert np.allclose(scores, rs.numpy()[j], rtol=1e-4, atol=1e-6)
+    assert np.all(np.diff(scores) <= 1e-6) or model.bbox_head.n_reg_outs == 7      # ScanNet: descending score (SUN RGB-D: class-major)
+
+
+def test_cpu_abi_dcn_trunk_and_layout_head_in_the_handle():
+    """The two trunk extras inside the native handle, on the CPU restatement.  (1) nuScenes with DCNv2 stages 3-4
+    (ModulatedDeformConv2dPack as conv_offset conv + ivx_dcn_im2col_fwd + 1x1 over 9*C): the FPN level-0 map of ivx_backbone_fpn_fwd
+    against the oracle's torch restatement of DCNv2 (mmcv is absent: parity unpinned, as for the layer-wise path).  (2) SUN RGB-D Total:
+    LayoutHead -> predicted angles -> projection inside ivx_model_detect: angles / layout against the oracle-free closed form (pool + MLPs
+    in torch on the oracle's C5), and detections equal to a detect() of the same model WITHOUT the head but with the extrinsics built
+    from those angles."""
+    import copy
+    import ctypes as C
+    import imvoxelnet_amd as ia
+    import kitti_cfg as kc
+    from oracle import imvoxel_oracle as orc
+    host = _load_cpu_host()
+    # (1) DCN trunk
+    mcfg = kc.nuscenes_model_cfg(n_voxels=(16, 16, 12), dcn=True)
+    model = ia.build_detector(mcfg, test_cfg=dict(kc.NUSCENES_TEST_CFG))
+    ia.randomize_(model, 31)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(9)
+        for name, m in model.backbone.named_modules():
+            if name.endswith('conv_offset'):
+                m.weight.normal_(0, 0.02, generator=g)
+                m.bias.normal_(0, 0.5, generator=g)
+    img = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(3))
+    cm = host.CpuModel(model)
+    try:
+        assert cm.family == 'anchor' and list(cm.cfg.dcn_stages) == [0, 0, 1, 1]
+        vp = C.c_void_p
+        x = np.ascontiguousarray(img.numpy())
+        n = cm.L.ivx_backbone_fpn_workspace_bytes(cm.h, 2, 64, 96)
+        assert n > 0, cm.L.ivx_last_error()
+        raw = np.empty(n + 256, np.uint8)
+        ws = raw.ctypes.data + (-raw.ctypes.data % 256)
+        fpn0 = np.empty((2, 1, 16, 24, 64), np.float32)
+        cm._ok(cm.L.ivx_backbone_fpn_fwd(cm.h, x.ctypes.data_as(vp), 2, 64, 96, fpn0.ctypes.data_as(vp), vp(ws), C.c_int64(n), None), 'ivx_backbone_fpn_fwd')
+    finally:
+        cm.close()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.fpn_level0(orc.resnet50(img, sd), sd).numpy()
+    got = fpn0[:, 0].transpose(0, 3, 1, 2)
+    assert float(np.abs(got - ref).max()) <= 2e-4 * float(np.abs(ref).max()), (float(np.abs(got - ref).max()), float(np.abs(ref).max()))
+    # (2) LayoutHead
+    cfg = kc.sunrgbd_fast_model_cfg()
+    cfg['n_voxels'] = (16, 16, 8)
+    cfg['head_2d'] = dict(type='LayoutHead', n_channels=2048, linear_size=32, dropout=0.0)
+    tcfg = dict(kc.SUNRGBD_FAST_TEST_CFG, nms_pre=60)
+    torch.manual_seed(1234)                       # the LayoutHead's Linear layers are initialised from the global generator
+    total = ia.build_detector(cfg, test_cfg=tcfg)
+    ia.randomize_(total, 5)
+    with torch.no_grad():
+        total.bbox_head.cls_conv.bias.fill_(-1.0)
+        total.head_2d.angle_mlp[6].weight.mul_(0.02)          # predicted (pitch, roll) near a pose that sees the volume
+        total.head_2d.angle_mlp[6].bias.copy_(torch.tensor([-0.26, 0.43]))
+    hw = (64, 96)
+    meta = kc.indoor_meta(1, img_hw=hw, origin=(0, 3, -1))
+    meta['lidar2img']['intrinsic'] = meta['lidar2img']['intrinsic'].copy()
+    meta['lidar2img']['intrinsic'][:2] *= hw[0] / 480.0
+    img = torch.randn(1, 1, 3, *hw, generator=torch.Generator().manual_seed(8))
+    cm = host.CpuModel(total)
+    try:
+        assert cm.family == 'indoor' and cm.cfg.layout_head == 1
+        dets, (ang, lay) = cm.detect(img, [meta])
+    finally:
+        cm.close()
+    sd = {k: v.detach().cpu() for k, v in total.state_dict().items()}
+    with torch.no_grad():
+        c5 = orc.resnet50(img[0], sd)[-1]
+        pooled = c5.mean(dim=(2, 3))
+        def mlp(name, x):
+            for i in (0, 3, 6):
+                x = torch.nn.functional.linear(x, sd[f'head_2d.{name}.{i}.weight'], sd[f'head_2d.{name}.{i}.bias'])
+                if i != 6:
+                    x = torch.relu(x)
+            return x
+        a_ref = ia.limit_period(mlp('angle_mlp', pooled))[0]
+        l_raw = mlp('layout_mlp', pooled)[0]
+        l_ref = torch.cat((l_raw[:3], torch.exp(l_raw[3:6]), l_raw[6:7]))
+    assert np.allclose(ang[0], a_ref.numpy(), rtol=1e-4, atol=1e-5) and np.allclose(lay[0], l_ref.numpy(), rtol=1e-4, atol=1e-5)
+    # the same network without the LayoutHead, fed the extrinsic the library builds from the predicted angles: identical detections
+    plain_cfg = copy.deepcopy(cfg)
+    del plain_cfg['head_2d']
+    plain = ia.build_detector(plain_cfg, test_cfg=tcfg)
+    plain.load_state_dict({k: v for k, v in total.state_dict().items() if not k.startswith('head_2d.')})
+    from imvoxelnet_amd.heads_layout import layout_extrinsics
+    meta2 = copy.deepcopy(meta)
+    meta2['lidar2img']['extrinsic'] = [layout_extrinsics(torch.from_numpy(ang[0])).numpy()]
+    cm = host.CpuModel(plain)
+    try:
+        (b2, s2, l2), = cm.detect(img, [meta2])
+    finally:
+        cm.close()
+    (b1, s1, l1), = dets
+    print('layout head: angles', ang[0], 'detections', len(s1), 'plain model with those extrinsics', len(s2))
+    assert len(s1) == len(s2) >= 3 and np.array_equal(b1, b2) and np.array_equal(s1, s2) and np.array_equal(l1, l2)
+    # and ivx_layout_extrinsics against the reference's get_extrinsics (torch ops): equal to an ulp of the trigonometric values
+    e_lib, e_ref = layout_extrinsics(torch.from_numpy(ang[0])), ia.get_extrinsics(torch.from_numpy(ang[0]))
+    assert torch.allclose(e_lib, e_ref, rtol=0, atol=2e-7), (e_lib - e_ref).abs().max()
 
 
 def test_cpu_abi_stage_trace_levels():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""tests/golden/e2e_small.npz -> tests/golden/e2e_small.bin, a flat little-endian container a C program can read without
-zip / npy parsing (tests/c/e2e_small.c).  Pure re-encoding of the golden vectors (inputs + the reference's outputs); the
-JSON test_cfg string is expanded into scalar entries.
+"""tests/golden/e2e_small.npz -> e2e_small.bin and e2e_indoor.npz -> e2e_indoor.bin: flat little-endian containers a C program can
+read without zip / npy parsing (tests/c/e2e_small.c, tests/c/e2e_indoor.c).  Pure re-encoding of the golden vectors (inputs + the
+reference's outputs); the JSON test_cfg / head_kw strings are expanded into scalar entries.
 
   file   := magic "IVXF0001" | int32 n_entries | entry*
   entry  := int32 name_len | name bytes | int32 dtype (0 f32, 1 i64, 2 u8) | int32 ndim | int64 shape[ndim] | data
@@ -16,22 +16,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main():
-    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'e2e_small.npz'), allow_pickle=False)
+def convert(name):
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'), allow_pickle=False)
     ent = []
     for k in g.files:
         a = g[k]
         if a.dtype.kind == 'U':
-            if k == 'test_cfg':
+            if k.endswith('test_cfg') or k.endswith('head_kw'):
                 for ck, cv in json.loads(str(a)).items():
-                    ent.append(('test_cfg::' + ck, np.asarray([float(cv)], np.float32)))
+                    if isinstance(cv, (int, float, bool)):
+                        ent.append((k + '::' + ck, np.asarray([float(cv)], np.float32)))
             continue
         if a.dtype == np.float64:
             a = a.astype(np.float32)
         if a.dtype == np.bool_:
             a = a.astype(np.uint8)
         ent.append((k, np.ascontiguousarray(a)))
-    out = os.path.join(ROOT, 'tests', 'golden', 'e2e_small.bin')
+    out = os.path.join(ROOT, 'tests', 'golden', name + '.bin')
     with open(out, 'wb') as f:
         f.write(b'IVXF0001')
         f.write(struct.pack('<i', len(ent)))
@@ -42,6 +43,11 @@ def main():
             f.write(struct.pack('<%dq' % a.ndim, *a.shape))
             f.write(a.tobytes())
     print(out, os.path.getsize(out), 'bytes,', len(ent), 'entries')
+
+
+def main():
+    for name in (sys.argv[1:] or ['e2e_small', 'e2e_indoor']):
+        convert(name)
 
 
 if __name__ == '__main__':
