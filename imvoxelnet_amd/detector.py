@@ -245,8 +245,11 @@ class ImVoxelNet(nn.Module):
         if native_ok:
             # the whole device side in one native call (csrc/model.cpp); host work: the camera set-up, as the reference
             B, V = img.shape[0], img.shape[1]
-            proj, new_origin, crop = self._camera_setup(img_metas, 4, img.device)
-            boxes, scores, labels, count = self._native.forward(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
+            if self._native.graph:          # hipGraph replay keeps the camera set-up in caller-owned static buffers
+                proj, new_origin, crop = self._camera_setup(img_metas, 4, img.device)
+                boxes, scores, labels, count = self._native.forward(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
+            else:                           # camera set-up inside the library too (ivx_model_detect): one H2D of the camera block
+                boxes, scores, labels, count = self._native.detect(img.contiguous(), img_metas)
             if gather:
                 from .dist import all_gather_detections, is_collecting_rank
                 boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)

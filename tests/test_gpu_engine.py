@@ -79,8 +79,8 @@ def test_native_model_equals_layerwise_kitti(ia, shape):
 
 
 def test_native_model_nuscenes_plain_resnet(ia):
-    """NuScenesImVoxelNeck family (6 views, dir_offset pi/4, nms_pre 1000) on the handle; the reference's DCNv2 backbone is
-    outside it (engine.eligible) and keeps the layer-by-layer path."""
+    """NuScenesImVoxelNeck family (6 views, dir_offset pi/4, nms_pre 1000) on the handle with the plain ResNet-50 (the reference's
+    DCNv2 backbone on the handle: test_native_detect_equals_layerwise[nuscenes_dcn])."""
     from imvoxelnet_amd import engine
     cfg = kc.nuscenes_model_cfg(n_voxels=(104, 104, 12), dcn=False)
     model = ia.build_detector(cfg, test_cfg=kc.NUSCENES_TEST_CFG)
@@ -105,7 +105,7 @@ def test_native_model_nuscenes_plain_resnet(ia):
     _assert_same_detections(out[:4], ref)
     assert torch.equal(out[4], valid) and 0.05 < float(valid.float().mean()) < 1.0
     dcn_model = ia.build_detector(kc.nuscenes_model_cfg(n_voxels=(104, 104, 12)), test_cfg=kc.NUSCENES_TEST_CFG)
-    assert not engine.eligible(dcn_model)
+    assert engine.family(dcn_model) == 'anchor' and list(engine.model_cfg(dcn_model).dcn_stages) == [0, 0, 1, 1]   # round 3: DCNv2 stages inside the handle
 
 
 def test_native_model_trace_and_errors(ia):
@@ -435,3 +435,21 @@ def test_native_handle_necks_vs_reference_golden(ia, name):
             assert_close(f'{name} native neck level {i}', y.contiguous().cpu().numpy(), g[f'{name}::y{i}'], 1e-3, 1e-4)
     finally:
         L.ivx_destroy(h)
+
+
+def test_bench_rccl_path_at_world_size_1(ia):
+    """bench.py under the driver's launcher with IVX_BENCH_FORCE_DIST=1: the process group is RCCL ('nccl'), every timed step runs
+    simple_test(gather=True) -> all_gather_into_tensor of the padded detections, and the JSON line carries the self-checks of the
+    N > 1 line (rccl_ranks from an actual all-reduce, per-rank ms) -- so the collective path executes on the GPU box every round even
+    though the box has one GPU."""
+    import json
+    env = dict(os.environ, IVX_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29533',
+           os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 1 and rec['config']['rccl_ranks'] == 1 and len(rec['config']['ms_per_step_by_rank']) == 1
+    assert rec['config']['collective'] and rec['value'] > 50 and rec['config']['detections_last_step'] > 0
+    assert rec['roofline']['frac'] > 0.5 and rec['measured_ceilings']['hbm_copy_gbps'] > 3000

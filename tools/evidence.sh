@@ -10,7 +10,7 @@ python bench.py --steps 20 --warmup 5 2>$OUT/bench.err | tail -1 > $OUT/bench_de
 python bench.py --steps 20 --warmup 5 --api composed --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_composed.json
 python bench.py --steps 20 --warmup 5 --graph --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_graph.json
 IVX_NARROW_EPILOGUE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_narrow_epilogue.json
-IVX_PIPE_CHUNKS=2 python bench.py --steps 20 --warmup 5 --api composed --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_pipelined.json
+IVX_NATIVE_GRAPH=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_native_graph.json
 python bench.py --steps 10 --warmup 3 --storage bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_bf16.json
 IVX_WINOGRAD=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_direct.json
 IVX_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
@@ -18,8 +18,9 @@ IVX_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-no
 for c in nuscenes sunrgbd_fast scannet_fast scannet_v1 lift_nuscenes lift_scannet; do python bench.py --config $c --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT/other.jsonl; done
 for c in scannet_v1 scannet_fast sunrgbd_fast; do python bench.py --config $c --storage bf16 --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl; done
 for c in scannet_v1 scannet_fast; do python bench.py --config $c --storage bf16 --trunk-fp8 --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl; done
-python tools/fp8_noise.py 2>/dev/null > $OUT/fp8_noise.log
-python tools/fp8_mfma_precision.py 2>/dev/null > $OUT/fp8_mfma_precision.log
+for c in scannet_v1 scannet_fast; do python bench.py --config $c --storage bf16 --trunk-fp8 --fp8-residual fp8 --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl; done
+python bench.py --config scannet_fast --views 20 --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT/other.jsonl
+python tools/wino_ab.py > $OUT/wino_ab.log 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $ROOT/$OUT/trace_bench.log 2>&1)
 grep '^{"metric' $OUT/trace_bench.log | tail -1 > $OUT/bench_profiled.json
 DB=$(find $OUT/trace -name "*.db" | head -1)
@@ -29,12 +30,8 @@ find $OUT/trace -name "*stats*.csv" | head -3 | while read f; do cp $f $OUT/; do
 DB=$(find $OUT/trace_scannet -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/kernel_trace_scannet_fast.md
 grep '^{"metric' $OUT/trace_scannet.log | tail -1 > $OUT/bench_profiled_scannet_fast.json
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace_v1bf16 -o t -- python $ROOT/bench.py --config scannet_v1 --storage bf16 --steps 3 --warmup 1 > $ROOT/$OUT/trace_v1bf16.log 2>&1)
-DB=$(find $OUT/trace_v1bf16 -name "*.db" | head -1)
-[ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/kernel_trace_scannet_v1_bf16.md
-for d in f32 bf16 fp8; do python tools/trunk_layers.py --config scannet_v1 --dtype $d --top 40 > $OUT/trunk_layers_scannet_v1_$d.md 2>/dev/null; done
+python tools/trunk_layers.py --config scannet_v1 --dtype f32 --top 40 > $OUT/trunk_layers_scannet_v1_f32.md 2>/dev/null
 python tools/trunk_layers.py --config kitti --top 40 > $OUT/trunk_layers_kitti.md 2>/dev/null
-python tools/trunk_ab.py > $OUT/trunk_ab.log 2>/dev/null
 bash tools/pmc_bench.sh $OUT/pmc > $OUT/pmc.log 2>&1
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.5 --json $OUT/pmc.json > $OUT/pmc.md
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.1 --match wino_ --json $OUT/pmc_wino.json > $OUT/pmc_wino.md
