@@ -233,8 +233,8 @@ def _control_run(ia, case, level_noise, seed=0):
 CONFIG5_BOUNDS = {
     #                    fpn0    volume  level0  level1  level2  cand_recall  id recall  box recall
     'bf16':             (0.010,  0.006,  0.012,  0.010,  0.010,  0.90,        0.70,      0.80),
-    'bf16+fp8conv':     (0.048,  0.028,  0.028,  0.026,  0.020,  0.80,        0.62,      0.80),
-    'bf16+fp8storage':  (0.125,  0.053,  0.052,  0.038,  0.035,  0.65,        0.35,      0.50),
+    'bf16+fp8conv':     (0.048,  0.028,  0.028,  0.026,  0.020,  0.88,        0.62,      0.80),
+    'bf16+fp8storage':  (0.125,  0.053,  0.052,  0.038,  0.035,  0.80,        0.35,      0.50),
 }
 
 
