@@ -328,6 +328,7 @@ def main():
     ap.add_argument('--graph', action='store_true',
                     help='replay the device side of the step as one captured hipGraph (kitti config); the roofline entry is then '
                          'taken from the eager warm-up steps, which run the same kernels with HIP events around the neck')
+    ap.add_argument('--graph-backend', default=None, choices=['native', 'torch'], help="--graph: 'native' (default) = hipGraph replay inside the native handle; 'torch' = torch.cuda.CUDAGraph of the layer-by-layer composition (A/B; fragile against later device allocations)")
     ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
                     help='f32 (default) = the reference precision and the headline metric; bf16 = optional reduced-precision '
                          'storage mode (kitti only), reported with dtype "bf16" and priced against the bf16 MFMA peak')
@@ -453,7 +454,7 @@ def main():
     if args.graph:
         if args.warmup < 1:
             raise SystemExit('--graph needs at least one eager warm-up step (the roofline entry is measured there)')
-        graphed = model.capture_graph(img, metas)
+        graphed = model.capture_graph(img, metas, backend=args.graph_backend)
 
         def step(i):   # noqa: F811  -- same work, one graph launch
             boxes, scores, labels, count = graphed.replay_device(img, metas)
@@ -572,7 +573,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'data': 'synthetic',
             'config': {'workload': 'kitti_mono_1x3x384x1280_vox216x248x12_resnet50_fpn64_kittineck_anchor3dhead',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'hip_graph': bool(args.graph),
-                       'api': 'hipGraph replay' if args.graph else ('ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages'),
+                       'api': ('hipGraph replay (%s)' % type(graphed).__name__) if args.graph else ('ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages'),
                        'device_side': ('native model handle (ivx_model_forward%s)' % (', hipGraph replay per shape' if model._native.graph else '')) if model._native is not None and args.api == 'simple_test' else 'layer-by-layer over the op-level C-ABI',
                        'stage_events': ('event-record nodes inside the replayed graph, read for the last timed step' if (native_trace and model._native.graph) else 'HIP event pairs around every launch of every timed step'),
                        'detections_last_step': n_det(last), 'rccl_ranks': rccl_ranks, 'ms_per_step_by_rank': rank_ms,

@@ -1017,6 +1017,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         // LayoutHead._forward_single (layout_head.py:52-74) + the projection from the PREDICTED angles (detectors/imvoxelnet.py:59-61,
         // 121-124, 164-187).  The one place where the forward returns to the host: 9 numbers per sample, as in the reference (its
         // extrinsics are built from `angles` with CPU ops).
+        if (!bd.metas && r.s1 == m->trunk1) break;      // ivx_backbone_fpn_fwd: the FPN map does not depend on the LayoutHead
         M_REQUIRE(bd.metas && bd.proj_dev, "%s: a handle with a LayoutHead runs through ivx_model_detect (the projection is built from its angles)", who);
         const int B = in.B;
         std::vector<float> a((size_t)B * 2), l((size_t)B * 7), pj((size_t)B * 12);

@@ -310,15 +310,24 @@ class ImVoxelNet(nn.Module):
             dets = self.detect_indoor_cl(volume, valid, img_metas)
         return [bbox3d2result(b, s, l) for b, s, l in dets]
 
-    def capture_graph(self, img, img_metas, warmup=2):
-        """Capture the device side of simple_test for this input shape as ONE hipGraph (anchor-head configs): every
-        launch from the layout change of the image to the NMS tail is recorded once on a capture stream and replayed
-        per batch, so a step costs one graph launch instead of ~150 kernel launches issued from Python.  The
-        captured region contains no host synchronisation: the camera parameters live in static device buffers
-        refreshed by small H2D copies before the replay, the result tensors are static too, and the only sync is the
-        packed D2H of the detections afterwards.  Returns a GraphedSimpleTest callable (img, img_metas) -> results."""
+    def capture_graph(self, img, img_metas, warmup=2, backend=None):
+        """Capture the device side of simple_test for this input shape as ONE hipGraph (anchor-head configs) and return a callable
+        (img, img_metas) -> results that replays it: a step costs one graph launch instead of ~150 kernel launches.  The captured
+        region contains no host synchronisation: the camera parameters live in static device buffers refreshed by small H2D copies
+        before the replay, the result tensors are static too, and the only sync is the packed D2H of the detections afterwards.
+        backend 'native' (default where the native handle covers the model): hipGraph replay inside the library
+        (ivx_model_cfg.use_graph: first call eager, second captured, then one hipGraphLaunch per call) -- NativeGraphedSimpleTest;
+        'torch': a torch.cuda.CUDAGraph of the layer-by-layer composition -- GraphedSimpleTest (A/B).
+        CAVEAT (both backends, this ROCm stack): a replay can return garbage after a later fresh device allocation of a few
+        hundred MB by the process (tools/graph_fragility.py; not root-caused) -- allocate everything before capturing.  Eager
+        execution, the default, is not affected."""
         if not isinstance(self.bbox_head, Anchor3DHead):
-            raise NotImplementedError('graph capture is built for the anchor-head configs (the indoor tails loop on the host)')
+            raise NotImplementedError('graph capture is built for the anchor-head configs')
+        from . import engine
+        if backend is None:
+            backend = 'native' if (engine.family(self) == 'anchor' and self.storage_dtype in (None, torch.float32)) else 'torch'
+        if backend == 'native':
+            return NativeGraphedSimpleTest(self, img, img_metas, warmup)
         return GraphedSimpleTest(self, img, img_metas, warmup)
 
     def forward_test(self, img, img_metas, **kwargs):
@@ -336,8 +345,37 @@ class ImVoxelNet(nn.Module):
         pass
 
 
+class NativeGraphedSimpleTest:
+    """hipGraph replay of ImVoxelNet.simple_test inside the native model handle (ivx_model_forward with use_graph) for a fixed input
+    shape: a second handle with the graph option on, its own static buffers and stream (engine.NativeModel graph mode)."""
+
+    def __init__(self, model, img, img_metas, warmup=2):
+        from . import engine
+        if model._prepared_device is None:
+            model.prepare(img.device)
+        self.model = model
+        self.native = engine.NativeModel(model, img.device, graph=True)
+        self.shape = tuple(img.shape)
+        for _ in range(max(2, warmup)):              # eager, capture, (replay ...)
+            self.replay_device(img, img_metas)
+        torch.cuda.synchronize(img.device)
+
+    def replay_device(self, img, img_metas):
+        """-> the handle's static (boxes, scores, labels, count) device tensors (consume them before the next call)."""
+        if tuple(img.shape) != self.shape:
+            raise ValueError(f'graph was captured for images of shape {self.shape}, got {tuple(img.shape)}')
+        B, V, _, H, W = img.shape
+        proj, new_origin, crop = self.model._camera_setup(img_metas, 4, img.device)
+        return self.native.forward(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
+
+    def __call__(self, img, img_metas):
+        boxes, scores, labels, count = self.replay_device(img, img_metas)
+        return self.model._results_one_copy(boxes, scores, labels, count, img_metas)
+
+
 class GraphedSimpleTest:
-    """hipGraph replay of ImVoxelNet.simple_test for a fixed input shape (see ImVoxelNet.capture_graph)."""
+    """torch.cuda.CUDAGraph replay of the layer-by-layer composition of ImVoxelNet.simple_test for a fixed input shape (see
+    ImVoxelNet.capture_graph, backend='torch': kept for A/B)."""
 
     def __init__(self, model, img, img_metas, warmup=2):
         self.model = model
