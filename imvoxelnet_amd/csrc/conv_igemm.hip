@@ -1408,7 +1408,9 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     // advantage of a fifth / sixth resident workgroup -- 128 x 128 at four per CU wins for every Cout >= 128 layer
     // (K = 192: 1.05 vs 1.12 ms at five; K = 384: 1.79 vs 1.86; K = 768: 3.37 vs 3.40), 128 x 64 at five for Cout <= 64
     // (1.08 vs 1.09 at six, 1.14 for 256 x 64)
-    else if (nblk >= 2500) pl.cfg = p.Cout > 64 ? 54 : 49;
+    // round 3, same tool with the 8-wave 256 x 128 tile added: it wins only the 128 -> 128 layers (K = 384: 1.838 vs
+    // 1.903 ms, spreads disjoint) and ties at K = 192 / 768 (profiles/r03_gemm_ab.log)
+    else if (nblk >= 2500) pl.cfg = p.Cout > 64 ? (p.Cout == 128 && p.K == 384 ? 58 : 54) : 49;
     else pl.cfg = p.K <= 640 ? 47 : 46;
   }
   TileInfo t;

@@ -354,11 +354,11 @@ extern "C" int ivx_anchor_head_get_bboxes(const ivx_anchor_head_desc *d, const f
 }
 
 // ---------------------------------------------------------------------------------------------- NMS entry points (via oracle/ivx_oracle.c)
-extern "C" int64_t ivx_nms_workspace_bytes(int32_t n) { return n < 0 ? -1 : 256; }
+extern "C" int64_t ivx_nms_workspace_bytes(int32_t n) { return n < 0 || n > 65536 ? -1 : 256; }
 
 extern "C" int ivx_nms_bev(const float *boxes_sorted, int32_t n, float thresh, int32_t rotated, void *, int64_t, int64_t *keep, int32_t *num_out,
                            ivx_stream_t) {
-  C_REQUIRE(n >= 0 && n <= 4096 && keep && num_out && (n == 0 || boxes_sorted), "ivx_nms_bev: bad argument");
+  C_REQUIRE(n >= 0 && n <= 65536 && keep && num_out && (n == 0 || boxes_sorted), "ivx_nms_bev: bad argument");
   *num_out = n == 0 ? 0 : (rotated ? ivxo_nms_rotated_sorted(boxes_sorted, n, thresh, keep) : ivxo_nms_normal_sorted(boxes_sorted, n, thresh, keep));
   return IVX_OK;
 }

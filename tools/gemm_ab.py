@@ -14,9 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from imvoxelnet_amd import ops, _lib  # noqa: E402
 
-CASES = [('64->64 z12', (216, 248, 12), 64, 64, 1, (1, 1, 1), [49, 56, 57, 52, 53]),
+CASES = [('64->64 z12', (216, 248, 12), 64, 64, 1, (1, 1, 1), [49, 56, 57, 52, 53, 43, 47, 46]),
          ('64->128 s112', (216, 248, 12), 64, 128, 2, (1, 1, 1), [54, 55, 51]),
-         ('128->128 z6', (216, 248, 6), 128, 128, 1, (1, 1, 1), [54, 55, 51]),
+         ('128->128 z6', (216, 248, 6), 128, 128, 1, (1, 1, 1), [54, 55, 51, 41, 58, 59]),
          ('128->256 s112', (216, 248, 6), 128, 256, 2, (1, 1, 1), [54, 55, 58]),
          ('256->256 z3', (216, 248, 3), 256, 256, 1, (1, 1, 1), [54, 55, 58])]
 
