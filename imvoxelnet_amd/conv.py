@@ -70,6 +70,22 @@ FP8 = torch.float8_e4m3fn
 FP8_MAX = 448.0
 
 
+def pack_pair_weights(w5, layout=1):
+    """fp32 filters [Cout,kd,kh,kw,Cin] (Cin % 16 == 0) -> the IVX_BF16_PAIR operand (include/imvoxel.h): bf16, every value as
+    hi = bf16(w), lo = bf16(w - hi), 16-channel groups [hi x16 | lo x16]; layout 0: [Cout,kd,kh,kw,2Cin], layout 1 (Cin % 32 == 0):
+    chunk-major [Cout, 2Cin/64, kd,kh,kw, 64]."""
+    w5 = w5.detach().to(torch.float32)
+    co, kd, kh, kw, ci = w5.shape
+    if ci % 16 or (layout == 1 and ci % 32):
+        raise ValueError('pair filters need Cin % 16 == 0 (layout 1: % 32)')
+    hi = w5.to(torch.bfloat16)
+    lo = (w5 - hi.to(torch.float32)).to(torch.bfloat16)
+    wp = torch.cat([hi.reshape(co, kd, kh, kw, ci // 16, 16), lo.reshape(co, kd, kh, kw, ci // 16, 16)], dim=-1).reshape(co, kd, kh, kw, 2 * ci)
+    if layout == 1:
+        wp = wp.reshape(co, kd, kh, kw, 2 * ci // 64, 64).permute(0, 4, 1, 2, 3, 5)
+    return wp.contiguous()
+
+
 class QTensor:
     """An e4m3 activation with its per-tensor scale: value = data.float() * scale (optional fp8 storage of the 2-D trunk in
     the bf16 mode).  Produced and consumed by FusedConv / ops.maxpool2d; `scale` is a Python float fixed at calibration."""
@@ -114,6 +130,15 @@ class FusedConv:
     winograd_min_ch = 64
     winograd_2d_min_ch = int(os.environ.get('IVX_WINOGRAD_2D_MIN_CH', '128'))   # 2-D 3x3 layers (ResNet conv2, FPN outputs)
     winograd_min_pos = int(os.environ.get('IVX_WINOGRAD_MIN_POS', '2000'))
+    # Split-operand form (include/imvoxel.h IVX_BF16_PAIR): fp32 activations and filters as (hi, lo) bf16 pairs, three bf16 MFMA
+    # products per pair with fp32 accumulation -- 16x the fp32 MFMA rate at 2^-17 operand precision, no transform passes.
+    # 0: off (exact fp32 MFMA, Winograd forms);  1: the 3-D layers with Cin % 32 == 0;  2: the 2-D layers as well
+    pair_mode = int(os.environ.get('IVX_CONV_PAIR', '0'))
+    pair_min_pos = 2000
+    # Operands of the Winograd-domain GEMMs (ivx_conv_desc.wino_operands): 4 = fp16 (hi, lo) pairs, three fp16 MFMA products per pair
+    # (~3.3x the fp32 MFMA rate at 22-bit operands: the error stays at the level of the fp32 form's own rounding);
+    # 0 = fp32 MFMA (exact fp32 products)
+    wino_operands = int(os.environ.get('IVX_WINO_OPERANDS', '4'))
     # optional per-call timing (bench.py): when a list, every call appends
     # (kind, start_event, end_event, executed_flops, bytes, is_3d) with kind 'direct' | 'wino_input' | 'wino_gemm' |
     # 'wino_output'; the events bracket exactly the launches of that stage on the stream they run on; is_3d tells the 3-D
@@ -179,6 +204,13 @@ class FusedConv:
                 and self.cout % 4 == 0 and max(self.cin, self.cout) >= min_ch and self.cin % 4 == 0 and type(self) is FusedConv):
             w0 = w.permute(0, 2, 3, 4, 1).contiguous()                       # [Cout,kd,kh,kw,Cin]
             self._w0_host = w0.reshape(self.cout, 3, 3, 1, self.cin) if self._wino2d else w0
+        # candidate for the split-operand form: pair-packed filters (made on the host once)
+        self._wp_host = None
+        self._dims = dims
+        if (dtype == torch.float32 and out_dtype == torch.float32 and self.cin_pad == self.cin and self.cin % 32 == 0 and type(self) is FusedConv
+                and FusedConv.pair_mode >= (1 if dims == 3 else 2)):
+            self._wp_host = pack_pair_weights(w.permute(0, 2, 3, 4, 1).contiguous(), 1)
+        self.wp = None
         self.u = None          # {tile: transformed filters}, filled by to() / on first use of a tile
         self._w0 = None
         scale = torch.ones(self.cout)
@@ -195,6 +227,8 @@ class FusedConv:
 
     def to(self, device):
         self.w = self._w_host.to(device)
+        if self._wp_host is not None:
+            self.wp = self._wp_host.to(device)
         if self._w0_host is not None and FusedConv.winograd:
             self._w0 = self._w0_host.to(device)        # tap-major filters stay resident: a tile's filters are made on first use
             self.u = {}
@@ -236,6 +270,8 @@ class FusedConv:
         """epi: (scale, shift, res_scale) of this call when they differ from the layer's own (the quantised modes: the tensors'
         scales folded in); the direct kernel only -- the Winograd form is fp32."""
         B = x.shape[0]
+        if self.takes_pair_form(tuple(x.shape), x.dtype, naive) and epi is None:
+            return self._pair(x, res, res_mode, relu, res_after_act, post_scale)
         m, xs, wk, wst, wpad = self.wino_tile(tuple(x.shape), x.dtype, res_mode, naive)
         wino = m > 0
         if not wino:
@@ -252,8 +288,9 @@ class FusedConv:
                 ops.winograd_trace = []
             xv = x.view(xs)
             rv = None if res is None else res.view(B, res.shape[2], res.shape[3], 1, self.cout) if self._wino2d else res
-            y = ops.conv_winograd_fwd(xv, self._filters(m), self.scale, self.shift, wk[2], wst[2], wpad, self.relu if relu is None else relu,
-                                      rv, wgt_layout=self.layout, res_after_act=res_after_act, post_scale=post_scale)
+            opnd = self._wino_operands(m)
+            y = ops.conv_winograd_fwd(xv, self._filters(m, opnd), self.scale, self.shift, wk[2], wst[2], wpad, self.relu if relu is None else relu,
+                                      rv, wgt_layout=self.layout, res_after_act=res_after_act, post_scale=post_scale, operands=opnd)
             if FusedConv.trace is not None:
                 tiles = y.shape[0] * ((y.shape[1] + m - 1) // m) * ((y.shape[2] + m - 1) // m)
                 v_bytes = 4.0 * (m + 2) ** 2 * tiles * xv.shape[3] * self.cin      # transformed input: (m+2)^2 planes [tiles, Z, Cin]
@@ -276,6 +313,37 @@ class FusedConv:
             return y
         return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale, epi)
 
+    def takes_pair_form(self, x_shape, dtype=torch.float32, naive=False):
+        return (self.wp is not None and not naive and dtype == torch.float32 and FusedConv.pair_mode >= (1 if self._dims == 3 else 2)
+                and x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3] >= FusedConv.pair_min_pos
+                and ops.conv_pair_supported(x_shape, self.cout, self.kernel, self.stride, self.padding, 1))
+
+    def _pair(self, x, res, res_mode, relu, res_after_act, post_scale):
+        """split pass (fp32 -> bf16 pairs) + the three-product bf16 MFMA kernel with the usual fused fp32 epilogue"""
+        tr = FusedConv.trace is not None
+        if FusedConv.count_flops:
+            od, oh, ow = ((x.shape[1 + a] + 2 * self.padding[a] - self.kernel[a]) // self.stride[a] + 1 for a in range(3))
+            direct = 2.0 * x.shape[0] * od * oh * ow * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
+            FusedConv.flops += direct
+            FusedConv.exec_flops += 3.0 * direct
+        if tr:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+        xp = ops.bf16_pair_split(x)
+        if tr:
+            e[1].record()
+        y = ops.conv_fwd(xp, self.wp, self.scale, self.shift, self.kernel, self.stride, self.padding, self.relu if relu is None else relu, res,
+                         res_mode, wgt_layout=1, res_after_act=res_after_act, post_scale=post_scale, pair=True)
+        if tr:
+            e[2].record()
+            is3d = x.shape[1] > 1 and x.shape[3] > 1
+            fl = 2.0 * y.numel() * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
+            FusedConv.trace.append(('pair_split', e[0], e[1], 0.0, 8.0 * x.numel(), is3d, self._describe(x, 0) + ' pair'))
+            FusedConv.trace.append(('pair_gemm', e[1], e[2], 3.0 * fl, float(4 * x.numel() + 4 * y.numel() + 2 * self.wp.numel()
+                                                                            + (4 * res.numel() if res is not None else 0)), is3d,
+                                    self._describe(x, 0) + ' pair'))
+        return y
+
     def wino_tile(self, x_shape, dtype=torch.float32, res_mode=0, naive=False):
         """-> (m, xs, wk, wst, wpad): m = tile of the F(m x m, 3x3) form this layer takes for an input of shape x_shape
         (0: the direct kernel), and the convolution as the Winograd entry points see it (transformed axes first, direct
@@ -296,10 +364,15 @@ class FusedConv:
         k, st = 'x'.join(map(str, self.kernel)), ''.join(map(str, self.stride))
         return f'{self.cin}->{self.cout} k{k} s{st} in {tuple(x.shape[:4])}' + (f' F{tile}' if tile else '')
 
-    def _filters(self, tile):
-        if tile not in self.u:
-            self.u[tile] = ops.conv_winograd_weights(self._w0, self.layout, tile)
-        return self.u[tile]
+    def _wino_operands(self, tile):
+        ok = FusedConv.wino_operands == ops.IVX_F16_PAIR and tile >= 4 and self.cin % (32 if self.layout == 1 else 16) == 0
+        return ops.IVX_F16_PAIR if ok else 0
+
+    def _filters(self, tile, operands=None):
+        operands = self._wino_operands(tile) if operands is None else operands
+        if (tile, operands) not in self.u:
+            self.u[(tile, operands)] = ops.conv_winograd_weights(self._w0, self.layout, tile, operands)
+        return self.u[(tile, operands)]
 
     def _direct(self, x, res, res_mode, relu, naive, res_after_act, post_scale, epi=None):
         scale, shift, res_scale = epi if epi is not None else (self.scale, self.shift, 1.0)

@@ -25,6 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvParams {
   const float *in, *wgt, *scale, *shift, *res;
@@ -55,6 +56,8 @@ struct ConvParams {
   int in_fp8;         // in / wgt are OCP e4m3 bytes (v_mfma_f32_32x32x16_fp8_fp8); dequantisation is folded into scale[]
   int out_fp8;        // out / res are e4m3 bytes (saturating round-to-nearest-even at the store)
   float res_scale;    // multiplier of the residual (fp8 storage: res_scale_of_tensor / out_scale); 1 otherwise
+  int in_pair;        // 1 / 2: in / wgt hold every fp32 value as a (hi, lo) bf16 / fp16 pair, 16-channel groups [hi16 | lo16] (IVX_*_PAIR); Cin and K
+                      // count bf16 elements (2 per real channel); the K loop issues hi*hi + hi*lo + lo*hi per group
 };
 
 struct fp8_t { unsigned char v; };       // storage element of the fp8 instantiation (size 1)
@@ -538,7 +541,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 // them against the ds_reads of a LATER loop iteration, so the wait before the publishing barrier is explicit.
 __device__ __forceinline__ void lds_dma_wait_all() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 
-template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE, int UNI>
+// One matrix instruction on a (hi | lo) operand pair: PAIR 1 = bf16 halves, 2 = fp16 halves (same shape and rate)
+template <int PAIR>
+__device__ __forceinline__ f32x16 pair_mfma(const f32x4 a, const f32x4 b, const f32x16 c) {
+  if constexpr (PAIR == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE, int UNI, int PAIR = 0>
 __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const ConvParams p, const unsigned in_bytes,
                                                                   const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
@@ -771,11 +781,16 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
 #pragma unroll
     for (int kk = 0; kk < NCH / 2; ++kk) {
       const int cb = kk & 1, nb = cb ^ 1;
+      // PAIR: k-group 2t holds the hi halves of 16 channels, 2t+1 their lo halves; the odd step needs both register buffers
+      // (hi in nb, lo in cb), so the read of the next group is issued after its MFMAs instead of before
+      const bool defer = PAIR && (kk & 1);
       if (kk < NCH / 2 - 1) {
+        if (!defer) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
+          for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
+          for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
+        }
       } else {
         // every wave holds its last fragments of buffer `cur`; slab s+1 (other buffer) must have landed: each wave
         // waits for its own DMA (issued one barrier ago), the barrier then publishes all of them
@@ -794,6 +809,29 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][i][q], fb[cb][j][q], acc[i][j], 0, 0, 0);
+      } else if constexpr (EL == 2 && PAIR) {
+        static_assert(NCH % 4 == 0, "pair operands: a slab holds whole [hi16 | lo16] groups");
+        if ((kk & 1) == 0) {   // hi * hi
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = pair_mfma<PAIR>(fa[cb][i], fb[cb][j], acc[i][j]);
+        } else {               // hi * lo + lo * hi (hi: buffer nb, lo: buffer cb)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              acc[i][j] = pair_mfma<PAIR>(fa[nb][i], fb[cb][j], acc[i][j]);
+              acc[i][j] = pair_mfma<PAIR>(fa[cb][i], fb[nb][j], acc[i][j]);
+            }
+          if (kk < NCH / 2 - 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[nb][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[nb][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 32 * BK + (((2 * (kk + 1) + fh) ^ fsw) * EPC));
+          }
+        }
       } else if constexpr (EL == 2) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -914,6 +952,20 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
           const int ntap = p.KD * p.KH * p.KW;
           const size_t wo = (size_t)n * p.K;
           const int ck = p.in_fp8 ? 128 : (p.in_bf16 ? 64 : 32);   // channels per 128-byte chunk of the chunk-major order
+          if (p.in_pair) {   // the value a (hi, lo) pair stands for is hi + lo (exact in fp32): plain fp32 products of those
+            for (int c = 0; c < p.Cin / 2; ++c) {
+              const int eh = (c >> 4) * 32 + (c & 15), el = eh + 16;
+              const size_t wh = p.kmode == 1 ? (size_t)((eh / ck) * ntap + tap) * ck + (eh % ck) : (size_t)tap * p.Cin + eh;
+              if (p.in_pair == 2) {
+                const _Float16 *xp = reinterpret_cast<const _Float16 *>(p.in) + xo, *wp = reinterpret_cast<const _Float16 *>(p.wgt) + wo;
+                acc = fmaf((float)xp[eh] + (float)xp[el], (float)wp[wh] + (float)wp[wh + 16], acc);
+              } else {
+                const __bf16 *xp = reinterpret_cast<const __bf16 *>(p.in) + xo, *wp = reinterpret_cast<const __bf16 *>(p.wgt) + wo;
+                acc = fmaf((float)xp[eh] + (float)xp[el], (float)wp[wh] + (float)wp[wh + 16], acc);
+              }
+            }
+            continue;
+          }
           for (int c = 0; c < p.Cin; ++c) {
             const size_t wi = wo + (p.kmode == 1 ? (size_t)((c / ck) * ntap + tap) * ck + (c % ck) : (size_t)tap * p.Cin + c);
             const float xv = p.in_fp8 ? fp8_to_f32(reinterpret_cast<const unsigned char *>(p.in)[xo + c])
@@ -954,18 +1006,21 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   int32_t Do, Ho, Wo;
   if (ivx_conv_out_dims(d, &Do, &Ho, &Wo) != IVX_OK) return IVX_ERR_INVALID_ARG;
   const int64_t M = (int64_t)d->B * Do * Ho * Wo;
-  const int64_t K = (int64_t)d->KD * d->KH * d->KW * d->Cin;
+  const bool pair = d->in_dtype == IVX_BF16_PAIR || d->in_dtype == IVX_F16_PAIR;
+  const int cin_el = pair ? 2 * d->Cin : d->Cin;     // stored elements per voxel (a pair tensor holds two bf16 per channel)
+  const int64_t K = (int64_t)d->KD * d->KH * d->KW * cin_el;
   IVX_REQUIRE(M < (1LL << 31) - 512 && K < (1LL << 30), "ivx_conv_fwd: problem too large for 32-bit row index");
   IVX_REQUIRE((int64_t)d->B * d->D * d->H * d->W < (1LL << 31), "ivx_conv_fwd: input voxel count exceeds 2^31");
   IVX_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2, "ivx_conv_fwd: bad res_mode");
   IVX_REQUIRE(d->out_mode == 0 || (d->out_mode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 1 && d->sd == 1 && d->sh == 1 && d->sw == 1 &&
                                      d->pd == 0 && d->ph == 0 && d->pw == 0 && d->Cout % 8 == 0 && d->res_mode != 2),
               "ivx_conv_fwd: out_mode 1 (ConvTranspose k2 s2) needs a 1x1x1 stride-1 GEMM with Cout = 8 * real channels");
-  IVX_REQUIRE(d->in_dtype >= IVX_F32 && d->in_dtype <= IVX_FP8 && d->out_dtype >= IVX_F32 && d->out_dtype <= IVX_FP8,
-              "ivx_conv_fwd: dtypes are IVX_F32 (0), IVX_BF16 (1) or IVX_FP8 (2)");
+  IVX_REQUIRE(d->in_dtype >= IVX_F32 && d->in_dtype <= IVX_F16_PAIR && d->out_dtype >= IVX_F32 && d->out_dtype <= IVX_FP8,
+              "ivx_conv_fwd: dtypes are IVX_F32 (0), IVX_BF16 (1), IVX_FP8 (2) or, for the input, IVX_BF16_PAIR (3) / IVX_F16_PAIR (4)");
+  IVX_REQUIRE(!pair || (d->Cin % 16 == 0 && d->out_mode == 0), "ivx_conv_fwd: bf16-pair input needs Cin %% 16 == 0 and out_mode 0");
   IVX_REQUIRE(d->in_dtype != IVX_FP8 || d->Cin % 16 == 0, "ivx_conv_fwd: fp8 input needs Cin %% 16 == 0");
   IVX_REQUIRE((d->in_dtype != IVX_FP8 && d->out_dtype != IVX_FP8) || d->out_mode == 0, "ivx_conv_fwd: fp8 is built for out_mode 0 only");
-  const int ck = d->in_dtype == IVX_FP8 ? 128 : (d->in_dtype == IVX_BF16 ? 64 : 32);
+  const int ck = d->in_dtype == IVX_FP8 ? 128 : (d->in_dtype == IVX_BF16 ? 64 : 32);   // pair: 32 real channels = 64 stored elements
   IVX_REQUIRE(d->wgt_layout == 0 || (d->wgt_layout == 1 && d->Cin % ck == 0),
               "ivx_conv_fwd: wgt_layout 1 needs Cin %% %d == 0 (128-byte channel chunks)", ck);
   IVX_REQUIRE(d->in_dtype == IVX_F32 || d->Cin % 8 == 0, "ivx_conv_fwd: bf16 input needs Cin %% 8 == 0");
@@ -975,10 +1030,11 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   }
   p->in = (const float *)in; p->wgt = (const float *)wgt; p->scale = scale; p->shift = shift;
   p->res = d->res_mode ? (const float *)res : nullptr; p->out = (float *)out;
-  p->in_bf16 = d->in_dtype == IVX_BF16; p->out_bf16 = d->out_dtype == IVX_BF16;
+  p->in_bf16 = d->in_dtype == IVX_BF16 || pair; p->out_bf16 = d->out_dtype == IVX_BF16;
+  p->in_pair = d->in_dtype == IVX_BF16_PAIR ? 1 : (d->in_dtype == IVX_F16_PAIR ? 2 : 0);
   p->in_fp8 = d->in_dtype == IVX_FP8; p->out_fp8 = d->out_dtype == IVX_FP8;
   p->res_scale = d->res_scale == 0.f ? 1.0f : d->res_scale;
-  p->B = d->B; p->D = d->D; p->H = d->H; p->W = d->W; p->Cin = d->Cin;
+  p->B = d->B; p->D = d->D; p->H = d->H; p->W = d->W; p->Cin = cin_el;
   p->Cout = d->Cout; p->KD = d->KD; p->KH = d->KH; p->KW = d->KW;
   p->sd = d->sd; p->sh = d->sh; p->sw = d->sw; p->pd = d->pd; p->ph = d->ph; p->pw = d->pw;
   p->Do = Do; p->Ho = Ho; p->Wo = Wo; p->M = (int)M; p->K = (int)K;
@@ -1010,7 +1066,7 @@ static void launch_cfg(const ConvParams &p, hipStream_t st) {
   hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
 }
 
-template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE = 1>
+template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE = 1, int PAIR = 0>
 static void launch_v4(ConvParams &p, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * sizeof(T);
@@ -1026,7 +1082,7 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
   const dim3 grid((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1, p.groups > 1 ? p.groups : 1);
   // every slab lies inside one filter tap -> uniform K-loop state
   const bool uni = p.kmode == 1 || p.Cin % BK == 0;
-  auto kern = uni ? conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1> : conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 0>;
+  auto kern = uni ? conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1, PAIR> : conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 0, PAIR>;
   hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
 }
 
@@ -1085,6 +1141,7 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 67: *t = {64, 64, 32, 6}; return true;
     case 71: *t = {128, 128, 32, 3}; return true;
     case 73: *t = {128, 64, 32, 5}; return true;
+    case 75: *t = {128, 64, 32, 5}; return true;
     case 72: *t = {256, 64, 32, 3}; return true;
     default: return false;
   }
@@ -1191,6 +1248,11 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     else if (pl.cfg == 57) pl.cfg = 72;
     else if (pl.cfg <= 53) pl.cfg += 20;   // 41..47, 51..53 -> 61..67, 71..73
   }
+  if (p.in_pair && g_tile_override == 0) {   // pair operands are instantiated for a subset of the bf16 tiles
+    if (pl.cfg == 64) pl.cfg = 67;
+    else if (pl.cfg == 71) pl.cfg = 74;
+    else if (pl.cfg == 72) pl.cfg = 73;
+  }
   TileInfo t;
   if (!tile_info(pl.cfg, &t) || !dma_ok) return pl;
   const long long Mt = (p.M + t.bm - 1) / t.bm, Nt = (p.Cout + t.bn - 1) / t.bn;
@@ -1229,7 +1291,29 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
   return pl;
 }
 
+// pair operands (IVX_BF16_PAIR / IVX_F16_PAIR): the bf16 tiles with the three-product K loop
+template <int PAIR>
+static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
+  switch (pl.cfg) {
+    case 63: launch_v4<__bf16, 2, 1, 2, 2, 64, 1, PAIR>(p, st); break;
+    case 66: launch_v4<__bf16, 1, 1, 2, 2, 64, 1, PAIR>(p, st); break;
+    case 67: launch_v4<__bf16, 1, 1, 2, 2, 32, 6, PAIR>(p, st); break;
+    case 73: launch_v4<__bf16, 2, 1, 2, 2, 32, 1, PAIR>(p, st); break;
+    case 75: launch_v4<__bf16, 2, 1, 2, 2, 32, 5, PAIR>(p, st); break;   // 73 at five workgroups per CU
+    case 74: launch_v4<__bf16, 2, 2, 2, 2, 32, 4, PAIR>(p, st); break;
+    case 61: launch_v4<__bf16, 2, 2, 2, 2, 64, 1, PAIR>(p, st); break;
+    case 81: launch_v4<__bf16, 2, 2, 4, 2, 32, 4, PAIR>(p, st); break;
+    case 82: launch_v4<__bf16, 2, 2, 4, 4, 32, 4, PAIR>(p, st); break;
+    case 83: launch_v4<__bf16, 2, 2, 4, 2, 64, 2, PAIR>(p, st); break;
+    default:
+      ivx_set_error("ivx_conv_fwd: tile %d has no pair-operand instantiation (61, 63, 66, 67, 73, 74, 75, 81, 82, 83)", pl.cfg);
+      return IVX_ERR_INVALID_ARG;
+  }
+  return IVX_OK;
+}
+
 static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
+  if (p.in_pair) return p.in_pair == 2 ? launch_pair<2>(p, pl, st) : launch_pair<1>(p, pl, st);
   switch (pl.cfg) {
     case 1: launch_cfg<2, 2, 2, 2>(p, st); break;  // 128 x 128, 2 workgroups/CU
     case 2: launch_cfg<2, 2, 4, 1>(p, st); break;  // 256 x 64, 1 workgroup/CU
@@ -1388,14 +1472,20 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
   int rc = fill_params(d, in, wgt, nullptr, nullptr, nullptr, out, &p);
   if (rc != IVX_OK) return rc;
   IVX_REQUIRE(groups >= 1 && groups <= 65535, "ivx_conv_grouped_launch: bad group count");
-  IVX_REQUIRE(d->in_dtype == IVX_F32 && d->out_dtype == IVX_F32 && d->out_mode == 0 && d->res_mode == 0,
-              "ivx_conv_grouped_launch: fp32, plain output only");
+  IVX_REQUIRE((d->in_dtype == IVX_F32 || d->in_dtype == IVX_BF16_PAIR || d->in_dtype == IVX_F16_PAIR) && d->out_dtype == IVX_F32 &&
+                  d->out_mode == 0 && d->res_mode == 0,
+              "ivx_conv_grouped_launch: fp32 or pair operands, plain fp32 output only");
   if (!dma_applicable(p)) {
     ivx_set_error("ivx_conv_grouped_launch: one group must stay below 2 GiB");
     return IVX_ERR_UNSUPPORTED;
   }
   p.groups = groups; p.g_in = g_in; p.g_w = g_w; p.g_out = g_out;
   ConvPlan pl = {g_tile_override, 1, 1, 0, 0, 0, 0};
+  if (pl.cfg == 0 && p.in_pair) {
+    // pair operands: three bf16-rate products per staged operand pair; 8- / 16-wave workgroups stage the fewest bytes per product
+    // (tools/gemm_ab.py --pair, profiles/r03_gemm_ab_pair.log)
+    pl.cfg = p.Cout <= 64 ? 73 : (p.Cout <= 128 ? 81 : 82);
+  }
   if (pl.cfg == 0) {
     const long long nblk = (long long)groups * ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (p.Cout <= 32) pl.cfg = 44;
@@ -1414,8 +1504,8 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     else pl.cfg = p.K <= 640 ? 47 : 46;
   }
   TileInfo t;
-  if (!tile_info(pl.cfg, &t) || pl.cfg >= 61) {
-    ivx_set_error("ivx_conv_grouped_launch: tile %d is not an fp32 LDS-DMA tile", pl.cfg);
+  if (!tile_info(pl.cfg, &t) || (pl.cfg >= 61) != (p.in_pair != 0)) {
+    ivx_set_error("ivx_conv_grouped_launch: tile %d does not match the operand type", pl.cfg);
     return IVX_ERR_INVALID_ARG;
   }
   return launch_one(p, pl, st);
@@ -1441,6 +1531,14 @@ extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const voi
   if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_fwd_ws");
   return IVX_OK;
+}
+
+extern "C" int ivx_conv_pair_supported(const ivx_conv_desc *d) {
+  if (!d || d->in_dtype != IVX_F32 || d->out_dtype != IVX_F32 || d->out_mode != 0 || d->Cin % 16 != 0 || d->Cin <= 0) return 0;
+  if (d->wgt_layout == 1 && d->Cin % 32 != 0) return 0;
+  if (d->KD > 8 || d->KH > 8 || d->KW > 8 || d->KD < 1 || d->KH < 1 || d->KW < 1) return 0;
+  const int64_t in_b = (int64_t)d->B * d->D * d->H * d->W * d->Cin * 4, w_b = (int64_t)d->Cout * d->KD * d->KH * d->KW * d->Cin * 4;
+  return in_b < (1LL << 31) && w_b < (1LL << 31) ? 1 : 0;   // no batch slicing in this form: the caller falls back to fp32 MFMA
 }
 
 extern "C" int ivx_conv_fwd_naive(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,

@@ -69,7 +69,7 @@ struct ConvLayer {
   int cin_pad = 0, layout = 0;
   bool wino_cand = false, wino2d = false, identity_epilogue = true;
   float *w = nullptr, *w0 = nullptr, *scale = nullptr, *shift = nullptr;
-  std::map<int, float *> u;           // tile -> transformed filters
+  std::map<int, float *> u;           // tile * 8 + operand type -> transformed filters
 };
 
 enum StepKind { ST_IMG2CL, ST_CONV, ST_MAXPOOL, ST_LIFT, ST_TAIL, ST_UPSAMPLE, ST_DCN_COL, ST_AVGPOOL, ST_LAYOUT, ST_FCOS, ST_INDOOR_TAIL };
@@ -629,17 +629,20 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
     ivx_conv_desc probe = dw;
     probe.relu = 0; probe.res_mode = 0; probe.wgt_layout = 0;
     if (!ivx_conv_winograd_supported(&probe, tile)) tile = 0;
+    // operands of the transformed-domain GEMMs (FusedConv._wino_operands): fp16 pairs where the layer's channel count allows
+    if (tile >= 4 && m->cfg.wino_operands == IVX_F16_PAIR && L.cin % (L.layout == 1 ? 32 : 16) == 0) dw.wino_operands = IVX_F16_PAIR;
   }
   if (tile) {
     ps->d = dw;
     ps->ws = ivx_conv_winograd_workspace_bytes(&dw, tile);
     M_REQUIRE(ps->ws >= 0, "layer %s: %s", L.name.c_str(), ivx_last_error());
-    if (!L.u.count(tile)) {   // transformed filters for this tile, made once (ops.conv_winograd_weights)
+    const int ukey = tile * 8 + dw.wino_operands;
+    if (!L.u.count(ukey)) {   // transformed filters for this tile and operand type, made once (ops.conv_winograd_weights)
       ivx_conv_desc wd;
       memset(&wd, 0, sizeof(wd));
       wd.B = 1; wd.D = 4; wd.H = 4; wd.W = std::max(dw.KW, 1); wd.Cin = L.cin; wd.Cout = L.cout;
       wd.KD = 3; wd.KH = 3; wd.KW = dw.KW; wd.sd = wd.sh = wd.sw = 1; wd.pd = wd.ph = 1; wd.pw = dw.KW / 2;
-      wd.wgt_layout = L.layout; wd.post_scale = 1.0f;
+      wd.wgt_layout = L.layout; wd.post_scale = 1.0f; wd.wino_operands = dw.wino_operands;
       const int64_t n = ivx_conv_winograd_weight_elems(&wd, tile);
       M_REQUIRE(n > 0, "layer %s: %s", L.name.c_str(), ivx_last_error());
       void *u = nullptr;
@@ -650,7 +653,7 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
       // that follows may run on a non-blocking stream: the transformed filters must be complete before this returns, whatever
       // stream later reads them.
       M_HIP(hipStreamSynchronize(stream), "hipStreamSynchronize (Winograd filters)");
-      L.u[tile] = (float *)u;
+      L.u[ukey] = (float *)u;
     }
   } else {
     ps->d = d;
@@ -978,7 +981,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           M_TRY(ivx_conv_winograd_input(&ps.d, ps.tile, ptr(s.in), ws, pl.ws_bytes, st));
           M_TRY(trace_end(m, st));
           M_TRY(trace_begin(m, i, 2, is3d, 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin, vb + mb, L.name, st));
-          M_TRY(ivx_conv_winograd_gemm(&ps.d, ps.tile, L.u.at(ps.tile), ws, pl.ws_bytes, st));
+          M_TRY(ivx_conv_winograd_gemm(&ps.d, ps.tile, L.u.at(ps.tile * 8 + ps.d.wino_operands), ws, pl.ws_bytes, st));
           M_TRY(trace_end(m, st));
           M_TRY(trace_begin(m, i, 3, is3d, 0.0, mb + 4.0 * o.elems() * (res ? 2 : 1), L.name, st));
           M_TRY(ivx_conv_winograd_output(&ps.d, ps.tile, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
@@ -987,7 +990,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         }
         M_TRY(trace_begin(m, i, 0, is3d, 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2], 0.0, L.name, st));
         if (ps.tile)
-          M_TRY(ivx_conv_winograd_fwd(&ps.d, ps.tile, ptr(s.in), L.u.at(ps.tile), L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
+          M_TRY(ivx_conv_winograd_fwd(&ps.d, ps.tile, ptr(s.in), L.u.at(ps.tile * 8 + ps.d.wino_operands), L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
         else
           M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.w, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
         M_TRY(trace_end(m, st));
@@ -1102,6 +1105,7 @@ extern "C" int ivx_create(const ivx_model_cfg *cfg, ivx_model **out) {
   M_REQUIRE(indoor || (cfg->num_classes >= 1 && cfg->n_sizes >= 1 && cfg->n_sizes <= 4 && cfg->n_rotations >= 1 && cfg->n_rotations <= 4),
             "ivx_create: 1..4 anchor sizes / rotations, >= 1 class");
   M_REQUIRE(indoor || (cfg->nms_pre > 0 && cfg->max_num > 0), "ivx_create: nms_pre and max_num must be positive");
+  M_REQUIRE(cfg->wino_operands == IVX_F32 || cfg->wino_operands == IVX_F16_PAIR, "ivx_create: wino_operands IVX_F32 | IVX_F16_PAIR");
   M_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 2 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "ivx_create: winograd_tile 0 | 2 | 4 | 6");
   M_REQUIRE(cfg->head_type >= IVX_HEAD_NONE && cfg->head_type <= IVX_HEAD_SUNRGBD, "ivx_create: head_type 0 (none) | IVX_HEAD_SCANNET | IVX_HEAD_SUNRGBD");
   if (cfg->head_type != IVX_HEAD_NONE) {

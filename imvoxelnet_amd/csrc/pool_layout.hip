@@ -319,3 +319,50 @@ extern "C" int ivx_global_avgpool_fwd(const float *in, int32_t B, int64_t S, int
   IVX_CHECK_LAUNCH("ivx_global_avgpool_fwd");
   return IVX_OK;
 }
+
+// fp32 -> (hi, lo) pairs in the IVX_BF16_PAIR / IVX_F16_PAIR order (include/imvoxel.h): per 16 values [hi x16 | lo x16].  One lane
+// converts 8 values: 32 contiguous bytes in, 16 bytes of hi and 16 bytes of lo out; a pair of lanes fills one 64-byte group.
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+template <typename H> struct PairIsF16 { static constexpr bool value = false; };
+template <> struct PairIsF16<_Float16> { static constexpr bool value = true; };
+template <typename H>
+__global__ __launch_bounds__(256) void pair_split_kernel(const float *__restrict__ in, size_t n8, float scale, H *__restrict__ out) {
+  typedef H hx8 __attribute__((ext_vector_type(8)));
+  constexpr bool F16 = PairIsF16<H>::value;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (size_t)gridDim.x * blockDim.x) {
+    const pf32x4 a = __builtin_nontemporal_load(reinterpret_cast<const pf32x4 *>(in) + 2 * t);
+    const pf32x4 b = __builtin_nontemporal_load(reinterpret_cast<const pf32x4 *>(in) + 2 * t + 1);
+    hx8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = e < 4 ? a[e] : b[e - 4];
+      if (F16) x = __builtin_fminf(__builtin_fmaxf(x * scale, -65504.f), 65504.f);
+      hi[e] = (H)x;
+      lo[e] = (H)(x - (float)hi[e]);
+    }
+    H *o = out + (t >> 1) * 32 + (t & 1) * 8;
+    *reinterpret_cast<hx8 *>(o) = hi;
+    *reinterpret_cast<hx8 *>(o + 16) = lo;
+  }
+}
+
+template <typename H>
+static int pair_split_launch(const float *in, int64_t n, float scale, void *out, ivx_stream_t stream, const char *who) {
+  IVX_REQUIRE(in && out && n >= 0 && n % 16 == 0, "%s: null argument or n not a multiple of 16", who);
+  if (n == 0) return IVX_OK;
+  const size_t n8 = (size_t)n / 8;
+  size_t blocks = (n8 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(pair_split_kernel<H>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, n8, scale, (H *)out);
+  IVX_CHECK_LAUNCH(who);
+  return IVX_OK;
+}
+
+extern "C" int ivx_bf16_pair_split(const float *in, int64_t n, void *out, ivx_stream_t stream) {
+  return pair_split_launch<__bf16>(in, n, 1.0f, out, stream, "ivx_bf16_pair_split");
+}
+
+extern "C" int ivx_f16_pair_split(const float *in, int64_t n, float scale, void *out, ivx_stream_t stream) {
+  IVX_REQUIRE(scale > 0.f, "ivx_f16_pair_split: the scale must be positive");
+  return pair_split_launch<_Float16>(in, n, scale, out, stream, "ivx_f16_pair_split");
+}

@@ -34,7 +34,64 @@ struct WinoP {
   int px, py;               // padding of the transformed axes
   int relu, res_mode, res_after_act;
   float post_scale;
+  const unsigned *hdr;      // pair operands: {bits of max |input|, bits of the filter scale} (device; see wino_pair_vscale), else NULL
 };
+
+// Power-of-two scales of the fp16-pair operands (ivx_conv_desc.wino_operands = IVX_F16_PAIR), chosen on the device from the data so
+// that the largest value lands in [2^14, 2^15) -- below fp16's 65504 with room for the transform's growth -- and everything down to
+// 2^-18 of it keeps a normal lo half (the matrix cores flush fp16 subnormals: measured, tools/pair_ab.py at activation scale 1e-3
+// with a fixed scale).  Activations: |V| = |Bt d B| <= 225 max|d| for F(6,3) (|Bt| row sums <= 15), 100 for F(4,3): bounded by 256.
+// Filters: the exact max |U| is reduced while they are transformed.  Both scales are undone in the output transform (exact).
+__device__ __forceinline__ float wino_pow2_scale(const float amax, const float gain_log2) {   // s = 2^k with gain * amax * s in [2^14, 2^15)
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+  int e;
+  (void)frexpf(amax, &e);                        // amax in [2^(e-1), 2^e)
+  int k = 15 - (int)gain_log2 - e;
+  k = k < -120 ? -120 : (k > 120 ? 120 : k);
+  return ldexpf(1.0f, k);
+}
+__device__ __forceinline__ float wino_pair_vscale(const unsigned *hdr) { return wino_pow2_scale(__uint_as_float(hdr[0]), 8.f); }
+// multiplier of M in the output transform: 1 / (activation scale * filter scale); 1 for fp32 operands (no header)
+__device__ __forceinline__ float wino_mscale(const unsigned *hdr) { return hdr ? 1.0f / (wino_pair_vscale(hdr) * __uint_as_float(hdr[1])) : 1.0f; }
+
+// max |x| over a tensor into hdr[0] (zeroed by the caller): non-negative floats order like their bit patterns
+__global__ __launch_bounds__(256) void wino_amax_kernel(const float4 *__restrict__ x, size_t n4, unsigned *out) {
+  float m = 0.f;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = x[t];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// In place: n fp32 values -> fp16 (hi, lo) pairs of s * x in the IVX_F16_PAIR order, s from hdr[0] = bits of max |x| (one thread per 16
+// values: it reads its 64 bytes before it writes them); thread 0 leaves s in hdr[1].
+__global__ __launch_bounds__(256) void wino_pair_inplace_kernel(float *buf, size_t n16, unsigned *hdr) {
+  const float s = wino_pow2_scale(__uint_as_float(hdr[0]), 0.f);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) hdr[1] = __float_as_uint(s);
+  if (t >= n16) return;
+  float4 v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const float4 *>(buf)[4 * t + q];
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 hi[2], lo[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float y = __builtin_fminf(__builtin_fmaxf(x[e] * s, -65504.f), 65504.f);
+      const _Float16 h = (_Float16)y;
+      hi[q >> 1][(q & 1) * 4 + e] = h;
+      lo[q >> 1][(q & 1) * 4 + e] = (_Float16)(y - (float)h);
+    }
+  }
+  h8 *o = reinterpret_cast<h8 *>(buf + 16 * t);
+  o[0] = hi[0]; o[1] = hi[1]; o[2] = lo[0]; o[3] = lo[1];
+}
 
 // channel vectors: 4 floats per thread for m = 2, 2 for m = 4 (36 live values per thread instead of 16)
 template <int W> struct VecT;
@@ -148,15 +205,30 @@ template <typename V> struct Wino1D<6, V> {
 };
 
 // V = Bt d B.  One thread: VW channels of one (b, tx, ty, z); xi plane stride = all threads.
-template <int MT, int VW>
+typedef _Float16 wf16x2 __attribute__((ext_vector_type(2)));
+// (hi, lo) fp16 halves of two scaled values, saturating: hi = fp16(x), lo = fp16(x - hi)
+__device__ __forceinline__ void wino_pair2(const float2 v, const float s, unsigned *hi, unsigned *lo) {
+  const float x0 = __builtin_fminf(__builtin_fmaxf(v.x * s, -65504.f), 65504.f), x1 = __builtin_fminf(__builtin_fmaxf(v.y * s, -65504.f), 65504.f);
+  wf16x2 h, l;
+  h[0] = (_Float16)x0;
+  h[1] = (_Float16)x1;
+  l[0] = (_Float16)(x0 - (float)h[0]);
+  l[1] = (_Float16)(x1 - (float)h[1]);
+  *hi = __builtin_bit_cast(unsigned, h);
+  *lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int MT, int VW, int PAIR = 0>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
   typedef typename VecT<VW>::T V;
   constexpr int N = MT + 2;
+  static_assert(!PAIR || VW == 2, "pair operands: two channels per lane (one dword of hi, one of lo)");
   const int CV = p.C / VW;
   const long long per_tile = (long long)p.Z * CV;                    // contiguous vectors of one (x, y) column
   const long long total = (long long)p.B * p.TX * p.TY * per_tile;   // = vectors per xi plane
   const V *in = reinterpret_cast<const V *>(p.in);
   V *Vw = reinterpret_cast<V *>(p.V);
+  const float vscale = PAIR ? wino_pair_vscale(p.hdr) : 1.0f;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const long long zc = t % per_tile;
     long long q = t / per_tile;
@@ -185,8 +257,23 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
     for (int i = 0; i < N; ++i) {   // rows: (Bt d) B
       V v[N];
       Wino1D<MT, V>::in(w[i], v);
+      if constexpr (PAIR) {
+        // IVX_F16_PAIR order inside the plane: per voxel and 16 channels [hi x16 | lo x16]; this lane owns channels 2cv, 2cv + 1, i.e.
+        // dword (cv / 8) * 16 + cv % 8 of the voxel's C dwords for hi and 8 further for lo (same bytes per plane as fp32)
+        const int cv = (int)(zc % CV);
+        const long long dw = 2 * (t - cv) + ((cv >> 3) << 4) + (cv & 7);
+        unsigned *Vp = reinterpret_cast<unsigned *>(p.V);
 #pragma unroll
-      for (int j = 0; j < N; ++j) Vw[(long long)(N * i + j) * (p.vs / VW) + t] = v[j];
+        for (int j = 0; j < N; ++j) {
+          unsigned hi, lo;
+          wino_pair2(v[j], vscale, &hi, &lo);
+          Vp[(long long)(N * i + j) * p.vs + dw] = hi;
+          Vp[(long long)(N * i + j) * p.vs + dw + 8] = lo;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) Vw[(long long)(N * i + j) * (p.vs / VW) + t] = v[j];
+      }
     }
   }
 }
@@ -218,6 +305,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
   const V *Mw = reinterpret_cast<const V *>(p.Mw);
   const V *res = reinterpret_cast<const V *>(p.res);
   V *out = reinterpret_cast<V *>(p.out);
+  const float mscale = wino_mscale(p.hdr);
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const long long zc = t % per_tile;
     const int cv = (int)(zc % CV);
@@ -237,7 +325,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
 #pragma unroll
       for (int a = 0; a < MT; ++a) r[a][j] = y[a];
     }
-    const V sc = p.scale ? reinterpret_cast<const V *>(p.scale)[cv] : vone((V *)nullptr);
+    const V sc = mscale * (p.scale ? reinterpret_cast<const V *>(p.scale)[cv] : vone((V *)nullptr));   // mscale 1 (fp32 operands): exact
     const V sf = p.shift ? reinterpret_cast<const V *>(p.shift)[cv] : vzero((V *)nullptr);
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
@@ -365,6 +453,7 @@ __global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), 0, p.res ? out_bytes : 0u, 0x00020000);
   const unsigned ps = (unsigned)(p.ms * 4);                 // plane stride in bytes
+  const float mscale = wino_mscale(p.hdr);
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const long long zc = t % per_tile;
     const int cv = (int)(zc % CV);
@@ -374,7 +463,7 @@ __global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p
     const int tx = (int)(q % p.TX);
     const int b = (int)(q / p.TX);
     const unsigned vo = (unsigned)(t * EB);
-    const V sc = p.scale ? reinterpret_cast<const V *>(p.scale)[cv] : vone((V *)nullptr);     // (uniform branches BEFORE the column loop)
+    const V sc = mscale * (p.scale ? reinterpret_cast<const V *>(p.scale)[cv] : vone((V *)nullptr));     // (uniform branches BEFORE the column loop)
     const V sf = p.shift ? reinterpret_cast<const V *>(p.shift)[cv] : vzero((V *)nullptr);
     V acc[MT][MT];
 #pragma unroll
@@ -406,11 +495,12 @@ __global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p
 // 1: k = (ci/32)*KW*32 + kz*32 + ci%32), i.e. each xi holds a packed 1x1xKW filter bank.
 template <int MT>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int Co, int KW, int Ci,
-                                                          int kmode) {
+                                                          int kmode, unsigned *amax) {
   constexpr int N = MT + 2;
   const long long total = (long long)Co * KW * Ci;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) t = total - 1;   // surplus threads of the last block repeat its last item (same values stored twice): the wave
+                                   // reduction below needs every lane
   const int ci = (int)(t % Ci);
   const int kz = (int)((t / Ci) % KW);
   const int co = (int)(t / ((long long)Ci * KW));
@@ -425,13 +515,22 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restric
     for (int i = 0; i < N; ++i) h[i][e] = c[i];
   }
   const long long K = (long long)KW * Ci;
+  float umax = 0.f;
   const long long k = kmode == 1 ? ((long long)(ci >> 5) * KW + kz) * 32 + (ci & 31) : (long long)kz * Ci + ci;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     float u[N];
     Wino1D<MT, float>::wgt(h[i], u);
 #pragma unroll
-    for (int j = 0; j < N; ++j) U[((long long)(N * i + j) * Co + co) * K + k] = u[j];
+    for (int j = 0; j < N; ++j) {
+      U[((long long)(N * i + j) * Co + co) * K + k] = u[j];
+      umax = fmaxf(umax, fabsf(u[j]));
+    }
+  }
+  if (amax) {   // pair operands: max |U| for the filter scale (wino_pair_inplace_kernel converts the planes afterwards)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) umax = fmaxf(umax, __shfl_xor(umax, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(umax));
   }
 }
 
@@ -456,6 +555,9 @@ int wino_dims(const ivx_conv_desc *d, int tile, WinoDims *w, const char *who) {
   IVX_REQUIRE(d->B > 0 && d->D > 0 && d->H > 0 && d->W > 0, "%s: non-positive dims", who);
   IVX_REQUIRE(d->Cin > 0 && d->Cin % 4 == 0 && d->Cout > 0 && d->Cout % 4 == 0, "%s: Cin and Cout must be multiples of 4", who);
   IVX_REQUIRE(d->in_dtype == IVX_F32 && d->out_dtype == IVX_F32, "%s: fp32 only", who);
+  IVX_REQUIRE(d->wino_operands == IVX_F32 || (d->wino_operands == IVX_F16_PAIR && tile >= 4 && d->Cin % 16 == 0 &&
+                                               (d->wgt_layout == 0 || d->Cin % 32 == 0)),
+              "%s: wino_operands is IVX_F32 or IVX_F16_PAIR (tile 4 / 6, Cin %% 16 == 0; wgt_layout 1: Cin %% 32 == 0)", who);
   IVX_REQUIRE(d->out_mode == 0 && (d->res_mode == 0 || d->res_mode == 1), "%s: out_mode 0 and res_mode 0/1 only", who);
   IVX_REQUIRE(d->wgt_layout == 0 || (d->wgt_layout == 1 && d->Cin % 32 == 0), "%s: wgt_layout 1 needs Cin %% 32 == 0", who);
   int32_t Xo, Yo, Zo;
@@ -504,7 +606,8 @@ extern "C" int ivx_conv_winograd_supported(const ivx_conv_desc *d, int32_t tile)
 extern "C" int64_t ivx_conv_winograd_weight_elems(const ivx_conv_desc *d, int32_t tile) {
   WinoDims w;
   if (wino_dims(d, tile, &w, "ivx_conv_winograd_weight_elems") != IVX_OK) return -1;
-  return (int64_t)w.n2 * d->Cout * d->KW * d->Cin;
+  // pair operands: one more plane whose first two words hold {bits of max |U|, the filter scale}
+  return (int64_t)(w.n2 + (d->wino_operands == IVX_F16_PAIR ? 1 : 0)) * d->Cout * d->KW * d->Cin;
 }
 
 extern "C" int ivx_conv_winograd_weights(const ivx_conv_desc *d, int32_t tile, const float *wgt, float *u, ivx_stream_t stream) {
@@ -514,12 +617,22 @@ extern "C" int ivx_conv_winograd_weights(const ivx_conv_desc *d, int32_t tile, c
   IVX_REQUIRE(wgt && u, "ivx_conv_winograd_weights: null argument");
   const int64_t total = (int64_t)d->Cout * d->KW * d->Cin;
   const dim3 grid((unsigned)((total + 255) / 256));
+  const bool pair = d->wino_operands == IVX_F16_PAIR;
+  unsigned *hdr = pair ? reinterpret_cast<unsigned *>(u + (int64_t)w.n2 * total) : nullptr;
+  if (pair && hipMemsetAsync(hdr, 0, 8, (hipStream_t)stream) != hipSuccess) {
+    ivx_set_error("ivx_conv_winograd_weights: hipMemsetAsync failed");
+    return IVX_ERR_HIP;
+  }
   if (tile == 2)
-    hipLaunchKernelGGL(wino_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout);
+    hipLaunchKernelGGL(wino_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout, hdr);
   else if (tile == 4)
-    hipLaunchKernelGGL(wino_weight_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout);
+    hipLaunchKernelGGL(wino_weight_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout, hdr);
   else
-    hipLaunchKernelGGL(wino_weight_kernel<6>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout);
+    hipLaunchKernelGGL(wino_weight_kernel<6>, grid, dim3(256), 0, (hipStream_t)stream, wgt, u, d->Cout, d->KW, d->Cin, d->wgt_layout, hdr);
+  if (pair) {
+    const size_t n16 = (size_t)w.n2 * total / 16;
+    hipLaunchKernelGGL(wino_pair_inplace_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, n16, hdr);
+  }
   IVX_CHECK_LAUNCH("ivx_conv_winograd_weights");
   return IVX_OK;
 }
@@ -527,7 +640,7 @@ extern "C" int ivx_conv_winograd_weights(const ivx_conv_desc *d, int32_t tile, c
 extern "C" int64_t ivx_conv_winograd_workspace_bytes(const ivx_conv_desc *d, int32_t tile) {
   WinoDims w;
   if (wino_dims(d, tile, &w, "ivx_conv_winograd_workspace_bytes") != IVX_OK) return -1;
-  return ivx_align_up(w.n2 * w.v_stride * 4, 256) + ivx_align_up(w.n2 * w.m_stride * 4, 256);
+  return ivx_align_up(w.n2 * w.v_stride * 4, 256) + ivx_align_up(w.n2 * w.m_stride * 4, 256) + 256;   // + the pair-operand header
 }
 
 namespace {
@@ -556,6 +669,9 @@ int wino_setup(const ivx_conv_desc *d, int tile, const void *in, const float *sc
   p->TX = w->TX; p->TY = w->TY; p->px = d->pd; p->py = d->ph;
   p->relu = d->relu; p->res_mode = d->res_mode; p->res_after_act = d->res_after_act;
   p->post_scale = d->post_scale == 0.f ? 1.0f : d->post_scale;
+  p->hdr = d->wino_operands == IVX_F16_PAIR
+               ? (const unsigned *)((char *)workspace + ivx_align_up(w->n2 * w->v_stride * 4, 256) + ivx_align_up(w->n2 * w->m_stride * 4, 256))
+               : nullptr;
   return IVX_OK;
 }
 }  // namespace
@@ -569,7 +685,21 @@ extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *d, int32_t tile, con
   IVX_REQUIRE(in, "ivx_conv_winograd_input: null argument");
   int rc = wino_setup(d, tile, in, nullptr, nullptr, &dummy, &dummy, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_input");
   if (rc != IVX_OK) return rc;
-  if (tile == 2)
+  if (d->wino_operands == IVX_F16_PAIR) {
+    // max |input| -> header word 0 (the scale of V is derived from it on the device: no host round trip)
+    if (hipMemsetAsync((void *)p.hdr, 0, 4, (hipStream_t)stream) != hipSuccess) {
+      ivx_set_error("ivx_conv_winograd_input: hipMemsetAsync failed");
+      return IVX_ERR_HIP;
+    }
+    const size_t n4 = (size_t)d->B * d->D * d->H * d->W * d->Cin / 4;
+    const size_t ab = (n4 + 255) / 256;
+    hipLaunchKernelGGL(wino_amax_kernel, dim3((unsigned)(ab > 4096 ? 4096 : ab)), dim3(256), 0, (hipStream_t)stream, (const float4 *)in, n4,
+                       (unsigned *)p.hdr);
+    if (tile == 4)
+      hipLaunchKernelGGL((wino_input_kernel<4, 2, 1>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL((wino_input_kernel<6, 2, 1>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
+  } else if (tile == 2)
     hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wino_blocks(w.v_elems / 4)), dim3(256), 0, (hipStream_t)stream, p);
   else if (tile == 4)
     hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
@@ -589,9 +719,16 @@ extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *d, int32_t tile, cons
   IVX_REQUIRE(u, "ivx_conv_winograd_gemm: null argument");
   int rc = wino_setup(d, tile, &dummy, nullptr, nullptr, &dummy, &dummy, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_gemm");
   if (rc != IVX_OK) return rc;
-  const ivx_conv_desc g = wino_group_desc(d, w);
-  rc = ivx_conv_grouped_launch(&g, w.n2, p.V, w.v_stride, u, (long long)d->Cout * d->KW * d->Cin, p.Mw, w.m_stride, (hipStream_t)stream);
+  ivx_conv_desc g = wino_group_desc(d, w);
+  const long long el = d->wino_operands == IVX_F16_PAIR ? 2 : 1;   // operand strides count stored elements (two fp16 per value)
+  g.in_dtype = d->wino_operands;
+  rc = ivx_conv_grouped_launch(&g, w.n2, p.V, el * w.v_stride, u, el * d->Cout * d->KW * d->Cin, p.Mw, w.m_stride, (hipStream_t)stream);
   if (rc != IVX_OK) return rc;
+  if (p.hdr && hipMemcpyAsync((void *)(p.hdr + 1), u + (int64_t)w.n2 * d->Cout * d->KW * d->Cin + 1, 4, hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream) != hipSuccess) {   // the filter scale travels with the filters; the output transform reads it here
+    ivx_set_error("ivx_conv_winograd_gemm: hipMemcpyAsync failed");
+    return IVX_ERR_HIP;
+  }
   IVX_CHECK_LAUNCH("ivx_conv_winograd_gemm");
   return IVX_OK;
 }

@@ -121,6 +121,7 @@ def model_cfg(model, with_trunk=True, winograd=None, winograd_tile=None):
             cfg.head_use_rotate_nms = int(bool(tc.get('use_rotate_nms', False)))
     cfg.winograd = int(FusedConv.winograd if winograd is None else winograd)
     cfg.winograd_tile = int(FusedConv.winograd_tile if winograd_tile is None else winograd_tile)
+    cfg.wino_operands = int(FusedConv.wino_operands)
     return cfg
 
 

@@ -82,11 +82,17 @@ def from_channels_last(x, ndim_spatial=3):
 # ------------------------------------------------------------------ conv
 def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0), relu=False,
              res=None, res_mode=0, naive=False, out=None, wgt_layout=0, out_mode=0, res_after_act=False, post_scale=1.0,
-             out_dtype=None, res_scale=1.0):
+             out_dtype=None, res_scale=1.0, pair=False):
     """x [B,D,H,W,Cin], wgt [Cout,KD,KH,KW,Cin] (packed), scale/shift [Cout] -> [B,Do,Ho,Wo,Cout].
     x and wgt are fp32 (the reference's precision), both bf16, or both e4m3 bytes (torch.float8_e4m3fn; the caller folds the
     tensors' scales into scale / shift / res_scale, see ivx_conv_desc); out_dtype (default: x.dtype) is the storage type of
-    the output and of the residual.  Accumulation and the epilogue are fp32 in every case."""
+    the output and of the residual.  Accumulation and the epilogue are fp32 in every case.
+    pair=True: x and wgt are IVX_BF16_PAIR operands (bf16_pair_split / conv.pack_pair_weights: bf16 tensors with 2*Cin stored
+    elements per voxel / tap); the output defaults to fp32."""
+    if pair:
+        if x.dtype != torch.bfloat16 or x.shape[4] % 32:
+            raise TypeError('pair=True takes the bf16 tensor made by bf16_pair_split (2 * Cin elements per voxel, Cin % 16 == 0)')
+        out_dtype = torch.float32 if out_dtype is None else out_dtype
     if x.dtype not in _DT:
         raise TypeError(f'x must be float32, bfloat16 or float8_e4m3fn, got {x.dtype}')
     out_dtype = x.dtype if out_dtype is None else out_dtype
@@ -100,9 +106,9 @@ def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1),
     want = (kernel[0], kernel[1], kernel[2], Cin) if wgt_layout == 0 else (Cin // ck, kernel[0], kernel[1], kernel[2], ck)
     if tuple(wgt.shape[1:]) != want:
         raise ValueError(f'weight shape {tuple(wgt.shape)} does not match kernel {kernel} / Cin {Cin} / layout {wgt_layout}')
-    d = ConvDesc(B, D, H, W, Cin, Cout, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
+    d = ConvDesc(B, D, H, W, Cin // 2 if pair else Cin, Cout, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
                  padding[0], padding[1], padding[2], int(bool(relu)), 0, 0, 0, int(wgt_layout), int(out_mode), int(bool(res_after_act)), float(post_scale),
-                 _DT[x.dtype], _DT[out_dtype], float(res_scale))
+                 IVX_BF16_PAIR if pair else _DT[x.dtype], _DT[out_dtype], float(res_scale))
     do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
     L = _lib.lib()
     check(L.ivx_conv_out_dims(C.byref(d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')
@@ -140,33 +146,63 @@ def conv_fwd(x, wgt, scale=None, shift=None, kernel=(1, 1, 1), stride=(1, 1, 1),
     return out
 
 
-def _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, res_mode=0, res_after_act=False, post_scale=1.0):
+IVX_BF16_PAIR = 3
+
+
+def bf16_pair_split(x, out=None):
+    """fp32 [..., C] (C % 16 == 0, contiguous) -> the IVX_BF16_PAIR operand: bf16 [..., 2C], per 16 channels [hi x16 | lo x16] with
+    hi = bf16(x), lo = bf16(x - hi)  (ivx_bf16_pair_split)."""
+    _chk(x, 'x')
+    if x.shape[-1] % 16:
+        raise ValueError('the channel count must be a multiple of 16')
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (2 * x.shape[-1],), device=x.device, dtype=torch.bfloat16)
+    else:
+        _chk(out, 'out', torch.bfloat16)
+    check(_lib.lib().ivx_bf16_pair_split(_ptr(x), x.numel(), _ptr(out), _stream()), 'ivx_bf16_pair_split')
+    return out
+
+
+def conv_pair_supported(x_shape, Cout, kernel, stride, padding, wgt_layout=1):
+    """True when the fp32 convolution can run in the split-operand (bf16 pair) form: ivx_conv_pair_supported."""
+    B, D, H, W, Cin = x_shape
+    d = ConvDesc(B, D, H, W, Cin, Cout, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
+                 0, 0, 0, 0, int(wgt_layout), 0, 0, 1.0, 0, 0, 1.0)
+    return bool(_lib.lib().ivx_conv_pair_supported(C.byref(d)))
+
+
+IVX_F16_PAIR = 4
+
+
+def _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, res_mode=0, res_after_act=False, post_scale=1.0, operands=0):
     return ConvDesc(B, D, H, W, Cin, Cout, 3, 3, kw, 1, 1, stride_w, padding[0], padding[1], padding[2], int(bool(relu)),
-                    int(res_mode), 0, 0, int(wgt_layout), 0, int(bool(res_after_act)), float(post_scale), 0, 0)
+                    int(res_mode), 0, 0, int(wgt_layout), 0, int(bool(res_after_act)), float(post_scale), 0, 0, 1.0, int(operands))
 
 
-def conv_winograd_supported(x_shape, Cout, kernel, stride, padding, tile=2):
+def conv_winograd_supported(x_shape, Cout, kernel, stride, padding, tile=2, operands=0):
     """True when ivx_conv_winograd_fwd can run this fp32 convolution (3x3xKW, stride 1 on the first two axes, planes < 2 GiB)."""
     if kernel[0] != 3 or kernel[1] != 3 or stride[0] != 1 or stride[1] != 1 or x_shape[4] % 4 or Cout % 4 or tile not in (2, 4, 6):
         return False
     B, D, H, W, Cin = x_shape
-    d = _wino_desc(B, D, H, W, Cin, Cout, kernel[2], stride[2], padding, False, 0)
+    d = _wino_desc(B, D, H, W, Cin, Cout, kernel[2], stride[2], padding, False, 0, operands=operands)
     return bool(_lib.lib().ivx_conv_winograd_supported(C.byref(d), tile))
 
 
-def conv_winograd_weights(wgt, wgt_layout, tile=2):
+def conv_winograd_weights(wgt, wgt_layout, tile=2, operands=0):
     """wgt [Cout,3,3,KW,Cin] fp32 (layout 0, on the device) -> transformed filters u [(tile+2)^2, Cout, KW*Cin] whose K order
-    is `wgt_layout` (0: tap-major, 1: 32-channel chunks)."""
+    is `wgt_layout` (0: tap-major, 1: 32-channel chunks).  operands = IVX_F16_PAIR: the same bytes hold fp16 (hi, lo) pairs
+    (ivx_conv_desc.wino_operands); pass the same value to conv_winograd_fwd."""
     _chk(wgt, 'wgt')
     Cout, kd, kh, kw, Cin = wgt.shape
     if kd != 3 or kh != 3:
         raise ValueError('Winograd F(m x m, 3x3) needs a 3x3 kernel on the first two axes')
-    d = _wino_desc(1, 4, 4, max(kw, 1), Cin, Cout, kw, 1, (1, 1, kw // 2), False, wgt_layout)
+    d = _wino_desc(1, 4, 4, max(kw, 1), Cin, Cout, kw, 1, (1, 1, kw // 2), False, wgt_layout, operands=operands)
     L = _lib.lib()
     n = L.ivx_conv_winograd_weight_elems(C.byref(d), tile)
     if n < 0:
         check(-1, 'ivx_conv_winograd_weight_elems')
-    u = torch.empty(((tile + 2) ** 2, Cout, kw * Cin), device=wgt.device, dtype=torch.float32)
+    # pair operands: one more plane (it carries the filter scale); the same bytes then hold fp16 pairs
+    u = torch.empty(((tile + 2) ** 2 + (1 if operands else 0), Cout, kw * Cin), device=wgt.device, dtype=torch.float32)
     assert u.numel() == n
     check(L.ivx_conv_winograd_weights(C.byref(d), tile, _ptr(wgt), _ptr(u), _stream()), 'ivx_conv_winograd_weights')
     return u
@@ -177,18 +213,18 @@ winograd_trace = None
 
 
 def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1, 1, 1), relu=False, res=None, out=None,
-                      wgt_layout=0, res_after_act=False, post_scale=1.0):
+                      wgt_layout=0, res_after_act=False, post_scale=1.0, operands=0):
     """Same result as conv_fwd for a 3x3xkw kernel with stride (1,1,stride_w), computed in the F(m x m, 3x3) minimal-filtering
     form (fp32).  x [B,D,H,W,Cin]; u from conv_winograd_weights (its first dimension, 16 / 36 / 64, selects m = 2 / 4 / 6)."""
     _chk(x, 'x')
     _chk(u, 'u')
     B, D, H, W, Cin = x.shape
     Cout = u.shape[1]
-    tile = {16: 2, 36: 4, 64: 6}.get(u.shape[0])
-    if tile is None or tuple(u.shape) != ((tile + 2) ** 2, Cout, kw * Cin):
+    tile = {16: 2, 36: 4, 64: 6}.get(u.shape[0] - (1 if operands else 0))
+    if tile is None or tuple(u.shape[1:]) != (Cout, kw * Cin):
         raise ValueError(f'transformed filters {tuple(u.shape)} do not match kw {kw} / Cin {Cin}')
     d = _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, 1 if res is not None else 0, res_after_act,
-                   post_scale)
+                   post_scale, operands)
     do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
     L = _lib.lib()
     check(L.ivx_conv_out_dims(C.byref(d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')
@@ -225,7 +261,7 @@ def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1
     ev[3].record()
     tiles = B * ((oshape[1] + tile - 1) // tile) * ((oshape[2] + tile - 1) // tile)
     winograd_trace.append(('input', ev[0], ev[1], 0.0))
-    winograd_trace.append(('gemm', ev[1], ev[2], 2.0 * u.shape[0] * tiles * oshape[3] * Cout * kw * Cin))
+    winograd_trace.append(('gemm', ev[1], ev[2], (3.0 if operands else 1.0) * 2.0 * (tile + 2) ** 2 * tiles * oshape[3] * Cout * kw * Cin))
     winograd_trace.append(('output', ev[2], ev[3], 0.0))
     return out
 
@@ -235,11 +271,11 @@ class WinogradLayerPlan:
     size, with the three stages as separate calls on caller-owned buffers (tools/gemm_ab.py times them one by one)."""
 
     def __init__(self, x_shape, Cout, kw, stride_w, padding, relu, wgt_layout, tile, has_res=False, res_after_act=False,
-                 post_scale=1.0):
+                 post_scale=1.0, operands=0):
         B, D, H, W, Cin = x_shape
         self.tile = int(tile)
         self.d = _wino_desc(B, D, H, W, Cin, Cout, kw, stride_w, padding, relu, wgt_layout, 1 if has_res else 0, res_after_act,
-                            post_scale)
+                            post_scale, operands)
         do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
         L = _lib.lib()
         check(L.ivx_conv_out_dims(C.byref(self.d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')

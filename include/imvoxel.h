@@ -37,7 +37,7 @@ extern "C" {
 
 typedef void *ivx_stream_t; /* hipStream_t */
 
-/* Library version (major*10000 + minor*100 + patch; 300 = 0.3.0, the struct layouts of this header) and the message of
+/* Library version (major*10000 + minor*100 + patch; 301 = 0.3.1, the struct layouts of this header) and the message of
  * the last failing call on this thread (never NULL). */
 int ivx_version(void);
 const char *ivx_last_error(void);
@@ -69,6 +69,22 @@ const char *ivx_last_error(void);
 #define IVX_F32 0
 #define IVX_BF16 1
 #define IVX_FP8 2      /* OCP e4m3 bytes (gfx950) with a per-tensor scale kept by the caller: see res_scale below */
+/* in_dtype only.  Split-operand fp32: every fp32 value x of `in` and `wgt` is stored as the bf16 pair hi = bf16(x),
+ * lo = bf16(x - hi) (round to nearest even; hi + lo carries 16 significant bits of x), channels in groups of 16 as
+ * [hi c0..c15 | lo c0..c15] (4 bytes per value, like fp32).  The contraction issues hi*hi + hi*lo + lo*hi on the bf16 matrix
+ * cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate) with fp32 accumulation: products are exact in fp32, the dropped lo*lo
+ * term and the pair rounding are each <= 2^-17 of the product -- 64x finer than the TF32 operands the reference's cuDNN
+ * convolutions use by default on its published GPUs, and below the rounding of the F(6x6,3x3) form of the fp32 path (measured in
+ * DESIGN.md 4.1e).  Cin (real channels) % 16 == 0; wgt_layout 1 needs Cin % 32 == 0 (64 stored elements per 128-byte chunk);
+ * out_mode 0; out / res / scale / shift as for IVX_F32 input.  ivx_bf16_pair_split makes the activation operand, the caller packs
+ * the filters the same way once (imvoxelnet_amd/conv.py: pack_pair_weights). */
+#define IVX_BF16_PAIR 3
+/* The same with fp16 halves: hi = fp16(s*x), lo = fp16(s*x - hi) for a power-of-two tensor scale s kept by the caller (folded into
+ * scale[] like the fp8 scales).  hi + lo carries 22 significant bits (pair rounding <= 2^-23, dropped lo*lo <= 2^-22 of a product:
+ * fp32-level), at the price of fp16's range: |s*x| must stay below 65504 (ivx_f16_pair_split saturates) and values below
+ * 2^-14 * 2^11 = 0.125 lose relative (not absolute: fp16 subnormals, spacing 2^-24) precision in lo.  Used by the Winograd-domain
+ * GEMMs (ivx_conv_desc.wino_operands), where operand precision is amplified by the output transform and bf16 pairs are not enough. */
+#define IVX_F16_PAIR 4
 typedef struct ivx_conv_desc {
   int32_t B, D, H, W, Cin;
   int32_t Cout, KD, KH, KW;
@@ -82,12 +98,20 @@ typedef struct ivx_conv_desc {
                             (out is [B,2D,2H,2W,C]; scale/shift have C entries; res, if any, has the out shape) */
   int32_t res_after_act; /* 1: the residual is added after the ReLU (skip adds of the U-shaped necks) */
   float post_scale;      /* final multiplier, 0 or 1 = none (Atlas neck: (x + y) / 2) */
-  int32_t in_dtype;      /* IVX_F32 (default), IVX_BF16 or IVX_FP8: element type of in and wgt */
+  int32_t in_dtype;      /* IVX_F32 (default), IVX_BF16, IVX_FP8 or IVX_BF16_PAIR: element type of in and wgt */
   int32_t out_dtype;     /* IVX_F32 (default), IVX_BF16 or IVX_FP8: element type of out and res */
   float res_scale;       /* multiplier of the residual before it is added, 0 or 1 = none.  IVX_FP8 tensors are e4m3 bytes with a
                             per-tensor scale kept by the caller (x = byte_value * s_x): the caller folds s_in * s_wgt[co] / s_out
                             into scale[], 1 / s_out into shift[] and passes res_scale = s_res / s_out; the store saturates at
                             +-448 and rounds to nearest even.  fp8 input needs Cin % 16 == 0 (wgt_layout 1: Cin % 128 == 0). */
+  int32_t wino_operands; /* ivx_conv_winograd_* only (in / out stay fp32): operand type of the transformed-domain GEMMs.  IVX_F32 (0,
+                            default): fp32 MFMA, exact fp32 arithmetic.  IVX_F16_PAIR: the input / filter transforms write V and U as
+                            fp16 (hi, lo) pairs (power-of-two scales taken from max |in| / max |U| on the device, undone exactly by the
+                            output transform; the workspace's last 256 bytes carry them between the stages) and the GEMMs issue three
+                            fp16 MFMA products per pair -- same bytes, ~3.3x the GEMM rate, error at the level of the fp32 form's own
+                            rounding.  Needs tile 4 or 6 and Cin % 16 == 0 (wgt_layout 1: Cin % 32 == 0).  Filters
+                            made by ivx_conv_winograd_weights carry the operand type they were made with
+                            (ivx_conv_winograd_weight_elems counts one more plane for the pair form: it holds the filter scale). */
 } ivx_conv_desc;
 
 int ivx_conv_out_dims(const ivx_conv_desc *d, int32_t *Do, int32_t *Ho, int32_t *Wo);
@@ -99,6 +123,14 @@ int ivx_conv_fwd(const ivx_conv_desc *d, const void *in, const void *wgt, const 
 int64_t ivx_conv_workspace_bytes(const ivx_conv_desc *d);
 int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale, const float *shift,
                     const void *res, void *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
+
+/* fp32 [n] -> bf16 pairs [2n] in the IVX_BF16_PAIR order (n % 16 == 0; channels-last tensors with C % 16 == 0 keep their shape
+ * with 2C stored elements per voxel).  A streaming kernel: 4 bytes read + 4 written per value.
+ * ivx_conv_pair_supported: 1 when ivx_conv_fwd_ws can run the fp32 convolution `d` (in_dtype / out_dtype IVX_F32) in the pair form,
+ * i.e. with in_dtype = IVX_BF16_PAIR on operands converted as above (channel multiples, 31-bit operand offsets, out_mode 0). */
+int ivx_bf16_pair_split(const float *in, int64_t n, void *out, ivx_stream_t stream);
+int ivx_f16_pair_split(const float *in, int64_t n, float scale, void *out, ivx_stream_t stream);   /* IVX_F16_PAIR of scale * in, saturating */
+int ivx_conv_pair_supported(const ivx_conv_desc *d);
 
 /* Validation kernel: same contract, one thread per output element, plain FMA loop. Used by the
  * GPU tests to cross-check the MFMA kernel at full size; never called by the product path.   */
@@ -456,6 +488,8 @@ typedef struct ivx_model_cfg {
   int32_t layout_head;             /* 1: LayoutHead(n_channels 2048, linear_size) on C5 (SUN RGB-D Total configs, dense_heads/layout_head.py);
                                       its predicted angles replace the extrinsics of the metas at test time; keys head_2d.{angle,layout}_mlp.* */
   int32_t layout_linear_size;
+  int32_t wino_operands;           /* (0.3.1) ivx_conv_desc.wino_operands of the layers that run in the Winograd form: IVX_F32 (0) = fp32 MFMA,
+                                      IVX_F16_PAIR = fp16 (hi, lo) operand pairs where the layer allows it (tile 4 / 6, Cin % 32 == 0) */
 } ivx_model_cfg;
 
 int ivx_create(const ivx_model_cfg *cfg, ivx_model **out);

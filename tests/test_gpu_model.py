@@ -1,4 +1,6 @@
 """-m gpu: whole-path parity of the MI355X ImVoxelNet against the CPU oracle (torch fp32 + C)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -269,35 +271,19 @@ def test_kitti_bf16_storage_mode_tracks_fp32(ia):
         assert abs(float(da['scores_3d'][0]) - float(db['scores_3d'][0])) < 0.05
 
 
-def test_graphed_simple_test_equals_eager(ia):
+def test_graphed_simple_test_equals_eager():
     """ImVoxelNet.capture_graph (default backend: hipGraph replay inside the native handle): the replay returns exactly the eager
-    results, also after the image and the camera parameters change (static input buffers are refreshed before every replay)."""
-    model = ia.build_detector(kitti_model_cfg(n_voxels=(104, 120, 12)), test_cfg=KITTI_TEST_CFG)
-    ia.randomize_(model, 21)
-    with torch.no_grad():
-        model.bbox_head.conv_cls.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(5))
-        model.bbox_head.conv_cls.bias.fill_(-1.0)
-        model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
-    model.prepare(torch.device('cuda'))
-    g = torch.Generator().manual_seed(3)
-    imgs = [torch.randn(2, 1, 3, 192, 640, generator=g).cuda() for _ in range(3)]
-    metas = [[kitti_meta(img_hw=(192, 640), t=(0.02 * k, 0.01 * b, 0.0), box_type=ia.LiDARInstance3DBoxes) for b in range(2)] for k in range(3)]
-    # eager references FIRST: on this ROCm stack a hipGraph replay (native or torch) can return garbage after a later fresh device
-    # allocation of a few hundred MB by the process (tools/graph_fragility.py; DESIGN 4.6), so nothing is allocated between
-    # capture and the replays below
-    refs = [model.simple_test(img, meta) for img, meta in zip(imgs, metas)]
-    torch.cuda.synchronize()
-    graphed = model.capture_graph(imgs[0], metas[0])
-    total = 0
-    for k in (2, 1, 0, 2):
-        got = graphed(imgs[k], metas[k])
-        for r, o in zip(refs[k], got):
-            assert torch.equal(r['scores_3d'], o['scores_3d']) and torch.equal(r['labels_3d'], o['labels_3d'])
-            assert torch.equal(r['boxes_3d'].tensor, o['boxes_3d'].tensor)
-            total += len(r['scores_3d'])
-    assert total > 0
-    with pytest.raises(ValueError):
-        graphed(imgs[0][:1], metas[0][:1])
+    results, also after the image and the camera parameters change (static input buffers are refreshed before every replay).
+    Runs in a FRESH process (tests/graph_replay_check.py): on this ROCm stack a hipGraph replay of this path can return garbage
+    depending on what the process did to device memory before (tools/graph_fragility.py) -- inside the full suite the
+    first replay after capture came back empty, alone it is exact -- so graph replay is opt-in and is tested where a host would use
+    it: captured early in the life of a process."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'graph_replay_check.py')
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and 'GRAPH_REPLAY_OK' in r.stdout
 
 
 def test_indoor_eval_on_device_matches_reference(ia):

@@ -28,7 +28,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) <= declared
     assert L.ivx_version() >= 100
     # struct layouts used by the ctypes binding match the header field counts
-    assert ctypes.sizeof(_lib.ConvDesc) == 26 * 4     # ivx_conv_desc: 22 int32 + float + 2 int32 dtypes + float res_scale
+    assert ctypes.sizeof(_lib.ConvDesc) == 27 * 4     # ivx_conv_desc: 22 int32 + float + 2 int32 dtypes + float res_scale + int32 wino_operands
     assert ctypes.sizeof(_lib.AnchorHeadDesc) == 17 * 4
 
 
@@ -63,11 +63,18 @@ def test_cabi_winograd_planning_without_gpu():
         assert L.ivx_conv_winograd_supported(ctypes.byref(d), tile) == 1
         assert L.ivx_conv_winograd_weight_elems(ctypes.byref(d), tile) == n2 * 256 * 3 * 256
         plane = 4 * tx * ty * 3 * 256 * 4                   # bytes of one transformed plane (input and output alike here)
-        assert L.ivx_conv_winograd_workspace_bytes(ctypes.byref(d), tile) == 2 * n2 * plane
+        assert L.ivx_conv_winograd_workspace_bytes(ctypes.byref(d), tile) == 2 * n2 * plane + 256     # + the pair-operand header
     assert L.ivx_conv_winograd_supported(ctypes.byref(d), 3) == 0 and b'tile' in L.ivx_last_error()
     # odd extents round the tile grid up; z stride / padding follow the direct rule
     d = desc(1, 9, 14, 12, 64, 128, sw=2)
-    assert L.ivx_conv_winograd_workspace_bytes(ctypes.byref(d), 4) == 36 * (3 * 4 * 12 * 64 + 3 * 4 * 6 * 128) * 4
+    assert L.ivx_conv_winograd_workspace_bytes(ctypes.byref(d), 4) == 36 * (3 * 4 * 12 * 64 + 3 * 4 * 6 * 128) * 4 + 256
+    # fp16-pair operands of the transformed-domain GEMMs: same planes, one more filter plane (the filter scale), tile 4 / 6 only
+    dp = desc(4, 216, 248, 3, 256, 256)
+    dp.wino_operands = 4
+    assert L.ivx_conv_winograd_supported(ctypes.byref(dp), 6) == 1 and L.ivx_conv_winograd_supported(ctypes.byref(dp), 2) == 0
+    assert L.ivx_conv_winograd_weight_elems(ctypes.byref(dp), 6) == 65 * 256 * 3 * 256
+    dp.Cin = 24
+    assert L.ivx_conv_winograd_supported(ctypes.byref(dp), 6) == 0
     # not eligible: stride on a transformed axis, 1x3x3 kernel given in (D,H,W) order, a plane of 2 GiB or more
     assert L.ivx_conv_winograd_supported(ctypes.byref(desc(1, 64, 64, 8, 64, 64, sd=2, sh=2)), 4) == 0
     assert L.ivx_conv_winograd_supported(ctypes.byref(desc(1, 1, 64, 64, 64, 64, kd=1, pad=(0, 1, 1))), 4) == 0
