@@ -338,6 +338,11 @@ def main():
                     help="what a timed step calls: 'simple_test' (default) = the drop-in public call ImVoxelNet.simple_test(img, img_metas) "
                          "(reference: tools/benchmark.py:74 model(return_loss=False, rescale=True, **data)); 'composed' = the same stages "
                          "called one by one with the packed D2H of round 1")
+    ap.add_argument('--wino-operands', default='f16pair', choices=['f16pair', 'f32'],
+                    help="operands of the Winograd-domain GEMMs of the neck: 'f16pair' (default) = every fp32 value as an fp16 (hi, lo) pair, three "
+                         "fp16 MFMA products per pair, fp32 accumulation (22-bit operands: error at the level of the fp32 form's own rounding); "
+                         "'f32' = fp32 MFMA (exact fp32 products).  The default run also times the other mode after the timed region and "
+                         "reports it as exact_fp32_mfma")
     args = ap.parse_args()
 
     # One process per GPU.  Under torch.distributed.run (the reference's launcher is tools/dist_test.sh:9-10,
@@ -395,10 +400,13 @@ def main():
         model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
         model.bbox_head.conv_dir_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(7))
     bf16 = args.storage == 'bf16'
-    ceil = measured_ceilings(dev, bf16) if os.environ.get('IVX_BENCH_UBENCH', '1') != '0' else {}
+    pair = args.wino_operands == 'f16pair' and not bf16
+    FusedConv.wino_operands = 4 if pair else 0
+    ceil = measured_ceilings(dev, bf16 or pair) if os.environ.get('IVX_BENCH_UBENCH', '1') != '0' else {}
     model.prepare(dev, dtype=torch.bfloat16 if bf16 else torch.float32)
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    peak_meas = ceil.get('mfma_bf16_tflops' if bf16 else 'mfma_f32_tflops')
+    # the pair form issues fp16 MFMAs (same rate as bf16): priced against the dense 16-bit MFMA peak, counting every product it issues
+    peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or pair) else PEAK_F32_MFMA_TFLOPS
+    peak_meas = ceil.get('mfma_bf16_tflops' if (bf16 or pair) else 'mfma_f32_tflops')
     hbm_meas = ceil.get('hbm_copy_gbps')
     esz = 2 if bf16 else 4
 
@@ -494,6 +502,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the same steps with fp32 MFMA in the transformed domain (exact fp32 products): a second native handle, timed after the region above
+    alt = None
+    if pair and args.api == 'simple_test' and model._native is not None and not multi and not args.graph and os.environ.get('IVX_BENCH_ALT', '1') != '0':
+        from imvoxelnet_amd import engine
+        recs_keep = model._native.trace_records() if native_trace else None
+        FusedConv.wino_operands = 0
+        keep, model._native = model._native, engine.NativeModel(model, dev)
+        FusedConv.wino_operands = 4
+        try:
+            for _ in range(min(3, max(1, args.warmup))):
+                out_alt = model.simple_test(img, metas)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(args.steps):
+                out_alt = model.simple_test(img, metas)
+            torch.cuda.synchronize()
+            ta = time.perf_counter() - ta
+        finally:
+            model._native = keep
+        same = [bool(len(a['scores_3d']) == len(b['scores_3d']) and torch.equal(a['labels_3d'], b['labels_3d'])
+                     and torch.allclose(a['scores_3d'], b['scores_3d'], atol=1e-4)) for a, b in zip(last, out_alt)]
+        alt = {'value': round(B * args.steps / ta, 3), 'unit': 'images/s', 'ms_per_step': round(ta / args.steps * 1e3, 3),
+               'note': 'bench.py --wino-operands f32: fp32 MFMA in the transformed domain (the round-2 arithmetic), same weights and images',
+               'detections_last_step': n_det(out_alt), 'same_detections_as_default': all(same)}
+
     ev_ids = range(args.warmup) if args.graph else range(args.warmup, args.warmup + args.steps)
     if args.graph and args.warmup > 1:
         ev_ids = range(1, args.warmup)       # skip the very first (cold) step
@@ -508,7 +541,7 @@ def main():
     KIND = {0: 'direct', 1: 'wino_input', 2: 'wino_gemm', 3: 'wino_output', 4: 'lift', 5: 'tail', 6: 'trunk2d'}
     per_step = []
     if native_trace:
-        recs = model._native.trace_records()
+        recs = recs_keep if alt is not None else model._native.trace_records()
         # graph replay (default): the stage events are nodes of the captured graph, re-recorded by every timed step; what is
         # read back after the timed region are the event pairs of its LAST step.  Eager handle: one record list per step.
         n_traced = 1 if model._native.graph else args.steps
@@ -564,23 +597,31 @@ def main():
                 traffic = None
             break
 
+    peak2d = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     if rank == 0:
         total_images = B * world * args.steps
         rec = {
             'metric': 'images/sec/node (KITTI 3x384x1280, 216x248x12 vox)',
             'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (f16-pair MFMA operands in the Winograd domain)' if pair else args.storage, 'data': 'synthetic',
             'config': {'workload': 'kitti_mono_1x3x384x1280_vox216x248x12_resnet50_fpn64_kittineck_anchor3dhead',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'hip_graph': bool(args.graph),
                        'api': ('hipGraph replay (%s)' % type(graphed).__name__) if args.graph else ('ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages'),
                        'device_side': ('native model handle (ivx_model_forward%s)' % (', hipGraph replay per shape' if model._native.graph else '')) if model._native is not None and args.api == 'simple_test' else 'layer-by-layer over the op-level C-ABI',
                        'stage_events': ('event-record nodes inside the replayed graph, read for the last timed step' if (native_trace and model._native.graph) else 'HIP event pairs around every launch of every timed step'),
+                       'neck_gemm_operands': ('fp16 (hi, lo) pairs of fp32 values: 3 fp16 MFMA products per pair, fp32 accumulate, device-side power-of-two scales '
+                                              '(ivx_conv_desc.wino_operands = IVX_F16_PAIR)') if pair else ('bf16' if bf16 else 'fp32 MFMA'),
                        'detections_last_step': n_det(last), 'rccl_ranks': rccl_ranks, 'ms_per_step_by_rank': rank_ms,
                        'collective': 'one all_gather_into_tensor of padded detections per step (RCCL)' if multi else None},
             'measured_ceilings': dict(ceil, note='csrc/ubench.hip at start-up: MFMA issue rate of the conv kernel\'s instruction, HBM copy rate '
                                                  '(read + written bytes) over 2 x 1 GiB') if ceil else None,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, %d launches/step)' % ('__bf16' if bf16 else 'float', n_launch),
+            'exact_fp32_mfma': alt,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, %d launches/step)' % ('__bf16' if bf16 else ('fp16 pair operands' if pair else 'float'), n_launch),
+                         'flops_counted': ('every fp16 MFMA product issued: 3 per fp32-equivalent multiply-add (hi*hi + hi*lo + lo*hi), priced against the dense '
+                                           '16-bit MFMA peak') if pair else 'one MFMA multiply-add per algorithmic multiply-add',
+                         'fp32_equivalent_tflops': round(achieved / 3, 2) if pair else None,
+                         'hbm_GBps_algorithmic': round(sum(t[4] for t in mfma) / nst / (mfma_ms * 1e-3) / 1e9, 1) if mfma_ms > 0 else None,
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4),
                          'peak_measured': peak_meas, 'frac_of_measured': round(achieved / peak_meas, 4) if peak_meas else None,
@@ -609,8 +650,9 @@ def main():
             'roofline_trunk_2d': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel (ResNet-50 + FPN level 0 + head conv; %s)' % (
                                       'one event pair around the whole trunk + one around the head conv' if native_trace else
                                       '%d launches/step, event-bracketed incl. their transform / split-K passes' % (len(t2d) // nst)),
-                                  'achieved': round(t2d_flops / (t2d_ms * 1e-3) / 1e12, 2) if t2d_ms > 0 else None, 'peak': peak, 'unit': 'TFLOP/s',
-                                  'frac': round(t2d_flops / (t2d_ms * 1e-3) / 1e12 / peak, 4) if t2d_ms > 0 else None,
+                                  'achieved': round(t2d_flops / (t2d_ms * 1e-3) / 1e12, 2) if t2d_ms > 0 else None, 'peak': peak2d, 'unit': 'TFLOP/s',
+                                  'frac': round(t2d_flops / (t2d_ms * 1e-3) / 1e12 / peak2d, 4) if t2d_ms > 0 else None,
+                                  'flops_counted': 'algorithmic multiply-adds of the executed form (direct / Winograd-domain), one per multiply-add; fp32 MFMA peak',
                                   'ms_per_step': round(t2d_ms, 3), 'executed_gflop_per_step': round(t2d_flops / 1e9, 1)},
         }
         if untraced:

@@ -21,6 +21,19 @@
 // Reference call sites replaced: see include/imvoxel.h (ivx_conv_fwd).
 #include "ivx_common.h"
 
+// This file is compiled five times (imvoxelnet_amd/_build.py), each translation unit instantiating one family of the LDS-DMA kernel, so that
+// the families build in parallel:  IVX_CONV_TU 0 = the host side, the generic / naive / reduce kernels;  1 = fp32;  2 = bf16 and e4m3;
+// 3 = bf16 (hi, lo) pair operands;  4 = fp16 pair operands.
+#ifndef IVX_CONV_TU
+#define IVX_CONV_TU 0
+#endif
+struct ConvParams;
+struct ConvPlan;
+int ivx_conv_launch_f32(ConvParams &p, const ConvPlan &pl, hipStream_t st);
+int ivx_conv_launch_lowp(ConvParams &p, const ConvPlan &pl, hipStream_t st);
+int ivx_conv_launch_pair_bf16(ConvParams &p, const ConvPlan &pl, hipStream_t st);
+int ivx_conv_launch_pair_f16(ConvParams &p, const ConvPlan &pl, hipStream_t st);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -893,6 +906,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
 
 // Epilogue + store of one output element (row m, column n) from its finished accumulator: shared by the validation
 // kernel and the split-K reduction.
+#if IVX_CONV_TU == 0
 __device__ __forceinline__ void conv_store_one(const ConvParams &p, int m, int n, float acc) {
   if (p.out_mode == 1) {
     const int tap = n / p.Cr, ch = n - tap * p.Cr;
@@ -1066,6 +1080,8 @@ static void launch_cfg(const ConvParams &p, hipStream_t st) {
   hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, WR, WC>), grid, dim3(256), 0, st, p);
 }
 
+#endif   // IVX_CONV_TU == 0
+
 template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE = 1, int PAIR = 0>
 static void launch_v4(ConvParams &p, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
@@ -1088,14 +1104,6 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
 
 
 
-static thread_local int g_tile_override = 0;
-// Tuning knob (A/B experiments, tools/conv_bench.py; per calling thread): 0 = automatic choice, else force a tile
-// config of launch_one (1..7 generic kernel, 41..53 LDS-DMA fp32, 61..73 LDS-DMA bf16).
-extern "C" int ivx_conv_set_tile_override(int cfg) {
-  g_tile_override = cfg;
-  return IVX_OK;
-}
-
 struct ConvPlan {
   int cfg;       // tile / kernel selector (see launch_one)
   int ksplit;    // > 1: split K over the whole problem (small outputs)
@@ -1105,6 +1113,16 @@ struct ConvPlan {
   int bm;        // tile rows of the chosen config
   int64_t ws_bytes;
 };
+
+
+#if IVX_CONV_TU == 0
+static thread_local int g_tile_override = 0;
+// Tuning knob (A/B experiments, tools/conv_bench.py; per calling thread): 0 = automatic choice, else force a tile
+// config of launch_one (1..7 generic kernel, 41..53 LDS-DMA fp32, 61..73 LDS-DMA bf16).
+extern "C" int ivx_conv_set_tile_override(int cfg) {
+  g_tile_override = cfg;
+  return IVX_OK;
+}
 
 struct TileInfo { int bm, bn, bk, wg_per_cu; };
 static bool tile_info(int cfg, TileInfo *t) {
@@ -1142,6 +1160,10 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 71: *t = {128, 128, 32, 3}; return true;
     case 73: *t = {128, 64, 32, 5}; return true;
     case 75: *t = {128, 64, 32, 5}; return true;
+    case 76: *t = {256, 64, 32, 4}; return true;
+    case 84: *t = {256, 128, 32, 2}; return true;
+    case 85: *t = {128, 256, 32, 2}; return true;
+    case 86: *t = {256, 256, 32, 2}; return true;
     case 72: *t = {256, 64, 32, 3}; return true;
     default: return false;
   }
@@ -1291,7 +1313,10 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
   return pl;
 }
 
+#endif   // IVX_CONV_TU == 0
+
 // pair operands (IVX_BF16_PAIR / IVX_F16_PAIR): the bf16 tiles with the three-product K loop
+#if IVX_CONV_TU == 3 || IVX_CONV_TU == 4
 template <int PAIR>
 static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
   switch (pl.cfg) {
@@ -1305,6 +1330,12 @@ static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 81: launch_v4<__bf16, 2, 2, 4, 2, 32, 4, PAIR>(p, st); break;
     case 82: launch_v4<__bf16, 2, 2, 4, 4, 32, 4, PAIR>(p, st); break;
     case 83: launch_v4<__bf16, 2, 2, 4, 2, 64, 2, PAIR>(p, st); break;
+    // larger wave tiles: fewer LDS fragment reads per product (the pair loop reads 4 fragments for 3 products; at 16x the fp32 MFMA rate
+    // the LDS port, shared by the DMA writes and the fragment reads, is as busy as the matrix pipe)
+    case 76: launch_v4<__bf16, 2, 2, 4, 1, 32, 4, PAIR>(p, st); break;   // 256 x 64, wave tile 64 x 64
+    case 84: launch_v4<__bf16, 4, 2, 2, 2, 32, 2, PAIR>(p, st); break;   // 256 x 128, 4 waves, wave tile 128 x 64
+    case 85: launch_v4<__bf16, 2, 4, 2, 2, 32, 2, PAIR>(p, st); break;   // 128 x 256, 4 waves, wave tile 64 x 128
+    case 86: launch_v4<__bf16, 4, 2, 2, 4, 32, 2, PAIR>(p, st); break;   // 256 x 256, 8 waves, wave tile 128 x 64
     default:
       ivx_set_error("ivx_conv_fwd: tile %d has no pair-operand instantiation (61, 63, 66, 67, 73, 74, 75, 81, 82, 83)", pl.cfg);
       return IVX_ERR_INVALID_ARG;
@@ -1312,16 +1343,16 @@ static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
   return IVX_OK;
 }
 
-static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
-  if (p.in_pair) return p.in_pair == 2 ? launch_pair<2>(p, pl, st) : launch_pair<1>(p, pl, st);
+#if IVX_CONV_TU == 3
+int ivx_conv_launch_pair_bf16(ConvParams &p, const ConvPlan &pl, hipStream_t st) { return launch_pair<1>(p, pl, st); }
+#else
+int ivx_conv_launch_pair_f16(ConvParams &p, const ConvPlan &pl, hipStream_t st) { return launch_pair<2>(p, pl, st); }
+#endif
+#endif
+
+#if IVX_CONV_TU == 1
+int ivx_conv_launch_f32(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
   switch (pl.cfg) {
-    case 1: launch_cfg<2, 2, 2, 2>(p, st); break;  // 128 x 128, 2 workgroups/CU
-    case 2: launch_cfg<2, 2, 4, 1>(p, st); break;  // 256 x 64, 1 workgroup/CU
-    case 3: launch_cfg<2, 1, 2, 2>(p, st); break;  // 128 x 64
-    case 4: launch_cfg<1, 1, 4, 1>(p, st); break;  // 128 x 32
-    case 5: launch_cfg<1, 2, 4, 1>(p, st); break;  // 128 x 64 (wave 32 x 64)
-    case 6: launch_cfg<1, 1, 2, 2>(p, st); break;  // 64 x 64
-    case 7: launch_cfg<1, 2, 2, 2>(p, st); break;  // 64 x 128
     case 41: launch_v4<float, 2, 2, 2, 2, 32>(p, st); break;   // LDS-DMA: 128 x 128, 128-byte LDS rows
     case 43: launch_v4<float, 2, 1, 2, 2, 32>(p, st); break;   //          128 x 64
     case 44: launch_v4<float, 1, 1, 4, 1, 32>(p, st); break;   //          128 x 32
@@ -1338,6 +1369,17 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 47: launch_v4<float, 1, 1, 2, 2, 16, 6>(p, st); break;  // 64 x 64, 64-byte rows: 16 KB LDS, 6 workgroups/CU
     case 48: launch_v4<float, 1, 2, 2, 2, 16, 5>(p, st); break;  // 64 x 128
     case 49: launch_v4<float, 2, 1, 2, 2, 16, 5>(p, st); break;  // 128 x 64 at 5 workgroups/CU
+    default:
+      ivx_set_error("ivx_conv_fwd: tile %d is not an fp32 LDS-DMA tile", pl.cfg);
+      return IVX_ERR_INVALID_ARG;
+  }
+  return IVX_OK;
+}
+#endif
+
+#if IVX_CONV_TU == 2
+int ivx_conv_launch_lowp(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
+  switch (pl.cfg) {
     case 74: launch_v4<__bf16, 2, 2, 2, 2, 32, 4>(p, st); break; // 71 at 4 workgroups/CU
     case 91: launch_v4<fp8_t, 2, 2, 2, 2, 64, 4>(p, st); break;  // e4m3 operands, v_mfma_f32_32x32x16_fp8_fp8: 128 x 128, 64-byte rows
     case 92: launch_v4<fp8_t, 2, 1, 2, 2, 64, 5>(p, st); break;  //   128 x 64
@@ -1354,6 +1396,26 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 71: launch_v4<__bf16, 2, 2, 2, 2, 32>(p, st); break;
     case 73: launch_v4<__bf16, 2, 1, 2, 2, 32>(p, st); break;
     case 72: launch_v4<__bf16, 2, 2, 4, 1, 32>(p, st); break;
+    default:
+      ivx_set_error("ivx_conv_fwd: tile %d is not a bf16 / e4m3 LDS-DMA tile", pl.cfg);
+      return IVX_ERR_INVALID_ARG;
+  }
+  return IVX_OK;
+}
+#endif
+
+#if IVX_CONV_TU == 0
+static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
+  if (p.in_pair) return p.in_pair == 2 ? ivx_conv_launch_pair_f16(p, pl, st) : ivx_conv_launch_pair_bf16(p, pl, st);
+  if (pl.cfg >= 40) return (p.in_bf16 || p.in_fp8) ? ivx_conv_launch_lowp(p, pl, st) : ivx_conv_launch_f32(p, pl, st);
+  switch (pl.cfg) {
+    case 1: launch_cfg<2, 2, 2, 2>(p, st); break;  // 128 x 128, 2 workgroups/CU
+    case 2: launch_cfg<2, 2, 4, 1>(p, st); break;  // 256 x 64, 1 workgroup/CU
+    case 3: launch_cfg<2, 1, 2, 2>(p, st); break;  // 128 x 64
+    case 4: launch_cfg<1, 1, 4, 1>(p, st); break;  // 128 x 32
+    case 5: launch_cfg<1, 2, 4, 1>(p, st); break;  // 128 x 64 (wave 32 x 64)
+    case 6: launch_cfg<1, 1, 2, 2>(p, st); break;  // 64 x 64
+    case 7: launch_cfg<1, 2, 2, 2>(p, st); break;  // 64 x 128
     default:
       ivx_set_error("ivx_conv_fwd: unknown tile override %d", pl.cfg);
       return IVX_ERR_INVALID_ARG;
@@ -1553,3 +1615,4 @@ extern "C" int ivx_conv_fwd_naive(const ivx_conv_desc *d, const void *in, const 
   IVX_CHECK_LAUNCH("ivx_conv_fwd_naive");
   return IVX_OK;
 }
+#endif   // IVX_CONV_TU == 0
