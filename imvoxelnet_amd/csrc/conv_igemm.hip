@@ -1161,9 +1161,7 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 73: *t = {128, 64, 32, 5}; return true;
     case 75: *t = {128, 64, 32, 5}; return true;
     case 76: *t = {256, 64, 32, 4}; return true;
-    case 84: *t = {256, 128, 32, 2}; return true;
     case 85: *t = {128, 256, 32, 2}; return true;
-    case 86: *t = {256, 256, 32, 2}; return true;
     case 72: *t = {256, 64, 32, 3}; return true;
     default: return false;
   }
@@ -1333,11 +1331,11 @@ static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     // larger wave tiles: fewer LDS fragment reads per product (the pair loop reads 4 fragments for 3 products; at 16x the fp32 MFMA rate
     // the LDS port, shared by the DMA writes and the fragment reads, is as busy as the matrix pipe)
     case 76: launch_v4<__bf16, 2, 2, 4, 1, 32, 4, PAIR>(p, st); break;   // 256 x 64, wave tile 64 x 64
-    case 84: launch_v4<__bf16, 4, 2, 2, 2, 32, 2, PAIR>(p, st); break;   // 256 x 128, 4 waves, wave tile 128 x 64
-    case 85: launch_v4<__bf16, 2, 4, 2, 2, 32, 2, PAIR>(p, st); break;   // 128 x 256, 4 waves, wave tile 64 x 128
-    case 86: launch_v4<__bf16, 4, 2, 2, 4, 32, 2, PAIR>(p, st); break;   // 256 x 256, 8 waves, wave tile 128 x 64
+    case 85: launch_v4<__bf16, 2, 4, 2, 2, 32, 2, PAIR>(p, st); break;   // 128 x 256, 4 waves, wave tile 64 x 128: no gain over 81 / 82, so the
+                                                                         // fragment reads are not what limits the loop (TM = 4 variants: the
+                                                                         // compiler keeps the accumulators in scratch, 10x slower; removed)
     default:
-      ivx_set_error("ivx_conv_fwd: tile %d has no pair-operand instantiation (61, 63, 66, 67, 73, 74, 75, 81, 82, 83)", pl.cfg);
+      ivx_set_error("ivx_conv_fwd: tile %d has no pair-operand instantiation (61, 63, 66, 67, 73 .. 76, 81 .. 83, 85)", pl.cfg);
       return IVX_ERR_INVALID_ARG;
   }
   return IVX_OK;
@@ -1546,7 +1544,9 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
   if (pl.cfg == 0 && p.in_pair) {
     // pair operands: three bf16-rate products per staged operand pair; 8- / 16-wave workgroups stage the fewest bytes per product
     // (tools/gemm_ab.py --pair, profiles/r03_gemm_ab_pair.log)
-    pl.cfg = p.Cout <= 64 ? 73 : (p.Cout <= 128 ? 81 : 82);
+    // measured on the KITTI neck (tools/pair_ab.py, profiles/r03_pair_ab.log): Cout 64: 256 x 64 at four per CU 0.69 ms (128 x 64: 0.74-0.84);
+    // Cout 128: 256 x 128 8 waves 0.60 / 0.88 (128 x 128: 0.63 / 0.89); Cout 256: 256 x 256 16 waves 0.87 / 1.39 (8 waves: 0.91 / 1.41)
+    pl.cfg = p.Cout <= 64 ? 76 : (p.Cout <= 128 ? 81 : 82);
   }
   if (pl.cfg == 0) {
     const long long nblk = (long long)groups * ((p.M + 127) / 128) * ((p.Cout + 127) / 128);

@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void wino_amax_kernel(const wf32x4 *__restrict
   for (; t < n4; t += stride) m = wino_amax4(__builtin_nontemporal_load(x + t), m);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  // one atomic per workgroup: same-address device-scope atomics serialise (8192 per-wave atomics cost more than the 658 MB read)
+  __shared__ float wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 // In place: n fp32 values -> fp16 (hi, lo) pairs of s * x in the IVX_F16_PAIR order, s from hdr[0] = bits of max |x| (one thread per 16
@@ -702,7 +706,7 @@ extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *d, int32_t tile, con
     }
     const size_t n4 = (size_t)d->B * d->D * d->H * d->W * d->Cin / 4;
     const size_t ab = (n4 + 1023) / 1024;
-    hipLaunchKernelGGL(wino_amax_kernel, dim3((unsigned)(ab > 2048 ? 2048 : (ab < 1 ? 1 : ab))), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(wino_amax_kernel, dim3((unsigned)(ab > 1536 ? 1536 : (ab < 1 ? 1 : ab))), dim3(256), 0, (hipStream_t)stream,
                        (const wf32x4 *)in, n4, (unsigned *)p.hdr);
     if (tile == 4)
       hipLaunchKernelGGL((wino_input_kernel<4, 2, 1>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
