@@ -130,9 +130,11 @@ class FusedConv:
     winograd_min_ch = 64
     winograd_2d_min_ch = int(os.environ.get('IVX_WINOGRAD_2D_MIN_CH', '128'))   # 2-D 3x3 layers (ResNet conv2, FPN outputs)
     winograd_min_pos = int(os.environ.get('IVX_WINOGRAD_MIN_POS', '2000'))
-    # Split-operand form (include/imvoxel.h IVX_BF16_PAIR): fp32 activations and filters as (hi, lo) bf16 pairs, three bf16 MFMA
-    # products per pair with fp32 accumulation -- 16x the fp32 MFMA rate at 2^-17 operand precision, no transform passes.
-    # 0: off (exact fp32 MFMA, Winograd forms);  1: the 3-D layers with Cin % 32 == 0;  2: the 2-D layers as well
+    # Split-operand direct form (include/imvoxel.h IVX_BF16_PAIR) for the layers the Winograd form does not take (1x1, strided, ...):
+    # fp32 activations and filters as (hi, lo) bf16 pairs, three bf16 MFMA products per pair with fp32 accumulation -- 16x the fp32 MFMA
+    # rate at 2^-17 operand precision, one split pass over the input.  Measured on the KITTI neck it loses to the Winograd form
+    # (1.9 / 2.9 / 5.2 ms vs 1.8 / 2.7 / 4.5 for the 64 / 128 / 256-channel layers: the minimal-filtering form needs 5x fewer products).
+    # 0: off;  1: 3-D layers with Cin % 32 == 0;  2: 2-D layers as well
     pair_mode = int(os.environ.get('IVX_CONV_PAIR', '0'))
     pair_min_pos = 2000
     # Operands of the Winograd-domain GEMMs (ivx_conv_desc.wino_operands): 4 = fp16 (hi, lo) pairs, three fp16 MFMA products per pair
@@ -270,10 +272,10 @@ class FusedConv:
         """epi: (scale, shift, res_scale) of this call when they differ from the layer's own (the quantised modes: the tensors'
         scales folded in); the direct kernel only -- the Winograd form is fp32."""
         B = x.shape[0]
-        if self.takes_pair_form(tuple(x.shape), x.dtype, naive) and epi is None:
-            return self._pair(x, res, res_mode, relu, res_after_act, post_scale)
         m, xs, wk, wst, wpad = self.wino_tile(tuple(x.shape), x.dtype, res_mode, naive)
         wino = m > 0
+        if not wino and epi is None and self.takes_pair_form(tuple(x.shape), x.dtype, naive):   # layers the Winograd form does not take
+            return self._pair(x, res, res_mode, relu, res_after_act, post_scale)
         if not wino:
             m = FusedConv.winograd_tile or 6      # only used by the executed-FLOP accounting below (not reached: wino False)
         if FusedConv.count_flops:

@@ -1547,6 +1547,9 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     // measured on the KITTI neck (tools/pair_ab.py, profiles/r03_pair_ab.log): Cout 64: 256 x 64 at four per CU 0.69 ms (128 x 64: 0.74-0.84);
     // Cout 128: 256 x 128 8 waves 0.60 / 0.88 (128 x 128: 0.63 / 0.89); Cout 256: 256 x 256 16 waves 0.87 / 1.39 (8 waves: 0.91 / 1.41)
     pl.cfg = p.Cout <= 64 ? 76 : (p.Cout <= 128 ? 81 : 82);
+    // few tiles (the 2-D 3x3 layers of the trunk at KITTI size, the indoor necks): the 8- / 16-wave tiles would leave most CUs idle
+    const long long nblk = (long long)groups * ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    if (nblk < 2500) pl.cfg = 67;
   }
   if (pl.cfg == 0) {
     const long long nblk = (long long)groups * ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
