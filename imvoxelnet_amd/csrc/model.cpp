@@ -97,6 +97,11 @@ struct PlanStep {
   ivx_conv_desc d;        // CONV: the descriptor handed to the conv entry point (Winograd: the transformed-axes view)
   int tile = 0;           // 0: direct kernel, else F(tile x tile, 3x3)
   int64_t ws = 0;
+  // max |tensor| for the fp16-pair operand scale of a Winograd layer whose input is another Winograd layer's output: the producer's
+  // output transform leaves one maximum per workgroup (arena offset amax_out, amax_n entries), the consumer's input stage reduces
+  // those instead of reading the whole tensor again (amax_in / amax_in_n); -1: the input stage reduces the tensor itself
+  int64_t amax_out = -1, amax_in = -1;
+  int amax_n = 0, amax_in_n = 0;
 };
 
 struct Plan {
@@ -815,6 +820,29 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
     }
     // an output nobody reads (should not happen) stays allocated
   }
+  // per-workgroup maxima between chained Winograd layers (see PlanStep)
+  for (int i = r.s0; i < r.s1; ++i) {
+    const Step &s = m->steps[i];
+    PlanStep &pc = pl->ps[i];
+    if (s.kind != ST_CONV || pc.tile == 0 || pc.d.wino_operands != IVX_F16_PAIR) continue;
+    for (int j = i - 1; j >= r.s0; --j) {
+      const Step &q = m->steps[j];
+      if (q.out != s.in) continue;
+      PlanStep &pp = pl->ps[j];
+      if (q.kind == ST_CONV && pp.tile > 0) {
+        if (pp.amax_out < 0) {
+          const int32_t nb = ivx_conv_winograd_output_blocks(&pp.d, pp.tile);
+          M_REQUIRE(nb > 0, "layer %s: %s", m->layers[q.layer].name.c_str(), ivx_last_error());
+          pp.amax_out = top;
+          pp.amax_n = nb;
+          top += align256((int64_t)nb * 4);
+        }
+        pc.amax_in = pp.amax_out;
+        pc.amax_in_n = pp.amax_n;
+      }
+      break;
+    }
+  }
   pl->arena = align256(top);
   pl->ws_off = pl->arena;
   pl->ws_bytes = align256(pl->ws_bytes);
@@ -979,21 +1007,27 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           M_TRY(ivx_conv_out_dims(&ps.d, &zo_d, &zo_h, &zo));
           const double vb = 4.0 * n * n * tiles * ps.d.W * ps.d.Cin, mb = 4.0 * n * n * tiles * zo * ps.d.Cout;
           M_TRY(trace_begin(m, i, 1, is3d, 0.0, 4.0 * in.elems() + vb, L.name, st));
-          M_TRY(ivx_conv_winograd_input(&ps.d, ps.tile, ptr(s.in), ws, pl.ws_bytes, st));
+          M_TRY(ivx_conv_winograd_input_amax(&ps.d, ps.tile, ptr(s.in), ws, pl.ws_bytes, ps.amax_in >= 0 ? (const float *)(base + ps.amax_in) : nullptr,
+                                             ps.amax_in_n, st));
           M_TRY(trace_end(m, st));
           // flops: the matrix-core products the stage issues (pair operands: hi*hi + hi*lo + lo*hi per multiply-add)
           M_TRY(trace_begin(m, i, 2, is3d, (ps.d.wino_operands ? 3.0 : 1.0) * 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin, vb + mb, L.name, st));
           M_TRY(ivx_conv_winograd_gemm(&ps.d, ps.tile, L.u.at(ps.tile * 8 + ps.d.wino_operands), ws, pl.ws_bytes, st));
           M_TRY(trace_end(m, st));
           M_TRY(trace_begin(m, i, 3, is3d, 0.0, mb + 4.0 * o.elems() * (res ? 2 : 1), L.name, st));
-          M_TRY(ivx_conv_winograd_output(&ps.d, ps.tile, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
+          M_TRY(ivx_conv_winograd_output_amax(&ps.d, ps.tile, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes,
+                                              ps.amax_out >= 0 ? (float *)(base + ps.amax_out) : nullptr, st));
           M_TRY(trace_end(m, st));
           break;
         }
         M_TRY(trace_begin(m, i, 0, is3d, 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2], 0.0, L.name, st));
-        if (ps.tile)
-          M_TRY(ivx_conv_winograd_fwd(&ps.d, ps.tile, ptr(s.in), L.u.at(ps.tile * 8 + ps.d.wino_operands), L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
-        else
+        if (ps.tile) {
+          M_TRY(ivx_conv_winograd_input_amax(&ps.d, ps.tile, ptr(s.in), ws, pl.ws_bytes, ps.amax_in >= 0 ? (const float *)(base + ps.amax_in) : nullptr,
+                                             ps.amax_in_n, st));
+          M_TRY(ivx_conv_winograd_gemm(&ps.d, ps.tile, L.u.at(ps.tile * 8 + ps.d.wino_operands), ws, pl.ws_bytes, st));
+          M_TRY(ivx_conv_winograd_output_amax(&ps.d, ps.tile, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes,
+                                              ps.amax_out >= 0 ? (float *)(base + ps.amax_out) : nullptr, st));
+        } else
           M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.w, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
         M_TRY(trace_end(m, st));
         break;

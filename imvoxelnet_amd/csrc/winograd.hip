@@ -34,6 +34,7 @@ struct WinoP {
   int px, py;               // padding of the transformed axes
   int relu, res_mode, res_after_act;
   float post_scale;
+  float *pmax;              // output transform: per-workgroup max |out| goes to pmax[blockIdx.x] (the next layer's input scale), or NULL
   const unsigned *hdr;      // pair operands: {bits of max |input|, bits of the filter scale} (device; see wino_pair_vscale), else NULL
 };
 
@@ -53,6 +54,27 @@ __device__ __forceinline__ float wino_pow2_scale(const float amax, const float g
 __device__ __forceinline__ float wino_pair_vscale(const unsigned *hdr) { return wino_pow2_scale(__uint_as_float(hdr[0]), 8.f); }
 // multiplier of M in the output transform: 1 / (activation scale * filter scale); 1 for fp32 operands (no header)
 __device__ __forceinline__ float wino_mscale(const unsigned *hdr) { return hdr ? 1.0f / (wino_pair_vscale(hdr) * __uint_as_float(hdr[1])) : 1.0f; }
+
+__device__ __forceinline__ float vabsmax(const float v) { return fabsf(v); }
+__device__ __forceinline__ float vabsmax(const float2 v) { return fmaxf(fabsf(v.x), fabsf(v.y)); }
+__device__ __forceinline__ float vabsmax(const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+// max over the 256 threads of a workgroup -> pmax[blockIdx.x] (every thread must call it)
+__device__ __forceinline__ void wino_block_max_store(float m, float *pmax) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) pmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+}
+// the per-workgroup maxima of a producer (wino_block_max_store) -> hdr[0] (zeroed by the caller)
+__global__ __launch_bounds__(256) void wino_amax_partials_kernel(const float *__restrict__ part, int n, unsigned *out) {
+  float m = 0.f;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) m = fmaxf(m, part[t]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
 
 // max |x| over a tensor into hdr[0] (zeroed by the caller): non-negative floats order like their bit patterns.  A read-only stream:
 // four independent 16-byte loads per lane and iteration keep enough bytes in flight for HBM (one load per iteration ran at 2.6 TB/s).
@@ -319,6 +341,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
   const V *res = reinterpret_cast<const V *>(p.res);
   V *out = reinterpret_cast<V *>(p.out);
   const float mscale = wino_mscale(p.hdr);
+  float omax = 0.f;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const long long zc = t % per_tile;
     const int cv = (int)(zc % CV);
@@ -353,10 +376,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
         const long long o = (((long long)b * p.Xo + x) * p.Yo + y) * per_tile + zc;
         V rr = vzero((V *)nullptr);
         if (p.res_mode) rr = res[o];
-        out[o] = wino_finish_v(p, yy[e], sc, sf, rr);
+        const V val = wino_finish_v(p, yy[e], sc, sf, rr);
+        out[o] = val;
+        if (p.pmax) omax = fmaxf(omax, vabsmax(val));
       }
     }
   }
+  if (p.pmax) wino_block_max_store(omax, p.pmax);
 }
 
 // Coefficients of At for the column-accumulate form of the output transform (wino_output_buf_kernel below).
@@ -467,6 +493,7 @@ __global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), 0, p.res ? out_bytes : 0u, 0x00020000);
   const unsigned ps = (unsigned)(p.ms * 4);                 // plane stride in bytes
   const float mscale = wino_mscale(p.hdr);
+  float omax = 0.f;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const long long zc = t % per_tile;
     const int cv = (int)(zc % CV);
@@ -497,11 +524,14 @@ __global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p
         const unsigned vo_ae = (xb + a < p.Xo && yb + e < p.Yo) ? o00 : 0x80000000u;
         const unsigned so = (unsigned)a * row + (unsigned)e * colb;
         const V rv = BufIO<VW>::load(rr, vo_ae, so);        // no residual: rr has zero records -> 0
-        BufIO<VW>::store(ro, vo_ae, so, wino_finish_v(p, acc[a][e], sc, sf, rv));
-      }
+        const V val = wino_finish_v(p, acc[a][e], sc, sf, rv);
+        BufIO<VW>::store(ro, vo_ae, so, val);
+        omax = fmaxf(omax, (vo_ae >> 31) ? 0.f : vabsmax(val));     // (unconditional: the epilogue stays one basic block) border
+      }                                                             // positions are not part of the tensor
       __builtin_amdgcn_sched_barrier(0);       // one output row's residual loads in flight at a time (else all 36 are hoisted)
     }
   }
+  if (p.pmax) wino_block_max_store(omax, p.pmax);
 }
 
 // U = G g Gt.  wgt is layout 0 [Co,3,3,KW,Ci]; U is [n*n][Co][K] with the K order of `kmode` (0: k = kz*Ci + ci;
@@ -682,6 +712,7 @@ int wino_setup(const ivx_conv_desc *d, int tile, const void *in, const float *sc
   p->TX = w->TX; p->TY = w->TY; p->px = d->pd; p->py = d->ph;
   p->relu = d->relu; p->res_mode = d->res_mode; p->res_after_act = d->res_after_act;
   p->post_scale = d->post_scale == 0.f ? 1.0f : d->post_scale;
+  p->pmax = nullptr;
   p->hdr = d->wino_operands == IVX_F16_PAIR
                ? (const unsigned *)((char *)workspace + ivx_align_up(w->n2 * w->v_stride * 4, 256) + ivx_align_up(w->n2 * w->m_stride * 4, 256))
                : nullptr;
@@ -690,8 +721,8 @@ int wino_setup(const ivx_conv_desc *d, int tile, const void *in, const float *sc
 }  // namespace
 
 // The three stages are separate entry points so that a caller can time them (bench.py); ivx_conv_winograd_fwd runs all.
-extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *d, int32_t tile, const void *in, void *workspace, int64_t workspace_bytes,
-                                       ivx_stream_t stream) {
+static int wino_input_impl(const ivx_conv_desc *d, int32_t tile, const void *in, void *workspace, int64_t workspace_bytes,
+                           const float *partials, int32_t n_partials, ivx_stream_t stream) {
   WinoDims w;
   WinoP p;
   float dummy;
@@ -704,10 +735,16 @@ extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *d, int32_t tile, con
       ivx_set_error("ivx_conv_winograd_input: hipMemsetAsync failed");
       return IVX_ERR_HIP;
     }
-    const size_t n4 = (size_t)d->B * d->D * d->H * d->W * d->Cin / 4;
-    const size_t ab = (n4 + 1023) / 1024;
-    hipLaunchKernelGGL(wino_amax_kernel, dim3((unsigned)(ab > 1536 ? 1536 : (ab < 1 ? 1 : ab))), dim3(256), 0, (hipStream_t)stream,
-                       (const wf32x4 *)in, n4, (unsigned *)p.hdr);
+    if (partials) {   // the producer left per-workgroup maxima of this tensor (ivx_conv_winograd_output_amax): reduce those few KB
+      const int pb = (n_partials + 255) / 256;
+      hipLaunchKernelGGL(wino_amax_partials_kernel, dim3((unsigned)(pb > 64 ? 64 : pb)), dim3(256), 0, (hipStream_t)stream, partials, n_partials,
+                         (unsigned *)p.hdr);
+    } else {
+      const size_t n4 = (size_t)d->B * d->D * d->H * d->W * d->Cin / 4;
+      const size_t ab = (n4 + 1023) / 1024;
+      hipLaunchKernelGGL(wino_amax_kernel, dim3((unsigned)(ab > 1536 ? 1536 : (ab < 1 ? 1 : ab))), dim3(256), 0, (hipStream_t)stream,
+                         (const wf32x4 *)in, n4, (unsigned *)p.hdr);
+    }
     if (tile == 4)
       hipLaunchKernelGGL((wino_input_kernel<4, 2, 1>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
     else
@@ -722,6 +759,17 @@ extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *d, int32_t tile, con
     hipLaunchKernelGGL((wino_input_kernel<6, 2>), dim3(wino_blocks(w.v_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
   IVX_CHECK_LAUNCH("ivx_conv_winograd_input");
   return IVX_OK;
+}
+
+extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *d, int32_t tile, const void *in, void *workspace, int64_t workspace_bytes,
+                                       ivx_stream_t stream) {
+  return wino_input_impl(d, tile, in, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int ivx_conv_winograd_input_amax(const ivx_conv_desc *d, int32_t tile, const void *in, void *workspace, int64_t workspace_bytes,
+                                            const float *partials, int32_t n_partials, ivx_stream_t stream) {
+  IVX_REQUIRE(!partials || n_partials > 0, "ivx_conv_winograd_input_amax: partials without a count");
+  return wino_input_impl(d, tile, in, workspace, workspace_bytes, partials, n_partials, stream);
 }
 
 extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *d, int32_t tile, const float *u, void *workspace, int64_t workspace_bytes,
@@ -746,8 +794,26 @@ extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *d, int32_t tile, cons
   return IVX_OK;
 }
 
-extern "C" int ivx_conv_winograd_output(const ivx_conv_desc *d, int32_t tile, const float *scale, const float *shift, const void *res,
-                                        void *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream) {
+namespace {
+// workgroups of the output transform's launch (= entries of the partial-maximum array of ivx_conv_winograd_output_amax)
+unsigned wino_output_grid(const ivx_conv_desc *d, int tile, const WinoDims &w) {
+  if (tile == 2) return wino_blocks(w.m_elems / 4);
+  if (tile == 4) return wino_blocks(w.m_elems / 2);
+  const bool buf_ok = (int64_t)w.n2 * w.m_stride * 4 < (1LL << 32) && (int64_t)d->B * w.Xo * w.Yo * w.Zo * d->Cout * 4 < (1LL << 31);
+  int v = g_wino_out_variant >= 0 ? g_wino_out_variant : (d->res_mode ? 2 : 1);
+  if (v >= 2 && !buf_ok) v = 0;
+  return (v == 2 || v == 0) ? wino_blocks(w.m_elems / 2) : wino_blocks(w.m_elems);
+}
+}  // namespace
+
+extern "C" int32_t ivx_conv_winograd_output_blocks(const ivx_conv_desc *d, int32_t tile) {
+  WinoDims w;
+  if (wino_dims(d, tile, &w, "ivx_conv_winograd_output_blocks") != IVX_OK) return -1;
+  return (int32_t)wino_output_grid(d, tile, w);
+}
+
+static int wino_output_impl(const ivx_conv_desc *d, int32_t tile, const float *scale, const float *shift, const void *res, void *out,
+                            void *workspace, int64_t workspace_bytes, float *partials, ivx_stream_t stream) {
   WinoDims w;
   WinoP p;
   float dummy;
@@ -755,6 +821,7 @@ extern "C" int ivx_conv_winograd_output(const ivx_conv_desc *d, int32_t tile, co
   IVX_REQUIRE(!d || d->res_mode == 0 || res, "ivx_conv_winograd_output: res_mode set but res is NULL");
   int rc = wino_setup(d, tile, &dummy, scale, shift, res, out, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_output");
   if (rc != IVX_OK) return rc;
+  p.pmax = partials;
   if (tile == 2)
     hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wino_blocks(w.m_elems / 4)), dim3(256), 0, (hipStream_t)stream, p);
   else if (tile == 4)
@@ -775,6 +842,16 @@ extern "C" int ivx_conv_winograd_output(const ivx_conv_desc *d, int32_t tile, co
   }
   IVX_CHECK_LAUNCH("ivx_conv_winograd_output");
   return IVX_OK;
+}
+
+extern "C" int ivx_conv_winograd_output(const ivx_conv_desc *d, int32_t tile, const float *scale, const float *shift, const void *res,
+                                        void *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream) {
+  return wino_output_impl(d, tile, scale, shift, res, out, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int ivx_conv_winograd_output_amax(const ivx_conv_desc *d, int32_t tile, const float *scale, const float *shift, const void *res,
+                                             void *out, void *workspace, int64_t workspace_bytes, float *partials, ivx_stream_t stream) {
+  return wino_output_impl(d, tile, scale, shift, res, out, workspace, workspace_bytes, partials, stream);
 }
 
 extern "C" int ivx_conv_winograd_fwd(const ivx_conv_desc *d, int32_t tile, const void *in, const float *u, const float *scale,

@@ -165,6 +165,16 @@ int ivx_conv_winograd_output(const ivx_conv_desc *d, int32_t tile, const float *
 int ivx_conv_winograd_fwd(const ivx_conv_desc *d, int32_t tile, const void *in, const float *u, const float *scale,
                           const float *shift, const void *res, void *out, void *workspace, int64_t workspace_bytes,
                           ivx_stream_t stream);
+/* Chained Winograd layers with fp16-pair operands: the scale of V needs max |in|, which ivx_conv_winograd_input takes with a pass over
+ * the tensor.  When `in` is the output of another Winograd layer, that layer's output transform can leave one maximum per workgroup
+ * (`partials`, ivx_conv_winograd_output_blocks(d, tile) floats, caller-owned device memory) and the consumer's input stage reduces those
+ * few KB instead: ivx_conv_winograd_output_amax / ivx_conv_winograd_input_amax (partials NULL = the plain entry points).  The maxima are
+ * those of the stored tensor (after the epilogue), so both routes give the same scale, bit for bit. */
+int32_t ivx_conv_winograd_output_blocks(const ivx_conv_desc *d, int32_t tile);
+int ivx_conv_winograd_output_amax(const ivx_conv_desc *d, int32_t tile, const float *scale, const float *shift, const void *res, void *out,
+                                  void *workspace, int64_t workspace_bytes, float *partials, ivx_stream_t stream);
+int ivx_conv_winograd_input_amax(const ivx_conv_desc *d, int32_t tile, const void *in, void *workspace, int64_t workspace_bytes,
+                                 const float *partials, int32_t n_partials, ivx_stream_t stream);
 
 /* Tuning knob for A/B experiments only (per calling thread): 0 = automatic tile choice (default); 1..7 force a tile
  * of the generic kernel, 41..53 of the LDS-DMA fp32 kernel, 61..73 of its bf16 instantiation. */

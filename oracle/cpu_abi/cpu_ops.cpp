@@ -158,6 +158,12 @@ extern "C" int ivx_conv_winograd_input(const ivx_conv_desc *, int32_t, const voi
 extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *, int32_t, const float *, void *, int64_t, ivx_stream_t) { return no_wino("ivx_conv_winograd_gemm"); }
 extern "C" int ivx_conv_winograd_output(const ivx_conv_desc *, int32_t, const float *, const float *, const void *, void *, void *, int64_t,
                                         ivx_stream_t) { return no_wino("ivx_conv_winograd_output"); }
+extern "C" int32_t ivx_conv_winograd_output_blocks(const ivx_conv_desc *, int32_t) { return -1; }
+extern "C" int ivx_conv_winograd_output_amax(const ivx_conv_desc *, int32_t, const float *, const float *, const void *, void *, void *, int64_t, float *,
+                                             ivx_stream_t) { return no_wino("ivx_conv_winograd_output_amax"); }
+extern "C" int ivx_conv_winograd_input_amax(const ivx_conv_desc *, int32_t, const void *, void *, int64_t, const float *, int32_t, ivx_stream_t) {
+  return no_wino("ivx_conv_winograd_input_amax");
+}
 extern "C" int ivx_conv_winograd_fwd(const ivx_conv_desc *, int32_t, const void *, const float *, const float *, const float *, const void *,
                                      void *, void *, int64_t, ivx_stream_t) { return no_wino("ivx_conv_winograd_fwd"); }
 

@@ -245,3 +245,27 @@ def test_native_handle_operand_modes_give_the_same_detections(ia):
         assert_close('boxes', a['boxes_3d'].tensor, b['boxes_3d'].tensor, 0, 1e-3)
         total += len(a['scores_3d'])
     assert total > 10
+
+
+@pytest.mark.parametrize('tile', [4, 6])
+def test_winograd_chained_amax_partials(ia, tile):
+    """ivx_conv_winograd_output_amax leaves one maximum per workgroup of the STORED tensor (after scale / shift / residual / ReLU, border
+    positions excluded): their maximum is max |out| exactly, and a consumer fed with them (ivx_conv_winograd_input_amax) produces the same
+    bits as one that reduces the tensor itself -- for the whole-tile and the buffer-addressed output transform, fp32 and pair operands."""
+    from imvoxelnet_amd import ops
+    P = ops.IVX_F16_PAIR
+    g = torch.Generator().manual_seed(50 + tile)
+    x = torch.randn(2, 27, 20, 4, 64, generator=g).cuda()                  # 27 and 20: border tiles for both tile sizes
+    w1 = (torch.randn(64, 3, 3, 3, 64, generator=g) * 0.03).cuda()
+    w2 = (torch.randn(32, 3, 3, 3, 64, generator=g) * 0.03).cuda()
+    sc, sh = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+    for operands in (0, P):
+        u1, u2 = ops.conv_winograd_weights(w1, 1, tile, operands), ops.conv_winograd_weights(w2, 1, tile, operands)
+        for res in (None, torch.randn(2, 27, 20, 4, 64, generator=g).cuda()):
+            y, part = ops.conv_winograd_fwd(x, u1, sc, sh, 3, 1, (1, 1, 1), True, res, wgt_layout=1, operands=operands, want_amax=True)
+            y0 = ops.conv_winograd_fwd(x, u1, sc, sh, 3, 1, (1, 1, 1), True, res, wgt_layout=1, operands=operands)
+            assert torch.equal(y, y0)
+            assert float(part.max()) == float(y.abs().max()) and float(part.min()) >= 0.0
+            z = ops.conv_winograd_fwd(y, u2, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=operands, amax_in=part)
+            z0 = ops.conv_winograd_fwd(y, u2, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=operands)
+            assert torch.equal(z, z0), (operands, res is not None)
