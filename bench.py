@@ -652,7 +652,8 @@ def main():
                                       '%d launches/step, event-bracketed incl. their transform / split-K passes' % (len(t2d) // nst)),
                                   'achieved': round(t2d_flops / (t2d_ms * 1e-3) / 1e12, 2) if t2d_ms > 0 else None, 'peak': peak2d, 'unit': 'TFLOP/s',
                                   'frac': round(t2d_flops / (t2d_ms * 1e-3) / 1e12 / peak2d, 4) if t2d_ms > 0 else None,
-                                  'flops_counted': 'algorithmic multiply-adds of the executed form (direct / Winograd-domain), one per multiply-add; fp32 MFMA peak',
+                                  'flops_counted': 'matrix-core products of the executed form: one per multiply-add on the fp32 MFMA layers, three on the 2-D 3x3 layers that run '
+                                                   'as Winograd on fp16-pair operands (priced against the fp32 MFMA peak all the same: a mixed span)',
                                   'ms_per_step': round(t2d_ms, 3), 'executed_gflop_per_step': round(t2d_flops / 1e9, 1)},
         }
         if untraced:

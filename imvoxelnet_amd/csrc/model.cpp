@@ -978,7 +978,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           M_TRY(ivx_conv_out_dims(&ps.d, &a_, &b_, &zo));
           const int n = ps.tile + 2;
           const double tiles = (double)o.B * ((ps.d.D + 2 * ps.d.pd - 2 + ps.tile - 1) / ps.tile) * ((ps.d.H + 2 * ps.d.ph - 2 + ps.tile - 1) / ps.tile);
-          span_flops += 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin;
+          span_flops += (ps.d.wino_operands ? 3.0 : 1.0) * 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin;   // as the per-launch records count
         } else {
           span_flops += 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2];
         }
