@@ -241,6 +241,7 @@ template <typename V> struct Wino1D<6, V> {
 
 // V = Bt d B.  One thread: VW channels of one (b, tx, ty, z); xi plane stride = all threads.
 typedef _Float16 wf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
 // (hi, lo) fp16 halves of two scaled values, saturating: hi = fp16(x), lo = fp16(x - hi)
 __device__ __forceinline__ void wino_pair2(const float2 v, const float s, unsigned *hi, unsigned *lo) {
   const float x0 = __builtin_fminf(__builtin_fmaxf(v.x * s, -65504.f), 65504.f), x1 = __builtin_fminf(__builtin_fmaxf(v.y * s, -65504.f), 65504.f);
@@ -295,15 +296,22 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
       if constexpr (PAIR) {
         // IVX_F16_PAIR order inside the plane: per voxel and 16 channels [hi x16 | lo x16]; this lane owns channels 2cv, 2cv + 1, i.e.
         // dword (cv / 8) * 16 + cv % 8 of the voxel's C dwords for hi and 8 further for lo (same bytes per plane as fp32)
+        // Neighbouring lanes (cv even / odd: CV is even, so they are the same voxel) trade halves so that each issues ONE 8-byte store
+        // per plane, as the fp32 form does: the even lane writes both lanes' hi dwords, the odd lane both lo dwords.
         const int cv = (int)(zc % CV);
-        const long long dw = 2 * (t - cv) + ((cv >> 3) << 4) + (cv & 7);
-        unsigned *Vp = reinterpret_cast<unsigned *>(p.V);
+        const bool odd = cv & 1;
+        const long long dw = 2 * (t - cv) + ((cv >> 3) << 4) + (cv & 6) + (odd ? 8 : 0);
+        u32x2w *Vp = reinterpret_cast<u32x2w *>(reinterpret_cast<unsigned *>(p.V) + dw);
+        const long long pstride = p.vs / 2;      // plane stride in 8-byte units (plane sizes are multiples of 16 dwords)
 #pragma unroll
         for (int j = 0; j < N; ++j) {
           unsigned hi, lo;
           wino_pair2(v[j], vscale, &hi, &lo);
-          Vp[(long long)(N * i + j) * p.vs + dw] = hi;
-          Vp[(long long)(N * i + j) * p.vs + dw + 8] = lo;
+          const unsigned give = odd ? hi : lo, got = (unsigned)__shfl_xor((int)give, 1);
+          u32x2w o;
+          o.x = odd ? got : hi;      // even lane: (hi_even, hi_odd); odd lane: (lo_even, lo_odd)
+          o.y = odd ? lo : got;
+          Vp[(long long)(N * i + j) * pstride] = o;
         }
       } else {
 #pragma unroll

@@ -452,4 +452,6 @@ def test_bench_rccl_path_at_world_size_1(ia):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 1 and rec['config']['rccl_ranks'] == 1 and len(rec['config']['ms_per_step_by_rank']) == 1
     assert rec['config']['collective'] and rec['value'] > 50 and rec['config']['detections_last_step'] > 0
-    assert rec['roofline']['frac'] > 0.5 and rec['measured_ceilings']['hbm_copy_gbps'] > 3000
+    # default operands: fp16 pairs priced against the 16-bit MFMA peak (every product counted); in fp32 multiply-adds the GEMMs must beat
+    # what the fp32 MFMA form could ever reach
+    assert rec['roofline']['frac'] > 0.2 and rec['roofline']['fp32_equivalent_tflops'] > 160 and rec['measured_ceilings']['hbm_copy_gbps'] > 3000

@@ -4,9 +4,9 @@ device allocation of a few hundred MB by the process (torch.empty; never written
 NaN activations -> no detections), permanently for that graph exec.  Seen with both backends of ImVoxelNet.capture_graph (torch
 CUDAGraph of the composed path: [33, 34] -> [0, 0] after torch.empty(700 MB); native hipGraph: [27, 43] -> [0, 0] after 800 MB) and not
 in other orders / sizes (native survived 900 MB in another run; a trivial torch graph is not affected).  Eager execution is never
-affected.  Not root-caused (the conv kernels carry 32 bytes of scratch per lane; a stale scratch or kernarg state of the pre-built
-dispatch packets is the suspicion).  Consequence: graph replay stays opt-in, and a host that uses it should allocate everything
-before capturing.
+affected.  Narrowed down to the runtime's graph packet capture: with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP
+runtime initialises the replays are exact (tests/graph_replay_check.py); `import imvoxelnet_amd` sets it by default, so run this
+reproducer with DEBUG_CLR_GRAPH_PACKET_CAPTURE=1 to see the failure.
   python tools/graph_fragility.py"""
 import os
 import sys
