@@ -249,6 +249,7 @@ def bench_other(args, ia, kc, dev, rank, world):
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
            'scaling': 'strong' if view_sharded else 'weak', 'vs_baseline': None, 'dtype': args.storage + ((' + fp8 2-D conv (bf16 residual stream)' if args.fp8_residual == 'bf16' else ' + fp8 trunk storage') if args.trunk_fp8 else ''), 'data': 'synthetic',
            'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'shard': args.shard, 'trunk_fp8': fp8_note, 'api': 'simple_test (native handle)' if public else 'composed',
+                      'wino_operands': 'fp16 pairs' if (FusedConv.wino_operands == 4 and args.storage != 'bf16') else 'storage type',
                       'detections_last_step': int(sum(len(r[1]) for r in last))},
            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck)' % ('__bf16' if args.storage == 'bf16' else 'float'),
                         'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS,
@@ -383,6 +384,8 @@ def main():
     if os.environ.get('IVX_NARROW_EPILOGUE') == '1':       # A/B of the conv epilogue (default: LDS-transposed wide stores)
         from imvoxelnet_amd import _lib
         _lib.lib().ivx_conv_set_epilogue_mode(1)
+    if args.wino_operands == 'f32':
+        FusedConv.wino_operands = 0            # fp32 MFMA in the Winograd domain for every workload of this run
     if args.config.startswith('lift_'):
         return bench_lift(args, ia, kc, dev)
     if args.config != 'kitti':
