@@ -21,9 +21,9 @@
 // Reference call sites replaced: see include/imvoxel.h (ivx_conv_fwd).
 #include "ivx_common.h"
 
-// This file is compiled five times (imvoxelnet_amd/_build.py), each translation unit instantiating one family of the LDS-DMA kernel, so that
+// This file is compiled six times (imvoxelnet_amd/_build.py), each translation unit instantiating one family of the LDS-DMA kernel, so that
 // the families build in parallel:  IVX_CONV_TU 0 = the host side, the generic / naive / reduce kernels;  1 = fp32;  2 = bf16 and e4m3;
-// 3 = bf16 (hi, lo) pair operands;  4 = fp16 pair operands.
+// 3 = bf16 (hi, lo) pair operands;  4 = fp16 pair operands;  5 = the z-halo kernel (conv_wino_halo_kernel).
 #ifndef IVX_CONV_TU
 #define IVX_CONV_TU 0
 #endif
@@ -33,6 +33,7 @@ int ivx_conv_launch_f32(ConvParams &p, const ConvPlan &pl, hipStream_t st);
 int ivx_conv_launch_lowp(ConvParams &p, const ConvPlan &pl, hipStream_t st);
 int ivx_conv_launch_pair_bf16(ConvParams &p, const ConvPlan &pl, hipStream_t st);
 int ivx_conv_launch_pair_f16(ConvParams &p, const ConvPlan &pl, hipStream_t st);
+int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st);    // TU 5: the z-halo kernel of the Winograd-domain GEMMs (pair operands)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1116,6 +1117,11 @@ struct ConvPlan {
 
 
 #if IVX_CONV_TU == 0
+static thread_local int g_halo_mode = -1;   // A/B knob (ivx_conv_set_halo_mode): -1 default rule | 0 never | 1 .. 9 force that z-halo config
+extern "C" int ivx_conv_set_halo_mode(int mode) {
+  g_halo_mode = mode;
+  return IVX_OK;
+}
 static thread_local int g_tile_override = 0;
 // Tuning knob (A/B experiments, tools/conv_bench.py; per calling thread): 0 = automatic choice, else force a tile
 // config of launch_one (1..7 generic kernel, 41..53 LDS-DMA fp32, 61..73 LDS-DMA bf16).
@@ -1348,6 +1354,200 @@ int ivx_conv_launch_pair_f16(ConvParams &p, const ConvPlan &pl, hipStream_t st) 
 #endif
 #endif
 
+#if IVX_CONV_TU == 5
+// Winograd-domain GEMM of a stride-1, pad-1, 1x1x3 convolution along z on pair operands, with the THREE z-taps served from ONE staged
+// tile.  The rows of a transformed plane are (tile column, z), z fastest, so the A rows of tap kz are the output rows shifted by
+// kz - 1: the generic kernel stages them three times (one K slab per tap: 3 x the L2 -> LDS traffic, 3 x the barriers), and at the 16-bit
+// MFMA rate that staging is what the pair GEMMs wait for (5.8 TB/s of LDS-DMA for 3.8 TB/s of HBM traffic, the per-slab
+// MFMA work of 0.18 us cannot hide one load).  Here an iteration covers one 16-channel pair group: BM + 2 rows of A (a one-row halo on
+// either side) and the three taps' B rows are staged once, and 9 * TM * TN MFMAs (3 taps x hi*hi + hi*lo + lo*hi) run on them; fragments
+// of tap kz are read kz rows further down, rows whose z + kz - 1 falls outside the column are zeroed in registers.
+// Same LDS row format as conv_igemm_v4_kernel (64-byte rows of 32 stored elements, XOR swizzle by (row >> 2) & 3), same epilogue.
+// (T = __bf16: the 2-byte storage element, as in conv_igemm_v4_kernel.)  NBUF staging buffers form a ring with a prefetch distance of
+// NBUF - 1 groups: at 16-bit MFMA rates one group of a 128 x 128 tile is 0.5 us of matrix work against 2-3 us of load latency under
+// load, so the tiles are large (bytes staged per MFMA fall with the tile edge) and the ring is as deep as the 160 KB of LDS allow.
+template <typename T, int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF>
+__global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const ConvParams p, const unsigned in_bytes, const unsigned w_bytes) {
+  constexpr int BM = WR * TM * 32, BN = WC * TN * 32, NT = 64 * WR * WC;
+  constexpr int BK = 32, EPC = 8, NCH = 4, RP = NT / NCH;
+  static_assert(BM % RP == 0 && (3 * BN) % RP == 0, "A rows and the three taps of B rows in whole passes (+ one 16-row tail pass of A)");
+  constexpr int APASS = BM / RP, AROWS = BM + 16;                         // rows m0 - 1 .. m0 + BM + 14 (BM + 2 are needed)
+  constexpr int BPASS = 3 * BN / RP;
+  constexpr int BUF = (AROWS + 3 * BN) * BK;                               // elements per buffer
+  constexpr int D = NBUF - 1;                                              // prefetch distance in groups
+  constexpr int LPG = APASS + BPASS;                                       // DMA instructions per group and wave (wave 0: one more)
+  static_assert((D - 1) * (LPG + 1) <= 15, "vmcnt immediate");
+  __shared__ __attribute__((aligned(16))) T smem[NBUF * BUF];
+  static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid / WC, wc = wid % WC;
+  int mt, nt;
+  {
+    const int Nt = (p.Cout + BN - 1) / BN;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int lt = idx / Nt;
+    nt = idx - lt * Nt;
+    mt = xcd * p.q_total + lt;
+  }
+  if (mt * BM >= p.M) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const size_t gz = blockIdx.z;
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.in + gz * (size_t)p.g_in * sizeof(T)), 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.wgt + gz * (size_t)p.g_w * sizeof(T)), 0, w_bytes, 0x00020000);
+  const int lr = tid / NCH;
+  const int cc = (tid & (NCH - 1)) ^ ((lr >> 2) & 3);            // the k-chunk this lane fetches (its LDS slot is tid % NCH)
+  const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+  const unsigned OOB = 0x80000000u;
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  // A: LDS row i holds plane row m0 - 1 + i; the last 16 rows are staged by wave 0 alone (only two of them are used)
+  unsigned a_base[APASS + 1];
+#pragma unroll
+  for (int j = 0; j <= APASS; ++j) {
+    const int row = m0 - 1 + (j < APASS ? lr + RP * j : BM + (lane >> 2));
+    a_base[j] = (row >= 0 && row < p.M && (j < APASS || (lane >> 2) < 2)) ? ((unsigned)row * (unsigned)p.Cin + cc * EPC) * (unsigned)sizeof(T) : OOB;
+  }
+  // B: LDS row t * BN + n holds filter row n0 + n of tap t; chunk-major K: (32 real channels = 64 stored) x tap
+  unsigned b_base[BPASS];
+#pragma unroll
+  for (int j = 0; j < BPASS; ++j) {
+    const int r = lr + RP * j, tap = r / BN, n = n0 + (r - tap * BN);
+    b_base[j] = n < p.Cout ? ((unsigned)n * (unsigned)p.K + tap * 64 + cc * EPC) * (unsigned)sizeof(T) : OOB;
+  }
+  const int G = p.Cin / BK;                                    // 16-channel pair groups
+  auto load_group = [&](int g, int buf) {
+    T *Ab = smem + buf * BUF + wid_u * (64 / NCH) * BK;     // wave-uniform base; the DMA adds lane * 16 B
+    T *Bb = Ab + AROWS * BK;
+    const unsigned ka = (unsigned)g * BK * (unsigned)sizeof(T);                                             // byte offset of the group inside an A row
+    const unsigned kb = ((unsigned)(g >> 1) * 3u * 64u + (unsigned)(g & 1) * 32u) * (unsigned)sizeof(T);    // ... inside a filter row (tap 0)
+    // (the offset goes through a named variable: with the conditional written inside the builtin's argument list the host pass of
+    // this clang drops the whole kernel without a diagnostic)
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      const unsigned vo = a_base[j] == OOB ? OOB : a_base[j] + ka;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + RP * j * BK), 16, vo, 0, 0, 0);
+    }
+    if (wid_u == 0) {
+      const unsigned vo = a_base[APASS] == OOB ? OOB : a_base[APASS] + ka;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(smem + buf * BUF + BM * BK), 16, vo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+      const unsigned vo = b_base[j] == OOB ? OOB : b_base[j] + kb;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bb + RP * j * BK), 16, vo, 0, 0, 0);
+    }
+  };
+  // validity of the z - 1 / z + 1 neighbours of this lane's rows (Wo = W = Z rows per tile column)
+  const int rl = lane & 31, fh = lane >> 5;
+  bool ok0[TM], ok2[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int z = (m0 + (wr * TM + i) * 32 + rl) % p.W;
+    ok0[i] = z >= 1;
+    ok2[i] = z + 1 < p.W;
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int g = 0; g < D; ++g)
+    if (g < G) load_group(g, g);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0, nxt = D % NBUF;          // buffer of group g / of group g + D
+  for (int g = 0; g < G; ++g) {
+    // group g has landed when at most the D - 1 younger groups are outstanding (this wave's own loads; the barrier publishes all waves')
+    if (D > 1 && g + D - 1 < G) {
+      if (wid_u == 0) __builtin_amdgcn_s_waitcnt(0x0f70 | ((D - 1) * (LPG + 1)));
+      else __builtin_amdgcn_s_waitcnt(0x0f70 | ((D - 1) * LPG));
+    } else {
+      lds_dma_wait_all();
+    }
+    __syncthreads();                    // ... and every wave is done reading the buffer of group g - 1, which group g + D now overwrites
+    if (g + D < G) load_group(g + D, nxt);
+    const T *Ac = smem + cur * BUF + wr * TM * 32 * BK;
+    const T *Bc = smem + cur * BUF + AROWS * BK + wc * TN * 32 * BK;
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      f32x4 ah[TM], al[TM], bh[TN], bl[TN];
+      const int ar = rl + kz, asw = (ar >> 2) & 3;            // A rows of this tap: kz further down (LDS row 0 is plane row m0 - 1)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const T *rowp = Ac + (i * 32 + ar) * BK;
+        ah[i] = *reinterpret_cast<const f32x4 *>(rowp + ((fh ^ asw) * EPC));
+        al[i] = *reinterpret_cast<const f32x4 *>(rowp + (((2 + fh) ^ asw) * EPC));
+      }
+      const int bsw = (rl >> 2) & 3;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const T *rowp = Bc + (kz * BN + j * 32 + rl) * BK;
+        bh[j] = *reinterpret_cast<const f32x4 *>(rowp + ((fh ^ bsw) * EPC));
+        bl[j] = *reinterpret_cast<const f32x4 *>(rowp + (((2 + fh) ^ bsw) * EPC));
+      }
+      if (kz != 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const bool ok = kz == 0 ? ok0[i] : ok2[i];
+          ah[i] = ok ? ah[i] : zero4;
+          al[i] = ok ? al[i] : zero4;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = pair_mfma<PAIR>(ah[i], bh[j], acc[i][j]);
+          acc[i][j] = pair_mfma<PAIR>(ah[i], bl[j], acc[i][j]);
+          acc[i][j] = pair_mfma<PAIR>(al[i], bh[j], acc[i][j]);
+        }
+    }
+    cur = cur + 1 == NBUF ? 0 : cur + 1;
+    nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+  }
+  __syncthreads();                      // the staging area of the epilogue overlaps the ring
+  conv_epilogue_wide<TM, TN>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, gz * (size_t)p.g_out);
+}
+
+template <int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF>
+static void launch_halo(ConvParams &p, hipStream_t st) {
+  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 2, w_bytes = (int64_t)p.Cout * p.K * 2;
+  const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
+  p.bm = BM;
+  p.q_total = (int)((Mt + 7) / 8); p.q_begin = 0; p.q_count = p.q_total;
+  const dim3 grid((unsigned)(8LL * p.q_total * Nt), 1, p.groups > 1 ? p.groups : 1);
+  auto kern = conv_wino_halo_kernel<__bf16, TM, TN, WR, WC, WPE, PAIR, NBUF>;
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
+}
+
+int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st) {
+  if (p.in_pair != 2) {
+    ivx_set_error("ivx_conv_launch_halo: fp16 pair operands only");
+    return IVX_ERR_INVALID_ARG;
+  }
+  switch (cfg) {
+    case 1: launch_halo<2, 2, 4, 1, 2, 2, 2>(p, st); break;   // 256 x 64, 4 waves, 2 buffers: 58 KB, two workgroups per CU
+    case 2: launch_halo<2, 2, 2, 2, 2, 2, 2>(p, st); break;   // 128 x 128, 4 waves, 2 buffers: 66 KB
+    case 3: launch_halo<2, 2, 4, 2, 1, 2, 2>(p, st); break;   // 256 x 128, 8 waves, 2 buffers: 82 KB
+    case 4: launch_halo<2, 1, 2, 2, 3, 2, 2>(p, st); break;   // 128 x 64, 4 waves, 2 buffers: 42 KB, three per CU
+    case 5: launch_halo<2, 2, 4, 4, 1, 2, 2>(p, st); break;   // 256 x 256, 16 waves, 2 buffers: 130 KB
+    case 6: launch_halo<2, 2, 4, 2, 1, 2, 3>(p, st); break;   // 256 x 128, 8 waves, 3 buffers: 123 KB
+    case 7: launch_halo<2, 1, 2, 2, 2, 2, 3>(p, st); break;   // 128 x 64, 4 waves, 3 buffers: 63 KB, two per CU
+    case 8: launch_halo<2, 2, 4, 1, 1, 2, 3>(p, st); break;   // 256 x 64, 4 waves, 3 buffers: 87 KB
+    case 9: launch_halo<2, 2, 2, 2, 1, 2, 3>(p, st); break;   // 128 x 128, 4 waves, 3 buffers: 99 KB
+    default:
+      ivx_set_error("ivx_conv_launch_halo: unknown config %d", cfg);
+      return IVX_ERR_INVALID_ARG;
+  }
+  return IVX_OK;
+}
+#endif
+
 #if IVX_CONV_TU == 1
 int ivx_conv_launch_f32(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
   switch (pl.cfg) {
@@ -1540,6 +1740,15 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     return IVX_ERR_UNSUPPORTED;
   }
   p.groups = groups; p.g_in = g_in; p.g_w = g_w; p.g_out = g_out;
+  // z-halo kernel (TU 5): 1x1x3 along z, stride 1, pad 1, chunk-major fp16 pairs -- the ResModule layers of the stack necks
+  if (p.in_pair == 2 && p.kmode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 3 && d->sw == 1 && d->pw == 1 && p.Cin % 64 == 0 &&
+      (g_halo_mode > 0 || (g_halo_mode < 0 && g_tile_override == 0))) {
+    // measured (tools/pair_ab.py --halo N, profiles/r03b_pair_ab_halo.log; generic kernel 0.73 / 0.90 / 1.41 ms for Cout 64 / 128 / 256):
+    // 128 x 64 at three per CU 0.57 / 0.84 / 1.44, 256 x 64 0.64 / 0.83 / 1.33, 256 x 128 0.99 / 0.84 / 1.37, 256 x 256 (16 waves) 1.44 / 1.19 /
+    // 1.27; every three-buffer ring is slower than its two-buffer form (occupancy hides the load latency better than depth does)
+    const int cfg = g_halo_mode > 0 ? g_halo_mode : (p.Cout <= 64 ? 4 : (p.Cout <= 128 ? 1 : 5));
+    return ivx_conv_launch_halo(p, cfg, st);
+  }
   ConvPlan pl = {g_tile_override, 1, 1, 0, 0, 0, 0};
   if (pl.cfg == 0 && p.in_pair) {
     // pair operands: three bf16-rate products per staged operand pair; 8- / 16-wave workgroups stage the fewest bytes per product

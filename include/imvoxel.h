@@ -131,6 +131,9 @@ int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const void *wgt, con
 int ivx_bf16_pair_split(const float *in, int64_t n, void *out, ivx_stream_t stream);
 int ivx_f16_pair_split(const float *in, int64_t n, float scale, void *out, ivx_stream_t stream);   /* IVX_F16_PAIR of scale * in, saturating */
 int ivx_conv_pair_supported(const ivx_conv_desc *d);
+/* A/B knob (per calling thread) of the Winograd-domain GEMMs on fp16 pairs: -1 (default) = the z-halo kernel where it applies (1x1x3 along z,
+ * stride 1, pad 1, Cin % 32 == 0: one staged tile serves the three z-taps), 0 = the generic LDS-DMA kernel always, 1 .. 4 = force a config. */
+int ivx_conv_set_halo_mode(int mode);
 
 /* Validation kernel: same contract, one thread per output element, plain FMA loop. Used by the
  * GPU tests to cross-check the MFMA kernel at full size; never called by the product path.   */

@@ -64,8 +64,10 @@ def main():
     ap.add_argument('--direct', action='store_true', help='also time the direct-form pair kernel (bf16 pairs)')
     ap.add_argument('--skip-accuracy', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--halo', type=int, default=-1, help='ivx_conv_set_halo_mode: -1 default rule, 0 generic kernel only, 1 .. 4 force a z-halo config')
     a = ap.parse_args()
     L = _lib.lib()
+    L.ivx_conv_set_halo_mode(a.halo)
     if not a.skip_accuracy:
         accuracy()
     cfgs = [int(c) for c in a.cfgs.split(',')]
