@@ -1117,7 +1117,7 @@ struct ConvPlan {
 
 
 #if IVX_CONV_TU == 0
-static thread_local int g_halo_mode = -1;   // A/B knob (ivx_conv_set_halo_mode): -1 default rule | 0 never | 1 .. 9 force that z-halo config
+static thread_local int g_halo_mode = -1;   // A/B knob (ivx_conv_set_halo_mode): -1 default rule | 0 never | 1 .. 14 force that z-halo config
 extern "C" int ivx_conv_set_halo_mode(int mode) {
   g_halo_mode = mode;
   return IVX_OK;
@@ -1366,17 +1366,21 @@ int ivx_conv_launch_pair_f16(ConvParams &p, const ConvPlan &pl, hipStream_t st) 
 // (T = __bf16: the 2-byte storage element, as in conv_igemm_v4_kernel.)  NBUF staging buffers form a ring with a prefetch distance of
 // NBUF - 1 groups: at 16-bit MFMA rates one group of a 128 x 128 tile is 0.5 us of matrix work against 2-3 us of load latency under
 // load, so the tiles are large (bytes staged per MFMA fall with the tile edge) and the ring is as deep as the 160 KB of LDS allow.
-template <typename T, int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF>
+// TAIL 1: a tile stores BM rows and stages BM + 16 (the last 16 by wave 0).  TAIL 0: a tile stages exactly BM rows and stores the BM - 2
+// in the middle, consecutive tiles overlapping by two rows (1.6 % more tiles at BM = 128): 40 KB of LDS for the 128 x 64 tile, i.e. a
+// fourth workgroup per CU -- and resident workgroups are what hides the load latency here.
+template <typename T, int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1>
 __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const ConvParams p, const unsigned in_bytes, const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32, NT = 64 * WR * WC;
   constexpr int BK = 32, EPC = 8, NCH = 4, RP = NT / NCH;
   static_assert(BM % RP == 0 && (3 * BN) % RP == 0, "A rows and the three taps of B rows in whole passes (+ one 16-row tail pass of A)");
-  constexpr int APASS = BM / RP, AROWS = BM + 16;                         // rows m0 - 1 .. m0 + BM + 14 (BM + 2 are needed)
+  constexpr int APASS = BM / RP, AROWS = BM + 16 * TAIL;                  // rows m0 - 1 .. (BM + 2 are needed when BM rows are stored)
+  constexpr int BMO = TAIL ? BM : BM - 2;                                  // rows a tile stores
   constexpr int BPASS = 3 * BN / RP;
   constexpr int BUF = (AROWS + 3 * BN) * BK;                               // elements per buffer
   constexpr int D = NBUF - 1;                                              // prefetch distance in groups
-  constexpr int LPG = APASS + BPASS;                                       // DMA instructions per group and wave (wave 0: one more)
-  static_assert((D - 1) * (LPG + 1) <= 15, "vmcnt immediate");
+  constexpr int LPG = APASS + BPASS;                                       // DMA instructions per group and wave (wave 0: TAIL more)
+  static_assert((D - 1) * (LPG + TAIL) <= 15, "vmcnt immediate");
   __shared__ __attribute__((aligned(16))) T smem[NBUF * BUF];
   static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1389,8 +1393,8 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
     nt = idx - lt * Nt;
     mt = xcd * p.q_total + lt;
   }
-  if (mt * BM >= p.M) return;
-  const int m0 = mt * BM, n0 = nt * BN;
+  if (mt * BMO >= p.M) return;
+  const int m0 = mt * BMO, n0 = nt * BN;
   const size_t gz = blockIdx.z;
   const __amdgpu_buffer_rsrc_t rs_in =
       __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.in + gz * (size_t)p.g_in * sizeof(T)), 0, in_bytes, 0x00020000);
@@ -1403,8 +1407,9 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
   // A: LDS row i holds plane row m0 - 1 + i; the last 16 rows are staged by wave 0 alone (only two of them are used)
   unsigned a_base[APASS + 1];
+  a_base[APASS] = OOB;
 #pragma unroll
-  for (int j = 0; j <= APASS; ++j) {
+  for (int j = 0; j < APASS + TAIL; ++j) {
     const int row = m0 - 1 + (j < APASS ? lr + RP * j : BM + (lane >> 2));
     a_base[j] = (row >= 0 && row < p.M && (j < APASS || (lane >> 2) < 2)) ? ((unsigned)row * (unsigned)p.Cin + cc * EPC) * (unsigned)sizeof(T) : OOB;
   }
@@ -1428,7 +1433,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
       const unsigned vo = a_base[j] == OOB ? OOB : a_base[j] + ka;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + RP * j * BK), 16, vo, 0, 0, 0);
     }
-    if (wid_u == 0) {
+    if (TAIL && wid_u == 0) {
       const unsigned vo = a_base[APASS] == OOB ? OOB : a_base[APASS] + ka;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(smem + buf * BUF + BM * BK), 16, vo, 0, 0, 0);
     }
@@ -1463,7 +1468,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
   for (int g = 0; g < G; ++g) {
     // group g has landed when at most the D - 1 younger groups are outstanding (this wave's own loads; the barrier publishes all waves')
     if (D > 1 && g + D - 1 < G) {
-      if (wid_u == 0) __builtin_amdgcn_s_waitcnt(0x0f70 | ((D - 1) * (LPG + 1)));
+      if (TAIL && wid_u == 0) __builtin_amdgcn_s_waitcnt(0x0f70 | ((D - 1) * (LPG + 1)));
       else __builtin_amdgcn_s_waitcnt(0x0f70 | ((D - 1) * LPG));
     } else {
       lds_dma_wait_all();
@@ -1510,18 +1515,43 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
     nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
   }
   __syncthreads();                      // the staging area of the epilogue overlaps the ring
-  conv_epilogue_wide<TM, TN>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, gz * (size_t)p.g_out);
+  if constexpr (TAIL) {
+    conv_epilogue_wide<TM, TN>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, gz * (size_t)p.g_out);
+  } else {
+    // the same LDS-transposed 16-byte stores (conv_epilogue_wide), plain values, rows limited to the BM - 2 this tile owns
+    float *stage = reinterpret_cast<float *>(smem) + wid_u * 1024;
+    float *outp = p.out + gz * (size_t)p.g_out;
+    const int mlim = (m0 + BMO < p.M) ? m0 + BMO : p.M;
+    const int col_l = lane & 31, hh = lane >> 5, rrow = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + (wc * TN + j) * 32 + c4;
+      const bool nok = nb < p.Cout;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col_l] = acc[i][j][r];
+        const int mb = m0 + (wr * TM + i) * 32 + rrow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + (rrow + 8 * q) * 32 + c4);
+          const int m = mb + 8 * q;
+          if (m < mlim && nok) *reinterpret_cast<f32x4 *>(outp + (size_t)m * p.Cout + nb) = v;
+        }
+      }
+    }
+  }
 }
 
-template <int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF>
+template <int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1>
 static void launch_halo(ConvParams &p, hipStream_t st) {
-  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  constexpr int BM = (WR * TM * 32) - (TAIL ? 0 : 2), BN = WC * TN * 32;     // rows a tile stores
   const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 2, w_bytes = (int64_t)p.Cout * p.K * 2;
   const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
   p.bm = BM;
   p.q_total = (int)((Mt + 7) / 8); p.q_begin = 0; p.q_count = p.q_total;
   const dim3 grid((unsigned)(8LL * p.q_total * Nt), 1, p.groups > 1 ? p.groups : 1);
-  auto kern = conv_wino_halo_kernel<__bf16, TM, TN, WR, WC, WPE, PAIR, NBUF>;
+  auto kern = conv_wino_halo_kernel<__bf16, TM, TN, WR, WC, WPE, PAIR, NBUF, TAIL>;
   hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
 }
 
@@ -1540,6 +1570,11 @@ int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st) {
     case 7: launch_halo<2, 1, 2, 2, 2, 2, 3>(p, st); break;   // 128 x 64, 4 waves, 3 buffers: 63 KB, two per CU
     case 8: launch_halo<2, 2, 4, 1, 1, 2, 3>(p, st); break;   // 256 x 64, 4 waves, 3 buffers: 87 KB
     case 9: launch_halo<2, 2, 2, 2, 1, 2, 3>(p, st); break;   // 128 x 128, 4 waves, 3 buffers: 99 KB
+    case 10: launch_halo<2, 1, 2, 2, 4, 2, 2, 0>(p, st); break;  // 126 (of 128) x 64, overlapping tiles, 40 KB: four per CU
+    case 11: launch_halo<2, 2, 4, 1, 2, 2, 2, 0>(p, st); break;  // 254 x 64, overlapping tiles, 56 KB: two per CU
+    case 12: launch_halo<2, 2, 4, 4, 1, 2, 2, 0>(p, st); break;  // 254 x 256, 16 waves, overlapping tiles, 128 KB
+    case 13: launch_halo<2, 2, 4, 2, 1, 2, 2, 0>(p, st); break;  // 254 x 128, 8 waves, overlapping tiles, 80 KB: two per CU
+    case 14: launch_halo<2, 2, 2, 2, 2, 2, 2, 0>(p, st); break;  // 126 x 128, 4 waves, overlapping tiles, 64 KB: two per CU
     default:
       ivx_set_error("ivx_conv_launch_halo: unknown config %d", cfg);
       return IVX_ERR_INVALID_ARG;
@@ -1744,9 +1779,11 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
   if (p.in_pair == 2 && p.kmode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 3 && d->sw == 1 && d->pw == 1 && p.Cin % 64 == 0 &&
       (g_halo_mode > 0 || (g_halo_mode < 0 && g_tile_override == 0))) {
     // measured (tools/pair_ab.py --halo N, profiles/r03b_pair_ab_halo.log; generic kernel 0.73 / 0.90 / 1.41 ms for Cout 64 / 128 / 256):
-    // 128 x 64 at three per CU 0.57 / 0.84 / 1.44, 256 x 64 0.64 / 0.83 / 1.33, 256 x 128 0.99 / 0.84 / 1.37, 256 x 256 (16 waves) 1.44 / 1.19 /
-    // 1.27; every three-buffer ring is slower than its two-buffer form (occupancy hides the load latency better than depth does)
-    const int cfg = g_halo_mode > 0 ? g_halo_mode : (p.Cout <= 64 ? 4 : (p.Cout <= 128 ? 1 : 5));
+    // with the 16-row tail pass: 128 x 64 at three per CU 0.57 / 0.84 / 1.44, 256 x 64 0.60-0.64 / 0.83 / 1.33, 256 x 128 0.99 / 0.84 / 1.37,
+    // 256 x 256 (16 waves) 1.40-1.44 / 1.19 / 1.24-1.27; every three-buffer ring is slower than its two-buffer form (resident workgroups
+    // hide the load latency better than depth does).  Overlapping tiles without the tail pass: 126 x 64 at FOUR per CU 0.49 / 0.74 / 1.35,
+    // 254 x 64 0.51 / 0.72 / 1.23, 254 x 128 (8 waves, two per CU) 0.65 / 0.64 / 1.15, 254 x 256 1.19 / 1.10 / 1.20
+    const int cfg = g_halo_mode > 0 ? g_halo_mode : (p.Cout <= 64 ? 10 : 13);
     return ivx_conv_launch_halo(p, cfg, st);
   }
   ConvPlan pl = {g_tile_override, 1, 1, 0, 0, 0, 0};

@@ -288,7 +288,7 @@ def test_winograd_halo_kernel_matches_generic(ia, shape):
         L.ivx_conv_set_halo_mode(0)
         ref = ops.conv_winograd_fwd(x, u, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=P)
         rng = float(ref.abs().max())
-        for mode in (-1, 1, 2, 3, 4, 5, 6, 7):
+        for mode in (-1, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 14):
             L.ivx_conv_set_halo_mode(mode)
             got = ops.conv_winograd_fwd(x, u, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=P)
             assert_close(f'halo mode {mode} vs generic', got, ref, 0, 2e-5 * rng)      # measured: max 1e-5, mean 4e-7 of the range
