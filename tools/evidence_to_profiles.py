@@ -45,7 +45,8 @@ def main():
                 f"{alt.get('same_detections_as_default')}.", '',
             'Earlier boxes of this half-round, default command: 170.9 (first pair GEMMs, tensor-wide max-reduction with per-wave atomics), 186.1 (reduction '
             'rewritten), 194.6 (one atomic per workgroup, 256x64 tile for Cout 64), 199.7 / 200.2 / 198.8 (maxima handed over by the producing output '
-            'transform), 203.1 (z-halo kernel for the stride-1 layers).', '',
+            'transform), 203.1 / 204.8 (z-halo kernel for the stride-1 layers), 215.1 (overlapping halo tiles: a fourth workgroup per CU; input transform '
+            'without the redundant saturation).', '',
             f'## Other workloads (images/s; `profiles/{pre}_bench_other_configs{{,_f32_operands}}.jsonl`)', '',
             '| workload | fp16-pair operands (default) | fp32 MFMA operands |', '|---|---|---|']
     a = [json.loads(l) for l in open(os.path.join(E, 'other.jsonl'))]
