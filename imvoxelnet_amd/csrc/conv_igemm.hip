@@ -1117,7 +1117,7 @@ struct ConvPlan {
 
 
 #if IVX_CONV_TU == 0
-static thread_local int g_halo_mode = -1;   // A/B knob (ivx_conv_set_halo_mode): -1 default rule | 0 never | 1 .. 14 force that z-halo config
+static thread_local int g_halo_mode = -1;   // A/B knob (ivx_conv_set_halo_mode): -1 default rule | 0 never | 1 .. 14 force that z-halo config of the stride-1 layers, 21 .. 24 of the z-stride-2 layers
 extern "C" int ivx_conv_set_halo_mode(int mode) {
   g_halo_mode = mode;
   return IVX_OK;
@@ -1369,13 +1369,17 @@ int ivx_conv_launch_pair_f16(ConvParams &p, const ConvPlan &pl, hipStream_t st) 
 // TAIL 1: a tile stores BM rows and stages BM + 16 (the last 16 by wave 0).  TAIL 0: a tile stages exactly BM rows and stores the BM - 2
 // in the middle, consecutive tiles overlapping by two rows (1.6 % more tiles at BM = 128): 40 KB of LDS for the 128 x 64 tile, i.e. a
 // fourth workgroup per CU -- and resident workgroups are what hides the load latency here.
-template <typename T, int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1>
+// SW 2 (TAIL 0 only): the z-stride-2 layers.  With an even Z the input row of output row r' and tap kz is 2 r' - 1 + kz whatever the
+// column, so a tile stages 2 BM consecutive input rows, stores BM - 1 output rows and reads the fragments of tap kz at rows 2 o + kz;
+// only tap 0 can fall outside the column (z' = 0).  One staged row serves 1.5 taps instead of 3.
+template <typename T, int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1, int SW = 1>
 __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const ConvParams p, const unsigned in_bytes, const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32, NT = 64 * WR * WC;
   constexpr int BK = 32, EPC = 8, NCH = 4, RP = NT / NCH;
-  static_assert(BM % RP == 0 && (3 * BN) % RP == 0, "A rows and the three taps of B rows in whole passes (+ one 16-row tail pass of A)");
-  constexpr int APASS = BM / RP, AROWS = BM + 16 * TAIL;                  // rows m0 - 1 .. (BM + 2 are needed when BM rows are stored)
-  constexpr int BMO = TAIL ? BM : BM - 2;                                  // rows a tile stores
+  static_assert((SW * BM) % RP == 0 && (3 * BN) % RP == 0, "A rows and the three taps of B rows in whole passes (+ one 16-row tail pass of A)");
+  static_assert(SW == 1 || TAIL == 0, "the stride-2 form uses overlapping tiles");
+  constexpr int APASS = SW * BM / RP, AROWS = SW * BM + 16 * TAIL;        // staged input rows: plane rows SW * m0 - 1 ...
+  constexpr int BMO = TAIL ? BM : (SW == 1 ? BM - 2 : BM - 1);             // rows a tile stores
   constexpr int BPASS = 3 * BN / RP;
   constexpr int BUF = (AROWS + 3 * BN) * BK;                               // elements per buffer
   constexpr int D = NBUF - 1;                                              // prefetch distance in groups
@@ -1410,8 +1414,8 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
   a_base[APASS] = OOB;
 #pragma unroll
   for (int j = 0; j < APASS + TAIL; ++j) {
-    const int row = m0 - 1 + (j < APASS ? lr + RP * j : BM + (lane >> 2));
-    a_base[j] = (row >= 0 && row < p.M && (j < APASS || (lane >> 2) < 2)) ? ((unsigned)row * (unsigned)p.Cin + cc * EPC) * (unsigned)sizeof(T) : OOB;
+    const int row = SW * m0 - 1 + (j < APASS ? lr + RP * j : BM + (lane >> 2));
+    a_base[j] = (row >= 0 && row < SW * p.M && (j < APASS || (lane >> 2) < 2)) ? ((unsigned)row * (unsigned)p.Cin + cc * EPC) * (unsigned)sizeof(T) : OOB;
   }
   // B: LDS row t * BN + n holds filter row n0 + n of tap t; chunk-major K: (32 real channels = 64 stored) x tap
   unsigned b_base[BPASS];
@@ -1448,9 +1452,9 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
   bool ok0[TM], ok2[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int z = (m0 + (wr * TM + i) * 32 + rl) % p.W;
+    const int z = (m0 + (wr * TM + i) * 32 + rl) % p.Wo;      // output z (Wo = W for stride 1)
     ok0[i] = z >= 1;
-    ok2[i] = z + 1 < p.W;
+    ok2[i] = SW == 2 || z + 1 < p.Wo;                        // stride 2: input z = 2 z' + 1 <= Z - 1 always
   }
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -1475,15 +1479,15 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
     }
     __syncthreads();                    // ... and every wave is done reading the buffer of group g - 1, which group g + D now overwrites
     if (g + D < G) load_group(g + D, nxt);
-    const T *Ac = smem + cur * BUF + wr * TM * 32 * BK;
+    const T *Ac = smem + cur * BUF + SW * wr * TM * 32 * BK;
     const T *Bc = smem + cur * BUF + AROWS * BK + wc * TN * 32 * BK;
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz) {
       f32x4 ah[TM], al[TM], bh[TN], bl[TN];
-      const int ar = rl + kz, asw = (ar >> 2) & 3;            // A rows of this tap: kz further down (LDS row 0 is plane row m0 - 1)
+      const int ar = SW * rl + kz, asw = (ar >> 2) & 3;       // A rows of this tap: LDS row SW * o + kz (LDS row 0 is plane row SW * m0 - 1)
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const T *rowp = Ac + (i * 32 + ar) * BK;
+        const T *rowp = Ac + (SW * i * 32 + ar) * BK;
         ah[i] = *reinterpret_cast<const f32x4 *>(rowp + ((fh ^ asw) * EPC));
         al[i] = *reinterpret_cast<const f32x4 *>(rowp + (((2 + fh) ^ asw) * EPC));
       }
@@ -1543,15 +1547,15 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
   }
 }
 
-template <int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1>
+template <int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1, int SW = 1>
 static void launch_halo(ConvParams &p, hipStream_t st) {
-  constexpr int BM = (WR * TM * 32) - (TAIL ? 0 : 2), BN = WC * TN * 32;     // rows a tile stores
+  constexpr int BM = (WR * TM * 32) - (TAIL ? 0 : (SW == 1 ? 2 : 1)), BN = WC * TN * 32;     // rows a tile stores
   const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 2, w_bytes = (int64_t)p.Cout * p.K * 2;
   const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
   p.bm = BM;
   p.q_total = (int)((Mt + 7) / 8); p.q_begin = 0; p.q_count = p.q_total;
   const dim3 grid((unsigned)(8LL * p.q_total * Nt), 1, p.groups > 1 ? p.groups : 1);
-  auto kern = conv_wino_halo_kernel<__bf16, TM, TN, WR, WC, WPE, PAIR, NBUF, TAIL>;
+  auto kern = conv_wino_halo_kernel<__bf16, TM, TN, WR, WC, WPE, PAIR, NBUF, TAIL, SW>;
   hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
 }
 
@@ -1575,6 +1579,11 @@ int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st) {
     case 12: launch_halo<2, 2, 4, 4, 1, 2, 2, 0>(p, st); break;  // 254 x 256, 16 waves, overlapping tiles, 128 KB
     case 13: launch_halo<2, 2, 4, 2, 1, 2, 2, 0>(p, st); break;  // 254 x 128, 8 waves, overlapping tiles, 80 KB: two per CU
     case 14: launch_halo<2, 2, 2, 2, 2, 2, 2, 0>(p, st); break;  // 126 x 128, 4 waves, overlapping tiles, 64 KB: two per CU
+    // z stride 2 (p.W == 2 * p.Wo): 2 BM staged rows
+    case 21: launch_halo<2, 1, 2, 2, 2, 2, 2, 0, 2>(p, st); break;  // 127 x 64, 4 waves: 56 KB, two per CU
+    case 22: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 2>(p, st); break;  // 127 x 128, 4 waves: 80 KB, two per CU
+    case 23: launch_halo<2, 2, 4, 2, 1, 2, 2, 0, 2>(p, st); break;  // 255 x 128, 8 waves: 112 KB, one per CU
+    case 24: launch_halo<1, 2, 4, 1, 2, 2, 2, 0, 2>(p, st); break;  // 127 x 64, 4 waves in M (wave tile 32 x 64): 56 KB
     default:
       ivx_set_error("ivx_conv_launch_halo: unknown config %d", cfg);
       return IVX_ERR_INVALID_ARG;
@@ -1776,8 +1785,12 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
   }
   p.groups = groups; p.g_in = g_in; p.g_w = g_w; p.g_out = g_out;
   // z-halo kernel (TU 5): 1x1x3 along z, stride 1, pad 1, chunk-major fp16 pairs -- the ResModule layers of the stack necks
+  if (p.in_pair == 2 && p.kmode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 3 && d->sw == 2 && d->pw == 1 && p.W == 2 * p.Wo && p.Cin % 64 == 0 &&
+      (g_halo_mode >= 21 || (g_halo_mode < 0 && g_tile_override == 0))) {
+    return ivx_conv_launch_halo(p, g_halo_mode >= 21 ? g_halo_mode : 22, st);
+  }
   if (p.in_pair == 2 && p.kmode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 3 && d->sw == 1 && d->pw == 1 && p.Cin % 64 == 0 &&
-      (g_halo_mode > 0 || (g_halo_mode < 0 && g_tile_override == 0))) {
+      ((g_halo_mode > 0 && g_halo_mode < 21) || (g_halo_mode < 0 && g_tile_override == 0))) {
     // measured (tools/pair_ab.py --halo N, profiles/r03b_pair_ab_halo.log; generic kernel 0.73 / 0.90 / 1.41 ms for Cout 64 / 128 / 256):
     // with the 16-row tail pass: 128 x 64 at three per CU 0.57 / 0.84 / 1.44, 256 x 64 0.60-0.64 / 0.83 / 1.33, 256 x 128 0.99 / 0.84 / 1.37,
     // 256 x 256 (16 waves) 1.40-1.44 / 1.19 / 1.24-1.27; every three-buffer ring is slower than its two-buffer form (resident workgroups

@@ -296,3 +296,31 @@ def test_winograd_halo_kernel_matches_generic(ia, shape):
         L.ivx_conv_set_halo_mode(-1)
     tref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).cpu().double(), w.permute(0, 4, 1, 2, 3).cpu().double(), padding=1).permute(0, 2, 3, 4, 1)
     assert_close('halo kernel vs torch fp64', got.cpu(), tref.float(), 1e-4, 1e-4 * float(tref.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(2, (19, 23, 12), 64, 128), (1, (14, 9, 6), 128, 256), (1, (9, 7, 4), 32, 64), (2, (7, 9, 2), 64, 64)])
+def test_winograd_halo_kernel_stride2_matches_generic(ia, shape):
+    """The z-stride-2 form of conv_wino_halo_kernel (even Z: input row 2 r' - 1 + kz for output row r', 2 BM staged rows, only tap 0 can
+    leave the column) against the generic kernel, default rule and every config, and against torch fp64."""
+    from imvoxelnet_amd import _lib, ops
+    L = _lib.lib()
+    P = ops.IVX_F16_PAIR
+    B, (X, Y, Z), ci, co = shape
+    g = torch.Generator().manual_seed(ci + 3 * Z)
+    x = torch.randn(B, X, Y, Z, ci, generator=g).cuda()
+    w = (torch.randn(co, 3, 3, 3, ci, generator=g) * (2.0 / (27 * ci)) ** 0.5).cuda()
+    u = ops.conv_winograd_weights(w, 1, 6, operands=P)
+    try:
+        L.ivx_conv_set_halo_mode(0)
+        ref = ops.conv_winograd_fwd(x, u, None, None, 3, 2, (1, 1, 1), False, wgt_layout=1, operands=P)
+        assert ref.shape[3] == Z // 2
+        rng = float(ref.abs().max())
+        for mode in (-1, 21, 22, 23, 24):
+            L.ivx_conv_set_halo_mode(mode)
+            got = ops.conv_winograd_fwd(x, u, None, None, 3, 2, (1, 1, 1), False, wgt_layout=1, operands=P)
+            assert_close(f'halo mode {mode} vs generic', got, ref, 0, 2e-5 * rng)
+    finally:
+        L.ivx_conv_set_halo_mode(-1)
+    tref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).cpu().double(), w.permute(0, 4, 1, 2, 3).cpu().double(), stride=(1, 1, 2),
+                                      padding=1).permute(0, 2, 3, 4, 1)
+    assert_close('stride-2 halo kernel vs torch fp64', got.cpu(), tref.float(), 1e-4, 1e-4 * float(tref.abs().max()))
