@@ -1308,3 +1308,67 @@ def test_cpu_abi_stage_trace_levels():
     neck_full, neck_coarse = [r for r in full if r[1] and r[0] <= 3], [r for r in coarse if r[1] and r[0] <= 3]
     assert len(neck_full) == len(neck_coarse) == 9                                            # direct convs on the CPU restatement (no Winograd stages)
     assert len(coarse) < len(full) / 3
+
+
+def test_pair_operand_host_side_without_gpu(monkeypatch):
+    """Split-operand MFMA, host side (no launch): the pair packing of the filters (hi = half(w), lo = half(w - hi), 16-channel groups
+    [hi | lo], chunk-major = the same elements re-ordered), which layers the forms accept, the partial-maximum count of the output
+    transform, and ivx_create's refusal of hipGraph replay when the packet-capture work-around is not in the environment."""
+    import ctypes as C
+    from imvoxelnet_amd import _lib, ops
+    from imvoxelnet_amd._lib import ConvDesc, ModelCfg
+    from imvoxelnet_amd.conv import FusedConv, pack_pair_weights
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(8, 3, 1, 2, 64, generator=g) * torch.logspace(-3, 1, 64)
+    p0, p1 = pack_pair_weights(w, 0), pack_pair_weights(w, 1)
+    assert p0.dtype == torch.bfloat16 and tuple(p0.shape) == (8, 3, 1, 2, 128) and tuple(p1.shape) == (8, 2, 3, 1, 2, 64)
+    v = p0.float().reshape(8, 3, 1, 2, 4, 2, 16)
+    hi, lo = v[..., 0, :].reshape(w.shape), v[..., 1, :].reshape(w.shape)
+    assert torch.equal(hi, w.to(torch.bfloat16).float()) and torch.equal(lo, (w - hi).to(torch.bfloat16).float())
+    assert float(((hi + lo) - w).abs().max() / w.abs().max()) < 2.0 ** -16
+    assert torch.equal(p1.permute(0, 2, 3, 4, 1, 5).reshape(8, 3, 1, 2, 128), p0)          # chunk-major: 64 stored elements = 32 channels per chunk
+    with pytest.raises(ValueError):
+        pack_pair_weights(torch.zeros(4, 1, 1, 1, 24))
+
+    def desc(ci, co, k=(3, 3, 3), st=(1, 1, 1), shape=(1, 8, 8, 4), layout=1, out_mode=0):
+        return ConvDesc(shape[0], shape[1], shape[2], shape[3], ci, co, k[0], k[1], k[2], st[0], st[1], st[2], 1, 1, 1, 0, 0, 0, 0, layout, out_mode, 0, 1.0, 0, 0, 1.0, 0)
+    assert L.ivx_conv_pair_supported(C.byref(desc(64, 32))) == 1 and L.ivx_conv_pair_supported(C.byref(desc(48, 32, layout=0))) == 1
+    assert L.ivx_conv_pair_supported(C.byref(desc(48, 32, layout=1))) == 0 and L.ivx_conv_pair_supported(C.byref(desc(24, 32, layout=0))) == 0
+    assert L.ivx_conv_pair_supported(C.byref(desc(64, 32, out_mode=1))) == 0
+    assert L.ivx_conv_pair_supported(C.byref(desc(64, 64, shape=(64, 216, 248, 12)))) == 0           # 31-bit operand offsets
+    d = desc(64, 64, shape=(4, 216, 248, 12))
+    nb = L.ivx_conv_winograd_output_blocks(C.byref(d), 6)
+    assert nb == -(-(4 * 36 * 42 * 12 * 64) // 256)          # no residual: one channel per lane, 256 lanes per workgroup
+    d.res_mode = 1
+    assert L.ivx_conv_winograd_output_blocks(C.byref(d), 6) == -(-(4 * 36 * 42 * 12 * 32) // 256)      # with residual: two channels per lane
+    # FusedConv: which operand type a layer's Winograd form takes
+    f = FusedConv(torch.zeros(64, 64, 3, 3, 3), padding=1)
+    old = FusedConv.wino_operands
+    try:
+        FusedConv.wino_operands = ops.IVX_F16_PAIR
+        assert f._wino_operands(6) == ops.IVX_F16_PAIR and f._wino_operands(2) == 0
+        assert FusedConv(torch.zeros(48, 48, 3, 3, 3), padding=1, layout=0)._wino_operands(6) == ops.IVX_F16_PAIR       # tap-major: Cin % 16
+        assert FusedConv(torch.zeros(40, 40, 3, 3, 3), padding=1)._wino_operands(6) == 0
+        FusedConv.wino_operands = 0
+        assert f._wino_operands(6) == 0
+    finally:
+        FusedConv.wino_operands = old
+    # hipGraph replay needs the packet-capture work-around in the environment (ROCm 7.2): refused without it
+    cfg = ModelCfg()
+    cfg.neck_type, cfg.with_trunk, cfg.fpn_channels, cfg.neck_out_channels = 0, 1, 64, 256
+    cfg.n_voxels[:] = [216, 248, 12]
+    cfg.voxel_size[:] = [.32, .32, .32]
+    cfg.num_classes, cfg.n_sizes, cfg.n_rotations = 1, 1, 2
+    cfg.anchor_range[:] = [0, -39.68, -1.78, 69.12 - .32, 39.68 - .32, -1.78]
+    cfg.anchor_sizes[:3] = [1.6, 3.9, 1.56]
+    cfg.anchor_rotations[:2] = [0, 1.57]
+    cfg.nms_pre, cfg.max_num, cfg.use_rotate_nms, cfg.score_thr, cfg.nms_thr = 100, 50, 1, .1, .01
+    cfg.dir_limit_offset, cfg.winograd, cfg.use_graph, cfg.wino_operands = 1.0, 1, 1, ops.IVX_F16_PAIR
+    h = C.c_void_p()
+    monkeypatch.delenv('DEBUG_CLR_GRAPH_PACKET_CAPTURE', raising=False)
+    assert L.ivx_create(C.byref(cfg), C.byref(h)) == -1 and b'DEBUG_CLR_GRAPH_PACKET_CAPTURE' in L.ivx_last_error()
+    monkeypatch.setenv('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+    assert L.ivx_create(C.byref(cfg), C.byref(h)) == 0 and L.ivx_destroy(h) == 0
+    cfg.wino_operands = 7
+    assert L.ivx_create(C.byref(cfg), C.byref(h)) == -1 and b'wino_operands' in L.ivx_last_error()
