@@ -17,6 +17,10 @@ the same path timed on this box's host cores on one image).
 import argparse
 import json
 import os
+
+# hipGraph replays of this path need the runtime's graph packet capture OFF on ROCm 7.2 (imvoxelnet_amd/__init__.py); the runtime reads the
+# variable when it initialises, which in this script happens (torch.cuda.set_device) before the package is imported: set it first
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 import sys
 import time
 

@@ -359,6 +359,20 @@ class NativeGraphedSimpleTest:
         for _ in range(max(2, warmup)):              # eager, capture, (replay ...)
             self.replay_device(img, img_metas)
         torch.cuda.synchronize(img.device)
+        # a replay must give what the eager handle gives.  It does not when the HIP runtime was initialised before
+        # DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was in the environment (ROCm 7.2: replays of pre-built dispatch packets return garbage for this
+        # path) -- nothing the library can see from inside, so the first replay is checked against an eager step, loudly
+        got = [t.clone() for t in self.replay_device(img, img_metas)]
+        B, V, _, H, W = img.shape
+        proj, new_origin, crop = model._camera_setup(img_metas, 4, img.device)
+        eager = model._native if model._native is not None else engine.NativeModel(model, img.device)
+        want = eager.forward(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
+        torch.cuda.synchronize(img.device)
+        same = torch.equal(got[3], want[3]) and all(torch.equal(got[1][b, :int(want[3][b])], want[1][b, :int(want[3][b])]) for b in range(B))
+        if not same:
+            raise RuntimeError('hipGraph replay does not reproduce the eager step (detections per sample %s vs %s): the HIP runtime was initialised '
+                               'before DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was set -- export it before the process touches the GPU'
+                               % (got[3].tolist(), want[3].tolist()))
 
     def replay_device(self, img, img_metas):
         """-> the handle's static (boxes, scores, labels, count) device tensors (consume them before the next call)."""
