@@ -39,6 +39,7 @@ struct BpParams {
   int N;        // X*Y*Z
   int nchunk;   // ceil(C / VEC)
   int lpv_log2; // lanes per voxel = 1 << lpv_log2
+  float *pmax;  // single-view lift only: per-workgroup max |volume| goes to pmax[blockIdx.y * gridDim.x + blockIdx.x], or NULL
 };
 
 // MEAN = true: the reference's view mean + valid mask.  MEAN = false (view-sharded multi-GPU mode): the raw sum over
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256) void backproject_single_view_kernel(const BpPa
   }
   const int nvox = (p.N - n0) < lpv ? (int)(p.N - n0) : lpv;   // group-uniform; <= 0 for groups past the end
   float *dst0 = p.volume + ((size_t)b * p.N + n0) * p.C;
+  float vmax = 0.f;      // max |value stored| (ivx_backproject_mean_fwd_amax: the first neck layer's operand scale needs max |volume|)
   for (int s = 0; s < lpv; ++s) {
     const int o = __shfl(off, gbase + s, 64);
     if (s >= nvox) continue;
@@ -220,16 +222,27 @@ __global__ __launch_bounds__(256) void backproject_single_view_kernel(const BpPa
         f32x4 x = {0.f, 0.f, 0.f, 0.f};
         if (o >= 0) x = *reinterpret_cast<const f32x4 *>(src + ch * 4);
         *reinterpret_cast<f32x4 *>(dst0 + (size_t)s * p.C + ch * 4) = x;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
       } else {
-        dst0[(size_t)s * p.C + ch] = o >= 0 ? src[ch] : 0.f;
+        const float x = o >= 0 ? src[ch] : 0.f;
+        dst0[(size_t)s * p.C + ch] = x;
+        vmax = fmaxf(vmax, fabsf(x));
       }
     }
+  }
+  if (p.pmax) {          // (uniform) every lane of the workgroup gets here
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    __shared__ float wmax[4];
+    if (lane == 0) wmax[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) p.pmax[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
   }
 }
 
 static int backproject_launch(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C, const float *proj,
                               const float *new_origin, const int32_t *crop_hw, const float *voxel_size, int32_t X, int32_t Y,
-                              int32_t Z, float *volume, uint8_t *valid, int32_t *count, ivx_stream_t stream) {
+                              int32_t Z, float *volume, uint8_t *valid, int32_t *count, ivx_stream_t stream, float *partials = nullptr) {
   const bool mean = count == nullptr;
   IVX_REQUIRE(feat && proj && new_origin && crop_hw && voxel_size && volume && (valid || count), "ivx_backproject_mean_fwd: null argument");
   IVX_REQUIRE(B > 0 && V > 0 && FH > 0 && FW > 0 && C > 0 && X > 0 && Y > 0 && Z > 0, "ivx_backproject_mean_fwd: non-positive dims");
@@ -239,6 +252,7 @@ static int backproject_launch(const float *feat, int32_t B, int32_t V, int32_t F
   BpParams p;
   p.feat = feat; p.proj = proj; p.new_origin = new_origin; p.crop_hw = crop_hw; p.volume = volume; p.valid = valid;
   p.count = count;
+  p.pmax = (mean && V == 1) ? partials : nullptr;
   p.vs0 = voxel_size[0]; p.vs1 = voxel_size[1]; p.vs2 = voxel_size[2];
   p.V = V; p.FH = FH; p.FW = FW; p.C = C; p.X = X; p.Y = Y; p.Z = Z; p.N = X * Y * Z;
   const int vec = (C % 4 == 0) ? 4 : 1;
@@ -280,6 +294,21 @@ extern "C" int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V,
                                         uint8_t *valid, ivx_stream_t stream) {
   IVX_REQUIRE(valid, "ivx_backproject_mean_fwd: null argument");
   return backproject_launch(feat, B, V, FH, FW, C, proj, new_origin, crop_hw, voxel_size, X, Y, Z, volume, valid, nullptr, stream);
+}
+
+// Single-view lift that also leaves one max |volume| per workgroup: ivx_backproject_amax_blocks(B, V, X, Y, Z) floats (0: this shape
+// takes the multi-view kernel, which does not -- the consumer reduces the volume itself), for ivx_conv_winograd_input_amax.
+extern "C" int32_t ivx_backproject_amax_blocks(int32_t B, int32_t V, int32_t X, int32_t Y, int32_t Z) {
+  if (B <= 0 || V != 1 || X <= 0 || Y <= 0 || Z <= 0 || (int64_t)X * Y * Z >= (1LL << 31)) return 0;
+  return (int32_t)(((int64_t)X * Y * Z + 255) / 256 * B);
+}
+
+extern "C" int ivx_backproject_mean_fwd_amax(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C, const float *proj,
+                                             const float *new_origin, const int32_t *crop_hw, const float *voxel_size, int32_t X, int32_t Y,
+                                             int32_t Z, float *volume, uint8_t *valid, float *partials, ivx_stream_t stream) {
+  IVX_REQUIRE(valid, "ivx_backproject_mean_fwd_amax: null argument");
+  IVX_REQUIRE(!partials || V == 1, "ivx_backproject_mean_fwd_amax: partial maxima come from the single-view kernel only");
+  return backproject_launch(feat, B, V, FH, FW, C, proj, new_origin, crop_hw, voxel_size, X, Y, Z, volume, valid, nullptr, stream, partials);
 }
 
 extern "C" int ivx_backproject_sum_fwd(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,

@@ -829,6 +829,15 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       const Step &q = m->steps[j];
       if (q.out != s.in) continue;
       PlanStep &pp = pl->ps[j];
+      if (q.kind == ST_LIFT) {          // the single-view unprojection leaves per-workgroup maxima too
+        const TInfo &vol = pl->t[q.out];
+        const int32_t nb = ivx_backproject_amax_blocks(vol.B, n_views, vol.D, vol.H, vol.W);
+        if (nb > 0) {
+          if (pp.amax_out < 0) { pp.amax_out = top; pp.amax_n = nb; top += align256((int64_t)nb * 4); }
+          pc.amax_in = pp.amax_out;
+          pc.amax_in_n = pp.amax_n;
+        }
+      }
       if (q.kind == ST_CONV && pp.tile > 0) {
         if (pp.amax_out < 0) {
           const int32_t nb = ivx_conv_winograd_output_blocks(&pp.d, pp.tile);
@@ -1036,8 +1045,9 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         M_REQUIRE(bd.proj && bd.new_origin && bd.crop, "%s: proj / new_origin / crop_hw are required", who);
         const TInfo &o = pl.t[s.out];
         M_TRY(trace_begin(m, i, 4, 1, 0.0, 4.0 * in.elems() + 4.0 * o.elems() + (double)o.elems() / o.C, "unprojection", st));
-        M_TRY(ivx_backproject_mean_fwd((const float *)ptr(s.in), o.B, bd.V, in.H, in.W, in.C, bd.proj, bd.new_origin, bd.crop, m->cfg.voxel_size,
-                                       o.D, o.H, o.W, (float *)ptr(s.out), (uint8_t *)ptr(s.out2), st));
+        M_TRY(ivx_backproject_mean_fwd_amax((const float *)ptr(s.in), o.B, bd.V, in.H, in.W, in.C, bd.proj, bd.new_origin, bd.crop, m->cfg.voxel_size,
+                                            o.D, o.H, o.W, (float *)ptr(s.out), (uint8_t *)ptr(s.out2),
+                                            pl.ps[i].amax_out >= 0 ? (float *)(base + pl.ps[i].amax_out) : nullptr, st));
         M_TRY(trace_end(m, st));
         break;
       }

@@ -268,6 +268,12 @@ int ivx_upsample_trilinear2x_fwd_bf16(const void *in, int32_t B, int32_t D, int3
  * place: volume = count ? sum / count : 0, valid = count > 0 (detectors/imvoxelnet.py:70-74).  C % 4 == 0.
  * The view sum is then ordered rank by rank instead of strictly by view: equal to the single-GPU result to fp32
  * rounding of the additions (the valid mask is exact).                                                         */
+/* ivx_backproject_mean_fwd that also leaves one max |volume| per workgroup (single view only: ivx_backproject_amax_blocks floats, 0 when the
+ * shape does not take that kernel) for the operand scale of the first neck layer (ivx_conv_winograd_input_amax). */
+int32_t ivx_backproject_amax_blocks(int32_t B, int32_t V, int32_t X, int32_t Y, int32_t Z);
+int ivx_backproject_mean_fwd_amax(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C, const float *proj,
+                                  const float *new_origin, const int32_t *crop_hw, const float *voxel_size, int32_t X, int32_t Y,
+                                  int32_t Z, float *volume, uint8_t *valid, float *partials, ivx_stream_t stream);
 int ivx_backproject_sum_fwd(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C,
                             const float *proj, const float *new_origin, const int32_t *crop_hw,
                             const float *voxel_size, int32_t X, int32_t Y, int32_t Z, float *volume_sum,

@@ -280,6 +280,12 @@ extern "C" int ivx_backproject_mean_fwd(const float *feat, int32_t B, int32_t V,
 // ---------------------------------------------------------------------------------------------- anchor tail (csrc/anchor_tail.hip)
 static int next_pow2(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
+extern "C" int32_t ivx_backproject_amax_blocks(int32_t, int32_t, int32_t, int32_t, int32_t) { return 0; }   // no partial maxima on the CPU restatement
+extern "C" int ivx_backproject_mean_fwd_amax(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C, const float *proj,
+                                             const float *new_origin, const int32_t *crop_hw, const float *voxel_size, int32_t X, int32_t Y, int32_t Z,
+                                             float *volume, uint8_t *valid, float *, ivx_stream_t st) {
+  return ivx_backproject_mean_fwd(feat, B, V, FH, FW, C, proj, new_origin, crop_hw, voxel_size, X, Y, Z, volume, valid, st);
+}
 extern "C" int64_t ivx_anchor_head_workspace_bytes(const ivx_anchor_head_desc *d) { return d ? 256 : -1; }
 
 // Anchor3DHead.get_bboxes_single (anchor3d_head.py:420-520): sigmoid scores, top nms_pre (ties -> lower index), box decoding,
