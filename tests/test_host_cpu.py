@@ -1372,3 +1372,30 @@ def test_pair_operand_host_side_without_gpu(monkeypatch):
     assert L.ivx_create(C.byref(cfg), C.byref(h)) == 0 and L.ivx_destroy(h) == 0
     cfg.wino_operands = 7
     assert L.ivx_create(C.byref(cfg), C.byref(h)) == -1 and b'wino_operands' in L.ivx_last_error()
+
+
+def test_halo_kernel_row_arithmetic():
+    """The index facts conv_wino_halo_kernel rests on (csrc/conv_igemm.hip), checked by enumeration: the rows of a
+    transformed plane are (tile column, z) with z fastest; for the 1x1x3 convolution along z with pad 1 the input row of output row r and
+    tap kz is r + kz - 1 at stride 1, and 2 r - 1 + kz at stride 2 when Z is even -- whatever the column -- and the only taps that can fall
+    outside the column are kz = 0 at z = 0 and (stride 1 only) kz = 2 at z = Z - 1."""
+    for Z in (1, 2, 3, 5, 6, 12):
+        for sw in (1, 2):
+            if sw == 2 and Z % 2:
+                continue
+            Zo = (Z + 2 - 3) // sw + 1
+            assert Zo == (Z if sw == 1 else Z // 2)
+            for col in range(4):
+                for zo in range(Zo):
+                    r = col * Zo + zo
+                    for kz in range(3):
+                        z = zo * sw - 1 + kz
+                        inside = 0 <= z < Z
+                        assert col * Z + z == sw * r - 1 + kz              # the shifted-row identity holds for every tap, also outside the column
+                        outside_expected = (kz == 0 and zo == 0) or (sw == 1 and kz == 2 and zo == Zo - 1)
+                        assert inside == (not outside_expected), (Z, sw, zo, kz)
+    # overlapping tiles: BM staged rows serve BM - 2 (stride 1) / 2 BM staged rows serve BM - 1 (stride 2) output rows
+    for BM, sw in ((128, 1), (256, 1), (128, 2), (256, 2)):
+        bmo = BM - (2 if sw == 1 else 1)
+        need = sw * (bmo - 1) + 2 + 1          # input rows sw*m0 - 1 .. sw*(m0 + bmo - 1) + 1
+        assert need <= sw * BM
