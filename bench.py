@@ -527,7 +527,9 @@ def main():
             torch.cuda.synchronize()
             ta = time.perf_counter() - ta
         finally:
-            model._native = keep
+            alt_native, model._native = model._native, keep
+            if alt_native is not keep:
+                alt_native.close()
         same = [bool(len(a['scores_3d']) == len(b['scores_3d']) and torch.equal(a['labels_3d'], b['labels_3d'])
                      and torch.allclose(a['scores_3d'], b['scores_3d'], atol=1e-4)) for a, b in zip(last, out_alt)]
         alt = {'value': round(B * args.steps / ta, 3), 'unit': 'images/s', 'ms_per_step': round(ta / args.steps * 1e3, 3),
