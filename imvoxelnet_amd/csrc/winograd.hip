@@ -40,8 +40,8 @@ struct WinoP {
 
 // Power-of-two scales of the fp16-pair operands (ivx_conv_desc.wino_operands = IVX_F16_PAIR), chosen on the device from the data so
 // that the largest value lands in [2^14, 2^15) -- below fp16's 65504 with room for the transform's growth -- and everything down to
-// 2^-18 of it keeps a normal lo half (the matrix cores flush fp16 subnormals: measured, tools/pair_ab.py at activation scale 1e-3
-// with a fixed scale).  Activations: |V| = |Bt d B| <= 225 max|d| for F(6,3) (|Bt| row sums <= 15), 100 for F(4,3): bounded by 256.
+// 2^-18 of it keeps a normal lo half (fp16 subnormals have a fixed spacing of 2^-24, so a lo half below 2^-14 loses relative precision:
+// measured 1.8e-4 rms with a fixed scale at activation scale 1e-3, reproduced by tools/wino_pair_sim.py).  Activations: |V| = |Bt d B| <= 225 max|d| for F(6,3) (|Bt| row sums <= 15), 100 for F(4,3): bounded by 256.
 // Filters: the exact max |U| is reduced while they are transformed.  Both scales are undone in the output transform (exact).
 __device__ __forceinline__ float wino_pow2_scale(const float amax, const float gain_log2) {   // s = 2^k with gain * amax * s in [2^14, 2^15)
   if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;

@@ -1399,3 +1399,23 @@ def test_halo_kernel_row_arithmetic():
         bmo = BM - (2 if sw == 1 else 1)
         need = sw * (bmo - 1) + 2 + 1          # input rows sw*m0 - 1 .. sw*(m0 + bmo - 1) + 1
         assert need <= sw * BM
+
+
+def test_winograd_operand_format_model():
+    """tools/wino_pair_sim.py, the numerical argument of DESIGN 4.1e in float64 on the CPU: in the F(6x6,3x3) domain bf16 (hi, lo) pairs
+    cost two orders of magnitude over fp32 operands, fp16 pairs with data-dependent power-of-two scales stay within a small factor of them
+    at any activation scale, the fixed scales tried first lose the lo halves at small activations, and the bound that lets the input
+    transform skip saturation holds (asserted inside the model)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('wino_pair_sim', os.path.join(ROOT, 'tools', 'wino_pair_sim.py'))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    fixed = 'fp16 pairs, fixed scales 2^-4 / 2^10, subnormals '
+    for act in (1.0, 1e-3, 300.0):
+        r = sim.layer_errors(64, 24, act, seed=3)
+        assert r['fp32 operands'] < 1.5e-6
+        assert r['bf16 pairs'] > 30 * r['fp32 operands']
+        assert r['fp16 pairs, data scales'] < 5 * r['fp32 operands']
+        assert r[fixed + 'flushed'] > 50 * r[fixed + 'honoured'] or act < 1e-2
+    small = sim.layer_errors(64, 24, 1e-3, seed=3)
+    assert small[fixed + 'honoured'] > 50 * small['fp16 pairs, data scales']          # what made the scales data-dependent
