@@ -348,6 +348,10 @@ def main():
                          "fp16 MFMA products per pair, fp32 accumulation (22-bit operands: error at the level of the fp32 form's own rounding); "
                          "'f32' = fp32 MFMA (exact fp32 products).  The default run also times the other mode after the timed region and "
                          "reports it as exact_fp32_mfma")
+    ap.add_argument('--trunk-operands', default='f16pair', choices=['f16pair', 'f32'],
+                    help="2-D trunk (ResNet-50 + FPN): 'f16pair' (default) = activations chained as fp16 (hi, lo) pair tensors with device-side "
+                         "power-of-two scales (ivx_conv_fwd_pio: three fp16 MFMA products per multiply-add, fp32 accumulation, no conversion "
+                         "passes); 'f32' = fp32 MFMA")
     args = ap.parse_args()
 
     # One process per GPU.  Under torch.distributed.run (the reference's launcher is tools/dist_test.sh:9-10,
@@ -390,6 +394,8 @@ def main():
         _lib.lib().ivx_conv_set_epilogue_mode(1)
     if args.wino_operands == 'f32':
         FusedConv.wino_operands = 0            # fp32 MFMA in the Winograd domain for every workload of this run
+    if args.trunk_operands == 'f32':
+        FusedConv.trunk_operands = 0           # fp32 MFMA in the 2-D trunk
     if args.config.startswith('lift_'):
         return bench_lift(args, ia, kc, dev)
     if args.config != 'kitti':
@@ -514,9 +520,10 @@ def main():
     if pair and args.api == 'simple_test' and model._native is not None and not multi and not args.graph and os.environ.get('IVX_BENCH_ALT', '1') != '0':
         from imvoxelnet_amd import engine
         recs_keep = model._native.trace_records() if native_trace else None
-        FusedConv.wino_operands = 0
+        trunk_keep = FusedConv.trunk_operands
+        FusedConv.wino_operands = FusedConv.trunk_operands = 0
         keep, model._native = model._native, engine.NativeModel(model, dev)
-        FusedConv.wino_operands = 4
+        FusedConv.wino_operands, FusedConv.trunk_operands = 4, trunk_keep
         try:
             for _ in range(min(3, max(1, args.warmup))):
                 out_alt = model.simple_test(img, metas)
@@ -533,7 +540,7 @@ def main():
         same = [bool(len(a['scores_3d']) == len(b['scores_3d']) and torch.equal(a['labels_3d'], b['labels_3d'])
                      and torch.allclose(a['scores_3d'], b['scores_3d'], atol=1e-4)) for a, b in zip(last, out_alt)]
         alt = {'value': round(B * args.steps / ta, 3), 'unit': 'images/s', 'ms_per_step': round(ta / args.steps * 1e3, 3),
-               'note': 'bench.py --wino-operands f32: fp32 MFMA in the transformed domain (the round-2 arithmetic), same weights and images',
+               'note': 'bench.py --wino-operands f32 --trunk-operands f32: fp32 MFMA everywhere (exact fp32 products; the round-2 arithmetic), same weights and images',
                'detections_last_step': n_det(out_alt), 'same_detections_as_default': all(same)}
 
     ev_ids = range(args.warmup) if args.graph else range(args.warmup, args.warmup + args.steps)

@@ -42,7 +42,13 @@ class ModelCfg(C.Structure):
                 ('unet_up_layers', C.c_int32 * 3),
                 ('head_type', C.c_int32), ('head_classes', C.c_int32), ('head_nms_pre', C.c_int32), ('head_use_rotate_nms', C.c_int32),
                 ('head_score_thr', C.c_float), ('head_nms_thr', C.c_float), ('dcn_stages', C.c_int32 * 4), ('layout_head', C.c_int32),
-                ('layout_linear_size', C.c_int32), ('wino_operands', C.c_int32)]
+                ('layout_linear_size', C.c_int32), ('wino_operands', C.c_int32), ('trunk_operands', C.c_int32)]
+
+
+class PairIO(C.Structure):
+    """ivx_pair_io: device-side scales / amax slots of a convolution on fp16-pair activations (ivx_conv_fwd_pio)."""
+    _fields_ = [('in_scale', C.c_void_p), ('res_scale', C.c_void_p), ('res_dtype', C.c_int32), ('out_scale', C.c_void_p), ('amax_in', C.c_void_p),
+                ('amax_res', C.c_void_p), ('amax_out', C.c_void_p), ('wbound', C.c_float), ('sbound', C.c_float)]
 
 
 class SampleMeta(C.Structure):
@@ -63,7 +69,7 @@ class TraceRec(C.Structure):
                 ('bytes', C.c_double), ('name', C.c_char * 48)]
 
 
-EXPORTS = ['ivx_conv_winograd_set_variant', 'ivx_ubench_mfma', 'ivx_ubench_copy', 'ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws', 'ivx_conv_set_halo_mode', 'ivx_bf16_pair_split', 'ivx_f16_pair_split', 'ivx_conv_pair_supported', 'ivx_conv_winograd_output_blocks', 'ivx_conv_winograd_output_amax', 'ivx_conv_winograd_input_amax',
+EXPORTS = ['ivx_conv_winograd_set_variant', 'ivx_ubench_mfma', 'ivx_ubench_copy', 'ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws', 'ivx_conv_set_halo_mode', 'ivx_bf16_pair_split', 'ivx_f16_pair_split', 'ivx_conv_pair_supported', 'ivx_conv_pio_workspace_bytes', 'ivx_conv_fwd_pio', 'ivx_conv_fwd_pio_naive', 'ivx_pair_pack_filters', 'ivx_nchw_to_nhwc_amax', 'ivx_maxpool2d_fwd_pair', 'ivx_f16_pair_merge', 'ivx_conv_winograd_output_blocks', 'ivx_conv_winograd_output_amax', 'ivx_conv_winograd_input_amax',
            'ivx_conv_winograd_supported', 'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_weights', 'ivx_conv_winograd_workspace_bytes',
            'ivx_conv_winograd_input', 'ivx_conv_winograd_gemm', 'ivx_conv_winograd_output', 'ivx_conv_winograd_fwd',
            'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_maxpool2d_fwd_fp8', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_image_s2d_bf16', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_amax', 'ivx_backproject_amax_blocks', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
@@ -106,6 +112,14 @@ def lib():
     L.ivx_bf16_pair_split.argtypes = [vp, i64, vp, vp]
     L.ivx_f16_pair_split.argtypes = [vp, i64, f32, vp, vp]
     L.ivx_conv_pair_supported.argtypes = [C.POINTER(ConvDesc)]
+    L.ivx_conv_pio_workspace_bytes.argtypes = [C.POINTER(ConvDesc), C.POINTER(PairIO)]
+    L.ivx_conv_pio_workspace_bytes.restype = i64
+    L.ivx_conv_fwd_pio.argtypes = [C.POINTER(ConvDesc), C.POINTER(PairIO), vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.ivx_conv_fwd_pio_naive.argtypes = [C.POINTER(ConvDesc), C.POINTER(PairIO), vp, vp, vp, vp, vp, vp, vp]
+    L.ivx_pair_pack_filters.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, C.POINTER(f32), C.POINTER(f32)]
+    L.ivx_nchw_to_nhwc_amax.argtypes = [vp, i32, i32, i64, i32, vp, vp, vp]
+    L.ivx_maxpool2d_fwd_pair.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp]
+    L.ivx_f16_pair_merge.argtypes = [vp, i64, vp, vp, vp]
     L.ivx_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
     L.ivx_conv_workspace_bytes.restype = i64
     L.ivx_conv_fwd_ws.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, i64, vp]

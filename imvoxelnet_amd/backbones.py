@@ -34,7 +34,7 @@ class _Bottleneck(nn.Module):
         else:
             self.downsample = None
 
-    def prepare(self, device, in_dtype=None, stream_dtype=None):
+    def prepare(self, device, in_dtype=None, stream_dtype=None, chain=False):
         """in_dtype: storage type of the block's INPUT when it differs from the block's own (the first bf16 block after the e4m3
         stages of the fp8 trunk): conv1 and the shortcut conv read it.
         stream_dtype (fp8 trunk, residual='bf16'): storage type of the RESIDUAL STREAM -- the block's input, its shortcut and its
@@ -45,7 +45,9 @@ class _Bottleneck(nn.Module):
         xd = stream_dtype or in_dtype or sd            # what conv1 / the shortcut read
         od = stream_dtype or sd                        # what conv3 / the shortcut write
         # style='pytorch': the stride sits on the 3x3 conv
-        self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2, dtype=xd, out_dtype=sd).to(device)
+        # chain (fp32 storage with FusedConv.trunk_operands == 4): the block's activations as fp16-pair tensors (ops.PairTensor)
+        chain = bool(chain) and sd == torch.float32 and xd == torch.float32 and od == torch.float32
+        self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2, dtype=xd, out_dtype=sd, chain=chain).to(device)
         if self.dcn:
             if sd != torch.float32:
                 raise NotImplementedError('the DCNv2 stages are built for float32 storage only')
@@ -55,23 +57,39 @@ class _Bottleneck(nn.Module):
             w_col = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1, 1, 1)
             self.f2 = FusedConv(w_col, bn=self.bn2.tensors(), relu=True, dims=2).to(device)
         else:
-            self.f2 = FusedConv(self.conv2.weight, bn=self.bn2.tensors(), stride=self.stride, padding=1, relu=True, dims=2).to(device)
-        self.f3 = FusedConv(self.conv3.weight, bn=self.bn3.tensors(), relu=True, dims=2, dtype=sd, out_dtype=od).to(device)  # relu after the add
+            self.f2 = FusedConv(self.conv2.weight, bn=self.bn2.tensors(), stride=self.stride, padding=1, relu=True, dims=2, chain=chain).to(device)
+        self.f3 = FusedConv(self.conv3.weight, bn=self.bn3.tensors(), relu=True, dims=2, dtype=sd, out_dtype=od, chain=chain).to(device)  # relu after the add
         self.fd = None
         if self.downsample is not None:
             self.fd = FusedConv(self.downsample[0].weight, bn=self.downsample[1].tensors(), stride=self.stride, dims=2,
-                                dtype=xd, out_dtype=od).to(device)
+                                dtype=xd, out_dtype=od, chain=chain).to(device)
         elif in_dtype is not None and in_dtype != sd and stream_dtype is None:
             raise ValueError('a block without a shortcut conv keeps the storage type of its input')
 
-    def forward_cl(self, x):
-        idt = x if self.fd is None else self.fd(x)
-        y = self.f1(x)
-        if self.dcn:
+    def takes_pairs(self):
+        """every layer that reads the block's INPUT has pair filters (csrc/model.cpp make_plan: wants_pair)"""
+        return self.f1.pair_ok and (self.fd is None or self.fd.pair_ok)
+
+    def forward_cl(self, x, out_pair=False):
+        """x: channels-last fp32 tensor or, in the pair chain, an ops.PairTensor; out_pair: the block's output as a PairTensor (the caller
+        knows its consumers).  Inside the block a tensor is a pair tensor when its producer read pairs and its only consumer has pair
+        filters -- the rule of the native handle, so both hosts run the same kernels on the same bits."""
+        if not isinstance(x, ops.PairTensor):
+            idt = x if self.fd is None else self.fd(x)
+            y = self.f1(x)
+            if self.dcn:
+                y = self.f2(ops.dcn_im2col(y, self.f_off(y), 3, self.stride, 1, 1))
+            else:
+                y = self.f2(y)
+            return self.f3(y, res=idt)
+        idt = x if self.fd is None else self.fd(x)                 # shortcut conv: fp32 out (only read as a residual), max |out| recorded
+        if self.dcn:                                               # conv1 feeds conv_offset and the column kernel: fp32
+            y = self.f1(x)
             y = self.f2(ops.dcn_im2col(y, self.f_off(y), 3, self.stride, 1, 1))
-        else:
-            y = self.f2(y)
-        return self.f3(y, res=idt)
+            return self.f3(y, res=idt)
+        y = self.f1(x, out_pair=self.f2.pair_ok)
+        y = self.f2(y, out_pair=self.f3.pair_ok)
+        return self.f3(y, res=idt, out_pair=out_pair)
 
 
 def stem_s2d_weights(w):
@@ -138,8 +156,10 @@ class ResNet(nn.Module):
         from .conv import current_storage_dtype, FP8
         fp8 = current_storage_dtype() == FP8       # optional: e4m3 storage of the trunk's activations (detector.calibrate_fp8)
         self.stem = None
+        # fp32 storage: the trunk's activations chained as fp16-pair tensors (FusedConv.trunk_operands, conv.py)
+        self.chain = current_storage_dtype() == torch.float32 and FusedConv.trunk_operands == ops.IVX_F16_PAIR
         if not fp8:
-            self.stem = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), stride=2, padding=3, relu=True, dims=2).to(device)
+            self.stem = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), stride=2, padding=3, relu=True, dims=2, chain=self.chain).to(device)
         # bf16 mode: the 7x7 stride-2 stem as a 4x4 stride-1 convolution over 2x2 space-to-depth blocks of the image
         # (ops.image_s2d_bf16): bf16 MFMA with K = 256 instead of the fp32 kernel on 3 (padded to 4) channels
         self.stem_s2d = None
@@ -167,7 +187,7 @@ class ResNet(nn.Module):
                     if res_bf16:
                         blk.prepare(device, stream_dtype=torch.bfloat16 if sd == FP8 else None)
                     else:
-                        blk.prepare(device, in_dtype=prev if (j == 0 and prev != sd) else None)
+                        blk.prepare(device, in_dtype=prev if (j == 0 and prev != sd) else None, chain=self.chain)
             self.stage_dtypes.append(torch.bfloat16 if res_bf16 else sd)
             prev = self.stage_dtypes[-1]
         self._device = device
@@ -181,21 +201,44 @@ class ResNet(nn.Module):
             return self._stages(self.stem_s2d(ops.image_s2d_bf16(img.contiguous())))
         if self.stem is None:
             raise ValueError('the fp8 trunk takes float32 images with even height and width')
+        if getattr(self, 'chain', False):
+            return self.forward_cl(ops.to_channels_last_amax(img.contiguous(), pad_to=4))
         return self.forward_cl(ops.to_channels_last(img.contiguous(), pad_to=4))
 
     def forward_cl(self, x):
         """x [N,1,H,W,4] channels-last image (3 channels zero-padded to 4) -> tuple of stage outputs."""
         if self._device is None:
             self.prepare(x.device)
-        return self._stages(self.stem(x))
+        return self._stages(self.stem(x), ops.slots_of(x))
 
-    def _stages(self, x):
+    # pair chain: which stage outputs may be PairTensors -- their consumers outside this module must be convolutions with pair filters
+    # (the FPN laterals); the detector clears the last entry when a LayoutHead pools C5 (features_2d_cl)
+    stage_out_pair = (True, True, True, True)
+
+    def _stages(self, x, img_slots=None):
         from .conv import QTensor
-        x = QTensor(ops.maxpool2d(x.data, 3, 2, 1), x.scale) if isinstance(x, QTensor) else ops.maxpool2d(x, 3, 2, 1)
+        blocks = [list(getattr(self, f'layer{i + 1}')) for i in range(self.num_stages)]
+        chain = (getattr(self, 'chain', False) and img_slots is not None and self.stem is not None and isinstance(x, torch.Tensor)
+                 and x.shape[-1] % 16 == 0 and blocks[0][0].takes_pairs()
+                 and x.shape[0] * ((x.shape[2] - 1) // 2 + 1) * ((x.shape[3] - 1) // 2 + 1) * x.shape[4] * 4 < 2 ** 31)
+        if chain:      # fp32 stem output -> pair tensor, scaled by the bound of the stem's output from max |image|
+            x = ops.maxpool2d_pair(x, img_slots, self.stem.wbound, self.stem.sbound, 3, 2, 1)
+        else:
+            x = QTensor(ops.maxpool2d(x.data, 3, 2, 1), x.scale) if isinstance(x, QTensor) else ops.maxpool2d(x, 3, 2, 1)
         outs = []
         for i in range(self.num_stages):
-            for blk in getattr(self, f'layer{i + 1}'):
-                x = blk.forward_cl(x)
+            for j, blk in enumerate(blocks[i]):
+                out_pair = False
+                if isinstance(x, ops.PairTensor):      # consumers of the block's output: the next block, the FPN lateral of a stage output
+                    if j + 1 < len(blocks[i]):
+                        out_pair = blocks[i][j + 1].takes_pairs()
+                    else:
+                        nxt = blocks[i + 1][0].takes_pairs() if i + 1 < self.num_stages else True
+                        lat = self.stage_out_pair[i] if i in self.out_indices else True
+                        out_pair = nxt and lat and (i + 1 < self.num_stages or i in self.out_indices)
+                    x = blk.forward_cl(x, out_pair=out_pair)
+                else:
+                    x = blk.forward_cl(x)
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)
@@ -203,7 +246,7 @@ class ResNet(nn.Module):
     def forward(self, img):
         """img [N,3,H,W] -> tuple of [N,C,h,w] (reference layout)."""
         from .conv import QTensor
-        return tuple(ops.from_channels_last(o.float() if isinstance(o, QTensor) else o, 2) for o in self.forward_image(img))
+        return tuple(ops.from_channels_last(o.float() if isinstance(o, (QTensor, ops.PairTensor)) else o, 2) for o in self.forward_image(img))
 
 
 @NECKS.register_module()
@@ -239,9 +282,10 @@ class FPN(nn.Module):
         from .conv import current_storage_dtype
         od = current_storage_dtype()
         ind = list(in_dtype) if isinstance(in_dtype, (list, tuple)) else [in_dtype] * len(self.lateral_convs)
-        self.flat = [FusedConv(m.conv.weight, m.conv.bias, dims=2, dtype=ind[i] or od, out_dtype=od).to(device)
+        chain = od == torch.float32 and all(t in (None, torch.float32) for t in ind) and FusedConv.trunk_operands == ops.IVX_F16_PAIR
+        self.flat = [FusedConv(m.conv.weight, m.conv.bias, dims=2, dtype=ind[i] or od, out_dtype=od, chain=chain).to(device)
                      for i, m in enumerate(self.lateral_convs)]
-        self.fout = [FusedConv(m.conv.weight, m.conv.bias, padding=1, dims=2).to(device) for m in self.fpn_convs]
+        self.fout = [FusedConv(m.conv.weight, m.conv.bias, padding=1, dims=2, chain=chain).to(device) for m in self.fpn_convs]
         self._device = device
         return self
 
@@ -250,13 +294,19 @@ class FPN(nn.Module):
             self.prepare(feats[0].device)
         n = len(feats)
         lat = [None] * n
-        lat[n - 1] = self.flat[n - 1](feats[n - 1])
+        # pair chain: a lateral map is written as a PairTensor when its lateral conv read one and an output conv with pair filters reads
+        # it (level 0 always; the others only with all_levels) -- maps that are only added top-down stay fp32
+        wp = lambda i: isinstance(feats[i], ops.PairTensor) and self.fout[i].pair_ok and (i == 0 or all_levels)
+        lat[n - 1] = self.flat[n - 1](feats[n - 1], out_pair=wp(n - 1))
         for i in range(n - 2, -1, -1):   # lateral conv + nearest-upsampled coarser level, fused in the epilogue
-            lat[i] = self.flat[i](feats[i], res=lat[i + 1], res_mode=2)
+            res = lat[i + 1]
+            if isinstance(res, ops.PairTensor) and not isinstance(feats[i], ops.PairTensor):
+                res = res.float()
+            lat[i] = self.flat[i](feats[i], res=res, res_mode=2, out_pair=wp(i) and ops.slots_of(res) is not None)
         outs = [self.fout[0](lat[0])]
         if all_levels:
             outs += [self.fout[i](lat[i]) for i in range(1, n)]
-        return outs
+        return [o.float() if isinstance(o, ops.PairTensor) else o for o in outs]
 
     def forward(self, inputs, all_levels=True):
         outs = self.forward_cl([ops.to_channels_last(t.contiguous()) for t in inputs], all_levels)

@@ -141,6 +141,10 @@ class FusedConv:
     # (~3.3x the fp32 MFMA rate at 22-bit operands: the error stays at the level of the fp32 form's own rounding);
     # 0 = fp32 MFMA (exact fp32 products)
     wino_operands = int(os.environ.get('IVX_WINO_OPERANDS', '4'))
+    # 2-D trunk (ResNet + FPN; ivx_model_cfg.trunk_operands): 4 = activations chained as fp16 (hi, lo) pair tensors with device-side
+    # scales (ops.PairTensor, ivx_conv_fwd_pio): every convolution whose input is such a tensor issues three fp16 MFMA products per
+    # multiply-add with fp32 accumulation and its epilogue writes the operand of the next layer -- no conversion pass; 0 = fp32 MFMA
+    trunk_operands = int(os.environ.get('IVX_TRUNK_OPERANDS', '4'))
     # optional per-call timing (bench.py): when a list, every call appends
     # (kind, start_event, end_event, executed_flops, bytes, is_3d) with kind 'direct' | 'wino_input' | 'wino_gemm' |
     # 'wino_output'; the events bracket exactly the launches of that stage on the stream they run on; is_3d tells the 3-D
@@ -153,7 +157,7 @@ class FusedConv:
     calib_margin = 1.0
 
     def __init__(self, weight, bias=None, bn=None, stride=1, padding=0, relu=False, dims=3, eps=1e-5, layout=None,
-                 dtype=None, out_dtype=None, key=None):
+                 dtype=None, out_dtype=None, key=None, chain=False):
         """weight: [Cout,Cin,kh,kw] (dims=2) or [Cout,Cin,kd,kh,kw] (dims=3) tensor (any device).
         bn: None or (gamma, beta, running_mean, running_var).
         dtype: storage type of the input and the packed weights (float32 = the reference's precision; bfloat16 is the
@@ -189,6 +193,7 @@ class FusedConv:
         wp = w.permute(0, 2, 3, 4, 1).contiguous()
         if self.cin_pad != self.cin:
             wp = torch.nn.functional.pad(wp, (0, self.cin_pad - self.cin))
+        wp_tap = wp                                  # [Cout,kd,kh,kw,Cin_pad], tap-major: what the pair form packs (chain=True)
         # layout 1 (chunk-major K) whenever the channel count allows it: see include/imvoxel.h
         self.layout = 1 if (self.cin_pad % ck == 0 and layout != 0) else 0
         if self.layout == 1:
@@ -226,6 +231,16 @@ class FusedConv:
         self.relu = relu
         self.out_mode = 0
         self.w = self.scale = self.shift = None
+        # chain=True (the layers of the 2-D trunk when FusedConv.trunk_operands == 4): pair filters + scale / s_w and the terms of the
+        # output bound (ivx_pair_pack_filters, as csrc/model.cpp pack_layer); layers the pair form does not take (the stem) get the bound only
+        self.pair_ok = False
+        self.wbound = self.sbound = None
+        self._wpair_host = self._scale_p_host = self.wpair = self.scale_p = None
+        if chain and dtype == torch.float32 and out_dtype == torch.float32 and dims == 2 and type(self) is FusedConv:
+            self.pair_ok = self.cin_pad == self.cin and self.cin % 32 == 0 and self.cout % 4 == 0
+            taps = self.kernel[0] * self.kernel[1] * self.kernel[2]
+            self._wpair_host, self._scale_p_host, self.wbound, self.sbound = ops.pair_pack_filters(
+                wp_tap.reshape(self.cout, taps, self.cin_pad), self._scale_host, self._shift_host, pack=self.pair_ok)
 
     def to(self, device):
         self.w = self._w_host.to(device)
@@ -239,11 +254,19 @@ class FusedConv:
         if not self._identity_epilogue:
             self.scale = self._scale_host.to(device)
             self.shift = self._shift_host.to(device)
+        if self._wpair_host is not None:
+            self.wpair = self._wpair_host.to(device)
+            self.scale_p = self._scale_p_host.to(device)
         return self
 
-    def __call__(self, x, res=None, res_mode=0, relu=None, naive=False, res_after_act=False, post_scale=1.0):
+    def __call__(self, x, res=None, res_mode=0, relu=None, naive=False, res_after_act=False, post_scale=1.0, out_pair=False):
+        """out_pair (pair chain only): write the output as a PairTensor -- the caller knows whether every consumer takes one."""
         if self.w is None:
             raise RuntimeError('FusedConv.to(device) must be called before use')
+        if isinstance(x, ops.PairTensor):
+            return self._call_pio(x, res, res_mode, relu, naive, res_after_act, post_scale, out_pair)
+        if isinstance(res, ops.PairTensor):
+            raise TypeError('a pair residual needs a pair input (the fp32 kernels read fp32 residuals)')
         if self.dtype == FP8 or self.out_dtype == FP8 or isinstance(res, QTensor):
             return self._call_quantized(x, res, res_mode, relu, naive, res_after_act, post_scale)
         y = self._call(x, res, res_mode, relu, naive, res_after_act, post_scale)
@@ -314,6 +337,29 @@ class FusedConv:
                                     x.shape[1] > 1 and x.shape[3] > 1, self._describe(x, 0)))
             return y
         return self._direct(x, res, res_mode, relu, naive, res_after_act, post_scale, epi)
+
+    def _call_pio(self, x, res, res_mode, relu, naive, res_after_act, post_scale, out_pair):
+        """the fp16-pair form on a PairTensor input (ops.conv_fwd_pio); out_pair needs Cout % 16 == 0"""
+        if self.wpair is None:
+            raise TypeError('this layer has no pair filters (FusedConv(chain=True) with Cin % 32 == 0)')
+        tr = FusedConv.trace is not None
+        fl = 2.0 * x.shape[0] * self.cout * self.cin * self.kernel[0] * self.kernel[1] * self.kernel[2]
+        if tr:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        y = ops.conv_fwd_pio(x, self.wpair, self.scale_p, self.shift, self.kernel, self.stride, self.padding, self.relu if relu is None else relu,
+                             self.wbound, self.sbound, res, res_mode, out_pair=bool(out_pair) and self.cout % 16 == 0, res_after_act=res_after_act,
+                             post_scale=post_scale, naive=naive)
+        npos = y.shape[1] * y.shape[2] * y.shape[3]
+        if FusedConv.count_flops:
+            FusedConv.flops += fl * npos
+            FusedConv.exec_flops += 3.0 * fl * npos
+        if tr:
+            e1.record()
+            FusedConv.trace.append(('direct', e0, e1, 3.0 * fl * npos,
+                                    float(4 * x.numel() + 4 * y.numel() + 2 * self.wpair.numel() + (4 * res.numel() if res is not None else 0)),
+                                    False, self._describe(x, 0) + ' pair'))
+        return y
 
     def takes_pair_form(self, x_shape, dtype=torch.float32, naive=False):
         return (self.wp is not None and not naive and dtype == torch.float32 and FusedConv.pair_mode >= (1 if self._dims == 3 else 2)

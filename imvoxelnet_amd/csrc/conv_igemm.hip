@@ -72,7 +72,44 @@ struct ConvParams {
   float res_scale;    // multiplier of the residual (fp8 storage: res_scale_of_tensor / out_scale); 1 otherwise
   int in_pair;        // 1 / 2: in / wgt hold every fp32 value as a (hi, lo) bf16 / fp16 pair, 16-channel groups [hi16 | lo16] (IVX_*_PAIR); Cin and K
                       // count bf16 elements (2 per real channel); the K loop issues hi*hi + hi*lo + lo*hi per group
+  // fp16-pair ACTIVATIONS with device-side power-of-two scales (ivx_pair_io, include/imvoxel.h): the 2-D trunk chained on the 16-bit
+  // matrix cores without split passes -- the producing epilogue writes the operand its consumer reads.
+  int pio;                       // any of the fields below is in use (in_pair == 2 kernels, the split-K reduction, the validation kernel)
+  const float *in_scale_p;       // device: the scale the pair input was written with (NULL: 1); the accumulator is divided by it
+  int out_pair, res_pair;        // out / res are IVX_F16_PAIR tensors [.., 2*Cout] (independently of each other)
+  const float *res_scale_p;      // device: scale of the pair residual
+  float *out_scale_p;            // device: receives the scale chosen for the output
+  const unsigned *amax_in, *amax_res;   // device, IVX_AMAX_SLOTS words: bits of max |in| / max |res| (true values); out_pair only
+  unsigned *amax_out;            // device, IVX_AMAX_SLOTS words the epilogue accumulates max |out| into (atomic max), or NULL
+  float wbound, sbound;          // |out| <= amax_in * wbound + sbound (+ amax_res): max_co |scale[co]| * sum_k |w[co][k]| and max_co |shift[co]|
 };
+
+// What a wave needs of the pair-IO state: multipliers of the accumulator / the residual (exact: powers of two) and the output scale.
+struct PairIO { float inv_in, inv_res, s_out; };
+// Every wave computes the same values from the same device words (no communication): the output scale comes from a BOUND of the
+// output -- |out| <= max|in| * wbound + sbound + max|res| with the MEASURED maxima of the operands, which their producers left in the
+// amax slots -- so nothing has to pass over the output before it is written as (hi, lo) halves.  A bound that is loose by a factor L
+// costs nothing up to L = 2^18: a value's error is max(2^-22 |x|, 2^-25 / s), i.e. relative to the tensor's maximum max(2^-22, 2^-40 L).
+__device__ __forceinline__ PairIO conv_pair_io(const ConvParams &p) {
+  PairIO io = {1.0f, 1.0f, 1.0f};
+  if (p.in_scale_p) io.inv_in = 1.0f / *p.in_scale_p;
+  if (p.res_pair && p.res_scale_p) io.inv_res = 1.0f / *p.res_scale_p;
+  if (p.out_pair) {
+    const int lane = threadIdx.x & 63;
+    float a = p.amax_in ? __uint_as_float(p.amax_in[lane]) : 0.f;
+    float r = (p.amax_res && p.res_mode) ? __uint_as_float(p.amax_res[lane]) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a = fmaxf(a, __shfl_xor(a, o));
+      r = fmaxf(r, __shfl_xor(r, o));
+    }
+    const float bound = (a * p.wbound + p.sbound + r) * fabsf(p.post_scale) * 1.001f;
+    io.s_out = ivx_pow2_scale(bound);
+  }
+  return io;
+}
+// element offset (in halves) of channel n of row `row` (C channels) inside an IVX_F16_PAIR tensor: hi; lo is 16 further
+__device__ __forceinline__ size_t pair_off(size_t row, int n, int C) { return row * (size_t)(2 * C) + (size_t)((n >> 4) * 32 + (n & 15)); }
 
 struct fp8_t { unsigned char v; };       // storage element of the fp8 instantiation (size 1)
 typedef long i64_t;
@@ -86,10 +123,21 @@ __device__ __forceinline__ unsigned int f32x2_to_fp8(float a, float b) {
 }
 
 __device__ __forceinline__ float conv_ld_res(const ConvParams &p, size_t i) {
+  if (p.res_pair) {      // (generic one-element paths only: split-K reduction, validation kernel); the caller multiplies by 1 / scale
+    const _Float16 *r = reinterpret_cast<const _Float16 *>(p.res) + pair_off(i / p.Cout, (int)(i % p.Cout), p.Cout);
+    return (float)r[0] + (float)r[16];
+  }
   if (p.out_fp8) return fp8_to_f32(reinterpret_cast<const unsigned char *>(p.res)[i]);
   return p.out_bf16 ? (float)reinterpret_cast<const __bf16 *>(p.res)[i] : p.res[i];
 }
 __device__ __forceinline__ void conv_st_out(const ConvParams &p, size_t i, float v) {
+  if (p.out_pair) {      // v is already multiplied by the output scale
+    _Float16 *o = reinterpret_cast<_Float16 *>(p.out) + pair_off(i / p.Cout, (int)(i % p.Cout), p.Cout);
+    const _Float16 h = (_Float16)v;
+    o[0] = h;
+    o[16] = (_Float16)(v - (float)h);
+    return;
+  }
   if (p.out_fp8)
     reinterpret_cast<unsigned char *>(p.out)[i] = (unsigned char)(f32x2_to_fp8(v, 0.f) & 0xffu);
   else if (p.out_bf16)
@@ -116,14 +164,17 @@ __device__ __noinline__ size_t res2_row_base(int m, int Ho, int Wo, int rH, int 
 }
 
 // y = act(acc*scale + shift [+ res]) [+ res] [* post_scale] for one output element; `oidx` is its flat offset.
-__device__ __forceinline__ float conv_finish(const ConvParams &p, float acc, float sc, float sf, size_t ridx) {
+__device__ __forceinline__ float conv_finish(const ConvParams &p, float acc, float sc, float sf, size_t ridx, float rscale) {
   float v = acc * sc + sf;
   // one fused multiply-add, spelled out so that every epilogue variant rounds the same way; res_scale is 1 outside the fp8 mode,
   // where fma(r, 1, v) == v + r exactly
-  if (p.res_mode && !p.res_after_act) v = __builtin_fmaf(conv_ld_res(p, ridx), p.res_scale, v);
+  if (p.res_mode && !p.res_after_act) v = __builtin_fmaf(conv_ld_res(p, ridx), rscale, v);
   if (p.relu) v = v > 0.f ? v : 0.f;
-  if (p.res_mode && p.res_after_act) v = __builtin_fmaf(conv_ld_res(p, ridx), p.res_scale, v);
+  if (p.res_mode && p.res_after_act) v = __builtin_fmaf(conv_ld_res(p, ridx), rscale, v);
   return v * p.post_scale;
+}
+__device__ __forceinline__ float conv_finish(const ConvParams &p, float acc, float sc, float sf, size_t ridx) {
+  return conv_finish(p, acc, sc, sf, ridx, p.res_scale);
 }
 
 // Flat output offset of (row m, column n) for out_mode 1 (ConvTranspose3d kernel 2, stride 2): row m is the INPUT
@@ -235,6 +286,77 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams &p, f32x16 (
       }
     }
   }
+}
+
+// Pair-IO variant of the wide epilogue (in_pair == 2 kernels; ConvParams::pio): the accumulator is divided by the input's scale, the
+// residual is fp32 or an fp16 (hi, lo) pair tensor with its own scale, the output is fp32 or a pair tensor written with the scale of
+// conv_pair_io -- a lane's 4 channels are 8 bytes of hi halves and, 32 bytes further, 8 bytes of lo halves -- and the maximum of the
+// stored values (true values, before the output scale) goes to the amax slots for the next layer's bound.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_wide_pio(const ConvParams &p, const PairIO io, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
+                                                       int lane, float *stage, int salt) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const int col_l = lane & 31, hh = lane >> 5;
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+  float omax = 0.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = n0 + (wc * TN + j) * 32 + c4;
+    const bool nok = nb < p.Cout;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+    if (nok && p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + nb);
+    if (nok && p.shift) sf = *reinterpret_cast<const f32x4 *>(p.shift + nb);
+    sc *= io.inv_in;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col_l] = acc[i][j][r];
+      const int mb = m0 + (wr * TM + i) * 32 + rrow;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(stage + (rrow + 8 * q) * 32 + c4);
+        const int m = mb + 8 * q;
+        if (m < p.M && nok) {
+          v = v * sc + sf;
+          f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+          if (p.res_mode) {
+            if (p.res_pair) {
+              const size_t row = p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, 1) : (size_t)m;
+              const _Float16 *rp = reinterpret_cast<const _Float16 *>(p.res) + pair_off(row, nb, p.Cout);
+              const f16x4 rh = *reinterpret_cast<const f16x4 *>(rp), rl = *reinterpret_cast<const f16x4 *>(rp + 16);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) rr[e] = ((float)rh[e] + (float)rl[e]) * io.inv_res;
+            } else {
+              rr = *reinterpret_cast<const f32x4 *>(p.res + (p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) : (size_t)m * p.Cout) + nb);
+            }
+          }
+          if (p.res_mode && !p.res_after_act) v += rr;
+          if (p.relu) {
+            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+          }
+          if (p.res_mode && p.res_after_act) v += rr;
+          v *= p.post_scale;
+          omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          if (p.out_pair) {
+            f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y = v[e] * io.s_out;
+              h[e] = (_Float16)y;
+              l[e] = (_Float16)(y - (float)h[e]);
+            }
+            _Float16 *op = reinterpret_cast<_Float16 *>(p.out) + pair_off((size_t)m, nb, p.Cout);
+            *reinterpret_cast<f16x4 *>(op) = h;
+            *reinterpret_cast<f16x4 *>(op + 16) = l;
+          } else {
+            *reinterpret_cast<f32x4 *>(p.out + (size_t)m * p.Cout + nb) = v;
+          }
+        }
+      }
+    }
+  }
+  if (p.amax_out) ivx_amax_commit(p.amax_out, omax, salt);
 }
 
 // bf16-output variant of the wide epilogue (Cout % 8 == 0).  The one-channel-per-lane epilogue stores 2 bytes per lane --
@@ -884,6 +1006,15 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
       }
     return;
   }
+  if constexpr (PAIR == 2) {
+    if (p.pio) {        // fill_params guarantees out_mode 0, Cout % 16 == 0, no grouped launch
+      static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
+      const PairIO io = conv_pair_io(p);
+      if (p.out_scale_p && blockIdx.x == 0 && tid == 0) *p.out_scale_p = io.s_out;     // (workgroup 0 owns M-tile q_begin of XCD 0: never out of range)
+      conv_epilogue_wide_pio<TM, TN>(p, io, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, (int)blockIdx.x * (NT / 64) + wid_u);
+      return;
+    }
+  }
   if (p.out_mode == 0 && !p.out_bf16 && !p.out_fp8 && (p.Cout & 3) == 0 && !p.narrow_epilogue) {
     static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
     conv_epilogue_wide<TM, TN>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, gz * (size_t)p.g_out);
@@ -908,18 +1039,28 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
 // Epilogue + store of one output element (row m, column n) from its finished accumulator: shared by the validation
 // kernel and the split-K reduction.
 #if IVX_CONV_TU == 0
-__device__ __forceinline__ void conv_store_one(const ConvParams &p, int m, int n, float acc) {
+// (pair IO: the scales of conv_pair_io; returns |stored value| before the output scale, for the amax slots)
+__device__ __forceinline__ float conv_store_one(const ConvParams &p, int m, int n, float acc, const PairIO io = {1.0f, 1.0f, 1.0f}) {
+  if (p.pio) {
+    const size_t idx = (size_t)m * p.Cout + n;
+    size_t ridx = idx;
+    if (p.res_mode == 2) ridx = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + n;
+    const float v = conv_finish(p, acc, (p.scale ? p.scale[n] : 1.0f) * io.inv_in, p.shift ? p.shift[n] : 0.0f, ridx, p.res_pair ? io.inv_res : 1.0f);
+    conv_st_out(p, idx, p.out_pair ? v * io.s_out : v);
+    return fabsf(v);
+  }
   if (p.out_mode == 1) {
     const int tap = n / p.Cr, ch = n - tap * p.Cr;
     const int a2 = tap >> 2, e2 = (tap >> 1) & 1, f2 = tap & 1;
     const size_t o = up2_row_base(m, p.D, p.H, p.W, p.Cr) + (((size_t)a2 * 2 * p.H + e2) * 2 * p.W + f2) * p.Cr + ch;
     conv_st_out(p, o, conv_finish(p, acc, p.scale ? p.scale[ch] : 1.0f, p.shift ? p.shift[ch] : 0.0f, o));
-    return;
+    return 0.f;
   }
   const size_t idx = (size_t)m * p.Cout + n;
   size_t ridx = idx;
   if (p.res_mode == 2) ridx = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + n;
   conv_st_out(p, idx, conv_finish(p, acc, p.scale ? p.scale[n] : 1.0f, p.shift ? p.shift[n] : 0.0f, ridx));
+  return 0.f;
 }
 
 // Split-K reduction: out = epilogue(sum over slices in slice order) -- deterministic.  Partial rows are compact:
@@ -927,6 +1068,12 @@ __device__ __forceinline__ void conv_store_one(const ConvParams &p, int m, int n
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const size_t rows = (size_t)8 * p.q_count * p.bm;
   const size_t total = rows * p.Cout;
+  PairIO io = {1.0f, 1.0f, 1.0f};
+  if (p.pio) {
+    io = conv_pair_io(p);
+    if (p.out_scale_p && blockIdx.x == 0 && threadIdx.x == 0) *p.out_scale_p = io.s_out;
+  }
+  float omax = 0.f;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int n = (int)(idx % p.Cout);
     const size_t cr = idx / p.Cout;
@@ -936,13 +1083,20 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
     if (m >= p.M) continue;
     float acc = 0.f;
     for (int z = 0; z < p.ksplit; ++z) acc += p.partial[(size_t)z * total + idx];
-    conv_store_one(p, (int)m, n, acc);
+    omax = fmaxf(omax, conv_store_one(p, (int)m, n, acc, io));
   }
+  if (p.pio && p.amax_out) ivx_amax_commit(p.amax_out, omax, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
 }
 
 // Validation kernel: one thread per output element, sequential fmaf over (kd,kh,kw,ci).
 __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p) {
   const size_t total = (size_t)p.M * p.Cout;
+  PairIO io = {1.0f, 1.0f, 1.0f};
+  if (p.pio) {
+    io = conv_pair_io(p);
+    if (p.out_scale_p && blockIdx.x == 0 && threadIdx.x == 0) *p.out_scale_p = io.s_out;
+  }
+  float omax = 0.f;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int n = (int)(idx % p.Cout);
     const int m = (int)(idx / p.Cout);
@@ -992,8 +1146,9 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
         }
       }
     }
-    conv_store_one(p, m, n, acc);
+    omax = fmaxf(omax, conv_store_one(p, m, n, acc, io));
   }
+  if (p.pio && p.amax_out) ivx_amax_commit(p.amax_out, omax, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
 }
 
 static thread_local int g_plan_mode = 0;
@@ -1012,7 +1167,7 @@ extern "C" int ivx_conv_set_epilogue_mode(int narrow) {
 }
 
 static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
-                       const float *shift, const void *res, void *out, ConvParams *p) {
+                       const float *shift, const void *res, void *out, ConvParams *p, const ivx_pair_io *io = nullptr) {
   IVX_REQUIRE(d && in && wgt && out, "ivx_conv_fwd: null argument");
   IVX_REQUIRE(d->B > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "ivx_conv_fwd: non-positive dims");
   IVX_REQUIRE(d->Cin % 4 == 0, "ivx_conv_fwd: Cin (%d) must be a multiple of 4 (pad the input channels)", d->Cin);
@@ -1030,8 +1185,17 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   IVX_REQUIRE(d->out_mode == 0 || (d->out_mode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 1 && d->sd == 1 && d->sh == 1 && d->sw == 1 &&
                                      d->pd == 0 && d->ph == 0 && d->pw == 0 && d->Cout % 8 == 0 && d->res_mode != 2),
               "ivx_conv_fwd: out_mode 1 (ConvTranspose k2 s2) needs a 1x1x1 stride-1 GEMM with Cout = 8 * real channels");
-  IVX_REQUIRE(d->in_dtype >= IVX_F32 && d->in_dtype <= IVX_F16_PAIR && d->out_dtype >= IVX_F32 && d->out_dtype <= IVX_FP8,
-              "ivx_conv_fwd: dtypes are IVX_F32 (0), IVX_BF16 (1), IVX_FP8 (2) or, for the input, IVX_BF16_PAIR (3) / IVX_F16_PAIR (4)");
+  IVX_REQUIRE(d->in_dtype >= IVX_F32 && d->in_dtype <= IVX_F16_PAIR && d->out_dtype >= IVX_F32 && (d->out_dtype <= IVX_FP8 || (io && d->out_dtype == IVX_F16_PAIR)),
+              "ivx_conv_fwd: dtypes are IVX_F32 (0), IVX_BF16 (1), IVX_FP8 (2) or, for the input, IVX_BF16_PAIR (3) / IVX_F16_PAIR (4); an IVX_F16_PAIR "
+              "output needs ivx_conv_fwd_pio");
+  if (io) {
+    IVX_REQUIRE(d->in_dtype == IVX_F16_PAIR && d->out_mode == 0 && d->Cout % 4 == 0 && (d->out_dtype == IVX_F32 || d->out_dtype == IVX_F16_PAIR),
+                "ivx_conv_fwd_pio: needs an IVX_F16_PAIR input, out_mode 0, Cout %% 4 == 0 and an IVX_F32 or IVX_F16_PAIR output");
+    IVX_REQUIRE(io->res_dtype == IVX_F32 || io->res_dtype == IVX_F16_PAIR, "ivx_conv_fwd_pio: res_dtype is IVX_F32 or IVX_F16_PAIR");
+    IVX_REQUIRE(d->out_dtype != IVX_F16_PAIR || (d->Cout % 16 == 0 && io->out_scale && io->amax_in && (d->res_mode == 0 || io->amax_res)),
+                "ivx_conv_fwd_pio: a pair output needs Cout %% 16 == 0, out_scale, amax_in (and amax_res with a residual)");
+    IVX_REQUIRE(!(d->res_mode && io->res_dtype == IVX_F16_PAIR) || (d->Cout % 16 == 0 && io->res_scale), "ivx_conv_fwd_pio: a pair residual needs Cout %% 16 == 0 and res_scale");
+  }
   IVX_REQUIRE(!pair || (d->Cin % 16 == 0 && d->out_mode == 0), "ivx_conv_fwd: bf16-pair input needs Cin %% 16 == 0 and out_mode 0");
   IVX_REQUIRE(d->in_dtype != IVX_FP8 || d->Cin % 16 == 0, "ivx_conv_fwd: fp8 input needs Cin %% 16 == 0");
   IVX_REQUIRE((d->in_dtype != IVX_FP8 && d->out_dtype != IVX_FP8) || d->out_mode == 0, "ivx_conv_fwd: fp8 is built for out_mode 0 only");
@@ -1059,6 +1223,17 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   p->ksplit = 1; p->partial = nullptr; p->q_total = 0; p->q_begin = 0; p->q_count = 0; p->bm = 0;
   p->groups = 1; p->g_in = p->g_w = p->g_out = 0;
   p->narrow_epilogue = g_narrow_epilogue;
+  p->pio = 0; p->in_scale_p = nullptr; p->out_pair = 0; p->res_pair = 0; p->res_scale_p = nullptr; p->out_scale_p = nullptr;
+  p->amax_in = p->amax_res = nullptr; p->amax_out = nullptr; p->wbound = 0.f; p->sbound = 0.f;
+  if (io) {
+    p->pio = 1;
+    p->in_scale_p = io->in_scale;
+    p->out_pair = d->out_dtype == IVX_F16_PAIR; p->out_bf16 = 0;
+    p->res_pair = d->res_mode && io->res_dtype == IVX_F16_PAIR;
+    p->res_scale_p = io->res_scale; p->out_scale_p = p->out_pair ? io->out_scale : nullptr;
+    p->amax_in = io->amax_in; p->amax_res = d->res_mode ? io->amax_res : nullptr; p->amax_out = io->amax_out;
+    p->wbound = io->wbound; p->sbound = io->sbound;
+  }
   return IVX_OK;
 }
 
@@ -1854,6 +2029,43 @@ extern "C" int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const voi
   rc = conv_dispatch(p, true, true, workspace, workspace_bytes, (hipStream_t)stream, &need, "ivx_conv_fwd_ws");
   if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_fwd_ws");
+  return IVX_OK;
+}
+
+extern "C" int64_t ivx_conv_pio_workspace_bytes(const ivx_conv_desc *d, const ivx_pair_io *io) {
+  ConvParams p;
+  float dummy;
+  if (!io) { ivx_set_error("ivx_conv_pio_workspace_bytes: null pair io"); return -1; }
+  if (fill_params(d, &dummy, &dummy, nullptr, nullptr, d && d->res_mode ? &dummy : nullptr, &dummy, &p, io) != IVX_OK) return -1;
+  int64_t need;
+  if (conv_dispatch(p, true, false, nullptr, 0, nullptr, &need, "ivx_conv_pio_workspace_bytes") != IVX_OK) return -1;
+  return need;
+}
+
+extern "C" int ivx_conv_fwd_pio(const ivx_conv_desc *d, const ivx_pair_io *io, const void *in, const void *wgt, const float *scale, const float *shift,
+                                const void *res, void *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream) {
+  ConvParams p;
+  IVX_REQUIRE(io, "ivx_conv_fwd_pio: null pair io");
+  int rc = fill_params(d, in, wgt, scale, shift, res, out, &p, io);
+  if (rc != IVX_OK) return rc;
+  int64_t need;
+  rc = conv_dispatch(p, true, true, workspace, workspace_bytes, (hipStream_t)stream, &need, "ivx_conv_fwd_pio");
+  if (rc != IVX_OK) return rc;
+  IVX_CHECK_LAUNCH("ivx_conv_fwd_pio");
+  return IVX_OK;
+}
+
+extern "C" int ivx_conv_fwd_pio_naive(const ivx_conv_desc *d, const ivx_pair_io *io, const void *in, const void *wgt, const float *scale, const float *shift,
+                                      const void *res, void *out, ivx_stream_t stream) {
+  ConvParams p;
+  IVX_REQUIRE(io, "ivx_conv_fwd_pio_naive: null pair io");
+  int rc = fill_params(d, in, wgt, scale, shift, res, out, &p, io);
+  if (rc != IVX_OK) return rc;
+  const size_t total = (size_t)p.M * p.Cout;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 65536 * 8) blocks = 65536 * 8;
+  hipLaunchKernelGGL(conv_naive_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  IVX_CHECK_LAUNCH("ivx_conv_fwd_pio_naive");
   return IVX_OK;
 }
 

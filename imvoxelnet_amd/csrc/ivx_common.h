@@ -26,3 +26,34 @@ void ivx_set_error(const char *fmt, ...);
   } while (0)
 
 static inline int64_t ivx_align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+#if defined(__HIPCC__)
+// Power-of-two scale of an fp16 (hi, lo) pair tensor (IVX_F16_PAIR): s = 2^k with amax * s in [2^14, 2^15); 1 for 0 / non-finite amax.
+__device__ __forceinline__ float ivx_pow2_scale(const float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+  int e;
+  (void)frexpf(amax, &e);                        // amax in [2^(e-1), 2^e)
+  int k = 15 - e;
+  k = k < -120 ? -120 : (k > 120 ? 120 : k);
+  return ldexpf(1.0f, k);
+}
+// max |tensor| accumulated into IVX_AMAX_SLOTS device words (include/imvoxel.h, ivx_pair_io): max over the calling wave (every lane
+// calls), then one atomic max on slot `salt` % 64 -- bits of non-negative floats order like the floats.  The slot is read first: the
+// values only grow, so a (possibly stale) slot that already holds >= m makes the atomic unnecessary, and after the first few waves
+// almost every wave skips it (same-address atomics serialise: 8192 of them cost 0.27 ms in round 3).
+__device__ __forceinline__ void ivx_amax_commit(unsigned *slots, float m, int salt) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) {
+    unsigned *s = slots + (salt & (IVX_AMAX_SLOTS - 1));
+    if (__float_as_uint(m) > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(s, __float_as_uint(m));
+  }
+}
+// the maximum the slots hold (every lane of a full wave calls; all lanes get the result)
+__device__ __forceinline__ float ivx_amax_read(const unsigned *slots) {
+  float a = __uint_as_float(slots[threadIdx.x & (IVX_AMAX_SLOTS - 1)]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o));
+  return a;
+}
+#endif

@@ -48,6 +48,41 @@ namespace {
 
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
+// IEEE binary16 <-> binary32 on the host, round to nearest even (bit-level: the CPU restatement of the ABI is built with a g++ that has
+// no _Float16).  Same bits as a device-side (_Float16) conversion and as torch's .to(float16).
+inline uint16_t f32_to_f16_bits(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u, ax = x & 0x7fffffffu;
+  if (ax >= 0x7f800000u) return (uint16_t)(sign | (ax > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (ax < 0x38800000u) {                       // below 2^-14: a subnormal half = the value in units of 2^-24
+    float a;
+    memcpy(&a, &ax, 4);
+    const float r = a * 16777216.0f;            // exact
+    return (uint16_t)(sign | (uint32_t)lrintf(r));   // default rounding mode: to nearest even; 1024 = the smallest normal half
+  }
+  const uint32_t mant = ax & 0x7fffffu, exp = (ax >> 23) - 127 + 15;
+  uint32_t h = (exp << 10) | (mant >> 13);
+  const uint32_t rem = mant & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;   // a carry out of the mantissa bumps the exponent; 65520 and above -> inf
+  return (uint16_t)(sign | h);
+}
+inline float f16_bits_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+  float f;
+  if (e == 0) {
+    f = (float)m * 5.9604644775390625e-08f;     // m * 2^-24
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    x |= sign;
+    memcpy(&f, &x, 4);
+    return f;
+  }
+  const uint32_t x = sign | (e == 31 ? 0x7f800000u | (m << 13) : ((e - 15 + 127) << 23) | (m << 13));
+  memcpy(&f, &x, 4);
+  return f;
+}
+
 struct HostTensor {
   std::vector<int64_t> shape;
   std::vector<float> data;
@@ -71,6 +106,10 @@ struct ConvLayer {
   bool wino_cand = false, wino2d = false, identity_epilogue = true;
   float *w = nullptr, *w0 = nullptr, *scale = nullptr, *shift = nullptr;
   std::map<int, float *> u;           // tile * 8 + operand type -> transformed filters
+  // fp16-pair form (cfg.trunk_operands = IVX_F16_PAIR; ivx_conv_fwd_pio): pair filters, scale / s_w, and the terms of the output bound
+  bool pair_ok = false;
+  float *wpair = nullptr, *scale_p = nullptr;
+  float wbound = 0.f, sbound = 0.f;
 };
 
 enum StepKind { ST_IMG2CL, ST_CONV, ST_MAXPOOL, ST_LIFT, ST_TAIL, ST_UPSAMPLE, ST_DCN_COL, ST_AVGPOOL, ST_LAYOUT, ST_FCOS, ST_INDOOR_TAIL };
@@ -90,6 +129,8 @@ struct TInfo {
   int64_t bytes = 0, off = -1;
   int first = -1, last = -1;
   bool raw = false;          // a byte buffer (candidate lists): `bytes` is set explicitly
+  int fmt = 0;               // 0: fp32; IVX_F16_PAIR: fp16 (hi, lo) pairs with a device-side scale (same bytes)
+  int64_t slot = -1;         // arena offset of the tensor's scalar block: IVX_AMAX_SLOTS words of max |tensor|, then its scale; -1: none
   int64_t elems() const { return (int64_t)B * D * H * W * C; }
 };
 
@@ -102,6 +143,8 @@ struct PlanStep {
   // those instead of reading the whole tensor again (amax_in / amax_in_n); -1: the input stage reduces the tensor itself
   int64_t amax_out = -1, amax_in = -1;
   int amax_n = 0, amax_in_n = 0;
+  int pio = 0;            // CONV: the fp16-pair form (ivx_conv_fwd_pio); MAXPOOL: pair output (aux = the stem's layer for the bound)
+  int bound_layer = -1;
 };
 
 struct Plan {
@@ -114,6 +157,7 @@ struct Plan {
   int n_views = 1;
   ivx_indoor_tail_desc itail;          // indoor families with a head
   int max_det = 0;                     // rows per sample of the detection outputs
+  int64_t scal_off = 0, scal_bytes = 0;   // scalar blocks of the pair-chained tensors (zeroed at the start of every forward)
 };
 
 }  // namespace
@@ -564,6 +608,20 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
     M_TRY(dev_upload(m, scale, &L.scale, st));
     M_TRY(dev_upload(m, shift, &L.shift, st));
   }
+  // fp16-pair form of the 2-D trunk (cfg.trunk_operands): pair filters + scale / s_w, and the bound terms (also for the layers that
+  // stay fp32: the stem's bound scales the max-pool's pair output)
+  const bool trunk_layer = L.name.rfind("backbone.", 0) == 0 || L.name.rfind("neck.", 0) == 0;
+  if (m->cfg.trunk_operands == IVX_F16_PAIR && trunk_layer && !L.conv_t && !L.dcn_cols && !L.linear) {
+    L.pair_ok = L.cin_pad == L.cin && L.cin % 32 == 0 && L.cout % 4 == 0;
+    std::vector<uint16_t> packed(L.pair_ok ? 2 * n_w : 0);
+    std::vector<float> sp(L.pair_ok ? L.cout : 0);
+    M_TRY(ivx_pair_pack_filters(wp.data(), L.cout, taps, L.cin_pad, scale.data(), shift.data(), L.pair_ok ? packed.data() : nullptr,
+                                L.pair_ok ? sp.data() : nullptr, &L.wbound, &L.sbound));
+    if (L.pair_ok) {
+      M_TRY(dev_upload_sync(m, reinterpret_cast<const float *>(packed.data()), n_w, &L.wpair, st));
+      M_TRY(dev_upload_sync(m, sp.data(), sp.size(), &L.scale_p, st));
+    }
+  }
   return IVX_OK;
 }
 
@@ -608,7 +666,7 @@ int conv_out(const ConvLayer &L, const TInfo &in, TInfo *o) {
 }
 
 // The Winograd decision of FusedConv.wino_tile (conv.py): returns the tile (0 = direct) and the descriptor to run.
-int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const TInfo *res, PlanStep *ps, hipStream_t stream) {
+int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const TInfo *res, PlanStep *ps, hipStream_t stream, int out_fmt = 0) {
   ivx_conv_desc d;
   memset(&d, 0, sizeof(d));
   d.B = in.B; d.D = in.D; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L.cout;
@@ -622,6 +680,21 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
   d.res_after_act = st.res_after_act;
   d.out_mode = L.conv_t ? 1 : 0;
   M_REQUIRE(in.C == L.cin_pad, "layer %s: input has %d channels, expected %d", L.name.c_str(), in.C, L.cin_pad);
+  if (in.fmt == IVX_F16_PAIR) {      // the fp16-pair form: direct kernel on the 16-bit matrix cores, scales on the device
+    M_REQUIRE(L.pair_ok && L.wpair, "internal: layer %s reads a pair tensor but has no pair filters", L.name.c_str());
+    d.in_dtype = IVX_F16_PAIR; d.out_dtype = out_fmt; d.wgt_layout = 1;
+    ivx_pair_io io;
+    memset(&io, 0, sizeof(io));
+    float f; uint32_t u;             // workspace query: the pointers are only tested for NULL
+    io.in_scale = &f; io.res_scale = &f; io.out_scale = &f; io.amax_in = &u; io.amax_res = &u; io.amax_out = &u;
+    io.res_dtype = res ? res->fmt : 0;
+    ps->d = d;
+    ps->ws = ivx_conv_pio_workspace_bytes(&d, &io);
+    M_REQUIRE(ps->ws >= 0, "layer %s: %s", L.name.c_str(), ivx_last_error());
+    ps->tile = 0;
+    ps->pio = 1;
+    return IVX_OK;
+  }
   int tile = 0;
   ivx_conv_desc dw = d;
   if (L.wino_cand && !L.conv_t && m->cfg.winograd && (st.res_mode == 0 || st.res_mode == 1) && (int64_t)in.B * in.D * in.H * in.W >= 2000) {
@@ -676,19 +749,56 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
   pl->ps.assign(m->steps.size(), PlanStep());
   for (auto &kv : inputs) { pl->t[kv.first] = kv.second; pl->t[kv.first].first = -2; }
   const ivx_model_cfg &c = m->cfg;
+  // fp16-pair chaining of the 2-D trunk (cfg.trunk_operands): a tensor is stored as pairs when its producer can write them (the
+  // max-pool after the stem, a convolution that itself reads pairs) and every step that reads it as an INPUT is a trunk convolution
+  // with pair filters; residual uses take either format.  Tensors that leave the trunk (FPN level 0, C5 for the LayoutHead, DCNv2
+  // columns) therefore stay fp32.  Every tensor of the chain owns a scalar block (amax slots + scale) in the arena.
+  const bool pair_mode = c.trunk_operands == IVX_F16_PAIR && c.with_trunk;
+  int n_slots = 0;
+  auto wants_pair = [&](int t, const TInfo &ti) {
+    if (!pair_mode || ti.C % 16 || ti.elems() * 4 >= (1LL << 31)) return false;
+    bool any = false;
+    for (int j = r.s0; j < r.s1; ++j) {
+      const Step &q = m->steps[j];
+      if (q.in != t) continue;
+      if (j < m->trunk0 || j >= m->trunk1 || q.kind != ST_CONV || !m->layers[q.layer].pair_ok) return false;
+      any = true;
+    }
+    return any;
+  };
   for (int i = r.s0; i < r.s1; ++i) {
     const Step &s = m->steps[i];
     const TInfo &in = pl->t[s.in];
     M_REQUIRE(in.B > 0, "internal: step %d reads an unplanned tensor", i);
     TInfo o;
+    o.fmt = 0; o.slot = -1;
     switch (s.kind) {
-      case ST_IMG2CL: o = in; o.C = 4; break;
-      case ST_MAXPOOL: o = in; o.H = (in.H + 2 - 3) / 2 + 1; o.W = (in.W + 2 - 3) / 2 + 1; break;
+      case ST_IMG2CL:
+        o = in; o.C = 4; o.fmt = 0; o.slot = -1;
+        if (pair_mode) o.slot = n_slots++;                 // max |image| for the bound of the stem's output
+        break;
+      case ST_MAXPOOL: {
+        o = in; o.H = (in.H + 2 - 3) / 2 + 1; o.W = (in.W + 2 - 3) / 2 + 1; o.fmt = 0; o.slot = -1;
+        int prod = -1;                                     // the stem: its bound terms and the image's maximum scale the pooled map
+        for (int j = r.s0; j < i; ++j)
+          if (m->steps[j].out == s.in && m->steps[j].kind == ST_CONV) prod = j;
+        if (prod >= 0 && pl->t[m->steps[prod].in].slot >= 0 && pl->t[m->steps[prod].in].fmt == 0 && wants_pair(s.out, o)) {
+          o.fmt = IVX_F16_PAIR; o.slot = n_slots++;
+          pl->ps[i].pio = 1; pl->ps[i].bound_layer = m->steps[prod].layer;
+        }
+        break;
+      }
       case ST_UPSAMPLE: o = in; o.D = 2 * in.D; o.H = 2 * in.H; o.W = 2 * in.W; break;
       case ST_CONV: {
         ConvLayer &L = m->layers[s.layer];
         M_TRY(conv_out(L, in, &o));
-        M_TRY(plan_conv(m, L, in, s, s.res >= 0 ? &pl->t[s.res] : nullptr, &pl->ps[i], stream));
+        int out_fmt = 0;
+        if (in.fmt == IVX_F16_PAIR) {                      // reads pairs: its epilogue leaves max |out|, and writes pairs when the consumers take them
+          o.slot = n_slots++;
+          if (o.C % 16 == 0 && in.slot >= 0 && (s.res < 0 || pl->t[s.res].slot >= 0) && wants_pair(s.out, o)) out_fmt = IVX_F16_PAIR;
+          o.fmt = out_fmt;
+        }
+        M_TRY(plan_conv(m, L, in, s, s.res >= 0 ? &pl->t[s.res] : nullptr, &pl->ps[i], stream, out_fmt));
         pl->ws_bytes = std::max(pl->ws_bytes, pl->ps[i].ws);
         break;
       }
@@ -754,6 +864,7 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       pl->max_det = c.max_num;
       continue;
     }
+    if (s.kind != ST_CONV && s.kind != ST_MAXPOOL && s.kind != ST_IMG2CL) { o.fmt = 0; o.slot = -1; }   // (`o = in` above copies the input's)
     o.bytes = align256(o.elems() * 4);
     o.first = i;
     pl->t[s.out] = o;
@@ -851,6 +962,12 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       }
       break;
     }
+  }
+  if (n_slots > 0) {        // scalar blocks of the pair chain: IVX_AMAX_SLOTS words + the scale, 512 bytes apart
+    top = align256(top);
+    pl->scal_off = top;
+    pl->scal_bytes = (int64_t)n_slots * 512;
+    top += pl->scal_bytes;
   }
   pl->arena = align256(top);
   pl->ws_off = pl->arena;
@@ -968,6 +1085,11 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
     if (it != bd.ext.end()) return it->second;
     return base + pl.t[t].off;
   };
+  // scalar block of a pair-chained tensor: IVX_AMAX_SLOTS words of max |tensor|, then its scale
+  auto slotp = [&](int t) -> uint32_t * { return (t >= 0 && pl.t[t].slot >= 0) ? (uint32_t *)(base + pl.scal_off + pl.t[t].slot * 512) : nullptr; };
+  auto scalep = [&](int t) -> float * { uint32_t *q = slotp(t); return q ? (float *)(q + IVX_AMAX_SLOTS) : nullptr; };
+  if (pl.scal_bytes > 0 && r.s0 <= m->trunk0 && r.s1 > m->trunk0)
+    M_HIP(hipMemsetAsync(base + pl.scal_off, 0, (size_t)pl.scal_bytes, st), "hipMemsetAsync (amax slots)");
   const bool span2d = m->trace_on && m->trace_level == 1 && m->cfg.with_trunk;     // coarse tracing: the trunk is one span
   double span_flops = 0.0;
   for (int i = r.s0; i < r.s1; ++i) {
@@ -989,17 +1111,29 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           const double tiles = (double)o.B * ((ps.d.D + 2 * ps.d.pd - 2 + ps.tile - 1) / ps.tile) * ((ps.d.H + 2 * ps.d.ph - 2 + ps.tile - 1) / ps.tile);
           span_flops += (ps.d.wino_operands ? 3.0 : 1.0) * 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin;   // as the per-launch records count
         } else {
-          span_flops += 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2];
+          span_flops += (ps.pio ? 3.0 : 1.0) * 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2];      // pair form: three products per multiply-add
         }
       }
     }
     struct Restore { ivx_model *m; bool on; ~Restore() { m->trace_on = on; } } restore{m, was_on};   // also on an error return
     switch (s.kind) {
       case ST_IMG2CL:
-        M_TRY(ivx_nchw_to_nhwc((const float *)ptr(s.in), in.B, 3, (int64_t)in.H * in.W, 4, (float *)ptr(s.out), st));
+        if (slotp(s.out))
+          M_TRY(ivx_nchw_to_nhwc_amax((const float *)ptr(s.in), in.B, 3, (int64_t)in.H * in.W, 4, (float *)ptr(s.out), slotp(s.out), st));
+        else
+          M_TRY(ivx_nchw_to_nhwc((const float *)ptr(s.in), in.B, 3, (int64_t)in.H * in.W, 4, (float *)ptr(s.out), st));
         break;
       case ST_MAXPOOL:
-        M_TRY(ivx_maxpool2d_fwd((const float *)ptr(s.in), in.B, in.H, in.W, in.C, 3, 2, 1, (float *)ptr(s.out), st));
+        if (pl.ps[i].pio) {        // fp32 stem output -> pair tensor, scaled by the bound of the stem's output from the image's maximum
+          const ConvLayer &Ls = m->layers[pl.ps[i].bound_layer];
+          int t_img4 = -1;
+          for (int j = r.s0; j < i; ++j)
+            if (m->steps[j].out == s.in) t_img4 = m->steps[j].in;
+          M_REQUIRE(slotp(t_img4), "internal: the pair max-pool needs the image's amax slots");
+          M_TRY(ivx_maxpool2d_fwd_pair((const float *)ptr(s.in), in.B, in.H, in.W, in.C, 3, 2, 1, ptr(s.out), slotp(t_img4), Ls.wbound, Ls.sbound,
+                                       scalep(s.out), slotp(s.out), st));
+        } else
+          M_TRY(ivx_maxpool2d_fwd((const float *)ptr(s.in), in.B, in.H, in.W, in.C, 3, 2, 1, (float *)ptr(s.out), st));
         break;
       case ST_UPSAMPLE:
         M_TRY(ivx_upsample_trilinear2x_fwd((const float *)ptr(s.in), in.B, in.D, in.H, in.W, in.C, (float *)ptr(s.out), st));
@@ -1029,8 +1163,18 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           M_TRY(trace_end(m, st));
           break;
         }
-        M_TRY(trace_begin(m, i, 0, is3d, 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2], 0.0, L.name, st));
-        if (ps.tile) {
+        M_TRY(trace_begin(m, i, 0, is3d, (ps.pio ? 3.0 : 1.0) * 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2], 0.0, L.name, st));
+        if (ps.pio) {
+          ivx_pair_io io;
+          memset(&io, 0, sizeof(io));
+          io.in_scale = scalep(s.in);
+          io.res_dtype = s.res >= 0 ? pl.t[s.res].fmt : 0;
+          io.res_scale = io.res_dtype == IVX_F16_PAIR ? scalep(s.res) : nullptr;
+          io.out_scale = scalep(s.out);
+          io.amax_in = slotp(s.in); io.amax_res = slotp(s.res); io.amax_out = slotp(s.out);
+          io.wbound = L.wbound; io.sbound = L.sbound;
+          M_TRY(ivx_conv_fwd_pio(&ps.d, &io, ptr(s.in), L.wpair, L.scale_p, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
+        } else if (ps.tile) {
           M_TRY(ivx_conv_winograd_input_amax(&ps.d, ps.tile, ptr(s.in), ws, pl.ws_bytes, ps.amax_in >= 0 ? (const float *)(base + ps.amax_in) : nullptr,
                                              ps.amax_in_n, st));
           M_TRY(ivx_conv_winograd_gemm(&ps.d, ps.tile, L.u.at(ps.tile * 8 + ps.d.wino_operands), ws, pl.ws_bytes, st));
@@ -1159,6 +1303,7 @@ extern "C" int ivx_create(const ivx_model_cfg *cfg, ivx_model **out) {
                                                  "runtime initialises (hipGraph replays of this path are wrong on ROCm 7.2 otherwise)");
   }
   M_REQUIRE(cfg->wino_operands == IVX_F32 || cfg->wino_operands == IVX_F16_PAIR, "ivx_create: wino_operands IVX_F32 | IVX_F16_PAIR");
+  M_REQUIRE(cfg->trunk_operands == IVX_F32 || cfg->trunk_operands == IVX_F16_PAIR, "ivx_create: trunk_operands IVX_F32 | IVX_F16_PAIR");
   M_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 2 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "ivx_create: winograd_tile 0 | 2 | 4 | 6");
   M_REQUIRE(cfg->head_type >= IVX_HEAD_NONE && cfg->head_type <= IVX_HEAD_SUNRGBD, "ivx_create: head_type 0 (none) | IVX_HEAD_SCANNET | IVX_HEAD_SUNRGBD");
   if (cfg->head_type != IVX_HEAD_NONE) {
@@ -1657,6 +1802,56 @@ extern "C" int ivx_model_trace_read(ivx_model *m, int32_t i, ivx_trace_rec *rec)
   M_HIP(hipEventElapsedTime(&start, m->trace[0].e0, r.e0), "hipEventElapsedTime");
   rec->step = r.step; rec->stage = r.stage; rec->is3d = r.is3d; rec->ms = ms; rec->start_ms = start; rec->flops = r.flops; rec->bytes = r.bytes;
   snprintf(rec->name, sizeof(rec->name), "%s", r.name.c_str());
+  return IVX_OK;
+}
+
+// Host-only: filters of the fp16-pair form (include/imvoxel.h).  Both hosts call this, so the kernels get the same bits from either.
+extern "C" int ivx_pair_pack_filters(const float *w, int32_t Cout, int32_t taps, int32_t Cin, const float *scale, const float *shift, void *packed,
+                                     float *scale_out, float *wbound, float *sbound) {
+  M_REQUIRE(w && Cout > 0 && taps > 0 && Cin > 0 && wbound && sbound, "ivx_pair_pack_filters: bad argument");
+  M_REQUIRE(!packed || (Cin % 32 == 0 && scale_out), "ivx_pair_pack_filters: pair filters need Cin %% 32 == 0 and scale_out");
+  const size_t per = (size_t)taps * Cin;
+  float amax = 0.f;
+  double wb = 0.0, sb = 0.0;
+  for (int co = 0; co < Cout; ++co) {
+    double l1 = 0.0;
+    const float *r = w + (size_t)co * per;
+    for (size_t k = 0; k < per; ++k) {
+      const float a = fabsf(r[k]);
+      amax = a > amax ? a : amax;
+      l1 += (double)a;
+    }
+    wb = std::max(wb, fabs((double)(scale ? scale[co] : 1.0f)) * l1);
+    sb = std::max(sb, fabs((double)(shift ? shift[co] : 0.0f)));
+  }
+  *wbound = nextafterf((float)wb, INFINITY);      // never below the exact value
+  *sbound = nextafterf((float)sb, INFINITY);
+  if (!packed) return IVX_OK;
+  float sw = 1.0f;
+  if (amax > 0.f && amax < 3.0e38f) {             // as ivx_pow2_scale on the device: max |w| * s_w in [2^14, 2^15)
+    int e;
+    (void)frexpf(amax, &e);
+    int k = 15 - e;
+    k = k < -120 ? -120 : (k > 120 ? 120 : k);
+    sw = ldexpf(1.0f, k);
+  }
+  const float inv = 1.0f / sw;
+  for (int co = 0; co < Cout; ++co) scale_out[co] = (scale ? scale[co] : 1.0f) * inv;
+  uint16_t *o = (uint16_t *)packed;
+  const int nch = Cin / 32;
+  for (int co = 0; co < Cout; ++co)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int t = 0; t < taps; ++t) {
+        uint16_t *dst = o + (((size_t)co * nch + ch) * taps + t) * 64;
+        const float *src = w + ((size_t)co * taps + t) * Cin + (size_t)ch * 32;
+        for (int g = 0; g < 2; ++g)
+          for (int e = 0; e < 16; ++e) {
+            const float y = src[g * 16 + e] * sw;
+            const uint16_t h = f32_to_f16_bits(y);
+            dst[g * 32 + e] = h;
+            dst[g * 32 + 16 + e] = f32_to_f16_bits(y - f16_bits_to_f32(h));
+          }
+      }
   return IVX_OK;
 }
 

@@ -366,3 +366,126 @@ extern "C" int ivx_f16_pair_split(const float *in, int64_t n, float scale, void 
   IVX_REQUIRE(scale > 0.f, "ivx_f16_pair_split: the scale must be positive");
   return pair_split_launch<_Float16>(in, n, scale, out, stream, "ivx_f16_pair_split");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Head of a chain of fp16-pair activations (include/imvoxel.h, "Chained fp16-pair activations").
+// ivx_nchw_to_nhwc that also accumulates max |in| (the image) into the caller's amax slots.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_amax_kernel(const float *in, int C, long long S, int Cpad, float *out, unsigned *amax) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const long long s0 = (long long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  float m = 0.f;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const long long s = s0 + tx;
+    const float v = (c < C && s < S) ? in[((size_t)b * C + c) * S + s] : 0.f;
+    tile[r][tx] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const long long s = s0 + r;
+    const int c = c0 + tx;
+    if (s < S && c < Cpad) out[((size_t)b * S + s) * Cpad + c] = tile[tx][r];
+  }
+  ivx_amax_commit(amax, m, (int)(blockIdx.x + blockIdx.z) * 4 + (int)(threadIdx.x >> 6));
+}
+
+extern "C" int ivx_nchw_to_nhwc_amax(const float *in, int32_t B, int32_t C, int64_t S, int32_t Cpad, float *out, uint32_t *amax,
+                                     ivx_stream_t stream) {
+  IVX_REQUIRE(in && out && amax && B > 0 && C > 0 && S > 0 && Cpad >= C, "ivx_nchw_to_nhwc_amax: bad argument");
+  IVX_REQUIRE(B <= 65535 && (Cpad + 31) / 32 <= 65535, "ivx_nchw_to_nhwc_amax: dims too large");
+  dim3 grid((unsigned)((S + 31) / 32), (Cpad + 31) / 32, B);
+  hipLaunchKernelGGL(nchw_to_nhwc_amax_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, C, (long long)S, Cpad, out, amax);
+  IVX_CHECK_LAUNCH("ivx_nchw_to_nhwc_amax");
+  return IVX_OK;
+}
+
+// nn.MaxPool2d(k, s, p) on an fp32 NHWC map -> IVX_F16_PAIR tensor.  One thread per (output pixel, 4 channels): 8 bytes of hi halves
+// and, 32 bytes further, 8 bytes of lo halves.  The scale comes from the bound amax_in * wbound + sbound of the INPUT map (the stem's
+// output as a function of the image's maximum): a window maximum cannot exceed it.  -inf padding semantics of torch as in
+// maxpool2d_nhwc_kernel; the pool is exact (a maximum of fp32 values), only the final split rounds (to 22 bits).
+__global__ __launch_bounds__(256) void maxpool2d_nhwc_pair_kernel(const float *in, int B, int H, int W, int C, int k, int s, int pd, int Ho,
+                                                                  int Wo, _Float16 *out, const unsigned *amax_in, float wbound, float sbound,
+                                                                  float *out_scale, unsigned *amax_out) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const float sc = ivx_pow2_scale((ivx_amax_read(amax_in) * wbound + sbound) * 1.001f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *out_scale = sc;
+  const int C4 = C >> 2;
+  const size_t total = (size_t)B * Ho * Wo * C4;
+  float omax = 0.f;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    size_t t = idx / C4;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int e = 0; e < k; ++e) {
+      const int ih = oh * s - pd + e;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int f = 0; f < k; ++f) {
+        const int iw = ow * s - pd + f;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (((size_t)b * H + ih) * W + iw) * C + c4 * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = (v[q] > m[q] || v[q] != v[q]) ? v[q] : m[q];
+      }
+    }
+    f16x4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      omax = fmaxf(omax, fabsf(m[q]));
+      const float y = m[q] * sc;
+      hi[q] = (_Float16)y;
+      lo[q] = (_Float16)(y - (float)hi[q]);
+    }
+    const int n = c4 * 4;
+    _Float16 *o = out + (idx / C4) * (size_t)(2 * C) + (size_t)((n >> 4) * 32 + (n & 15));
+    *reinterpret_cast<f16x4 *>(o) = hi;
+    *reinterpret_cast<f16x4 *>(o + 16) = lo;
+  }
+  if (amax_out) ivx_amax_commit(amax_out, omax, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+}
+
+extern "C" int ivx_maxpool2d_fwd_pair(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p, void *out,
+                                      const uint32_t *amax_in, float wbound, float sbound, float *out_scale, uint32_t *amax_out,
+                                      ivx_stream_t stream) {
+  IVX_REQUIRE(in && out && amax_in && out_scale, "ivx_maxpool2d_fwd_pair: null argument");
+  IVX_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0, "ivx_maxpool2d_fwd_pair: bad dims (C %% 16 must be 0)");
+  IVX_REQUIRE(k > 0 && s > 0 && p >= 0 && 2 * p <= k, "ivx_maxpool2d_fwd_pair: bad window");
+  IVX_REQUIRE(wbound >= 0.f && sbound >= 0.f, "ivx_maxpool2d_fwd_pair: negative bound terms");
+  const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  IVX_REQUIRE(Ho > 0 && Wo > 0, "ivx_maxpool2d_fwd_pair: empty output");
+  const size_t total = (size_t)B * Ho * Wo * (C / 4);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(maxpool2d_nhwc_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, B, H, W, C, k, s, p, Ho, Wo,
+                     (_Float16 *)out, amax_in, wbound, sbound, out_scale, amax_out);
+  IVX_CHECK_LAUNCH("ivx_maxpool2d_fwd_pair");
+  return IVX_OK;
+}
+
+// IVX_F16_PAIR [n] -> fp32 [n]: x = (hi + lo) / scale (exact: hi + lo has at most 22 significant bits, the scale is a power of two)
+__global__ __launch_bounds__(256) void pair_merge_kernel(const _Float16 *in, size_t n16, const float *scale, float *out) {
+  const float inv = scale ? 1.0f / *scale : 1.0f;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n16; t += (size_t)gridDim.x * blockDim.x) {
+    const _Float16 *g = in + t * 32;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[t * 16 + e] = ((float)g[e] + (float)g[16 + e]) * inv;
+  }
+}
+
+extern "C" int ivx_f16_pair_merge(const void *in, int64_t n, const float *scale_dev, float *out, ivx_stream_t stream) {
+  IVX_REQUIRE(in && out && n >= 0 && n % 16 == 0, "ivx_f16_pair_merge: null argument or n not a multiple of 16");
+  if (n == 0) return IVX_OK;
+  const size_t n16 = (size_t)n / 16;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(pair_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)in, n16, scale_dev, out);
+  IVX_CHECK_LAUNCH("ivx_f16_pair_merge");
+  return IVX_OK;
+}

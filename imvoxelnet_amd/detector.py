@@ -74,6 +74,8 @@ class ImVoxelNet(nn.Module):
                 m.prepare(device)
             if self.head_2d is not None:
                 self.head_2d.prepare(device)
+                if hasattr(self.backbone, 'stage_out_pair'):      # the LayoutHead pools C5: that stage output stays fp32 in the pair chain
+                    self.backbone.stage_out_pair = (True, True, True, False)
         self.storage_dtype, self._prepared_device, self.trunk_fp8 = dtype, device, False
         import os
         from . import engine

@@ -122,6 +122,7 @@ def model_cfg(model, with_trunk=True, winograd=None, winograd_tile=None):
     cfg.winograd = int(FusedConv.winograd if winograd is None else winograd)
     cfg.winograd_tile = int(FusedConv.winograd_tile if winograd_tile is None else winograd_tile)
     cfg.wino_operands = int(FusedConv.wino_operands)
+    cfg.trunk_operands = int(FusedConv.trunk_operands) if with_trunk else 0
     return cfg
 
 

@@ -335,6 +335,179 @@ def maxpool2d(x, k=3, s=2, p=1):
     return out
 
 
+# ------------------------------------------------------------------ chained fp16-pair activations (include/imvoxel.h, ivx_pair_io)
+AMAX_SLOTS = 64
+
+
+def new_slots(device):
+    """Scalar block of one tensor of a pair chain: AMAX_SLOTS words of max |tensor| (float bits, accumulated by the producing kernel
+    with atomic max: they start at zero) followed by the tensor's power-of-two scale."""
+    return torch.zeros(AMAX_SLOTS + 16, device=device, dtype=torch.int32)
+
+
+def _scale_ptr(slots):
+    return C.c_void_p(slots.data_ptr() + 4 * AMAX_SLOTS)
+
+
+class PairTensor:
+    """An IVX_F16_PAIR activation: data = float16 [B,D,H,W,2C] (per 16 channels [hi x16 | lo x16]) of s * x, with the scalar block
+    (amax slots, scale s) its producer filled on the device.  `shape` is the logical fp32 shape [B,D,H,W,C]."""
+    __slots__ = ('data', 'slots')
+
+    def __init__(self, data, slots):
+        self.data, self.slots = data, slots
+
+    shape = property(lambda self: tuple(self.data.shape[:4]) + (self.data.shape[4] // 2,))
+    device = property(lambda self: self.data.device)
+    dtype = property(lambda self: torch.float32)       # what the values are; the storage is fp16 pairs
+
+    def numel(self):
+        return self.data.numel() // 2
+
+    def element_size(self):
+        return 4
+
+    def float(self):
+        """fp32 values (hi + lo) / s (ivx_f16_pair_merge)."""
+        out = torch.empty(self.shape, device=self.data.device, dtype=torch.float32)
+        check(_lib.lib().ivx_f16_pair_merge(_ptr(self.data), out.numel(), _scale_ptr(self.slots), _ptr(out), _stream()), 'ivx_f16_pair_merge')
+        return out
+
+    def amax(self):
+        """max |x| as the producer recorded it (host float; synchronises)."""
+        return float(self.slots[:AMAX_SLOTS].view(torch.float32).max())
+
+    def scale(self):
+        return float(self.slots[AMAX_SLOTS:AMAX_SLOTS + 1].view(torch.float32)[0])
+
+
+def slots_of(t):
+    """The scalar block a tensor of the chain carries (a PairTensor's, or the one attached to an fp32 tensor by its producer), or None."""
+    return t.slots if isinstance(t, PairTensor) else getattr(t, 'ivx_slots', None)
+
+
+def to_channels_last_amax(x, pad_to=None):
+    """to_channels_last that also records max |x| in a scalar block attached to the result (out.ivx_slots): ivx_nchw_to_nhwc_amax."""
+    _chk(x, 'x')
+    B, Cn = x.shape[0], x.shape[1]
+    sp = list(x.shape[2:])
+    if len(sp) == 2:
+        sp = [1] + sp
+    S = sp[0] * sp[1] * sp[2]
+    Cp = Cn if pad_to is None else ((Cn + pad_to - 1) // pad_to) * pad_to
+    out = torch.empty([B] + sp + [Cp], device=x.device, dtype=torch.float32)
+    slots = new_slots(x.device)
+    check(_lib.lib().ivx_nchw_to_nhwc_amax(_ptr(x), B, Cn, S, Cp, _ptr(out), _ptr(slots), _stream()), 'ivx_nchw_to_nhwc_amax')
+    out.ivx_slots = slots
+    return out
+
+
+def maxpool2d_pair(x, amax_in, wbound, sbound, k=3, s=2, p=1):
+    """nn.MaxPool2d on an fp32 map -> PairTensor scaled by the bound amax_in * wbound + sbound of the input map (ivx_maxpool2d_fwd_pair);
+    amax_in: the scalar block of the tensor the bound refers to (the image)."""
+    _chk(x, 'x')
+    B, D, H, W, Cn = x.shape
+    if D != 1 or Cn % 16:
+        raise ValueError('maxpool2d_pair expects a 2-D map with C % 16 == 0')
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    out = torch.empty((B, 1, Ho, Wo, 2 * Cn), device=x.device, dtype=torch.float16)
+    slots = new_slots(x.device)
+    check(_lib.lib().ivx_maxpool2d_fwd_pair(_ptr(x), B, H, W, Cn, k, s, p, _ptr(out), _ptr(amax_in), float(wbound), float(sbound),
+                                            _scale_ptr(slots), _ptr(slots), _stream()), 'ivx_maxpool2d_fwd_pair')
+    return PairTensor(out, slots)
+
+
+def pair_pack_filters(w_tap, scale, shift, pack=True):
+    """Host: fp32 filters [Cout, taps, Cin] (tap-major, CPU) + the epilogue vectors -> (pair filters float16 [Cout, Cin/32, taps, 64] or None,
+    scale / s_w [Cout] or None, wbound, sbound) through ivx_pair_pack_filters (the native handle packs with the same function)."""
+    w_tap = w_tap.detach().to(torch.float32).cpu().contiguous()
+    co, taps, ci = w_tap.shape
+    sc = None if scale is None else scale.detach().to(torch.float32).cpu().contiguous()
+    sf = None if shift is None else shift.detach().to(torch.float32).cpu().contiguous()
+    packed = torch.empty((co, ci // 32, taps, 64), dtype=torch.float16) if pack else None
+    sp = torch.empty(co, dtype=torch.float32) if pack else None
+    wb, sb = C.c_float(), C.c_float()
+    check(_lib.lib().ivx_pair_pack_filters(_ptr_any(w_tap), co, taps, ci, _ptr_any(sc), _ptr_any(sf), _ptr_any(packed), _ptr_any(sp), C.byref(wb),
+                                           C.byref(sb)), 'ivx_pair_pack_filters')
+    return packed, sp, wb.value, sb.value
+
+
+def _ptr_any(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def conv_fwd_pio(x, wgt, scale, shift, kernel, stride, padding, relu, wbound, sbound, res=None, res_mode=0, out_pair=False,
+                 res_after_act=False, post_scale=1.0, naive=False):
+    """Convolution on a PairTensor (ivx_conv_fwd_pio): wgt = pair filters of pair_pack_filters (device), scale = scale / s_w.
+    res: None, an fp32 tensor or a PairTensor.  Returns a PairTensor (out_pair) or an fp32 tensor; either carries the scalar block with
+    max |out| (result.slots / result.ivx_slots)."""
+    if not isinstance(x, PairTensor):
+        raise TypeError('conv_fwd_pio takes a PairTensor')
+    _chk(x.data, 'x', torch.float16)
+    _chk(wgt, 'wgt', torch.float16)
+    B, D, H, W, Cin = x.shape
+    Cout = wgt.shape[0]
+    if tuple(wgt.shape[1:]) != (Cin // 32, kernel[0] * kernel[1] * kernel[2], 64):
+        raise ValueError(f'pair filters {tuple(wgt.shape)} do not match kernel {kernel} / Cin {Cin}')
+    d = ConvDesc(B, D, H, W, Cin, Cout, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
+                 int(bool(relu)), 0, 0, 0, 1, 0, int(bool(res_after_act)), float(post_scale), IVX_F16_PAIR, IVX_F16_PAIR if out_pair else 0, 1.0)
+    do, ho, wo = C.c_int32(), C.c_int32(), C.c_int32()
+    L = _lib.lib()
+    check(L.ivx_conv_out_dims(C.byref(d), C.byref(do), C.byref(ho), C.byref(wo)), 'ivx_conv_out_dims')
+    oshape = (B, do.value, ho.value, wo.value, Cout)
+    out_pair = bool(out_pair) and Cout % 16 == 0 and B * do.value * ho.value * wo.value * Cout * 4 < 2 ** 31     # (as csrc/model.cpp wants_pair)
+    io = _lib.PairIO()
+    io.in_scale = _scale_ptr(x.slots)
+    io.amax_in = _ptr(x.slots)
+    rd = None
+    if res is not None:
+        res_mode = res_mode or 1
+        rshape = tuple(res.shape)
+        if res_mode == 1 and rshape != oshape:
+            raise ValueError(f'residual shape {rshape} != output shape')
+        if res_mode == 2:
+            if rshape[0] != B or rshape[1] != 1 or rshape[4] != Cout:
+                raise ValueError('res_mode 2 residual must be [B,1,h,w,Cout]')
+            d.res_h, d.res_w = rshape[2], rshape[3]
+        d.res_mode = res_mode
+        if isinstance(res, PairTensor):
+            rd = _chk(res.data, 'res', torch.float16)
+            io.res_dtype, io.res_scale = IVX_F16_PAIR, _scale_ptr(res.slots)
+        else:
+            rd = _chk(res, 'res')
+        rs = slots_of(res)
+        io.amax_res = _ptr(rs)
+        if out_pair and rs is None:
+            raise ValueError('a pair output needs the scalar block (max |res|) of its residual')
+    for t, n in ((scale, 'scale'), (shift, 'shift')):
+        if t is not None:
+            _chk(t, n)
+            if t.numel() != Cout:
+                raise ValueError(f'{n} must have {Cout} elements')
+    slots = new_slots(x.device)
+    io.amax_out = _ptr(slots)
+    io.out_scale = _scale_ptr(slots)
+    io.wbound, io.sbound = float(wbound), float(sbound)
+    if out_pair:
+        out = torch.empty(oshape[:4] + (2 * Cout,), device=x.device, dtype=torch.float16)
+    else:
+        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+    if naive:
+        check(L.ivx_conv_fwd_pio_naive(C.byref(d), C.byref(io), _ptr(x.data), _ptr(wgt), _ptr(scale), _ptr(shift), _ptr(rd), _ptr(out), _stream()),
+              'ivx_conv_fwd_pio_naive')
+    else:
+        wsb = L.ivx_conv_pio_workspace_bytes(C.byref(d), C.byref(io))
+        if wsb < 0:
+            check(-1, 'ivx_conv_pio_workspace_bytes')
+        ws = torch.empty((wsb,), device=x.device, dtype=torch.uint8) if wsb > 0 else None
+        check(L.ivx_conv_fwd_pio(C.byref(d), C.byref(io), _ptr(x.data), _ptr(wgt), _ptr(scale), _ptr(shift), _ptr(rd), _ptr(out), _ptr(ws),
+                                 max(wsb, 0), _stream()), 'ivx_conv_fwd_pio')
+    if out_pair:
+        return PairTensor(out, slots)
+    out.ivx_slots = slots
+    return out
+
+
 def global_avgpool(x):
     """[B,D,H,W,C] channels-last -> [B,1,1,1,C]: mean over every spatial position."""
     _chk(x, 'x')

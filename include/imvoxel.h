@@ -37,7 +37,7 @@ extern "C" {
 
 typedef void *ivx_stream_t; /* hipStream_t */
 
-/* Library version (major*10000 + minor*100 + patch; 301 = 0.3.1, the struct layouts of this header) and the message of
+/* Library version (major*10000 + minor*100 + patch; 400 = 0.4.0, the struct layouts of this header) and the message of
  * the last failing call on this thread (never NULL). */
 int ivx_version(void);
 const char *ivx_last_error(void);
@@ -134,6 +134,57 @@ int ivx_conv_pair_supported(const ivx_conv_desc *d);
 /* A/B knob (per calling thread) of the Winograd-domain GEMMs on fp16 pairs: -1 (default) = the z-halo kernel where it applies (1x1x3 along z,
  * stride 1, pad 1, Cin % 32 == 0: one staged tile serves the three z-taps), 0 = the generic LDS-DMA kernel always, 1 .. 4 = force a config. */
 int ivx_conv_set_halo_mode(int mode);
+
+/* ---------------------------------------------------------------------------------------
+ * Chained fp16-pair activations (0.4.0): the 2-D trunk on the 16-bit matrix cores without split passes.
+ * Replaces the same call sites as ivx_conv_fwd (ResNet-50 / FPN: mmdet3d/models/detectors/imvoxelnet.py:48,50) -- same arithmetic
+ * contract, fp32 values, fp32 accumulation -- with the ACTIVATIONS between the layers stored as IVX_F16_PAIR tensors [B,D,H,W,2C]
+ * (hi = fp16(s x), lo = fp16(s x - hi), 16-channel groups [hi x16 | lo x16], 4 bytes per value like fp32; 22 significant bits) so
+ * that every convolution issues hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate, three products per
+ * multiply-add) and the epilogue of the PRODUCING layer writes the operand the consuming layer reads: no conversion pass.
+ * The power-of-two scale s of a tensor lives in device memory and is chosen on the device, without a pass over the tensor, from a
+ * bound of the output:  |out| <= max|in| * wbound + sbound + max|res|,  wbound = max_co |scale[co]| * sum_k |w[co][k]|,
+ * sbound = max_co |shift[co]|, with the MEASURED maxima of the operands: every epilogue accumulates max |out| (true values) into
+ * IVX_AMAX_SLOTS words of the tensor (atomic max on the bits; the caller zeroes them before the producer runs).  The bound
+ * puts the largest value below 2^15 (fp16 holds 65504); a bound that is loose by a factor L costs accuracy only beyond L = 2^18
+ * (error relative to the tensor's maximum: max(2^-22, 2^-40 L)).
+ *   in      IVX_F16_PAIR (d->in_dtype), written with *in_scale (NULL: 1); wgt: IVX_F16_PAIR filters (ivx_conv_desc), their
+ *           power-of-two scale folded into scale[] by the caller (scale[co] = bn_scale[co] / s_w: exact)
+ *   out     d->out_dtype IVX_F32 or IVX_F16_PAIR (then *out_scale receives its scale; needs amax_in, and amax_res with a residual)
+ *   res     res_dtype IVX_F32 or IVX_F16_PAIR (*res_scale), independent of the output's type
+ *   amax_out  slots that receive max |out| (or NULL)
+ * Restrictions: out_mode 0, Cout % 4 == 0 (pair output / residual: Cout % 16 == 0), tensors below 2 GiB. */
+#define IVX_AMAX_SLOTS 64
+typedef struct ivx_pair_io {
+  const float *in_scale;       /* device [1] or NULL */
+  const float *res_scale;      /* device [1]; res_dtype IVX_F16_PAIR */
+  int32_t res_dtype;           /* IVX_F32 | IVX_F16_PAIR */
+  float *out_scale;            /* device [1]; out_dtype IVX_F16_PAIR */
+  const uint32_t *amax_in;     /* device [IVX_AMAX_SLOTS]: bits of max |in| */
+  const uint32_t *amax_res;    /* device [IVX_AMAX_SLOTS]: bits of max |res| */
+  uint32_t *amax_out;          /* device [IVX_AMAX_SLOTS] or NULL */
+  float wbound, sbound;
+} ivx_pair_io;
+int64_t ivx_conv_pio_workspace_bytes(const ivx_conv_desc *d, const ivx_pair_io *io);
+int ivx_conv_fwd_pio(const ivx_conv_desc *d, const ivx_pair_io *io, const void *in, const void *wgt, const float *scale, const float *shift,
+                     const void *res, void *out, void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
+/* validation kernel of the same contract (tests only): plain fp32 products of the values the pairs stand for */
+int ivx_conv_fwd_pio_naive(const ivx_conv_desc *d, const ivx_pair_io *io, const void *in, const void *wgt, const float *scale, const float *shift,
+                           const void *res, void *out, ivx_stream_t stream);
+/* Host-only (both hosts of the library call it, so they hand the kernels identical bits): fp32 filters w [Cout][taps][Cin] (tap-major,
+ * Cin % 32 == 0) -> IVX_F16_PAIR filters `packed` (2 * Cout * taps * Cin halves, chunk-major K: [Cout][Cin/32][taps][hi16|lo16|hi16|lo16])
+ * of s_w * w with s_w the power of two that puts max |w| into [2^14, 2^15); scale_out[co] = scale[co] / s_w (scale NULL: 1 / s_w);
+ * *wbound = max_co |scale[co]| * sum_k |w[co][k]|, *sbound = max_co |shift[co]| (shift NULL: 0) -- the terms of ivx_pair_io's bound. */
+int ivx_pair_pack_filters(const float *w, int32_t Cout, int32_t taps, int32_t Cin, const float *scale, const float *shift, void *packed,
+                          float *scale_out, float *wbound, float *sbound);
+/* The head of such a chain.  ivx_nchw_to_nhwc that also accumulates max |in| into amax (the image);  nn.MaxPool2d on an fp32 map
+ * (the stem's output) that writes an IVX_F16_PAIR tensor with the scale of the bound amax_in * wbound + sbound (the stem as a function
+ * of the image: a maximum over a window cannot exceed it), leaves that scale in *out_scale and max |out| in amax_out.  C % 16 == 0. */
+int ivx_nchw_to_nhwc_amax(const float *in, int32_t B, int32_t C, int64_t S, int32_t Cpad, float *out, uint32_t *amax, ivx_stream_t stream);
+int ivx_maxpool2d_fwd_pair(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p, void *out,
+                           const uint32_t *amax_in, float wbound, float sbound, float *out_scale, uint32_t *amax_out, ivx_stream_t stream);
+/* IVX_F16_PAIR [n] (scale *scale_dev or 1) -> fp32 [n] (tests / hosts that want to look at an intermediate tensor) */
+int ivx_f16_pair_merge(const void *in, int64_t n, const float *scale_dev, float *out, ivx_stream_t stream);
 
 /* Validation kernel: same contract, one thread per output element, plain FMA loop. Used by the
  * GPU tests to cross-check the MFMA kernel at full size; never called by the product path.   */
@@ -509,6 +560,11 @@ typedef struct ivx_model_cfg {
   int32_t layout_linear_size;
   int32_t wino_operands;           /* (0.3.1) ivx_conv_desc.wino_operands of the layers that run in the Winograd form: IVX_F32 (0) = fp32 MFMA,
                                       IVX_F16_PAIR = fp16 (hi, lo) operand pairs where the layer allows it (tile 4 / 6, Cin % 32 == 0) */
+  int32_t trunk_operands;          /* (0.4.0) IVX_F32 (0): the 2-D trunk (ResNet-50 + FPN) on fp32 MFMA.  IVX_F16_PAIR: its activations chained as
+                                      fp16 (hi, lo) pair tensors on the 16-bit matrix cores (ivx_conv_fwd_pio: three fp16 MFMA products per
+                                      multiply-add, fp32 accumulate, device-side power-of-two scales, no conversion passes) wherever a tensor's
+                                      consumers are all convolutions with Cin % 32 == 0; the stem, DCNv2 columns, the LayoutHead and what
+                                      leaves the trunk (FPN level 0, C5) stay fp32 */
 } ivx_model_cfg;
 
 int ivx_create(const ivx_model_cfg *cfg, ivx_model **out);

@@ -144,6 +144,135 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const void *in, const void *
   return ivx_conv_fwd_ws(d, in, wgt, scale, shift, res, out, nullptr, 0, stream);
 }
 
+// ---------------------------------------------------------------------------------------------- chained fp16-pair activations
+// (include/imvoxel.h "Chained fp16-pair activations"; csrc/conv_igemm.hip conv_epilogue_wide_pio, csrc/pool_layout.hip).  The CPU
+// restatement decodes the pairs to the fp32 values they stand for, runs the fp32 convolution above and encodes the result with the
+// scale rule of the device (bound of the output from the measured maxima of the operands): the handle's planning of the chain -- which
+// tensors are pairs, which scalar block feeds which layer -- runs unchanged on top.  Values agree with the device to fp32 rounding
+// (the device drops the lo*lo term of every product, 2^-22 of it).
+static uint16_t c_f32_to_f16(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u, ax = x & 0x7fffffffu;
+  if (ax >= 0x7f800000u) return (uint16_t)(sign | (ax > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (ax < 0x38800000u) {
+    float a;
+    memcpy(&a, &ax, 4);
+    return (uint16_t)(sign | (uint32_t)lrintf(a * 16777216.0f));
+  }
+  const uint32_t mant = ax & 0x7fffffu, exp = (ax >> 23) - 127 + 15;
+  uint32_t h = (exp << 10) | (mant >> 13);
+  const uint32_t rem = mant & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+  return (uint16_t)(sign | h);
+}
+static float c_f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+  float f;
+  if (e == 0) {
+    f = (float)m * 5.9604644775390625e-08f;
+    return sign ? -f : f;
+  }
+  const uint32_t x = sign | (e == 31 ? 0x7f800000u | (m << 13) : ((e - 15 + 127) << 23) | (m << 13));
+  memcpy(&f, &x, 4);
+  return f;
+}
+static float c_pow2_scale(float amax) {          // ivx_pow2_scale of csrc/ivx_common.h
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+  int e;
+  (void)frexpf(amax, &e);
+  int k = 15 - e;
+  k = k < -120 ? -120 : (k > 120 ? 120 : k);
+  return ldexpf(1.0f, k);
+}
+static float c_amax_read(const uint32_t *slots) {
+  float a = 0.f;
+  for (int i = 0; i < IVX_AMAX_SLOTS; ++i) { float v; memcpy(&v, slots + i, 4); a = v > a ? v : a; }
+  return a;
+}
+static void c_amax_commit(uint32_t *slots, float m) {
+  float cur;
+  memcpy(&cur, slots, 4);
+  if (m > cur) memcpy(slots, &m, 4);
+}
+// pair tensor [rows, 2C] halves -> fp32 [rows, C] of (hi + lo) * inv
+static void c_pair_decode(const uint16_t *p, int64_t rows, int C, float inv, float *out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < rows; ++r)
+    for (int n = 0; n < C; ++n) {
+      const uint16_t *g = p + r * 2 * C + (n >> 4) * 32 + (n & 15);
+      out[r * C + n] = (c_f16_to_f32(g[0]) + c_f16_to_f32(g[16])) * inv;
+    }
+}
+static void c_pair_encode(const float *x, int64_t rows, int C, float s, uint16_t *p) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < rows; ++r)
+    for (int n = 0; n < C; ++n) {
+      const float y = x[r * C + n] * s;
+      const uint16_t h = c_f32_to_f16(y);
+      uint16_t *g = p + r * 2 * C + (n >> 4) * 32 + (n & 15);
+      g[0] = h;
+      g[16] = c_f32_to_f16(y - c_f16_to_f32(h));
+    }
+}
+
+extern "C" int64_t ivx_conv_pio_workspace_bytes(const ivx_conv_desc *d, const ivx_pair_io *io) { return d && io ? 0 : -1; }
+
+extern "C" int ivx_conv_fwd_pio(const ivx_conv_desc *d, const ivx_pair_io *io, const void *in_, const void *wgt_, const float *scale, const float *shift,
+                                const void *res_, void *out_, void *, int64_t, ivx_stream_t stream) {
+  C_REQUIRE(d && io && in_ && wgt_ && out_, "ivx_conv_fwd_pio: null argument");
+  C_REQUIRE(d->in_dtype == IVX_F16_PAIR && d->out_mode == 0 && d->Cout % 4 == 0 && d->Cin % 32 == 0 && d->wgt_layout == 1 &&
+                (d->out_dtype == IVX_F32 || d->out_dtype == IVX_F16_PAIR),
+            "ivx_conv_fwd_pio (CPU restatement): IVX_F16_PAIR input, chunk-major pair filters, out_mode 0, Cout %% 4 == 0");
+  const bool out_pair = d->out_dtype == IVX_F16_PAIR, res_pair = d->res_mode && io->res_dtype == IVX_F16_PAIR;
+  C_REQUIRE(!out_pair || (d->Cout % 16 == 0 && io->out_scale && io->amax_in && (d->res_mode == 0 || io->amax_res)),
+            "ivx_conv_fwd_pio: a pair output needs Cout %% 16 == 0, out_scale, amax_in (and amax_res with a residual)");
+  C_REQUIRE(!res_pair || (d->Cout % 16 == 0 && io->res_scale), "ivx_conv_fwd_pio: a pair residual needs Cout %% 16 == 0 and res_scale");
+  int32_t Do, Ho, Wo;
+  if (ivx_conv_out_dims(d, &Do, &Ho, &Wo) != IVX_OK) return IVX_ERR_INVALID_ARG;
+  const int64_t rows_in = (int64_t)d->B * d->D * d->H * d->W, M = (int64_t)d->B * Do * Ho * Wo;
+  const int ntap = d->KD * d->KH * d->KW;
+  std::vector<float> x((size_t)rows_in * d->Cin), w((size_t)d->Cout * ntap * d->Cin), r, o;
+  c_pair_decode((const uint16_t *)in_, rows_in, d->Cin, io->in_scale ? 1.0f / *io->in_scale : 1.0f, x.data());
+  // pair filters [Cout][Cin/32][taps][hi16 lo16 hi16 lo16] -> fp32 chunk-major [Cout][Cin/32][taps][32] of s_w * w (scale[] carries 1 / s_w)
+  c_pair_decode((const uint16_t *)wgt_, (int64_t)d->Cout * (d->Cin / 32) * ntap, 32, 1.0f, w.data());
+  ivx_conv_desc f = *d;
+  f.in_dtype = IVX_F32; f.out_dtype = IVX_F32; f.res_scale = 1.0f;
+  const float *resf = (const float *)res_;
+  if (res_pair) {
+    const int64_t rrows = d->res_mode == 2 ? (int64_t)d->B * d->res_h * d->res_w : M;
+    r.resize((size_t)rrows * d->Cout);
+    c_pair_decode((const uint16_t *)res_, rrows, d->Cout, 1.0f / *io->res_scale, r.data());
+    resf = r.data();
+  }
+  float *outf = (float *)out_;
+  if (out_pair) { o.resize((size_t)M * d->Cout); outf = o.data(); }
+  int rc = ivx_conv_fwd_ws(&f, x.data(), w.data(), scale, shift, resf, outf, nullptr, 0, stream);
+  if (rc != IVX_OK) return rc;
+  float omax = 0.f;
+  for (int64_t i = 0; i < M * d->Cout; ++i) omax = fabsf(outf[i]) > omax ? fabsf(outf[i]) : omax;
+  if (io->amax_out) c_amax_commit(io->amax_out, omax);
+  if (out_pair) {
+    const float a = c_amax_read(io->amax_in), rr = (d->res_mode && io->amax_res) ? c_amax_read(io->amax_res) : 0.f;
+    const float post = d->post_scale == 0.f ? 1.0f : d->post_scale;
+    const float s = c_pow2_scale((a * io->wbound + io->sbound + rr) * fabsf(post) * 1.001f);
+    *io->out_scale = s;
+    c_pair_encode(outf, M, d->Cout, s, (uint16_t *)out_);
+  }
+  return IVX_OK;
+}
+
+extern "C" int ivx_conv_fwd_pio_naive(const ivx_conv_desc *d, const ivx_pair_io *io, const void *in, const void *wgt, const float *scale, const float *shift,
+                                      const void *res, void *out, ivx_stream_t stream) {
+  return ivx_conv_fwd_pio(d, io, in, wgt, scale, shift, res, out, nullptr, 0, stream);
+}
+
+extern "C" int ivx_f16_pair_merge(const void *in, int64_t n, const float *scale_dev, float *out, ivx_stream_t) {
+  C_REQUIRE(in && out && n >= 0 && n % 16 == 0, "ivx_f16_pair_merge: null argument or n not a multiple of 16");
+  c_pair_decode((const uint16_t *)in, n / 16, 16, scale_dev ? 1.0f / *scale_dev : 1.0f, out);
+  return IVX_OK;
+}
+
 // The minimal-filtering form is a device-side optimisation: the CPU restatement reports "not supported" and the handle
 // (csrc/model.cpp plan_conv) falls back to the direct convolution, as it does for any layer the Winograd entry points refuse.
 extern "C" int ivx_conv_winograd_supported(const ivx_conv_desc *, int32_t) { return 0; }
@@ -190,6 +319,33 @@ extern "C" int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t 
           }
           out[(((size_t)b * Ho + oh) * Wo + ow) * C + c] = m;
         }
+  return IVX_OK;
+}
+
+extern "C" int ivx_maxpool2d_fwd_pair(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p, void *out,
+                                      const uint32_t *amax_in, float wbound, float sbound, float *out_scale, uint32_t *amax_out, ivx_stream_t st) {
+  C_REQUIRE(in && out && amax_in && out_scale && C % 16 == 0, "ivx_maxpool2d_fwd_pair: bad argument");
+  const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  std::vector<float> o((size_t)B * Ho * Wo * C);
+  int rc = ivx_maxpool2d_fwd(in, B, H, W, C, k, s, p, o.data(), st);
+  if (rc != IVX_OK) return rc;
+  const float sc = c_pow2_scale((c_amax_read(amax_in) * wbound + sbound) * 1.001f);
+  *out_scale = sc;
+  float omax = 0.f;
+  for (float v : o) omax = fabsf(v) > omax ? fabsf(v) : omax;
+  if (amax_out) c_amax_commit(amax_out, omax);
+  c_pair_encode(o.data(), (int64_t)B * Ho * Wo, C, sc, (uint16_t *)out);
+  return IVX_OK;
+}
+
+extern "C" int ivx_nchw_to_nhwc(const float *in, int32_t B, int32_t C, int64_t S, int32_t Cpad, float *out, ivx_stream_t);
+extern "C" int ivx_nchw_to_nhwc_amax(const float *in, int32_t B, int32_t C, int64_t S, int32_t Cpad, float *out, uint32_t *amax, ivx_stream_t st) {
+  C_REQUIRE(amax, "ivx_nchw_to_nhwc_amax: null amax");
+  int rc = ivx_nchw_to_nhwc(in, B, C, S, Cpad, out, st);
+  if (rc != IVX_OK) return rc;
+  float m = 0.f;
+  for (int64_t i = 0; i < (int64_t)B * C * S; ++i) m = fabsf(in[i]) > m ? fabsf(in[i]) : m;
+  c_amax_commit(amax, m);
   return IVX_OK;
 }
 

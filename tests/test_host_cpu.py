@@ -1255,6 +1255,26 @@ def test_cpu_abi_dcn_trunk_and_layout_head_in_the_handle():
         cm.close()
     (b1, s1, l1), = dets
     print('layout head: angles', ang[0], 'detections', len(s1), 'plain model with those extrinsics', len(s2))
+    # In the default operand mode of the trunk (chained fp16-pair activations) the two handles do not run the same kernels: with a
+    # LayoutHead C5 is pooled, so it stays an fp32 tensor and its FPN lateral runs on fp32 MFMA; without the head C5 is a pair tensor.
+    # Same detections up to the 22-bit operand rounding; bit-identical with fp32 MFMA in the trunk (checked below).
+    assert len(s1) == len(s2) >= 3 and np.array_equal(l1, l2) and np.allclose(s1, s2, rtol=1e-4, atol=1e-6)
+    assert bool((np.abs(b1 - b2) <= 2e-3 * np.abs(b2) + 2e-4 * np.abs(b2).max(axis=0, keepdims=True)).all())      # (random weights: box sizes up to 1e14)
+    from imvoxelnet_amd.conv import FusedConv
+    old_mode, FusedConv.trunk_operands = FusedConv.trunk_operands, 0
+    try:
+        cm = host.CpuModel(total)
+        try:
+            (b1, s1, l1), = cm.detect(img, [meta])[0]
+        finally:
+            cm.close()
+        cm = host.CpuModel(plain)
+        try:
+            (b2, s2, l2), = cm.detect(img, [meta2])
+        finally:
+            cm.close()
+    finally:
+        FusedConv.trunk_operands = old_mode
     assert len(s1) == len(s2) >= 3 and np.array_equal(b1, b2) and np.array_equal(s1, s2) and np.array_equal(l1, l2)
     # and ivx_layout_extrinsics against the reference's get_extrinsics (torch ops): equal to an ulp of the trigonometric values
     e_lib, e_ref = layout_extrinsics(torch.from_numpy(ang[0])), ia.get_extrinsics(torch.from_numpy(ang[0]))
