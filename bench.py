@@ -613,14 +613,18 @@ def main():
                 traffic = None
             break
 
-    peak2d = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    trunk_pair = FusedConv.trunk_operands == 4 and not bf16
+    peak2d = PEAK_BF16_MFMA_TFLOPS if (bf16 or trunk_pair) else PEAK_F32_MFMA_TFLOPS
     if rank == 0:
         total_images = B * world * args.steps
         rec = {
             'metric': 'images/sec/node (KITTI 3x384x1280, 216x248x12 vox)',
             'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (f16-pair MFMA operands in the Winograd domain)' if pair else args.storage, 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': ('f32 (fp16 (hi, lo) pair MFMA operands: %s)' % ' and '.join(
+                (['the Winograd-domain neck GEMMs'] if pair else []) + (['the chained 2-D trunk'] if (FusedConv.trunk_operands == 4 and not bf16) else [])))
+            if (pair or (FusedConv.trunk_operands == 4 and not bf16)) else args.storage, 'data': 'synthetic',
             'config': {'workload': 'kitti_mono_1x3x384x1280_vox216x248x12_resnet50_fpn64_kittineck_anchor3dhead',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'hip_graph': bool(args.graph),
                        'api': ('hipGraph replay (%s)' % type(graphed).__name__) if args.graph else ('ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages'),
@@ -628,12 +632,17 @@ def main():
                        'stage_events': ('event-record nodes inside the replayed graph, read for the last timed step' if (native_trace and model._native.graph) else 'HIP event pairs around every launch of every timed step'),
                        'neck_gemm_operands': ('fp16 (hi, lo) pairs of fp32 values: 3 fp16 MFMA products per pair, fp32 accumulate, device-side power-of-two scales '
                                               '(ivx_conv_desc.wino_operands = IVX_F16_PAIR)') if pair else ('bf16' if bf16 else 'fp32 MFMA'),
+                       'trunk_operands': ('fp16 (hi, lo) pair ACTIVATIONS chained between the layers (ivx_conv_fwd_pio: device-side power-of-two scales '
+                                          'from a bound of each output, three fp16 MFMA products per multiply-add, no conversion passes; '
+                                          'ivx_model_cfg.trunk_operands = IVX_F16_PAIR)') if (FusedConv.trunk_operands == 4 and not bf16) else ('bf16' if bf16 else 'fp32 MFMA'),
                        'detections_last_step': n_det(last), 'rccl_ranks': rccl_ranks, 'ms_per_step_by_rank': rank_ms,
                        'collective': 'one all_gather_into_tensor of padded detections per step (RCCL)' if multi else None},
             'measured_ceilings': dict(ceil, note='csrc/ubench.hip at start-up: MFMA issue rate of the conv kernel\'s instruction, HBM copy rate '
                                                  '(read + written bytes) over 2 x 1 GiB') if ceil else None,
             'exact_fp32_mfma': alt,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck, %d launches/step)' % ('__bf16' if bf16 else ('fp16 pair operands' if pair else 'float'), n_launch),
+            'roofline': {'bound': 'mfma', 'kernel': ('conv_wino_halo_kernel<fp16 pair operands> (the 8 Winograd-domain GEMMs of the stride-1 / z-stride-2 neck layers) + '
+                                                    'conv_igemm_v4_kernel<fp16 pair operands> (the last, pad-0 layer): %d launches/step' % n_launch) if pair else
+                                                   'conv_igemm_v4_kernel<%s> (3-D neck, %d launches/step)' % ('__bf16' if bf16 else 'float', n_launch),
                          'flops_counted': ('every fp16 MFMA product issued: 3 per fp32-equivalent multiply-add (hi*hi + hi*lo + lo*hi), priced against the dense '
                                            '16-bit MFMA peak') if pair else 'one MFMA multiply-add per algorithmic multiply-add',
                          'fp32_equivalent_tflops': round(achieved / 3, 2) if pair else None,
@@ -668,8 +677,11 @@ def main():
                                       '%d launches/step, event-bracketed incl. their transform / split-K passes' % (len(t2d) // nst)),
                                   'achieved': round(t2d_flops / (t2d_ms * 1e-3) / 1e12, 2) if t2d_ms > 0 else None, 'peak': peak2d, 'unit': 'TFLOP/s',
                                   'frac': round(t2d_flops / (t2d_ms * 1e-3) / 1e12 / peak2d, 4) if t2d_ms > 0 else None,
-                                  'flops_counted': 'matrix-core products of the executed form: one per multiply-add on the fp32 MFMA layers, three on the 2-D 3x3 layers that run '
-                                                   'as Winograd on fp16-pair operands (priced against the fp32 MFMA peak all the same: a mixed span)',
+                                  'flops_counted': ('every fp16 MFMA product issued by the chained pair form: 3 per fp32 multiply-add (the stem alone runs on fp32 MFMA), '
+                                                    'priced against the dense 16-bit MFMA peak; these layers are bound by HBM / launch latency, not by the matrix pipe') if trunk_pair else
+                                                   ('matrix-core products of the executed form: one per multiply-add on the fp32 MFMA layers, three on the 2-D 3x3 layers that run '
+                                                    'as Winograd on fp16-pair operands (priced against the fp32 MFMA peak all the same: a mixed span)'),
+                                  'fp32_equivalent_tflops': round(t2d_flops / 3 / (t2d_ms * 1e-3) / 1e12, 2) if (trunk_pair and t2d_ms > 0) else None,
                                   'ms_per_step': round(t2d_ms, 3), 'executed_gflop_per_step': round(t2d_flops / 1e9, 1)},
         }
         if untraced:

@@ -20,6 +20,7 @@
 //
 // Reference call sites replaced: see include/imvoxel.h (ivx_conv_fwd).
 #include "ivx_common.h"
+#include <stdlib.h>
 
 // This file is compiled six times (imvoxelnet_amd/_build.py), each translation unit instantiating one family of the LDS-DMA kernel, so that
 // the families build in parallel:  IVX_CONV_TU 0 = the host side, the generic / naive / reduce kernels;  1 = fp32;  2 = bf16 and e4m3;
@@ -292,10 +293,49 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams &p, f32x16 (
 // residual is fp32 or an fp16 (hi, lo) pair tensor with its own scale, the output is fp32 or a pair tensor written with the scale of
 // conv_pair_io -- a lane's 4 channels are 8 bytes of hi halves and, 32 bytes further, 8 bytes of lo halves -- and the maximum of the
 // stored values (true values, before the output scale) goes to the amax slots for the next layer's bound.
+// epilogue of 4 consecutive channels nb .. nb + 3 of output row m (pair IO): v = the accumulators; returns max |stored value|
+__device__ __forceinline__ float conv_pio_finish4(const ConvParams &p, const PairIO io, f32x4 v, const int m, const int nb, const f32x4 sc, const f32x4 sf) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  v = v * sc + sf;
+  f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+  if (p.res_mode) {
+    if (p.res_pair) {
+      const size_t row = p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, 1) : (size_t)m;
+      const _Float16 *rp = reinterpret_cast<const _Float16 *>(p.res) + pair_off(row, nb, p.Cout);
+      const f16x4 rh = *reinterpret_cast<const f16x4 *>(rp), rl = *reinterpret_cast<const f16x4 *>(rp + 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rr[e] = ((float)rh[e] + (float)rl[e]) * io.inv_res;
+    } else {
+      rr = *reinterpret_cast<const f32x4 *>(p.res + (p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) : (size_t)m * p.Cout) + nb);
+    }
+  }
+  if (p.res_mode && !p.res_after_act) v += rr;
+  if (p.relu) {
+    v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+    v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+  }
+  if (p.res_mode && p.res_after_act) v += rr;
+  v *= p.post_scale;
+  if (p.out_pair) {
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float y = v[e] * io.s_out;
+      h[e] = (_Float16)y;
+      l[e] = (_Float16)(y - (float)h[e]);
+    }
+    _Float16 *op = reinterpret_cast<_Float16 *>(p.out) + pair_off((size_t)m, nb, p.Cout);
+    *reinterpret_cast<f16x4 *>(op) = h;
+    *reinterpret_cast<f16x4 *>(op + 16) = l;
+  } else {
+    *reinterpret_cast<f32x4 *>(p.out + (size_t)m * p.Cout + nb) = v;
+  }
+  return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_wide_pio(const ConvParams &p, const PairIO io, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
                                                        int lane, float *stage, int salt) {
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   const int col_l = lane & 31, hh = lane >> 5;
   const int rrow = lane >> 3, c4 = (lane & 7) * 4;
   float omax = 0.f;
@@ -314,45 +354,9 @@ __device__ __forceinline__ void conv_epilogue_wide_pio(const ConvParams &p, cons
       const int mb = m0 + (wr * TM + i) * 32 + rrow;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        f32x4 v = *reinterpret_cast<const f32x4 *>(stage + (rrow + 8 * q) * 32 + c4);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + (rrow + 8 * q) * 32 + c4);
         const int m = mb + 8 * q;
-        if (m < p.M && nok) {
-          v = v * sc + sf;
-          f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-          if (p.res_mode) {
-            if (p.res_pair) {
-              const size_t row = p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, 1) : (size_t)m;
-              const _Float16 *rp = reinterpret_cast<const _Float16 *>(p.res) + pair_off(row, nb, p.Cout);
-              const f16x4 rh = *reinterpret_cast<const f16x4 *>(rp), rl = *reinterpret_cast<const f16x4 *>(rp + 16);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) rr[e] = ((float)rh[e] + (float)rl[e]) * io.inv_res;
-            } else {
-              rr = *reinterpret_cast<const f32x4 *>(p.res + (p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) : (size_t)m * p.Cout) + nb);
-            }
-          }
-          if (p.res_mode && !p.res_after_act) v += rr;
-          if (p.relu) {
-            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
-            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
-          }
-          if (p.res_mode && p.res_after_act) v += rr;
-          v *= p.post_scale;
-          omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-          if (p.out_pair) {
-            f16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float y = v[e] * io.s_out;
-              h[e] = (_Float16)y;
-              l[e] = (_Float16)(y - (float)h[e]);
-            }
-            _Float16 *op = reinterpret_cast<_Float16 *>(p.out) + pair_off((size_t)m, nb, p.Cout);
-            *reinterpret_cast<f16x4 *>(op) = h;
-            *reinterpret_cast<f16x4 *>(op + 16) = l;
-          } else {
-            *reinterpret_cast<f32x4 *>(p.out + (size_t)m * p.Cout + nb) = v;
-          }
-        }
+        if (m < p.M && nok) omax = fmaxf(omax, conv_pio_finish4(p, io, v, m, nb, sc, sf));
       }
     }
   }
@@ -1088,6 +1092,31 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   if (p.pio && p.amax_out) ivx_amax_commit(p.amax_out, omax, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
 }
 
+// The same reduction for pair IO (the chained fp16-pair trunk), four channels per thread: 16-byte partial loads, the epilogue of
+// conv_pio_finish4 (8-byte hi / lo stores).  32-bit indexing: split K is only planned for small outputs (the launcher checks).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_pio_kernel(const ConvParams p) {
+  const PairIO io = conv_pair_io(p);
+  if (p.out_scale_p && blockIdx.x == 0 && threadIdx.x == 0) *p.out_scale_p = io.s_out;
+  const unsigned C4 = (unsigned)p.Cout >> 2, rows = 8u * (unsigned)p.q_count * (unsigned)p.bm, total4 = rows * C4;
+  const size_t total = (size_t)rows * p.Cout;
+  float omax = 0.f;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+    const unsigned cr = i / C4, nb = (i - cr * C4) * 4;
+    const unsigned ctile = cr / (unsigned)p.bm, rit = cr - ctile * (unsigned)p.bm;
+    const unsigned xcd = ctile / (unsigned)p.q_count, lt = ctile - xcd * (unsigned)p.q_count;
+    const long long m = (long long)(xcd * p.q_total + p.q_begin + lt) * p.bm + rit;
+    if (m >= p.M) continue;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.ksplit; ++z) acc += *reinterpret_cast<const f32x4 *>(p.partial + (size_t)z * total + (size_t)cr * p.Cout + nb);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + nb);
+    if (p.shift) sf = *reinterpret_cast<const f32x4 *>(p.shift + nb);
+    sc *= io.inv_in;
+    omax = fmaxf(omax, conv_pio_finish4(p, io, acc, (int)m, (int)nb, sc, sf));
+  }
+  if (p.amax_out) ivx_amax_commit(p.amax_out, omax, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+}
+
 // Validation kernel: one thread per output element, sequential fmaf over (kd,kh,kw,ci).
 __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p) {
   const size_t total = (size_t)p.M * p.Cout;
@@ -1454,6 +1483,19 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     else if (pl.cfg == 71) pl.cfg = 74;
     else if (pl.cfg == 72) pl.cfg = 73;
   }
+  static const int pio_rule = getenv("IVX_PIO_RULE") ? atoi(getenv("IVX_PIO_RULE")) : 1;        // A/B knobs of the round-4 measurements
+  static const int pio_splitk = getenv("IVX_PIO_SPLITK") ? atoi(getenv("IVX_PIO_SPLITK")) : 1;
+  if (p.in_pair == 2 && p.pio && g_tile_override == 0 && dma_ok && pio_rule) {
+    // Chained fp16-pair activations (the 2-D trunk): interleaved A/B of every pair tile on the trunk's layer shapes at KITTI batch 4 and at
+    // 50 views (tools/pio_ab.py, profiles/r04_pio_ab_*.md).  128 x 128 with 64-byte LDS rows at four per CU (74) is the best or within
+    // 5-10 % of it wherever it fills the chip, also for Cout = 64 at KITTI size (half of its B tile is zero fill, and it still beats
+    // 128 x 64 / 256 x 64: 43 vs 50 / 47 us); the 50-view maps of 64 output channels take 256 x 64 (76); layers with few tiles take
+    // 64 x 64 with 128-byte rows (66: 63 vs 90 us on 256 -> 256 3x3 at 24 x 80 x 4, 49 vs 58 on 1024 -> 256) + split K.
+    const long long t128 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    if (p.Cout <= 64) pl.cfg = p.M >= 400000 ? 76 : (p.M >= 60000 ? 74 : 66);
+    else pl.cfg = t128 >= 200 ? 74 : 66;
+    small = pl.cfg == 66 && pio_splitk;
+  }
   TileInfo t;
   if (!tile_info(pl.cfg, &t) || !dma_ok) return pl;
   const long long Mt = (p.M + t.bm - 1) / t.bm, Nt = (p.Cout + t.bn - 1) / t.bn;
@@ -1464,7 +1506,14 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
   if (small) {
     const long long tiles = Mt * Nt;
     const long long slots = 256LL * t.wg_per_cu;           // resident workgroups on the chip
-    if (2 * tiles <= slots && S >= 16) {                    // under half a round: split K until the slots are filled once
+    static const long long pio_split_tiles = getenv("IVX_PIO_SPLIT_TILES") ? atoll(getenv("IVX_PIO_SPLIT_TILES")) : 320;
+    // Pair IO: at 16-bit MFMA rates a tile is short and a split costs a second launch plus the partial sums' round trip, so it pays only
+    // below about one tile per CU, and for the mid-sized layers only when the K loop is long.  Measured through bench.py's trunk span
+    // (profiles/r04_pio_split_rule.md): KITTI 4.24 ms with the fp32 rule (2 * tiles <= slots), 4.01 without any split, 3.88 with
+    // tiles <= 320; single-view SUN RGB-D 2.42 without, 2.06 with tiles <= 320, 1.86 with tiles <= 100 (its 150 / 160-tile layers have
+    // K loops of 16 .. 36 slabs and lose from the split; KITTI's 240-tile layers have 64 .. 144 and gain).
+    const bool pio_split = tiles <= pio_split_tiles && (tiles <= 100 || S >= 48);
+    if ((p.pio ? pio_split : 2 * tiles <= slots) && S >= 16) {     // under half a round: split K until the slots are filled once
       long long ks = (slots + tiles - 1) / tiles;
       if (ks > S / 8) ks = S / 8;
       if (ks > 32) ks = 32;
@@ -1842,6 +1891,12 @@ static int launch_one(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
 
 static void launch_reduce(const ConvParams &p, hipStream_t st) {
   const size_t total = (size_t)8 * p.q_count * p.bm * p.Cout;
+  if (p.pio && (p.Cout & 3) == 0 && total < (1ull << 31)) {
+    size_t b4 = (total / 4 + 255) / 256;
+    if (b4 > 4096) b4 = 4096;
+    hipLaunchKernelGGL(conv_splitk_reduce_pio_kernel, dim3((unsigned)b4), dim3(256), 0, st, p);
+    return;
+  }
   size_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);

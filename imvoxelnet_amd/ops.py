@@ -381,6 +381,23 @@ class PairTensor:
         return float(self.slots[AMAX_SLOTS:AMAX_SLOTS + 1].view(torch.float32)[0])
 
 
+def pair_from_float(x):
+    """fp32 device tensor [.., C] (C % 16 == 0) -> PairTensor, scaled by its exact maximum (one pass over the tensor + a host sync:
+    for tools and tests; inside the model the producing kernels write pairs)."""
+    import math
+    _chk(x, 'x')
+    amax = float(x.abs().max())
+    s = 1.0
+    if 0.0 < amax < 3e38:
+        s = 2.0 ** (15 - math.frexp(amax)[1])
+    data = torch.empty(tuple(x.shape[:-1]) + (2 * x.shape[-1],), device=x.device, dtype=torch.float16)
+    check(_lib.lib().ivx_f16_pair_split(_ptr(x), x.numel(), C.c_float(s), _ptr(data), _stream()), 'ivx_f16_pair_split')
+    slots = new_slots(x.device)
+    slots[:1].view(torch.float32)[0] = amax
+    slots[AMAX_SLOTS:AMAX_SLOTS + 1].view(torch.float32)[0] = s
+    return PairTensor(data, slots)
+
+
 def slots_of(t):
     """The scalar block a tensor of the chain carries (a PairTensor's, or the one attached to an fp32 tensor by its producer), or None."""
     return t.slots if isinstance(t, PairTensor) else getattr(t, 'ivx_slots', None)

@@ -16,7 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('dir')
     ap.add_argument('--min-ms', type=float, default=0.0)
-    ap.add_argument('--match', default='conv_igemm')
+    ap.add_argument('--match', default='conv_igemm,conv_wino_halo', help='comma-separated substrings of the kernel names to keep')
     ap.add_argument('--json', default=None)
     a = ap.parse_args()
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -33,7 +33,7 @@ def main():
             d[r['Dispatch_Id']] = ((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6, r['Kernel_Name'])
         for r in csv.DictReader(open(cc[0])):
             ms, name = d.get(r['Dispatch_Id'], (0.0, r['Kernel_Name']))
-            if a.match not in name or ms < a.min_ms:
+            if not any(mm in name for mm in a.match.split(',')) or ms < a.min_ms:
                 continue
             key = name.replace('(anonymous namespace)::', '').split('(')[0][:80]
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))

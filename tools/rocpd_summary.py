@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 (ROCm 7.2 rocpd sqlite) kernel trace: per-kernel calls / total / avg / min / max, and
-per-(kernel, grid) rows for the conv kernel.  Usage: rocpd_summary.py results.db [steps] [> profiles/xxx.md]
+per-(kernel, grid) rows for the conv kernels.  Usage: rocpd_summary.py results.db [steps] [> profiles/xxx.md]
 With `steps` (timed + warm-up steps of the profiled bench.py run) it also prints the per-step total of the conv launches
-of the 3-D neck (every conv launch >= 0.3 ms plus the K-split tail launches and reductions), the number bench.py's
-event-bracketed `neck_ms_per_step` must agree with."""
+of the 3-D neck -- every launch >= 0.3 ms of the two kernels that run the Winograd-domain GEMMs, `conv_wino_halo_kernel` (the
+stride-1 / z-stride-2 layers on fp16 pairs) and `conv_igemm_v4_kernel` (the last layer, and every layer with fp32 operands) --
+plus the transforms: the numbers bench.py's event-bracketed `roofline.mfma_launch_ms_per_step` / `neck_ms_per_step` must agree with."""
 import sqlite3
 import sys
 
@@ -29,30 +30,33 @@ def main(path, steps=0):
         print('\n## conv kernel by launch shape\n')
         print('| kernel | grid | calls | avg us |')
         print('|---|---|---|---|')
-        for r in c.execute(f"select {sel}, count(*), avg(end-start) from kernels where {name} like '%conv_igemm%' group by {sel} order by avg(end-start) desc"):
+        for r in c.execute(f"select {sel}, count(*), avg(end-start) from kernels where ({name} like '%conv_igemm%' or {name} like '%conv_wino_halo%') group by {sel} order by avg(end-start) desc"):
             print(f'| `{r[0][:60]}` | {r[1:-2]} | {r[-2]} | {r[-1] / 1e3:.1f} |')
 
 
     if steps:
-        big = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%conv_igemm%' and end-start >= 300000").fetchone()
+        gemm = f"({name} like '%conv_igemm%' or {name} like '%conv_wino_halo%')"
+        big = c.execute(f"select count(*), sum(end-start) from kernels where {gemm} and end-start >= 300000").fetchone()
+        halo = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%conv_wino_halo%'").fetchone()
         gy_ok = gcols and gy and gy in cols
         tail = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%conv_igemm%' and end-start < 300000 and {gy} > 1 and {gx} <= 65536").fetchone() if gy_ok else (0, 0)
         red = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%splitk_reduce%'").fetchone()
         xin = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%wino_input_kernel%' and end-start >= 100000").fetchone()
-        xout = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%wino_output_kernel%' and end-start >= 100000").fetchone()
+        xout = c.execute(f"select count(*), sum(end-start) from kernels where ({name} like '%wino_output_kernel%' or {name} like '%wino_output_buf_kernel%') and end-start >= 100000").fetchone()
         print(f'\n## 3-D neck reconciliation ({steps} steps profiled)\n')
         print('| launches | per step | ms per step | avg ms |')
         print('|---|---|---|---|')
-        print(f'| implicit-GEMM launches >= 0.3 ms (the 9 neck layers: direct conv, or the grouped Winograd-domain GEMM) | {big[0] / steps:.1f} | '
+        print(f'| GEMM launches >= 0.3 ms of conv_wino_halo_kernel + conv_igemm_v4_kernel (the 9 neck layers: grouped Winograd-domain GEMMs, or direct convs) | {big[0] / steps:.1f} | '
               f'{(big[1] or 0) / 1e6 / steps:.3f} | {(big[1] or 0) / 1e6 / max(big[0], 1):.4f} |')
+        print(f'| ... of which conv_wino_halo_kernel (all its launches) | {halo[0] / steps:.1f} | {(halo[1] or 0) / 1e6 / steps:.3f} | {(halo[1] or 0) / 1e6 / max(halo[0], 1):.4f} |')
         print(f'| wino_input_kernel launches >= 0.1 ms | {xin[0] / steps:.1f} | {(xin[1] or 0) / 1e6 / steps:.3f} | {(xin[1] or 0) / 1e6 / max(xin[0], 1):.4f} |')
-        print(f'| wino_output_kernel launches >= 0.1 ms | {xout[0] / steps:.1f} | {(xout[1] or 0) / 1e6 / steps:.3f} | {(xout[1] or 0) / 1e6 / max(xout[0], 1):.4f} |')
+        print(f'| wino_output_kernel / wino_output_buf_kernel launches >= 0.1 ms | {xout[0] / steps:.1f} | {(xout[1] or 0) / 1e6 / steps:.3f} | {(xout[1] or 0) / 1e6 / max(xout[0], 1):.4f} |')
         print(f'| K-split launches (small 2-D layers) | {tail[0] / steps:.1f} | {(tail[1] or 0) / 1e6 / steps:.3f} | |')
         print(f'| split-K reductions | {red[0] / steps:.1f} | {(red[1] or 0) / 1e6 / steps:.3f} | |')
         tot_n = ((big[1] or 0) + (xin[1] or 0) + (xout[1] or 0)) / 1e6 / steps
         print(f'\nneck kernel time per step ~ {tot_n:.2f} ms = GEMM launches + transforms; bench.py brackets the same launches with HIP events: '
-              '`roofline.avg_launch_ms` x `launches_per_step` is the first row (its avg ms column is `roofline.avg_launch_ms`), '
-              '`roofline_winograd_transforms.ms_per_step` the sum of rows two and three, `roofline.neck_ms_per_step` the total.')
+              '`roofline.mfma_launch_ms_per_step` is the first row (`roofline.avg_launch_ms` its avg ms column, `roofline.launches_per_step` its count), '
+              '`roofline_winograd_transforms.ms_per_step` the sum of the transform rows, `roofline.neck_ms_per_step` the total.')
 
 
 if __name__ == '__main__':
