@@ -18,9 +18,6 @@ import argparse
 import json
 import os
 
-# hipGraph replays of this path need the runtime's graph packet capture OFF on ROCm 7.2 (imvoxelnet_amd/__init__.py); the runtime reads the
-# variable when it initialises, which in this script happens (torch.cuda.set_device) before the package is imported: set it first
-os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 import sys
 import time
 
@@ -330,10 +327,6 @@ def main():
     ap.add_argument('--fp8-stages', type=int, default=None, help='--trunk-fp8: how many leading ResNet stages store e4m3 (default: all four)')
     ap.add_argument('--fp8-residual', default='bf16', choices=['bf16', 'fp8'], help="--trunk-fp8: 'bf16' (default) keeps the residual stream in bf16 and stores the bottleneck interiors as e4m3; 'fp8' stores every trunk activation as e4m3 (bandwidth stress mode, ~10 %% feature noise)")
     ap.add_argument('--trunk-fp8', action='store_true', help='with --storage bf16 and an indoor --config: e4m3 storage of the 2-D trunk (calibrated on the bench batch)')
-    ap.add_argument('--graph', action='store_true',
-                    help='replay the device side of the step as one captured hipGraph (kitti config); the roofline entry is then '
-                         'taken from the eager warm-up steps, which run the same kernels with HIP events around the neck')
-    ap.add_argument('--graph-backend', default=None, choices=['native', 'torch'], help="--graph: 'native' (default) = hipGraph replay inside the native handle; 'torch' = torch.cuda.CUDAGraph of the layer-by-layer composition (A/B; fragile against later device allocations)")
     ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
                     help='f32 (default) = the reference precision and the headline metric; bf16 = optional reduced-precision '
                          'storage mode (kitti only), reported with dtype "bf16" and priced against the bf16 MFMA peak')
@@ -434,8 +427,6 @@ def main():
     traces = [[] for _ in range(nsteps)]      # per step: the conv stage launches (FusedConv.trace)
     lifts = [[] for _ in range(nsteps)]       # per step: the unprojection launch (ops.stage_trace)
 
-    if args.graph:
-        args.api = 'composed'      # the graph replays the layer-by-layer launches; its eager warm-up steps carry the stage events
     native_trace = False
     if args.api == 'simple_test':
         native_trace = model._native is not None and os.environ.get('IVX_BENCH_TRACE', '1') != '0'   # stage events are recorded inside the native handle
@@ -472,21 +463,6 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if args.graph:
-        if args.warmup < 1:
-            raise SystemExit('--graph needs at least one eager warm-up step (the roofline entry is measured there)')
-        graphed = model.capture_graph(img, metas, backend=args.graph_backend)
-
-        def step(i):   # noqa: F811  -- same work, one graph launch
-            boxes, scores, labels, count = graphed.replay_device(img, metas)
-            if multi:
-                boxes, scores, labels, count = ivx_dist.all_gather_detections(boxes, scores, labels, count)
-            return ivx_dist.pack_detections(boxes, scores, labels, count).cpu()
-
-        def n_det(out):   # noqa: F811
-            return int(out[:, -1].sum().item())
-        step(0)
-        torch.cuda.synchronize()
     if native_trace:
         model._native.trace(0)
         model._native.trace(1)             # drop the warm-up records; the event pool they created is kept
@@ -517,7 +493,7 @@ def main():
 
     # the same steps with fp32 MFMA in the transformed domain (exact fp32 products): a second native handle, timed after the region above
     alt = None
-    if pair and args.api == 'simple_test' and model._native is not None and not multi and not args.graph and os.environ.get('IVX_BENCH_ALT', '1') != '0':
+    if pair and args.api == 'simple_test' and model._native is not None and not multi and os.environ.get('IVX_BENCH_ALT', '1') != '0':
         from imvoxelnet_amd import engine
         recs_keep = model._native.trace_records() if native_trace else None
         trunk_keep = FusedConv.trunk_operands
@@ -543,10 +519,7 @@ def main():
                'note': 'bench.py --wino-operands f32 --trunk-operands f32: fp32 MFMA everywhere (exact fp32 products; the round-2 arithmetic), same weights and images',
                'detections_last_step': n_det(out_alt), 'same_detections_as_default': all(same)}
 
-    ev_ids = range(args.warmup) if args.graph else range(args.warmup, args.warmup + args.steps)
-    if args.graph and args.warmup > 1:
-        ev_ids = range(1, args.warmup)       # skip the very first (cold) step
-    ev_ids = list(ev_ids)
+    ev_ids = list(range(args.warmup, args.warmup + args.steps))
     # The nine conv layers of KittiImVoxelNeck run in the F(6x6,3x3) minimal-filtering form (csrc/winograd.hip): input
     # transform -> ONE grouped launch of the implicit-GEMM kernel -> output transform.  The roofline entry is the implicit-GEMM kernel over its launches on the 3-D neck with the
     # FLOPs the kernel EXECUTES (64/324 of the direct count for an F(6x6,3x3) layer) over the event-bracketed duration of
@@ -558,9 +531,7 @@ def main():
     per_step = []
     if native_trace:
         recs = recs_keep if alt is not None else model._native.trace_records()
-        # graph replay (default): the stage events are nodes of the captured graph, re-recorded by every timed step; what is
-        # read back after the timed region are the event pairs of its LAST step.  Eager handle: one record list per step.
-        n_traced = 1 if model._native.graph else args.steps
+        n_traced = args.steps              # one record list per step
         n_per = len(recs) // n_traced
         for k in range(n_traced):
             per_step.append([(KIND[r['stage']], r['ms'], r['start_ms'], r['flops'], r['bytes'], r['is3d']) for r in recs[k * n_per:(k + 1) * n_per]])
@@ -626,10 +597,10 @@ def main():
                 (['the Winograd-domain neck GEMMs'] if pair else []) + (['the chained 2-D trunk'] if (FusedConv.trunk_operands == 4 and not bf16) else [])))
             if (pair or (FusedConv.trunk_operands == 4 and not bf16)) else args.storage, 'data': 'synthetic',
             'config': {'workload': 'kitti_mono_1x3x384x1280_vox216x248x12_resnet50_fpn64_kittineck_anchor3dhead',
-                       'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'hip_graph': bool(args.graph),
-                       'api': ('hipGraph replay (%s)' % type(graphed).__name__) if args.graph else ('ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages'),
-                       'device_side': ('native model handle (ivx_model_forward%s)' % (', hipGraph replay per shape' if model._native.graph else '')) if model._native is not None and args.api == 'simple_test' else 'layer-by-layer over the op-level C-ABI',
-                       'stage_events': ('event-record nodes inside the replayed graph, read for the last timed step' if (native_trace and model._native.graph) else 'HIP event pairs around every launch of every timed step'),
+                       'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'hip_graph': False,
+                       'api': 'ImVoxelNet.simple_test(img, img_metas)' if args.api == 'simple_test' else 'composed stages',
+                       'device_side': 'native model handle (ivx_model_detect)' if model._native is not None and args.api == 'simple_test' else 'layer-by-layer over the op-level C-ABI',
+                       'stage_events': 'HIP event pairs around every launch of every timed step',
                        'neck_gemm_operands': ('fp16 (hi, lo) pairs of fp32 values: 3 fp16 MFMA products per pair, fp32 accumulate, device-side power-of-two scales '
                                               '(ivx_conv_desc.wino_operands = IVX_F16_PAIR)') if pair else ('bf16' if bf16 else 'fp32 MFMA'),
                        'trunk_operands': ('fp16 (hi, lo) pair ACTIVATIONS chained between the layers (ivx_conv_fwd_pio: device-side power-of-two scales '

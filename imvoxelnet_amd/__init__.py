@@ -4,15 +4,6 @@ Importing the package registers the modules under the reference's registry names
 into mmdet's is an explicit register_into_mmdet() call or IVX_REGISTER_MMDET=1); it does NOT load the
 HIP library (that happens on first use and fails loudly if libimvoxel_hip.so is missing).
 """
-import os as _os
-
-# hipGraph replays of this path come back as garbage on ROCm 7.2 when the runtime pre-builds the dispatch packets of a graph
-# ("graph packet capture"): found by A/B -- with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 the replay is exact (tests/graph_replay_check.py),
-# with the default it returns no detections.  The runtime reads the variable when it initialises, i.e. at the first device call of
-# the process, so it is set here, before anything of this package touches the device; ivx_create refuses use_graph = 1 when it is
-# not in effect (a host that initialised HIP earlier must export it itself).  Eager execution is not affected either way.
-_os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
-
 from .registry import (BACKBONES, NECKS, HEADS, DETECTORS, ANCHOR_GENERATORS, BBOX_CODERS, ConfigDict,  # noqa: F401
                        build_backbone, build_neck, build_head, build_detector)
 from .backbones import ResNet, FPN                                           # noqa: F401

@@ -37,7 +37,7 @@ class ModelCfg(C.Structure):
                 ('n_rotations', C.c_int32), ('anchor_range', C.c_float * 6), ('anchor_sizes', C.c_float * 12),
                 ('anchor_rotations', C.c_float * 4), ('nms_pre', C.c_int32), ('max_num', C.c_int32), ('use_rotate_nms', C.c_int32),
                 ('score_thr', C.c_float), ('nms_thr', C.c_float), ('dir_offset', C.c_float), ('dir_limit_offset', C.c_float),
-                ('winograd', C.c_int32), ('winograd_tile', C.c_int32), ('use_graph', C.c_int32),
+                ('winograd', C.c_int32), ('winograd_tile', C.c_int32),
                 ('fast_n_blocks', C.c_int32 * 3), ('unet_channels', C.c_int32 * 4), ('unet_down_layers', C.c_int32 * 4),
                 ('unet_up_layers', C.c_int32 * 3),
                 ('head_type', C.c_int32), ('head_classes', C.c_int32), ('head_nms_pre', C.c_int32), ('head_use_rotate_nms', C.c_int32),

@@ -188,10 +188,6 @@ struct ivx_model {
   std::map<std::string, std::unique_ptr<Plan>> plans;
   std::vector<void *> owned;           // device allocations (weights, filters, anchors)
   std::vector<float> pack_a, pack_b;   // host staging of ivx_weights_finalize (released there)
-  // hipGraph replay of ivx_model_forward (cfg.use_graph): one captured graph per distinct set of caller buffers
-  struct GraphEntry { std::vector<uintptr_t> key; hipGraphExec_t exec; };
-  std::vector<GraphEntry> graphs;
-  std::vector<std::vector<uintptr_t>> warmed;      // buffer sets that ran eagerly once (anchors uploaded, filters made)
   // optional stage timing (ivx_model_trace): one record per launch group, events recorded on the caller's stream
   bool trace_on = false;
   int trace_level = 2;                 // 2: every launch group; 1: the 3-D neck stages, the unprojection and the tail individually,
@@ -1295,13 +1291,6 @@ extern "C" int ivx_create(const ivx_model_cfg *cfg, ivx_model **out) {
   M_REQUIRE(indoor || (cfg->num_classes >= 1 && cfg->n_sizes >= 1 && cfg->n_sizes <= 4 && cfg->n_rotations >= 1 && cfg->n_rotations <= 4),
             "ivx_create: 1..4 anchor sizes / rotations, >= 1 class");
   M_REQUIRE(indoor || (cfg->nms_pre > 0 && cfg->max_num > 0), "ivx_create: nms_pre and max_num must be positive");
-  if (cfg->use_graph) {
-    // ROCm 7.2: replays of a graph whose dispatch packets the runtime pre-built come back as garbage for this path (exact with the
-    // feature off: tests/graph_replay_check.py).  The runtime reads the variable once, at its initialisation.
-    const char *pc = getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
-    M_REQUIRE(pc && pc[0] == '0' && pc[1] == 0, "ivx_create: use_graph needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP "
-                                                 "runtime initialises (hipGraph replays of this path are wrong on ROCm 7.2 otherwise)");
-  }
   M_REQUIRE(cfg->wino_operands == IVX_F32 || cfg->wino_operands == IVX_F16_PAIR, "ivx_create: wino_operands IVX_F32 | IVX_F16_PAIR");
   M_REQUIRE(cfg->trunk_operands == IVX_F32 || cfg->trunk_operands == IVX_F16_PAIR, "ivx_create: trunk_operands IVX_F32 | IVX_F16_PAIR");
   M_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 2 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "ivx_create: winograd_tile 0 | 2 | 4 | 6");
@@ -1324,15 +1313,8 @@ extern "C" int ivx_destroy(ivx_model *m) {
   if (!m) return IVX_OK;
   for (void *p : m->owned) (void)hipFree(p);
   for (hipEvent_t e : m->event_pool) (void)hipEventDestroy(e);
-  for (ivx_model::GraphEntry &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
   delete m;
   return IVX_OK;
-}
-
-static void drop_graphs(ivx_model *m) {
-  for (ivx_model::GraphEntry &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
-  m->graphs.clear();
-  m->warmed.clear();
 }
 
 extern "C" int ivx_weights_load(ivx_model *m, const char *key, const float *data, const int64_t *shape, int32_t ndim) {
@@ -1350,7 +1332,6 @@ extern "C" int ivx_weights_load(ivx_model *m, const char *key, const float *data
     M_REQUIRE(ndim == 2 && shape[1] == 7, "ivx_weights_load: anchors must be [n, 7]");
     m->anchors_given = t.data;
     m->anchors_h = m->anchors_w = 0;      // re-upload on the next forward
-    drop_graphs(m);                       // captured graphs replay the old grid (and possibly an old device pointer)
     return IVX_OK;
   }
   std::string k = key;
@@ -1441,48 +1422,7 @@ extern "C" int ivx_model_forward(ivx_model *m, const float *input, int32_t B, in
   if (out_valid) bd.ext[m->t_valid] = out_valid;
   bd.proj = proj; bd.new_origin = new_origin; bd.crop = crop_hw; bd.V = V;
   bd.boxes = out_boxes; bd.scores = out_scores; bd.labels = out_labels; bd.count = out_count;
-  hipStream_t st = (hipStream_t)stream;
-  if (!m->cfg.use_graph || !st)      // (the legacy default stream cannot be captured)
-    return run_steps(m, *pl, r, bd, workspace, workspace_bytes, st, "ivx_model_forward");
-  // Graph replay: the ~150 launches of a forward are recorded once per set of caller buffers and replayed with one
-  // hipGraphLaunch.  First call with a buffer set: eager (settles one-time work: anchor upload); second: capture; then replay.
-  const std::vector<uintptr_t> key = {(uintptr_t)pl, (uintptr_t)input, (uintptr_t)proj, (uintptr_t)new_origin, (uintptr_t)crop_hw,
-                                      (uintptr_t)workspace, (uintptr_t)out_boxes, (uintptr_t)out_scores, (uintptr_t)out_labels,
-                                      (uintptr_t)out_count, (uintptr_t)out_valid, (uintptr_t)workspace_bytes};
-  for (const ivx_model::GraphEntry &g : m->graphs)
-    if (g.key == key) {
-      M_HIP(hipGraphLaunch(g.exec, st), "hipGraphLaunch");
-      return IVX_OK;
-    }
-  M_TRY(ensure_anchors(m, pl->tail, st, "ivx_model_forward"));    // allocation + H2D copy: never inside a capture
-  if (std::find(m->warmed.begin(), m->warmed.end(), key) == m->warmed.end()) {
-    if (m->warmed.size() >= 8) m->warmed.erase(m->warmed.begin());     // a host that passes new buffers every call: bounded
-    m->warmed.push_back(key);
-    return run_steps(m, *pl, r, bd, workspace, workspace_bytes, st, "ivx_model_forward");
-  }
-  if (m->trace_on) {          // the stage events become event-record nodes of the graph: every replay re-records them, so the
-    m->trace.clear();         // records read back after a replay are those of the LAST step
-    m->events_used = 0;
-  }
-  M_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-  const int rc = run_steps(m, *pl, r, bd, workspace, workspace_bytes, st, "ivx_model_forward");
-  hipGraph_t graph = nullptr;
-  const hipError_t e_end = hipStreamEndCapture(st, &graph);
-  if (rc != IVX_OK) {
-    if (graph) (void)hipGraphDestroy(graph);
-    return rc;
-  }
-  M_HIP(e_end, "hipStreamEndCapture");
-  hipGraphExec_t exec = nullptr;
-  M_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
-  (void)hipGraphDestroy(graph);
-  if (m->graphs.size() >= 8) {                      // callers with ever-changing buffers: keep the table small
-    (void)hipGraphExecDestroy(m->graphs.front().exec);
-    m->graphs.erase(m->graphs.begin());
-  }
-  m->graphs.push_back({key, exec});
-  M_HIP(hipGraphLaunch(exec, st), "hipGraphLaunch");
-  return IVX_OK;
+  return run_steps(m, *pl, r, bd, workspace, workspace_bytes, (hipStream_t)stream, "ivx_model_forward");
 }
 
 // ---- 2-D trunk alone
@@ -1778,17 +1718,10 @@ extern "C" int ivx_voxel_new_origin(const float *origin, const int32_t *n_voxels
 // 5 anchor tail.  Read the records after synchronising the stream; enabling clears them.
 extern "C" int ivx_model_trace(ivx_model *m, int32_t enable) {
   M_REQUIRE(m, "ivx_model_trace: null handle");
-  if (m->trace_on != (enable != 0) || (enable && enable != m->trace_level)) {   // captured graphs hold (or lack) the event-record nodes: drop them on a change
-    drop_graphs(m);
-    m->trace.clear();
-    m->events_used = 0;
-  }
+  m->trace.clear();
+  m->events_used = 0;
   m->trace_on = enable != 0;
   if (enable == 1 || enable == 2) m->trace_level = enable;
-  if (m->graphs.empty()) {                 // eager mode (or nothing captured yet): start a fresh record list
-    m->trace.clear();
-    m->events_used = 0;
-  }
   return IVX_OK;
 }
 

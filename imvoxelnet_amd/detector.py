@@ -247,11 +247,8 @@ class ImVoxelNet(nn.Module):
         if native_ok:
             # the whole device side in one native call (csrc/model.cpp); host work: the camera set-up, as the reference
             B, V = img.shape[0], img.shape[1]
-            if self._native.graph:          # hipGraph replay keeps the camera set-up in caller-owned static buffers
-                proj, new_origin, crop = self._camera_setup(img_metas, 4, img.device)
-                boxes, scores, labels, count = self._native.forward(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
-            else:                           # camera set-up inside the library too (ivx_model_detect): one H2D of the camera block
-                boxes, scores, labels, count = self._native.detect(img.contiguous(), img_metas)
+            # camera set-up inside the library too (ivx_model_detect): one H2D of the camera block
+            boxes, scores, labels, count = self._native.detect(img.contiguous(), img_metas)
             if gather:
                 from .dist import all_gather_detections, is_collecting_rank
                 boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)
@@ -312,26 +309,6 @@ class ImVoxelNet(nn.Module):
             dets = self.detect_indoor_cl(volume, valid, img_metas)
         return [bbox3d2result(b, s, l) for b, s, l in dets]
 
-    def capture_graph(self, img, img_metas, warmup=2, backend=None):
-        """Capture the device side of simple_test for this input shape as ONE hipGraph (anchor-head configs) and return a callable
-        (img, img_metas) -> results that replays it: a step costs one graph launch instead of ~150 kernel launches.  The captured
-        region contains no host synchronisation: the camera parameters live in static device buffers refreshed by small H2D copies
-        before the replay, the result tensors are static too, and the only sync is the packed D2H of the detections afterwards.
-        backend 'native' (default where the native handle covers the model): hipGraph replay inside the library
-        (ivx_model_cfg.use_graph: first call eager, second captured, then one hipGraphLaunch per call) -- NativeGraphedSimpleTest;
-        'torch': a torch.cuda.CUDAGraph of the layer-by-layer composition -- GraphedSimpleTest (A/B).
-        CAVEAT (both backends, this ROCm stack): a replay can return garbage after a later fresh device allocation of a few
-        hundred MB by the process (tools/graph_fragility.py; not root-caused) -- allocate everything before capturing.  Eager
-        execution, the default, is not affected."""
-        if not isinstance(self.bbox_head, Anchor3DHead):
-            raise NotImplementedError('graph capture is built for the anchor-head configs')
-        from . import engine
-        if backend is None:
-            backend = 'native' if (engine.family(self) == 'anchor' and self.storage_dtype in (None, torch.float32)) else 'torch'
-        if backend == 'native':
-            return NativeGraphedSimpleTest(self, img, img_metas, warmup)
-        return GraphedSimpleTest(self, img, img_metas, warmup)
-
     def forward_test(self, img, img_metas, **kwargs):
         return self.simple_test(img, img_metas, gather=bool(kwargs.get('gather', False)))
 
@@ -345,90 +322,3 @@ class ImVoxelNet(nn.Module):
 
     def show_results(self, *args, **kwargs):
         pass
-
-
-class NativeGraphedSimpleTest:
-    """hipGraph replay of ImVoxelNet.simple_test inside the native model handle (ivx_model_forward with use_graph) for a fixed input
-    shape: a second handle with the graph option on, its own static buffers and stream (engine.NativeModel graph mode)."""
-
-    def __init__(self, model, img, img_metas, warmup=2):
-        from . import engine
-        if model._prepared_device is None:
-            model.prepare(img.device)
-        self.model = model
-        self.native = engine.NativeModel(model, img.device, graph=True)
-        self.shape = tuple(img.shape)
-        for _ in range(max(2, warmup)):              # eager, capture, (replay ...)
-            self.replay_device(img, img_metas)
-        torch.cuda.synchronize(img.device)
-        # a replay must give what the eager handle gives.  It does not when the HIP runtime was initialised before
-        # DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was in the environment (ROCm 7.2: replays of pre-built dispatch packets return garbage for this
-        # path; DESIGN 4.6) -- nothing the library can see from inside, so the first replay is checked against an eager step, loudly
-        got = [t.clone() for t in self.replay_device(img, img_metas)]
-        B, V, _, H, W = img.shape
-        proj, new_origin, crop = model._camera_setup(img_metas, 4, img.device)
-        eager = model._native if model._native is not None else engine.NativeModel(model, img.device)
-        want = eager.forward(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
-        torch.cuda.synchronize(img.device)
-        same = torch.equal(got[3], want[3]) and all(torch.equal(got[1][b, :int(want[3][b])], want[1][b, :int(want[3][b])]) for b in range(B))
-        if not same:
-            raise RuntimeError('hipGraph replay does not reproduce the eager step (detections per sample %s vs %s): the HIP runtime was initialised '
-                               'before DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was set -- export it before the process touches the GPU'
-                               % (got[3].tolist(), want[3].tolist()))
-
-    def replay_device(self, img, img_metas):
-        """-> the handle's static (boxes, scores, labels, count) device tensors (consume them before the next call)."""
-        if tuple(img.shape) != self.shape:
-            raise ValueError(f'graph was captured for images of shape {self.shape}, got {tuple(img.shape)}')
-        B, V, _, H, W = img.shape
-        proj, new_origin, crop = self.model._camera_setup(img_metas, 4, img.device)
-        return self.native.forward(img.reshape(B * V, 3, H, W).contiguous(), B, V, H, W, proj, new_origin, crop)
-
-    def __call__(self, img, img_metas):
-        boxes, scores, labels, count = self.replay_device(img, img_metas)
-        return self.model._results_one_copy(boxes, scores, labels, count, img_metas)
-
-
-class GraphedSimpleTest:
-    """torch.cuda.CUDAGraph replay of the layer-by-layer composition of ImVoxelNet.simple_test for a fixed input shape (see
-    ImVoxelNet.capture_graph, backend='torch': kept for A/B)."""
-
-    def __init__(self, model, img, img_metas, warmup=2):
-        self.model = model
-        dev = img.device
-        self.img = img.clone()
-        proj, origin, crop = model._camera_setup(img_metas, 4, dev)
-        self.proj, self.origin, self.crop = proj.clone(), origin.clone(), crop.clone()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):          # warm-up off the default stream: fills caches (anchors, allocator pools)
-            for _ in range(max(1, warmup)):
-                self._device_step(img_metas)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = self._device_step(img_metas)
-
-    def _device_step(self, img_metas):
-        m = self.model
-        p0 = m.features_2d_cl(self.img)
-        vol, _ = ops.backproject_mean(p0, self.proj, self.origin, self.crop, m.voxel_size, m.n_voxels)
-        return m.detect_cl(vol, img_metas)
-
-    def replay_device(self, img, img_metas):
-        """Refresh the static inputs and launch the graph; returns the static (boxes, scores, labels, count) tensors."""
-        if tuple(img.shape) != tuple(self.img.shape):
-            raise ValueError(f'graph was captured for images of shape {tuple(self.img.shape)}, got {tuple(img.shape)}')
-        self.img.copy_(img, non_blocking=True)
-        proj, origin, crop = self.model._camera_setup(img_metas, 4, torch.device('cpu'))
-        self.proj.copy_(proj, non_blocking=True)
-        self.origin.copy_(origin, non_blocking=True)
-        self.crop.copy_(crop, non_blocking=True)
-        self.graph.replay()
-        return self.out
-
-    def __call__(self, img, img_metas):
-        boxes, scores, labels, count = self.replay_device(img, img_metas)
-        dets = self.model.bbox_head._wrap(boxes, scores, labels, count, img_metas)
-        return [bbox3d2result(b, s, l) for b, s, l in dets]

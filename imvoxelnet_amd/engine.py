@@ -129,25 +129,15 @@ def model_cfg(model, with_trunk=True, winograd=None, winograd_tile=None):
 class NativeModel:
     """ivx_model handle built from an ImVoxelNet module (its config and its state dict)."""
 
-    def __init__(self, model, device, with_trunk=True, winograd=None, winograd_tile=None, graph=None):
+    def __init__(self, model, device, with_trunk=True, winograd=None, winograd_tile=None):
         self.family = family(model)
         cfg = model_cfg(model, with_trunk, winograd, winograd_tile)
         self.device = torch.device(device)
         L = self.L = _lib.lib()
         head = model.bbox_head
         g = getattr(head, 'anchor_generator', None)
-        import os
-        # hipGraph replay inside the handle (one graph per set of caller buffers): opt-in (IVX_NATIVE_GRAPH=1).  Measured on
-        # KITTI batch 4: the handle issues its ~150 launches from C++ fast enough that the replay gains nothing (28.07 vs 27.86 ms
-        # eager), so it stays off by default; it helps a host that is slow to issue launches.
-        self.graph = (os.environ.get('IVX_NATIVE_GRAPH', '0') == '1') if graph is None else bool(graph)
-        cfg.use_graph = int(self.graph)
         self.cfg = cfg
         self.max_num, self.n_voxels = cfg.max_num, tuple(model.n_voxels)
-        if graph and self.family != 'anchor':
-            raise NotImplementedError('graph replay is wired for ivx_model_forward (anchor-head families) only')
-        if self.family != 'anchor':
-            self.graph, cfg.use_graph = False, 0
         self.has_head = self.family == 'anchor' or cfg.head_type != 0          # ivx_model_detect runs the whole simple_test
         self.layout = bool(cfg.layout_head)
         h = C.c_void_p()
@@ -176,8 +166,6 @@ class NativeModel:
                 check(L.ivx_neck3d_levels(h, 1, dims), 'ivx_neck3d_levels')
                 self.level_dims = [tuple(d) for d in dims if d[3] > 0]    # (X, Y, Z, C) per level, finest first
         self._ws = {}
-        self._static = {}          # graph mode: stable input / output buffers per shape
-        self._gstream = torch.cuda.Stream(device=self.device) if self.graph else None   # the default stream cannot be captured
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -199,10 +187,7 @@ class NativeModel:
 
     def forward(self, x, B, V, H, W, proj, new_origin, crop_hw, want_valid=False):
         """x: image batch [B*V,3,H,W] (with_trunk) or FPN level-0 maps [B*V,1,H/4,W/4,Cf]; -> (boxes [B,max_num,7], scores,
-        labels int64, count int32[, valid bool [B,X,Y,Z]]) device tensors.
-        Graph mode (opt-in): inputs are copied into stable buffers, the handle replays one hipGraph per shape on its own
-        stream, and the returned tensors are the handle's stable output buffers -- consume (or clone) them before the next
-        forward of the same shape, as simple_test does."""
+        labels int64, count int32[, valid bool [B,X,Y,Z]]) device tensors."""
         L = self.L
         for t, nm in ((x, 'input'), (proj, 'proj'), (new_origin, 'new_origin')):
             if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
@@ -224,25 +209,8 @@ class NativeModel:
                                       C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()), C.c_void_p(out[3].data_ptr()),
                                       C.c_void_p(out[4].data_ptr()) if out[4] is not None else None, stream), 'ivx_model_forward')
 
-        if not self.graph:
-            out = outputs()
-            call(x, proj, new_origin, crop_hw, out, _stream())
-        else:
-            key = (tuple(x.shape), B, V, H, W, bool(want_valid))
-            st = self._static.get(key)
-            if st is None:
-                st = self._static[key] = (torch.empty_like(x), torch.empty_like(proj), torch.empty_like(new_origin), torch.empty_like(crop_hw),
-                                          outputs())
-            xs, ps, os_, cs, out = st
-            cur = torch.cuda.current_stream(dev)
-            self._gstream.wait_stream(cur)
-            with torch.cuda.stream(self._gstream):
-                xs.copy_(x, non_blocking=True)
-                ps.copy_(proj, non_blocking=True)
-                os_.copy_(new_origin, non_blocking=True)
-                cs.copy_(crop_hw, non_blocking=True)
-                call(xs, ps, os_, cs, out, C.c_void_p(self._gstream.cuda_stream))
-            cur.wait_stream(self._gstream)
+        out = outputs()
+        call(x, proj, new_origin, crop_hw, out, _stream())
         return (out[0], out[1], out[2], out[3], out[4].view(torch.bool)) if want_valid else out[:4]
 
     def detect(self, img, img_metas, want_valid=False):

@@ -537,9 +537,6 @@ typedef struct ivx_model_cfg {
   float dir_offset, dir_limit_offset;         /* Anchor3DHead(dir_offset, dir_limit_offset) */
   int32_t winograd;           /* 1: F(m x m, 3x3) form for the eligible layers (default of the Python host), 0: direct only */
   int32_t winograd_tile;      /* 0: automatic (6 on planes >= 16384 positions, else 4) | 2 | 4 | 6 */
-  int32_t use_graph;          /* 1: ivx_model_forward records its launches into a hipGraph per distinct set of caller buffers
-                                 (1st call eager, 2nd captured, then one hipGraphLaunch per call); needs a non-NULL stream and
-                                 stable buffers -- a host that passes new pointers every call gains nothing */
   /* indoor necks (zero for the outdoor ones; the anchor / test_cfg fields above are ignored for them) */
   int32_t fast_n_blocks[3];        /* FastIndoorImVoxelNeck(n_blocks) */
   int32_t unet_channels[4];        /* ImVoxelNeck(channels); [0] = fpn_channels; [3] = 0: three scales (two output levels) */
@@ -637,9 +634,7 @@ int ivx_layout_extrinsics(const float *angles /*[2]*/, float *extrinsic4x4);
 /* Optional stage timing (measurement only): while enabled, every launch group of the forward calls is bracketed by a pair
  * of HIP events on the caller's stream; the Winograd layers run as their three stages so each is timed.  stage: 0 direct
  * conv, 1 Winograd input transform, 2 grouped GEMM, 3 output transform, 4 unprojection, 5 anchor tail.  flops = FLOPs the
- * launch executes, bytes = algorithmic bytes of a transform / unprojection launch.  Read after synchronising the stream.
- * With use_graph the events are nodes of the captured graph: every replay re-records them and the records read back are
- * those of the last forward. */
+ * launch executes, bytes = algorithmic bytes of a transform / unprojection launch.  Read after synchronising the stream. */
 typedef struct ivx_trace_rec {
   int32_t step, stage, is3d;
   float ms;        /* duration of the launch group */

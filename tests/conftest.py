@@ -3,9 +3,6 @@ import sys
 
 import pytest
 
-# before anything can initialise the HIP runtime (see imvoxelnet_amd/__init__.py): hipGraph replays need the packet capture off on ROCm 7.2
-os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -271,21 +271,6 @@ def test_kitti_bf16_storage_mode_tracks_fp32(ia):
         assert abs(float(da['scores_3d'][0]) - float(db['scores_3d'][0])) < 0.05
 
 
-def test_graphed_simple_test_equals_eager():
-    """ImVoxelNet.capture_graph (default backend: hipGraph replay inside the native handle): the replay returns exactly the eager
-    results, also after the image and the camera parameters change (static input buffers are refreshed before every replay).
-    Runs in a FRESH process (tests/graph_replay_check.py): on this ROCm stack a hipGraph replay of this path can return garbage
-    depending on what the process did to device memory before (tools/graph_fragility.py) -- inside the full suite the
-    first replay after capture came back empty, alone it is exact -- so graph replay is opt-in and is tested where a host would use
-    it: captured early in the life of a process."""
-    import subprocess
-    import sys
-    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'graph_replay_check.py')
-    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
-    print(r.stdout[-2000:], r.stderr[-2000:])
-    assert r.returncode == 0 and 'GRAPH_REPLAY_OK' in r.stdout
-
-
 def test_indoor_eval_on_device_matches_reference(ia):
     """indoor_eval with the 3-D IoU from the device kernel (BaseInstance3DBoxes.overlaps -> ivx_boxes_overlap_bev)."""
     from test_host_cpu import _eval_inputs

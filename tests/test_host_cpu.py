@@ -1374,7 +1374,7 @@ def test_pair_operand_host_side_without_gpu(monkeypatch):
         assert f._wino_operands(6) == 0
     finally:
         FusedConv.wino_operands = old
-    # hipGraph replay needs the packet-capture work-around in the environment (ROCm 7.2): refused without it
+    # the operand-type fields of the handle's configuration are validated
     cfg = ModelCfg()
     cfg.neck_type, cfg.with_trunk, cfg.fpn_channels, cfg.neck_out_channels = 0, 1, 64, 256
     cfg.n_voxels[:] = [216, 248, 12]
@@ -1384,12 +1384,12 @@ def test_pair_operand_host_side_without_gpu(monkeypatch):
     cfg.anchor_sizes[:3] = [1.6, 3.9, 1.56]
     cfg.anchor_rotations[:2] = [0, 1.57]
     cfg.nms_pre, cfg.max_num, cfg.use_rotate_nms, cfg.score_thr, cfg.nms_thr = 100, 50, 1, .1, .01
-    cfg.dir_limit_offset, cfg.winograd, cfg.use_graph, cfg.wino_operands = 1.0, 1, 1, ops.IVX_F16_PAIR
+    cfg.dir_limit_offset, cfg.winograd, cfg.wino_operands, cfg.trunk_operands = 1.0, 1, ops.IVX_F16_PAIR, ops.IVX_F16_PAIR
     h = C.c_void_p()
-    monkeypatch.delenv('DEBUG_CLR_GRAPH_PACKET_CAPTURE', raising=False)
-    assert L.ivx_create(C.byref(cfg), C.byref(h)) == -1 and b'DEBUG_CLR_GRAPH_PACKET_CAPTURE' in L.ivx_last_error()
-    monkeypatch.setenv('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
     assert L.ivx_create(C.byref(cfg), C.byref(h)) == 0 and L.ivx_destroy(h) == 0
+    cfg.trunk_operands = 3
+    assert L.ivx_create(C.byref(cfg), C.byref(h)) == -1 and b'trunk_operands' in L.ivx_last_error()
+    cfg.trunk_operands = 0
     cfg.wino_operands = 7
     assert L.ivx_create(C.byref(cfg), C.byref(h)) == -1 and b'wino_operands' in L.ivx_last_error()
 

@@ -8,9 +8,7 @@ mkdir -p $ROOT/$OUT
 cd $ROOT
 python bench.py --steps 20 --warmup 5 2>$OUT/bench.err | tail -1 > $OUT/bench_default.json
 python bench.py --steps 20 --warmup 5 --api composed --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_composed.json
-python bench.py --steps 20 --warmup 5 --graph --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_graph.json
 IVX_NARROW_EPILOGUE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_narrow_epilogue.json
-IVX_NATIVE_GRAPH=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_native_graph.json
 python bench.py --steps 10 --warmup 3 --storage bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_bf16.json
 IVX_WINOGRAD=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_direct.json
 IVX_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \

@@ -9,7 +9,6 @@ python bench.py --steps 20 --warmup 5 2>$OUT/bench.err | tail -1 > $OUT/bench_de
 python bench.py --steps 20 --warmup 5 --wino-operands f32 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_f32_operands.json
 if [ -z "$IVX_EVIDENCE_SHORT" ]; then      # IVX_EVIDENCE_SHORT=1: only the default / fp32-operand lines, the kernel trace and the PMC passes
 python bench.py --steps 20 --warmup 5 --api composed --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_composed.json
-python bench.py --steps 20 --warmup 5 --graph --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_graph.json
 python bench.py --steps 10 --warmup 3 --storage bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_bf16.json
 IVX_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_dist1.json

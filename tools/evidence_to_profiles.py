@@ -23,7 +23,6 @@ def main():
     rows = [('default: `python bench.py --steps 20 --warmup 5` (simple_test -> ivx_model_detect, eager; Winograd-domain GEMMs on fp16 pair operands)', 'bench_default.json'),
             ('`--wino-operands f32` (fp32 MFMA in the Winograd domain: the round-2 arithmetic)', 'bench_f32_operands.json'),
             ('--api composed (layer by layer over the op-level ABI; every input stage reduces its tensor itself)', 'bench_composed.json'),
-            ('--graph (hipGraph replay inside the native handle; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0)', 'bench_graph.json'),
             ('--storage bf16 (optional reduced-precision mode; NOT the headline)', 'bench_bf16.json'),
             ('IVX_BENCH_FORCE_DIST=1 under torch.distributed.run, world size 1 (RCCL all-gather in every step)', 'bench_dist1.json'),
             (f'the run under rocprofv3 --kernel-trace --stats (profiles/{pre}_bench_kernel_trace.md)', 'bench_profiled.json')]
