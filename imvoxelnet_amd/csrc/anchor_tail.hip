@@ -142,23 +142,26 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *boxes, const 
                                                       int cb_stride, float thr, int rotated, unsigned long long *mask) {
   const int bz = blockIdx.z;
   const int n = n_arr ? n_arr[bz] : n_fixed;
-  const int row = blockIdx.y, col_start = blockIdx.x;
-  if (row >= n || col_start * 64 >= n || col_start < (row >> 6)) return;
+  const int col_start = blockIdx.x;
   const float *bx = boxes + (size_t)bz * box_stride * 5;
   const int col = col_start * 64 + threadIdx.x;
-  bool hit = false;
-  if (col < n && col > row) {
-    float a[5], b[5];
+  // rows beyond gridDim.y wrap around (the grid's y extent stops at 65535; n may be 65536)
+  for (int row = blockIdx.y; row < n; row += gridDim.y) {
+    if (col_start * 64 >= n || col_start < (row >> 6)) continue;
+    bool hit = false;
+    if (col < n && col > row) {
+      float a[5], b[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      a[q] = bx[(size_t)row * 5 + q];
-      b[q] = bx[(size_t)col * 5 + q];
+      for (int q = 0; q < 5; ++q) {
+        a[q] = bx[(size_t)row * 5 + q];
+        b[q] = bx[(size_t)col * 5 + q];
+      }
+      const float v = rotated ? iou_bev_dev(a, b) : iou_normal_dev(a, b);
+      hit = v > thr;
     }
-    const float v = rotated ? iou_bev_dev(a, b) : iou_normal_dev(a, b);
-    hit = v > thr;
+    const unsigned long long w = __ballot(hit);
+    if (threadIdx.x == 0) mask[((size_t)bz * box_stride + row) * cb_stride + col_start] = w;
   }
-  const unsigned long long w = __ballot(hit);
-  if (threadIdx.x == 0) mask[((size_t)bz * box_stride + row) * cb_stride + col_start] = w;
 }
 
 // Greedy scan by one wave: lane w owns removal word w (n <= 4096).  Returns the number kept (all lanes)
@@ -596,6 +599,87 @@ static void launch_topk(const HeadP &hp, const float *keys, int *topk, int *cnt,
   hipLaunchKernelGGL(topk_final_kernel, dim3(hp.B), dim3(1024), 0, st, hp, keys, cand, state, topk, cnt, n1);
 }
 
+// ---- top-k for more than 4096 candidates per list (the reference's topk takes any nms_pre, dense_heads/anchor3d_head.py:468-490).  The
+// three radix levels above give the exact 32-bit key of the k-th largest score; every key >= it is compacted (any count: thousands of
+// bit-equal scores at the threshold -- e.g. a level with fewer valid voxels than nms_pre -- all become candidates), ranked among the
+// candidates by composite key (score bits << 32 | ~index: unique, ties resolve to the lower index; O(c^2) compares from LDS tiles,
+// 0.1 G at c = 10 000) and the first k ranks are scattered to their places.  Same indices in the same order as the forms above.
+__global__ __launch_bounds__(256) void topk_compact_big_kernel(const float *keys, int n, TopkState *state, unsigned long long *cand) {
+  const int b = blockIdx.y;
+  const float *kb = keys + (size_t)b * n;
+  unsigned long long *cb = cand + (size_t)b * n;
+  const unsigned int thr = state[b].thr;
+  const int lane = threadIdx.x & 63;
+  for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+    const int i = base + threadIdx.x;
+    unsigned int fk = 0;
+    bool sel = false;
+    if (i < n) {
+      fk = f2key(kb[i]);
+      sel = fk >= thr;
+    }
+    const unsigned long long m = __ballot(sel);
+    if (!m) continue;
+    unsigned int pos = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) pos = atomicAdd(&state[b].cand_cnt, (unsigned int)__popcll(m));
+    pos = __shfl(pos, leader);
+    if (sel) cb[pos + (unsigned int)__popcll(m & ((1ULL << lane) - 1ULL))] = ((unsigned long long)fk << 32) | (unsigned int)(~(unsigned int)i);
+  }
+}
+
+__global__ __launch_bounds__(256) void topk_rank_big_kernel(const HeadP p, const unsigned long long *cand, const TopkState *state, int *topk_idx,
+                                                            int *n1_out) {
+  __shared__ unsigned long long tile[1024];
+  const int b = blockIdx.y;
+  const int c = (int)state[b].cand_cnt;
+  if ((int)(blockIdx.x * 256) >= c) return;                  // (whole workgroups: the barriers below stay uniform)
+  const unsigned long long *k = cand + (size_t)b * p.n;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long mine = i < c ? k[i] : 0ULL;
+  int r = 0;
+  for (int base = 0; base < c; base += 1024) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = base + t < c ? k[base + t] : 0ULL;
+    __syncthreads();
+    const int lim = c - base < 1024 ? c - base : 1024;
+    for (int t = 0; t < lim; ++t) r += tile[t] > mine ? 1 : 0;
+  }
+  const int kk = (p.nms_pre > 0 && p.nms_pre < p.n) ? p.nms_pre : p.n;
+  if (i < c && r < kk) {
+    topk_idx[(size_t)b * p.kpad + r] = (int)(~(unsigned int)(mine & 0xffffffffULL));
+    if (key2f((unsigned int)(mine >> 32)) > p.score_thr) atomicAdd(&n1_out[b], 1);
+  }
+}
+
+__global__ void topk_count_big_kernel(const HeadP p, int *cnt_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < p.B) cnt_out[b] = (p.nms_pre > 0 && p.nms_pre < p.n) ? p.nms_pre : p.n;
+}
+
+static int64_t topk_scratch_big_bytes(int B, int n) {
+  return ivx_align_up((int64_t)B * 3 * TOPK_BINS * 4, 256) + ivx_align_up((int64_t)B * (int64_t)sizeof(TopkState), 256) + ivx_align_up((int64_t)B * n * 8, 256);
+}
+
+static void launch_topk_big(const HeadP &hp, const float *keys, int *topk, int *cnt, int *n1, void *scratch, hipStream_t st) {
+  unsigned int *hist = (unsigned int *)scratch;
+  TopkState *state = (TopkState *)((char *)scratch + ivx_align_up((int64_t)hp.B * 3 * TOPK_BINS * 4, 256));
+  unsigned long long *cand = (unsigned long long *)((char *)state + ivx_align_up((int64_t)hp.B * (int64_t)sizeof(TopkState), 256));
+  (void)hipMemsetAsync(hist, 0, (size_t)hp.B * 3 * TOPK_BINS * 4, st);
+  (void)hipMemsetAsync(topk, 0xff, (size_t)hp.B * hp.kpad * 4, st);        // -1: the slots past k
+  (void)hipMemsetAsync(n1, 0, (size_t)hp.B * 4, st);
+  int g = (hp.n + 2047) / 2048;
+  const int gmax = hp.B >= 4 ? 64 : 128;
+  if (g > gmax) g = gmax;
+  for (int level = 0; level < 3; ++level) {
+    hipLaunchKernelGGL(topk_hist_kernel, dim3(g, hp.B), dim3(256), 0, st, keys, hp.n, level, state, hist);
+    hipLaunchKernelGGL(topk_thresh_kernel, dim3(hp.B), dim3(256), 0, st, hist, hp.n, hp.nms_pre, level, state);
+  }
+  hipLaunchKernelGGL(topk_compact_big_kernel, dim3(g, hp.B), dim3(256), 0, st, keys, hp.n, state, cand);
+  hipLaunchKernelGGL(topk_rank_big_kernel, dim3((hp.n + 255) / 256, hp.B), dim3(256), 0, st, hp, cand, state, topk, n1);
+  hipLaunchKernelGGL(topk_count_big_kernel, dim3((hp.B + 63) / 64), dim3(64), 0, st, hp, cnt);
+}
+
 // Decode the selected candidates (DeltaXYZWLHRBBoxCoder.decode, coders/delta_xyzwhlr_bbox_coder.py:56-90),
 // direction argmax (anchor3d_head.py:465-466), BEV xyxyr boxes (lidar_box3d.py:86-90, utils.py:64-82).
 __global__ __launch_bounds__(64) void decode_kernel(const HeadP p, const float *keys, const int *topk_idx,
@@ -678,6 +762,40 @@ __global__ __launch_bounds__(256) void nms_finalize_kernel(const HeadP p, const 
   if (threadIdx.x == 0) out_count[b] = nk;
 }
 
+// The same for more than 4096 candidates (any nms_pre / max_num): the removal words live in the scanning wave's LDS, the kept list in
+// global memory (keep_g [B][max_num]); one wave per batch item scans, then gathers.
+__global__ __launch_bounds__(64) void nms_finalize_big_kernel(const HeadP p, const int *n1_arr, const unsigned long long *mask,
+                                                              const float *cand_boxes, const float *cand_scores, const int *cand_dir,
+                                                              int *keep_g, float *out_boxes, float *out_scores, long long *out_labels,
+                                                              int *out_count) {
+  __shared__ unsigned long long remv[IVX_NMS_MAX_N / 64];
+  const int b = blockIdx.x;
+  int *keep = keep_g + (size_t)b * p.max_num;
+  const int nk = greedy_scan_big<int>(mask + (size_t)b * p.kpad * p.cb, nullptr, n1_arr[b], p.cb, p.max_num, nullptr, remv, keep);
+  __threadfence_block();
+  __syncthreads();
+  for (int j = threadIdx.x; j < p.max_num; j += 64) {
+    float *ob = out_boxes + ((size_t)b * p.max_num + j) * 7;
+    if (j < nk) {
+      const int i = __builtin_nontemporal_load(keep + j);
+      const float *cb_ = cand_boxes + ((size_t)b * p.kpad + i) * 7;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) ob[q] = cb_[q];
+      const float val = cb_[6] - p.dir_offset;
+      const float t = floorf(val / IVX_PI_F + p.dir_limit_offset);
+      const float dir_rot = val - t * IVX_PI_F;
+      ob[6] = (dir_rot + p.dir_offset) + IVX_PI_F * (float)cand_dir[(size_t)b * p.kpad + i];
+      out_scores[(size_t)b * p.max_num + j] = cand_scores[(size_t)b * p.kpad + i];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 7; ++q) ob[q] = 0.f;
+      out_scores[(size_t)b * p.max_num + j] = 0.f;
+    }
+    out_labels[(size_t)b * p.max_num + j] = 0;
+  }
+  if (threadIdx.x == 0) out_count[b] = nk;
+}
+
 __global__ void export_cands_kernel(const HeadP p, const int *topk_idx, const float *cand_boxes, const float *cand_scores,
                                     long long *o_idx, float *o_boxes, float *o_scores) {
   const int b = blockIdx.y;
@@ -698,7 +816,8 @@ static int next_pow2(int v) {
 }
 
 struct HeadWs {
-  int64_t keys, topk, cnt, n1, boxes, scores, dir, bev, mask, topk_scratch, total;
+  int64_t keys, topk, cnt, n1, boxes, scores, dir, bev, mask, topk_scratch, keep, total;
+  bool big;
 };
 
 static int head_layout(const ivx_anchor_head_desc *d, HeadP *p, HeadWs *w) {
@@ -714,13 +833,17 @@ static int head_layout(const ivx_anchor_head_desc *d, HeadP *p, HeadWs *w) {
   IVX_REQUIRE(n64 < (1LL << 31) && (int64_t)d->B * n64 < (1LL << 40), "ivx_anchor_head: too many anchors");
   const int n = (int)n64;
   const int k = (d->nms_pre > 0 && d->nms_pre < n) ? d->nms_pre : n;
-  IVX_REQUIRE(k <= 4096, "ivx_anchor_head: at most 4096 NMS candidates per sample (nms_pre=%d, anchors=%d)", d->nms_pre, n);
-  IVX_REQUIRE(d->max_num > 0 && d->max_num <= 4096, "ivx_anchor_head: max_num must be in 1..4096");
+  // up to 4096 candidates: the tuned forms (LDS sorts, removal words in registers); beyond: rank sort + LDS removal words, any nms_pre the
+  // NMS mask can index (IVX_NMS_MAX_N), as the reference's topk + nms_gpu (dense_heads/anchor3d_head.py:468-490, ops/iou3d/src/iou3d.cpp:95-147)
+  const bool big = k > 4096 || d->max_num > 4096;
+  IVX_REQUIRE(k <= IVX_NMS_MAX_N, "ivx_anchor_head: at most %d NMS candidates per sample (nms_pre=%d, anchors=%d)", IVX_NMS_MAX_N, d->nms_pre, n);
+  IVX_REQUIRE(d->max_num > 0 && d->max_num <= IVX_NMS_MAX_N, "ivx_anchor_head: max_num must be in 1..%d", IVX_NMS_MAX_N);
   IVX_REQUIRE(d->nms_pre > 0, "ivx_anchor_head: nms_pre must be positive (size of the candidate outputs)");
   p->Hh = d->H; p->Ww = d->W; p->transposed = d->hw_transposed ? 1 : 0;
   p->B = d->B; p->HW = d->H * d->W; p->CH = d->CH; p->A = d->num_anchors; p->ncls = d->num_classes;
   p->cls_off = d->cls_off; p->reg_off = d->reg_off; p->dir_off = d->dir_off; p->n = n;
-  p->nms_pre = d->nms_pre; p->max_num = d->max_num; p->kpad = next_pow2(k < 64 ? 64 : k); p->cb = p->kpad / 64;
+  p->nms_pre = d->nms_pre; p->max_num = d->max_num; p->kpad = big ? (k + 63) / 64 * 64 : next_pow2(k < 64 ? 64 : k); p->cb = p->kpad / 64;
+  w->big = big;
   p->score_thr = d->score_thr; p->nms_thr = d->nms_thr; p->dir_offset = d->dir_offset; p->dir_limit_offset = d->dir_limit_offset;
   p->rotated = d->use_rotate_nms;
   int64_t o = 0;
@@ -733,7 +856,8 @@ static int head_layout(const ivx_anchor_head_desc *d, HeadP *p, HeadWs *w) {
   w->dir = o; o = ivx_align_up(o + (int64_t)d->B * p->kpad * 4, 256);
   w->bev = o; o = ivx_align_up(o + (int64_t)d->B * p->kpad * 5 * 4, 256);
   w->mask = o; o = ivx_align_up(o + (int64_t)d->B * p->kpad * p->cb * 8, 256);
-  w->topk_scratch = o; o += topk_scratch_bytes(d->B);
+  w->topk_scratch = o; o += big ? topk_scratch_big_bytes(d->B, n) : topk_scratch_bytes(d->B);
+  w->keep = o; o = ivx_align_up(o + (big ? (int64_t)d->B * d->max_num * 4 : 0), 256);
   w->total = o;
   return IVX_OK;
 }
@@ -777,11 +901,16 @@ extern "C" int ivx_anchor_head_get_bboxes(const ivx_anchor_head_desc *d, const f
   size_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(anchor_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, keys);
-  launch_topk(p, keys, topk, cnt, n1, (char *)workspace + w.topk_scratch, st);
+  if (w.big) launch_topk_big(p, keys, topk, cnt, n1, (char *)workspace + w.topk_scratch, st);
+  else launch_topk(p, keys, topk, cnt, n1, (char *)workspace + w.topk_scratch, st);
   hipLaunchKernelGGL(decode_kernel, dim3(p.kpad / 64, p.B), dim3(64), 0, st, p, keys, topk, cboxes, cscores, cdir, cbev);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(p.cb, p.kpad, p.B), dim3(64), 0, st, cbev, n1, 0, p.kpad, p.cb, p.nms_thr, p.rotated, mask);
-  hipLaunchKernelGGL(nms_finalize_kernel, dim3(p.B), dim3(256), 0, st, p, n1, mask, cboxes, cscores, cdir, out_boxes, out_scores,
-                     (long long *)out_labels, out_count);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(p.cb, p.kpad > 65535 ? 65535 : p.kpad, p.B), dim3(64), 0, st, cbev, n1, 0, p.kpad, p.cb, p.nms_thr, p.rotated, mask);
+  if (w.big)
+    hipLaunchKernelGGL(nms_finalize_big_kernel, dim3(p.B), dim3(64), 0, st, p, n1, mask, cboxes, cscores, cdir, (int *)(ws + w.keep), out_boxes,
+                       out_scores, (long long *)out_labels, out_count);
+  else
+    hipLaunchKernelGGL(nms_finalize_kernel, dim3(p.B), dim3(256), 0, st, p, n1, mask, cboxes, cscores, cdir, out_boxes, out_scores,
+                       (long long *)out_labels, out_count);
   if (cand_idx || cand_boxes || cand_scores)
     hipLaunchKernelGGL(export_cands_kernel, dim3((p.nms_pre + 63) / 64, p.B), dim3(64), 0, st, p, topk, cboxes, cscores,
                        (long long *)cand_idx, cand_boxes, cand_scores);
@@ -825,7 +954,7 @@ extern "C" int ivx_nms_bev(const float *boxes_sorted, int32_t n, float thresh, i
   }
   const int cb = (n + 63) / 64;
   unsigned long long *mask = (unsigned long long *)workspace;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, n, 1), dim3(64), 0, st, boxes_sorted, (const int *)nullptr, n, n, cb, thresh, rotated, mask);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, n > 65535 ? 65535 : n, 1), dim3(64), 0, st, boxes_sorted, (const int *)nullptr, n, n, cb, thresh, rotated, mask);
   if (n <= 4096)
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, mask, n, cb, (long long *)keep, num_out);
   else       // removal words in LDS instead of one per lane: same kept sequence
@@ -898,20 +1027,22 @@ __global__ __launch_bounds__(1024) void mc_select_sort_kernel(const McP p) {
 // the order is not known here) instead of once per class over the sorted candidates.
 __global__ __launch_bounds__(64) void nms_hit_full_kernel(const float *boxes, int n, int cb, float thr, int rotated,
                                                           unsigned long long *mask) {
-  const int row = blockIdx.y, col = blockIdx.x * 64 + threadIdx.x;
-  bool hit = false;
-  if (col < n && col != row) {
-    float a[5], b[5];
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  for (int row = blockIdx.y; row < n; row += gridDim.y) {      // (grid.y stops at 65535; n may be 65536)
+    bool hit = false;
+    if (col < n && col != row) {
+      float a[5], b[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      a[q] = boxes[(size_t)row * 5 + q];
-      b[q] = boxes[(size_t)col * 5 + q];
+      for (int q = 0; q < 5; ++q) {
+        a[q] = boxes[(size_t)row * 5 + q];
+        b[q] = boxes[(size_t)col * 5 + q];
+      }
+      const float v = rotated ? iou_bev_dev(a, b) : iou_normal_dev(a, b);
+      hit = v > thr;
     }
-    const float v = rotated ? iou_bev_dev(a, b) : iou_normal_dev(a, b);
-    hit = v > thr;
+    const unsigned long long w = __ballot(hit);
+    if (threadIdx.x == 0) mask[(size_t)row * cb + blockIdx.x] = w;
   }
-  const unsigned long long w = __ballot(hit);
-  if (threadIdx.x == 0) mask[(size_t)row * cb + blockIdx.x] = w;
 }
 
 // Greedy scan of class c over the shared hit matrix: candidates are visited in score order (sidx), the removal set is a
@@ -1116,7 +1247,7 @@ extern "C" int ivx_multiclass_nms_bev(const float *boxes, const float *scores, i
     hipLaunchKernelGGL(mc_keys_big_kernel, g, dim3(256), 0, st, p, keys);
     hipLaunchKernelGGL(rank_sort_kernel, g, dim3(256), 0, st, keys, n, p.ns, rank);
     hipLaunchKernelGGL(mc_scatter_big_kernel, g, dim3(256), 0, st, p, keys, rank);
-    hipLaunchKernelGGL(nms_hit_full_kernel, dim3(cb, n), dim3(64), 0, st, boxes, n, cb, nms_thr, rotated, p.mask);
+    hipLaunchKernelGGL(nms_hit_full_kernel, dim3(cb, n > 65535 ? 65535 : n), dim3(64), 0, st, boxes, n, cb, nms_thr, rotated, p.mask);
     hipLaunchKernelGGL(mc_scan_big_kernel, dim3(num_classes), dim3(64), 0, st, p);
     const int cap = p.ns < max_num ? p.ns : max_num;
     const unsigned blocks = (unsigned)(((long long)num_classes * cap + 255) / 256);
@@ -1127,9 +1258,9 @@ extern "C" int ivx_multiclass_nms_bev(const float *boxes, const float *scores, i
   hipLaunchKernelGGL(mc_select_sort_kernel, dim3(num_classes), dim3(1024), (size_t)p.npad * 8, st, p);
   const int shared = num_classes >= 3;
   if (shared)
-    hipLaunchKernelGGL(nms_hit_full_kernel, dim3(cb, n), dim3(64), 0, st, boxes, n, cb, nms_thr, rotated, p.mask);
+    hipLaunchKernelGGL(nms_hit_full_kernel, dim3(cb, n > 65535 ? 65535 : n), dim3(64), 0, st, boxes, n, cb, nms_thr, rotated, p.mask);
   else
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, n, num_classes), dim3(64), 0, st, p.cboxes, (const int *)p.n_arr, 0, p.ns, cb, nms_thr,
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, n > 65535 ? 65535 : n, num_classes), dim3(64), 0, st, p.cboxes, (const int *)p.n_arr, 0, p.ns, cb, nms_thr,
                        rotated, p.mask);
   hipLaunchKernelGGL(mc_scan_kernel, dim3(num_classes), dim3(64), 0, st, p, shared);
   {
@@ -1387,9 +1518,10 @@ __global__ __launch_bounds__(256) void aligned_scatter_big_kernel(const float *b
 }
 
 __global__ __launch_bounds__(64) void aligned_mask_big_kernel(int n, int cb, float thresh, AnmsScratch w, unsigned long long *mask) {
-  const int row = blockIdx.y, col_start = blockIdx.x;
-  if (col_start < (row >> 6)) return;
+  const int col_start = blockIdx.x;
   const int col = col_start * 64 + threadIdx.x;
+  for (int row = blockIdx.y; row < n; row += gridDim.y) {      // (grid.y stops at 65535; n may be 65536)
+  if (col_start < (row >> 6)) continue;
   bool hit = false;
   if (col < n && col > row) {
     const float *B1 = w.sbox + (size_t)row * 6, *B2 = w.sbox + (size_t)col * 6;
@@ -1406,6 +1538,7 @@ __global__ __launch_bounds__(64) void aligned_mask_big_kernel(int n, int cb, flo
   }
   const unsigned long long m = __ballot(hit);
   if (threadIdx.x == 0) mask[(size_t)row * cb + col_start] = m;
+  }
 }
 
 static int64_t anms_big_bytes(int64_t n, int64_t *o_keys, int64_t *o_rank, int64_t *o_mask) {
@@ -1462,7 +1595,7 @@ extern "C" int ivx_aligned_3d_nms_ws(const float *boxes, const float *scores, co
     hipLaunchKernelGGL(aligned_keys_big_kernel, g, dim3(256), 0, st, scores, n, keys);
     hipLaunchKernelGGL(rank_sort_kernel, dim3(g.x, 1), dim3(256), 0, st, keys, n, n, rank);
     hipLaunchKernelGGL(aligned_scatter_big_kernel, g, dim3(256), 0, st, boxes, (const long long *)classes, n, rank, w);
-    hipLaunchKernelGGL(aligned_mask_big_kernel, dim3(cb, n), dim3(64), 0, st, n, cb, thresh, w, mask);
+    hipLaunchKernelGGL(aligned_mask_big_kernel, dim3(cb, n > 65535 ? 65535 : n), dim3(64), 0, st, n, cb, thresh, w, mask);
     hipLaunchKernelGGL(nms_scan_big_kernel, dim3(1), dim3(64), 0, st, mask, (const int *)nullptr, n, cb, (const int *)w.sidx, (long long *)pick,
                        num_out);
     IVX_CHECK_LAUNCH("ivx_aligned_3d_nms_ws");
@@ -1575,9 +1708,10 @@ __global__ __launch_bounds__(64) void fcos_decode_kernel(const FcosP p, const in
 extern "C" int64_t ivx_fcos_head_workspace_bytes(int32_t B, int32_t n, int32_t nms_pre) {
   if (B <= 0 || n <= 0) return -1;
   const int k = (nms_pre > 0 && nms_pre < n) ? nms_pre : n;
-  if (k > 4096) return -1;
-  const int kpad = next_pow2(k < 64 ? 64 : k);
-  return ivx_align_up((int64_t)B * n * 4, 256) + ivx_align_up((int64_t)B * kpad * 4, 256) + 2 * 256 + topk_scratch_bytes(B);
+  if (k > IVX_NMS_MAX_N) return -1;
+  const int kpad = k > 4096 ? (k + 63) / 64 * 64 : next_pow2(k < 64 ? 64 : k);
+  return ivx_align_up((int64_t)B * n * 4, 256) + ivx_align_up((int64_t)B * kpad * 4, 256) + 2 * ivx_align_up((int64_t)B * 4, 256) +
+         (k > 4096 ? topk_scratch_big_bytes(B, n) : topk_scratch_bytes(B));
 }
 
 extern "C" int ivx_fcos_head_level_candidates(const float *head_out, const uint8_t *valid0, const float *level_vs,
@@ -1595,7 +1729,7 @@ extern "C" int ivx_fcos_head_level_candidates(const float *head_out, const uint8
   IVX_REQUIRE(n64 < (1LL << 31), "ivx_fcos_head_level_candidates: grid too large");
   const int n = (int)n64;
   const int k = (nms_pre > 0 && nms_pre < n) ? nms_pre : n;
-  IVX_REQUIRE(k <= 4096, "ivx_fcos_head_level_candidates: at most 4096 candidates per level (got %d)", k);
+  IVX_REQUIRE(k <= IVX_NMS_MAX_N, "ivx_fcos_head_level_candidates: at most %d candidates per level (got %d)", IVX_NMS_MAX_N, k);
   const int64_t need = ivx_fcos_head_workspace_bytes(B, n, nms_pre);
   if (workspace_bytes < need) {
     ivx_set_error("ivx_fcos_head_level_candidates: workspace too small");
@@ -1605,11 +1739,12 @@ extern "C" int ivx_fcos_head_level_candidates(const float *head_out, const uint8
   FcosP p;
   p.head_out = head_out; p.valid0 = valid0; p.vs = level_vs; p.new_origin = level_new_origin; p.scale = scale;
   p.B = B; p.nx = nx; p.ny = ny; p.nz = nz; p.n = n; p.CH = CH; p.ncls = n_classes; p.R = n_reg; p.level = level;
-  p.X = X; p.Y = Y; p.Z = Z; p.k = k; p.kpad = next_pow2(k < 64 ? 64 : k);
+  p.X = X; p.Y = Y; p.Z = Z; p.k = k; p.kpad = k > 4096 ? (k + 63) / 64 * 64 : next_pow2(k < 64 ? 64 : k);
   char *ws = (char *)workspace;
   float *keys = (float *)ws;
   int *topk = (int *)(ws + ivx_align_up((int64_t)B * n * 4, 256));
   int *n1 = (int *)(ws + ivx_align_up((int64_t)B * n * 4, 256) + ivx_align_up((int64_t)B * p.kpad * 4, 256));
+  const int64_t n1_bytes = 2 * ivx_align_up((int64_t)B * 4, 256);
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (size_t)B * n;
   size_t blocks = (total + 255) / 256;
@@ -1617,7 +1752,8 @@ extern "C" int ivx_fcos_head_level_candidates(const float *head_out, const uint8
   hipLaunchKernelGGL(fcos_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, keys);
   HeadP hp = {};
   hp.n = n; hp.nms_pre = nms_pre; hp.kpad = p.kpad; hp.score_thr = 0.f; hp.B = B;
-  launch_topk(hp, keys, topk, cand_count, n1, (char *)n1 + 2 * 256, st);
+  if (k > 4096) launch_topk_big(hp, keys, topk, cand_count, n1, (char *)n1 + n1_bytes, st);
+  else launch_topk(hp, keys, topk, cand_count, n1, (char *)n1 + n1_bytes, st);
   hipLaunchKernelGGL(fcos_decode_kernel, dim3((k + 63) / 64, B), dim3(64), 0, st, p, topk, cand_boxes, cand_scores);
   IVX_CHECK_LAUNCH("ivx_fcos_head_level_candidates");
   return IVX_OK;

@@ -86,13 +86,13 @@ struct ConvParams {
 };
 
 // What a wave needs of the pair-IO state: multipliers of the accumulator / the residual (exact: powers of two) and the output scale.
-struct PairIO { float inv_in, inv_res, s_out; };
+struct PairIO { float inv_in, inv_res, s_out; bool sat; };
 // Every wave computes the same values from the same device words (no communication): the output scale comes from a BOUND of the
 // output -- |out| <= max|in| * wbound + sbound + max|res| with the MEASURED maxima of the operands, which their producers left in the
 // amax slots -- so nothing has to pass over the output before it is written as (hi, lo) halves.  A bound that is loose by a factor L
 // costs nothing up to L = 2^18: a value's error is max(2^-22 |x|, 2^-25 / s), i.e. relative to the tensor's maximum max(2^-22, 2^-40 L).
 __device__ __forceinline__ PairIO conv_pair_io(const ConvParams &p) {
-  PairIO io = {1.0f, 1.0f, 1.0f};
+  PairIO io = {1.0f, 1.0f, 1.0f, false};
   if (p.in_scale_p) io.inv_in = 1.0f / *p.in_scale_p;
   if (p.res_pair && p.res_scale_p) io.inv_res = 1.0f / *p.res_scale_p;
   if (p.out_pair) {
@@ -106,6 +106,10 @@ __device__ __forceinline__ PairIO conv_pair_io(const ConvParams &p) {
     }
     const float bound = (a * p.wbound + p.sbound + r) * fabsf(p.post_scale) * 1.001f;
     io.s_out = ivx_pow2_scale(bound);
+    // a non-finite bound (an Inf / NaN among the operands) says nothing about the finite outputs: fixed scale 2^-8 and a saturating
+    // split, so that the damage stays where fp32 arithmetic keeps it instead of the whole tensor overflowing to Inf
+    io.sat = !(bound < 3.0e38f);
+    if (io.sat) io.s_out = 0.00390625f;
   }
   return io;
 }
@@ -320,7 +324,8 @@ __device__ __forceinline__ float conv_pio_finish4(const ConvParams &p, const Pai
     f16x4 h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float y = v[e] * io.s_out;
+      float y = v[e] * io.s_out;
+      if (io.sat) y = (y > 65504.f && y < __builtin_inff()) ? 65504.f : ((y < -65504.f && y > -__builtin_inff()) ? -65504.f : y);
       h[e] = (_Float16)y;
       l[e] = (_Float16)(y - (float)h[e]);
     }
@@ -1044,13 +1049,15 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
 // kernel and the split-K reduction.
 #if IVX_CONV_TU == 0
 // (pair IO: the scales of conv_pair_io; returns |stored value| before the output scale, for the amax slots)
-__device__ __forceinline__ float conv_store_one(const ConvParams &p, int m, int n, float acc, const PairIO io = {1.0f, 1.0f, 1.0f}) {
+__device__ __forceinline__ float conv_store_one(const ConvParams &p, int m, int n, float acc, const PairIO io = {1.0f, 1.0f, 1.0f, false}) {
   if (p.pio) {
     const size_t idx = (size_t)m * p.Cout + n;
     size_t ridx = idx;
     if (p.res_mode == 2) ridx = res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) + n;
     const float v = conv_finish(p, acc, (p.scale ? p.scale[n] : 1.0f) * io.inv_in, p.shift ? p.shift[n] : 0.0f, ridx, p.res_pair ? io.inv_res : 1.0f);
-    conv_st_out(p, idx, p.out_pair ? v * io.s_out : v);
+    float y = p.out_pair ? v * io.s_out : v;
+    if (p.out_pair && io.sat) y = (y > 65504.f && y < __builtin_inff()) ? 65504.f : ((y < -65504.f && y > -__builtin_inff()) ? -65504.f : y);
+    conv_st_out(p, idx, y);
     return fabsf(v);
   }
   if (p.out_mode == 1) {
@@ -1072,7 +1079,7 @@ __device__ __forceinline__ float conv_store_one(const ConvParams &p, int m, int 
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const size_t rows = (size_t)8 * p.q_count * p.bm;
   const size_t total = rows * p.Cout;
-  PairIO io = {1.0f, 1.0f, 1.0f};
+  PairIO io = {1.0f, 1.0f, 1.0f, false};
   if (p.pio) {
     io = conv_pair_io(p);
     if (p.out_scale_p && blockIdx.x == 0 && threadIdx.x == 0) *p.out_scale_p = io.s_out;
@@ -1120,7 +1127,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_pio_kernel(const ConvP
 // Validation kernel: one thread per output element, sequential fmaf over (kd,kh,kw,ci).
 __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p) {
   const size_t total = (size_t)p.M * p.Cout;
-  PairIO io = {1.0f, 1.0f, 1.0f};
+  PairIO io = {1.0f, 1.0f, 1.0f, false};
   if (p.pio) {
     io = conv_pair_io(p);
     if (p.out_scale_p && blockIdx.x == 0 && threadIdx.x == 0) *p.out_scale_p = io.s_out;

@@ -820,7 +820,7 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
         const int n = in.D * in.H * in.W, k = (c.head_nms_pre > 0 && c.head_nms_pre < n) ? c.head_nms_pre : n;
         const int R = c.head_type == IVX_HEAD_SCANNET ? 6 : 7;
         const int64_t fw = ivx_fcos_head_workspace_bytes(in.B, n, c.head_nms_pre);
-        M_REQUIRE(fw >= 0, "indoor head level %d: more than 4096 candidates per level (nms_pre %d)", s.aux, c.head_nms_pre);
+        M_REQUIRE(fw >= 0, "indoor head level %d: more than 65536 candidates per level (nms_pre %d)", s.aux, c.head_nms_pre);
         pl->ws_bytes = std::max(pl->ws_bytes, fw);
         pl->itail.k[s.aux] = k;
         TInfo cb; cb.B = in.B; cb.D = cb.H = 1; cb.W = k; cb.C = R; cb.raw = true; cb.bytes = align256((int64_t)in.B * k * R * 4); cb.first = i;
@@ -1298,7 +1298,7 @@ extern "C" int ivx_create(const ivx_model_cfg *cfg, ivx_model **out) {
   if (cfg->head_type != IVX_HEAD_NONE) {
     M_REQUIRE(indoor, "ivx_create: the anchor-free heads sit on the FAST / UNET necks (the stack necks end in the Anchor3DHead)");
     M_REQUIRE(cfg->head_classes >= 1 && (cfg->head_type == IVX_HEAD_SCANNET || cfg->head_classes <= 64), "ivx_create: bad head_classes");
-    M_REQUIRE(cfg->head_nms_pre > 0 && cfg->head_nms_pre <= 4096, "ivx_create: head_nms_pre must be in 1..4096");
+    M_REQUIRE(cfg->head_nms_pre > 0 && cfg->head_nms_pre <= 65536, "ivx_create: head_nms_pre must be in 1..65536");
   }
   M_REQUIRE(!cfg->layout_head || (cfg->with_trunk && cfg->layout_linear_size > 0), "ivx_create: the LayoutHead needs the trunk and a positive layout_linear_size");
   for (int i = 0; i < 4; ++i) M_REQUIRE(cfg->dcn_stages[i] == 0 || cfg->with_trunk, "ivx_create: dcn_stages without the trunk");

@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256) void maxpool2d_nhwc_pair_kernel(const float *i
                                                                   int Wo, _Float16 *out, const unsigned *amax_in, float wbound, float sbound,
                                                                   float *out_scale, unsigned *amax_out) {
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  const float sc = ivx_pow2_scale((ivx_amax_read(amax_in) * wbound + sbound) * 1.001f);
+  const float bound = (ivx_amax_read(amax_in) * wbound + sbound) * 1.001f;
+  const bool sat = !(bound < 3.0e38f);                      // non-finite image: fixed scale, saturating split (as conv_pair_io)
+  const float sc = sat ? 0.00390625f : ivx_pow2_scale(bound);
   if (blockIdx.x == 0 && threadIdx.x == 0) *out_scale = sc;
   const int C4 = C >> 2;
   const size_t total = (size_t)B * Ho * Wo * C4;
@@ -439,7 +441,8 @@ __global__ __launch_bounds__(256) void maxpool2d_nhwc_pair_kernel(const float *i
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       omax = fmaxf(omax, fabsf(m[q]));
-      const float y = m[q] * sc;
+      float y = m[q] * sc;
+      if (sat) y = (y > 65504.f && y < __builtin_inff()) ? 65504.f : ((y < -65504.f && y > -__builtin_inff()) ? -65504.f : y);
       hi[q] = (_Float16)y;
       lo[q] = (_Float16)(y - (float)hi[q]);
     }

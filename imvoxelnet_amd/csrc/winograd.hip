@@ -43,8 +43,13 @@ struct WinoP {
 // 2^-18 of it keeps a normal lo half (fp16 subnormals have a fixed spacing of 2^-24, so a lo half below 2^-14 loses relative precision:
 // measured 1.8e-4 rms with a fixed scale at activation scale 1e-3, reproduced by tools/wino_pair_sim.py).  Activations: |V| = |Bt d B| <= 225 max|d| for F(6,3) (|Bt| row sums <= 15), 100 for F(4,3): bounded by 256.
 // Filters: the exact max |U| is reduced while they are transformed.  Both scales are undone in the output transform (exact).
+// A non-finite maximum (an Inf / NaN somewhere in the tensor, or values beyond 3e38) carries no information about the finite values: the
+// operands then get the fixed scale 2^-8 and the conversion SATURATES finite values at +-65504 (wino_pair2's `sat`), so that the damage
+// stays where fp32 arithmetic would keep it -- the tiles that touch the non-finite element -- instead of every V overflowing to Inf.
+__device__ __forceinline__ bool wino_amax_bad(const float amax) { return !(amax < 3.0e38f); }      // NaN / Inf / huge
 __device__ __forceinline__ float wino_pow2_scale(const float amax, const float gain_log2) {   // s = 2^k with gain * amax * s in [2^14, 2^15)
-  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+  if (wino_amax_bad(amax)) return 0.00390625f;
+  if (!(amax > 0.f)) return 1.0f;
   int e;
   (void)frexpf(amax, &e);                        // amax in [2^(e-1), 2^e)
   int k = 15 - (int)gain_log2 - e;
@@ -244,8 +249,12 @@ typedef _Float16 wf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
 // (hi, lo) fp16 halves of two scaled values: hi = fp16(x), lo = fp16(x - hi).  No saturation needed: the scale puts 256 max|in| below
 // 2^15 and |V| <= 225 max|in| (wino_pair_vscale), so |x| < 65504 for every finite input.
-__device__ __forceinline__ void wino_pair2(const float2 v, const float s, unsigned *hi, unsigned *lo) {
-  const float x0 = v.x * s, x1 = v.y * s;
+__device__ __forceinline__ float wino_sat16(const float x) {      // finite overflow -> +-65504; Inf and NaN pass through
+  return (x > 65504.f && x < __builtin_inff()) ? 65504.f : ((x < -65504.f && x > -__builtin_inff()) ? -65504.f : x);
+}
+__device__ __forceinline__ void wino_pair2(const float2 v, const float s, unsigned *hi, unsigned *lo, const bool sat = false) {
+  float x0 = v.x * s, x1 = v.y * s;
+  if (sat) { x0 = wino_sat16(x0); x1 = wino_sat16(x1); }      // (wave-uniform: only when the tensor's maximum is not finite)
   wf16x2 h, l;
   h[0] = (_Float16)x0;
   h[1] = (_Float16)x1;
@@ -266,6 +275,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
   const V *in = reinterpret_cast<const V *>(p.in);
   V *Vw = reinterpret_cast<V *>(p.V);
   const float vscale = PAIR ? wino_pair_vscale(p.hdr) : 1.0f;
+  const bool sat = PAIR ? wino_amax_bad(__uint_as_float(p.hdr[0])) : false;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const long long zc = t % per_tile;
     long long q = t / per_tile;
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
           unsigned hi, lo;
-          wino_pair2(v[j], vscale, &hi, &lo);
+          wino_pair2(v[j], vscale, &hi, &lo, sat);
           const unsigned give = odd ? hi : lo, got = (unsigned)__shfl_xor((int)give, 1);
           u32x2w o;
           o.x = odd ? got : hi;      // even lane: (hi_even, hi_odd); odd lane: (lo_even, lo_odd)
@@ -805,12 +815,19 @@ extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *d, int32_t tile, cons
 
 namespace {
 // workgroups of the output transform's launch (= entries of the partial-maximum array of ivx_conv_winograd_output_amax)
-unsigned wino_output_grid(const ivx_conv_desc *d, int tile, const WinoDims &w) {
+// The F(6x6,3x3) kernel variant of a launch.  A launch that leaves per-workgroup maxima (`with_partials`) always takes the library's rule,
+// whatever the A/B knob of the calling thread says: the caller sized its partials array with ivx_conv_winograd_output_blocks -- possibly
+// at another time and on another thread -- and the number of workgroups must be the one that call returned.
+int wino_output_variant(const ivx_conv_desc *d, const WinoDims &w, bool with_partials) {
+  const bool buf_ok = (int64_t)w.n2 * w.m_stride * 4 < (1LL << 32) && (int64_t)d->B * w.Xo * w.Yo * w.Zo * d->Cout * 4 < (1LL << 31);
+  int v = (g_wino_out_variant >= 0 && !with_partials) ? g_wino_out_variant : (d->res_mode ? 2 : 1);
+  if (v >= 2 && !buf_ok) v = 0;
+  return v;
+}
+unsigned wino_output_grid(const ivx_conv_desc *d, int tile, const WinoDims &w, bool with_partials) {
   if (tile == 2) return wino_blocks(w.m_elems / 4);
   if (tile == 4) return wino_blocks(w.m_elems / 2);
-  const bool buf_ok = (int64_t)w.n2 * w.m_stride * 4 < (1LL << 32) && (int64_t)d->B * w.Xo * w.Yo * w.Zo * d->Cout * 4 < (1LL << 31);
-  int v = g_wino_out_variant >= 0 ? g_wino_out_variant : (d->res_mode ? 2 : 1);
-  if (v >= 2 && !buf_ok) v = 0;
+  const int v = wino_output_variant(d, w, with_partials);
   return (v == 2 || v == 0) ? wino_blocks(w.m_elems / 2) : wino_blocks(w.m_elems);
 }
 }  // namespace
@@ -818,7 +835,7 @@ unsigned wino_output_grid(const ivx_conv_desc *d, int tile, const WinoDims &w) {
 extern "C" int32_t ivx_conv_winograd_output_blocks(const ivx_conv_desc *d, int32_t tile) {
   WinoDims w;
   if (wino_dims(d, tile, &w, "ivx_conv_winograd_output_blocks") != IVX_OK) return -1;
-  return (int32_t)wino_output_grid(d, tile, w);
+  return (int32_t)wino_output_grid(d, tile, w, true);
 }
 
 static int wino_output_impl(const ivx_conv_desc *d, int32_t tile, const float *scale, const float *shift, const void *res, void *out,
@@ -836,9 +853,7 @@ static int wino_output_impl(const ivx_conv_desc *d, int32_t tile, const float *s
   else if (tile == 4)
     hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p);
   else {
-    const bool buf_ok = (int64_t)w.n2 * w.m_stride * 4 < (1LL << 32) && (int64_t)d->B * w.Xo * w.Yo * w.Zo * d->Cout * 4 < (1LL << 31);
-    int v = g_wino_out_variant >= 0 ? g_wino_out_variant : (d->res_mode ? 2 : 1);
-    if (v >= 2 && !buf_ok) v = 0;
+    const int v = wino_output_variant(d, w, partials != nullptr);
     const unsigned mb = (unsigned)((int64_t)w.n2 * w.m_stride * 4), ob = (unsigned)((int64_t)d->B * w.Xo * w.Yo * w.Zo * d->Cout * 4);
     if (v == 2)
       hipLaunchKernelGGL((wino_output_buf_kernel<2, 3>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p, mb, ob);

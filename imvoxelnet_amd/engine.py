@@ -50,7 +50,7 @@ def family(model):
         h = model.bbox_head
         tc = getattr(h, 'test_cfg', None)
         n_levels = 3 if isinstance(n3, FastIndoorImVoxelNeck) else len(n3.model.channels) - 1
-        ok = (isinstance(h, _ImVoxelHeadBase) and h.n_convs == 0 and tc is not None and 0 < int(tc.get('nms_pre', 0)) <= 4096
+        ok = (isinstance(h, _ImVoxelHeadBase) and h.n_convs == 0 and tc is not None and 0 < int(tc.get('nms_pre', 0)) <= 65536
               and h.n_scales >= n_levels and (h.n_reg_outs == 6 or h.n_classes <= 64))
         if ok:
             return 'indoor'

@@ -120,7 +120,7 @@ class _ImVoxelHeadBase(nn.Module):
             vs, no = self._level_geometry((nx, ny, nz), lvl, img_metas, f.device)
             wsb = L.ivx_fcos_head_workspace_bytes(B, n, int(cfg.nms_pre))
             if wsb < 0:
-                raise ValueError('ivx_fcos_head_workspace_bytes: unsupported size (more than 4096 candidates per level?)')
+                raise ValueError('ivx_fcos_head_workspace_bytes: unsupported size (more than 65536 candidates per level?)')
             ws = torch.empty((wsb,), device=f.device, dtype=torch.uint8)
             cb = torch.empty((B, k, self.n_reg_outs), device=f.device, dtype=torch.float32)
             cs = torch.empty((B, k, self.n_classes), device=f.device, dtype=torch.float32)

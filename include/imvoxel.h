@@ -381,7 +381,7 @@ int ivx_anchor_head_get_bboxes(const ivx_anchor_head_desc *d, const float *head_
  * valid0   [B, X, Y, Z] u8      level-0 mask from ivx_backproject_mean_fwd; (nx,ny,nz) * 2^level == (X,Y,Z)
  * level_vs, level_new_origin [B,3]  voxel_size * 2^level and origin - n_level/2 * that (host-built fp32, as get_points)
  * n_reg 6: boxes are corners (x1,y1,z1,x2,y2,z2); n_reg 7: (cx,cy,cz,w,l,h,alpha)
- * cand_boxes [B, k, n_reg], cand_scores [B, k, n_classes], cand_count [B] with k = min(nms_pre, nx*ny*nz) <= 4096,
+ * cand_boxes [B, k, n_reg], cand_scores [B, k, n_classes], cand_count [B] with k = min(nms_pre, nx*ny*nz) <= 65536 (beyond 4096: rank sort of the candidates, same order),
  * candidates in descending class-maximum score.  The (cross-level) NMS is ivx_aligned_3d_nms / ivx_nms_bev.     */
 int64_t ivx_fcos_head_workspace_bytes(int32_t B, int32_t n, int32_t nms_pre);
 int ivx_fcos_head_level_candidates(const float *head_out, const uint8_t *valid0, const float *level_vs,

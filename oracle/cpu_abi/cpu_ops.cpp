@@ -255,7 +255,8 @@ extern "C" int ivx_conv_fwd_pio(const ivx_conv_desc *d, const ivx_pair_io *io, c
   if (out_pair) {
     const float a = c_amax_read(io->amax_in), rr = (d->res_mode && io->amax_res) ? c_amax_read(io->amax_res) : 0.f;
     const float post = d->post_scale == 0.f ? 1.0f : d->post_scale;
-    const float s = c_pow2_scale((a * io->wbound + io->sbound + rr) * fabsf(post) * 1.001f);
+    const float bound = (a * io->wbound + io->sbound + rr) * fabsf(post) * 1.001f;
+    const float s = !(bound < 3.0e38f) ? 0.00390625f : c_pow2_scale(bound);      // (non-finite bound: fixed scale; the device also saturates)
     *io->out_scale = s;
     c_pair_encode(outf, M, d->Cout, s, (uint16_t *)out_);
   }
@@ -454,7 +455,7 @@ extern "C" int ivx_anchor_head_get_bboxes(const ivx_anchor_head_desc *d, const f
   C_REQUIRE(d->num_classes == 1, "ivx_anchor_head: only num_classes == 1 is built; got %d", d->num_classes);
   const int HW = d->H * d->W, A = d->num_anchors, n = HW * A;
   const int k = (d->nms_pre > 0 && d->nms_pre < n) ? d->nms_pre : n;
-  C_REQUIRE(k <= 4096 && d->max_num > 0 && d->max_num <= 4096 && d->nms_pre > 0, "ivx_anchor_head: nms_pre / max_num out of range");
+  C_REQUIRE(k <= 65536 && d->max_num > 0 && d->max_num <= 65536 && d->nms_pre > 0, "ivx_anchor_head: nms_pre / max_num out of range");
   (void)next_pow2;
   const float PI = 3.14159265358979323846f;
   for (int b = 0; b < d->B; ++b) {
@@ -607,7 +608,7 @@ extern "C" int ivx_multiclass_nms_bev(const float *boxes, const float *scores, i
 extern "C" int64_t ivx_fcos_head_workspace_bytes(int32_t B, int32_t n, int32_t nms_pre) {
   if (B <= 0 || n <= 0) return -1;
   const int k = (nms_pre > 0 && nms_pre < n) ? nms_pre : n;
-  return k > 4096 ? -1 : 256;
+  return k > 65536 ? -1 : 256;
 }
 
 static inline float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -622,7 +623,7 @@ extern "C" int ivx_fcos_head_level_candidates(const float *head_out, const uint8
                 level >= 0 && level < 8 && (nx << level) == X && (ny << level) == Y && (nz << level) == Z,
             "ivx_fcos_head_level_candidates: bad dims");
   const int n = nx * ny * nz, k = (nms_pre > 0 && nms_pre < n) ? nms_pre : n;
-  C_REQUIRE(k <= 4096, "ivx_fcos_head_level_candidates: at most 4096 candidates per level (got %d)", k);
+  C_REQUIRE(k <= 65536, "ivx_fcos_head_level_candidates: at most 65536 candidates per level (got %d)", k);
   auto validf = [&](int b, int i) -> float {
     const int iz = i % nz, t = i / nz, iy = t % ny, ix = t / ny;
     const uint8_t *v = valid0 + (size_t)b * X * Y * Z;

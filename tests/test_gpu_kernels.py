@@ -1240,3 +1240,94 @@ def test_conv_fp8_storage(ia, case):
         mp = ops.maxpool2d(xin.data, 3, 2, 1)
         want = F.max_pool2d(xq.float(), 3, 2, 1)
         assert torch.equal(to_host(mp), want)
+
+
+@pytest.mark.parametrize('nms_pre,max_num', [(6000, 300), (10000, 5000), (20000, 200)])
+def test_anchor_tail_general_nms_pre_vs_oracle(ia, nms_pre, max_num):
+    """ivx_anchor_head_get_bboxes beyond 4096 candidates per sample (the reference's topk + nms_gpu take any nms_pre,
+    dense_heads/anchor3d_head.py:468-490, ops/iou3d/src/iou3d.cpp:95-147): rank-sorted top-k, NMS mask over all candidates, greedy scan
+    with the removal words in LDS -- against the oracle's get_bboxes_single (torch top-k + the C oracle's rotated NMS): identical top-k
+    anchor indices in identical order, identical kept boxes; 20000 > the 16 800 anchors: every anchor is a candidate."""
+    from oracle import imvoxel_oracle as orc
+    from imvoxelnet_amd import ops
+    H, W, A = 60, 70, 2
+    g = torch.Generator().manual_seed(nms_pre)
+    B = 2
+    cls = torch.randn(B, A, H, W, generator=g) * 1.5 - 1.0
+    reg = torch.randn(B, A * 7, H, W, generator=g) * 0.05
+    dr = torch.randn(B, A * 2, H, W, generator=g)
+    ranges = [[0, -22.4, -1.78, 38.4 - .64, 22.4 - .64, -1.78]]
+    anchors = orc.grid_anchors((H, W), ranges, [[1.6, 3.9, 1.56]], [0, 1.57])
+    cfg = dict(nms_pre=nms_pre, max_num=max_num, use_rotate_nms=True, nms_thr=0.3, score_thr=0.3)
+    head_out = torch.cat([cls, reg, dr], 1).permute(0, 2, 3, 1).contiguous().cuda()         # [B, H, W, CH]
+    boxes, scores, labels, count, (ci, cb, cs) = ops.anchor_head_get_bboxes(head_out, anchors.cuda(), H, W, A, 1, (0, A, A + A * 7), cfg,
+                                                                           want_candidates=True)
+    torch.cuda.synchronize()
+    n = H * W * A
+    k = min(nms_pre, n)
+    for b in range(B):
+        ob, osc, odir, topk = orc.anchor_head_candidates(cls[b], reg[b], dr[b], anchors, 1, nms_pre)
+        want_idx = topk if topk is not None else torch.arange(n)
+        got_idx = ci[b, :k].cpu()
+        if topk is not None:      # identical sequence; the only tolerated difference: neighbours whose scores are tied to 1e-5 relative
+            from gpu_util import assert_same_kept       # (the device's expf and torch's sigmoid differ by an ulp: such pairs have no defined order)
+            assert_same_kept(f'top-{k} sample {b}', got_idx.numpy(), cs[b, :k].cpu().numpy(), want_idx.numpy(), osc[:, 0].numpy(), boundary=True)
+        else:       # all anchors selected: the device returns them in descending score order
+            assert torch.equal(got_idx.sort()[0], want_idx)
+            assert bool((cs[b, :k - 1] >= cs[b, 1:k]).all())
+        rb, rs, rl = orc.anchor_head_get_bboxes_single(cls[b], reg[b], dr[b], anchors, 1, cfg)
+        nk = int(count[b])
+        print(f'nms_pre {nms_pre}: sample {b} kept {nk}, oracle {len(rs)}')
+        assert nk == len(rs) and nk > 20
+        assert_close(f'scores{b}', scores[b, :nk], rs, 1e-5, 1e-6)
+        assert_close(f'boxes{b}', boxes[b, :nk], rb, 1e-4, 1e-4)
+        assert bool((scores[b, nk:] == 0).all()) and bool((boxes[b, nk:] == 0).all())
+
+
+def test_fcos_candidates_general_nms_pre(ia):
+    """ivx_fcos_head_level_candidates with nms_pre beyond 4096 (and beyond the number of VALID voxels, so thousands of candidates tie
+    at score 0 and the order among them is by index): the same candidates in the same order as torch's top-k of the class maximum
+    with the lower index first among ties."""
+    import ctypes as C
+    from imvoxelnet_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(77)
+    B, nx, ny, nz, ncls, R = 2, 40, 40, 16, 5, 6
+    n, CH = nx * ny * nz, 1 + R + ncls
+    head = (torch.randn(B, nx, ny, nz, CH, generator=g) * 0.7).cuda()
+    valid = (torch.rand(B, nx, ny, nz, generator=g) < 0.3).to(torch.uint8).cuda()           # ~7700 valid voxels of 25 600
+    vs = torch.tensor([[.08, .08, .08]] * B).cuda()
+    no = torch.tensor([[-1.6, -1.6, -.64]] * B).cuda()
+    for nms_pre in (5000, 12000):
+        k = min(nms_pre, n)
+        wsb = L.ivx_fcos_head_workspace_bytes(B, n, nms_pre)
+        assert wsb > 0
+        ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
+        cb = torch.empty(B, k, R, device='cuda')
+        cs = torch.empty(B, k, ncls, device='cuda')
+        cc = torch.empty(B, dtype=torch.int32, device='cuda')
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(L.ivx_fcos_head_level_candidates(p(head), p(valid), p(vs), p(no), 1.0, B, nx, ny, nz, CH, ncls, R, 0, nx, ny, nz, nms_pre,
+                                                    p(ws), wsb, p(cb), p(cs), p(cc), None), 'ivx_fcos_head_level_candidates')
+        torch.cuda.synchronize()
+        assert cc.tolist() == [k] * B
+        hd = head.double().cpu().reshape(B, n, CH)
+        sc = torch.sigmoid(hd[..., 1 + R:]) * torch.sigmoid(hd[..., :1]) * valid.cpu().reshape(B, n, 1).double()
+        mx = sc.max(-1)[0]
+        got_mx = cs.double().cpu().max(-1)[0]
+        for b in range(B):
+            assert bool((got_mx[b, :-1] >= got_mx[b, 1:] - 1e-12).all()), 'candidates must be in descending order of the class maximum'
+            # the selected SET: everything strictly above the k-th value must be there; ties at the cut (score 0) resolve to the lower index
+            order = sorted(range(n), key=lambda i: (-float(mx[b, i]), i))[:k]
+            nz_sel = [i for i in order if mx[b, i] > 0]
+            assert_close(f'nms_pre {nms_pre} sample {b}: positive class maxima', got_mx[b, :len(nz_sel)].float(), mx[b, nz_sel].float(), 1e-5, 1e-7)
+            assert bool((got_mx[b, len(nz_sel):] == 0).all())
+            # among the zero-score tail the library takes the lowest indices: their decoded boxes are those voxels' boxes
+            zero_idx = [i for i in order if mx[b, i] == 0]
+            if zero_idx:
+                i = zero_idx[-1]
+                ix, iy, iz = i // (ny * nz), (i // nz) % ny, i % nz
+                d = torch.exp(head[b, ix, iy, iz, 1:7].cpu())
+                px, py, pz = ix * .08 - 1.6, iy * .08 - 1.6, iz * .08 - .64
+                want = torch.tensor([px - d[0], py - d[2], pz - d[4], px + d[1], py + d[3], pz + d[5]])
+                assert_close('last tied candidate', cb[b, k - 1].cpu(), want, 1e-5, 1e-5)
