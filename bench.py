@@ -155,6 +155,11 @@ def bench_other(args, ia, kc, dev, rank, world):
 
     def step(i, traced=False):
         FusedConv.trace = trunk_tr[i] if traced else None
+        if view_sharded and args.exchange != 'all_reduce' and hasattr(model.neck_3d, 'strides') and isinstance(model.bbox_head, ia.Anchor3DHead):
+            FusedConv.trace = None               # reduce-scatter over x-slabs: the neck runs on this rank's slab inside the call
+            ev[i][0].record(); ev[i][1].record()
+            res = model.simple_test_view_sharded(img, metas, exchange='reduce_scatter' if multi else 'all_reduce')
+            return [(r['boxes_3d'].tensor, r['scores_3d'], r['labels_3d']) for r in res]
         if view_sharded:
             from imvoxelnet_amd.dist import view_sharded_lift
             vol, valid = view_sharded_lift(model, img, metas)       # 2-D trunk + partial lift on this rank's views, all-reduce
@@ -176,8 +181,10 @@ def bench_other(args, ia, kc, dev, rank, world):
         return [(b.tensor.cpu(), s.cpu(), l.cpu()) for b, s, l in res]
 
     multi = dist.is_available() and dist.is_initialized()
-    if multi and not view_sharded:
-        raise SystemExit('--config other than kitti runs single-process, or with --shard views under torch.distributed.run')
+    # N > 1: --shard samples (default; BASELINE configs 4 / 5: every rank its own scenes, one all-gather of padded detections per step,
+    # weak scaling) needs the public call through the native handle; --shard views (one scene set, views split, strong scaling)
+    if multi and not view_sharded and not (args.api == 'simple_test' and getattr(model, '_native', None) is not None and model.head_2d is None):
+        raise SystemExit('--config other than kitti on N > 1 ranks: --shard samples needs the native handle (fp32 storage), or use --shard views')
     # default: the public call.  model.simple_test runs trunk + unprojection + neck (+ the anchor head and tail for nuScenes)
     # through the native model handle; stage times come from its coarse trace (neck stages individually, trunk as one span)
     public = args.api == 'simple_test' and getattr(model, '_native', None) is not None and not view_sharded
@@ -186,7 +193,9 @@ def bench_other(args, ia, kc, dev, rank, world):
         step(0)                                  # one composed step: the neck's direct / executed FLOP counts
 
         def step(i, traced=False):               # noqa: F811
-            res = model.simple_test(img, metas)
+            res = model.simple_test(img, metas, gather=multi)
+            if res is None:                      # N > 1: the collected list exists on rank 0 only (as collect_results)
+                return []
             return [(r['boxes_3d'].tensor, r['scores_3d'], r['labels_3d']) for r in res]
         model._native.trace(0)      # the timed steps run without stage events: these steps are short (4-30 ms, ~100 launches)
     for i in range(args.warmup):
@@ -203,7 +212,16 @@ def bench_other(args, ia, kc, dev, rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    rccl_ranks, rank_ms = None, None
     if multi:
+        # self-check of the N > 1 line, as on the KITTI line: every rank's own step time and the rank count an actual all-reduce sees
+        tl = torch.tensor([dt], device=dev, dtype=torch.float64)
+        allt = torch.empty((dist.get_world_size(),), device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, tl)
+        rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in allt.cpu()]
+        ones = torch.ones((1,), device=dev, dtype=torch.float32)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(ones.item())
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -211,6 +229,8 @@ def bench_other(args, ia, kc, dev, rank, world):
             return
     trunk_note = ''
     if public and not traced_run:                # throughput only
+        neck_ms, t2d, t2d_ms, t2d_flops, nt = 1e9, [], 0.0, 0.0, 0
+    elif public and multi:                       # (the gathered step holds a collective: no extra single-rank steps)
         neck_ms, t2d, t2d_ms, t2d_flops, nt = 1e9, [], 0.0, 0.0, 0
     elif public:
         nt = min(3, args.steps)                  # stage events (native coarse trace) in extra steps after the timed region
@@ -246,10 +266,15 @@ def bench_other(args, ia, kc, dev, rank, world):
     ach = neck_exec[0] / (neck_ms * 1e-3) / 1e12      # executed FLOPs over the whole neck time (transform kernels included)
     pk = PEAK_BF16_MFMA_TFLOPS if args.storage == 'bf16' else PEAK_F32_MFMA_TFLOPS
     rec = {'metric': f'images/sec/node ({args.config}: {V} view(s) 3x{H}x{W}, {"x".join(map(str, cfg["n_voxels"]))} vox)',
-           'value': round(B * V * args.steps / dt, 3), 'unit': 'images/s', 'scenes_per_s': round(B * args.steps / dt, 3), 'n_gpus': world,
+           'value': round(B * V * (1 if view_sharded else world) * args.steps / dt, 3), 'unit': 'images/s',
+           'scenes_per_s': round(B * (1 if view_sharded else world) * args.steps / dt, 3), 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
            'scaling': 'strong' if view_sharded else 'weak', 'vs_baseline': None, 'dtype': args.storage + ((' + fp8 2-D conv (bf16 residual stream)' if args.fp8_residual == 'bf16' else ' + fp8 trunk storage') if args.trunk_fp8 else ''), 'data': 'synthetic',
-           'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'shard': args.shard, 'trunk_fp8': fp8_note, 'api': 'simple_test (native handle)' if public else 'composed',
+           'config': {'workload': args.config, 'views': V, 'batch_per_gpu': B, 'global_batch': B * (1 if view_sharded else world), 'parallelism': f'dp{world}' if not view_sharded else f'views/{world}',
+                      'shard': args.shard, 'rccl_ranks': rccl_ranks, 'ms_per_step_by_rank': rank_ms,
+                      'collective': (None if not multi else ('reduce-scatter of the partial volume over x-slabs (+ halo) + all-gather of the neck rows' if (view_sharded and args.exchange != 'all_reduce' and hasattr(model.neck_3d, 'strides'))
+                                                             else ('all-reduce of the partial volume sums / view counts' if view_sharded else 'one all_gather_into_tensor of padded detections per step (RCCL)'))),
+                      'trunk_fp8': fp8_note, 'api': 'simple_test (native handle)' if public else 'composed',
                       'wino_operands': 'fp16 pairs' if (FusedConv.wino_operands == 4 and args.storage != 'bf16') else 'storage type',
                       'detections_last_step': int(sum(len(r[1]) for r in last))},
            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel<%s> (3-D neck)' % ('__bf16' if args.storage == 'bf16' else 'float'),
@@ -279,11 +304,15 @@ def self_launch(n):
 
 
 def bench_dry(args, rank, world):
-    """--dry: the launch / sharding / collection plumbing of the N > 1 path without a GPU (CPU test with --backend gloo):
-    every rank takes its slice of a synthetic global batch of detections, the slices are all-gathered exactly as in the
-    timed step, rank 0 checks the reassembled batch and prints the JSON line (value is NOT a measurement)."""
+    """--dry: the launch / sharding / collection plumbing of the N > 1 path without a GPU (CPU test with --backend gloo), for the
+    workload `--config` names: every rank takes its slice of a synthetic global batch of detections (max_num rows of that config), the
+    slices are all-gathered exactly as in the timed step, rank 0 checks the reassembled batch and prints the JSON line (value is NOT a
+    measurement).  With --shard views the exchange of the view-sharded mode runs on synthetic partial volumes in BOTH forms -- the
+    all-reduce and the reduce-scatter over x-slabs with the neck's halo (dist.exchange_volume_slabs) -- and every rank checks that its
+    slab of the latter equals the same rows of the former, then the neck rows are all-gathered (dist.all_gather_rows)."""
     from imvoxelnet_amd import dist as ivx_dist
-    B, M = args.batch, 50
+    B = args.batch
+    M = {'kitti': 50, 'nuscenes': 500, 'scannet_fast': 3000, 'scannet_v1': 3000, 'sunrgbd_fast': 1000}.get(args.config, 50)
     g = torch.Generator().manual_seed(7)
     gb, gs = torch.randn(B * world, M, 7, generator=g), torch.rand(B * world, M, generator=g)
     gl, gc = torch.randint(0, 3, (B * world, M), generator=g), torch.randint(0, M + 1, (B * world,), generator=g, dtype=torch.int32)
@@ -296,17 +325,43 @@ def bench_dry(args, rank, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     ok = bool(torch.equal(boxes, gb) and torch.equal(scores, gs) and torch.equal(labels, gl) and torch.equal(count, gc))
+    slab_ok, slab_note = None, None
+    if args.shard == 'views':
+        import imvoxelnet_amd as ia
+        neck = (ia.KittiImVoxelNeck if args.config == 'kitti' else ia.NuScenesImVoxelNeck)(8, 16)
+        X, Y, Z, C = 48, 5, 4, 8
+        plans = [ivx_dist.StackNeckSlabs(neck, X, world, r) for r in range(world)]
+        gp = torch.Generator().manual_seed(100 + rank)                     # this rank's partial view sum / view count over the whole volume
+        part = torch.randn(B, X, Y, Z, C, generator=gp)
+        cnt = torch.randint(0, 3, (B, X, Y, Z), generator=gp, dtype=torch.int32)
+        sv, sc = ivx_dist.exchange_volume_slabs(part, cnt, plans, rank=rank)
+        full_v, full_c = ivx_dist.all_reduce_volume(part.clone(), cnt.clone())
+        me = plans[rank]
+        # the rank-ordered sum of the slab form against the all-reduce's: equal to fp32 rounding of the additions (bit-equal at 2 ranks)
+        slab_ok = bool(torch.equal(sc, full_c[:, me.ea:me.eb]) and torch.allclose(sv, full_v[:, me.ea:me.eb], rtol=0, atol=1e-5)
+                       and (world > 2 or torch.equal(sv, full_v[:, me.ea:me.eb])))
+        rows = torch.arange(me.oa, me.ob, dtype=torch.float32).reshape(1, -1, 1, 1, 1).expand(B, -1, 3, 1, 2).contiguous()
+        allrows = ivx_dist.all_gather_rows(rows, plans, rank=rank)
+        slab_ok = slab_ok and bool(torch.equal(allrows[0, :, 0, 0, 0], torch.arange(me.Xo, dtype=torch.float32)))
+        flag = torch.tensor([1.0 if slab_ok else 0.0])
+        if multi:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        slab_ok = bool(flag.item() == 1.0)
+        slab_note = 'x-slabs (oa, ob, ea, eb) of a %d-row volume: %s' % (X, [(p.oa, p.ob, p.ea, p.eb) for p in plans])
     if rank == 0:
-        print(json.dumps({'metric': 'images/sec/node (KITTI 3x384x1280, 216x248x12 vox)', 'value': 0.0, 'unit': 'images/s', 'n_gpus': world,
+        print(json.dumps({'metric': 'images/sec/node (KITTI 3x384x1280, 216x248x12 vox)' if args.config == 'kitti' else f'images/sec/node ({args.config})',
+                          'value': 0.0, 'unit': 'images/s', 'n_gpus': world,
                           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / (args.steps + args.warmup) * 1e3, 3),
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                          'dry': True, 'gathered_ok': ok,
-                          'config': {'workload': 'plumbing only (no GPU work)', 'batch_per_gpu': B, 'global_batch': B * world,
-                                     'parallelism': f'dp{world}', 'backend': args.backend}}))
+                          'dry': True, 'gathered_ok': ok, 'slab_exchange_ok': slab_ok,
+                          'config': {'workload': 'plumbing only (no GPU work): ' + args.config, 'batch_per_gpu': B, 'global_batch': B * world,
+                                     'parallelism': f'dp{world}', 'backend': args.backend, 'max_num': M, 'shard': args.shard, 'slabs': slab_note}}))
     if multi:
         dist.destroy_process_group()
     if not ok:
         raise SystemExit('dry run: the all-gathered batch differs from the global batch')
+    if slab_ok is False:
+        raise SystemExit('dry run: the reduce-scatter exchange over x-slabs differs from the all-reduce form')
 
 
 def main():
@@ -341,6 +396,9 @@ def main():
                          "fp16 MFMA products per pair, fp32 accumulation (22-bit operands: error at the level of the fp32 form's own rounding); "
                          "'f32' = fp32 MFMA (exact fp32 products).  The default run also times the other mode after the timed region and "
                          "reports it as exact_fp32_mfma")
+    ap.add_argument('--exchange', default='auto', choices=['auto', 'all_reduce', 'reduce_scatter'],
+                    help="--shard views: 'all_reduce' = whole partial volumes all-reduced, neck replicated; 'reduce_scatter' / 'auto' = x-slabs (+ halo) of the "
+                         "partial volumes exchanged, every rank convolves its slab (stack necks with an anchor head: nuScenes), neck rows all-gathered")
     ap.add_argument('--trunk-operands', default='f16pair', choices=['f16pair', 'f32'],
                     help="2-D trunk (ResNet-50 + FPN): 'f16pair' (default) = activations chained as fp16 (hi, lo) pair tensors with device-side "
                          "power-of-two scales (ivx_conv_fwd_pio: three fp16 MFMA products per multiply-add, fp32 accumulation, no conversion "

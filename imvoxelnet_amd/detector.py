@@ -215,7 +215,7 @@ class ImVoxelNet(nn.Module):
         return self.bbox_head.get_bboxes_cl(self.bbox_head.forward_cl(levels), valid, img_metas)
 
     def simple_test(self, img, img_metas, gather=False):
-        """detectors/imvoxelnet.py:93-106.  gather (anchor-head configs, torch.distributed initialised): every rank passes
+        """detectors/imvoxelnet.py:93-106.  gather (native-handle families, torch.distributed initialised): every rank passes
         its slice of the batch; ONE all-gather of the fixed-size padded device tensors (dist.all_gather_detections) replaces
         mmdet's pickle-based collect_results after the loop (tools/test.py:131-136), and -- as there -- the collected result list
         (whole batch, rank order) is built and returned on rank 0 only; the other ranks return None, so the host work of a step
@@ -229,6 +229,12 @@ class ImVoxelNet(nn.Module):
             # -> unprojection -> neck_3d -> anchor-free head -> per-level candidates -> cross-level NMS; camera set-up inside the library
             out = self._native.detect(img.contiguous(), img_metas)
             boxes, scores, labels, count = out[:4]
+            if gather and self.head_2d is None:      # sample-sharded ranks: one all-gather of the padded detections, result list on rank 0
+                from .dist import all_gather_detections, is_collecting_rank
+                boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)
+                if not is_collecting_rank():
+                    return None
+                img_metas = [img_metas[i % len(img_metas)] for i in range(boxes.shape[0])]
             results = self._results_one_copy(boxes, scores, labels, count, img_metas, with_yaw=self.bbox_head.n_reg_outs == 7, indoor=True)
             if self.head_2d is not None:                           # detectors/imvoxelnet.py:101-105
                 ang, lay = out[-1]
@@ -295,12 +301,32 @@ class ImVoxelNet(nn.Module):
             res.append(dict(boxes_3d=box_type(b[i, :n], box_dim=7, with_yaw=bool(with_yaw)), scores_3d=s[i, :n].clone(), labels_3d=l[i, :n].clone()))
         return res
 
-    def simple_test_view_sharded(self, img, img_metas, group=None):
+    def simple_test_view_sharded(self, img, img_metas, group=None, exchange='auto'):
         """simple_test with the VIEWS of the scene(s) sharded over the ranks of `group` (second mode): every
-        rank computes the 2-D features and the partial unprojection of its views, one all-reduce of the partial volume
-        sums and view counts (RCCL) is the only exchange, the 3-D neck / head / NMS then run replicated, so every rank
-        returns the full result.  Same output as simple_test up to fp32 rounding of the view sum."""
-        from .dist import view_sharded_lift
+        rank computes the 2-D features and the partial unprojection of its views; then
+          exchange='all_reduce': one all-reduce of the partial volume sums and view counts (RCCL), the 3-D neck / head / NMS run
+            replicated;
+          exchange='reduce_scatter' (stack necks + Anchor3DHead: the nuScenes family): every rank receives the totals of ITS x-slab of
+            the volume (+ the neck's receptive field as a halo), normalises and convolves that slab only, and the cropped neck outputs
+            are all-gathered (dist.view_sharded_neck_slabs) -- half the bytes on the wire, the neck divided by the ranks too;
+          'auto': reduce_scatter where it applies and there is more than one rank.
+        Every rank returns the full result.  Same output as simple_test up to fp32 rounding (the order of the view sum; with the slab
+        form also the alignment of the neck's Winograd tiles)."""
+        from .dist import view_sharded_lift, view_sharded_neck_slabs, _rank_world
+        from .necks3d import _StackNeck
+        slab_ok = isinstance(self.neck_3d, _StackNeck) and isinstance(self.bbox_head, Anchor3DHead) and self.head_2d is None
+        if exchange == 'auto':
+            exchange = 'reduce_scatter' if (slab_ok and _rank_world(None, None)[1] > 1) else 'all_reduce'
+        if exchange == 'reduce_scatter':
+            if not slab_ok:
+                raise NotImplementedError('the reduce-scatter exchange is built for the stack necks (Kitti / NuScenes) with an Anchor3DHead')
+            y = view_sharded_neck_slabs(self, img, img_metas, group=group)
+            h = self.bbox_head.forward_cl(y)
+            boxes, scores, labels, count = self.bbox_head.get_bboxes_cl(h, y.shape[2], y.shape[1], img_metas, hw_transposed=True)
+            dets = self.bbox_head._wrap(boxes, scores, labels, count, img_metas)
+            return [bbox3d2result(b, s, l) for b, s, l in dets]
+        if exchange != 'all_reduce':
+            raise ValueError("exchange must be 'auto', 'all_reduce' or 'reduce_scatter'")
         volume, valid = view_sharded_lift(self, img, img_metas, group=group)
         if isinstance(self.bbox_head, Anchor3DHead):
             boxes, scores, labels, count = self.detect_cl(volume, img_metas)

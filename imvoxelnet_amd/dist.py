@@ -10,6 +10,12 @@ Second, optional mode for single-scene latency with many views: VIEW
 trunk and the partial unprojection on its slice of the views, the partial view sums and view counts are all-reduced
 (the one real exchange step of the path: 26-300 MB fp32 per scene, ring all-reduce over xGMI), every rank normalises
 and continues with the (replicated) 3-D neck and head.  See view_sharded_lift / ImVoxelNet.simple_test_view_sharded.
+
+SURVEY 8e's preferred form of that exchange for the stack necks (KittiImVoxelNeck / NuScenesImVoxelNeck): a REDUCE-SCATTER OVER X-SLABS
+WITH A HALO (exchange_volume_slabs): rank r receives only the totals of its own slab of the volume, widened by the receptive field of
+the neck along x, normalises and convolves that slab alone, and the ranks all-gather the cropped neck outputs (one x-slab of
+[B,X',Y',1,C] each: 8x smaller than the volume).  Half the bytes of the all-reduce on the wire, and the 3-D neck -- the other half of a
+multi-view step -- is divided by the number of ranks as well (minus the halo's redundant rows).  See StackNeckSlabs.
 """
 import torch
 import torch.distributed as dist
@@ -125,3 +131,113 @@ def view_sharded_lift(model, img, img_metas, rank=None, world=None, group=None):
         cnt = torch.zeros((B,) + tuple(model.n_voxels), device=img.device, dtype=torch.int32)
     all_reduce_volume(vol, cnt, group)
     return ops.volume_normalize_(vol, cnt)
+
+
+# ------------------------------------------------------------------ reduce-scatter over X-slabs (+ halo) for the stack necks
+class StackNeckSlabs:
+    """Index arithmetic of running a stack neck (block, conv, block, conv, block, conv: necks3d._StackNeck) on one x-slab.
+    Along x every layer is a k = 3 convolution with its own stride / padding; output index o of a layer reads the inputs
+    o*s - p .. o*s - p + 2.  For the output slab [oa, ob) of rank r the constructor walks the layers backwards to the input
+    rows [lo, hi] those outputs depend on, widens the slab to [ea, eb) = [floor(lo) to a multiple of the total x stride, hi + 1)
+    (so that local and global indices of every strided layer stay congruent), clipped to the volume.  Outputs of the local run
+    that depend on the artificial zero padding at ea / eb lie outside [oa, ob) by construction and are cropped away."""
+
+    def __init__(self, neck, X, world, rank):
+        from .necks3d import BasicBlock3d
+        layers, k = [], 0
+        for m in neck.model:
+            if isinstance(m, BasicBlock3d):
+                layers += [(1, 1), (1, 1)]
+            else:
+                layers.append((int(neck.strides[k][0]), int(neck.paddings[k][0])))
+                k += 1
+        self.layers = layers
+        n = X
+        self.S = 1
+        for s_, p_ in layers:
+            n = (n + 2 * p_ - 3) // s_ + 1
+            self.S *= s_
+        self.X, self.Xo = X, n
+        if X % self.S:
+            raise ValueError(f'the x extent {X} of the volume is not a multiple of the neck\'s x stride {self.S}')
+        self.oa, self.ob = shard_range(self.Xo, rank, world)
+        if self.ob <= self.oa:
+            raise ValueError(f'more ranks ({world}) than output rows ({self.Xo}): use the all-reduce exchange')
+        lo, hi = self.oa, self.ob - 1
+        for s_, p_ in reversed(layers):
+            lo, hi = lo * s_ - p_, hi * s_ - p_ + 2
+        self.ea = max(0, lo // self.S * self.S)
+        self.eb = min(X, hi + 1)
+        self.off = self.ea // self.S                     # global output index of local output row 0
+
+    def crop(self, y_local):
+        """[B, x_local, Y', 1, C] of the local run -> this rank's output rows [oa, ob)."""
+        return y_local[:, self.oa - self.off:self.ob - self.off].contiguous()
+
+
+def exchange_volume_slabs(vol_sum, count, plans, group=None, rank=None):
+    """The exchange step in its reduce-scatter form.  vol_sum [B,X,Y,Z,C] fp32 / count [B,X,Y,Z] int32: this rank's partial
+    view sum and view count over the WHOLE volume; plans[r] = StackNeckSlabs of rank r (every rank builds all of them: pure
+    arithmetic).  Every rank sends rank r its partial rows [ea_r, eb_r) and adds up what it receives in rank order (a fixed order:
+    deterministic) -- grouped point-to-point transfers, i.e. an all-to-all over xGMI, which both RCCL and gloo provide.
+    Returns (sum_ext [B, eb-ea, Y, Z, C], count_ext [B, eb-ea, Y, Z]) of this rank's widened slab, totals over all ranks."""
+    on = dist.is_available() and dist.is_initialized()
+    rank, world = _rank_world(rank, len(plans) if not on else None)
+    me = plans[rank]
+    mine_v = vol_sum[:, me.ea:me.eb].contiguous()
+    mine_c = count[:, me.ea:me.eb].contiguous()
+    if not on or world == 1:
+        return mine_v, mine_c
+    send, recv_v, recv_c, ops_ = [], {}, {}, []
+    for r in range(world):
+        if r == rank:
+            continue
+        pr = plans[r]
+        sv, sc = vol_sum[:, pr.ea:pr.eb].contiguous(), count[:, pr.ea:pr.eb].contiguous()
+        send += [sv, sc]                               # keep alive until the transfers complete
+        recv_v[r], recv_c[r] = torch.empty_like(mine_v), torch.empty_like(mine_c)
+        ops_ += [dist.P2POp(dist.isend, sv, r, group), dist.P2POp(dist.isend, sc, r, group),
+                 dist.P2POp(dist.irecv, recv_v[r], r, group), dist.P2POp(dist.irecv, recv_c[r], r, group)]
+    for q in dist.batch_isend_irecv(ops_):
+        q.wait()
+    tot_v, tot_c = None, None
+    for r in range(world):                             # rank order, whoever we are
+        v, c = (mine_v, mine_c) if r == rank else (recv_v[r], recv_c[r])
+        tot_v, tot_c = (v.clone(), c.clone()) if tot_v is None else (tot_v.add_(v), tot_c.add_(c))
+    return tot_v, tot_c
+
+
+def all_gather_rows(y, plans, group=None, rank=None):
+    """Cropped neck outputs [B, ob-oa, Y', 1, C] of every rank -> the whole map [B, X', Y', 1, C] on every rank (slabs differ by at
+    most one row: padded to the longest for the fixed-size all-gather)."""
+    on = dist.is_available() and dist.is_initialized()
+    if not on or len(plans) == 1:
+        return y
+    rows = max(p.ob - p.oa for p in plans)
+    B = y.shape[0]
+    pad = y if y.shape[1] == rows else torch.cat([y, y.new_zeros((B, rows - y.shape[1]) + tuple(y.shape[2:]))], 1)
+    out = torch.empty((len(plans) * B,) + tuple(pad.shape[1:]), dtype=y.dtype, device=y.device)      # concatenation along dim 0 (both backends)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    out = out.view((len(plans), B) + tuple(pad.shape[1:]))
+    return torch.cat([out[r][:, :plans[r].ob - plans[r].oa] for r in range(len(plans))], 1).contiguous()
+
+
+def view_sharded_neck_slabs(model, img, img_metas, group=None, rank=None, world=None):
+    """View-sharded step up to the neck output with the reduce-scatter exchange (stack necks only): -> [B, X', Y', 1, C] on every rank."""
+    from . import ops
+    rank, world = _rank_world(rank, world)
+    X = int(model.n_voxels[0])
+    plans = [StackNeckSlabs(model.neck_3d, X, world, r) for r in range(world)]
+    img_l, metas_l, (v0, v1) = shard_views(img, img_metas, rank, world)
+    if v1 > v0:
+        p0 = model.features_2d_cl(img_l)
+        proj, origin, crop = model._camera_setup(metas_l, 4, p0.device)
+        vol, cnt = ops.backproject_sum(p0, proj, origin, crop, model.voxel_size, model.n_voxels)
+    else:
+        B = img.shape[0]
+        vol = torch.zeros((B,) + tuple(model.n_voxels) + (model.neck.out_channels,), device=img.device, dtype=torch.float32)
+        cnt = torch.zeros((B,) + tuple(model.n_voxels), device=img.device, dtype=torch.int32)
+    sv, sc = exchange_volume_slabs(vol, cnt, plans, group, rank)
+    slab, _ = ops.volume_normalize_(sv, sc)
+    y = plans[rank].crop(model.neck_3d.forward_cl(slab))
+    return all_gather_rows(y, plans, group, rank)

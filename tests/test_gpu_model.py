@@ -471,3 +471,51 @@ def test_fp8_trunk_tracks_bf16(ia, cfg_name, views):
     rel2 = float((p0_2 - ref2).pow(2).mean().sqrt() / ref2.pow(2).mean().sqrt())
     print(f'{cfg_name} fp8 trunk, second batch with the first batch\'s scales: {rel2:.4f} of the signal rms')
     assert rel2 < 0.25
+
+
+@pytest.mark.parametrize('neck_name,nv,world', [('nuscenes', (48, 40, 12), 3), ('kitti', (42, 36, 12), 4)])
+def test_view_sharded_slab_neck_matches_replicated_neck(ia, neck_name, nv, world):
+    """SURVEY 8e's reduce-scatter form of the view-sharded mode on one device (ranks simulated one after the other): every rank
+    normalises and convolves only its x-slab of the volume, widened by the neck's receptive field (dist.StackNeckSlabs), crops its
+    rows, and the concatenated rows equal the neck run on the whole volume -- to the rounding of the Winograd tiles, whose alignment
+    moves with the slab's origin -- and the detections are the same."""
+    from imvoxelnet_amd import dist as ivd, ops
+    from imvoxelnet_amd.workloads import kitti_model_cfg, KITTI_TEST_CFG, nuscenes_model_cfg, NUSCENES_TEST_CFG
+    cfg = nuscenes_model_cfg(n_voxels=nv, dcn=False) if neck_name == 'nuscenes' else kitti_model_cfg(n_voxels=nv)
+    model = ia.build_detector(cfg, test_cfg=dict(NUSCENES_TEST_CFG if neck_name == 'nuscenes' else KITTI_TEST_CFG, score_thr=0.05))
+    ia.randomize_(model, 17)
+    with torch.no_grad():
+        model.bbox_head.conv_cls.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(5))
+        model.bbox_head.conv_cls.bias.fill_(-1.5)
+        model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=torch.Generator().manual_seed(6))
+    model.prepare(torch.device('cuda'))
+    g = torch.Generator().manual_seed(3)
+    C = model.neck.out_channels
+    B = 2
+    # a partial view sum / view count per simulated rank (what ops.backproject_sum leaves), totals as the exchange would deliver them
+    parts = [(torch.randn(B, *nv, C, generator=g).cuda(), torch.randint(0, 3, (B,) + tuple(nv), generator=g, dtype=torch.int32).cuda()) for _ in range(world)]
+    tot_v, tot_c = sum(p[0] for p in parts), sum(p[1] for p in parts)
+    vol, _ = ops.volume_normalize_(tot_v.clone(), tot_c.clone())
+    y_ref = model.neck_3d.forward_cl(vol)
+    plans = [ivd.StackNeckSlabs(model.neck_3d, nv[0], world, r) for r in range(world)]
+    rows = []
+    for r, pl in enumerate(plans):
+        sv, sc = ivd.exchange_volume_slabs(tot_v, tot_c, plans, rank=r)          # no process group: this rank's rows of the totals
+        assert sv.shape[1] == pl.eb - pl.ea
+        slab, _ = ops.volume_normalize_(sv.clone(), sc.clone())
+        rows.append(pl.crop(model.neck_3d.forward_cl(slab)))
+        assert rows[-1].shape[1] == pl.ob - pl.oa
+    y = torch.cat(rows, 1)
+    assert y.shape == y_ref.shape
+    rng = float(y_ref.abs().max())
+    from gpu_util import assert_close
+    assert_close(f'{neck_name} neck: {world} x-slabs vs the whole volume', y, y_ref, 0, 1e-4 * rng)
+    metas = [dict(box_type_3d=ia.LiDARInstance3DBoxes)] * B
+    outs = []
+    for t in (y_ref, y):
+        h = model.bbox_head.forward_cl(t)
+        outs.append(model.bbox_head.get_bboxes_cl(h, t.shape[2], t.shape[1], metas, hw_transposed=True))
+    (b0, s0, l0, c0), (b1, s1, l1, c1) = outs
+    assert torch.equal(c0, c1) and int(c0.sum()) > 10
+    assert_close('scores', s1, s0, 0, 1e-4)
+    assert_close('boxes', b1, b0, 0, 1e-3)

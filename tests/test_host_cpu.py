@@ -520,6 +520,75 @@ def test_view_sharded_exchange_gloo_world2():
     assert np.abs(mean - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('extra,batch,max_num', [(['--config', 'nuscenes', '--batch', '1'], 1, 500), (['--config', 'scannet_v1', '--batch', '2'], 2, 3000),
+                                                 (['--config', 'nuscenes', '--batch', '1', '--shard', 'views'], 1, 500)])
+def test_bench_sharded_configs_launch_n_ranks(extra, batch, max_num):
+    """BASELINE configs 4 / 5 as sharded (`bench.py --config nuscenes --gpus N --batch 1`, `--config scannet_v1 --gpus N --batch 2`):
+    the N-rank launch, the per-config detection all-gather, and -- with --shard views -- the exchange of the view-sharded mode in its
+    reduce-scatter form (x-slabs + halo) checked against the all-reduce form on every rank, under two gloo processes."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+    cmd = [sys.executable, bench, '--gpus', '2', '--backend', 'gloo', '--dry', '--steps', '2', '--warmup', '1'] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['dry'] is True and rec['gathered_ok'] is True
+    assert rec['config']['global_batch'] == 2 * batch and rec['config']['max_num'] == max_num
+    if '--shard' in extra:
+        assert rec['slab_exchange_ok'] is True and 'x-slabs' in rec['config']['slabs']
+    else:
+        assert rec['slab_exchange_ok'] is None
+
+
+def _slab_worker(rank, world, port, out_q):
+    """One rank of the reduce-scatter exchange on CPU (gloo): synthetic partial volumes, the product's exchange functions."""
+    import torch.distributed as dist
+    import imvoxelnet_amd as ia
+    from imvoxelnet_amd import dist as ivd
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    neck = ia.KittiImVoxelNeck(8, 16)
+    X = 40
+    plans = [ivd.StackNeckSlabs(neck, X, world, r) for r in range(world)]
+    g = torch.Generator().manual_seed(rank)
+    part = torch.randn(2, X, 6, 3, 8, generator=g)
+    cnt = torch.randint(0, 4, (2, X, 6, 3), generator=g, dtype=torch.int32)
+    sv, sc = ivd.exchange_volume_slabs(part, cnt, plans)
+    fv, fc = ivd.all_reduce_volume(part.clone(), cnt.clone())
+    me = plans[rank]
+    y = torch.full((2, me.ob - me.oa, 4, 1, 3), float(rank))
+    rows = ivd.all_gather_rows(y, plans)
+    out_q.put((rank, (me.oa, me.ob, me.ea, me.eb), sv.numpy(), sc.numpy(), fv[:, me.ea:me.eb].numpy(), fc[:, me.ea:me.eb].numpy(), rows[0, :, 0, 0, 0].numpy()))
+    dist.destroy_process_group()
+
+
+def test_slab_exchange_equals_all_reduce_gloo_world2():
+    """SURVEY 8e's reduce-scatter over x-slabs (+ the neck's receptive field as halo): after dist.exchange_volume_slabs every rank holds,
+    for its widened slab, exactly what the all-reduce form holds there (two ranks: the sums commute, so bit for bit), and
+    dist.all_gather_rows reassembles the neck rows in rank order."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == (0, 19, 0, 29) and res[1][1] == (19, 38, 11, 40)          # 38 output rows of a 40-row volume: 9 conv layers, 10-row halo
+    for r in range(2):
+        assert np.array_equal(res[r][2], res[r][4]) and np.array_equal(res[r][3], res[r][5])
+        assert np.array_equal(res[r][6], np.array([0.0] * 19 + [1.0] * 19, np.float32))
+
+
 @pytest.mark.parametrize('how', ['bare', 'torchrun'])
 def test_bench_launches_n_ranks(how):
     """`python bench.py --gpus 2` starts two ranks by itself (and runs as given under torch.distributed.run, the driver's
