@@ -42,7 +42,7 @@ class ModelCfg(C.Structure):
                 ('unet_up_layers', C.c_int32 * 3),
                 ('head_type', C.c_int32), ('head_classes', C.c_int32), ('head_nms_pre', C.c_int32), ('head_use_rotate_nms', C.c_int32),
                 ('head_score_thr', C.c_float), ('head_nms_thr', C.c_float), ('dcn_stages', C.c_int32 * 4), ('layout_head', C.c_int32),
-                ('layout_linear_size', C.c_int32), ('wino_operands', C.c_int32), ('trunk_operands', C.c_int32)]
+                ('layout_linear_size', C.c_int32), ('wino_operands', C.c_int32), ('trunk_operands', C.c_int32), ('storage', C.c_int32)]
 
 
 class PairIO(C.Structure):

@@ -67,6 +67,13 @@ inline uint16_t f32_to_f16_bits(float f) {
   if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;   // a carry out of the mantissa bumps the exponent; 65520 and above -> inf
   return (uint16_t)(sign | h);
 }
+inline uint16_t f32_to_bf16_bits(float f) {        // round to nearest even (torch's .to(bfloat16)); NaN stays NaN
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x40u);
+  x += 0x7fffu + ((x >> 16) & 1u);
+  return (uint16_t)(x >> 16);
+}
 inline float f16_bits_to_f32(uint16_t h) {
   const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
   float f;
@@ -107,12 +114,14 @@ struct ConvLayer {
   float *w = nullptr, *w0 = nullptr, *scale = nullptr, *shift = nullptr;
   std::map<int, float *> u;           // tile * 8 + operand type -> transformed filters
   // fp16-pair form (cfg.trunk_operands = IVX_F16_PAIR; ivx_conv_fwd_pio): pair filters, scale / s_w, and the terms of the output bound
+  bool stem_s2d = false;              // bf16 storage: the 7x7 stride-2 stem as a 4x4 stride-1 conv over 2x2 space-to-depth blocks (weights re-indexed at pack time)
+  bool out_f32 = false;               // bf16 storage: this layer writes fp32 (the head convs: the tails decode fp32 scores / deltas)
   bool pair_ok = false;
   float *wpair = nullptr, *scale_p = nullptr;
   float wbound = 0.f, sbound = 0.f;
 };
 
-enum StepKind { ST_IMG2CL, ST_CONV, ST_MAXPOOL, ST_LIFT, ST_TAIL, ST_UPSAMPLE, ST_DCN_COL, ST_AVGPOOL, ST_LAYOUT, ST_FCOS, ST_INDOOR_TAIL };
+enum StepKind { ST_IMG2CL, ST_IMG_S2D, ST_CONV, ST_MAXPOOL, ST_LIFT, ST_TAIL, ST_UPSAMPLE, ST_DCN_COL, ST_AVGPOOL, ST_LAYOUT, ST_FCOS, ST_INDOOR_TAIL };
 
 struct Step {
   StepKind kind;
@@ -129,6 +138,7 @@ struct TInfo {
   int64_t bytes = 0, off = -1;
   int first = -1, last = -1;
   bool raw = false;          // a byte buffer (candidate lists): `bytes` is set explicitly
+  int esz = 4;               // bytes per element: 4, or 2 for a bf16 tensor (cfg.storage = IVX_BF16)
   int fmt = 0;               // 0: fp32; IVX_F16_PAIR: fp16 (hi, lo) pairs with a device-side scale (same bytes)
   int64_t slot = -1;         // arena offset of the tensor's scalar block: IVX_AMAX_SLOTS words of max |tensor|, then its scale; -1: none
   int64_t elems() const { return (int64_t)B * D * H * W * C; }
@@ -240,9 +250,13 @@ ConvLayer conv3d(const std::string &name, int cin, int cout, const int s[3], con
 void build_trunk(ivx_model *m) {
   m->trunk0 = (int)m->steps.size();
   m->t_img = new_tensor(m);
-  Step a; a.kind = ST_IMG2CL; a.in = m->t_img; a.out = new_tensor(m);
+  const bool bf16 = m->cfg.storage == IVX_BF16;
+  Step a; a.kind = bf16 ? ST_IMG_S2D : ST_IMG2CL; a.in = m->t_img; a.out = new_tensor(m);
   m->steps.push_back(a);
-  int x = add_conv(m, conv2d("backbone.conv1", 3, 64, 7, 2, 3, true, "backbone.conv1.weight", "", "backbone.bn1"), a.out);
+  ConvLayer stem = bf16 ? conv2d("backbone.conv1", 16, 64, 4, 1, 1, true, "backbone.conv1.weight", "", "backbone.bn1")
+                        : conv2d("backbone.conv1", 3, 64, 7, 2, 3, true, "backbone.conv1.weight", "", "backbone.bn1");
+  stem.stem_s2d = bf16;
+  int x = add_conv(m, stem, a.out);
   Step mp; mp.kind = ST_MAXPOOL; mp.in = x; mp.out = new_tensor(m);
   m->steps.push_back(mp);
   x = mp.out;
@@ -451,6 +465,7 @@ void build_graph(ivx_model *m) {
       // as ONE conv shared by the levels, then per level the candidate kernel and ONE cross-level tail
       const int R = m->cfg.head_type == IVX_HEAD_SCANNET ? 6 : 7, nc = m->cfg.head_classes, oc = m->cfg.neck_out_channels;
       ConvLayer h = conv3d_k("bbox_head", oc, 1 + R + nc, 3, 1, 1, false, "", "", "");
+      h.out_f32 = true;
       h.w_keys = {"bbox_head.centerness_conv.weight", "bbox_head.reg_conv.weight", "bbox_head.cls_conv.weight"};
       h.b_keys = {"", "", "bbox_head.cls_conv.bias"};
       m->layers.push_back(h);
@@ -476,6 +491,7 @@ void build_graph(ivx_model *m) {
   // Anchor3DHead: conv_cls | conv_reg | conv_dir_cls as one 1x1 conv (anchor3d_head.py:122-130,138-153)
   const int A = m->cfg.n_sizes * m->cfg.n_rotations, oc = m->cfg.neck_out_channels;
   ConvLayer h = conv2d("bbox_head", oc, A * (m->cfg.num_classes + 7 + 2), 1, 1, 0, false, "", "", "");
+  h.out_f32 = true;
   h.w_keys = {"bbox_head.conv_cls.weight", "bbox_head.conv_reg.weight", "bbox_head.conv_dir_cls.weight"};
   h.b_keys = {"bbox_head.conv_cls.bias", "bbox_head.conv_reg.bias", "bbox_head.conv_dir_cls.bias"};
   m->head_step = (int)m->steps.size();
@@ -514,8 +530,9 @@ const HostTensor *find_w(const ivx_model *m, const std::string &key) {
 // Deploy form of one layer: imvoxelnet_amd/conv.py FusedConv.__init__ in C++ (same fp32 operations in the same order).
 int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing) {
   const int kd = L.k[0], kh = L.k[1], kw = L.k[2], taps = kd * kh * kw;
-  L.cin_pad = (L.cin + 3) / 4 * 4;
-  L.layout = (L.cin_pad % 32 == 0) ? 1 : 0;
+  const bool bf16 = m->cfg.storage == IVX_BF16;      // bf16 storage (conv.py FusedConv with dtype bfloat16): 8-channel chunks, 64-channel K chunks
+  L.cin_pad = bf16 ? (L.cin + 7) / 8 * 8 : (L.cin + 3) / 4 * 4;
+  L.layout = (L.cin_pad % (bf16 ? 64 : 32) == 0) ? 1 : 0;
   // staging buffers live in the handle and are reused by every layer (fresh 100 MB vectors per layer cost seconds of first-touch
   // page faults in a sandboxed container); only channel padding needs the zero fill
   std::vector<float> &wp = m->pack_a, &wc = m->pack_b;
@@ -549,6 +566,21 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
       co0 = L.cout;
       continue;
     }
+    if (L.stem_s2d) {   // [64, 3, 7, 7] -> the 4x4 conv over 2x2 space-to-depth blocks (backbones.stem_s2d_weights): channel (a*2+e)*3 + c of
+                        // tap (th, tw) is w[co][c][2*th + a][2*tw + e] (the eighth row / column and channels 12..15 are zero)
+      M_REQUIRE(nd == 4 && w->shape[1] == 3 && w->shape[2] == 7 && w->shape[3] == 7 && (int)w->shape[0] == L.cout,
+                "ivx_weights_finalize: bf16 storage is built for the 3-channel 7x7 stem (%s)", L.w_keys[q].c_str());
+      std::fill(wp.begin(), wp.begin() + n_w, 0.f);
+      for (int co = 0; co < L.cout; ++co)
+        for (int c = 0; c < 3; ++c)
+          for (int r = 0; r < 7; ++r)
+            for (int cc = 0; cc < 7; ++cc) {
+              const int th = r >> 1, a = r & 1, tw = cc >> 1, e = cc & 1;
+              wp[((size_t)co * 16 + th * 4 + tw) * L.cin_pad + (a * 2 + e) * 3 + c] = w->data[(((size_t)co * 3 + c) * 7 + r) * 7 + cc];
+            }
+      co0 = L.cout;
+      continue;
+    }
     M_REQUIRE((L.linear ? nd == 2 : nd == (size_t)(L.dims + 2)) && w->shape[1] == L.cin, "ivx_weights_finalize: %s has the wrong rank / input channels",
               L.w_keys[q].c_str());
     const int co_n = (int)w->shape[0];
@@ -574,18 +606,25 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
   L.wino2d = kd == 1 && kh == 3 && kw == 3 && L.s[0] == 1 && L.s[1] == 1 && L.s[2] == 1;
   const bool wino3d = kd == 3 && kh == 3 && L.s[0] == 1 && L.s[1] == 1;
   const int min_ch = L.wino2d ? 128 : 64;
-  L.wino_cand = (wino3d || L.wino2d) && L.cin_pad == L.cin && L.cout % 4 == 0 && std::max(L.cin, L.cout) >= min_ch && L.cin % 4 == 0;
+  L.wino_cand = !bf16 && (wino3d || L.wino2d) && L.cin_pad == L.cin && L.cout % 4 == 0 && std::max(L.cin, L.cout) >= min_ch && L.cin % 4 == 0;
   if (L.wino_cand) M_TRY(dev_upload_sync(m, wp.data(), n_w, &L.w0, st));   // tap-major [Cout,kd,kh,kw,Cin]; (1,3,3) is the same memory as (3,3,1)
-  if (L.layout == 1) {           // chunk-major K: [Cout, Cin/32, kd,kh,kw, 32]
+  const int ck = bf16 ? 64 : 32;
+  const float *w_src = wp.data();
+  if (L.layout == 1) {           // chunk-major K: [Cout, Cin/32, kd,kh,kw, 32] (bf16: 64-channel chunks)
     if (wc.size() < n_w) wc.resize(n_w);
-    const int nch = L.cin_pad / 32;
+    const int nch = L.cin_pad / ck;
     for (int co = 0; co < L.cout; ++co)
       for (int ch = 0; ch < nch; ++ch)
         for (int t = 0; t < taps; ++t)
-          memcpy(&wc[(((size_t)co * nch + ch) * taps + t) * 32], &wp[((size_t)co * taps + t) * L.cin_pad + ch * 32], 32 * sizeof(float));
-    M_TRY(dev_upload_sync(m, wc.data(), n_w, &L.w, st));
+          memcpy(&wc[(((size_t)co * nch + ch) * taps + t) * ck], &wp[((size_t)co * taps + t) * L.cin_pad + ch * ck], ck * sizeof(float));
+    w_src = wc.data();
+  }
+  if (bf16) {                    // round to nearest even, two values per uploaded word
+    std::vector<uint16_t> wb(n_w + (n_w & 1));
+    for (size_t i = 0; i < n_w; ++i) wb[i] = f32_to_bf16_bits(w_src[i]);
+    M_TRY(dev_upload_sync(m, reinterpret_cast<const float *>(wb.data()), (n_w + 1) / 2, &L.w, st));
   } else {
-    M_TRY(dev_upload_sync(m, wp.data(), n_w, &L.w, st));
+    M_TRY(dev_upload_sync(m, w_src, n_w, &L.w, st));
   }
   const int n_aff = L.conv_t ? L.cout / 8 : L.cout;     // the transposed conv's BN has the REAL channel count (epilogue indexes n % Cr)
   std::vector<float> scale(n_aff, 1.f), shift(bias.begin(), bias.begin() + n_aff);
@@ -607,7 +646,7 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
   // fp16-pair form of the 2-D trunk (cfg.trunk_operands): pair filters + scale / s_w, and the bound terms (also for the layers that
   // stay fp32: the stem's bound scales the max-pool's pair output)
   const bool trunk_layer = L.name.rfind("backbone.", 0) == 0 || L.name.rfind("neck.", 0) == 0;
-  if (m->cfg.trunk_operands == IVX_F16_PAIR && trunk_layer && !L.conv_t && !L.dcn_cols && !L.linear) {
+  if (m->cfg.trunk_operands == IVX_F16_PAIR && !bf16 && trunk_layer && !L.conv_t && !L.dcn_cols && !L.linear) {
     L.pair_ok = L.cin_pad == L.cin && L.cin % 32 == 0 && L.cout % 4 == 0;
     std::vector<uint16_t> packed(L.pair_ok ? 2 * n_w : 0);
     std::vector<float> sp(L.pair_ok ? L.cout : 0);
@@ -676,6 +715,10 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
   d.res_after_act = st.res_after_act;
   d.out_mode = L.conv_t ? 1 : 0;
   M_REQUIRE(in.C == L.cin_pad, "layer %s: input has %d channels, expected %d", L.name.c_str(), in.C, L.cin_pad);
+  if (m->cfg.storage == IVX_BF16) {   // bf16 storage: the direct kernel on bf16 operands, fp32 accumulate; the head convs write fp32
+    d.in_dtype = IVX_BF16;
+    d.out_dtype = L.out_f32 ? IVX_F32 : IVX_BF16;
+  }
   if (in.fmt == IVX_F16_PAIR) {      // the fp16-pair form: direct kernel on the 16-bit matrix cores, scales on the device
     M_REQUIRE(L.pair_ok && L.wpair, "internal: layer %s reads a pair tensor but has no pair filters", L.name.c_str());
     d.in_dtype = IVX_F16_PAIR; d.out_dtype = out_fmt; d.wgt_layout = 1;
@@ -693,7 +736,7 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
   }
   int tile = 0;
   ivx_conv_desc dw = d;
-  if (L.wino_cand && !L.conv_t && m->cfg.winograd && (st.res_mode == 0 || st.res_mode == 1) && (int64_t)in.B * in.D * in.H * in.W >= 2000) {
+  if (L.wino_cand && !L.conv_t && m->cfg.winograd && m->cfg.storage == IVX_F32 && (st.res_mode == 0 || st.res_mode == 1) && (int64_t)in.B * in.D * in.H * in.W >= 2000) {
     if (L.wino2d) {   // [B,1,H,W,C] as [B,H,W,1,C] with a 3x3x1 kernel
       dw.D = in.H; dw.H = in.W; dw.W = 1;
       dw.KD = 3; dw.KH = 3; dw.KW = 1; dw.sd = dw.sh = dw.sw = 1;
@@ -749,7 +792,8 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
   // max-pool after the stem, a convolution that itself reads pairs) and every step that reads it as an INPUT is a trunk convolution
   // with pair filters; residual uses take either format.  Tensors that leave the trunk (FPN level 0, C5 for the LayoutHead, DCNv2
   // columns) therefore stay fp32.  Every tensor of the chain owns a scalar block (amax slots + scale) in the arena.
-  const bool pair_mode = c.trunk_operands == IVX_F16_PAIR && c.with_trunk;
+  const bool pair_mode = c.trunk_operands == IVX_F16_PAIR && c.with_trunk && c.storage == IVX_F32;
+  const int esz = c.storage == IVX_BF16 ? 2 : 4;       // bytes per activation element (head outputs: always 4)
   int n_slots = 0;
   auto wants_pair = [&](int t, const TInfo &ti) {
     if (!pair_mode || ti.C % 16 || ti.elems() * 4 >= (1LL << 31)) return false;
@@ -772,6 +816,10 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       case ST_IMG2CL:
         o = in; o.C = 4; o.fmt = 0; o.slot = -1;
         if (pair_mode) o.slot = n_slots++;                 // max |image| for the bound of the stem's output
+        break;
+      case ST_IMG_S2D:                                     // bf16 storage: [BV, 3, H, W] fp32 -> [BV, 1, H/2+1, W/2+1, 16] bf16 blocks
+        M_REQUIRE(in.H % 2 == 0 && in.W % 2 == 0, "bf16 storage: the image height and width must be even");
+        o = in; o.H = in.H / 2 + 1; o.W = in.W / 2 + 1; o.C = 16;
         break;
       case ST_MAXPOOL: {
         o = in; o.H = (in.H + 2 - 3) / 2 + 1; o.W = (in.W + 2 - 3) / 2 + 1; o.fmt = 0; o.slot = -1;
@@ -861,7 +909,8 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       continue;
     }
     if (s.kind != ST_CONV && s.kind != ST_MAXPOOL && s.kind != ST_IMG2CL) { o.fmt = 0; o.slot = -1; }   // (`o = in` above copies the input's)
-    o.bytes = align256(o.elems() * 4);
+    o.esz = (s.kind == ST_CONV && m->layers[s.layer].out_f32) ? 4 : esz;
+    o.bytes = align256(o.elems() * o.esz);
     o.first = i;
     pl->t[s.out] = o;
   }
@@ -978,8 +1027,8 @@ std::string plan_key(const char *what, int B, int V, int H, int W) {
   return buf;
 }
 
-TInfo tinfo(int B, int D, int H, int W, int C) {
-  TInfo t; t.B = B; t.D = D; t.H = H; t.W = W; t.C = C; t.bytes = align256(t.elems() * 4);
+TInfo tinfo(int B, int D, int H, int W, int C, int esz = 4) {
+  TInfo t; t.B = B; t.D = D; t.H = H; t.W = W; t.C = C; t.esz = esz; t.bytes = align256(t.elems() * esz);
   return t;
 }
 
@@ -1119,7 +1168,14 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         else
           M_TRY(ivx_nchw_to_nhwc((const float *)ptr(s.in), in.B, 3, (int64_t)in.H * in.W, 4, (float *)ptr(s.out), st));
         break;
+      case ST_IMG_S2D:
+        M_TRY(ivx_image_s2d_bf16((const float *)ptr(s.in), in.B, in.H, in.W, ptr(s.out), st));
+        break;
       case ST_MAXPOOL:
+        if (m->cfg.storage == IVX_BF16) {
+          M_TRY(ivx_maxpool2d_fwd_bf16(ptr(s.in), in.B, in.H, in.W, in.C, 3, 2, 1, ptr(s.out), st));
+          break;
+        }
         if (pl.ps[i].pio) {        // fp32 stem output -> pair tensor, scaled by the bound of the stem's output from the image's maximum
           const ConvLayer &Ls = m->layers[pl.ps[i].bound_layer];
           int t_img4 = -1;
@@ -1132,7 +1188,10 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           M_TRY(ivx_maxpool2d_fwd((const float *)ptr(s.in), in.B, in.H, in.W, in.C, 3, 2, 1, (float *)ptr(s.out), st));
         break;
       case ST_UPSAMPLE:
-        M_TRY(ivx_upsample_trilinear2x_fwd((const float *)ptr(s.in), in.B, in.D, in.H, in.W, in.C, (float *)ptr(s.out), st));
+        if (m->cfg.storage == IVX_BF16)
+          M_TRY(ivx_upsample_trilinear2x_fwd_bf16(ptr(s.in), in.B, in.D, in.H, in.W, in.C, ptr(s.out), st));
+        else
+          M_TRY(ivx_upsample_trilinear2x_fwd((const float *)ptr(s.in), in.B, in.D, in.H, in.W, in.C, (float *)ptr(s.out), st));
         break;
       case ST_CONV: {
         const ConvLayer &L = m->layers[s.layer];
@@ -1184,7 +1243,19 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
       case ST_LIFT: {
         M_REQUIRE(bd.proj && bd.new_origin && bd.crop, "%s: proj / new_origin / crop_hw are required", who);
         const TInfo &o = pl.t[s.out];
-        M_TRY(trace_begin(m, i, 4, 1, 0.0, 4.0 * in.elems() + 4.0 * o.elems() + (double)o.elems() / o.C, "unprojection", st));
+        M_TRY(trace_begin(m, i, 4, 1, 0.0, (double)in.esz * in.elems() + (double)o.esz * o.elems() + (double)o.elems() / o.C, "unprojection", st));
+        if (m->cfg.storage == IVX_BF16) {
+          // one view: the lift is a gather-copy (no arithmetic on the features: the reference divides by a count of 1), so a bf16 map
+          // with C channels goes through the fp32 kernel as C / 2 32-bit words; several views: sum and division in fp32 (bf16 kernel)
+          if (bd.V == 1 && in.C % 8 == 0)
+            M_TRY(ivx_backproject_mean_fwd((const float *)ptr(s.in), o.B, 1, in.H, in.W, in.C / 2, bd.proj, bd.new_origin, bd.crop, m->cfg.voxel_size, o.D,
+                                           o.H, o.W, (float *)ptr(s.out), (uint8_t *)ptr(s.out2), st));
+          else
+            M_TRY(ivx_backproject_mean_fwd_bf16(ptr(s.in), o.B, bd.V, in.H, in.W, in.C, bd.proj, bd.new_origin, bd.crop, m->cfg.voxel_size, o.D, o.H, o.W,
+                                                ptr(s.out), (uint8_t *)ptr(s.out2), st));
+          M_TRY(trace_end(m, st));
+          break;
+        }
         M_TRY(ivx_backproject_mean_fwd_amax((const float *)ptr(s.in), o.B, bd.V, in.H, in.W, in.C, bd.proj, bd.new_origin, bd.crop, m->cfg.voxel_size,
                                             o.D, o.H, o.W, (float *)ptr(s.out), (uint8_t *)ptr(s.out2),
                                             pl.ps[i].amax_out >= 0 ? (float *)(base + pl.ps[i].amax_out) : nullptr, st));
@@ -1293,6 +1364,12 @@ extern "C" int ivx_create(const ivx_model_cfg *cfg, ivx_model **out) {
   M_REQUIRE(indoor || (cfg->nms_pre > 0 && cfg->max_num > 0), "ivx_create: nms_pre and max_num must be positive");
   M_REQUIRE(cfg->wino_operands == IVX_F32 || cfg->wino_operands == IVX_F16_PAIR, "ivx_create: wino_operands IVX_F32 | IVX_F16_PAIR");
   M_REQUIRE(cfg->trunk_operands == IVX_F32 || cfg->trunk_operands == IVX_F16_PAIR, "ivx_create: trunk_operands IVX_F32 | IVX_F16_PAIR");
+  M_REQUIRE(cfg->storage == IVX_F32 || cfg->storage == IVX_BF16, "ivx_create: storage IVX_F32 | IVX_BF16");
+  if (cfg->storage == IVX_BF16) {
+    M_REQUIRE(!cfg->layout_head && !cfg->dcn_stages[0] && !cfg->dcn_stages[1] && !cfg->dcn_stages[2] && !cfg->dcn_stages[3],
+              "ivx_create: bf16 storage is not built for the DCNv2 stages / the LayoutHead");
+    M_REQUIRE(cfg->fpn_channels % 8 == 0 && cfg->neck_out_channels % 8 == 0, "ivx_create: bf16 storage needs channel counts that are multiples of 8");
+  }
   M_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 2 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "ivx_create: winograd_tile 0 | 2 | 4 | 6");
   M_REQUIRE(cfg->head_type >= IVX_HEAD_NONE && cfg->head_type <= IVX_HEAD_SUNRGBD, "ivx_create: head_type 0 (none) | IVX_HEAD_SCANNET | IVX_HEAD_SUNRGBD");
   if (cfg->head_type != IVX_HEAD_NONE) {
@@ -1394,7 +1471,7 @@ static int plan_forward(ivx_model *m, int B, int V, int H, int W, Plan **pl, Ran
     in[m->t_img] = tinfo(B * V, 1, H, W, 3);
     *r = {m->trunk0, end};
   } else {
-    in[m->t_fpn0] = tinfo(B * V, 1, H / 4, W / 4, m->cfg.fpn_channels);
+    in[m->t_fpn0] = tinfo(B * V, 1, H / 4, W / 4, m->cfg.fpn_channels, m->cfg.storage == IVX_BF16 ? 2 : 4);
     *r = {m->lift_step, end};
   }
   return get_plan(m, whole ? "detect" : "forward", *r, B, V, H, W, in, pl, st);
@@ -1455,7 +1532,7 @@ extern "C" int ivx_backbone_fpn_fwd(ivx_model *m, const float *img, int32_t BV, 
 // ---- 3-D neck alone
 static int plan_neck(ivx_model *m, int B, Plan **pl, hipStream_t st) {
   std::map<int, TInfo> in;
-  in[m->t_volume] = tinfo(B, m->cfg.n_voxels[0], m->cfg.n_voxels[1], m->cfg.n_voxels[2], m->cfg.fpn_channels);
+  in[m->t_volume] = tinfo(B, m->cfg.n_voxels[0], m->cfg.n_voxels[1], m->cfg.n_voxels[2], m->cfg.fpn_channels, m->cfg.storage == IVX_BF16 ? 2 : 4);
   return get_plan(m, "neck", {m->neck0, m->neck1}, B, 1, 0, 0, in, pl, st);
 }
 

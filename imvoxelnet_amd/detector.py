@@ -84,7 +84,10 @@ class ImVoxelNet(nn.Module):
         if self._native is not None:
             self._native.close()
         self._native = None
-        if native and dtype == torch.float32 and engine.eligible(self):
+        # fp32, or the bf16 storage mode (ivx_model_cfg.storage; not with DCNv2 stages / a LayoutHead, which are fp32-only everywhere)
+        bf16_ok = dtype == torch.bfloat16 and self.head_2d is None and not any(
+            getattr(blk, 'dcn', False) for i in range(4) for blk in getattr(self.backbone, f'layer{i + 1}', []))
+        if native and (dtype == torch.float32 or bf16_ok) and engine.eligible(self):
             self._native = engine.NativeModel(self, device)
         return self
 
@@ -125,6 +128,9 @@ class ImVoxelNet(nn.Module):
         finally:
             FusedConv.calib, FusedConv.calib_margin = None, 1.0
         self.trunk_fp8 = 'fp8' if residual == 'fp8' else 'fp8-branches'
+        if self._native is not None:                  # the native handle holds the bf16 trunk: the e4m3 trunk runs layer by layer
+            self._native.close()
+            self._native = None
         return calib
 
     # ------------------------------------------------------------------ host-side camera set-up
@@ -224,6 +230,12 @@ class ImVoxelNet(nn.Module):
             self.prepare(img.device)                             # first call: pack the weights (and build the native handle)
         H, W = img.shape[-2:]
         native_ok = self._native is not None and H % 32 == 0 and W % 32 == 0 and img.dtype == torch.float32
+        if self._native is not None and not native_ok and not getattr(self, '_warned_off_native', False):
+            import warnings                              # said once: same results, another (slower) path
+            self._warned_off_native = True
+            warnings.warn(f'simple_test: input {tuple(img.shape)} {img.dtype} does not go through the native model handle (it takes float32 images whose '
+                          'padded height and width are multiples of 32, Pad(size_divisor=32)); running the layer-by-layer composition instead',
+                          RuntimeWarning, stacklevel=2)
         if native_ok and self._native.family == 'indoor':
             # the whole of simple_test in ONE native call (ivx_model_detect): trunk [+ LayoutHead -> predicted angles -> projection]
             # -> unprojection -> neck_3d -> anchor-free head -> per-level candidates -> cross-level NMS; camera set-up inside the library

@@ -123,6 +123,7 @@ def model_cfg(model, with_trunk=True, winograd=None, winograd_tile=None):
     cfg.winograd_tile = int(FusedConv.winograd_tile if winograd_tile is None else winograd_tile)
     cfg.wino_operands = int(FusedConv.wino_operands)
     cfg.trunk_operands = int(FusedConv.trunk_operands) if with_trunk else 0
+    cfg.storage = 1 if getattr(model, 'storage_dtype', None) == torch.bfloat16 else 0       # IVX_BF16: the optional reduced-precision mode
     return cfg
 
 
@@ -137,6 +138,7 @@ class NativeModel:
         head = model.bbox_head
         g = getattr(head, 'anchor_generator', None)
         self.cfg = cfg
+        self.act_dtype = torch.bfloat16 if cfg.storage == 1 else torch.float32      # type of the sub-path tensors (fpn0, volume, levels)
         self.max_num, self.n_voxels = cfg.max_num, tuple(model.n_voxels)
         self.has_head = self.family == 'anchor' or cfg.head_type != 0          # ivx_model_detect runs the whole simple_test
         self.layout = bool(cfg.layout_head)
@@ -264,7 +266,7 @@ class NativeModel:
         return res + ((ang, lay),) if self.layout else res
 
     def _level_buffers(self, B, dev):
-        outs = [torch.empty((B, X, Y, Z, Cn), device=dev, dtype=torch.float32) for X, Y, Z, Cn in self.level_dims]
+        outs = [torch.empty((B, X, Y, Z, Cn), device=dev, dtype=self.act_dtype) for X, Y, Z, Cn in self.level_dims]
         return outs, (C.c_void_p * 3)(*([o.data_ptr() for o in outs] + [None] * (3 - len(outs))))
 
     def forward_levels(self, x, B, V, H, W, proj, new_origin, crop_hw):
@@ -305,7 +307,7 @@ class NativeModel:
         if n < 0:
             check(-1, 'ivx_backbone_fpn_workspace_bytes')
         ws = self._workspace('trunk', n)
-        out = torch.empty((BV, 1, H // 4, W // 4, self.cfg.fpn_channels), device=img.device, dtype=torch.float32)
+        out = torch.empty((BV, 1, H // 4, W // 4, self.cfg.fpn_channels), device=img.device, dtype=self.act_dtype)
         check(self.L.ivx_backbone_fpn_fwd(self.h, C.c_void_p(img.data_ptr()), BV, H, W, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
                                           ws.numel(), _stream()), 'ivx_backbone_fpn_fwd')
         return out
@@ -317,7 +319,7 @@ class NativeModel:
         if n < 0:
             check(-1, 'ivx_neck3d_workspace_bytes')
         ws = self._workspace('neck', n)
-        out = torch.empty((B, self.grid_hw[1], self.grid_hw[0], 1, self.cfg.neck_out_channels), device=volume.device, dtype=torch.float32)
+        out = torch.empty((B, self.grid_hw[1], self.grid_hw[0], 1, self.cfg.neck_out_channels), device=volume.device, dtype=self.act_dtype)
         fn = self.L.ivx_neck3d_kitti_fwd if self.cfg.neck_type == 0 else self.L.ivx_neck3d_nuscenes_fwd
         check(fn(self.h, C.c_void_p(volume.data_ptr()), B, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
               'ivx_neck3d_fwd')

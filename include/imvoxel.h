@@ -562,6 +562,13 @@ typedef struct ivx_model_cfg {
                                       multiply-add, fp32 accumulate, device-side power-of-two scales, no conversion passes) wherever a tensor's
                                       consumers are all convolutions with Cin % 32 == 0; the stem, DCNv2 columns, the LayoutHead and what
                                       leaves the trunk (FPN level 0, C5) stay fp32 */
+  int32_t storage;                 /* (0.4.0) IVX_F32 (0, the reference's precision and the one every parity claim is made for) or IVX_BF16: the
+                                      optional reduced-precision mode inside the handle (BASELINE config 5 names it) -- activations and weights
+                                      stored as bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulation and epilogues, the 7x7 stem as a 4x4 convolution
+                                      over 2x2 space-to-depth blocks of the image), head outputs and the detection tails fp32.  The image input and
+                                      the detection outputs keep their types; the tensors of the sub-path entry points (ivx_backbone_fpn_fwd's
+                                      fpn0, ivx_neck3d_*_fwd's volume / levels, ivx_model_forward_levels' levels) are bf16.  Not with DCNv2 stages
+                                      or a LayoutHead; the Winograd and pair forms are fp32-storage forms and are not used */
 } ivx_model_cfg;
 
 int ivx_create(const ivx_model_cfg *cfg, ivx_model **out);

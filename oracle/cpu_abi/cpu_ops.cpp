@@ -297,6 +297,23 @@ extern "C" int ivx_conv_winograd_input_amax(const ivx_conv_desc *, int32_t, cons
 extern "C" int ivx_conv_winograd_fwd(const ivx_conv_desc *, int32_t, const void *, const float *, const float *, const float *, const void *,
                                      void *, void *, int64_t, ivx_stream_t) { return no_wino("ivx_conv_winograd_fwd"); }
 
+// bf16 storage (ivx_model_cfg.storage = IVX_BF16) is a device-side mode: the CPU restatement is fp32 only
+static int no_bf16(const char *who) {
+  ivx_set_error("%s: the CPU restatement has no bf16 storage mode", who);
+  return IVX_ERR_UNSUPPORTED;
+}
+extern "C" int ivx_image_s2d_bf16(const float *, int32_t, int32_t, int32_t, void *, ivx_stream_t) { return no_bf16("ivx_image_s2d_bf16"); }
+extern "C" int ivx_maxpool2d_fwd_bf16(const void *, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, void *, ivx_stream_t) {
+  return no_bf16("ivx_maxpool2d_fwd_bf16");
+}
+extern "C" int ivx_upsample_trilinear2x_fwd_bf16(const void *, int32_t, int32_t, int32_t, int32_t, int32_t, void *, ivx_stream_t) {
+  return no_bf16("ivx_upsample_trilinear2x_fwd_bf16");
+}
+extern "C" int ivx_backproject_mean_fwd_bf16(const void *, int32_t, int32_t, int32_t, int32_t, int32_t, const float *, const float *, const int32_t *,
+                                             const float *, int32_t, int32_t, int32_t, void *, uint8_t *, ivx_stream_t) {
+  return no_bf16("ivx_backproject_mean_fwd_bf16");
+}
+
 // ---------------------------------------------------------------------------------------------- pool / layout (csrc/pool_layout.hip)
 extern "C" int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p, float *out,
                                  ivx_stream_t) {

@@ -455,3 +455,57 @@ def test_bench_rccl_path_at_world_size_1(ia):
     # default operands: fp16 pairs priced against the 16-bit MFMA peak (every product counted); in fp32 multiply-adds the GEMMs must beat
     # what the fp32 MFMA form could ever reach
     assert rec['roofline']['frac'] > 0.2 and rec['roofline']['fp32_equivalent_tflops'] > 160 and rec['measured_ceilings']['hbm_copy_gbps'] > 3000
+
+
+@pytest.mark.parametrize('cfg_name,views', [('scannet_v1', 6), ('scannet_fast', 4), ('sunrgbd_fast', 1), ('kitti', 1)])
+def test_native_bf16_storage_equals_layerwise(ia, cfg_name, views):
+    """The optional reduced-precision mode BASELINE config 5 names, INSIDE the model-level C-ABI (ivx_model_cfg.storage = IVX_BF16):
+    simple_test through one native call (bf16 activations and weights, the s2d stem, bf16 unprojection / trilinear steps, fp32 head
+    outputs and tails) against the layer-by-layer bf16 composition over the op-level ABI -- the same kernels with the same plans:
+    identical detections bit for bit."""
+    if cfg_name == 'kitti':
+        mcfg, tcfg = kc.kitti_model_cfg(n_voxels=(104, 120, 12)), dict(kc.KITTI_TEST_CFG)
+        hw, metas = (192, 640), [kc.kitti_meta(img_hw=(192, 640), box_type=ia.LiDARInstance3DBoxes) for _ in range(2)]
+        B = 2
+    else:
+        mcfg, tcfg = getattr(kc, f'{cfg_name}_model_cfg')(), dict(getattr(kc, f'{cfg_name.upper()}_TEST_CFG'))
+        hw = (480, 640)
+        metas = [kc.indoor_meta(views, img_hw=hw, origin=(0, 3, -1) if cfg_name == 'sunrgbd_fast' else (0, 0, .5), box_type=ia.DepthInstance3DBoxes)]
+        B = 1
+    model = ia.build_detector(mcfg, test_cfg=tcfg)
+    ia.randomize_(model, 41)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        if cfg_name == 'kitti':
+            model.bbox_head.conv_cls.weight.normal_(0, 0.05, generator=g)
+            model.bbox_head.conv_cls.bias.fill_(-1.0)
+            model.bbox_head.conv_reg.weight.normal_(0, 0.002, generator=g)
+        else:
+            model.bbox_head.cls_conv.weight.normal_(0, 0.01, generator=g)
+            model.bbox_head.cls_conv.bias.fill_(-2.0)
+            model.bbox_head.centerness_conv.weight.normal_(0, 0.005, generator=g)
+            model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
+    img = torch.randn(B, views, 3, *hw, generator=torch.Generator().manual_seed(9)).cuda()
+    model.prepare(torch.device('cuda'), dtype=torch.bfloat16, native=False)
+    ref = model.simple_test(img, metas)
+    model.prepare(torch.device('cuda'), dtype=torch.bfloat16)
+    assert model._native is not None and model._native.cfg.storage == 1
+    res = model.simple_test(img, metas)
+    assert len(res) == len(ref) == B and sum(len(r['scores_3d']) for r in ref) > 5
+    for a, b in zip(res, ref):
+        assert torch.equal(a['scores_3d'], b['scores_3d']) and torch.equal(a['labels_3d'], b['labels_3d'])
+        assert torch.equal(a['boxes_3d'].tensor, b['boxes_3d'].tensor)
+    print(cfg_name, 'bf16 storage: detections', [len(r['scores_3d']) for r in res])
+
+
+def test_c_program_e2e_indoor_bf16_storage_without_python(ia):
+    """The third C host run (verdict round 3, item 6): tests/c/e2e_indoor.c with `bf16` -- ivx_model_cfg.storage = IVX_BF16 -- on the
+    reference's indoor end-to-end goldens: valid masks identical, at least 80 % of the fp32 reference's detections found."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'c'))
+    import build as cbuild
+    exe = cbuild.build('e2e_indoor')
+    fx = os.path.join(ROOT, 'tests', 'golden', 'e2e_indoor.bin')
+    out = subprocess.run([exe, fx, 'bf16'], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'C e2e_indoor OK (bf16 storage)' in out.stdout
