@@ -116,6 +116,13 @@ struct ConvLayer {
   // fp16-pair form (cfg.trunk_operands = IVX_F16_PAIR; ivx_conv_fwd_pio): pair filters, scale / s_w, and the terms of the output bound
   bool stem_s2d = false;              // bf16 storage: the 7x7 stride-2 stem as a 4x4 stride-1 conv over 2x2 space-to-depth blocks (weights re-indexed at pack time)
   bool out_f32 = false;               // bf16 storage: this layer writes fp32 (the head convs: the tails decode fp32 scores / deltas)
+  // e4m3 interior of the bottlenecks (ivx_model_calibrate_fp8 on a bf16 handle): 1 conv1 (bf16 in, e4m3 out), 2 conv2 (e4m3 in / filters /
+  // out), 3 conv3 (e4m3 in / filters, bf16 out + bf16 shortcut); 0: not part of it
+  int fp8_role = 0;
+  std::vector<float> w_tap, scale_h, shift_h;   // roles 2 / 3: the fp32 filters (tap-major) kept for the quantisation; the epilogue vectors of every role
+  float *wq = nullptr, *scale_q = nullptr, *shift_q = nullptr;
+  int layout_q = 0;
+  double out_scale_q = 1.0;
   bool pair_ok = false;
   float *wpair = nullptr, *scale_p = nullptr;
   float wbound = 0.f, sbound = 0.f;
@@ -198,6 +205,8 @@ struct ivx_model {
   std::map<std::string, std::unique_ptr<Plan>> plans;
   std::vector<void *> owned;           // device allocations (weights, filters, anchors)
   std::vector<float> pack_a, pack_b;   // host staging of ivx_weights_finalize (released there)
+  bool fp8_on = false;                 // the bottleneck interiors are e4m3 (ivx_model_calibrate_fp8)
+  float *calib_dev = nullptr;          // during the calibration pass: one max |output| per layer (device)
   // optional stage timing (ivx_model_trace): one record per launch group, events recorded on the caller's stream
   bool trace_on = false;
   int trace_level = 2;                 // 2: every launch group; 1: the 3-D neck stages, the unprojection and the tail individually,
@@ -270,7 +279,9 @@ void build_trunk(ivx_model *m) {
       int idt = x;
       if (j == 0)
         idt = add_conv(m, conv2d(pre + "downsample", cin, planes * 4, 1, stride, 0, false, pre + "downsample.0.weight", "", pre + "downsample.1"), x);
-      int y = add_conv(m, conv2d(pre + "conv1", cin, planes, 1, 1, 0, true, pre + "conv1.weight", "", pre + "bn1"), x);
+      ConvLayer c1 = conv2d(pre + "conv1", cin, planes, 1, 1, 0, true, pre + "conv1.weight", "", pre + "bn1");
+      c1.fp8_role = (bf16 && !m->cfg.dcn_stages[i]) ? 1 : 0;
+      int y = add_conv(m, c1, x);
       if (m->cfg.dcn_stages[i]) {
         // ModulatedDeformConv2dPack (mmcv; configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14): conv_offset (3x3, bias) -> 27 raw channels,
         // ivx_dcn_im2col_fwd builds the modulated, bilinearly sampled columns, the main conv is a 1x1 over K = 9 * C
@@ -282,9 +293,13 @@ void build_trunk(ivx_model *m) {
         c2.dcn_cols = true;
         y = add_conv(m, c2, dc.out);
       } else {
-        y = add_conv(m, conv2d(pre + "conv2", planes, planes, 3, stride, 1, true, pre + "conv2.weight", "", pre + "bn2"), y);
+        ConvLayer c2 = conv2d(pre + "conv2", planes, planes, 3, stride, 1, true, pre + "conv2.weight", "", pre + "bn2");
+        c2.fp8_role = bf16 ? 2 : 0;
+        y = add_conv(m, c2, y);
       }
-      x = add_conv(m, conv2d(pre + "conv3", planes, planes * 4, 1, 1, 0, true, pre + "conv3.weight", "", pre + "bn3"), y, idt, 1);
+      ConvLayer c3 = conv2d(pre + "conv3", planes, planes * 4, 1, 1, 0, true, pre + "conv3.weight", "", pre + "bn3");
+      c3.fp8_role = (bf16 && !m->cfg.dcn_stages[i]) ? 3 : 0;
+      x = add_conv(m, c3, y, idt, 1);
       cin = planes * 4;
     }
     feats[i] = x;
@@ -638,6 +653,11 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
     M_TRY(ivx_fold_batchnorm(g->data.data(), b->data.data(), mu->data.data(), var->data.data(), bias_in.data(), 1e-5f, n_aff, scale.data(),
                              shift.data()));
   }
+  if (L.fp8_role) {                  // kept for ivx_model_calibrate_fp8
+    if (L.fp8_role >= 2) L.w_tap.assign(wp.begin(), wp.begin() + n_w);
+    L.scale_h = scale;
+    L.shift_h = shift;
+  }
   L.identity_epilogue = !has_bias && L.bn.empty();
   if (!L.identity_epilogue) {
     M_TRY(dev_upload(m, scale, &L.scale, st));
@@ -718,6 +738,12 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
   if (m->cfg.storage == IVX_BF16) {   // bf16 storage: the direct kernel on bf16 operands, fp32 accumulate; the head convs write fp32
     d.in_dtype = IVX_BF16;
     d.out_dtype = L.out_f32 ? IVX_F32 : IVX_BF16;
+    if (m->fp8_on && L.fp8_role) {    // e4m3 interior of a bottleneck: tensor scales are folded into scale_q / shift_q
+      d.in_dtype = L.fp8_role == 1 ? IVX_BF16 : IVX_FP8;
+      d.out_dtype = L.fp8_role == 3 ? IVX_BF16 : IVX_FP8;
+      if (L.fp8_role >= 2) d.wgt_layout = L.layout_q;
+      d.res_scale = 1.0f;
+    }
   }
   if (in.fmt == IVX_F16_PAIR) {      // the fp16-pair form: direct kernel on the 16-bit matrix cores, scales on the device
     M_REQUIRE(L.pair_ok && L.wpair, "internal: layer %s reads a pair tensor but has no pair filters", L.name.c_str());
@@ -910,6 +936,7 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
     }
     if (s.kind != ST_CONV && s.kind != ST_MAXPOOL && s.kind != ST_IMG2CL) { o.fmt = 0; o.slot = -1; }   // (`o = in` above copies the input's)
     o.esz = (s.kind == ST_CONV && m->layers[s.layer].out_f32) ? 4 : esz;
+    if (s.kind == ST_CONV && m->fp8_on && (m->layers[s.layer].fp8_role == 1 || m->layers[s.layer].fp8_role == 2)) o.esz = 1;
     o.bytes = align256(o.elems() * o.esz);
     o.first = i;
     pl->t[s.out] = o;
@@ -1235,8 +1262,13 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           M_TRY(ivx_conv_winograd_gemm(&ps.d, ps.tile, L.u.at(ps.tile * 8 + ps.d.wino_operands), ws, pl.ws_bytes, st));
           M_TRY(ivx_conv_winograd_output_amax(&ps.d, ps.tile, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes,
                                               ps.amax_out >= 0 ? (float *)(base + ps.amax_out) : nullptr, st));
-        } else
+        } else if (m->fp8_on && L.fp8_role) {
+          M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.fp8_role >= 2 ? L.wq : L.w, L.scale_q, L.shift_q, res, ptr(s.out), ws, pl.ws_bytes, st));
+        } else {
           M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.w, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
+          if (m->calib_dev && (L.fp8_role == 1 || L.fp8_role == 2))       // calibration pass: max |output| of the tensors that will be e4m3
+            M_TRY(ivx_amax_bf16(ptr(s.out), o.elems(), m->calib_dev + s.layer, st));
+        }
         M_TRY(trace_end(m, st));
         break;
       }
@@ -1527,6 +1559,95 @@ extern "C" int ivx_backbone_fpn_fwd(ivx_model *m, const float *img, int32_t BV, 
   bd.ext[m->t_img] = (void *)img;
   bd.ext[m->t_fpn0] = fpn0;
   return run_steps(m, *pl, {m->trunk0, m->trunk1}, bd, workspace, workspace_bytes, (hipStream_t)stream, "ivx_backbone_fpn_fwd");
+}
+
+// ---- e4m3 interior of the bottlenecks ("bf16 with fp8 2-D conv MFMA", BASELINE config 5) on a bf16 handle
+namespace {
+// fp32 -> OCP e4m3 (bias 7, 3 mantissa bits, max 448, no infinities), round to nearest even; |x| <= 448 by construction here
+inline uint8_t f32_to_e4m3_bits(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint8_t sign = (uint8_t)((x >> 24) & 0x80u);
+  float a = fabsf(f);
+  if (!(a == a)) return (uint8_t)(sign | 0x7fu);
+  if (a > 448.f) a = 448.f;
+  if (a < 0.015625f) return (uint8_t)(sign | (uint8_t)lrintf(a * 512.0f));       // below 2^-6: units of 2^-9 (8 = the smallest normal)
+  int e;
+  const float mant = frexpf(a, &e) * 2.0f;                                         // a = mant * 2^(e-1), mant in [1, 2)
+  int q = (int)lrintf((mant - 1.0f) * 8.0f), ex = e - 1;
+  if (q == 8) { q = 0; ++ex; }
+  return (uint8_t)(sign | (uint8_t)(((ex + 7) << 3) | q));
+}
+}  // namespace
+
+extern "C" int ivx_model_calibrate_fp8(ivx_model *m, const float *img, int32_t BV, int32_t H, int32_t W, float margin, void *workspace,
+                                       int64_t workspace_bytes, ivx_stream_t stream) {
+  M_TRY(check_img(m, BV, 1, H, W, "ivx_model_calibrate_fp8"));
+  M_REQUIRE(img && margin > 0.f, "ivx_model_calibrate_fp8: bad argument");
+  M_REQUIRE(m->cfg.storage == IVX_BF16 && m->cfg.with_trunk, "ivx_model_calibrate_fp8: needs a handle with storage = IVX_BF16 and the 2-D trunk");
+  hipStream_t st = (hipStream_t)stream;
+  m->fp8_on = false;                         // a second calibration starts from the bf16 trunk again
+  m->plans.clear();
+  Plan *pl;
+  M_TRY(plan_trunk(m, BV, H, W, &pl, st));
+  const size_t nl = m->layers.size();
+  void *cd = nullptr;
+  M_HIP(hipMalloc(&cd, nl * sizeof(float)), "hipMalloc (calibration maxima)");
+  M_HIP(hipMemsetAsync(cd, 0, nl * sizeof(float), st), "hipMemsetAsync");
+  Bind bd;
+  bd.ext[m->t_img] = (void *)img;
+  m->calib_dev = (float *)cd;
+  const int rc = run_steps(m, *pl, {m->trunk0, m->trunk1}, bd, workspace, workspace_bytes, st, "ivx_model_calibrate_fp8");
+  m->calib_dev = nullptr;
+  std::vector<float> amax(nl, 0.f);
+  hipError_t e1 = hipMemcpyAsync(amax.data(), cd, nl * sizeof(float), hipMemcpyDeviceToHost, st), e2 = hipStreamSynchronize(st);
+  (void)hipFree(cd);
+  if (rc != IVX_OK) return rc;
+  M_HIP(e1, "hipMemcpyAsync (calibration maxima)");
+  M_HIP(e2, "hipStreamSynchronize");
+  // scales and e4m3 filters (conv.py FusedConv with dtype / out_dtype FP8, in the same fp32 operation order)
+  double s_prev = 1.0;                       // scale of the e4m3 tensor the next layer of the block reads
+  for (size_t li = 0; li < nl; ++li) {
+    ConvLayer &L = m->layers[li];
+    if (!L.fp8_role) continue;
+    const double s_in = L.fp8_role == 1 ? 1.0 : s_prev;
+    const double s_out = L.fp8_role == 3 ? 1.0 : std::max((double)amax[li], 1e-12) * (double)margin / 448.0;
+    L.out_scale_q = s_out;
+    const int taps = L.k[0] * L.k[1] * L.k[2];
+    std::vector<float> ws_(L.cout, 1.0f);
+    if (L.fp8_role >= 2) {
+      M_REQUIRE(L.cin_pad % 16 == 0 && !L.w_tap.empty(), "ivx_model_calibrate_fp8: layer %s: e4m3 filters need Cin %% 16 == 0", L.name.c_str());
+      const size_t per = (size_t)taps * L.cin_pad, n_w = per * L.cout;
+      L.layout_q = L.cin_pad % 128 == 0 ? 1 : 0;
+      std::vector<uint8_t> q(n_w + 3, 0);
+      const int nch = L.cin_pad / 128;
+      for (int co = 0; co < L.cout; ++co) {
+        const float *src = L.w_tap.data() + (size_t)co * per;
+        float mx = 0.f;
+        for (size_t k = 0; k < per; ++k) mx = std::max(mx, fabsf(src[k]));
+        ws_[co] = std::max(mx, 1e-12f) / 448.0f;                                       // one scale per output channel: max |w| -> 448
+        for (int t = 0; t < taps; ++t)
+          for (int c = 0; c < L.cin_pad; ++c) {
+            const size_t dst = L.layout_q ? (((size_t)co * nch + c / 128) * taps + t) * 128 + (c % 128) : ((size_t)co * taps + t) * L.cin_pad + c;
+            q[dst] = f32_to_e4m3_bits(src[(size_t)t * L.cin_pad + c] / ws_[co]);
+          }
+      }
+      M_TRY(dev_upload_sync(m, reinterpret_cast<const float *>(q.data()), (n_w + 3) / 4, &L.wq, st));
+    }
+    const float r = (float)(s_in / s_out);
+    const float so = (float)s_out;
+    std::vector<float> sc(L.cout), sf(L.cout);
+    for (int co = 0; co < L.cout; ++co) {
+      sc[co] = (L.scale_h[co] * ws_[co]) * r;                                          // bn_scale * s_w[co] * (s_in / s_out)
+      sf[co] = L.shift_h[co] / so;                                                     // bn_shift / s_out
+    }
+    M_TRY(dev_upload_sync(m, sc.data(), sc.size(), &L.scale_q, st));
+    M_TRY(dev_upload_sync(m, sf.data(), sf.size(), &L.shift_q, st));
+    s_prev = s_out;
+  }
+  m->fp8_on = true;
+  m->plans.clear();                           // element sizes and dtypes changed
+  return IVX_OK;
 }
 
 // ---- 3-D neck alone

@@ -492,3 +492,24 @@ extern "C" int ivx_f16_pair_merge(const void *in, int64_t n, const float *scale_
   IVX_CHECK_LAUNCH("ivx_f16_pair_merge");
   return IVX_OK;
 }
+
+
+// max |x| over a bf16 tensor into *out (atomic max on the bits of a non-negative float; the caller zeroes it): the calibration pass of the
+// e4m3 trunk (ivx_model_calibrate_fp8) records the maximum of every tensor it is going to store as e4m3.
+__global__ __launch_bounds__(256) void amax_bf16_kernel(const __bf16 *x, size_t n, unsigned *out) {
+  float m = 0.f;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf((float)x[t]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+extern "C" int ivx_amax_bf16(const void *x, int64_t n, float *out, ivx_stream_t stream) {
+  IVX_REQUIRE(x && out && n >= 0, "ivx_amax_bf16: bad argument");
+  if (n == 0) return IVX_OK;
+  size_t blocks = ((size_t)n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(amax_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x, (size_t)n, (unsigned *)out);
+  IVX_CHECK_LAUNCH("ivx_amax_bf16");
+  return IVX_OK;
+}

@@ -128,9 +128,12 @@ class ImVoxelNet(nn.Module):
         finally:
             FusedConv.calib, FusedConv.calib_margin = None, 1.0
         self.trunk_fp8 = 'fp8' if residual == 'fp8' else 'fp8-branches'
-        if self._native is not None:                  # the native handle holds the bf16 trunk: the e4m3 trunk runs layer by layer
-            self._native.close()
-            self._native = None
+        if self._native is not None:
+            if residual == 'bf16' and stages is None and self._native.cfg.with_trunk:
+                self._native.calibrate_fp8(x, margin)     # the same mode inside the native handle (its own calibration pass: same maxima)
+            else:                                         # forms the handle does not hold: the e4m3 trunk runs layer by layer
+                self._native.close()
+                self._native = None
         return calib
 
     # ------------------------------------------------------------------ host-side camera set-up

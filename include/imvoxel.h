@@ -633,6 +633,18 @@ int32_t ivx_model_max_detections(ivx_model *m, int32_t B, int32_t V, int32_t H, 
 int ivx_model_detect(ivx_model *m, const float *img, int32_t B, int32_t V, int32_t H, int32_t W, const ivx_sample_meta *metas /*host [B]*/,
                      void *workspace, int64_t workspace_bytes, float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_count,
                      uint8_t *out_valid, float *out_angles /*host*/, float *out_layout /*host*/, ivx_stream_t stream);
+/* BASELINE config 5's named mode inside the handle: "bf16 with fp8 2-D conv MFMA".  On a handle with storage = IVX_BF16 and the trunk
+ * (no DCNv2 stages): runs ONE bf16 pass of ResNet-50 + FPN over the given images (img [BV,3,H,W] fp32; synchronises the stream once),
+ * records max |output| of conv1 and conv2 of every bottleneck, and from then on stores the INSIDE of every bottleneck as OCP e4m3:
+ * conv1 reads the bf16 residual stream and writes e4m3 (per-tensor scale amax * margin / 448), conv2 and conv3 run on
+ * v_mfma_f32_32x32x16_fp8_fp8 (e4m3 activations, e4m3 filters with one scale per output channel), conv3 adds the bf16 shortcut and writes
+ * bf16 -- the residual stream itself is never re-quantised (ImVoxelNet.calibrate_fp8(residual='bf16') of the Python host; both hosts
+ * run the same kernels).  Plans are rebuilt on the next forward.  workspace as for ivx_backbone_fpn_fwd.  ivx_amax_bf16: the max |x|
+ * reduction it uses (out: device float, zeroed by the caller). */
+int ivx_model_calibrate_fp8(ivx_model *m, const float *img, int32_t BV, int32_t H, int32_t W, float margin, void *workspace,
+                            int64_t workspace_bytes, ivx_stream_t stream);
+int ivx_amax_bf16(const void *x, int64_t n, float *out, ivx_stream_t stream);
+
 /* Host-only LayoutHead arithmetic in a fixed fp32 order (both hosts of the library use it): angle = limit_period(raw) and layout =
  * (centre, exp(size), yaw) (layout_head.py:52-74); the camera extrinsic of detectors/imvoxelnet.py:164-187 from (pitch, roll). */
 int ivx_layout_head_decode(const float *angle_raw /*[2]*/, const float *layout_raw /*[7]*/, float *angle /*[2]*/, float *layout /*[7] or NULL*/);

@@ -302,6 +302,7 @@ static int no_bf16(const char *who) {
   ivx_set_error("%s: the CPU restatement has no bf16 storage mode", who);
   return IVX_ERR_UNSUPPORTED;
 }
+extern "C" int ivx_amax_bf16(const void *, int64_t, float *, ivx_stream_t) { return no_bf16("ivx_amax_bf16"); }
 extern "C" int ivx_image_s2d_bf16(const float *, int32_t, int32_t, int32_t, void *, ivx_stream_t) { return no_bf16("ivx_image_s2d_bf16"); }
 extern "C" int ivx_maxpool2d_fwd_bf16(const void *, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, void *, ivx_stream_t) {
   return no_bf16("ivx_maxpool2d_fwd_bf16");

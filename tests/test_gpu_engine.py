@@ -509,3 +509,41 @@ def test_c_program_e2e_indoor_bf16_storage_without_python(ia):
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'C e2e_indoor OK (bf16 storage)' in out.stdout
+
+
+@pytest.mark.parametrize('cfg_name,views', [('scannet_v1', 6), ('scannet_fast', 4)])
+def test_native_config5_named_mode_equals_layerwise(ia, cfg_name, views):
+    """BASELINE config 5's named mode -- bf16 storage with the fp8 2-D conv trunk (e4m3 bottleneck interiors, bf16 residual stream) --
+    behind the C-ABI (ivx_model_cfg.storage = IVX_BF16 + ivx_model_calibrate_fp8): one native call against the layer-by-layer
+    composition of ImVoxelNet.calibrate_fp8(residual='bf16'): the same calibration maxima, the same e4m3 filters and epilogue vectors,
+    the same kernels -- identical detections."""
+    mcfg, tcfg = getattr(kc, f'{cfg_name}_model_cfg')(), dict(getattr(kc, f'{cfg_name.upper()}_TEST_CFG'))
+    hw = (480, 640)
+    metas = [kc.indoor_meta(views, img_hw=hw, origin=(0, 0, .5), box_type=ia.DepthInstance3DBoxes)]
+    model = ia.build_detector(mcfg, test_cfg=tcfg)
+    ia.randomize_(model, 43)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        model.bbox_head.cls_conv.weight.normal_(0, 0.01, generator=g)
+        model.bbox_head.cls_conv.bias.fill_(-2.0)
+        model.bbox_head.centerness_conv.weight.normal_(0, 0.005, generator=g)
+        model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
+    img = torch.randn(1, views, 3, *hw, generator=torch.Generator().manual_seed(9)).cuda()
+    model.prepare(torch.device('cuda'), dtype=torch.bfloat16, native=False)
+    model.calibrate_fp8(img)
+    assert model._native is None
+    ref = model.simple_test(img, metas)
+    fpn_ref = model.features_2d_cl(img).float()
+    model.prepare(torch.device('cuda'), dtype=torch.bfloat16)
+    model.calibrate_fp8(img)
+    assert model._native is not None and model._native.cfg.storage == 1
+    fpn_nat = model._native.backbone_fpn(img.reshape(views, 3, *hw)).float()
+    res = model.simple_test(img, metas)
+    torch.cuda.synchronize()
+    d = float((fpn_nat - fpn_ref).abs().max())
+    print(cfg_name, 'fp8 trunk: max |FPN native - layerwise|', d, 'detections', len(res[0]['scores_3d']), len(ref[0]['scores_3d']))
+    assert torch.equal(fpn_nat, fpn_ref)
+    assert len(ref[0]['scores_3d']) > 5
+    for a, b in zip(res, ref):
+        assert torch.equal(a['scores_3d'], b['scores_3d']) and torch.equal(a['labels_3d'], b['labels_3d'])
+        assert torch.equal(a['boxes_3d'].tensor, b['boxes_3d'].tensor)
