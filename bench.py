@@ -364,6 +364,26 @@ def bench_dry(args, rank, world):
         raise SystemExit('dry run: the reduce-scatter exchange over x-slabs differs from the all-reduce form')
 
 
+def physical_cores():
+    """Distinct (package, core) pairs of the host (`cores` of the CPU legs is the THREAD count used; SMT siblings share a core)."""
+    try:
+        seen, pkg, core = set(), None, None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                pkg = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                core = line.split(':')[1].strip()
+            elif not line.strip():
+                if core is not None:
+                    seen.add((pkg, core))
+                pkg = core = None
+        if core is not None:
+            seen.add((pkg, core))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -630,7 +650,7 @@ def main():
     # from the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh -> profiles/*_bench_pmc.json;
     # FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as reported), averaged per launch; null if absent.
     traffic, traffic_src = None, None
-    for name in (('r03b_bench_pmc.json',) if pair else ('r03_bench_pmc.json', 'r02_bench_pmc.json', 'r01_bench_pmc.json')):
+    for name in (('r04_bench_pmc.json', 'r03b_bench_pmc.json') if pair else ('r03_bench_pmc.json', 'r02_bench_pmc.json', 'r01_bench_pmc.json')):
         pj = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pj) and not bf16:
             try:   # the summary covers the main launch of every neck layer: HBM bytes averaged per launch
@@ -733,7 +753,7 @@ def main():
             ts = ts[1:]
             tc = sum(ts) / len(ts)
             rec['cpu_baseline'] = {'value': round(1.0 / tc, 4), 'unit': 'images/s', 'cores': torch.get_num_threads(),
-                                   'kind': 'port', 'host_cpus': os.cpu_count(),
+                                   'kind': 'port', 'host_cpus': os.cpu_count(), 'physical_cores': physical_cores(),
                                    'sample': '%d images (1x3x384x1280 -> 216x248x12 each, one at a time) through the oracle port (torch-CPU fp32 '
                                              'convs + C unprojection/NMS) after one untimed warm-up image: %s s, mean %.2f s'
                                              % (len(ts), ' / '.join('%.2f' % t for t in ts), tc)}
@@ -756,7 +776,8 @@ def main():
                     cm.close()
                 tcs = tcs[1:]
                 rec['cpu_baseline_cabi'] = {'value': round(len(tcs) / sum(tcs), 4), 'unit': 'images/s', 'cores': int(os.environ['OMP_NUM_THREADS']),
-                                            'kind': 'port', 'host_cpus': os.cpu_count(), 'detections_last_image': int(len(cdet[0][1])),
+                                            'kind': 'port', 'host_cpus': os.cpu_count(), 'physical_cores': physical_cores(),
+                                            'detections_last_image': int(len(cdet[0][1])),
                                             'sample': '%d images through ivx_model_forward of oracle/_cpuabi/libimvoxel_cpu.so (the model-level C-ABI '
                                                       'over the CPU restatement: direct convolutions, no Winograd form) after one untimed warm-up '
                                                       'image: %s s' % (len(tcs), ' / '.join('%.2f' % t for t in tcs))}

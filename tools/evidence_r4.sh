@@ -8,9 +8,9 @@ mkdir -p $ROOT/$OUT
 cd $ROOT
 nproc > $OUT/host.txt; lscpu | grep -E "Model name|Socket|Core|Thread" >> $OUT/host.txt
 python bench.py --steps 20 --warmup 5 2>$OUT/bench.err | tail -1 > $OUT/bench_default.json
-python bench.py --steps 20 --warmup 5 --wino-operands f32 --trunk-operands f32 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_f32_operands.json
-python bench.py --steps 20 --warmup 5 --trunk-operands f32 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_trunk_f32.json
-python bench.py --steps 20 --warmup 5 --api composed --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_composed.json
+python bench.py --steps 10 --warmup 3 --wino-operands f32 --trunk-operands f32 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_f32_operands.json
+python bench.py --steps 10 --warmup 3 --trunk-operands f32 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_trunk_f32.json
+python bench.py --steps 10 --warmup 3 --api composed --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_composed.json
 python bench.py --steps 10 --warmup 3 --storage bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_bf16.json
 IVX_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_dist1.json
@@ -20,7 +20,6 @@ for c in nuscenes sunrgbd_fast scannet_fast scannet_v1; do python bench.py --con
 python bench.py --config scannet_fast --views 20 --steps 10 --warmup 3 --wino-operands f32 --trunk-operands f32 2>/dev/null | tail -1 >> $OUT/other_f32_operands.jsonl
 python bench.py --config scannet_v1 --steps 10 --warmup 3 --storage bf16 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl
 python bench.py --config scannet_v1 --steps 10 --warmup 3 --storage bf16 --trunk-fp8 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl
-python bench.py --config scannet_fast --steps 10 --warmup 3 --storage bf16 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl
 IVX_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 \
     bench.py --gpus 1 --config nuscenes --batch 1 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_dist1_nuscenes.json
 IVX_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29535 \
@@ -48,8 +47,6 @@ python tools/pmc_summary.py $OUT/pmc --min-ms 0.1 --match wino_ --json $OUT/pmc_
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.02 --match "conv_igemm_v4_kernel<DF16b" --json $OUT/pmc_trunk.json > $OUT/pmc_trunk.md
 bash tools/pmc_bench.sh $OUT/pmc_scannet_v1 --config scannet_v1 > $OUT/pmc_scannet_v1.log 2>&1
 python tools/pmc_summary.py $OUT/pmc_scannet_v1 --min-ms 0.1 --match conv_igemm,conv_wino_halo,wino_,backproject --json $OUT/pmc_scannet_v1.json > $OUT/pmc_scannet_v1.md
-bash tools/pmc_bench.sh $OUT/pmc_nuscenes --config nuscenes > $OUT/pmc_nuscenes.log 2>&1
-python tools/pmc_summary.py $OUT/pmc_nuscenes --min-ms 0.1 --match conv_igemm,conv_wino_halo,wino_,backproject,dcn --json $OUT/pmc_nuscenes.json > $OUT/pmc_nuscenes.md
 rm -rf $OUT/pmc*/pass*/*.db 2>/dev/null
 find $OUT -name "*.csv" -size +2M -delete
 du -sh $OUT
