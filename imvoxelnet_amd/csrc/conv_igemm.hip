@@ -1328,7 +1328,7 @@ struct ConvPlan {
 
 
 #if IVX_CONV_TU == 0
-static thread_local int g_halo_mode = -1;   // A/B knob (ivx_conv_set_halo_mode): -1 default rule | 0 never | 1 .. 14 force that z-halo config of the stride-1 layers, 21 .. 24 of the z-stride-2 layers
+static thread_local int g_halo_mode = -1;   // A/B knob (ivx_conv_set_halo_mode): -1 default rule | 0 never | 1 .. 14 / 30 .. 34 force that z-halo config of the stride-1 layers, 21 .. 24 / 41 .. 45 of the z-stride-2 layers
 extern "C" int ivx_conv_set_halo_mode(int mode) {
   g_halo_mode = mode;
   return IVX_OK;
@@ -1603,14 +1603,25 @@ int ivx_conv_launch_pair_f16(ConvParams &p, const ConvPlan &pl, hipStream_t st) 
 // SW 2 (TAIL 0 only): the z-stride-2 layers.  With an even Z the input row of output row r' and tap kz is 2 r' - 1 + kz whatever the
 // column, so a tile stages 2 BM consecutive input rows, stores BM - 1 output rows and reads the fragments of tap kz at rows 2 o + kz;
 // only tap 0 can fall outside the column (z' = 0).  One staged row serves 1.5 taps instead of 3.
-template <typename T, int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1, int SW = 1>
+// ZR 1: a lane whose z - 1 / z + 1 neighbour lies outside the column reads the fragments of that tap from an LDS row that is ALWAYS zero
+// instead of zeroing the eight dwords it read (32 v_cndmask per group in the 126 x 64 tile, where the loop has 18 MFMAs): the address is
+// chosen once per tile.  The zero row costs no LDS: it is a staged row that no stored output reads -- row BM + 2 of the tail pass, the
+// last of the 2 BM rows of the stride-2 form, and for the overlapping stride-1 tiles the last staged row, given up as a source row (a
+// tile then stores BM - 3 rows instead of BM - 2) -- whose DMA lanes get an out-of-range offset, i.e. zeros, in every group.
+// DI 1 (SW 2 only): the staged rows are de-interleaved -- LDS rows 0 .. BM - 1 hold the even staged rows, BM .. 2 BM - 1 the odd ones -- so
+// that the fragment rows of a tap are CONSECUTIVE LDS rows as in the stride-1 form (rows two apart start on two of the four 16-bank groups
+// only: 27 % of the LDS cycles of the interleaved form were bank conflicts, profiles/r04_bench_pmc.md).  Only the global row a DMA lane
+// fetches changes; tap kz of output row o reads LDS row o (kz 0), BM + o (kz 1), o + 1 (kz 2).
+template <typename T, int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1, int SW = 1, int ZR = 0, int DI = 0>
 __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const ConvParams p, const unsigned in_bytes, const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32, NT = 64 * WR * WC;
   constexpr int BK = 32, EPC = 8, NCH = 4, RP = NT / NCH;
   static_assert((SW * BM) % RP == 0 && (3 * BN) % RP == 0, "A rows and the three taps of B rows in whole passes (+ one 16-row tail pass of A)");
   static_assert(SW == 1 || TAIL == 0, "the stride-2 form uses overlapping tiles");
+  static_assert(!DI || SW == 2, "de-interleaved staging is the stride-2 form's");
   constexpr int APASS = SW * BM / RP, AROWS = SW * BM + 16 * TAIL;        // staged input rows: plane rows SW * m0 - 1 ...
-  constexpr int BMO = TAIL ? BM : (SW == 1 ? BM - 2 : BM - 1);             // rows a tile stores
+  constexpr int BMO = TAIL ? BM : (SW == 1 ? BM - 2 - ZR : BM - 1);        // rows a tile stores
+  constexpr int ZROW = TAIL ? BM + 2 : SW * BM - 1;                        // ZR: the LDS row of A that stays zero
   constexpr int BPASS = 3 * BN / RP;
   constexpr int BUF = (AROWS + 3 * BN) * BK;                               // elements per buffer
   constexpr int D = NBUF - 1;                                              // prefetch distance in groups
@@ -1645,8 +1656,10 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
   a_base[APASS] = OOB;
 #pragma unroll
   for (int j = 0; j < APASS + TAIL; ++j) {
-    const int row = SW * m0 - 1 + (j < APASS ? lr + RP * j : BM + (lane >> 2));
-    a_base[j] = (row >= 0 && row < SW * p.M && (j < APASS || (lane >> 2) < 2)) ? ((unsigned)row * (unsigned)p.Cin + cc * EPC) * (unsigned)sizeof(T) : OOB;
+    const int li = j < APASS ? lr + RP * j : BM + (lane >> 2);
+    const int row = SW * m0 - 1 + (DI ? (li < BM ? 2 * li : 2 * (li - BM) + 1) : li);
+    const bool zr = ZR && !TAIL && li == ZROW;
+    a_base[j] = (row >= 0 && row < SW * p.M && (j < APASS || (lane >> 2) < 2) && !zr) ? ((unsigned)row * (unsigned)p.Cin + cc * EPC) * (unsigned)sizeof(T) : OOB;
   }
   // B: LDS row t * BN + n holds filter row n0 + n of tap t; chunk-major K: (32 real channels = 64 stored) x tap
   unsigned b_base[BPASS];
@@ -1687,6 +1700,16 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
     ok0[i] = z >= 1;
     ok2[i] = SW == 2 || z + 1 < p.Wo;                        // stride 2: input z = 2 z' + 1 <= Z - 1 always
   }
+  // ZR: element offset of this lane's hi fragment of taps 0 and 2 inside the A area of a buffer (lo: the same ^ 2 chunks)
+  int aoff[2][TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ar = DI ? rl + t : SW * rl + 2 * t;
+      const bool ok = t == 0 ? ok0[i] : ok2[i];
+      aoff[t][i] = ok ? ((DI ? 1 : SW) * (wr * TM + i) * 32 + ar) * BK + ((fh ^ ((ar >> 2) & 3)) * EPC) : ZROW * BK + fh * EPC;
+    }
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -1710,17 +1733,24 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
     }
     __syncthreads();                    // ... and every wave is done reading the buffer of group g - 1, which group g + D now overwrites
     if (g + D < G) load_group(g + D, nxt);
-    const T *Ac = smem + cur * BUF + SW * wr * TM * 32 * BK;
+    const T *Ac = smem + cur * BUF + (DI ? 1 : SW) * wr * TM * 32 * BK;
     const T *Bc = smem + cur * BUF + AROWS * BK + wc * TN * 32 * BK;
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz) {
       f32x4 ah[TM], al[TM], bh[TN], bl[TN];
-      const int ar = SW * rl + kz, asw = (ar >> 2) & 3;       // A rows of this tap: LDS row SW * o + kz (LDS row 0 is plane row SW * m0 - 1)
+      // A rows of this tap: LDS row SW * o + kz (LDS row 0 is plane row SW * m0 - 1); DI: o + (kz >> 1) in the even (kz 0, 2) / odd (kz 1) half
+      const int ar = DI ? rl + (kz >> 1) + (kz & 1) * BM : SW * rl + kz, asw = (ar >> 2) & 3;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const T *rowp = Ac + (SW * i * 32 + ar) * BK;
-        ah[i] = *reinterpret_cast<const f32x4 *>(rowp + ((fh ^ asw) * EPC));
-        al[i] = *reinterpret_cast<const f32x4 *>(rowp + (((2 + fh) ^ asw) * EPC));
+        if (ZR && kz != 1) {
+          const T *A0 = smem + cur * BUF;
+          ah[i] = *reinterpret_cast<const f32x4 *>(A0 + aoff[kz >> 1][i]);
+          al[i] = *reinterpret_cast<const f32x4 *>(A0 + (aoff[kz >> 1][i] ^ (2 * EPC)));
+        } else {
+          const T *rowp = Ac + ((DI ? 1 : SW) * i * 32 + ar) * BK;
+          ah[i] = *reinterpret_cast<const f32x4 *>(rowp + ((fh ^ asw) * EPC));
+          al[i] = *reinterpret_cast<const f32x4 *>(rowp + (((2 + fh) ^ asw) * EPC));
+        }
       }
       const int bsw = (rl >> 2) & 3;
 #pragma unroll
@@ -1729,7 +1759,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
         bh[j] = *reinterpret_cast<const f32x4 *>(rowp + ((fh ^ bsw) * EPC));
         bl[j] = *reinterpret_cast<const f32x4 *>(rowp + (((2 + fh) ^ bsw) * EPC));
       }
-      if (kz != 1) {
+      if (!ZR && kz != 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const bool ok = kz == 0 ? ok0[i] : ok2[i];
@@ -1778,15 +1808,15 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
   }
 }
 
-template <int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1, int SW = 1>
+template <int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1, int SW = 1, int ZR = 0, int DI = 0>
 static void launch_halo(ConvParams &p, hipStream_t st) {
-  constexpr int BM = (WR * TM * 32) - (TAIL ? 0 : (SW == 1 ? 2 : 1)), BN = WC * TN * 32;     // rows a tile stores
+  constexpr int BM = (WR * TM * 32) - (TAIL ? 0 : (SW == 1 ? 2 + ZR : 1)), BN = WC * TN * 32;     // rows a tile stores
   const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 2, w_bytes = (int64_t)p.Cout * p.K * 2;
   const long long Mt = (p.M + BM - 1) / BM, Nt = (p.Cout + BN - 1) / BN;
   p.bm = BM;
   p.q_total = (int)((Mt + 7) / 8); p.q_begin = 0; p.q_count = p.q_total;
   const dim3 grid((unsigned)(8LL * p.q_total * Nt), 1, p.groups > 1 ? p.groups : 1);
-  auto kern = conv_wino_halo_kernel<__bf16, TM, TN, WR, WC, WPE, PAIR, NBUF, TAIL, SW>;
+  auto kern = conv_wino_halo_kernel<__bf16, TM, TN, WR, WC, WPE, PAIR, NBUF, TAIL, SW, ZR, DI>;
   hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
 }
 
@@ -1815,6 +1845,16 @@ int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st) {
     case 22: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 2>(p, st); break;  // 127 x 128, 4 waves: 80 KB, two per CU
     case 23: launch_halo<2, 2, 4, 2, 1, 2, 2, 0, 2>(p, st); break;  // 255 x 128, 8 waves: 112 KB, one per CU
     case 24: launch_halo<1, 2, 4, 1, 2, 2, 2, 0, 2>(p, st); break;  // 127 x 64, 4 waves in M (wave tile 32 x 64): 56 KB
+    // ZR: masked taps read a zero row (10 / 13 / 14 / 11 / 22 / 21 with the fragment address selected instead of the fragment zeroed)
+    case 30: launch_halo<2, 1, 2, 2, 4, 2, 2, 0, 1, 1>(p, st); break;  // 125 x 64
+    case 31: launch_halo<2, 2, 4, 1, 2, 2, 2, 0, 1, 1>(p, st); break;  // 253 x 64
+    case 33: launch_halo<2, 2, 4, 2, 1, 2, 2, 0, 1, 1>(p, st); break;  // 253 x 128, 8 waves
+    case 34: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 1, 1>(p, st); break;  // 125 x 128
+    case 41: launch_halo<2, 1, 2, 2, 2, 2, 2, 0, 2, 1>(p, st); break;  // stride 2: 127 x 64
+    case 42: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 2, 1>(p, st); break;  // stride 2: 127 x 128
+    case 43: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 2, 1, 1>(p, st); break;  // 42 with de-interleaved staging
+    case 44: launch_halo<2, 1, 2, 2, 2, 2, 2, 0, 2, 1, 1>(p, st); break;  // 41 with de-interleaved staging
+    case 45: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 2, 0, 1>(p, st); break;  // 22 with de-interleaved staging
     default:
       ivx_set_error("ivx_conv_launch_halo: unknown config %d", cfg);
       return IVX_ERR_INVALID_ARG;
@@ -2023,17 +2063,21 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
   p.groups = groups; p.g_in = g_in; p.g_w = g_w; p.g_out = g_out;
   // z-halo kernel (TU 5): 1x1x3 along z, stride 1, pad 1, chunk-major fp16 pairs -- the ResModule layers of the stack necks
   if (p.in_pair == 2 && p.kmode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 3 && d->sw == 2 && d->pw == 1 && p.W == 2 * p.Wo && p.Cin % 64 == 0 &&
-      (g_halo_mode >= 21 || (g_halo_mode < 0 && g_tile_override == 0))) {
-    return ivx_conv_launch_halo(p, g_halo_mode >= 21 ? g_halo_mode : 22, st);
+      ((g_halo_mode >= 21 && g_halo_mode < 30) || g_halo_mode >= 40 || (g_halo_mode < 0 && g_tile_override == 0))) {
+    // (round 4, tools/halo_ab.py, profiles/r04_halo_ab.md: the zero-row form 42 vs 22: 0.494 / 0.790 vs 0.492 / 0.811 ms; de-interleaved staging
+    // 43 / 45: equal -- neither the masks nor the bank conflicts are what this kernel waits for)
+    return ivx_conv_launch_halo(p, g_halo_mode >= 21 ? g_halo_mode : 42, st);
   }
   if (p.in_pair == 2 && p.kmode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 3 && d->sw == 1 && d->pw == 1 && p.Cin % 64 == 0 &&
-      ((g_halo_mode > 0 && g_halo_mode < 21) || (g_halo_mode < 0 && g_tile_override == 0))) {
+      ((g_halo_mode > 0 && g_halo_mode < 21) || (g_halo_mode >= 30 && g_halo_mode < 40) || (g_halo_mode < 0 && g_tile_override == 0))) {
     // measured (tools/pair_ab.py --halo N, profiles/r03b_pair_ab_halo.log; generic kernel 0.73 / 0.90 / 1.41 ms for Cout 64 / 128 / 256):
     // with the 16-row tail pass: 128 x 64 at three per CU 0.57 / 0.84 / 1.44, 256 x 64 0.60-0.64 / 0.83 / 1.33, 256 x 128 0.99 / 0.84 / 1.37,
     // 256 x 256 (16 waves) 1.40-1.44 / 1.19 / 1.24-1.27; every three-buffer ring is slower than its two-buffer form (resident workgroups
     // hide the load latency better than depth does).  Overlapping tiles without the tail pass: 126 x 64 at FOUR per CU 0.49 / 0.74 / 1.35,
     // 254 x 64 0.51 / 0.72 / 1.23, 254 x 128 (8 waves, two per CU) 0.65 / 0.64 / 1.15, 254 x 256 1.19 / 1.10 / 1.20
-    const int cfg = g_halo_mode > 0 ? g_halo_mode : (p.Cout <= 64 ? 10 : 13);
+    // round 4: the zero-row forms (30 / 33: the fragment ADDRESS of a masked tap selected once per tile instead of 32 v_cndmask per group):
+    // 125 x 64 0.487 / 0.756 / 1.410 (= 10), 253 x 128 0.597 / 0.644 / 1.144 (13: 0.607 / 0.653 / 1.167); bit-identical results
+    const int cfg = g_halo_mode > 0 ? g_halo_mode : (p.Cout <= 64 ? 30 : 33);
     return ivx_conv_launch_halo(p, cfg, st);
   }
   ConvPlan pl = {g_tile_override, 1, 1, 0, 0, 0, 0};

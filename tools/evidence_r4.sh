@@ -44,7 +44,7 @@ python tools/trunk_layers.py --config scannet_v1 --top 60 > $OUT/trunk_layers_sc
 bash tools/pmc_bench.sh $OUT/pmc > $OUT/pmc.log 2>&1
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.3 --json $OUT/pmc.json > $OUT/pmc.md
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.1 --match wino_ --json $OUT/pmc_wino.json > $OUT/pmc_wino.md
-python tools/pmc_summary.py $OUT/pmc --min-ms 0.02 --match "conv_igemm_v4_kernel<DF16b" --json $OUT/pmc_trunk.json > $OUT/pmc_trunk.md
+python tools/pmc_summary.py $OUT/pmc --min-ms 0.02 --match "conv_igemm_v4_kernel<__bf16" --json $OUT/pmc_trunk.json > $OUT/pmc_trunk.md
 bash tools/pmc_bench.sh $OUT/pmc_scannet_v1 --config scannet_v1 > $OUT/pmc_scannet_v1.log 2>&1
 python tools/pmc_summary.py $OUT/pmc_scannet_v1 --min-ms 0.1 --match conv_igemm,conv_wino_halo,wino_,backproject --json $OUT/pmc_scannet_v1.json > $OUT/pmc_scannet_v1.md
 rm -rf $OUT/pmc*/pass*/*.db 2>/dev/null

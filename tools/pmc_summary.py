@@ -4,6 +4,9 @@
 HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte
 requests at 64 B, so the read side is doubled before use; WRITE_SIZE is used as reported (it matches the
 algorithmic output bytes of the conv launches exactly)."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _kname import pretty
 import argparse
 import collections
 import csv
@@ -33,6 +36,7 @@ def main():
             d[r['Dispatch_Id']] = ((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6, r['Kernel_Name'])
         for r in csv.DictReader(open(cc[0])):
             ms, name = d.get(r['Dispatch_Id'], (0.0, r['Kernel_Name']))
+            name = pretty(name)
             if not any(mm in name for mm in a.match.split(',')) or ms < a.min_ms:
                 continue
             key = name.replace('(anonymous namespace)::', '').split('(')[0][:80]

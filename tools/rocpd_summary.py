@@ -5,6 +5,9 @@ With `steps` (timed + warm-up steps of the profiled bench.py run) it also prints
 of the 3-D neck -- every launch >= 0.3 ms of the two kernels that run the Winograd-domain GEMMs, `conv_wino_halo_kernel` (the
 stride-1 / z-stride-2 layers on fp16 pairs) and `conv_igemm_v4_kernel` (the last layer, and every layer with fp32 operands) --
 plus the transforms: the numbers bench.py's event-bracketed `roofline.mfma_launch_ms_per_step` / `neck_ms_per_step` must agree with."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _kname import pretty
 import sqlite3
 import sys
 
@@ -20,7 +23,7 @@ def main(path, steps=0):
     print('| kernel | calls | total ms | avg us | min us | max us | % |')
     print('|---|---|---|---|---|---|---|')
     for n, k, t, a, mn, mx in rows:
-        print(f'| `{n[:110]}` | {k} | {t / 1e6:.3f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | {100 * t / tot:.2f} |')
+        print(f'| `{pretty(n)[:110]}` | {k} | {t / 1e6:.3f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | {100 * t / tot:.2f} |')
     gcols = [x for x in ('grid_x', 'grid_size_x', 'grid_size') if x in cols]
     gx = gy = None
     if gcols:
@@ -31,7 +34,7 @@ def main(path, steps=0):
         print('| kernel | grid | calls | avg us |')
         print('|---|---|---|---|')
         for r in c.execute(f"select {sel}, count(*), avg(end-start) from kernels where ({name} like '%conv_igemm%' or {name} like '%conv_wino_halo%') group by {sel} order by avg(end-start) desc"):
-            print(f'| `{r[0][:60]}` | {r[1:-2]} | {r[-2]} | {r[-1] / 1e3:.1f} |')
+            print(f'| `{pretty(r[0])[:60]}` | {r[1:-2]} | {r[-2]} | {r[-1] / 1e3:.1f} |')
 
 
     if steps:
