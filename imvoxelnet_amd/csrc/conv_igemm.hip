@@ -298,21 +298,35 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvParams &p, f32x16 (
 // conv_pair_io -- a lane's 4 channels are 8 bytes of hi halves and, 32 bytes further, 8 bytes of lo halves -- and the maximum of the
 // stored values (true values, before the output scale) goes to the amax slots for the next layer's bound.
 // epilogue of 4 consecutive channels nb .. nb + 3 of output row m (pair IO): v = the accumulators; returns max |stored value|
-__device__ __forceinline__ float conv_pio_finish4(const ConvParams &p, const PairIO io, f32x4 v, const int m, const int nb, const f32x4 sc, const f32x4 sf) {
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
+// the residual of 4 consecutive channels nb .. nb + 3 of row `row` as it lies in memory: 4 floats, or (pair tensor) 8 bytes of hi halves
+// and, 32 bytes further, 8 bytes of lo halves
+__device__ __forceinline__ u32x4r conv_pio_res_load(const ConvParams &p, const size_t row, const int nb) {
+  if (p.res_pair) {
+    const _Float16 *rp = reinterpret_cast<const _Float16 *>(p.res) + pair_off(row, nb, p.Cout);
+    const u32x2r h = *reinterpret_cast<const u32x2r *>(rp), l = *reinterpret_cast<const u32x2r *>(rp + 16);
+    return u32x4r{h.x, h.y, l.x, l.y};
+  }
+  return *reinterpret_cast<const u32x4r *>(p.res + row * (size_t)p.Cout + nb);
+}
+__device__ __forceinline__ f32x4 conv_pio_res_decode(const ConvParams &p, const PairIO io, const u32x4r raw) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f32x4 rr;
+  if (p.res_pair) {
+    const f16x4 rh = __builtin_bit_cast(f16x4, u32x2r{raw.x, raw.y}), rl = __builtin_bit_cast(f16x4, u32x2r{raw.z, raw.w});
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rr[e] = ((float)rh[e] + (float)rl[e]) * io.inv_res;
+  } else {
+    rr = __builtin_bit_cast(f32x4, raw);
+  }
+  return rr;
+}
+// v = the accumulators, rr = the decoded residual (zeros without one); stores the 4 channels, returns max |stored value|
+__device__ __forceinline__ float conv_pio_finish4_rr(const ConvParams &p, const PairIO io, f32x4 v, const int m, const int nb, const f32x4 sc, const f32x4 sf,
+                                                     const f32x4 rr) {
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   v = v * sc + sf;
-  f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-  if (p.res_mode) {
-    if (p.res_pair) {
-      const size_t row = p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, 1) : (size_t)m;
-      const _Float16 *rp = reinterpret_cast<const _Float16 *>(p.res) + pair_off(row, nb, p.Cout);
-      const f16x4 rh = *reinterpret_cast<const f16x4 *>(rp), rl = *reinterpret_cast<const f16x4 *>(rp + 16);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) rr[e] = ((float)rh[e] + (float)rl[e]) * io.inv_res;
-    } else {
-      rr = *reinterpret_cast<const f32x4 *>(p.res + (p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, p.Cout) : (size_t)m * p.Cout) + nb);
-    }
-  }
   if (p.res_mode && !p.res_after_act) v += rr;
   if (p.relu) {
     v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
@@ -337,7 +351,20 @@ __device__ __forceinline__ float conv_pio_finish4(const ConvParams &p, const Pai
   }
   return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
+__device__ __forceinline__ float conv_pio_finish4(const ConvParams &p, const PairIO io, f32x4 v, const int m, const int nb, const f32x4 sc, const f32x4 sf) {
+  f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+  if (p.res_mode) {
+    const size_t row = p.res_mode == 2 ? res2_row_base(m, p.Ho, p.Wo, p.rH, p.rW, 1) : (size_t)m;
+    rr = conv_pio_res_decode(p, io, conv_pio_res_load(p, row, nb));
+  }
+  return conv_pio_finish4_rr(p, io, v, m, nb, sc, sf, rr);
+}
 
+// Measured and removed (round 4, profiles/r04_pio_epilogue_prefetch_ab.md): requesting the residual of block b + 2 before block b is
+// transposed and stored (two blocks = 32 registers in flight) so that a wave waits for one memory round trip instead of TM * TN --
+// the 128 x 128 tile went from 5 to 26 spilled registers and every residual layer got SLOWER (64 -> 256 at 50 views 0.67 -> 0.77 ms,
+// 128 -> 512 0.41 -> 0.45, 256 -> 1024 0.27 -> 0.29): the serial load -> store chain of a wave is hidden by the other fifteen waves of
+// the CU; what bounds these layers is not the residual's latency.
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_wide_pio(const ConvParams &p, const PairIO io, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
                                                        int lane, float *stage, int salt) {

@@ -36,14 +36,17 @@ def main():
     ap.add_argument('--iters', type=int, default=2)
     ap.add_argument('--cfgs', default='0,67,66,63,73,75,74,61,76,81')
     ap.add_argument('--only', default='')
+    ap.add_argument('--epis', default='0', help='epilogue modes to interleave per pair config (ivx_conv_set_epilogue_mode): 0 default, 1 narrow')
     a = ap.parse_args()
     L = _lib.lib()
     B, IH, IW = SETS[a.set]
     cfgs = [int(c) for c in a.cfgs.split(',')]
+    epis = [int(e) for e in a.epis.split(',')]
+    cfgs = [(c, e) for c in cfgs for e in epis]
     g = torch.Generator().manual_seed(0)
     tot = {'f32': 0.0, 'pair default': 0.0, 'pair best': 0.0}
     print(f'# {a.set}: batch {B}, image {IH}x{IW}; median ms over {a.reps} interleaved repetitions; f32 = FusedConv fp32 path (Winograd where it applies)')
-    print('| layer | f32 ms | ' + ' | '.join(f'pair cfg {c}' for c in cfgs) + ' | best | GB/s (best) | TFLOP/s fp32-equivalent (best) |')
+    print('| layer | f32 ms | ' + ' | '.join(f'pair cfg {c}' + (f' epi {e}' if len(epis) > 1 else '') for c, e in cfgs) + ' | best | GB/s (best) | TFLOP/s fp32-equivalent (best) |')
     print('|---|---|' + '---|' * (len(cfgs) + 3))
     for name, ci, co, k, st, div, res_kind, out_pair in LAYERS:
         if a.only and a.only not in name:
@@ -67,7 +70,7 @@ def main():
         xp = ops.pair_from_float(x)
         nbytes = (x.numel() + B * Ho * Wo * co + (res.numel() if res is not None else 0) + w.numel()) * 4
         flops = 2.0 * B * Ho * Wo * co * ci * k * k
-        variants = [('f32', None)] + [(f'pair {c}', c) for c in cfgs]
+        variants = [('f32', None)] + [(f'pair {c}' + (f' e{e}' if len(epis) > 1 else ''), (c, e)) for c, e in cfgs]
         times = {n: [] for n, _ in variants}
         bad = set()
 
@@ -75,11 +78,13 @@ def main():
             if c is None:
                 L.ivx_conv_set_tile_override(0)
                 return fc(x, res=res, res_mode=res_mode)
-            L.ivx_conv_set_tile_override(c)
+            L.ivx_conv_set_tile_override(c[0])
+            L.ivx_conv_set_epilogue_mode(c[1])
             try:
                 return fc(xp, res=rp, res_mode=res_mode, out_pair=out_pair)
             finally:
                 L.ivx_conv_set_tile_override(0)
+                L.ivx_conv_set_epilogue_mode(0)
         for n, c in variants:          # warm-up + which configs the layer takes
             try:
                 run(n, c)
@@ -101,7 +106,7 @@ def main():
         pairs = {n: v for n, v in med.items() if n != 'f32' and v == v}
         best = min(pairs, key=pairs.get)
         tot['f32'] += med['f32']
-        tot['pair default'] += med.get('pair 0', float('nan'))
+        tot['pair default'] += med.get('pair 0', med.get(f'pair 0 e{epis[0]}', float('nan')))
         tot['pair best'] += pairs[best]
         print(f'| {name} {H}x{W} | {med["f32"]:.4f} | ' + ' | '.join(f'{med[n]:.4f}' for n, _ in variants[1:]) +
               f' | {best} | {nbytes / pairs[best] / 1e6:.0f} | {flops / pairs[best] / 1e9:.1f} |', flush=True)
