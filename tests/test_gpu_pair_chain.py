@@ -256,3 +256,53 @@ def test_kitti_fullsize_operand_modes_identical_kept_anchor_indices(ia, monkeypa
         assert np.allclose(gs, rs, rtol=1e-4, atol=1e-6)
         total += len(gi)
     assert total > 20
+
+
+def test_nonfinite_input_stays_local_in_pair_operands(ia, monkeypatch):
+    """The advisor's round-3 finding: a pair tensor's scale comes from a maximum (measured, or a bound built from measured maxima), and ONE
+    Inf / NaN element makes that maximum useless.  Rule (winograd.hip wino_pow2_scale / conv_igemm.hip conv_pair_io): a non-finite maximum
+    selects the fixed scale 2^-8 and a saturating split, so the damage stays where fp32 arithmetic keeps it -- the outputs whose receptive
+    field holds the element -- instead of every value of the tensor overflowing.  Checked on (a) a Winograd F(6x6,3x3) layer with fp16
+    pair operands and (b) the chained stem + max-pool of the 2-D trunk: far from the element the results equal the clean run's."""
+    from imvoxelnet_amd.conv import FusedConv
+    from imvoxelnet_amd import ops
+    g = torch.Generator().manual_seed(17)
+    # (a) 3-D layer, Winograd domain, pair operands
+    monkeypatch.setattr(FusedConv, 'winograd', True)
+    monkeypatch.setattr(FusedConv, 'wino_operands', 4)
+    monkeypatch.setattr(FusedConv, 'winograd_min_pos', 0)
+    w = torch.randn(64, 64, 3, 3, 3, generator=g) * (2.0 / (64 * 27)) ** 0.5
+    fc = FusedConv(w, padding=1, relu=True, dims=3).to('cuda')
+    x = torch.randn(1, 48, 54, 6, 64, generator=g).cuda().relu_()
+    clean = fc(x)
+    for bad in (float('inf'), float('nan')):
+        xb = x.clone()
+        xb[0, 20, 25, 3, 7] = bad
+        y = fc(xb)
+        torch.cuda.synchronize()
+        far = torch.ones(48, 54, dtype=torch.bool, device='cuda')
+        far[20 - 9:20 + 10, 25 - 9:25 + 10] = False           # every 8x8 input tile that can hold the element, plus the 3x3 reach
+        yf, cf = y[0][far], clean[0][far]
+        assert bool(torch.isfinite(yf).all()), 'a non-finite input element spread beyond its tiles'
+        assert float((yf - cf).abs().max()) <= 1e-4 * float(clean.abs().max())
+        assert not bool(torch.isfinite(y[0, 20, 25]).all())    # ... and it is still visible where fp32 arithmetic shows it
+    # (b) the chained trunk: image -> layout change (records max |image| = Inf) -> stem conv (bound = Inf: fixed scale, saturating) -> pool
+    monkeypatch.setattr(FusedConv, 'trunk_operands', 4)
+    model, _ = _kitti_like_model(ia)
+    model.prepare('cuda', native=False)
+    bb = model.backbone
+    assert bb.chain
+    img = torch.randn(1, 3, 128, 224, generator=g).cuda()
+    ib = img.clone()
+    ib[0, 1, 60, 100] = float('inf')
+
+    def stem_pool(im):      # backbones.ResNet._stages: fp32 stem -> pair max-pool scaled by the bound max |image| * wbound + sbound
+        x0 = ops.to_channels_last_amax(im.contiguous(), pad_to=4)
+        return ops.maxpool2d_pair(bb.stem(x0), ops.slots_of(x0), bb.stem.wbound, bb.stem.sbound, 3, 2, 1)
+    a, b = stem_pool(img), stem_pool(ib)
+    assert isinstance(a, ops.PairTensor) and isinstance(b, ops.PairTensor) and b.scale() == 2.0 ** -8
+    av, bv = a.float(), b.float()
+    far = torch.ones(av.shape[2], av.shape[3], dtype=torch.bool, device='cuda')
+    far[15 - 3:15 + 4, 25 - 3:25 + 4] = False          # stem output (30, 50) +- 2 sees pixel (60, 100); pooled (15, 25) +- 2 sees those
+    assert bool(torch.isfinite(bv[0, 0][far]).all())
+    assert float((bv[0, 0][far] - av[0, 0][far]).abs().max()) <= 1e-4 * float(av.abs().max())

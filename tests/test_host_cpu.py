@@ -1488,6 +1488,71 @@ def test_halo_kernel_row_arithmetic():
         bmo = BM - (2 if sw == 1 else 1)
         need = sw * (bmo - 1) + 2 + 1          # input rows sw*m0 - 1 .. sw*(m0 + bmo - 1) + 1
         assert need <= sw * BM
+    # round 4, the zero-row form (ZR): the last staged LDS row is never a source row of a stored output, so it can be kept zero and
+    # serve as the fragment row of every masked tap: stride 1 gives one output row up (BM - 3 stored), stride 2 had the row to spare
+    for BM, sw in ((128, 1), (256, 1), (128, 2), (256, 2)):
+        zrow = sw * BM - 1
+        bmo = BM - 3 if sw == 1 else BM - 1
+        used = {sw * o + kz for o in range(bmo) for kz in range(3)}          # LDS rows (row 0 = plane row sw * m0 - 1) the stored outputs read
+        assert zrow not in used and max(used) == zrow - 1
+    # de-interleaved staging of the stride-2 form (DI): LDS row L < BM holds staged row 2 L, row BM + L holds 2 L + 1; tap kz of output o
+    # (staged row 2 o + kz) is then LDS row o (kz 0), BM + o (kz 1), o + 1 (kz 2): consecutive rows per tap, as at stride 1
+    for BM in (128, 256):
+        lds_of = {}
+        for L in range(2 * BM):
+            lds_of[2 * L if L < BM else 2 * (L - BM) + 1] = L
+        assert sorted(lds_of) == list(range(2 * BM))
+        for o in range(BM - 1):
+            assert [lds_of[2 * o + kz] for kz in range(3)] == [o, BM + o, o + 1]
+        assert lds_of[2 * BM - 1] == 2 * BM - 1                              # the zero row keeps its index
+
+
+def test_stack_neck_slabs_cover_the_receptive_field():
+    """dist.StackNeckSlabs (the x-slab + halo arithmetic of the reduce-scatter exchange) against brute-force dependency
+    propagation: for both stack necks and 1 .. 8 ranks, (a) the widened slab [ea, eb) holds every input row the rank's output rows
+    [oa, ob) depend on, (b) running the layers on the slab alone -- zero padding at its ends instead of the neighbours' rows -- computes
+    exactly those output rows from true data (no cropped-in row saw artificial padding unless the whole volume pads there too), (c) local
+    and global indices of every strided layer are congruent, and (d) the slabs of all ranks tile the output."""
+    import imvoxelnet_amd as ia
+    from imvoxelnet_amd import dist as ivd
+    from imvoxelnet_amd import workloads as kc
+    for cfg, X in ((kc.kitti_model_cfg(), 216), (kc.nuscenes_model_cfg(), 192), (kc.nuscenes_model_cfg(), 312)):
+        neck = ia.build_detector(cfg, test_cfg=None).neck_3d
+        for world in range(1, 9):
+            plans = [ivd.StackNeckSlabs(neck, X, world, r) for r in range(world)]
+            assert [p.oa for p in plans] + [plans[-1].ob] == sorted({p.oa for p in plans} | {plans[-1].ob}) and plans[0].oa == 0 and plans[-1].ob == plans[0].Xo
+            for pl in plans:
+                layers = pl.layers
+                # global dependency sets: rows of the layer's INPUT a set of its output rows reads (rows outside the tensor = true zero padding)
+                need = set(range(pl.oa, pl.ob))
+                sizes = [X]
+                for s_, p_ in layers:
+                    sizes.append((sizes[-1] + 2 * p_ - 3) // s_ + 1)
+                for (s_, p_), n_in in zip(reversed(layers), reversed(sizes[:-1])):
+                    need = {o * s_ - p_ + t for o in need for t in range(3)}
+                    need = {i for i in need if 0 <= i < n_in}
+                assert need and min(need) >= pl.ea and max(need) < pl.eb
+                assert pl.ea % pl.S == 0 and pl.off * pl.S == pl.ea
+                # the local run: a row is 'clean' if every input row it reads is either clean data of the slab or padding that the whole
+                # volume has at the same place (global index outside the tensor)
+                clean = {i: True for i in range(pl.ea, pl.eb)}           # global input index -> computed from true data
+                g0, n_glob = pl.ea, X
+                for s_, p_ in layers:
+                    n_loc = (len(clean) + 2 * p_ - 3) // s_ + 1
+                    assert g0 % s_ == 0
+                    nxt, go0 = {}, g0 // s_
+                    n_glob_out = (n_glob + 2 * p_ - 3) // s_ + 1
+                    for ol in range(n_loc):
+                        og = go0 + ol
+                        ok = og < n_glob_out
+                        for t in range(3):
+                            ig = og * s_ - p_ + t
+                            if 0 <= ig < n_glob:
+                                ok = ok and clean.get(ig, False)
+                        nxt[og] = ok
+                    clean, g0, n_glob = nxt, go0, n_glob_out
+                assert g0 == pl.off
+                assert all(clean[o] for o in range(pl.oa, pl.ob)), (world, pl.oa, pl.ob)
 
 
 def test_winograd_operand_format_model():
