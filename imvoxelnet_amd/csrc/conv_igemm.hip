@@ -364,7 +364,8 @@ __device__ __forceinline__ float conv_pio_finish4(const ConvParams &p, const Pai
 // transposed and stored (two blocks = 32 registers in flight) so that a wave waits for one memory round trip instead of TM * TN --
 // the 128 x 128 tile went from 5 to 26 spilled registers and every residual layer got SLOWER (64 -> 256 at 50 views 0.67 -> 0.77 ms,
 // 128 -> 512 0.41 -> 0.45, 256 -> 1024 0.27 -> 0.29): the serial load -> store chain of a wave is hidden by the other fifteen waves of
-// the CU; what bounds these layers is not the residual's latency.
+// the CU; what bounds these layers is not the residual's latency.  (A one-block-ahead form with the request issued before the block is
+// consumed: 55 spilled registers, 0.68 -> 1.11 ms.)
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_wide_pio(const ConvParams &p, const PairIO io, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
                                                        int lane, float *stage, int salt) {

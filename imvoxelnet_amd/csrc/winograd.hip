@@ -264,6 +264,9 @@ __device__ __forceinline__ void wino_pair2(const float2 v, const float s, unsign
   *lo = __builtin_bit_cast(unsigned, l);
 }
 
+// (Round 4, an ablation that skips the loads of the two halo columns / of all halo rows and columns -- wrong results, valid timing: 0.357 ->
+// 0.347 / 0.345 ms: the 1.78x re-read of the input through L2 / the Infinity Cache costs this kernel 3 %, not the 20 % its share of the
+// fabric traffic suggests; a tile order or an LDS exchange that removes it has nothing to win.)
 template <int MT, int VW, int PAIR = 0>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
   typedef typename VecT<VW>::T V;
@@ -436,6 +439,7 @@ __device__ __forceinline__ float4 vfma(float s, float4 a, float4 c) {
 //  * the epilogue is branch-free (border positions get an out-of-range lane offset: the buffer hardware drops those stores and
 //    returns 0 for those loads), which keeps the loop body one basic block -- otherwise LLVM sinks the column arithmetic into the
 //    conditional store blocks and every load is hoisted to the top again.
+// Round 4 (RPF, profiles/r04_wino_ab.log): with the residual requested before the column loop 0.537 -> 0.454 ms (4.67 -> 5.52 TB/s).
 // Measured on the KITTI neck at batch 4 (tools/wino_ab.py, profiles/r03_wino_ab.log): with residual 0.63 -> 0.52 ms per launch
 // (3.95 -> 4.8 TB/s), without 0.37 -> 0.35.  Needs the (m+2)^2 planes of M below 4 GiB and the output tensor below 2 GiB (the
 // launcher falls back to the pointer kernel otherwise).  The sums are accumulated in another order than in the whole-tile form:
@@ -500,7 +504,11 @@ template <int VW> struct Wino6Columns<8, VW> {
   static __device__ __forceinline__ void run(V (&)[6][6], const V (&)[8], const __amdgpu_buffer_rsrc_t, const unsigned, const unsigned) {}
 };
 
-template <int VW, int WPE>
+// RPF 1 (residual layers): the 36 residual values of the tile are requested BEFORE the column loop instead of row by row in the epilogue.
+// A wave of the row-by-row form goes through 8 + 6 dependent memory round trips (eight columns of M, then six rows of residual loads ->
+// stores); here the epilogue has no load left to wait for, at the price of 36 * VW registers held through the column loop (two waves per
+// SIMD instead of three at VW = 2).
+template <int VW, int WPE, int RPF = 0>
 __global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p, const unsigned m_bytes, const unsigned out_bytes) {
   typedef typename VecT<VW>::T V;
   constexpr int MT = 6, N = 8, EB = VW * 4;     // bytes per lane item
@@ -524,6 +532,18 @@ __global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p
     const unsigned vo = (unsigned)(t * EB);
     const V sc = mscale * (p.scale ? reinterpret_cast<const V *>(p.scale)[cv] : vone((V *)nullptr));     // (uniform branches BEFORE the column loop)
     const V sf = p.shift ? reinterpret_cast<const V *>(p.shift)[cv] : vzero((V *)nullptr);
+    const int xb = MT * tx, yb = MT * ty;
+    const unsigned o00 = (unsigned)(((((long long)b * p.Xo + xb) * p.Yo + yb) * per_tile + zc) * EB);
+    const unsigned row = (unsigned)(p.Yo * per_tile * EB), colb = (unsigned)(per_tile * EB);
+    V rres[RPF ? MT : 1][RPF ? MT : 1];
+    if constexpr (RPF) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int e = 0; e < MT; ++e)
+          rres[a][e] = BufIO<VW>::load(rr, (xb + a < p.Xo && yb + e < p.Yo) ? o00 : 0x80000000u, (unsigned)a * row + (unsigned)e * colb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     V acc[MT][MT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -533,16 +553,15 @@ __global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p
 #pragma unroll
     for (int i = 0; i < N; ++i) col[i] = BufIO<VW>::load(rm, vo, (unsigned)(N * i) * ps);
     Wino6Columns<0, VW>::run(acc, col, rm, vo, ps);
-    const int xb = MT * tx, yb = MT * ty;
-    const unsigned o00 = (unsigned)(((((long long)b * p.Xo + xb) * p.Yo + yb) * per_tile + zc) * EB);
-    const unsigned row = (unsigned)(p.Yo * per_tile * EB), colb = (unsigned)(per_tile * EB);
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
 #pragma unroll
       for (int e = 0; e < MT; ++e) {
         const unsigned vo_ae = (xb + a < p.Xo && yb + e < p.Yo) ? o00 : 0x80000000u;
         const unsigned so = (unsigned)a * row + (unsigned)e * colb;
-        const V rv = BufIO<VW>::load(rr, vo_ae, so);        // no residual: rr has zero records -> 0
+        V rv;
+        if constexpr (RPF) rv = rres[a][e];
+        else rv = BufIO<VW>::load(rr, vo_ae, so);           // no residual: rr has zero records -> 0
         const V val = wino_finish_v(p, acc[a][e], sc, sf, rv);
         BufIO<VW>::store(ro, vo_ae, so, val);
         omax = fmaxf(omax, (vo_ae >> 31) ? 0.f : vabsmax(val));     // (unconditional: the epilogue stays one basic block) border
@@ -605,7 +624,8 @@ struct WinoDims {
 
 // A/B knob (per calling thread; ivx_conv_winograd_set_variant): the F(6x6,3x3) output transform kernel.
 //  -1 default rule (2 with a residual, 1 without) | 0 whole tile, 2 channels per lane (the round-2 kernel) | 1 whole tile, 1 channel
-//  per lane | 2 buffer addressing + column accumulation, 2 channels per lane | 3 the same, 1 channel per lane
+//  per lane | 2 buffer addressing + column accumulation, 2 channels per lane | 3 the same, 1 channel per lane | 4 / 5 = 2 / 3 with the
+//  residual prefetched before the column loop (residual layers only)
 thread_local int g_wino_out_variant = -1;
 thread_local int g_wino_in_variant = -1;     // input transform of F(6x6,3x3): -1 default (0) | 0: 2 channels per lane | 1: 1 channel per lane
 
@@ -820,15 +840,16 @@ namespace {
 // at another time and on another thread -- and the number of workgroups must be the one that call returned.
 int wino_output_variant(const ivx_conv_desc *d, const WinoDims &w, bool with_partials) {
   const bool buf_ok = (int64_t)w.n2 * w.m_stride * 4 < (1LL << 32) && (int64_t)d->B * w.Xo * w.Yo * w.Zo * d->Cout * 4 < (1LL << 31);
-  int v = (g_wino_out_variant >= 0 && !with_partials) ? g_wino_out_variant : (d->res_mode ? 2 : 1);
+  int v = (g_wino_out_variant >= 0 && !with_partials) ? g_wino_out_variant : (d->res_mode ? 4 : 1);      // (round 4: 4 instead of 2, 0.54 -> 0.45 ms per launch)
   if (v >= 2 && !buf_ok) v = 0;
+  if (v >= 4 && !d->res_mode) v = v == 4 ? 2 : 3;      // the prefetching forms are the residual layers' 
   return v;
 }
 unsigned wino_output_grid(const ivx_conv_desc *d, int tile, const WinoDims &w, bool with_partials) {
   if (tile == 2) return wino_blocks(w.m_elems / 4);
   if (tile == 4) return wino_blocks(w.m_elems / 2);
   const int v = wino_output_variant(d, w, with_partials);
-  return (v == 2 || v == 0) ? wino_blocks(w.m_elems / 2) : wino_blocks(w.m_elems);
+  return (v == 2 || v == 0 || v == 4) ? wino_blocks(w.m_elems / 2) : wino_blocks(w.m_elems);
 }
 }  // namespace
 
@@ -859,6 +880,10 @@ static int wino_output_impl(const ivx_conv_desc *d, int32_t tile, const float *s
       hipLaunchKernelGGL((wino_output_buf_kernel<2, 3>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p, mb, ob);
     else if (v == 3)
       hipLaunchKernelGGL((wino_output_buf_kernel<1, 5>), dim3(wino_blocks(w.m_elems)), dim3(256), 0, (hipStream_t)stream, p, mb, ob);
+    else if (v == 4)
+      hipLaunchKernelGGL((wino_output_buf_kernel<2, 2, 1>), dim3(wino_blocks(w.m_elems / 2)), dim3(256), 0, (hipStream_t)stream, p, mb, ob);
+    else if (v == 5)
+      hipLaunchKernelGGL((wino_output_buf_kernel<1, 4, 1>), dim3(wino_blocks(w.m_elems)), dim3(256), 0, (hipStream_t)stream, p, mb, ob);
     else if (v == 1)
       hipLaunchKernelGGL((wino_output_kernel<6, 1>), dim3(wino_blocks(w.m_elems)), dim3(256), 0, (hipStream_t)stream, p);
     else
