@@ -72,7 +72,7 @@ class TraceRec(C.Structure):
 EXPORTS = ['ivx_conv_winograd_set_variant', 'ivx_ubench_mfma', 'ivx_ubench_copy', 'ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws', 'ivx_conv_set_halo_mode', 'ivx_bf16_pair_split', 'ivx_f16_pair_split', 'ivx_conv_pair_supported', 'ivx_conv_pio_workspace_bytes', 'ivx_conv_fwd_pio', 'ivx_conv_fwd_pio_naive', 'ivx_pair_pack_filters', 'ivx_nchw_to_nhwc_amax', 'ivx_maxpool2d_fwd_pair', 'ivx_f16_pair_merge', 'ivx_model_calibrate_fp8', 'ivx_amax_bf16', 'ivx_conv_winograd_output_blocks', 'ivx_conv_winograd_output_amax', 'ivx_conv_winograd_input_amax',
            'ivx_conv_winograd_supported', 'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_weights', 'ivx_conv_winograd_workspace_bytes',
            'ivx_conv_winograd_input', 'ivx_conv_winograd_gemm', 'ivx_conv_winograd_output', 'ivx_conv_winograd_fwd',
-           'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_maxpool2d_fwd_fp8', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_nchw_to_nhwc', 'ivx_image_s2d_bf16', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_amax', 'ivx_backproject_amax_blocks', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
+           'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_maxpool2d_fwd_fp8', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_dcn_im2col_fwd_pair', 'ivx_nchw_to_nhwc', 'ivx_image_s2d_bf16', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_amax', 'ivx_backproject_amax_blocks', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
            'ivx_anchor_head_workspace_bytes', 'ivx_anchor_head_get_bboxes', 'ivx_fcos_head_workspace_bytes',
            'ivx_fcos_head_level_candidates', 'ivx_nms_workspace_bytes',
            'ivx_nms_bev', 'ivx_boxes_overlap_bev', 'ivx_aligned_3d_nms', 'ivx_aligned_3d_nms_workspace_bytes', 'ivx_aligned_3d_nms_ws', 'ivx_multiclass_nms_workspace_bytes', 'ivx_multiclass_nms_bev',
@@ -138,6 +138,7 @@ def lib():
     L.ivx_global_avgpool_fwd.argtypes = [vp, i32, i64, i32, vp, vp]
     L.ivx_upsample_trilinear2x_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     L.ivx_dcn_im2col_fwd.argtypes = [vp, vp] + [i32] * 10 + [vp, vp]
+    L.ivx_dcn_im2col_fwd_pair.argtypes = [vp, vp, vp] + [i32] * 10 + [vp, vp, vp, vp]
     L.ivx_nchw_to_nhwc.argtypes = [vp, i32, i32, i64, i32, vp, vp]
     L.ivx_nhwc_to_nchw.argtypes = [vp, i32, i64, i32, vp, vp]
     L.ivx_backproject_mean_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(f32), i32, i32, i32,

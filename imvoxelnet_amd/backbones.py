@@ -52,10 +52,14 @@ class _Bottleneck(nn.Module):
             if sd != torch.float32:
                 raise NotImplementedError('the DCNv2 stages are built for float32 storage only')
             co = self.conv2.conv_offset
-            self.f_off = FusedConv(co.weight, co.bias, stride=self.stride, padding=1, dims=2).to(device)
+            # 27 raw channels + one zero channel (csrc/model.cpp cout_zero): Cout % 4 == 0, so the layer can read pair tensors; the column
+            # kernel takes the map's channel count as its row stride
+            w_off = torch.cat([co.weight.detach().float(), torch.zeros_like(co.weight.detach()[:1]).float()], 0)
+            b_off = torch.cat([co.bias.detach().float(), torch.zeros(1, dtype=torch.float32, device=co.bias.device)], 0)
+            self.f_off = FusedConv(w_off, b_off, stride=self.stride, padding=1, dims=2, chain=chain).to(device)
             w = self.conv2.weight.detach()                               # [Cout, C, 3, 3] -> 1x1 over K = (tap, c)
             w_col = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1, 1, 1)
-            self.f2 = FusedConv(w_col, bn=self.bn2.tensors(), relu=True, dims=2).to(device)
+            self.f2 = FusedConv(w_col, bn=self.bn2.tensors(), relu=True, dims=2, chain=chain).to(device)
         else:
             self.f2 = FusedConv(self.conv2.weight, bn=self.bn2.tensors(), stride=self.stride, padding=1, relu=True, dims=2, chain=chain).to(device)
         self.f3 = FusedConv(self.conv3.weight, bn=self.bn3.tensors(), relu=True, dims=2, dtype=sd, out_dtype=od, chain=chain).to(device)  # relu after the add
@@ -83,7 +87,14 @@ class _Bottleneck(nn.Module):
                 y = self.f2(y)
             return self.f3(y, res=idt)
         idt = x if self.fd is None else self.fd(x)                 # shortcut conv: fp32 out (only read as a residual), max |out| recorded
-        if self.dcn:                                               # conv1 feeds conv_offset and the column kernel: fp32
+        if self.dcn:
+            # conv1 feeds conv_offset and the column kernel: pairs when both can read them and the columns can be pairs too (wants_pair of
+            # csrc/model.cpp: the contraction conv has pair filters, 9x the map stays below 2 GiB); else fp32 as before round 4
+            n1 = x.shape[0] * x.shape[2] * x.shape[3] * self.f1.cout
+            if self.f_off.pair_ok and self.f2.pair_ok and self.f1.cout % 16 == 0 and n1 * 9 * 4 < 2 ** 31:
+                y = self.f1(x, out_pair=True)
+                col = ops.dcn_im2col_pair(y, self.f_off(y), 3, self.stride, 1, 1)
+                return self.f3(self.f2(col, out_pair=self.f3.pair_ok), res=idt, out_pair=out_pair)
             y = self.f1(x)
             y = self.f2(ops.dcn_im2col(y, self.f_off(y), 3, self.stride, 1, 1))
             return self.f3(y, res=idt)

@@ -71,3 +71,91 @@ extern "C" int ivx_dcn_im2col_fwd(const float *x, const float *offset_mask, int3
   IVX_CHECK_LAUNCH("ivx_dcn_im2col_fwd");
   return IVX_OK;
 }
+
+// The same columns inside a chain of fp16-pair activations (include/imvoxel.h, "Chained fp16-pair activations"; round 4): x is an
+// IVX_F16_PAIR map, col an IVX_F16_PAIR tensor with 9 * C channels -- so that the contraction over (k, c) runs on the 16-bit matrix cores
+// (ivx_conv_fwd_pio) instead of the fp32 MFMA (K = 2304 / 4608: the DCNv2 stages were 8 ms of a 20 ms nuScenes step).  The columns keep
+// the SCALE of x: every column is a convex combination of four values of x times a mask in (0, 1), so |col| <= max |x|, and since the
+// scale is a power of two, blending the scaled values equals scaling the blend bit for bit -- the kernel never multiplies by the scale; it
+// copies it to the column tensor's scalar block and records max |col| (true units) for the bound of the next layer.
+__global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const _Float16 *x, const float *x_scale, const float *om, int B, int H, int W, int C,
+                                                              int kh, int kw, int stride, int pad, int dil, int Ho, int Wo, int OMC, _Float16 *col,
+                                                              float *col_scale, unsigned *amax_out) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const int C4 = C >> 2;
+  const int KK = kh * kw;
+  const size_t total = (size_t)B * Ho * Wo * KK * C4;
+  const float sx = *x_scale;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *col_scale = sx;
+  float omax = 0.f;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    size_t t = idx / C4;
+    const int k = (int)(t % KK);
+    t /= KK;                       // t = output pixel m
+    const size_t m = t;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const float *o = om + m * OMC;
+    const float dh = o[2 * k], dw = o[2 * k + 1];
+    const float mk = 1.0f / (1.0f + expf(-o[2 * KK + k]));
+    const int i = k / kw, j = k - i * kw;
+    const float h_im = (float)(ho * stride - pad + i * dil) + dh;
+    const float w_im = (float)(wo * stride - pad + j * dil) + dw;
+    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const int h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - h_low, lw = w_im - w_low, hh = 1.f - lh, hw = 1.f - lw;
+      const int n = c4 * 4;
+      const _Float16 *xb = x + (size_t)b * H * W * (2 * C) + (size_t)((n >> 4) * 32 + (n & 15));
+      auto at = [&](int hy, int wx) {
+        const _Float16 *q = xb + ((size_t)hy * W + wx) * (size_t)(2 * C);
+        const f16x4 h4 = *reinterpret_cast<const f16x4 *>(q), l4 = *reinterpret_cast<const f16x4 *>(q + 16);
+        return f32x4{(float)h4[0] + (float)l4[0], (float)h4[1] + (float)l4[1], (float)h4[2] + (float)l4[2], (float)h4[3] + (float)l4[3]};
+      };
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 v1 = (h_low >= 0 && w_low >= 0) ? at(h_low, w_low) : z;
+      const f32x4 v2 = (h_low >= 0 && w_high <= W - 1) ? at(h_low, w_high) : z;
+      const f32x4 v3 = (h_high <= H - 1 && w_low >= 0) ? at(h_high, w_low) : z;
+      const f32x4 v4 = (h_high <= H - 1 && w_high <= W - 1) ? at(h_high, w_high) : z;
+      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) val[q] = (w1 * v1[q] + w2 * v2[q] + w3 * v3[q] + w4 * v4[q]) * mk;
+    }
+    f16x4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      omax = fmaxf(omax, fabsf(val[q]));
+      hi[q] = (_Float16)val[q];
+      lo[q] = (_Float16)(val[q] - (float)hi[q]);
+    }
+    const int nc = k * C + c4 * 4;       // channel of the 9 * C columns
+    _Float16 *op = col + m * (size_t)(2 * KK * C) + (size_t)((nc >> 4) * 32 + (nc & 15));
+    *reinterpret_cast<f16x4 *>(op) = hi;
+    *reinterpret_cast<f16x4 *>(op + 16) = lo;
+  }
+  if (amax_out) ivx_amax_commit(amax_out, omax / sx, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+}
+
+extern "C" int ivx_dcn_im2col_fwd_pair(const void *x, const float *x_scale, const float *offset_mask, int32_t B, int32_t H, int32_t W, int32_t C,
+                                       int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t dil, int32_t om_channels, void *col,
+                                       float *col_scale, uint32_t *col_amax, ivx_stream_t stream) {
+  IVX_REQUIRE(x && x_scale && offset_mask && col && col_scale, "ivx_dcn_im2col_fwd_pair: null argument");
+  IVX_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0, "ivx_dcn_im2col_fwd_pair: bad dims (C %% 16 must be 0)");
+  IVX_REQUIRE(kh > 0 && kw > 0 && stride > 0 && pad >= 0 && dil > 0, "ivx_dcn_im2col_fwd_pair: bad window");
+  IVX_REQUIRE(om_channels >= 3 * kh * kw, "ivx_dcn_im2col_fwd_pair: offset/mask map needs 3*kh*kw channels (deform_groups = 1)");
+  const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+  const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+  IVX_REQUIRE(Ho > 0 && Wo > 0, "ivx_dcn_im2col_fwd_pair: empty output");
+  const size_t total = (size_t)B * Ho * Wo * kh * kw * (C / 4);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(dcn_im2col_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x, x_scale, offset_mask, B, H, W,
+                     C, kh, kw, stride, pad, dil, Ho, Wo, om_channels, (_Float16 *)col, col_scale, col_amax);
+  IVX_CHECK_LAUNCH("ivx_dcn_im2col_fwd_pair");
+  return IVX_OK;
+}
+

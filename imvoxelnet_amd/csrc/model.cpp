@@ -104,6 +104,8 @@ struct ConvLayer {
   bool relu = false;
   bool conv_t = false;                // nn.ConvTranspose3d(k2, s2) weights [Cin,Cout,2,2,2] run as a 1x1x1 GEMM with 8*Cout columns (out_mode 1)
   bool dcn_cols = false;              // DCNv2 main conv: weights [Cout,C,3,3] run as a 1x1 conv over the 9*C columns of ivx_dcn_im2col_fwd
+  int cout_zero = 0;                  // output channels appended with zero filters / zero bias (conv_offset: 27 -> 28, so that Cout % 4 == 0
+                                      // and the layer can read pair tensors; the column kernel takes the map's channel count as its row stride)
   bool linear = false;                // nn.Linear weights [Cout,Cin] run as a 1x1 conv on a [B,1,1,1,Cin] tensor (LayoutHead MLPs)
   std::vector<std::string> w_keys;    // > 1: filter banks concatenated along Cout (the fused head conv)
   std::vector<std::string> b_keys;    // parallel to w_keys; "" = no bias
@@ -285,8 +287,10 @@ void build_trunk(ivx_model *m) {
       if (m->cfg.dcn_stages[i]) {
         // ModulatedDeformConv2dPack (mmcv; configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14): conv_offset (3x3, bias) -> 27 raw channels,
         // ivx_dcn_im2col_fwd builds the modulated, bilinearly sampled columns, the main conv is a 1x1 over K = 9 * C
-        const int off = add_conv(m, conv2d(pre + "conv2.conv_offset", planes, 27, 3, stride, 1, false, pre + "conv2.conv_offset.weight",
-                                           pre + "conv2.conv_offset.bias", ""), y);
+        ConvLayer co = conv2d(pre + "conv2.conv_offset", planes, 28, 3, stride, 1, false, pre + "conv2.conv_offset.weight",
+                              pre + "conv2.conv_offset.bias", "");
+        co.cout_zero = 1;                                   // 27 raw channels + one zero channel
+        const int off = add_conv(m, co, y);
         Step dc; dc.kind = ST_DCN_COL; dc.in = y; dc.res = off; dc.out = new_tensor(m); dc.aux = stride;
         m->steps.push_back(dc);
         ConvLayer c2 = conv2d(pre + "conv2", 9 * planes, planes, 1, 1, 0, true, pre + "conv2.weight", "", pre + "bn2");
@@ -616,6 +620,10 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
     }
     co0 += co_n;
   }
+  if (L.cout_zero > 0 && co0 + L.cout_zero == L.cout) {       // appended zero channels (bias stays 0)
+    std::fill(wp.begin() + (size_t)co0 * taps * L.cin_pad, wp.begin() + n_w, 0.f);
+    co0 = L.cout;
+  }
   M_REQUIRE(co0 == L.cout, "ivx_weights_finalize: layer %s: %d output channels loaded, %d expected", L.name.c_str(), co0, L.cout);
   // Winograd candidate (FusedConv: 3x3 on the transformed axes with stride 1, fp32, unpadded Cin, >= 64 channels 3-D / 128 2-D)
   L.wino2d = kd == 1 && kh == 3 && kw == 3 && L.s[0] == 1 && L.s[1] == 1 && L.s[2] == 1;
@@ -666,7 +674,7 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
   // fp16-pair form of the 2-D trunk (cfg.trunk_operands): pair filters + scale / s_w, and the bound terms (also for the layers that
   // stay fp32: the stem's bound scales the max-pool's pair output)
   const bool trunk_layer = L.name.rfind("backbone.", 0) == 0 || L.name.rfind("neck.", 0) == 0;
-  if (m->cfg.trunk_operands == IVX_F16_PAIR && !bf16 && trunk_layer && !L.conv_t && !L.dcn_cols && !L.linear) {
+  if (m->cfg.trunk_operands == IVX_F16_PAIR && !bf16 && trunk_layer && !L.conv_t && !L.linear) {
     L.pair_ok = L.cin_pad == L.cin && L.cin % 32 == 0 && L.cout % 4 == 0;
     std::vector<uint16_t> packed(L.pair_ok ? 2 * n_w : 0);
     std::vector<float> sp(L.pair_ok ? L.cout : 0);
@@ -827,6 +835,15 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
     for (int j = r.s0; j < r.s1; ++j) {
       const Step &q = m->steps[j];
       if (q.in != t) continue;
+      if (j >= m->trunk0 && j < m->trunk1 && q.kind == ST_DCN_COL) {
+        // the column kernel reads pairs when it can also WRITE pairs: the contraction conv has pair filters and 9x the map fits 2 GiB
+        bool ok = ti.elems() * 9 * 4 < (1LL << 31);
+        for (int j2 = j + 1; j2 < r.s1 && ok; ++j2)
+          if (m->steps[j2].in == q.out && (m->steps[j2].kind != ST_CONV || !m->layers[m->steps[j2].layer].pair_ok)) ok = false;
+        if (!ok) return false;
+        any = true;
+        continue;
+      }
       if (j < m->trunk0 || j >= m->trunk1 || q.kind != ST_CONV || !m->layers[q.layer].pair_ok) return false;
       any = true;
     }
@@ -885,7 +902,12 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       case ST_TAIL: break;
       case ST_DCN_COL: {
         const TInfo &om = pl->t[s.res];          // the conv_offset output fixes the output grid
-        o = om; o.C = 9 * in.C;
+        o = om; o.C = 9 * in.C; o.fmt = 0; o.slot = -1;
+        if (in.fmt == IVX_F16_PAIR) {            // (wants_pair let the input be a pair tensor only if the columns can be one too)
+          M_REQUIRE(in.slot >= 0 && wants_pair(s.out, o), "internal: DCNv2 columns of a pair tensor must be a pair tensor");
+          o.fmt = IVX_F16_PAIR; o.slot = n_slots++;
+          pl->ps[i].pio = 1;
+        }
         break;
       }
       case ST_AVGPOOL: o = in; o.D = 1; o.H = 1; o.W = 1; break;
@@ -934,7 +956,7 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       pl->max_det = c.max_num;
       continue;
     }
-    if (s.kind != ST_CONV && s.kind != ST_MAXPOOL && s.kind != ST_IMG2CL) { o.fmt = 0; o.slot = -1; }   // (`o = in` above copies the input's)
+    if (s.kind != ST_CONV && s.kind != ST_MAXPOOL && s.kind != ST_IMG2CL && s.kind != ST_DCN_COL) { o.fmt = 0; o.slot = -1; }   // (`o = in` above copies the input's)
     o.esz = (s.kind == ST_CONV && m->layers[s.layer].out_f32) ? 4 : esz;
     if (s.kind == ST_CONV && m->fp8_on && (m->layers[s.layer].fp8_role == 1 || m->layers[s.layer].fp8_role == 2)) o.esz = 1;
     o.bytes = align256(o.elems() * o.esz);
@@ -1297,8 +1319,12 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
       case ST_DCN_COL: {
         const TInfo &om = pl.t[s.res];
         M_TRY(trace_begin(m, i, 0, 0, 0.0, 4.0 * pl.t[s.out].elems(), "dcn columns", st));
-        M_TRY(ivx_dcn_im2col_fwd((const float *)ptr(s.in), (const float *)ptr(s.res), in.B, in.H, in.W, in.C, 3, 3, s.aux, 1, 1, om.C,
-                                 (float *)ptr(s.out), st));
+        if (pl.ps[i].pio)            // inside the pair chain: pair map in, pair columns out (same scale)
+          M_TRY(ivx_dcn_im2col_fwd_pair(ptr(s.in), scalep(s.in), (const float *)ptr(s.res), in.B, in.H, in.W, in.C, 3, 3, s.aux, 1, 1, om.C,
+                                        ptr(s.out), scalep(s.out), slotp(s.out), st));
+        else
+          M_TRY(ivx_dcn_im2col_fwd((const float *)ptr(s.in), (const float *)ptr(s.res), in.B, in.H, in.W, in.C, 3, 3, s.aux, 1, 1, om.C,
+                                   (float *)ptr(s.out), st));
         M_TRY(trace_end(m, st));
         break;
       }

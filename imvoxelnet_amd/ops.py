@@ -550,6 +550,25 @@ def dcn_im2col(x, offset_mask, kernel=3, stride=1, pad=1, dil=1):
     return col
 
 
+def dcn_im2col_pair(x, offset_mask, kernel=3, stride=1, pad=1, dil=1):
+    """The columns inside the pair chain (ivx_dcn_im2col_fwd_pair): x a PairTensor [B,1,H,W,2C], offset_mask fp32 [B,1,Ho,Wo,>=3*k*k] ->
+    PairTensor [B,1,Ho,Wo,2*k*k*C] with x's scale and its own recorded maximum."""
+    if not isinstance(x, PairTensor):
+        raise TypeError('dcn_im2col_pair takes a PairTensor')
+    _chk(offset_mask, 'offset_mask')
+    B, D, H, W, C2 = x.data.shape
+    Cn = C2 // 2
+    Ho = (H + 2 * pad - (dil * (kernel - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (kernel - 1) + 1)) // stride + 1
+    if D != 1 or Cn % 16 or tuple(offset_mask.shape[:4]) != (B, 1, Ho, Wo):
+        raise ValueError('offset/mask map does not match the output size (or C % 16 != 0)')
+    col = torch.empty((B, 1, Ho, Wo, 2 * kernel * kernel * Cn), device=x.data.device, dtype=torch.float16)
+    slots = new_slots(x.data.device)
+    check(_lib.lib().ivx_dcn_im2col_fwd_pair(_ptr(x.data), _scale_ptr(x.slots), _ptr(offset_mask), B, H, W, Cn, kernel, kernel, stride, pad, dil,
+                                             offset_mask.shape[4], _ptr(col), _scale_ptr(slots), _ptr(slots), _stream()), 'ivx_dcn_im2col_fwd_pair')
+    return PairTensor(col, slots)
+
+
 def upsample_trilinear2x(x):
     if x.dtype not in _DT:
         raise TypeError(f'x must be float32 or bfloat16, got {x.dtype}')

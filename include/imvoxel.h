@@ -257,6 +257,13 @@ int ivx_topk_set_mode(int32_t single_workgroup);
 int ivx_dcn_im2col_fwd(const float *x, const float *offset_mask, int32_t B, int32_t H, int32_t W, int32_t C, int32_t kh,
                        int32_t kw, int32_t stride, int32_t pad, int32_t dil, int32_t om_channels, float *col,
                        ivx_stream_t stream);
+/* The same inside a chain of fp16-pair activations (0.4.0): x is an IVX_F16_PAIR map [B,H,W,2C] with the scale *x_scale (device), col an
+ * IVX_F16_PAIR tensor [B,Ho,Wo,2*kh*kw*C]; the columns keep x's scale (every column is a convex combination of values of x times a mask
+ * in (0, 1)): *col_scale = *x_scale, and max |col| goes to the amax slots col_amax (may be NULL).  The decoded columns are the fp32
+ * columns of the decoded x rounded to the pair format.  C % 16 == 0.  The contraction is ivx_conv_fwd_pio with Cin = kh*kw*C. */
+int ivx_dcn_im2col_fwd_pair(const void *x, const float *x_scale, const float *offset_mask, int32_t B, int32_t H, int32_t W, int32_t C,
+                            int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t dil, int32_t om_channels, void *col,
+                            float *col_scale, uint32_t *col_amax, ivx_stream_t stream);
 
 /* nn.MaxPool2d(kernel, stride, padding) on NHWC (ResNet stem: 3, 2, 1). */
 int ivx_maxpool2d_fwd(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,

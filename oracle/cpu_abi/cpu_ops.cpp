@@ -809,6 +809,24 @@ extern "C" int ivx_dcn_im2col_fwd(const float *x, const float *offset_mask, int3
   return IVX_OK;
 }
 
+// csrc/dcn.hip dcn_im2col_pair_kernel: the columns inside the pair chain -- decode the map, the fp32 columns above, encode with the MAP's scale
+extern "C" int ivx_dcn_im2col_fwd_pair(const void *x, const float *x_scale, const float *offset_mask, int32_t B, int32_t H, int32_t W, int32_t C,
+                                       int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t dil, int32_t om_channels, void *col,
+                                       float *col_scale, uint32_t *col_amax, ivx_stream_t st) {
+  C_REQUIRE(x && x_scale && col && col_scale && C % 16 == 0, "ivx_dcn_im2col_fwd_pair: bad argument");
+  const int K = kh * kw, Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  std::vector<float> xf((size_t)B * H * W * C), cf((size_t)B * Ho * Wo * K * C);
+  c_pair_decode((const uint16_t *)x, (int64_t)B * H * W, C, 1.0f / *x_scale, xf.data());
+  int rc = ivx_dcn_im2col_fwd(xf.data(), offset_mask, B, H, W, C, kh, kw, stride, pad, dil, om_channels, cf.data(), st);
+  if (rc != IVX_OK) return rc;
+  *col_scale = *x_scale;
+  float omax = 0.f;
+  for (float v : cf) omax = fabsf(v) > omax ? fabsf(v) : omax;
+  if (col_amax) c_amax_commit(col_amax, omax);
+  c_pair_encode(cf.data(), (int64_t)B * Ho * Wo, K * C, *x_scale, (uint16_t *)col);
+  return IVX_OK;
+}
+
 // csrc/pool_layout.hip global_avgpool: in [B,S,C] -> out [B,C] (LayoutHead, layout_head.py:42)
 extern "C" int ivx_global_avgpool_fwd(const float *in, int32_t B, int64_t S, int32_t C, float *out, ivx_stream_t) {
   C_REQUIRE(in && out && B > 0 && S > 0 && C > 0, "ivx_global_avgpool_fwd: bad argument");

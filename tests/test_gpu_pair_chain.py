@@ -306,3 +306,35 @@ def test_nonfinite_input_stays_local_in_pair_operands(ia, monkeypatch):
     far[15 - 3:15 + 4, 25 - 3:25 + 4] = False          # stem output (30, 50) +- 2 sees pixel (60, 100); pooled (15, 25) +- 2 sees those
     assert bool(torch.isfinite(bv[0, 0][far]).all())
     assert float((bv[0, 0][far] - av[0, 0][far]).abs().max()) <= 1e-4 * float(av.abs().max())
+
+
+def test_dcn_columns_in_the_pair_chain(ia):
+    """ivx_dcn_im2col_fwd_pair: the DCNv2 columns of a pair map are the fp32 columns of the decoded map rounded to the pair format (the
+    columns keep the map's scale: a convex combination times a mask in (0, 1) cannot exceed max |x|), their recorded maximum is exact, and
+    the contraction over them (FusedConv on the 9 C columns, pair filters) agrees with the fp32 path to 22 bits."""
+    from imvoxelnet_amd import ops
+    from imvoxelnet_amd.conv import FusedConv
+    g = torch.Generator().manual_seed(23)
+    B, H, W, Cn = 2, 29, 50, 64
+    x = (torch.randn(B, 1, H, W, Cn, generator=g) * 1.7).cuda().relu_()
+    for stride in (1, 2):
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        om = torch.randn(B, 1, Ho, Wo, 28, generator=g).cuda()
+        om[..., :18] *= 2.5                                     # offsets of a few pixels, some beyond the border
+        xp = make_pair(x)
+        xd = xp.float()                                         # what the pair map holds
+        ref = ops.dcn_im2col(xd, om, 3, stride, 1, 1)
+        got = ops.dcn_im2col_pair(xp, om, 3, stride, 1, 1)
+        assert isinstance(got, ops.PairTensor) and got.shape == tuple(ref.shape) and got.scale() == xp.scale()
+        gv = got.float()
+        assert float((gv - ref).abs().max()) <= float(ref.abs().max()) * 2.0 ** -21 + 2.0 ** -24 / got.scale()
+        assert got.amax() == float(ref.abs().max())
+        # contraction: 1x1 over K = 9 C, pair filters against fp32 MFMA on the fp32 columns
+        w = torch.randn(64, 9 * Cn, 1, 1, generator=g) * (2.0 / (9 * Cn)) ** 0.5
+        bn = (torch.rand(64, generator=g) + .5, torch.randn(64, generator=g) * .1, torch.randn(64, generator=g) * .1, torch.rand(64, generator=g) + .5)
+        f_pair = FusedConv(w, bn=bn, relu=True, dims=2, chain=True).to('cuda')
+        f_f32 = FusedConv(w, bn=bn, relu=True, dims=2).to('cuda')
+        assert f_pair.pair_ok
+        y_pair = f_pair(got)
+        y_f32 = f_f32(ref)
+        assert_close('DCNv2 contraction on pair columns vs fp32 MFMA on fp32 columns', y_pair, y_f32, 0, 2e-5 * float(y_f32.abs().max()))
