@@ -81,66 +81,68 @@ extern "C" int ivx_dcn_im2col_fwd(const float *x, const float *offset_mask, int3
 __global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const _Float16 *x, const float *x_scale, const float *om, int B, int H, int W, int C,
                                                               int kh, int kw, int stride, int pad, int dil, int Ho, int Wo, int OMC, _Float16 *col,
                                                               float *col_scale, unsigned *amax_out) {
-  // one thread: 8 channels of one (pixel, tap) -- 16 bytes of hi halves and, 32 bytes further, 16 bytes of lo halves per corner and for the
-  // column (the 4-channel form of the fp32 kernel would move 8 bytes per access: 178 us per launch against 127 for the fp32 columns)
+  // one thread: 8 channels of one pixel, the kh * kw taps one after the other -- 16 bytes of hi halves and, 32 bytes further, 16 bytes of lo
+  // halves per corner and for the column.  The corners of a pixel's taps overlap (offsets of a trained net are a few pixels), so walking
+  // the taps in one thread turns most of the 4 x 9 corner reads into L1 hits; with one thread per (pixel, tap) the taps of a pixel sit in
+  // different workgroups and every corner comes from L2.
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
   const int C8 = C >> 3;
   const int KK = kh * kw;
-  const size_t total = (size_t)B * Ho * Wo * KK * C8;
+  const size_t total = (size_t)B * Ho * Wo * C8;
   const float sx = *x_scale;
   if (blockIdx.x == 0 && threadIdx.x == 0) *col_scale = sx;
   float omax = 0.f;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int c8 = (int)(idx % C8);
-    size_t t = idx / C8;
-    const int k = (int)(t % KK);
-    t /= KK;                       // t = output pixel m
+    size_t t = idx / C8;            // t = output pixel m
     const size_t m = t;
     const int wo = (int)(t % Wo);
     t /= Wo;
     const int ho = (int)(t % Ho);
     const int b = (int)(t / Ho);
     const float *o = om + m * OMC;
-    const float dh = o[2 * k], dw = o[2 * k + 1];
-    const float mk = 1.0f / (1.0f + expf(-o[2 * KK + k]));
-    const int i = k / kw, j = k - i * kw;
-    const float h_im = (float)(ho * stride - pad + i * dil) + dh;
-    const float w_im = (float)(wo * stride - pad + j * dil) + dw;
-    float val[8];
+    const int n = c8 * 8;
+    const _Float16 *xb = x + (size_t)b * H * W * (2 * C) + (size_t)((n >> 4) * 32 + (n & 15));
+    for (int k = 0; k < KK; ++k) {
+      const float dh = o[2 * k], dw = o[2 * k + 1];
+      const float mk = 1.0f / (1.0f + expf(-o[2 * KK + k]));
+      const int i = k / kw, j = k - i * kw;
+      const float h_im = (float)(ho * stride - pad + i * dil) + dh;
+      const float w_im = (float)(wo * stride - pad + j * dil) + dw;
+      float val[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) val[q] = 0.f;
-    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-      const int h_high = h_low + 1, w_high = w_low + 1;
-      const float lh = h_im - h_low, lw = w_im - w_low, hh = 1.f - lh, hw = 1.f - lw;
-      const int n = c8 * 8;
-      const _Float16 *xb = x + (size_t)b * H * W * (2 * C) + (size_t)((n >> 4) * 32 + (n & 15));
-      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-      const bool ok1 = h_low >= 0 && w_low >= 0, ok2 = h_low >= 0 && w_high <= W - 1, ok3 = h_high <= H - 1 && w_low >= 0,
-                 ok4 = h_high <= H - 1 && w_high <= W - 1;
-      const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-      auto ld = [&](bool ok, int hy, int wx, int off) {
-        return ok ? *reinterpret_cast<const f16x8 *>(xb + ((size_t)hy * W + wx) * (size_t)(2 * C) + off) : z8;
-      };
-      const f16x8 h1 = ld(ok1, h_low, w_low, 0), l1 = ld(ok1, h_low, w_low, 16), h2 = ld(ok2, h_low, w_high, 0), l2 = ld(ok2, h_low, w_high, 16);
-      const f16x8 h3 = ld(ok3, h_high, w_low, 0), l3 = ld(ok3, h_high, w_low, 16), h4 = ld(ok4, h_high, w_high, 0), l4 = ld(ok4, h_high, w_high, 16);
+      for (int q = 0; q < 8; ++q) val[q] = 0.f;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - h_low, lw = w_im - w_low, hh = 1.f - lh, hw = 1.f - lw;
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const bool ok1 = h_low >= 0 && w_low >= 0, ok2 = h_low >= 0 && w_high <= W - 1, ok3 = h_high <= H - 1 && w_low >= 0,
+                   ok4 = h_high <= H - 1 && w_high <= W - 1;
+        const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto ld = [&](bool ok, int hy, int wx, int off) {
+          return ok ? *reinterpret_cast<const f16x8 *>(xb + ((size_t)hy * W + wx) * (size_t)(2 * C) + off) : z8;
+        };
+        const f16x8 h1 = ld(ok1, h_low, w_low, 0), l1 = ld(ok1, h_low, w_low, 16), h2 = ld(ok2, h_low, w_high, 0), l2 = ld(ok2, h_low, w_high, 16);
+        const f16x8 h3 = ld(ok3, h_high, w_low, 0), l3 = ld(ok3, h_high, w_low, 16), h4 = ld(ok4, h_high, w_high, 0), l4 = ld(ok4, h_high, w_high, 16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float v1 = (float)h1[q] + (float)l1[q], v2 = (float)h2[q] + (float)l2[q], v3 = (float)h3[q] + (float)l3[q], v4 = (float)h4[q] + (float)l4[q];
+          val[q] = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * mk;
+        }
+      }
+      f16x8 hi, lo;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float v1 = (float)h1[q] + (float)l1[q], v2 = (float)h2[q] + (float)l2[q], v3 = (float)h3[q] + (float)l3[q], v4 = (float)h4[q] + (float)l4[q];
-        val[q] = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * mk;
+        omax = fmaxf(omax, fabsf(val[q]));
+        hi[q] = (_Float16)val[q];
+        lo[q] = (_Float16)(val[q] - (float)hi[q]);
       }
+      const int nc = k * C + n;          // channel of the 9 * C columns
+      _Float16 *op = col + m * (size_t)(2 * KK * C) + (size_t)((nc >> 4) * 32 + (nc & 15));
+      *reinterpret_cast<f16x8 *>(op) = hi;
+      *reinterpret_cast<f16x8 *>(op + 16) = lo;
     }
-    f16x8 hi, lo;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      omax = fmaxf(omax, fabsf(val[q]));
-      hi[q] = (_Float16)val[q];
-      lo[q] = (_Float16)(val[q] - (float)hi[q]);
-    }
-    const int nc = k * C + c8 * 8;       // channel of the 9 * C columns
-    _Float16 *op = col + m * (size_t)(2 * KK * C) + (size_t)((nc >> 4) * 32 + (nc & 15));
-    *reinterpret_cast<f16x8 *>(op) = hi;
-    *reinterpret_cast<f16x8 *>(op + 16) = lo;
   }
   if (amax_out) ivx_amax_commit(amax_out, omax / sx, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
 }
@@ -155,7 +157,7 @@ extern "C" int ivx_dcn_im2col_fwd_pair(const void *x, const float *x_scale, cons
   const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
   const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
   IVX_REQUIRE(Ho > 0 && Wo > 0, "ivx_dcn_im2col_fwd_pair: empty output");
-  const size_t total = (size_t)B * Ho * Wo * kh * kw * (C / 8);
+  const size_t total = (size_t)B * Ho * Wo * (C / 8);
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
   hipLaunchKernelGGL(dcn_im2col_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x, x_scale, offset_mask, B, H, W,
