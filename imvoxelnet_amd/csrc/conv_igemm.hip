@@ -1848,6 +1848,165 @@ static void launch_halo(ConvParams &p, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
 }
 
+// z-BLOCKED form of the same GEMM for shallow columns (Z = 3 or 6: the 256- and 128-channel stride-1 layers of the KITTI neck), where the
+// halo kernel multiplies zeros: with z the fastest row index a 32-row MFMA block mixes all z, so the taps that fall outside the column
+// (kz = 0 at z = 0, kz = 2 at z = Z - 1: 2 of the 3 Z tap-slices) are issued and masked -- 22 % of the matrix work at Z = 3, 11 % at
+// Z = 6, on launches whose clock the matrix pipe already pulls down to 1.7 GHz (PMC).  Here a tile is CT = 32 WCOL whole
+// columns and the DMA lanes place plane row m0 + c Z + z at LDS row z CT + c (the lane -> global row map of an LDS-DMA is free): every
+// 32-row block of the staged tile then holds ONE z, a wave owns three consecutive output z-blocks of 32 columns and 32 channels, and a
+// tap whose source block lies outside the column is a wave-uniform skip -- no masks, no zero products, no halo rows (a tile stores every
+// row it stages).  V and M keep their layout: only this kernel's addressing differs.  Per output element the products are accumulated
+// in the halo kernel's order (group by group, tap 0, 1, 2), so the results are bit-identical.
+// Z = output slices per column (3 or 6); SW = z stride (1, or 2 with Z_in = 2 Z: the source block of output block zo and tap kz is
+// SW zo + kz - 1, and only zo = 0, kz = 0 falls outside).
+template <typename T, int Z, int WCOL, int WN, int WPE, int PAIR, int SW = 1>
+__global__ __launch_bounds__(64 * WCOL * (Z / 3) * WN, WPE) void conv_wino_zblk_kernel(const ConvParams p, const unsigned in_bytes, const unsigned w_bytes) {
+  static_assert(Z == 3 || Z == 6, "three output z-blocks per wave");
+  constexpr int ZI = SW * Z;                     // input slices per column
+  constexpr int ZH = Z / 3, NW = WCOL * ZH * WN, NT = 64 * NW;
+  constexpr int CT = WCOL * 32, AR = ZI * CT, BN = WN * 32;
+  constexpr int NS = 2 * SW + 3;                 // source blocks of a wave's three output blocks
+  constexpr int BK = 32, EPC = 8, NCH = 4, RP = NT / NCH;
+  constexpr int APASS = (AR + RP - 1) / RP, BPASS = (3 * BN + RP - 1) / RP;
+  static_assert(AR % 16 == 0 && (3 * BN) % 16 == 0, "a wave's 16 rows of a pass are inside or outside as a whole");
+  constexpr int BUF = (AR + 3 * BN) * BK;
+  __shared__ __attribute__((aligned(16))) T smem[2 * BUF];
+  static_assert(sizeof(smem) >= (size_t)NW * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+  const int cg = wid_u / (ZH * WN), zh = (wid_u / WN) % ZH, nb = wid_u % WN;
+  int mt, nt;
+  {
+    const int Nt = (p.Cout + BN - 1) / BN;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int lt = idx / Nt;
+    nt = idx - lt * Nt;
+    mt = xcd * p.q_total + lt;
+  }
+  const int c0 = mt * CT, n0 = nt * BN;          // first column of the tile
+  const int m0 = c0 * Z;                         // its first OUTPUT row (columns x Z)
+  if (m0 >= p.M) return;
+  const size_t gz = blockIdx.z;
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.in + gz * (size_t)p.g_in * sizeof(T)), 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.wgt + gz * (size_t)p.g_w * sizeof(T)), 0, w_bytes, 0x00020000);
+  const int lr = tid / NCH;
+  const int cc = (tid & (NCH - 1)) ^ ((lr >> 2) & 3);            // the k-chunk this lane fetches (its LDS slot is tid % NCH); RP % 16 == 0
+  const unsigned OOB = 0x80000000u;
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  unsigned a_base[APASS], b_base[BPASS];
+#pragma unroll
+  for (int j = 0; j < APASS; ++j) {
+    const int li = lr + RP * j;                                  // LDS row: z * CT + c
+    const int z = li / CT, c = li - z * CT;
+    const int row = (c0 + c) * ZI + z;                           // input plane row of (column, z)
+    a_base[j] = (li < AR && row < SW * p.M) ? ((unsigned)row * (unsigned)p.Cin + cc * EPC) * (unsigned)sizeof(T) : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < BPASS; ++j) {
+    const int r = lr + RP * j, tap = r / BN, n = n0 + (r - tap * BN);
+    b_base[j] = (r < 3 * BN && n < p.Cout) ? ((unsigned)n * (unsigned)p.K + tap * 64 + cc * EPC) * (unsigned)sizeof(T) : OOB;
+  }
+  const int G = p.Cin / BK;
+  auto load_group = [&](int g, int buf) {
+    T *Ab = smem + buf * BUF + wid_u * (64 / NCH) * BK;     // wave-uniform base; the DMA adds lane * 16 B
+    T *Bb = Ab + AR * BK;
+    const unsigned ka = (unsigned)g * BK * (unsigned)sizeof(T);
+    const unsigned kb = ((unsigned)(g >> 1) * 3u * 64u + (unsigned)(g & 1) * 32u) * (unsigned)sizeof(T);
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      if (RP * j + wid_u * 16 < AR) {                       // (wave-uniform: the last pass may be a partial one)
+        const unsigned vo = a_base[j] == OOB ? OOB : a_base[j] + ka;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + RP * j * BK), 16, vo, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+      if (RP * j + wid_u * 16 < 3 * BN) {
+        const unsigned vo = b_base[j] == OOB ? OOB : b_base[j] + kb;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bb + RP * j * BK), 16, vo, 0, 0, 0);
+      }
+    }
+  };
+  const int rl = lane & 31, fh = lane >> 5, sw = (rl >> 2) & 3;
+  const int z0 = zh * 3;
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  load_group(0, 0);
+  int cur = 0;
+  for (int g = 0; g < G; ++g) {
+    lds_dma_wait_all();                 // this wave's loads of group g have landed; the barrier publishes all waves'
+    __syncthreads();                    // ... and every wave is done reading the other buffer (group g - 1)
+    if (g + 1 < G) load_group(g + 1, cur ^ 1);
+    const T *A0 = smem + cur * BUF + (cg * 32 + rl) * BK;
+    const T *B0 = smem + cur * BUF + AR * BK + (nb * 32 + rl) * BK;
+    f32x4 ah[NS], al[NS];               // source blocks SW z0 - 1 .. SW (z0 + 2) + 1 of this wave's columns
+#pragma unroll
+    for (int s5 = 0; s5 < NS; ++s5) {
+      const int zs = SW * z0 + s5 - 1;
+      if (zs >= 0 && zs < ZI) {
+        const T *rowp = A0 + zs * CT * BK;
+        ah[s5] = *reinterpret_cast<const f32x4 *>(rowp + ((fh ^ sw) * EPC));
+        al[s5] = *reinterpret_cast<const f32x4 *>(rowp + (((2 + fh) ^ sw) * EPC));
+      }
+    }
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      const T *rowp = B0 + kz * BN * BK;
+      const f32x4 bh = *reinterpret_cast<const f32x4 *>(rowp + ((fh ^ sw) * EPC));
+      const f32x4 bl = *reinterpret_cast<const f32x4 *>(rowp + (((2 + fh) ^ sw) * EPC));
+#pragma unroll
+      for (int zo = 0; zo < 3; ++zo) {
+        const int zs = SW * (z0 + zo) + kz - 1;
+        if (zs >= 0 && zs < ZI) {       // (wave-uniform) a tap outside the column is skipped, not multiplied by zeros
+          acc[zo] = pair_mfma<PAIR>(ah[SW * zo + kz], bh, acc[zo]);
+          acc[zo] = pair_mfma<PAIR>(ah[SW * zo + kz], bl, acc[zo]);
+          acc[zo] = pair_mfma<PAIR>(al[SW * zo + kz], bh, acc[zo]);
+        }
+      }
+    }
+    cur ^= 1;
+  }
+  __syncthreads();                      // the staging area of the epilogue overlaps the ring
+  float *stage = reinterpret_cast<float *>(smem) + wid_u * 1024;
+  float *outp = p.out + gz * (size_t)p.g_out;
+  const int col_l = lane & 31, hh = lane >> 5, rrow = lane >> 3, c4 = (lane & 7) * 4;
+  const int nbc = n0 + nb * 32 + c4;
+  const bool nok = nbc < p.Cout;
+#pragma unroll
+  for (int zo = 0; zo < 3; ++zo) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col_l] = acc[zo][r];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + (rrow + 8 * q) * 32 + c4);
+      const int m = m0 + (cg * 32 + rrow + 8 * q) * Z + z0 + zo;      // plane row of (column, z)
+      if (m < p.M && nok) *reinterpret_cast<f32x4 *>(outp + (size_t)m * p.Cout + nbc) = v;
+    }
+  }
+}
+
+template <int Z, int WCOL, int WN, int WPE, int SW = 1>
+static void launch_zblk(ConvParams &p, hipStream_t st) {
+  constexpr int AR = Z * WCOL * 32, BN = WN * 32;          // output rows of a tile
+  const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * 2, w_bytes = (int64_t)p.Cout * p.K * 2;
+  const long long Mt = (p.M + AR - 1) / AR, Nt = (p.Cout + BN - 1) / BN;
+  p.bm = AR;
+  p.q_total = (int)((Mt + 7) / 8); p.q_begin = 0; p.q_count = p.q_total;
+  const dim3 grid((unsigned)(8LL * p.q_total * Nt), 1, p.groups > 1 ? p.groups : 1);
+  auto kern = conv_wino_zblk_kernel<__bf16, Z, WCOL, WN, WPE, 2, SW>;
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WCOL * (Z / 3) * WN), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
+}
+
+static int zblk_wrong_z(int want, int got) {
+  ivx_set_error("ivx_conv_launch_halo: this z-blocked config is built for columns of %d slices, the layer has %d", want, got);
+  return IVX_ERR_INVALID_ARG;
+}
+
 int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st) {
   if (p.in_pair != 2) {
     ivx_set_error("ivx_conv_launch_halo: fp16 pair operands only");
@@ -1883,6 +2042,15 @@ int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st) {
     case 43: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 2, 1, 1>(p, st); break;  // 42 with de-interleaved staging
     case 44: launch_halo<2, 1, 2, 2, 2, 2, 2, 0, 2, 1, 1>(p, st); break;  // 41 with de-interleaved staging
     case 45: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 2, 0, 1>(p, st); break;  // 22 with de-interleaved staging
+    // z-blocked tiles (conv_wino_zblk_kernel; Wo = 3 or 6 only): 50 / 51 = 8 / 16 waves at Z = 3, 60 at Z = 6.  Measured and not kept as
+    // instantiations (profiles/r04_zblk_ab.md): 384 x 64 (8 waves) 1.04, 192 x 64 (4 waves) 1.07, 192 x 256 (16 waves) 1.05, 96 x 128 1.22 ms at
+    // Z = 3 (50: 0.99); at Z = 6: 192 x 64 0.675, 192 x 256 1.08, 384 x 128 0.67 (60: 0.63-0.65); z stride 2: 6 -> 3 slices 64 columns 0.874, 12 -> 6 0.578
+    // (the halo form 42: 0.785 / 0.507)
+    case 50: if (p.Wo != 3) return zblk_wrong_z(3, p.Wo); launch_zblk<3, 2, 4, 4>(p, st); return IVX_OK;   // 192 rows (64 columns) x 128: 72 KB, two per CU
+    case 51: if (p.Wo != 3) return zblk_wrong_z(3, p.Wo); launch_zblk<3, 4, 4, 4>(p, st); return IVX_OK;   // 384 rows x 128, 16 waves: 96 KB, one per CU
+    case 60: if (p.Wo != 6) return zblk_wrong_z(6, p.Wo); launch_zblk<6, 1, 4, 4>(p, st); return IVX_OK;   // 192 rows (32 columns) x 128
+    // z stride 2 (p.W == 2 p.Wo), 6 -> 3 slices: 0.818 ms against 0.785 of the halo form 42 -- an A/B point, not the rule
+    case 71: if (p.Wo != 3 || p.W != 6) return zblk_wrong_z(3, p.Wo); launch_zblk<3, 1, 4, 4, 2>(p, st); return IVX_OK;   // 32 columns x 128
     default:
       ivx_set_error("ivx_conv_launch_halo: unknown config %d", cfg);
       return IVX_ERR_INVALID_ARG;
@@ -2075,6 +2243,18 @@ extern "C" int ivx_conv_fwd(const ivx_conv_desc *d, const void *in, const void *
 
 // Internal (winograd.hip): `groups` independent convolutions of the same shape in ONE launch of the LDS-DMA kernel
 // (grid.z = group), identity epilogue.  `d` describes one group; operands of group g start g*stride elements further.
+// the default rule takes the z-blocked tile (conv_wino_zblk_kernel, config 50) for 3-slice columns with more than 64 output channels
+static bool zblk_rule(const ConvParams &p) { return p.Wo == 3 && p.W == 3 && p.Cout > 64; }
+
+// Fraction of the 3 Z tap-slices a stride-1, pad-1 Winograd-domain GEMM issues under the default rule (for FLOP accounting: the z-blocked
+// tile skips the taps outside the column, the halo tile multiplies zeros there).  d: the LAYER descriptor (W = slices, KW = 3).
+extern "C" float ivx_conv_winograd_issued_fraction(const ivx_conv_desc *d) {
+  if (!d || d->wino_operands != IVX_F16_PAIR || d->KW != 3 || d->sw != 1 || d->pw != 1 || d->W != 3 || d->Cin % 64 || d->Cout <= 64 || d->wgt_layout != 1 ||
+      g_halo_mode >= 0 || g_tile_override != 0)
+    return 1.0f;
+  return 7.0f / 9.0f;
+}
+
 int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w,
                             float *out, long long g_out, hipStream_t st) {
   ConvParams p;
@@ -2091,13 +2271,14 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
   p.groups = groups; p.g_in = g_in; p.g_w = g_w; p.g_out = g_out;
   // z-halo kernel (TU 5): 1x1x3 along z, stride 1, pad 1, chunk-major fp16 pairs -- the ResModule layers of the stack necks
   if (p.in_pair == 2 && p.kmode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 3 && d->sw == 2 && d->pw == 1 && p.W == 2 * p.Wo && p.Cin % 64 == 0 &&
-      ((g_halo_mode >= 21 && g_halo_mode < 30) || g_halo_mode >= 40 || (g_halo_mode < 0 && g_tile_override == 0))) {
+      ((g_halo_mode >= 21 && g_halo_mode < 30) || (g_halo_mode >= 40 && g_halo_mode < 50) || g_halo_mode >= 70 || (g_halo_mode < 0 && g_tile_override == 0))) {
     // (round 4, tools/halo_ab.py, profiles/r04_halo_ab.md: the zero-row form 42 vs 22: 0.494 / 0.790 vs 0.492 / 0.811 ms; de-interleaved staging
     // 43 / 45: equal -- neither the masks nor the bank conflicts are what this kernel waits for)
     return ivx_conv_launch_halo(p, g_halo_mode >= 21 ? g_halo_mode : 42, st);
   }
   if (p.in_pair == 2 && p.kmode == 1 && d->KD == 1 && d->KH == 1 && d->KW == 3 && d->sw == 1 && d->pw == 1 && p.Cin % 64 == 0 &&
-      ((g_halo_mode > 0 && g_halo_mode < 21) || (g_halo_mode >= 30 && g_halo_mode < 40) || (g_halo_mode < 0 && g_tile_override == 0))) {
+      ((g_halo_mode > 0 && g_halo_mode < 21) || (g_halo_mode >= 30 && g_halo_mode < 40) || (g_halo_mode >= 50 && g_halo_mode < 70) ||
+       (g_halo_mode < 0 && g_tile_override == 0))) {
     // measured (tools/pair_ab.py --halo N, profiles/r03b_pair_ab_halo.log; generic kernel 0.73 / 0.90 / 1.41 ms for Cout 64 / 128 / 256):
     // with the 16-row tail pass: 128 x 64 at three per CU 0.57 / 0.84 / 1.44, 256 x 64 0.60-0.64 / 0.83 / 1.33, 256 x 128 0.99 / 0.84 / 1.37,
     // 256 x 256 (16 waves) 1.40-1.44 / 1.19 / 1.24-1.27; every three-buffer ring is slower than its two-buffer form (resident workgroups
@@ -2105,7 +2286,9 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     // 254 x 64 0.51 / 0.72 / 1.23, 254 x 128 (8 waves, two per CU) 0.65 / 0.64 / 1.15, 254 x 256 1.19 / 1.10 / 1.20
     // round 4: the zero-row forms (30 / 33: the fragment ADDRESS of a masked tap selected once per tile instead of 32 v_cndmask per group):
     // 125 x 64 0.487 / 0.756 / 1.410 (= 10), 253 x 128 0.597 / 0.644 / 1.144 (13: 0.607 / 0.653 / 1.167); bit-identical results
-    const int cfg = g_halo_mode > 0 ? g_halo_mode : (p.Cout <= 64 ? 30 : 33);
+    // round 4, z-blocked tiles for 3-slice columns (50: a tap outside the column is skipped instead of multiplied by zeros: 7 of 9
+    // tap-slices): 256 -> 256 at 216 x 248 x 3 0.99 vs 1.135-1.15 ms, bit-identical; at 6 slices (60) 0.626-0.651 vs 0.637-0.650: a wash
+    const int cfg = g_halo_mode > 0 ? g_halo_mode : (p.Cout <= 64 ? 30 : (zblk_rule(p) ? 50 : 33));
     return ivx_conv_launch_halo(p, cfg, st);
   }
   ConvPlan pl = {g_tile_override, 1, 1, 0, 0, 0, 0};

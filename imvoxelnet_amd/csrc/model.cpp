@@ -1203,7 +1203,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           M_TRY(ivx_conv_out_dims(&ps.d, &a_, &b_, &zo));
           const int n = ps.tile + 2;
           const double tiles = (double)o.B * ((ps.d.D + 2 * ps.d.pd - 2 + ps.tile - 1) / ps.tile) * ((ps.d.H + 2 * ps.d.ph - 2 + ps.tile - 1) / ps.tile);
-          span_flops += (ps.d.wino_operands ? 3.0 : 1.0) * 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin;   // as the per-launch records count
+          span_flops += (ps.d.wino_operands ? 3.0 : 1.0) * ivx_conv_winograd_issued_fraction(&ps.d) * 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin;   // as the per-launch records count
         } else {
           span_flops += (ps.pio ? 3.0 : 1.0) * 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2];      // pair form: three products per multiply-add
         }
@@ -1258,7 +1258,8 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
                                              ps.amax_in_n, st));
           M_TRY(trace_end(m, st));
           // flops: the matrix-core products the stage issues (pair operands: hi*hi + hi*lo + lo*hi per multiply-add)
-          M_TRY(trace_begin(m, i, 2, is3d, (ps.d.wino_operands ? 3.0 : 1.0) * 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin, vb + mb, L.name, st));
+          M_TRY(trace_begin(m, i, 2, is3d, (ps.d.wino_operands ? 3.0 : 1.0) * ivx_conv_winograd_issued_fraction(&ps.d) * 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin,
+                            vb + mb, L.name, st));      // (the z-blocked tile skips the taps outside a 3-slice column)
           M_TRY(ivx_conv_winograd_gemm(&ps.d, ps.tile, L.u.at(ps.tile * 8 + ps.d.wino_operands), ws, pl.ws_bytes, st));
           M_TRY(trace_end(m, st));
           M_TRY(trace_begin(m, i, 3, is3d, 0.0, mb + 4.0 * o.elems() * (res ? 2 : 1), L.name, st));

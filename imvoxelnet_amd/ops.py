@@ -278,7 +278,8 @@ def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1
     ev[3].record()
     tiles = B * ((oshape[1] + tile - 1) // tile) * ((oshape[2] + tile - 1) // tile)
     winograd_trace.append(('input', ev[0], ev[1], 0.0))
-    winograd_trace.append(('gemm', ev[1], ev[2], (3.0 if operands else 1.0) * 2.0 * (tile + 2) ** 2 * tiles * oshape[3] * Cout * kw * Cin))
+    frac = float(L.ivx_conv_winograd_issued_fraction(C.byref(d)))      # the z-blocked tile skips the taps outside a 3-slice column
+    winograd_trace.append(('gemm', ev[1], ev[2], (3.0 if operands else 1.0) * frac * 2.0 * (tile + 2) ** 2 * tiles * oshape[3] * Cout * kw * Cin))
     winograd_trace.append(('output', ev[2], ev[3], 0.0))
     return out
 

@@ -191,6 +191,10 @@ int ivx_f16_pair_merge(const void *in, int64_t n, const float *scale_dev, float 
 int ivx_conv_fwd_naive(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
                        const float *shift, const void *res, void *out, ivx_stream_t stream);
 
+/* Fraction of the 3 x slices tap-slices the Winograd-domain GEMM of this layer issues under the library's default kernel rule (FLOP
+ * accounting of bench.py / the stage trace): 7/9 for stride-1, pad-1 layers on 3-slice columns with fp16 pair operands and more than 64
+ * output channels (their z-blocked tile skips the taps outside the column), else 1.  d: the layer descriptor (W = slices). */
+float ivx_conv_winograd_issued_fraction(const ivx_conv_desc *d);
 /* Minimal-filtering (Winograd F(m x m, 3x3), tile m = 2, 4 or 6) form of the same convolution for 3x3xKW kernels with
  * stride 1 on the first two spatial axes (D, H) -- the 3x3x3 layers of the KITTI / nuScenes necks
  * (mmdet3d/models/necks/imvoxelnet.py:99-113,181-230), which are bound by the fp32 MFMA rate: (m+2)^2 instead of 9*m*m

@@ -277,6 +277,7 @@ extern "C" int ivx_f16_pair_merge(const void *in, int64_t n, const float *scale_
 // The minimal-filtering form is a device-side optimisation: the CPU restatement reports "not supported" and the handle
 // (csrc/model.cpp plan_conv) falls back to the direct convolution, as it does for any layer the Winograd entry points refuse.
 extern "C" int ivx_conv_winograd_supported(const ivx_conv_desc *, int32_t) { return 0; }
+extern "C" float ivx_conv_winograd_issued_fraction(const ivx_conv_desc *) { return 1.0f; }
 extern "C" int64_t ivx_conv_winograd_weight_elems(const ivx_conv_desc *, int32_t) { return -1; }
 extern "C" int64_t ivx_conv_winograd_workspace_bytes(const ivx_conv_desc *, int32_t) { return -1; }
 static int no_wino(const char *who) {
