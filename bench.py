@@ -705,11 +705,13 @@ def main():
             'measured_ceilings': dict(ceil, note='csrc/ubench.hip at start-up: MFMA issue rate of the conv kernel\'s instruction, HBM copy rate '
                                                  '(read + written bytes) over 2 x 1 GiB') if ceil else None,
             'exact_fp32_mfma': alt,
-            'roofline': {'bound': 'mfma', 'kernel': ('conv_wino_halo_kernel<fp16 pair operands> (the 8 Winograd-domain GEMMs of the stride-1 / z-stride-2 neck layers) + '
-                                                    'conv_igemm_v4_kernel<fp16 pair operands> (the last, pad-0 layer): %d launches/step' % n_launch) if pair else
+            'roofline': {'bound': 'mfma', 'kernel': ('conv_wino_halo_kernel / conv_wino_zblk_kernel<fp16 pair operands> (the 8 Winograd-domain GEMMs of the stride-1 / '
+                                                    'z-stride-2 neck layers; z-blocked tiles on the 3-slice columns) + conv_igemm_v4_kernel<fp16 pair operands> (the last, '
+                                                    'pad-0 layer): %d launches/step' % n_launch) if pair else
                                                    'conv_igemm_v4_kernel<%s> (3-D neck, %d launches/step)' % ('__bf16' if bf16 else 'float', n_launch),
                          'flops_counted': ('every fp16 MFMA product issued: 3 per fp32-equivalent multiply-add (hi*hi + hi*lo + lo*hi), priced against the dense '
-                                           '16-bit MFMA peak') if pair else 'one MFMA multiply-add per algorithmic multiply-add',
+                                           '16-bit MFMA peak; the z-blocked launches skip the taps outside the column and are counted at the 7/9 they issue '
+                                           '(ivx_conv_winograd_issued_fraction)') if pair else 'one MFMA multiply-add per algorithmic multiply-add',
                          'fp32_equivalent_tflops': round(achieved / 3, 2) if pair else None,
                          'hbm_GBps_algorithmic': round(sum(t[4] for t in mfma) / nst / (mfma_ms * 1e-3) / 1e9, 1) if mfma_ms > 0 else None,
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',

@@ -46,7 +46,7 @@ python tools/pmc_summary.py $OUT/pmc --min-ms 0.3 --json $OUT/pmc.json > $OUT/pm
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.1 --match wino_ --json $OUT/pmc_wino.json > $OUT/pmc_wino.md
 python tools/pmc_summary.py $OUT/pmc --min-ms 0.02 --match "conv_igemm_v4_kernel<__bf16" --json $OUT/pmc_trunk.json > $OUT/pmc_trunk.md
 bash tools/pmc_bench.sh $OUT/pmc_scannet_v1 --config scannet_v1 > $OUT/pmc_scannet_v1.log 2>&1
-python tools/pmc_summary.py $OUT/pmc_scannet_v1 --min-ms 0.1 --match conv_igemm,conv_wino_halo,wino_,backproject --json $OUT/pmc_scannet_v1.json > $OUT/pmc_scannet_v1.md
+python tools/pmc_summary.py $OUT/pmc_scannet_v1 --min-ms 0.1 --match conv_igemm,conv_wino_halo,conv_wino_zblk,wino_,backproject --json $OUT/pmc_scannet_v1.json > $OUT/pmc_scannet_v1.md
 rm -rf $OUT/pmc*/pass*/*.db 2>/dev/null
 find $OUT -name "*.csv" -size +2M -delete
 du -sh $OUT

@@ -19,7 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('dir')
     ap.add_argument('--min-ms', type=float, default=0.0)
-    ap.add_argument('--match', default='conv_igemm,conv_wino_halo', help='comma-separated substrings of the kernel names to keep')
+    ap.add_argument('--match', default='conv_igemm,conv_wino_halo,conv_wino_zblk', help='comma-separated substrings of the kernel names to keep')
     ap.add_argument('--json', default=None)
     a = ap.parse_args()
     agg = collections.defaultdict(lambda: collections.defaultdict(list))

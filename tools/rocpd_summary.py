@@ -33,14 +33,14 @@ def main(path, steps=0):
         print('\n## conv kernel by launch shape\n')
         print('| kernel | grid | calls | avg us |')
         print('|---|---|---|---|')
-        for r in c.execute(f"select {sel}, count(*), avg(end-start) from kernels where ({name} like '%conv_igemm%' or {name} like '%conv_wino_halo%') group by {sel} order by avg(end-start) desc"):
+        for r in c.execute(f"select {sel}, count(*), avg(end-start) from kernels where ({name} like '%conv_igemm%' or {name} like '%conv_wino_halo%' or {name} like '%conv_wino_zblk%') group by {sel} order by avg(end-start) desc"):
             print(f'| `{pretty(r[0])[:60]}` | {r[1:-2]} | {r[-2]} | {r[-1] / 1e3:.1f} |')
 
 
     if steps:
-        gemm = f"({name} like '%conv_igemm%' or {name} like '%conv_wino_halo%')"
+        gemm = f"({name} like '%conv_igemm%' or {name} like '%conv_wino_halo%' or {name} like '%conv_wino_zblk%')"
         big = c.execute(f"select count(*), sum(end-start) from kernels where {gemm} and end-start >= 300000").fetchone()
-        halo = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%conv_wino_halo%'").fetchone()
+        halo = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%conv_wino_halo%' or {name} like '%conv_wino_zblk%'").fetchone()
         gy_ok = gcols and gy and gy in cols
         tail = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%conv_igemm%' and end-start < 300000 and {gy} > 1 and {gx} <= 65536").fetchone() if gy_ok else (0, 0)
         red = c.execute(f"select count(*), sum(end-start) from kernels where {name} like '%splitk_reduce%'").fetchone()
@@ -49,9 +49,9 @@ def main(path, steps=0):
         print(f'\n## 3-D neck reconciliation ({steps} steps profiled)\n')
         print('| launches | per step | ms per step | avg ms |')
         print('|---|---|---|---|')
-        print(f'| GEMM launches >= 0.3 ms of conv_wino_halo_kernel + conv_igemm_v4_kernel (the 9 neck layers: grouped Winograd-domain GEMMs, or direct convs) | {big[0] / steps:.1f} | '
+        print(f'| GEMM launches >= 0.3 ms of conv_wino_halo_kernel / conv_wino_zblk_kernel + conv_igemm_v4_kernel (the 9 neck layers: grouped Winograd-domain GEMMs, or direct convs) | {big[0] / steps:.1f} | '
               f'{(big[1] or 0) / 1e6 / steps:.3f} | {(big[1] or 0) / 1e6 / max(big[0], 1):.4f} |')
-        print(f'| ... of which conv_wino_halo_kernel (all its launches) | {halo[0] / steps:.1f} | {(halo[1] or 0) / 1e6 / steps:.3f} | {(halo[1] or 0) / 1e6 / max(halo[0], 1):.4f} |')
+        print(f'| ... of which conv_wino_halo_kernel + conv_wino_zblk_kernel (all their launches) | {halo[0] / steps:.1f} | {(halo[1] or 0) / 1e6 / steps:.3f} | {(halo[1] or 0) / 1e6 / max(halo[0], 1):.4f} |')
         print(f'| wino_input_kernel launches >= 0.1 ms | {xin[0] / steps:.1f} | {(xin[1] or 0) / 1e6 / steps:.3f} | {(xin[1] or 0) / 1e6 / max(xin[0], 1):.4f} |')
         print(f'| wino_output_kernel / wino_output_buf_kernel launches >= 0.1 ms | {xout[0] / steps:.1f} | {(xout[1] or 0) / 1e6 / steps:.3f} | {(xout[1] or 0) / 1e6 / max(xout[0], 1):.4f} |')
         print(f'| K-split launches (small 2-D layers) | {tail[0] / steps:.1f} | {(tail[1] or 0) / 1e6 / steps:.3f} | |')
