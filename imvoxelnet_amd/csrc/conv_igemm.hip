@@ -2050,7 +2050,7 @@ int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st) {
     case 51: if (p.Wo != 3) return zblk_wrong_z(3, p.Wo); launch_zblk<3, 4, 4, 4>(p, st); return IVX_OK;   // 384 rows x 128, 16 waves: 96 KB, one per CU
     case 60: if (p.Wo != 6) return zblk_wrong_z(6, p.Wo); launch_zblk<6, 1, 4, 4>(p, st); return IVX_OK;   // 192 rows (32 columns) x 128
     // z stride 2 (p.W == 2 p.Wo), 6 -> 3 slices: 0.818 ms against 0.785 of the halo form 42 -- an A/B point, not the rule
-    case 71: if (p.Wo != 3 || p.W != 6) return zblk_wrong_z(3, p.Wo); launch_zblk<3, 1, 4, 4, 2>(p, st); return IVX_OK;   // 32 columns x 128
+    case 71: if (p.Wo != 3 || p.W != 6) return zblk_wrong_z(3, p.Wo); launch_zblk<3, 1, 4, 2, 2>(p, st); return IVX_OK;   // 32 columns x 128 (two waves per SIMD)
     default:
       ivx_set_error("ivx_conv_launch_halo: unknown config %d", cfg);
       return IVX_ERR_INVALID_ARG;

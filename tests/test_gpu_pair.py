@@ -292,6 +292,18 @@ def test_winograd_halo_kernel_matches_generic(ia, shape):
             L.ivx_conv_set_halo_mode(mode)
             got = ops.conv_winograd_fwd(x, u, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=P)
             assert_close(f'halo mode {mode} vs generic', got, ref, 0, 2e-5 * rng)      # measured: max 1e-5, mean 4e-7 of the range
+        # round 4: the zero-row forms (30 .. 34) and the z-blocked tiles (50 / 51 on 3-slice columns, 60 on 6-slice ones) accumulate every
+        # output element's products in the halo kernel's order: bit-identical to it; a z-blocked config on another column height is refused
+        L.ivx_conv_set_halo_mode(13)
+        base = ops.conv_winograd_fwd(x, u, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=P)
+        for mode in (30, 31, 33, 34, 50, 51, 60):
+            L.ivx_conv_set_halo_mode(mode)
+            if (mode in (50, 51) and Z != 3) or (mode == 60 and Z != 6):
+                with pytest.raises(ValueError):
+                    ops.conv_winograd_fwd(x, u, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=P)
+                continue
+            got = ops.conv_winograd_fwd(x, u, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=P)
+            assert torch.equal(got, base), f'halo mode {mode} differs from mode 13'
     finally:
         L.ivx_conv_set_halo_mode(-1)
     tref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).cpu().double(), w.permute(0, 4, 1, 2, 3).cpu().double(), padding=1).permute(0, 2, 3, 4, 1)
@@ -319,6 +331,17 @@ def test_winograd_halo_kernel_stride2_matches_generic(ia, shape):
             L.ivx_conv_set_halo_mode(mode)
             got = ops.conv_winograd_fwd(x, u, None, None, 3, 2, (1, 1, 1), False, wgt_layout=1, operands=P)
             assert_close(f'halo mode {mode} vs generic', got, ref, 0, 2e-5 * rng)
+        # round 4: zero-row (41, 42), de-interleaved staging (43 .. 45) and the z-blocked tile for 6 -> 3 slices (71): bit-identical to mode 22
+        L.ivx_conv_set_halo_mode(22)
+        base = ops.conv_winograd_fwd(x, u, None, None, 3, 2, (1, 1, 1), False, wgt_layout=1, operands=P)
+        for mode in (41, 42, 43, 44, 45, 71):
+            L.ivx_conv_set_halo_mode(mode)
+            if mode == 71 and Z != 6:
+                with pytest.raises(ValueError):
+                    ops.conv_winograd_fwd(x, u, None, None, 3, 2, (1, 1, 1), False, wgt_layout=1, operands=P)
+                continue
+            got = ops.conv_winograd_fwd(x, u, None, None, 3, 2, (1, 1, 1), False, wgt_layout=1, operands=P)
+            assert torch.equal(got, base), f'halo mode {mode} differs from mode 22'
     finally:
         L.ivx_conv_set_halo_mode(-1)
     tref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).cpu().double(), w.permute(0, 4, 1, 2, 3).cpu().double(), stride=(1, 1, 2),

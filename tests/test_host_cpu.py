@@ -1507,6 +1507,38 @@ def test_halo_kernel_row_arithmetic():
         assert lds_of[2 * BM - 1] == 2 * BM - 1                              # the zero row keeps its index
 
 
+def test_zblk_tile_index_arithmetic():
+    """conv_wino_zblk_kernel (csrc/conv_igemm.hip), by enumeration: the DMA places input plane row (c0 + c) ZI + z at LDS row
+    z CT + c, so every 32-row block of the staged tile holds one z; a wave owns output blocks z0 .. z0 + 2 of 32 columns; the source block of
+    output block zo and tap kz is SW zo + kz - 1, inside the column except for the taps the halo kernel masks; every plane row of the tile is
+    staged exactly once and every output row stored exactly once; the products the skipped taps would have been are 2 of 3 Z (stride 1)."""
+    for Z, SW, WCOL in ((3, 1, 2), (3, 1, 4), (6, 1, 1), (3, 2, 1)):
+        ZI, CT = SW * Z, 32 * WCOL
+        c0 = 5 * CT
+        staged = {}
+        for li in range(ZI * CT):
+            z, c = divmod(li, CT)
+            staged[(c0 + c) * ZI + z] = li
+            assert (li // 32) * 32 // CT == z                      # a 32-row block never straddles two z
+        assert sorted(staged) == list(range(c0 * ZI, (c0 + CT) * ZI))
+        stored, issued = set(), 0
+        for cg in range(WCOL):
+            for zh in range(Z // 3):
+                for zo in range(3):
+                    zout = 3 * zh + zo
+                    for kz in range(3):
+                        zs = SW * zout + kz - 1
+                        inside = 0 <= zs < ZI
+                        assert inside == (not ((kz == 0 and zout == 0) or (SW == 1 and kz == 2 and zout == Z - 1)))
+                        issued += inside
+                        if inside:
+                            assert 0 <= SW * zo + kz <= 2 * SW + 2     # index into the wave's NS = 2 SW + 3 source blocks
+                    for col in range(32):
+                        stored.add((c0 + cg * 32 + col) * Z + zout)
+        assert stored == set(range(c0 * Z, (c0 + CT) * Z))
+        assert issued == WCOL * (3 * Z - (2 if SW == 1 else 1))
+
+
 def test_stack_neck_slabs_cover_the_receptive_field():
     """dist.StackNeckSlabs (the x-slab + halo arithmetic of the reduce-scatter exchange) against brute-force dependency
     propagation: for both stack necks and 1 .. 8 ranks, (a) the widened slab [ea, eb) holds every input row the rank's output rows
