@@ -14,11 +14,16 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float *x, const float *om, int B, int H, int W, int C, int kh,
-                                                         int kw, int stride, int pad, int dil, int Ho, int Wo, int OMC, float *col) {
+                                                         int kw, int stride, int pad, int dil, int Ho, int Wo, int OMC, float *col, int xcd_order) {
   const int C4 = C >> 2;
   const int KK = kh * kw;
   const size_t total = (size_t)B * Ho * Wo * KK * C4;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+  size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (xcd_order) {     // one pass, grid rounded up to 8 * per blocks: XCD x takes the x-th contiguous eighth (see dcn_im2col_pair_kernel)
+    const size_t per = gridDim.x >> 3;
+    first = ((size_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3)) * blockDim.x + threadIdx.x;
+  }
+  for (size_t idx = first; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(idx % C4);
     size_t t = idx / C4;
     const int k = (int)(t % KK);
@@ -65,9 +70,11 @@ extern "C" int ivx_dcn_im2col_fwd(const float *x, const float *offset_mask, int3
   IVX_REQUIRE(Ho > 0 && Wo > 0, "ivx_dcn_im2col_fwd: empty output");
   const size_t total = (size_t)B * Ho * Wo * kh * kw * (C / 4);
   size_t blocks = (total + 255) / 256;
-  if (blocks > 256 * 64) blocks = 256 * 64;
+  int xcd_order = 0;
+  if (blocks <= 256 * 256 - 8) { blocks = (blocks + 7) / 8 * 8; xcd_order = 1; }
+  else blocks = 256 * 64;
   hipLaunchKernelGGL(dcn_im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, offset_mask, B, H, W, C, kh, kw,
-                     stride, pad, dil, Ho, Wo, om_channels, col);
+                     stride, pad, dil, Ho, Wo, om_channels, col, xcd_order);
   IVX_CHECK_LAUNCH("ivx_dcn_im2col_fwd");
   return IVX_OK;
 }
