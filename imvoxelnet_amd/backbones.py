@@ -307,7 +307,10 @@ class FPN(nn.Module):
         lat = [None] * n
         # pair chain: a lateral map is written as a PairTensor when its lateral conv read one and an output conv with pair filters reads
         # it (level 0 always; the others only with all_levels) -- maps that are only added top-down stay fp32
-        wp = lambda i: isinstance(feats[i], ops.PairTensor) and self.fout[i].pair_ok and (i == 0 or all_levels)
+        # ... unless that output conv is one of the wide layers on a large map whose Winograd form wins (FusedConv.prefers_winograd)
+        npos = lambda i: feats[i].shape[0] * feats[i].shape[2] * feats[i].shape[3]
+        wp = lambda i: (isinstance(feats[i], ops.PairTensor) and self.fout[i].pair_ok and (i == 0 or all_levels)
+                        and not self.fout[i].prefers_winograd(npos(i)))
         lat[n - 1] = self.flat[n - 1](feats[n - 1], out_pair=wp(n - 1))
         for i in range(n - 2, -1, -1):   # lateral conv + nearest-upsampled coarser level, fused in the epilogue
             res = lat[i + 1]

@@ -408,6 +408,17 @@ class FusedConv:
         ok = ok and ops.conv_winograd_supported(xs, self.cout, wk, wst, wpad, m)
         return (m if ok else 0), xs, wk, wst, wpad
 
+    # a 3x3 layer of the pair chain whose Winograd form (three launches on fp32 tensors, fp16 pair operands in the transformed domain)
+    # beats its direct pair form: wide and on a large map, where the direct form is bound by its 5x as many matrix products (measured,
+    # tools/pio_ab.py: 256 -> 256 at 120x160x50 views 2.25 vs 3.14 ms, at 20 views 1.00 vs 1.30; 256 -> 256 at 30x40x50 0.29 vs 0.21, 128 ->
+    # 128 at 60x80x50 0.36 vs 0.24: the rule below takes only the FPN output conv of the FastIndoor configs).  Mirrored by csrc/model.cpp.
+    WINO_OVER_PAIR_MIN_CH, WINO_OVER_PAIR_MIN_POS = 256, 200000
+
+    def prefers_winograd(self, npos):
+        return (self._wino2d and self.u is not None and FusedConv.winograd and FusedConv.wino_operands == ops.IVX_F16_PAIR
+                and self.cin >= FusedConv.WINO_OVER_PAIR_MIN_CH and self.cout >= FusedConv.WINO_OVER_PAIR_MIN_CH
+                and npos >= FusedConv.WINO_OVER_PAIR_MIN_POS and self.cin % 32 == 0)
+
     def _describe(self, x, tile):
         k, st = 'x'.join(map(str, self.kernel)), ''.join(map(str, self.stride))
         return f'{self.cin}->{self.cout} k{k} s{st} in {tuple(x.shape[:4])}' + (f' F{tile}' if tile else '')

@@ -845,6 +845,13 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
         continue;
       }
       if (j < m->trunk0 || j >= m->trunk1 || q.kind != ST_CONV || !m->layers[q.layer].pair_ok) return false;
+      {   // a wide 3x3 layer on a large map keeps fp32 tensors and runs in its Winograd form with pair operands in the transformed domain
+          // (conv.py FusedConv.prefers_winograd: 256 -> 256 at 120x160x50 2.25 vs 3.14 ms for the direct pair form)
+        const ConvLayer &Lq = m->layers[q.layer];
+        if (Lq.wino2d && Lq.wino_cand && c.winograd && c.wino_operands == IVX_F16_PAIR && Lq.cin >= 256 && Lq.cout >= 256 && Lq.cin % 32 == 0 &&
+            (int64_t)ti.B * ti.H * ti.W >= 200000)
+          return false;
+      }
       any = true;
     }
     return any;

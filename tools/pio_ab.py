@@ -25,7 +25,9 @@ LAYERS = [('64->64 1x1 /4', 64, 64, 1, 1, 4, '', True), ('64->64 3x3 /4', 64, 64
           ('512->512 3x3 s2 /16', 512, 512, 3, 2, 16, '', True), ('1024->2048 1x1 s2 /16', 1024, 2048, 1, 2, 16, '', False),
           ('512->2048 1x1 /32 res', 512, 2048, 1, 1, 32, 'same', True), ('2048->512 1x1 /32', 2048, 512, 1, 1, 32, '', True), ('512->512 3x3 /32', 512, 512, 3, 1, 32, '', True),
           ('2048->64 1x1 /32 lat', 2048, 64, 1, 1, 32, '', False), ('1024->64 1x1 /16 lat', 1024, 64, 1, 1, 16, 'up', False),
-          ('512->64 1x1 /8 lat', 512, 64, 1, 1, 8, 'up', False), ('256->64 1x1 /4 lat', 256, 64, 1, 1, 4, 'up', True), ('64->64 3x3 /4 fpn', 64, 64, 3, 1, 4, '', False)]
+          ('512->64 1x1 /8 lat', 512, 64, 1, 1, 8, 'up', False), ('256->64 1x1 /4 lat', 256, 64, 1, 1, 4, 'up', True), ('64->64 3x3 /4 fpn', 64, 64, 3, 1, 4, '', False),
+          # FastIndoor configs: FPN with 256 channels
+          ('256->256 1x1 /4 lat256', 256, 256, 1, 1, 4, 'up', True), ('256->256 3x3 /4 fpn256', 256, 256, 3, 1, 4, '', False)]
 SETS = {'kitti': (4, 384, 1280), 'views50': (50, 480, 640), 'views20': (20, 480, 640), 'nuscenes': (6, 928, 1600)}
 
 
