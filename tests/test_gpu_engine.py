@@ -185,7 +185,9 @@ def test_c_program_e2e_indoor_without_python(ia):
     assert 'C e2e_indoor OK' in out.stdout
 
 
-@pytest.mark.parametrize('cfg_name,views', [('scannet_fast', 5), ('sunrgbd_fast', 1), ('scannet_v1', 4), ('sunrgbd_total', 1), ('nuscenes_dcn', 6)])
+# ('scannet_fast', 12): 12 x 120 x 160 positions >= 200 000 -- the 256-channel FPN output conv takes its Winograd form in BOTH hosts (wants_pair /
+# FusedConv.prefers_winograd); at 5 views it is a link of the pair chain
+@pytest.mark.parametrize('cfg_name,views', [('scannet_fast', 5), ('scannet_fast', 12), ('sunrgbd_fast', 1), ('scannet_v1', 4), ('sunrgbd_total', 1), ('nuscenes_dcn', 6)])
 def test_native_detect_equals_layerwise(ia, cfg_name, views):
     """The WHOLE of simple_test inside the native handle (round 3): the anchor-free heads + per-level candidates + cross-level NMS
     (ScanNet fast / SUN RGB-D fast / ScanNet v1), the LayoutHead with its predicted angles feeding the unprojection (SUN RGB-D Total),
