@@ -22,6 +22,7 @@
 //   mean    = (sum over valid views in view order) / float(count)  (IEEE divide), 0 if count == 0
 // This file is compiled with -ffp-contract=off.
 #include "ivx_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -40,6 +41,7 @@ struct BpParams {
   int nchunk;   // ceil(C / VEC)
   int lpv_log2; // lanes per voxel = 1 << lpv_log2
   float *pmax;  // single-view lift only: per-workgroup max |volume| goes to pmax[blockIdx.y * gridDim.x + blockIdx.x], or NULL
+  int nblk, q;  // multi-view kernel: voxel blocks per sample and per XCD (grid.x = 8 * q, see the kernel's block order); q = 0: plain order (A/B)
 };
 
 // MEAN = true: the reference's view mean + valid mask.  MEAN = false (view-sharded multi-GPU mode): the raw sum over
@@ -55,7 +57,13 @@ __global__ __launch_bounds__(256) void backproject_mean_kernel(const BpParams p)
   const int g = lane & (lpv - 1);        // lane inside the voxel group
   const int gbase = lane & ~(lpv - 1);   // first lane of the group inside the wave
   const int vox_per_block = 256 >> p.lpv_log2;
-  const int n = blockIdx.x * vox_per_block + (threadIdx.x >> p.lpv_log2);
+  // XCD-aware block order (round 5; for speed only): workgroup w runs on XCD w % 8 (observed dispatch rule) and grid.x = 8 * q, so XCD x
+  // gets the x-th contiguous eighth of a sample's voxel blocks -- an x-slab of the volume, which projects into a band of every view's
+  // map.  Dealt round-robin, every XCD's L2 pulled in the whole gather source (ScanNet, 50 views: 950 MB fetched per scene for 300 MB of
+  // maps + volume, profiles/r04_pmc_scannet_v1.md); the values do not depend on the order.
+  const int vb = p.q ? (int)(blockIdx.x & 7) * p.q + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (vb >= p.nblk) return;              // padding of the last XCD's range (whole workgroups; no barrier in this kernel)
+  const int n = vb * vox_per_block + (threadIdx.x >> p.lpv_log2);
   const bool active = n < p.N;
   const int nn = active ? n : p.N - 1;
 
@@ -240,6 +248,13 @@ __global__ __launch_bounds__(256) void backproject_single_view_kernel(const BpPa
   }
 }
 
+// A/B knob of the block order (IVX_BP_ORDER=0: workgroups in plain voxel order, the round-4 launch)
+static int bp_q(int nblk) {
+  static const int xcd_order = getenv("IVX_BP_ORDER") ? atoi(getenv("IVX_BP_ORDER")) : 1;
+  return xcd_order ? (nblk + 7) / 8 : 0;
+}
+static unsigned bp_grid(const BpParams &p) { return p.q ? 8u * (unsigned)p.q : (unsigned)p.nblk; }
+
 static int backproject_launch(const float *feat, int32_t B, int32_t V, int32_t FH, int32_t FW, int32_t C, const float *proj,
                               const float *new_origin, const int32_t *crop_hw, const float *voxel_size, int32_t X, int32_t Y,
                               int32_t Z, float *volume, uint8_t *valid, int32_t *count, ivx_stream_t stream, float *partials = nullptr) {
@@ -253,6 +268,7 @@ static int backproject_launch(const float *feat, int32_t B, int32_t V, int32_t F
   p.feat = feat; p.proj = proj; p.new_origin = new_origin; p.crop_hw = crop_hw; p.volume = volume; p.valid = valid;
   p.count = count;
   p.pmax = (mean && V == 1) ? partials : nullptr;
+  p.nblk = 0; p.q = 0;
   p.vs0 = voxel_size[0]; p.vs1 = voxel_size[1]; p.vs2 = voxel_size[2];
   p.V = V; p.FH = FH; p.FW = FW; p.C = C; p.X = X; p.Y = Y; p.Z = Z; p.N = X * Y * Z;
   const int vec = (C % 4 == 0) ? 4 : 1;
@@ -264,7 +280,8 @@ static int backproject_launch(const float *feat, int32_t B, int32_t V, int32_t F
   if (!mean) {
     IVX_REQUIRE(vec == 4, "ivx_backproject_sum_fwd: C %% 4 must be 0");
     const int vpb = 256 >> lg;
-    hipLaunchKernelGGL((backproject_mean_kernel<4, false>), dim3((p.N + vpb - 1) / vpb, B), dim3(256), 0, (hipStream_t)stream, p);
+    p.nblk = (p.N + vpb - 1) / vpb; p.q = bp_q(p.nblk);
+    hipLaunchKernelGGL((backproject_mean_kernel<4, false>), dim3(bp_grid(p), B), dim3(256), 0, (hipStream_t)stream, p);
     IVX_CHECK_LAUNCH("ivx_backproject_sum_fwd");
     return IVX_OK;
   }
@@ -279,7 +296,8 @@ static int backproject_launch(const float *feat, int32_t B, int32_t V, int32_t F
     return IVX_OK;
   }
   const int vox_per_block = 256 >> lg;
-  dim3 grid((p.N + vox_per_block - 1) / vox_per_block, B);
+  p.nblk = (p.N + vox_per_block - 1) / vox_per_block; p.q = bp_q(p.nblk);
+  dim3 grid(bp_grid(p), B);
   if (vec == 4)
     hipLaunchKernelGGL(backproject_mean_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else
@@ -343,7 +361,7 @@ extern "C" int ivx_backproject_mean_fwd_bf16(const void *feat, int32_t B, int32_
   IVX_REQUIRE((int64_t)X * Y * Z < (1LL << 31) && (int64_t)B * V * FH * FW < (1LL << 31) && B <= 65535, "ivx_backproject_mean_fwd_bf16: problem too large");
   BpParams p;
   p.feat = (const float *)feat; p.proj = proj; p.new_origin = new_origin; p.crop_hw = crop_hw; p.volume = (float *)volume; p.valid = valid;
-  p.count = nullptr;
+  p.count = nullptr; p.pmax = nullptr;
   p.vs0 = voxel_size[0]; p.vs1 = voxel_size[1]; p.vs2 = voxel_size[2];
   p.V = V; p.FH = FH; p.FW = FW; p.C = C; p.X = X; p.Y = Y; p.Z = Z; p.N = X * Y * Z;
   p.nchunk = C / 4;
@@ -352,7 +370,8 @@ extern "C" int ivx_backproject_mean_fwd_bf16(const void *feat, int32_t B, int32_
   while ((1 << lg) < p.nchunk && lg < 6) ++lg;
   p.lpv_log2 = lg;
   const int vpb = 256 >> lg;
-  hipLaunchKernelGGL((backproject_mean_kernel<4, true, __bf16>), dim3((p.N + vpb - 1) / vpb, B), dim3(256), 0, (hipStream_t)stream, p);
+  p.nblk = (p.N + vpb - 1) / vpb; p.q = bp_q(p.nblk);
+  hipLaunchKernelGGL((backproject_mean_kernel<4, true, __bf16>), dim3(bp_grid(p), B), dim3(256), 0, (hipStream_t)stream, p);
   IVX_CHECK_LAUNCH("ivx_backproject_mean_fwd_bf16");
   return IVX_OK;
 }

@@ -541,6 +541,19 @@ int dev_upload_sync(ivx_model *m, const float *h, size_t n, float **out, hipStre
   return IVX_OK;
 }
 
+// The same for a buffer that is REPLACED (a second ivx_model_calibrate_fp8): the previous device copy is released first -- after a
+// stream synchronisation, a forward in flight may still read it -- instead of piling up in m->owned until ivx_destroy.
+int dev_reupload_sync(ivx_model *m, const float *h, size_t n, float **out, hipStream_t st) {
+  if (*out) {
+    M_HIP(hipStreamSynchronize(st), "hipStreamSynchronize (replacing weights)");
+    auto it = std::find(m->owned.begin(), m->owned.end(), (void *)*out);
+    if (it != m->owned.end()) m->owned.erase(it);
+    (void)hipFree(*out);
+    *out = nullptr;
+  }
+  return dev_upload_sync(m, h, n, out, st);
+}
+
 const HostTensor *find_w(const ivx_model *m, const std::string &key) {
   auto it = m->weights.find(key);
   return it == m->weights.end() ? nullptr : &it->second;
@@ -768,6 +781,10 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
     ps->pio = 1;
     return IVX_OK;
   }
+  // An fp32-input convolution reads its residual as fp32 (or as the storage type): a pair residual here would be read as garbage without
+  // an error (round-4 advisor).  Unreachable with ResNet-50 -- a tensor is a pair only when every INPUT consumer reads pairs, and a
+  // residual's producer and consumer sit in the same bottleneck -- but the format rule must not rest on that.
+  M_REQUIRE(!res || res->fmt == 0, "internal: layer %s has an fp32 input and a pair residual (the pair chain broke between them)", L.name.c_str());
   int tile = 0;
   ivx_conv_desc dw = d;
   if (L.wino_cand && !L.conv_t && m->cfg.winograd && m->cfg.storage == IVX_F32 && (st.res_mode == 0 || st.res_mode == 1) && (int64_t)in.B * in.D * in.H * in.W >= 2000) {
@@ -848,8 +865,10 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       {   // a wide 3x3 layer on a large map keeps fp32 tensors and runs in its Winograd form with pair operands in the transformed domain
           // (conv.py FusedConv.prefers_winograd: 256 -> 256 at 120x160x50 2.25 vs 3.14 ms for the direct pair form)
         const ConvLayer &Lq = m->layers[q.layer];
-        if (Lq.wino2d && Lq.wino_cand && c.winograd && c.wino_operands == IVX_F16_PAIR && Lq.cin >= 256 && Lq.cout >= 256 && Lq.cin % 32 == 0 &&
-            (int64_t)ti.B * ti.H * ti.W >= 200000)
+        // Only the FPN output conv: the bottleneck's conv2 always takes the direct pair form in BOTH hosts (backbones.py _Bottleneck.forward_cl
+        // does not consult prefers_winograd; a rule applied to every wide trunk 3x3 here would let the two copies drift apart at 167+ views).
+        if (Lq.name.rfind("neck.fpn_conv", 0) == 0 && Lq.wino2d && Lq.wino_cand && c.winograd && c.wino_operands == IVX_F16_PAIR && Lq.cin >= 256 &&
+            Lq.cout >= 256 && Lq.cin % 32 == 0 && (int64_t)ti.B * ti.H * ti.W >= 200000)
           return false;
       }
       any = true;
@@ -1308,7 +1327,9 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         M_TRY(trace_begin(m, i, 4, 1, 0.0, (double)in.esz * in.elems() + (double)o.esz * o.elems() + (double)o.elems() / o.C, "unprojection", st));
         if (m->cfg.storage == IVX_BF16) {
           // one view: the lift is a gather-copy (no arithmetic on the features: the reference divides by a count of 1), so a bf16 map
-          // with C channels goes through the fp32 kernel as C / 2 32-bit words; several views: sum and division in fp32 (bf16 kernel)
+          // with C channels goes through the fp32 kernel as C / 2 32-bit words; several views: sum and division in fp32 (bf16 kernel).
+          // (V == 1 takes backproject_single_view_kernel, which only loads and stores the words -- no add, no divide, so no denormal
+          // flush, no -0 -> +0 and no Inf/NaN arithmetic on the bit patterns of bf16 pairs: a bit copy whatever the float mode.)
           if (bd.V == 1 && in.C % 8 == 0)
             M_TRY(ivx_backproject_mean_fwd((const float *)ptr(s.in), o.B, 1, in.H, in.W, in.C / 2, bd.proj, bd.new_origin, bd.crop, m->cfg.voxel_size, o.D,
                                            o.H, o.W, (float *)ptr(s.out), (uint8_t *)ptr(s.out2), st));
@@ -1666,7 +1687,7 @@ extern "C" int ivx_model_calibrate_fp8(ivx_model *m, const float *img, int32_t B
             q[dst] = f32_to_e4m3_bits(src[(size_t)t * L.cin_pad + c] / ws_[co]);
           }
       }
-      M_TRY(dev_upload_sync(m, reinterpret_cast<const float *>(q.data()), (n_w + 3) / 4, &L.wq, st));
+      M_TRY(dev_reupload_sync(m, reinterpret_cast<const float *>(q.data()), (n_w + 3) / 4, &L.wq, st));
     }
     const float r = (float)(s_in / s_out);
     const float so = (float)s_out;
@@ -1675,8 +1696,8 @@ extern "C" int ivx_model_calibrate_fp8(ivx_model *m, const float *img, int32_t B
       sc[co] = (L.scale_h[co] * ws_[co]) * r;                                          // bn_scale * s_w[co] * (s_in / s_out)
       sf[co] = L.shift_h[co] / so;                                                     // bn_shift / s_out
     }
-    M_TRY(dev_upload_sync(m, sc.data(), sc.size(), &L.scale_q, st));
-    M_TRY(dev_upload_sync(m, sf.data(), sf.size(), &L.shift_q, st));
+    M_TRY(dev_reupload_sync(m, sc.data(), sc.size(), &L.scale_q, st));
+    M_TRY(dev_reupload_sync(m, sf.data(), sf.size(), &L.shift_q, st));
     s_prev = s_out;
   }
   m->fp8_on = true;

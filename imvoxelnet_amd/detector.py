@@ -130,7 +130,17 @@ class ImVoxelNet(nn.Module):
         self.trunk_fp8 = 'fp8' if residual == 'fp8' else 'fp8-branches'
         if self._native is not None:
             if residual == 'bf16' and stages is None and self._native.cfg.with_trunk:
-                self._native.calibrate_fp8(x, margin)     # the same mode inside the native handle (its own calibration pass: same maxima)
+                try:
+                    self._native.calibrate_fp8(x, margin)     # the same mode inside the native handle (its own calibration pass: same maxima)
+                except Exception as e:
+                    # (e.g. calibration images whose H / W are not multiples of 32: ivx_model_calibrate_fp8 refuses them.)  The Python
+                    # modules are e4m3 already; a handle left in bf16 would make simple_test run ANOTHER mode than extract_feat without a
+                    # word, so the handle goes and the layer-by-layer composition (the calibrated one) serves every call.
+                    import warnings
+                    self._native.close()
+                    self._native = None
+                    warnings.warn(f'calibrate_fp8: the native handle could not be calibrated ({e}); simple_test runs the layer-by-layer e4m3 composition',
+                                  RuntimeWarning, stacklevel=2)
             else:                                         # forms the handle does not hold: the e4m3 trunk runs layer by layer
                 self._native.close()
                 self._native = None
@@ -244,6 +254,11 @@ class ImVoxelNet(nn.Module):
             # -> unprojection -> neck_3d -> anchor-free head -> per-level candidates -> cross-level NMS; camera set-up inside the library
             out = self._native.detect(img.contiguous(), img_metas)
             boxes, scores, labels, count = out[:4]
+            if gather and self.head_2d is not None and not getattr(self, '_warned_gather', False):
+                import warnings                      # said once: the per-rank result list is returned, nothing is collected
+                self._warned_gather = True
+                warnings.warn('simple_test(gather=True) is not honoured for models with a head_2d (LayoutHead): its angles / layouts are host tensors '
+                              'outside the padded detection block; every rank returns its own results', RuntimeWarning, stacklevel=2)
             if gather and self.head_2d is None:      # sample-sharded ranks: one all-gather of the padded detections, result list on rank 0
                 from .dist import all_gather_detections, is_collecting_rank
                 boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)
@@ -331,7 +346,16 @@ class ImVoxelNet(nn.Module):
         from .necks3d import _StackNeck
         slab_ok = isinstance(self.neck_3d, _StackNeck) and isinstance(self.bbox_head, Anchor3DHead) and self.head_2d is None
         if exchange == 'auto':
-            exchange = 'reduce_scatter' if (slab_ok and _rank_world(None, None)[1] > 1) else 'all_reduce'
+            world = _rank_world(None, None, group)[1]
+            exchange = 'reduce_scatter' if (slab_ok and world > 1) else 'all_reduce'
+            if exchange == 'reduce_scatter':
+                # the slab plan has its own preconditions (x extent a multiple of the neck's x stride, no more ranks than output rows): 'auto'
+                # falls back to the all-reduce form where they fail -- pure index arithmetic, the same decision on every rank
+                from .dist import StackNeckSlabs
+                try:
+                    StackNeckSlabs(self.neck_3d, int(self.n_voxels[0]), world, world - 1)
+                except ValueError:
+                    exchange = 'all_reduce'
         if exchange == 'reduce_scatter':
             if not slab_ok:
                 raise NotImplementedError('the reduce-scatter exchange is built for the stack necks (Kitti / NuScenes) with an Anchor3DHead')

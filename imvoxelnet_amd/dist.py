@@ -28,10 +28,16 @@ def shard_range(n_items, rank, world):
     return start, start + q + (1 if rank < r else 0)
 
 
-def _rank_world(rank, world):
-    """Defaults from the process group; (0, 1) when torch.distributed is not initialised (single process)."""
+def _rank_world(rank, world, group=None):
+    """Defaults from the process group (`group`: a sub-group, whose ranks are numbered 0 .. size-1; None: the default group);
+    (0, 1) when torch.distributed is not initialised (single process)."""
     on = dist.is_available() and dist.is_initialized()
-    return ((dist.get_rank() if on else 0) if rank is None else rank, (dist.get_world_size() if on else 1) if world is None else world)
+    return ((dist.get_rank(group) if on else 0) if rank is None else rank, (dist.get_world_size(group) if on else 1) if world is None else world)
+
+
+def _peer(group, r):
+    """Global rank of group rank r (point-to-point ops address peers by GLOBAL rank, also inside a sub-group)."""
+    return r if group is None else dist.get_global_rank(group, r)
 
 
 def is_collecting_rank(group=None):
@@ -119,6 +125,7 @@ def view_sharded_lift(model, img, img_metas, rank=None, world=None, group=None):
     """The exchange step of the view-sharded mode.  img [B,V,3,H,W] and img_metas are the FULL inputs (present on every
     rank); returns the complete (volume [B,X,Y,Z,C], valid [B,X,Y,Z] bool) on every rank."""
     from . import ops
+    rank, world = _rank_world(rank, world, group)
     img_l, metas_l, (v0, v1) = shard_views(img, img_metas, rank, world)
     if v1 > v0:
         p0 = model.features_2d_cl(img_l)
@@ -182,7 +189,9 @@ def exchange_volume_slabs(vol_sum, count, plans, group=None, rank=None):
     deterministic) -- grouped point-to-point transfers, i.e. an all-to-all over xGMI, which both RCCL and gloo provide.
     Returns (sum_ext [B, eb-ea, Y, Z, C], count_ext [B, eb-ea, Y, Z]) of this rank's widened slab, totals over all ranks."""
     on = dist.is_available() and dist.is_initialized()
-    rank, world = _rank_world(rank, len(plans) if not on else None)
+    rank, world = _rank_world(rank, len(plans) if not on else None, group)
+    if world != len(plans):
+        raise ValueError(f'{len(plans)} slab plans for a group of {world} ranks')
     me = plans[rank]
     mine_v = vol_sum[:, me.ea:me.eb].contiguous()
     mine_c = count[:, me.ea:me.eb].contiguous()
@@ -196,8 +205,9 @@ def exchange_volume_slabs(vol_sum, count, plans, group=None, rank=None):
         sv, sc = vol_sum[:, pr.ea:pr.eb].contiguous(), count[:, pr.ea:pr.eb].contiguous()
         send += [sv, sc]                               # keep alive until the transfers complete
         recv_v[r], recv_c[r] = torch.empty_like(mine_v), torch.empty_like(mine_c)
-        ops_ += [dist.P2POp(dist.isend, sv, r, group), dist.P2POp(dist.isend, sc, r, group),
-                 dist.P2POp(dist.irecv, recv_v[r], r, group), dist.P2POp(dist.irecv, recv_c[r], r, group)]
+        pr_g = _peer(group, r)                         # plans are indexed by GROUP rank; the transfer names the peer's global rank
+        ops_ += [dist.P2POp(dist.isend, sv, pr_g, group), dist.P2POp(dist.isend, sc, pr_g, group),
+                 dist.P2POp(dist.irecv, recv_v[r], pr_g, group), dist.P2POp(dist.irecv, recv_c[r], pr_g, group)]
     for q in dist.batch_isend_irecv(ops_):
         q.wait()
     tot_v, tot_c = None, None
@@ -225,7 +235,7 @@ def all_gather_rows(y, plans, group=None, rank=None):
 def view_sharded_neck_slabs(model, img, img_metas, group=None, rank=None, world=None):
     """View-sharded step up to the neck output with the reduce-scatter exchange (stack necks only): -> [B, X', Y', 1, C] on every rank."""
     from . import ops
-    rank, world = _rank_world(rank, world)
+    rank, world = _rank_world(rank, world, group)
     X = int(model.n_voxels[0])
     plans = [StackNeckSlabs(model.neck_3d, X, world, r) for r in range(world)]
     img_l, metas_l, (v0, v1) = shard_views(img, img_metas, rank, world)

@@ -441,6 +441,27 @@ def test_bench_rccl_path_at_world_size_1(ia):
     assert rec['roofline']['frac'] > 0.2 and rec['roofline']['fp32_equivalent_tflops'] > 160 and rec['measured_ceilings']['hbm_copy_gbps'] > 3000
 
 
+def test_rccl_two_gpus_gather_and_slab_exchange(ia):
+    """First contact with a multi-GPU node (round-4 verdict item 8): two ranks over RCCL -- simple_test(gather=True) on the halves of a
+    batch equals simple_test over the whole batch on one GPU, and the view-sharded step (reduce-scatter over x-slabs / all-reduce) equals
+    the single-GPU call.  On the one-GPU boxes of this pool the same worker runs at world size 1; tests/test_host_cpu.py covers the
+    exchanges between ranks on gloo."""
+    import json
+    n = 2 if torch.cuda.device_count() >= 2 else 1       # one-GPU boxes: the same worker at world size 1 (RCCL group of one rank), so the code runs every round
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', '29541',
+           os.path.join(ROOT, 'tests', 'rccl_worker.py')]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['world'] == n and rec['rccl_ranks'] == n
+    assert rec['gather_len'] == 2 * n and rec['gather_same'] and rec['gather_detections'] > 0
+    assert rec['view_sharded_same']
+
+
 @pytest.mark.parametrize('cfg_name,views', [('scannet_v1', 6), ('scannet_fast', 4), ('sunrgbd_fast', 1), ('kitti', 1)])
 def test_native_bf16_storage_equals_layerwise(ia, cfg_name, views):
     """The optional reduced-precision mode BASELINE config 5 names, INSIDE the model-level C-ABI (ivx_model_cfg.storage = IVX_BF16):

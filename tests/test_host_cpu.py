@@ -589,6 +589,53 @@ def test_slab_exchange_equals_all_reduce_gloo_world2():
         assert np.array_equal(res[r][6], np.array([0.0] * 19 + [1.0] * 19, np.float32))
 
 
+def _subgroup_slab_worker(rank, world, port, out_q):
+    """Rank of a 3-process gloo job whose exchange runs inside the SUB-GROUP {0, 2}: plans are indexed by group rank, the point-to-point
+    transfers must name the peers' GLOBAL ranks (round-4 advisor: exchange_volume_slabs took rank / world from the default group)."""
+    import torch.distributed as dist
+    import imvoxelnet_amd as ia
+    from imvoxelnet_amd import dist as ivd
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    grp = dist.new_group([0, 2])               # (collective: every rank creates it)
+    if rank in (0, 2):
+        neck = ia.KittiImVoxelNeck(8, 16)
+        X = 40
+        gr, gw = ivd._rank_world(None, None, grp)
+        plans = [ivd.StackNeckSlabs(neck, X, gw, r) for r in range(gw)]
+        g = torch.Generator().manual_seed(rank)
+        part = torch.randn(1, X, 4, 3, 8, generator=g)
+        cnt = torch.randint(0, 4, (1, X, 4, 3), generator=g, dtype=torch.int32)
+        sv, sc = ivd.exchange_volume_slabs(part, cnt, plans, group=grp)
+        fv, fc = part.clone(), cnt.clone()
+        dist.all_reduce(fv, group=grp)
+        dist.all_reduce(fc, group=grp)
+        me = plans[gr]
+        out_q.put((rank, gr, gw, sv.numpy(), sc.numpy(), fv[:, me.ea:me.eb].numpy(), fc[:, me.ea:me.eb].numpy()))
+    else:
+        out_q.put((rank, -1, -1, None, None, None, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_exchange_inside_a_subgroup_gloo_world3():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_slab_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert (res[0][1], res[0][2]) == (0, 2) and (res[2][1], res[2][2]) == (1, 2) and res[1][1] == -1
+    for r in (0, 2):
+        assert np.array_equal(res[r][3], res[r][5]) and np.array_equal(res[r][4], res[r][6])
+
+
 @pytest.mark.parametrize('how', ['bare', 'torchrun'])
 def test_bench_launches_n_ranks(how):
     """`python bench.py --gpus 2` starts two ranks by itself (and runs as given under torch.distributed.run, the driver's
