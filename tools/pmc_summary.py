@@ -6,7 +6,7 @@ requests at 64 B, so the read side is doubled before use; WRITE_SIZE is used as 
 algorithmic output bytes of the conv launches exactly)."""
 import os as _os, sys as _sys
 _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
-from _kname import pretty
+from kname import pretty
 import argparse
 import collections
 import csv

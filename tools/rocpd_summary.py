@@ -7,7 +7,7 @@ stride-1 / z-stride-2 layers on fp16 pairs) and `conv_igemm_v4_kernel` (the last
 plus the transforms: the numbers bench.py's event-bracketed `roofline.mfma_launch_ms_per_step` / `neck_ms_per_step` must agree with."""
 import os as _os, sys as _sys
 _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
-from _kname import pretty
+from kname import pretty
 import sqlite3
 import sys
 
