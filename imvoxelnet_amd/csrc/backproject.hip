@@ -57,10 +57,13 @@ __global__ __launch_bounds__(256) void backproject_mean_kernel(const BpParams p)
   const int g = lane & (lpv - 1);        // lane inside the voxel group
   const int gbase = lane & ~(lpv - 1);   // first lane of the group inside the wave
   const int vox_per_block = 256 >> p.lpv_log2;
-  // XCD-aware block order (round 5; for speed only): workgroup w runs on XCD w % 8 (observed dispatch rule) and grid.x = 8 * q, so XCD x
-  // gets the x-th contiguous eighth of a sample's voxel blocks -- an x-slab of the volume, which projects into a band of every view's
-  // map.  Dealt round-robin, every XCD's L2 pulled in the whole gather source (ScanNet, 50 views: 950 MB fetched per scene for 300 MB of
-  // maps + volume, profiles/r04_pmc_scannet_v1.md); the values do not depend on the order.
+  // Optional XCD-contiguous block order (IVX_BP_ORDER=1; round 5, the round-4 verdict's item 5): workgroup w runs on XCD w % 8 (observed
+  // dispatch rule) and grid.x = 8 * q, so XCD x gets the x-th contiguous eighth of a sample's voxel blocks -- an x-slab of the volume.
+  // MEASURED AND NOT ADOPTED (profiles/r05_unprojection_block_order.md): ScanNet, 50 views, 80x80x32: 0.300 -> 0.370 ms per 2 scenes,
+  // FETCH_SIZE 871 -> 928 MB per scene, L2 hits -29 %.  An x-slab is seen by all 50 views (a band of ~1 MB of each 4.9 MB map: 50 MB per
+  // XCD against 4 MB of L2), neighbouring voxels land 4-5 feature pixels apart, and the reuse that exists -- voxels along one camera ray --
+  // is far apart in any voxel order; dealt round-robin the eight XCDs at least walk the same region at the same time, so the Infinity
+  // Cache serves their common lines once.  The values do not depend on the order (bit-exact tests run both).
   const int vb = p.q ? (int)(blockIdx.x & 7) * p.q + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (vb >= p.nblk) return;              // padding of the last XCD's range (whole workgroups; no barrier in this kernel)
   const int n = vb * vox_per_block + (threadIdx.x >> p.lpv_log2);
@@ -248,9 +251,9 @@ __global__ __launch_bounds__(256) void backproject_single_view_kernel(const BpPa
   }
 }
 
-// A/B knob of the block order (IVX_BP_ORDER=0: workgroups in plain voxel order, the round-4 launch)
+// A/B knob of the block order (default 0: workgroups in plain voxel order; IVX_BP_ORDER=1: XCD-contiguous eighths, see the kernel)
 static int bp_q(int nblk) {
-  static const int xcd_order = getenv("IVX_BP_ORDER") ? atoi(getenv("IVX_BP_ORDER")) : 1;
+  static const int xcd_order = getenv("IVX_BP_ORDER") ? atoi(getenv("IVX_BP_ORDER")) : 0;
   return xcd_order ? (nblk + 7) / 8 : 0;
 }
 static unsigned bp_grid(const BpParams &p) { return p.q ? 8u * (unsigned)p.q : (unsigned)p.nblk; }

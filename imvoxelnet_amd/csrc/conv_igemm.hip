@@ -721,7 +721,23 @@ __device__ __forceinline__ f32x16 pair_mfma(const f32x4 a, const f32x4 b, const 
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE, int UNI, int PAIR = 0>
+// s_waitcnt vmcnt(n), n a runtime value in 0 .. 12 (the tail of a deep ring: fewer slabs are outstanding than in the steady state)
+__device__ __forceinline__ void lds_dma_wait_le(const int n) {
+  switch (n) {
+    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
+    case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;      // (waiting for more than needed is always correct)
+  }
+}
+
+// NB (round 5): depth of the LDS ring.  2 = the form described above (prefetch distance two slabs).  With NB buffers the DMA of slab s + NB is
+// issued when slab s retires, so NB slabs are in flight per workgroup: the layers of the 2-D trunk whose launch has fewer tiles than the chip
+// has workgroup slots (every /8 .. /32 layer at KITTI's batch of 4: 240 - 480 tiles of 0.7 - 1.5 us per slab with 6 - 12 MFMAs of work in it)
+// are bound by that latency, and resident workgroups cannot hide it when there are not enough tiles to be resident.  The products are
+// accumulated in the same order: results are bit-identical to NB = 2.
+template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE, int UNI, int PAIR = 0, int NB = 2>
 __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const ConvParams p, const unsigned in_bytes,
                                                                   const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
@@ -737,9 +753,11 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   static_assert(BM % RP == 0 && BN % RP == 0, "tile rows");
   static_assert(WR * WC == 4 || WR * WC == 8 || WR * WC == 16, "4, 8 or 16 waves per workgroup");
   // LDS-DMA staging: rows are BK elements (128 or 64 B), unpadded
-  __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * BK];
+  static_assert(NB == 2 || NB == 4, "ring depth");
+  static_assert(NB == 2 || (AR + BR == 4), "deep ring: the tail waits are written for four DMA instructions per slab and wave");
+  __shared__ __attribute__((aligned(16))) T smem[NB * (BM + BN) * BK];
   T *As = smem;
-  T *Bs = smem + 2 * BM * BK;
+  T *Bs = smem + NB * BM * BK;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -932,16 +950,23 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   // the DMA of slab s+2 is issued into it right there and has the last MFMA group of slab s plus all but the last
   // group of slab s+1 to land (a full slab of MFMA time), instead of being issued only at the top of the next slab.
   load_slab(0);
-  if (S > 1) {
-    advance_k();
-    load_slab(1);
+#pragma unroll
+  for (int j = 1; j < NB; ++j)
+    if (S > j) {
+      advance_k();
+      load_slab(j);
+    }
+  if constexpr (NB == 2) {
+    lds_dma_wait_all();
+  } else {
+    const int newer = (S - 1 < NB - 1) ? S - 1 : NB - 1;      // slabs issued after slab 0
+    lds_dma_wait_le(newer * (AR + BR));
   }
-  lds_dma_wait_all();
-  __syncthreads();   // slabs 0 (and 1) landed in every wave's view
+  __syncthreads();   // slab 0 (NB = 2: and 1) landed in every wave's view
 
   const int frow = (lane & 31) * BK, fsw = ((lane & 31) >> SW_SH) & SW_MSK, fh = lane >> 5;
+  int cur = 0;
   for (int s = 0; s < S; ++s) {
-    const int cur = s & 1;
     const T *Ac = As + cur * BM * BK + wr * TM * 32 * BK + frow;
     const T *Bc = Bs + cur * BN * BK + wc * TN * 32 * BK + frow;
     // one 16-byte read per operand tile and k-step: half-wave h takes chunk 2*kk + h (4 fp32 k -> 4 MFMAs 32x32x2,
@@ -967,9 +992,15 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
       } else {
         // every wave holds its last fragments of buffer `cur`; slab s+1 (other buffer) must have landed: each wave
         // waits for its own DMA (issued one barrier ago), the barrier then publishes all of them
-        lds_dma_wait_all();
+        if constexpr (NB == 2) {
+          lds_dma_wait_all();
+        } else {           // slab s + 1 has landed when only the slabs issued after it are outstanding: min(NB - 2, S - s - 2) of them
+          int newer = S - s - 2;
+          newer = newer < 0 ? 0 : (newer > NB - 2 ? NB - 2 : newer);
+          lds_dma_wait_le(newer * (AR + BR));
+        }
         __syncthreads();
-        if (s + 2 < S) {
+        if (s + NB < S) {
           advance_k();
           load_slab(cur);
         }
@@ -1024,6 +1055,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
                                                                     acc[i][j], 0, 0, 0);
       }
     }
+    cur = cur + 1 == NB ? 0 : cur + 1;
   }
   if (p.ksplit > 1) {
     // raw partial sums; ivx split-K reduce kernel applies the epilogue
@@ -1322,7 +1354,7 @@ static void launch_cfg(const ConvParams &p, hipStream_t st) {
 
 #endif   // IVX_CONV_TU == 0
 
-template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE = 1, int PAIR = 0>
+template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE = 1, int PAIR = 0, int NB = 2>
 static void launch_v4(ConvParams &p, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * sizeof(T);
@@ -1338,8 +1370,17 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
   const dim3 grid((unsigned)g1, p.ksplit > 1 ? p.ksplit : 1, p.groups > 1 ? p.groups : 1);
   // every slab lies inside one filter tap -> uniform K-loop state
   const bool uni = p.kmode == 1 || p.Cin % BK == 0;
-  auto kern = uni ? conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1, PAIR> : conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 0, PAIR>;
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
+  if constexpr (NB > 2) {      // deep ring: the uniform K-loop state only (every pair layer of the trunk: chunk-major filters)
+    if (!uni) {
+      launch_v4<T, TM, TN, WR, WC, BK, WPE, PAIR, 2>(p, st);
+      return;
+    }
+    auto kern = conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1, PAIR, NB>;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
+  } else {
+    auto kern = uni ? conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1, PAIR> : conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 0, PAIR>;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
+  }
 }
 
 
@@ -1408,6 +1449,9 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 76: *t = {256, 64, 32, 4}; return true;
     case 85: *t = {128, 256, 32, 2}; return true;
     case 72: *t = {256, 64, 32, 3}; return true;
+    // deep-ring forms of 66 / 74 (pair operands): NB = 4 -> 64 KB of LDS, two workgroups per CU; NB = 3 -> 48 KB, three
+    case 166: *t = {64, 64, 64, 2}; return true;
+    case 174: *t = {128, 128, 32, 2}; return true;
     default: return false;
   }
 }
@@ -1530,6 +1574,24 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     if (p.Cout <= 64) pl.cfg = p.M >= 400000 ? 76 : (p.M >= 60000 ? 74 : 66);
     else pl.cfg = t128 >= 200 ? 74 : 66;
     small = pl.cfg == 66 && pio_splitk;
+    // Round 5, measured and NOT adopted (IVX_PIO_DEEP=4 turns it on for an A/B; default 0): the deep-ring form of the tile (four slabs in
+    // flight per workgroup instead of two; bit-identical results) for launches with fewer tiles than the chip has workgroup slots.  The
+    // hypothesis -- such launches wait for their slab latency -- did not hold: trunk span 3.91 ms without, 3.98 with (KITTI; ScanNet /
+    // nuScenes equal), and in isolation the 64 KB workgroups run 13 - 25 us SLOWER per launch than the 32 KB ones at every K
+    // (profiles/r05_trunk_deep_ring.md).
+    static const int pio_deep = getenv("IVX_PIO_DEEP") ? atoi(getenv("IVX_PIO_DEEP")) : 0;
+    if (pio_deep == 4) {
+      TileInfo td;
+      tile_info(pl.cfg, &td);
+      const long long tl = (long long)((p.M + td.bm - 1) / td.bm) * ((p.Cout + td.bn - 1) / td.bn);
+      const int Sd = (p.K + td.bk - 1) / td.bk;
+      static const long long split_tiles = getenv("IVX_PIO_SPLIT_TILES") ? atoll(getenv("IVX_PIO_SPLIT_TILES")) : 320;
+      const bool will_split = small && allow_ws && Sd >= 16 && tl <= split_tiles && (tl <= 100 || Sd >= 48);      // (the rule of the split-K block below)
+      if (!will_split && p.kmode == 1 && Sd >= 6 && tl <= 512) {
+        pl.cfg += 100;       // 66 -> 166, 74 -> 174
+        small = false;
+      }
+    }
   }
   TileInfo t;
   if (!tile_info(pl.cfg, &t) || !dma_ok) return pl;
@@ -1596,11 +1658,15 @@ static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     // larger wave tiles: fewer LDS fragment reads per product (the pair loop reads 4 fragments for 3 products; at 16x the fp32 MFMA rate
     // the LDS port, shared by the DMA writes and the fragment reads, is as busy as the matrix pipe)
     case 76: launch_v4<__bf16, 2, 2, 4, 1, 32, 4, PAIR>(p, st); break;   // 256 x 64, wave tile 64 x 64
+    // deep LDS rings (NB = 4: four slabs in flight per workgroup): 64 KB, two per CU.  A/B configs, NOT taken by the rule: measured neutral in the
+    // model (trunk span 3.91 -> 3.98 ms) and slower in isolation (profiles/r05_trunk_deep_ring.md); three-buffer forms measured the same
+    case 166: launch_v4<__bf16, 1, 1, 2, 2, 64, 2, PAIR, 4>(p, st); break;   // 66 (64 x 64, 128-byte rows)
+    case 174: launch_v4<__bf16, 2, 2, 2, 2, 32, 2, PAIR, 4>(p, st); break;   // 74 (128 x 128, 64-byte rows)
     case 85: launch_v4<__bf16, 2, 4, 2, 2, 32, 2, PAIR>(p, st); break;   // 128 x 256, 4 waves, wave tile 64 x 128: no gain over 81 / 82, so the
                                                                          // fragment reads are not what limits the loop (TM = 4 variants: the
                                                                          // compiler keeps the accumulators in scratch, 10x slower; removed)
     default:
-      ivx_set_error("ivx_conv_fwd: tile %d has no pair-operand instantiation (61, 63, 66, 67, 73 .. 76, 81 .. 83, 85)", pl.cfg);
+      ivx_set_error("ivx_conv_fwd: tile %d has no pair-operand instantiation (61, 63, 66, 67, 73 .. 76, 81 .. 83, 85, 166, 174)", pl.cfg);
       return IVX_ERR_INVALID_ARG;
   }
   return IVX_OK;
@@ -2151,7 +2217,8 @@ static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStrea
     ivx_set_error("ivx_conv_fwd: fp8 input is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;
   }
-  if (p.in_bf16 && (!dma_applicable(p) || !(tile_info(pl.cfg, &ti) && pl.cfg >= 61 && pl.cfg < 91))) {
+  const bool deep_cfg = pl.cfg == 166 || pl.cfg == 174;      // deep-ring pair tiles
+  if (p.in_bf16 && (!dma_applicable(p) || !(tile_info(pl.cfg, &ti) && ((pl.cfg >= 61 && pl.cfg < 91) || (deep_cfg && p.in_pair))))) {
     ivx_set_error("ivx_conv_fwd: bf16 input is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;
   }

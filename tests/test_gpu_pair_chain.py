@@ -137,6 +137,64 @@ def test_conv_pio_vs_fp64(ia, case):
     assert abs(rec - float(gv.abs().max())) <= rec * 2.0 ** -20
 
 
+DEEP_CASES = [
+    # B, (H,W), Cin, Cout, k, stride, residual, out_pair -- the /8 .. /32 layer shapes of the KITTI trunk (240 - 480 tiles) and short / odd K loops
+    (4, (24, 80), 1024, 256, 1, 1, '', True), (4, (24, 80), 256, 256, 3, 1, '', True), (4, (24, 80), 256, 1024, 1, 1, 'pair', True),
+    (4, (48, 160), 256, 256, 3, 2, '', True), (4, (12, 40), 2048, 512, 1, 1, '', True), (2, (24, 40), 512, 64, 1, 1, 'up_f32', False),
+    (1, (9, 13), 64, 64, 1, 1, '', True), (1, (9, 13), 96, 64, 3, 1, '', False), (2, (17, 23), 160, 128, 1, 1, 'f32', True),
+]
+
+
+@pytest.mark.parametrize('case', DEEP_CASES)
+def test_deep_ring_tiles_are_bit_identical(ia, case):
+    """Round 5: the deep-ring forms of the pair tiles (conv_igemm_v4_kernel<.., NB = 4>: 166 = 64 x 64, 174 = 128 x 128; A/B configs) issue
+    the same products in the same order as the two-buffer tiles 66 / 74 -- only the DMA of slab s + NB is issued earlier -- so outputs,
+    scales and recorded maxima are equal bit for bit, for K loops shorter than the ring, odd slab counts and every residual form."""
+    from imvoxelnet_amd import _lib, ops
+    L = _lib.lib()
+    B, (H, W), ci, co, k, st, res_kind, out_pair = case
+    g = torch.Generator().manual_seed(ci + 7 * co + k)
+    x = (torch.randn(B, 1, H, W, ci, generator=g).abs_() * 2.0).cuda()
+    w = torch.randn(co, ci, 1, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5
+    scale, shift = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1
+    xp = make_pair(x)
+    packed, sp, wb, sb = ops.pair_pack_filters(w.permute(0, 2, 3, 4, 1).reshape(co, k * k, ci).contiguous(), scale, shift)
+    Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+    res, res_mode = None, 0
+    if res_kind:
+        shp = (B, 1, Ho, Wo, co) if not res_kind.startswith('up') else (B, 1, Ho // 2, Wo // 2, co)
+        rf = (torch.randn(shp, generator=g) * 2.0).cuda()
+        res = make_pair(rf) if res_kind.endswith('pair') else rf
+        if not isinstance(res, ops.PairTensor):
+            res.ivx_slots = ops.new_slots('cuda')
+            res.ivx_slots[:ops.AMAX_SLOTS].view(torch.float32)[3] = float(rf.abs().max())
+        res_mode = 2 if res_kind.startswith('up') else 0
+    args = (xp, packed.cuda(), sp.cuda(), shift.cuda(), (1, k, k), (1, st, st), (0, k // 2, k // 2), True, wb, sb)
+
+    def run(cfg):
+        L.ivx_conv_set_tile_override(cfg)
+        try:
+            y = ops.conv_fwd_pio(*args, res=res, res_mode=res_mode, out_pair=out_pair)
+            torch.cuda.synchronize()
+            return y
+        finally:
+            L.ivx_conv_set_tile_override(0)
+
+    for base, deep in ((66, (166,)), (74, (174,))):
+        want = run(base)
+        for cfg in deep:
+            got = run(cfg)
+            if out_pair:
+                assert got.scale() == want.scale() and torch.equal(got.data, want.data), (base, cfg)
+                assert torch.equal(got.slots, want.slots), (base, cfg)
+            else:
+                assert torch.equal(got, want) and torch.equal(got.ivx_slots, want.ivx_slots), (base, cfg)
+    auto = run(0)                      # the library's own choice: same bits as tile 66 / 74 ...
+    gv = auto.float() if out_pair else auto
+    wv = want.float() if out_pair else want
+    assert_close('default plan vs tile 74', gv, wv, 0, 1e-5 * float(wv.abs().max()))      # ... or to accumulation order when it splits K
+
+
 def test_maxpool_pair_and_image_amax(ia):
     """ivx_nchw_to_nhwc_amax records max |image|; ivx_maxpool2d_fwd_pair == the fp32 pool, written as pairs with the scale of the bound."""
     from imvoxelnet_amd import ops
