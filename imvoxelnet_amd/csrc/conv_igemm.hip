@@ -35,6 +35,8 @@ int ivx_conv_launch_lowp(ConvParams &p, const ConvPlan &pl, hipStream_t st);
 int ivx_conv_launch_pair_bf16(ConvParams &p, const ConvPlan &pl, hipStream_t st);
 int ivx_conv_launch_pair_f16(ConvParams &p, const ConvPlan &pl, hipStream_t st);
 int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st);    // TU 5: the z-halo kernel of the Winograd-domain GEMMs (pair operands)
+int ivx_conv_launch_fold4(ConvParams &p, const IvxWinoFold &f, int n2, hipStream_t st);    // TU 5: GEMM + output transform of F(4x4,3x3) fused
+int ivx_conv_fold4_blocks(long long M, int Cout);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -721,14 +723,25 @@ __device__ __forceinline__ f32x16 pair_mfma(const f32x4 a, const f32x4 b, const 
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// s_waitcnt vmcnt(n), n a runtime value in 0 .. 12 (the tail of a deep ring: fewer slabs are outstanding than in the steady state)
+// s_waitcnt vmcnt(n), n a runtime value in 0 .. 15 (the tail of a deep ring: fewer slabs are outstanding than in the steady state)
 __device__ __forceinline__ void lds_dma_wait_le(const int n) {
   switch (n) {
-    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+    case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
     case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
+    case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
+    case 7: __builtin_amdgcn_s_waitcnt(0x0f77); break;
     case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
+    case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0x0f7a); break;
+    case 11: __builtin_amdgcn_s_waitcnt(0x0f7b); break;
     case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
-    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;      // (waiting for more than needed is always correct)
+    case 13: __builtin_amdgcn_s_waitcnt(0x0f7d); break;
+    case 14: __builtin_amdgcn_s_waitcnt(0x0f7e); break;
+    case 15: __builtin_amdgcn_s_waitcnt(0x0f7f); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;      // 0 (and anything larger: waiting for more than needed is always correct)
   }
 }
 
@@ -753,8 +766,8 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   static_assert(BM % RP == 0 && BN % RP == 0, "tile rows");
   static_assert(WR * WC == 4 || WR * WC == 8 || WR * WC == 16, "4, 8 or 16 waves per workgroup");
   // LDS-DMA staging: rows are BK elements (128 or 64 B), unpadded
-  static_assert(NB == 2 || NB == 4, "ring depth");
-  static_assert(NB == 2 || (AR + BR == 4), "deep ring: the tail waits are written for four DMA instructions per slab and wave");
+  static_assert(NB >= 2 && NB <= 4, "ring depth");
+  static_assert(NB == 2 || (NB - 1) * (AR + BR) <= 15, "deep ring: vmcnt immediates of the tail waits");
   __shared__ __attribute__((aligned(16))) T smem[NB * (BM + BN) * BK];
   T *As = smem;
   T *Bs = smem + NB * BM * BK;
@@ -962,7 +975,15 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
     const int newer = (S - 1 < NB - 1) ? S - 1 : NB - 1;      // slabs issued after slab 0
     lds_dma_wait_le(newer * (AR + BR));
   }
-  __syncthreads();   // slab 0 (NB = 2: and 1) landed in every wave's view
+  // (NB > 2: a RAW barrier -- the workgroup fence of __syncthreads() waits for vmcnt(0), i.e. for every request of the ring, which makes
+  // any ring deeper than two a two-deep one: seen in the ISA, round 5.  The clobbers keep LDS accesses on their side of it.)
+  if constexpr (NB == 2) {
+    __syncthreads();   // slabs 0 and 1 landed in every wave's view
+  } else {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
 
   const int frow = (lane & 31) * BK, fsw = ((lane & 31) >> SW_SH) & SW_MSK, fh = lane >> 5;
   int cur = 0;
@@ -999,7 +1020,14 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
           newer = newer < 0 ? 0 : (newer > NB - 2 ? NB - 2 : newer);
           lds_dma_wait_le(newer * (AR + BR));
         }
-        __syncthreads();
+        if constexpr (NB == 2) {
+          __syncthreads();
+        } else {           // this wave's fragment reads of slab s are complete (they sit in registers: the compiler waited for them)
+          __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
         if (s + NB < S) {
           advance_k();
           load_slab(cur);
@@ -1574,12 +1602,13 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     if (p.Cout <= 64) pl.cfg = p.M >= 400000 ? 76 : (p.M >= 60000 ? 74 : 66);
     else pl.cfg = t128 >= 200 ? 74 : 66;
     small = pl.cfg == 66 && pio_splitk;
-    // Round 5, measured and NOT adopted (IVX_PIO_DEEP=4 turns it on for an A/B; default 0): the deep-ring form of the tile (four slabs in
-    // flight per workgroup instead of two; bit-identical results) for launches with fewer tiles than the chip has workgroup slots.  The
-    // hypothesis -- such launches wait for their slab latency -- did not hold: trunk span 3.91 ms without, 3.98 with (KITTI; ScanNet /
-    // nuScenes equal), and in isolation the 64 KB workgroups run 13 - 25 us SLOWER per launch than the 32 KB ones at every K
-    // (profiles/r05_trunk_deep_ring.md).
-    static const int pio_deep = getenv("IVX_PIO_DEEP") ? atoi(getenv("IVX_PIO_DEEP")) : 0;
+    // Round 5: a launch with fewer tiles than the chip has workgroup slots (every /8 .. /32 layer of the trunk at KITTI's batch of 4: 240 - 480
+    // tiles) cannot hide its slab latency behind other resident workgroups; it takes the deep-ring form of its tile (166 / 174: FOUR slabs
+    // in flight per workgroup, raw barriers; bit-identical results) unless the split-K rule below takes it.  Measured (profiles/
+    // r05_trunk_deep_ring.md): trunk span 3.85 -> 3.39 ms at KITTI; tiles <= 512 is the best threshold (1024 / 2048 / all: 3.61 -- above one
+    // tile per slot the 64 KB workgroups lose more occupancy than the depth returns).  The first form of the deep ring kept __syncthreads(),
+    // whose fence waits for vmcnt(0): no effect in the model and +25 us per launch in isolation.  IVX_PIO_DEEP=0 turns the rule off (A/B).
+    static const int pio_deep = getenv("IVX_PIO_DEEP") ? atoi(getenv("IVX_PIO_DEEP")) : 4;
     if (pio_deep == 4) {
       TileInfo td;
       tile_info(pl.cfg, &td);
@@ -1587,7 +1616,9 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
       const int Sd = (p.K + td.bk - 1) / td.bk;
       static const long long split_tiles = getenv("IVX_PIO_SPLIT_TILES") ? atoll(getenv("IVX_PIO_SPLIT_TILES")) : 320;
       const bool will_split = small && allow_ws && Sd >= 16 && tl <= split_tiles && (tl <= 100 || Sd >= 48);      // (the rule of the split-K block below)
-      if (!will_split && p.kmode == 1 && Sd >= 6 && tl <= 512) {
+      static const long long deep_tiles = getenv("IVX_PIO_DEEP_TILES") ? atoll(getenv("IVX_PIO_DEEP_TILES")) : 512;
+      static const int deep_slabs = getenv("IVX_PIO_DEEP_SLABS") ? atoi(getenv("IVX_PIO_DEEP_SLABS")) : 6;
+      if (!will_split && p.kmode == 1 && Sd >= deep_slabs && tl <= deep_tiles) {
         pl.cfg += 100;       // 66 -> 166, 74 -> 174
         small = false;
       }
@@ -1658,10 +1689,12 @@ static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     // larger wave tiles: fewer LDS fragment reads per product (the pair loop reads 4 fragments for 3 products; at 16x the fp32 MFMA rate
     // the LDS port, shared by the DMA writes and the fragment reads, is as busy as the matrix pipe)
     case 76: launch_v4<__bf16, 2, 2, 4, 1, 32, 4, PAIR>(p, st); break;   // 256 x 64, wave tile 64 x 64
-    // deep LDS rings (NB = 4: four slabs in flight per workgroup): 64 KB, two per CU.  A/B configs, NOT taken by the rule: measured neutral in the
-    // model (trunk span 3.91 -> 3.98 ms) and slower in isolation (profiles/r05_trunk_deep_ring.md); three-buffer forms measured the same
+    // deep LDS rings (NB = 4: four slabs in flight per workgroup, raw barriers): 64 KB, two per CU -- the rule's choice for launches of at
+    // most 512 tiles (plan_conv; profiles/r05_trunk_deep_ring.md)
     case 166: launch_v4<__bf16, 1, 1, 2, 2, 64, 2, PAIR, 4>(p, st); break;   // 66 (64 x 64, 128-byte rows)
     case 174: launch_v4<__bf16, 2, 2, 2, 2, 32, 2, PAIR, 4>(p, st); break;   // 74 (128 x 128, 64-byte rows)
+    // (measured and removed, profiles/r05_trunk_deep_ring.md: 74 with three buffers for launches of 513 .. 4096 tiles: trunk 3.44 -> 3.57 ms; on the
+    // last neck layer's grouped GEMM 81 / 76 / 74 with three or four buffers: 0.66 / 0.67 / 0.74 / 0.62 ms against 0.57 of tile 82)
     case 85: launch_v4<__bf16, 2, 4, 2, 2, 32, 2, PAIR>(p, st); break;   // 128 x 256, 4 waves, wave tile 64 x 128: no gain over 81 / 82, so the
                                                                          // fragment reads are not what limits the loop (TM = 4 variants: the
                                                                          // compiler keeps the accumulators in scratch, 10x slower; removed)
@@ -2123,6 +2156,333 @@ int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st) {
   }
   return IVX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: the Winograd-domain GEMM of an F(4x4, 3x3) layer with its OUTPUT TRANSFORM AND EPILOGUE FUSED -- M never reaches HBM.
+// (Round-4 verdict item 1; reference layers: mmdet3d/models/necks/imvoxelnet.py:94-123, the ResModule convolutions of the stack necks.)
+// A workgroup owns BM - 2 = 62 rows (tile column, z) x 64 output channels for ALL 36 frequency points xi.  It walks xi = (i, j), j fastest;
+// for each xi the z-halo K loop of conv_wino_halo_kernel (one staged tile serves the three z-taps; hi*hi + hi*lo + lo*hi per 16-channel pair
+// group) leaves M[xi] of its tile in 16 accumulator registers per lane, which are folded into the output domain right away:
+//     P[e]      += At[e][j] * M[i][j]          (e = 0 .. 3; after the six j of a row i:)
+//     out[a][e] += At[a][i] * P[e]             (a = 0 .. 3)        ->  out = At M A  in 16 + 4 + 1 accumulator tiles instead of 36
+// -- an all-xi workgroup that kept M itself would hold 36 tiles (576 registers per lane at this tile size).  The groups of all xi form ONE
+// stream of 36 * Cin / 16 iterations through an NBUF-deep LDS ring (16 KB per group: 64 rows of V[xi] and the three taps' 64 filter rows of
+// U[xi]), so the pipeline fills once per tile, not once per xi.  The epilogue transposes each of the 16 output tiles through LDS and applies
+// the scales of the pair operands, BN scale / shift, residual and ReLU exactly as wino_output_kernel does, writing 16-byte pieces of the
+// channels-last output, and leaves the workgroup's max |out| for the next layer's operand scale.
+// Cost: the filters of all 36 xi are re-read (from L2) by every row tile: 36 x 12 KB x Cin / 16 per 62 rows; V is read once per 64 output
+// channels.  One workgroup per CU (64 KB of LDS, > 256 registers per lane: the accumulators spill into the AGPR half of the file).
+__constant__ float kWinoAt4[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
+
+__device__ __forceinline__ float fold4_vscale(const float amax) {      // == winograd.hip wino_pair_vscale: 2^k with 256 amax 2^k in [2^14, 2^15)
+  if (!(amax < 3.0e38f)) return 0.00390625f;
+  if (!(amax > 0.f)) return 1.0f;
+  int e;
+  (void)frexpf(amax, &e);
+  int k = 15 - 8 - e;
+  k = k < -120 ? -120 : (k > 120 ? 120 : k);
+  return ldexpf(1.0f, k);
+}
+
+template <int PAIR, int NA, int NB>
+__global__ __launch_bounds__(256, 1) void conv_wino_fold4_kernel(const ConvParams p, const IvxWinoFold f, const unsigned in_bytes, const unsigned w_bytes) {
+  typedef __bf16 T;
+  constexpr int BM = 64, BN = 64, NT = 256, BK = 32, EPC = 8, NCH = 4, RP = NT / NCH;
+  constexpr int BMO = BM - 2;                       // rows a tile stores (consecutive tiles overlap by two staged rows)
+  // Two rings with their own depths: the rows of V[xi] come from HBM (every byte is read once: 2 - 4 us under load), the filter rows of
+  // U[xi] from L2 (all 36 banks are re-read by every row tile), and with one wave per SIMD nothing but the ring hides either.  An A slot
+  // holds the 64 staged rows and one row that is ALWAYS ZERO (row 64: the DMA never writes it): a lane whose z - 1 / z + 1 neighbour lies
+  // outside the column reads that tap's fragments from it -- an address chosen once -- instead of masking 8 registers per group.
+  constexpr int ASL = (BM + 1) * BK, BSL = 3 * BN * BK;   // elements per slot of the A ring (4160 B) / of the B ring (12 KB)
+  constexpr int NXI = 36;
+  static_assert(RP == BM && RP == BN, "one pass of the workgroup's lanes covers the A rows / one tap of the B rows");
+  static_assert(NA >= NB && NB >= 3 && (NB - 2) * 4 <= 15, "vmcnt immediates; the A ring runs at least as far ahead as the B ring");
+  __shared__ __attribute__((aligned(16))) T smem[NA * ASL + NB * BSL];
+  __shared__ float wmax[4];
+  static_assert(sizeof(smem) >= 4 * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
+  T *const As = smem, *const Bs = smem + NA * ASL;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  int mt, nt;
+  {
+    const int Nt = (p.Cout + BN - 1) / BN;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int lt = idx / Nt;
+    nt = idx - lt * Nt;
+    mt = xcd * p.q_total + lt;
+  }
+  if (mt * BMO >= p.M) {                            // padding of the last XCD's range
+    if (f.pmax && tid == 0) f.pmax[blockIdx.x] = 0.f;
+    return;
+  }
+  const int m0 = mt * BMO, n0 = nt * BN;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, in_bytes, 0x00020000);     // all 36 planes of V
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, w_bytes, 0x00020000);      // all 36 filter banks
+  const int lr = tid / NCH;
+  const int cc = (tid & (NCH - 1)) ^ ((lr >> 2) & 3);
+  const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+  const unsigned OOB = 0x80000000u;
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  typedef __attribute__((address_space(3))) T *lds_t;
+  // A: LDS row lr of a slot holds plane row m0 - 1 + lr;  B: LDS row t * BN + lr of a slot holds filter row n0 + lr of tap t (chunk-major K).
+  // The per-lane part of a request's address never changes (voffset); the group / xi part is a wave-uniform running byte offset (soffset).
+  const int arow = m0 - 1 + lr;
+  const unsigned a_vo = (arow >= 0 && arow < p.M) ? ((unsigned)arow * (unsigned)p.Cin + cc * EPC) * 2u : OOB;
+  unsigned b_vo[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) b_vo[t] = (n0 + lr < p.Cout) ? ((unsigned)(n0 + lr) * (unsigned)p.K + t * 64 + cc * EPC) * 2u : OOB;
+  const int G = p.Cin / BK;                                   // 16-channel pair groups per xi
+  const unsigned xi_in = (unsigned)p.g_in * 2u, xi_w = (unsigned)p.g_w * 2u;      // byte strides between the xi planes / filter banks
+  const int NIT = NXI * G;
+  // zero rows of the A slots
+  for (int t = tid; t < NA * 16; t += NT) reinterpret_cast<float *>(smem)[(t >> 4) * (ASL / 2) + BM * (BK / 2) + (t & 15)] = 0.f;
+  // request cursors (all wave-uniform): byte offset of the next group inside V / U, its group index inside the xi, its ring slot
+  unsigned sa = 0, sb = 0;
+  int ga = 0, gb = 0, slot_a = 0, slot_b = 0;
+  const unsigned a_lds0 = (unsigned)(uintptr_t)(lds_t)As + (unsigned)(wid_u * (64 / NCH) * BK * 2);
+  const unsigned b_lds0 = (unsigned)(uintptr_t)(lds_t)Bs + (unsigned)(wid_u * (64 / NCH) * BK * 2);
+  auto issue_a = [&]() {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(uintptr_t)(a_lds0 + (unsigned)slot_a * (ASL * 2)), 16, a_vo, sa, 0, 0);
+    sa += BK * 2;
+    if (++ga == G) { ga = 0; sa += xi_in - (unsigned)G * (BK * 2); }
+    slot_a = slot_a + 1 == NA ? 0 : slot_a + 1;
+  };
+  auto issue_b = [&]() {
+    const unsigned l = b_lds0 + (unsigned)slot_b * (BSL * 2);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(uintptr_t)(l + t * RP * BK * 2), 16, b_vo[t], sb, 0, 0);
+    // next group of the chunk-major K order: the second half of a 32-channel chunk lies 64 bytes on, the next chunk 3 * 128 bytes after the chunk's start
+    sb += (gb & 1) ? (3 * 128 - 64) : 64;
+    if (++gb == G) { gb = 0; sb += xi_w - (unsigned)(G >> 1) * (3 * 128); }
+    slot_b = slot_b + 1 == NB ? 0 : slot_b + 1;
+  };
+  auto skip_a = [&]() {                                       // advance the A cursor by one group without a request
+    sa += BK * 2;
+    if (++ga == G) { ga = 0; sa += xi_in - (unsigned)G * (BK * 2); }
+    slot_a = slot_a + 1 == NA ? 0 : slot_a + 1;
+  };
+  const int rl = lane & 31, fh = lane >> 5;
+  const int Z = p.Wo;
+  const int zl = (m0 + wr * 32 + rl) % Z;                     // z of this lane's output row
+  const bool ok0 = zl >= 1, ok2 = zl + 1 < Z;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // The 16 output-domain tiles live in the AGPR half of the register file (every access below goes through v_accvgpr_read / _write with
+  // an "a" operand), the four row accumulators P, the product tile and everything the group loop touches in VGPRs: left to itself the
+  // compiler put `out` into VGPRs and P / the product tile into AGPRs, i.e. the moves on the per-xi path instead of the per-row path.
+  float outa[4][4][16];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(outa[a][e][r]));
+  f32x16 acc, P[4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) P[e] = acc;
+  // Prologue: requests in the order the steady state leaves behind (one A and three B requests per group, group after group; the A ring
+  // runs NA - NB groups further ahead, so its extra requests are the OLDEST): A of groups NB - 1 .. NA - 2 first, then (A, B) of 0 .. NB - 2.
+  {
+    for (int k = 0; k < NB - 1; ++k) skip_a();
+    for (int k = NB - 1; k < NA - 1; ++k) issue_a();           // (NIT >= 36 > NA)
+    const unsigned e_sa = sa; const int e_ga = ga, e_slot = slot_a;
+    sa = 0; ga = 0; slot_a = 0;
+    for (int k = 0; k < NB - 1; ++k) { issue_a(); issue_b(); }
+    sa = e_sa; ga = e_ga; slot_a = e_slot;                     // next A request: group NA - 1
+  }
+  // group 0 (and the zero rows) has landed when only the (A, B) pairs of groups 1 .. NB - 2 are younger.  No __syncthreads() from here to
+  // the epilogue: its fence waits for vmcnt(0), i.e. for every request of the rings (the first form of this kernel ran at the full memory
+  // latency per group whatever the ring depth -- as every deeper ring tried in this library did).  RAW barriers, bracketed by compiler-level
+  // memory clobbers; a wave's fragment reads of a group are complete when it arrives (its MFMAs consumed them).
+  __builtin_amdgcn_s_waitcnt(0x0070 | ((NB - 2) * 4));        // vmcnt(..) lgkmcnt(0): the zero-row stores too
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // Fragment reads as inline asm: the compiler's wait-count pass puts s_waitcnt vmcnt(0) in front of any LDS read it can see while an
+  // LDS-DMA request is in flight (it cannot tell the ring slots apart).  Byte offsets of this lane's fragments inside a slot (hi chunk fh,
+  // lo chunk 2 + fh, XOR-swizzled by the row as the DMA lanes wrote them); a masked tap points at the slot's zero row.
+  const unsigned as_lds = (unsigned)(uintptr_t)(lds_t)As, bs_lds = (unsigned)(uintptr_t)(lds_t)Bs;
+  unsigned aoh[3], aol[3];
+#pragma unroll
+  for (int kz = 0; kz < 3; ++kz) {
+    const int ar = rl + kz, asw = (ar >> 2) & 3;              // A rows of tap kz: slot row o + kz (row 0 is plane row m0 - 1)
+    const bool ok = kz == 0 ? ok0 : (kz == 2 ? ok2 : true);
+    aoh[kz] = ok ? (unsigned)(((wr * 32 + ar) * BK + ((fh ^ asw) * EPC)) * 2) : (unsigned)(BM * BK * 2);
+    aol[kz] = ok ? (unsigned)(((wr * 32 + ar) * BK + (((2 + fh) ^ asw) * EPC)) * 2) : (unsigned)(BM * BK * 2);
+  }
+  const int bsw = (rl >> 2) & 3;
+  const unsigned boh = (unsigned)(((wc * 32 + rl) * BK + ((fh ^ bsw) * EPC)) * 2), bol = (unsigned)(((wc * 32 + rl) * BK + (((2 + fh) ^ bsw) * EPC)) * 2);
+#define FOLD_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  unsigned abase = as_lds, bbase = bs_lds;                    // slot bases of the current group
+  int it = 0;
+  // Three nested loops (i, j, group) over ONE request stream: the innermost touches only the product tile and the fragments.
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) {
+      for (int gq = 0; gq < G; ++gq, ++it) {
+        f32x4 ah[3], al[3], bh[3], bl[3];
+        {
+          const unsigned b0 = bbase + boh, b1 = bbase + bol;
+          FOLD_DS_READ(ah[0], abase + aoh[0], 0); FOLD_DS_READ(al[0], abase + aol[0], 0);
+          FOLD_DS_READ(bh[0], b0, 0);             FOLD_DS_READ(bl[0], b1, 0);
+          FOLD_DS_READ(ah[1], abase + aoh[1], 0); FOLD_DS_READ(al[1], abase + aol[1], 0);
+          FOLD_DS_READ(bh[1], b0, BN * BK * 2);   FOLD_DS_READ(bl[1], b1, BN * BK * 2);
+          FOLD_DS_READ(ah[2], abase + aoh[2], 0); FOLD_DS_READ(al[2], abase + aol[2], 0);
+          FOLD_DS_READ(bh[2], b0, 2 * BN * BK * 2); FOLD_DS_READ(bl[2], b1, 2 * BN * BK * 2);
+        }
+        // LDS returns in order: tap 0's four fragments are there when eight reads are outstanding, and so on (the operands tie the MFMAs
+        // to the wait).  The four requests that refill the slots group it - 1 left (A: group it + NA - 1, B: group it + NB - 1) are issued
+        // BETWEEN the MFMAs: an LDS-DMA instruction holds the issuing wave for 60 - 180 cycles, which only its own matrix work can cover.
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
+        acc = pair_mfma<PAIR>(ah[0], bh[0], acc);
+        acc = pair_mfma<PAIR>(ah[0], bl[0], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + NA - 1 < NIT) issue_a();
+        __builtin_amdgcn_sched_barrier(0);
+        acc = pair_mfma<PAIR>(al[0], bh[0], acc);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[1]), "+v"(al[1]), "+v"(bh[1]), "+v"(bl[1]));
+        acc = pair_mfma<PAIR>(ah[1], bh[1], acc);
+        acc = pair_mfma<PAIR>(ah[1], bl[1], acc);
+        acc = pair_mfma<PAIR>(al[1], bh[1], acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[2]), "+v"(al[2]), "+v"(bh[2]), "+v"(bl[2]));
+        acc = pair_mfma<PAIR>(ah[2], bh[2], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + NB - 1 < NIT) issue_b();
+        __builtin_amdgcn_sched_barrier(0);
+        acc = pair_mfma<PAIR>(ah[2], bl[2], acc);
+        acc = pair_mfma<PAIR>(al[2], bh[2], acc);
+        // group it + 1 must have landed: younger are the requests of groups it + 2 .. it + NB - 1 (B ring) with their A partners while
+        // the A ring still issues
+        if (it + 1 < NIT) {
+          if (it + NA - 1 < NIT) __builtin_amdgcn_s_waitcnt(0x0f70 | ((NB - 2) * 4));         // steady state
+          else if (it + NB - 1 < NIT) __builtin_amdgcn_s_waitcnt(0x0f70 | ((NB - 2) * 3));    // the A ring has run dry: only B requests are younger
+          else lds_dma_wait_all();
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_s_barrier();   // group it + 1 is visible to every wave; every wave is done with the slots of group `it`
+          asm volatile("" ::: "memory");
+        }
+        abase = abase + ASL * 2 == as_lds + NA * ASL * 2 ? as_lds : abase + ASL * 2;
+        bbase = bbase + BSL * 2 == bs_lds + NB * BSL * 2 ? bs_lds : bbase + BSL * 2;
+      }
+      // M[xi] of this tile is complete (xi = 6 i + j): fold it into the row accumulators
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float c = kWinoAt4[e][j];
+        if (c != 0.f) P[e] = c * acc + P[e];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+    // the six j of row i are in: out[a][e] += At[a][i] * P[e]
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float c = kWinoAt4[a][i];
+      if (c != 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float t;
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(outa[a][e][r]));
+            t = __builtin_fmaf(c, P[e][r], t);
+            asm("v_accvgpr_write_b32 %0, %1" : "=a"(outa[a][e][r]) : "v"(t));
+          }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) P[e][r] = 0.f;
+  }
+  __syncthreads();                      // the staging area of the epilogue overlaps the rings
+  // ---- epilogue: out[a][e] is the (4 tx + a, 4 ty + e) output of the tile rows; as wino_output_kernel: v = act(M * sc + sf [+ res])
+  float *stage = reinterpret_cast<float *>(smem) + wid_u * 1024;
+  const float mscale = 1.0f / (fold4_vscale(__uint_as_float(f.hdr_v[0])) * f.uscale[0]);
+  const int col_l = lane & 31, hh = lane >> 5, rrow = lane >> 3, c4 = (lane & 7) * 4;
+  const int nb = n0 + wc * 32 + c4;
+  const bool nok = nb < p.Cout;
+  f32x4 sc = {mscale, mscale, mscale, mscale}, sf = {0.f, 0.f, 0.f, 0.f};
+  if (nok && f.scale) sc = mscale * *reinterpret_cast<const f32x4 *>(f.scale + nb);
+  if (nok && f.shift) sf = *reinterpret_cast<const f32x4 *>(f.shift + nb);
+  size_t base[4];
+  int xlim[4], ylim[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = wr * 32 + rrow + 8 * q, m = m0 + o;
+    xlim[q] = 0; ylim[q] = 0; base[q] = 0;
+    if (o < BMO && m < p.M && nok) {
+      const int z = m % Z, col = m / Z;
+      const int ty = col % f.TY, t2 = col / f.TY;
+      const int tx = t2 % f.TX, b = t2 / f.TX;
+      base[q] = ((((size_t)b * f.Xo + 4 * tx) * f.Yo + 4 * ty) * Z + z) * (size_t)f.Co + nb;
+      xlim[q] = f.Xo - 4 * tx;
+      ylim[q] = f.Yo - 4 * ty;
+    }
+  }
+  const size_t ystep = (size_t)Z * f.Co, xstep = (size_t)f.Yo * ystep;
+  float omax = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float t;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(outa[a][e][r]));
+        stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col_l] = t;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(stage + (rrow + 8 * q) * 32 + c4);
+        if (a < xlim[q] && e < ylim[q]) {
+          const size_t o = base[q] + a * xstep + e * ystep;
+          v = v * sc + sf;
+          f32x4 rr = zero4;
+          if (f.res_mode) rr = *reinterpret_cast<const f32x4 *>(f.res + o);
+          if (f.res_mode && !f.res_after_act) v += rr;
+          if (f.relu) {
+            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+          }
+          if (f.res_mode && f.res_after_act) v += rr;
+          v *= f.post_scale;
+          *reinterpret_cast<f32x4 *>(f.out + o) = v;
+          omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+      }
+    }
+  if (f.pmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+    if (lane == 0) wmax[wid_u] = omax;
+    __syncthreads();
+    if (tid == 0) f.pmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  }
+}
+
+// workgroups of the fused launch for M rows and Cout channels (= entries of its partial-maximum array)
+int ivx_conv_fold4_blocks(long long M, int Cout) {
+  const long long Mt = (M + 61) / 62, Nt = (Cout + 63) / 64;
+  return (int)(8 * ((Mt + 7) / 8) * Nt);
+}
+
+int ivx_conv_launch_fold4(ConvParams &p, const IvxWinoFold &f, int n2, hipStream_t st) {
+  if (p.in_pair != 2 || n2 != 36 || p.kmode != 1 || p.Cin % 64 != 0 || p.K != 3 * p.Cin) {
+    ivx_set_error("ivx_conv_launch_fold4: fp16 pair operands, F(4x4,3x3), chunk-major filters, Cin %% 32 == 0 and a 3-tap z kernel only");
+    return IVX_ERR_INVALID_ARG;
+  }
+  const long long in_bytes = (long long)n2 * p.g_in * 2, w_bytes = (long long)n2 * p.g_w * 2;
+  if (in_bytes >= (1LL << 31) || w_bytes >= (1LL << 31)) {
+    ivx_set_error("ivx_conv_launch_fold4: the %d transformed planes must stay below 2 GiB together", n2);
+    return IVX_ERR_UNSUPPORTED;
+  }
+  const long long Mt = (p.M + 61) / 62, Nt = (p.Cout + 63) / 64;
+  p.bm = 62;
+  p.q_total = (int)((Mt + 7) / 8); p.q_begin = 0; p.q_count = p.q_total;
+  const dim3 grid((unsigned)(8LL * p.q_total * Nt));
+  hipLaunchKernelGGL((conv_wino_fold4_kernel<2, 16, 5>), grid, dim3(256), 0, st, p, f, (unsigned)in_bytes, (unsigned)w_bytes);      // A ring 16 slots, B ring 5: 124 KB (8 + 4 and 20 + 5 slots measured the same)
+  return IVX_OK;
+}
 #endif
 
 #if IVX_CONV_TU == 1
@@ -2392,6 +2752,20 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     return IVX_ERR_INVALID_ARG;
   }
   return launch_one(p, pl, st);
+}
+
+// Internal (winograd.hip): the n2 = 36 Winograd-domain convolutions of an F(4x4,3x3) layer with the output transform and the layer's epilogue
+// fused into the launch (conv_wino_fold4_kernel).  `d` describes one xi convolution (as for ivx_conv_grouped_launch).
+int ivx_conv_grouped_fold4(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w, const IvxWinoFold *f,
+                           hipStream_t st) {
+  ConvParams p;
+  float dummy;
+  int rc = fill_params(d, in, wgt, nullptr, nullptr, nullptr, &dummy, &p);
+  if (rc != IVX_OK) return rc;
+  IVX_REQUIRE(d->in_dtype == IVX_F16_PAIR && d->KD == 1 && d->KH == 1 && d->KW == 3 && d->sw == 1 && d->pw == 1 && d->wgt_layout == 1 && f && f->out,
+              "ivx_conv_grouped_fold4: fp16 pair operands, 1x1x3 along z with stride 1 and padding 1, chunk-major filters");
+  p.groups = groups; p.g_in = g_in; p.g_w = g_w; p.g_out = 0;
+  return ivx_conv_launch_fold4(p, *f, groups, st);
 }
 
 extern "C" int64_t ivx_conv_workspace_bytes(const ivx_conv_desc *d) {

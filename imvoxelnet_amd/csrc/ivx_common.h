@@ -27,6 +27,19 @@ void ivx_set_error(const char *fmt, ...);
 
 static inline int64_t ivx_align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// Epilogue description of the fused Winograd GEMM + output transform (conv_igemm.hip conv_wino_fold4_kernel; filled by winograd.hip):
+// out[b, 4 tx + a, 4 ty + e, z, :] = act((At M A)[a][e] * mscale * scale + shift [+ res]) with M accumulated on chip.
+struct IvxWinoFold {
+  float *out;
+  const float *res, *scale, *shift;
+  const unsigned *hdr_v;     // device: bits of max |layer input| (the operand scale of V is derived from it as in winograd.hip)
+  const float *uscale;       // device: the filter scale chosen by ivx_conv_winograd_weights
+  float *pmax;               // per-workgroup max |out| (the next layer's operand scale), or NULL
+  int B, TX, TY, Z, Xo, Yo, Co;
+  int relu, res_mode, res_after_act;
+  float post_scale;
+};
+
 #if defined(__HIPCC__)
 // Power-of-two scale of an fp16 (hi, lo) pair tensor (IVX_F16_PAIR): s = 2^k with amax * s in [2^14, 2^15); 1 for 0 / non-finite amax.
 __device__ __forceinline__ float ivx_pow2_scale(const float amax) {

@@ -20,6 +20,9 @@
 
 int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w,
                             float *out, long long g_out, hipStream_t st);
+int ivx_conv_grouped_fold4(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w, const IvxWinoFold *f,
+                           hipStream_t st);
+int ivx_conv_fold4_blocks(long long M, int Cout);
 
 namespace {
 
@@ -830,6 +833,54 @@ extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *d, int32_t tile, cons
     return IVX_ERR_HIP;
   }
   IVX_CHECK_LAUNCH("ivx_conv_winograd_gemm");
+  return IVX_OK;
+}
+
+// ---- F(4x4,3x3) on fp16-pair operands with the output transform fused into the GEMM launch (conv_igemm.hip conv_wino_fold4_kernel): the
+// second and third stage of ivx_conv_winograd_fwd in one kernel, M stays on chip.  Same workspace as the three-stage form (V + header; the
+// M region is not touched), so ivx_conv_winograd_input[_amax] is its first stage unchanged.
+extern "C" int ivx_conv_winograd_fused_supported(const ivx_conv_desc *d, int32_t tile) {
+  WinoDims w;
+  if (tile != 4 || !d || d->wino_operands != IVX_F16_PAIR || d->KW != 3 || d->sw != 1 || d->pw != 1 || d->wgt_layout != 1 || d->Cin % 32 || d->Cout % 4)
+    return 0;
+  if (!ivx_conv_winograd_supported(d, tile) || wino_dims(d, tile, &w, "ivx_conv_winograd_fused_supported") != IVX_OK) return 0;
+  if ((int64_t)w.n2 * w.v_stride * 4 >= (1LL << 31) || (int64_t)w.n2 * d->Cout * d->KW * d->Cin * 4 >= (1LL << 31)) return 0;   // one buffer resource over all planes
+  return 1;
+}
+
+extern "C" int32_t ivx_conv_winograd_fused_blocks(const ivx_conv_desc *d, int32_t tile) {
+  WinoDims w;
+  if (!ivx_conv_winograd_fused_supported(d, tile) || wino_dims(d, tile, &w, "ivx_conv_winograd_fused_blocks") != IVX_OK) return -1;
+  return ivx_conv_fold4_blocks((long long)d->B * w.TX * w.TY * w.Zo, d->Cout);
+}
+
+extern "C" int ivx_conv_winograd_gemm_output_amax(const ivx_conv_desc *d, int32_t tile, const float *u, const float *scale, const float *shift,
+                                                  const void *res, void *out, void *workspace, int64_t workspace_bytes, float *partials,
+                                                  ivx_stream_t stream) {
+  WinoDims w;
+  WinoP p;
+  float dummy;
+  IVX_REQUIRE(u && out, "ivx_conv_winograd_gemm_output: null argument");
+  IVX_REQUIRE(!d || d->res_mode == 0 || res, "ivx_conv_winograd_gemm_output: res_mode set but res is NULL");
+  if (!ivx_conv_winograd_fused_supported(d, tile)) {
+    ivx_set_error("ivx_conv_winograd_gemm_output: the fused form takes F(4x4,3x3) on IVX_F16_PAIR operands, a 3-tap z kernel with stride 1 and padding 1, "
+                  "wgt_layout 1, Cin %% 32 == 0, and all 36 planes of V below 2 GiB (ivx_conv_winograd_fused_supported)");
+    return IVX_ERR_UNSUPPORTED;
+  }
+  int rc = wino_setup(d, tile, &dummy, scale, shift, res, out, workspace, workspace_bytes, &w, &p, "ivx_conv_winograd_gemm_output");
+  if (rc != IVX_OK) return rc;
+  ivx_conv_desc g = wino_group_desc(d, w);
+  g.in_dtype = d->wino_operands;
+  IvxWinoFold f;
+  f.out = p.out; f.res = p.res; f.scale = p.scale; f.shift = p.shift;
+  f.hdr_v = p.hdr;
+  f.uscale = u + (int64_t)w.n2 * d->Cout * d->KW * d->Cin + 1;        // the filter scale travels with the filters (ivx_conv_winograd_weights)
+  f.pmax = partials;
+  f.B = d->B; f.TX = w.TX; f.TY = w.TY; f.Z = w.Zo; f.Xo = w.Xo; f.Yo = w.Yo; f.Co = d->Cout;
+  f.relu = p.relu; f.res_mode = p.res_mode; f.res_after_act = p.res_after_act; f.post_scale = p.post_scale;
+  rc = ivx_conv_grouped_fold4(&g, w.n2, p.V, 2 * w.v_stride, u, 2LL * d->Cout * d->KW * d->Cin, &f, (hipStream_t)stream);
+  if (rc != IVX_OK) return rc;
+  IVX_CHECK_LAUNCH("ivx_conv_winograd_gemm_output");
   return IVX_OK;
 }
 

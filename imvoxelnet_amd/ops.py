@@ -213,7 +213,7 @@ winograd_trace = None
 
 
 def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1, 1, 1), relu=False, res=None, out=None,
-                      wgt_layout=0, res_after_act=False, post_scale=1.0, operands=0, amax_in=None, want_amax=False):
+                      wgt_layout=0, res_after_act=False, post_scale=1.0, operands=0, amax_in=None, want_amax=False, fused=False):
     """Same result as conv_fwd for a 3x3xkw kernel with stride (1,1,stride_w), computed in the F(m x m, 3x3) minimal-filtering
     form (fp32).  x [B,D,H,W,Cin]; u from conv_winograd_weights (its first dimension, 16 / 36 / 64, selects m = 2 / 4 / 6)."""
     _chk(x, 'x')
@@ -246,6 +246,20 @@ def conv_winograd_fwd(x, u, scale=None, shift=None, kw=3, stride_w=1, padding=(1
     if wsb < 0:
         check(-1, 'ivx_conv_winograd_workspace_bytes')
     ws = torch.empty((wsb,), device=x.device, dtype=torch.uint8)
+    if fused:
+        # F(4x4,3x3) pair operands: GEMM + output transform in one launch, M on chip (ivx_conv_winograd_gemm_output_amax)
+        if not L.ivx_conv_winograd_fused_supported(C.byref(d), tile):
+            raise ValueError('this layer does not take the fused GEMM + output form (ivx_conv_winograd_fused_supported)')
+        part = None
+        if want_amax:
+            part = torch.empty((L.ivx_conv_winograd_fused_blocks(C.byref(d), tile),), device=x.device, dtype=torch.float32)
+        if amax_in is not None:
+            _chk(amax_in, 'amax_in')
+        check(L.ivx_conv_winograd_input_amax(C.byref(d), tile, _ptr(x), _ptr(ws), wsb, _ptr(amax_in), 0 if amax_in is None else amax_in.numel(),
+                                             _stream()), 'ivx_conv_winograd_input_amax')
+        check(L.ivx_conv_winograd_gemm_output_amax(C.byref(d), tile, _ptr(u), _ptr(scale), _ptr(shift), _ptr(res), _ptr(out), _ptr(ws), wsb, _ptr(part),
+                                                   _stream()), 'ivx_conv_winograd_gemm_output_amax')
+        return (out, part) if want_amax else out
     if amax_in is not None or want_amax:
         # chained layers (ivx_conv_winograd_output_amax / _input_amax): amax_in = the producer's per-workgroup maxima of x;
         # want_amax: also return this layer's own -> (out, partials)

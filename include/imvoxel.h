@@ -233,6 +233,19 @@ int ivx_conv_winograd_output_amax(const ivx_conv_desc *d, int32_t tile, const fl
                                   void *workspace, int64_t workspace_bytes, float *partials, ivx_stream_t stream);
 int ivx_conv_winograd_input_amax(const ivx_conv_desc *d, int32_t tile, const void *in, void *workspace, int64_t workspace_bytes,
                                  const float *partials, int32_t n_partials, ivx_stream_t stream);
+/* F(4x4,3x3) on IVX_F16_PAIR operands with the GEMM stage and the output stage fused into ONE launch (round 5): the workgroup that
+ * multiplies a block of tile rows walks all 36 frequency points, folds every partial product block into the output domain on chip
+ * (out = At M A accumulated in registers) and applies the epilogue -- M is never written to the workspace.  Replaces the pair
+ * ivx_conv_winograd_gemm + ivx_conv_winograd_output[_amax] after ivx_conv_winograd_input[_amax] on the SAME workspace; applies to the
+ * stride-1, pad-1, 3-tap z kernels of the ResModules (mmdet3d/models/necks/imvoxelnet.py:94-123) with wgt_layout 1 and Cin % 32 == 0
+ * while the 36 planes of V stay below 2 GiB (ivx_conv_winograd_fused_supported).  Results equal the three-stage form up to fp32
+ * rounding (another summation order of the same products).  partials (or NULL): ivx_conv_winograd_fused_blocks(d, tile) floats, one
+ * max |out| per workgroup, for the consumer's ivx_conv_winograd_input_amax. */
+int ivx_conv_winograd_fused_supported(const ivx_conv_desc *d, int32_t tile);
+int32_t ivx_conv_winograd_fused_blocks(const ivx_conv_desc *d, int32_t tile);
+int ivx_conv_winograd_gemm_output_amax(const ivx_conv_desc *d, int32_t tile, const float *u, const float *scale, const float *shift,
+                                       const void *res, void *out, void *workspace, int64_t workspace_bytes, float *partials,
+                                       ivx_stream_t stream);
 
 /* Tuning knob for A/B experiments only (per calling thread): 0 = automatic tile choice (default); 1..7 force a tile
  * of the generic kernel, 41..53 of the LDS-DMA fp32 kernel, 61..73 of its bf16 instantiation. */

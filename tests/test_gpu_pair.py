@@ -347,3 +347,72 @@ def test_winograd_halo_kernel_stride2_matches_generic(ia, shape):
     tref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).cpu().double(), w.permute(0, 4, 1, 2, 3).cpu().double(), stride=(1, 1, 2),
                                       padding=1).permute(0, 2, 3, 4, 1)
     assert_close('stride-2 halo kernel vs torch fp64', got.cpu(), tref.float(), 1e-4, 1e-4 * float(tref.abs().max()))
+
+
+FUSED_CASES = [
+    # B, (X,Y,Z), Cin, Cout, residual, relu   (F(4x4,3x3), stride-1 pad-1 z kernel, chunk-major filters)
+    (2, (19, 23, 12), 64, 64, False, True),      # odd X and Y: border tiles in both directions; 12 slices as KITTI level 0
+    (1, (16, 12, 6), 64, 64, True, True),        # residual
+    (1, (9, 14, 5), 32, 128, True, False),       # Cin 32 (two pair groups), two N tiles, no ReLU
+    (3, (12, 8, 3), 128, 96, False, True),       # Cout not a multiple of 64
+    (1, (40, 40, 16), 128, 128, True, True),     # an indoor-neck shape (tile 4 is that family's default)
+    (1, (5, 3, 2), 64, 64, False, False),        # fewer rows than one row tile
+]
+
+
+@pytest.mark.parametrize('case', FUSED_CASES)
+def test_conv_winograd_fused_gemm_output(ia, case):
+    """Round 5: ivx_conv_winograd_gemm_output_amax (conv_wino_fold4_kernel: the 36 Winograd-domain GEMMs of an F(4x4,3x3) layer with the
+    output transform and the epilogue fused, M kept on chip) against the three-stage form on the same V and U -- the same products summed
+    in another order: 2e-5 of the output range -- and against torch fp64 with an error no larger than the three-stage form's; the
+    per-workgroup maxima are those of the stored tensor, and a consumer fed with them gives the same bits as one that reduces the tensor."""
+    from imvoxelnet_amd import ops
+    P = ops.IVX_F16_PAIR
+    B, (X, Y, Z), ci, co, use_res, relu = case
+    g = torch.Generator().manual_seed(X * 17 + ci + co)
+    x = torch.randn(B, X, Y, Z, ci, generator=g).cuda()
+    w = (torch.randn(co, 3, 3, 3, ci, generator=g) * (2.0 / (27 * ci)) ** 0.5).cuda()
+    scale, shift = (torch.rand(co, generator=g) + 0.5).cuda(), (torch.randn(co, generator=g) * 0.1).cuda()
+    res = torch.randn(B, X, Y, Z, co, generator=g).cuda() if use_res else None
+    tref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).cpu().double(), w.permute(0, 4, 1, 2, 3).cpu().double(), padding=1).permute(0, 2, 3, 4, 1)
+    tref = tref * scale.cpu().double() + shift.cpu().double()
+    if use_res:
+        tref = tref + res.cpu().double()
+    if relu:
+        tref = tref.clamp_min(0)
+    u = ops.conv_winograd_weights(w, 1, 4, operands=P)
+    want = ops.conv_winograd_fwd(x, u, scale, shift, 3, 1, (1, 1, 1), relu, res, wgt_layout=1, operands=P)
+    got, part = ops.conv_winograd_fwd(x, u, scale, shift, 3, 1, (1, 1, 1), relu, res, wgt_layout=1, operands=P, fused=True, want_amax=True)
+    rng = float(tref.abs().max())
+    assert got.shape == want.shape
+    assert_close('fused GEMM + output vs three stages', got, want, 0, 2e-5 * rng)
+    e_f, e_3 = float((got.cpu().double() - tref).pow(2).mean().sqrt()), float((want.cpu().double() - tref).pow(2).mean().sqrt())
+    print(f'rms error / range: fused {e_f / rng:.2e}  three-stage {e_3 / rng:.2e}')
+    assert e_f <= 1.5 * e_3 + 2e-7 * rng
+    assert float(part.max()) == float(got.abs().max()) and float(part.min()) >= 0.0
+    # power-of-two rescaling of the input: exact (the operand scale comes from max |input|, the fold is linear)
+    a = ops.conv_winograd_fwd(x, u, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=P, fused=True)
+    b = ops.conv_winograd_fwd(x * 2.0 ** -7, u, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=P, fused=True)
+    assert torch.equal(b, a * 2.0 ** -7)
+    # chained: the consumer's operand scale from this layer's partial maxima == from the tensor
+    w2 = (torch.randn(32, 3, 3, 3, co, generator=g) * 0.03).cuda() if co % 32 == 0 else None
+    if w2 is not None:
+        u2 = ops.conv_winograd_weights(w2, 1, 4, operands=P)
+        z = ops.conv_winograd_fwd(got, u2, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=P, amax_in=part)
+        z0 = ops.conv_winograd_fwd(got, u2, None, None, 3, 1, (1, 1, 1), False, wgt_layout=1, operands=P)
+        assert torch.equal(z, z0)
+
+
+def test_conv_winograd_fused_refusals(ia):
+    from imvoxelnet_amd import ops, _lib
+    import ctypes as C
+    L = _lib.lib()
+    P = ops.IVX_F16_PAIR
+    d = ops._wino_desc(1, 12, 12, 4, 64, 64, 3, 1, (1, 1, 1), False, 1, operands=P)
+    assert L.ivx_conv_winograd_fused_supported(C.byref(d), 4) == 1
+    assert L.ivx_conv_winograd_fused_supported(C.byref(d), 6) == 0                                                             # F(4x4) only
+    assert L.ivx_conv_winograd_fused_supported(C.byref(ops._wino_desc(1, 12, 12, 4, 64, 64, 3, 2, (1, 1, 1), False, 1, operands=P)), 4) == 0   # z stride 2
+    assert L.ivx_conv_winograd_fused_supported(C.byref(ops._wino_desc(1, 12, 12, 3, 64, 64, 3, 1, (1, 1, 0), False, 1, operands=P)), 4) == 0   # z padding 0
+    assert L.ivx_conv_winograd_fused_supported(C.byref(ops._wino_desc(1, 12, 12, 4, 64, 64, 3, 1, (1, 1, 1), False, 0, operands=P)), 4) == 0   # tap-major filters
+    assert L.ivx_conv_winograd_fused_supported(C.byref(ops._wino_desc(1, 12, 12, 4, 64, 64, 3, 1, (1, 1, 1), False, 1, operands=0)), 4) == 0   # fp32 operands
+    assert L.ivx_conv_winograd_fused_supported(C.byref(ops._wino_desc(8, 216, 248, 12, 64, 64, 3, 1, (1, 1, 1), False, 1, operands=P)), 4) == 0   # 36 planes of V >= 2 GiB
