@@ -268,20 +268,31 @@ def get_mAP(prec):
     return sums / 11 * 100
 
 
+# The three overlap metrics of the KITTI protocol: (eval_types name, metric index of eval_class, key infix of the result dict, report label)
+_METRICS = (('bbox', 0, '2D', 'bbox'), ('bev', 1, 'BEV', 'bev '), ('3d', 2, '3D', '3d  '))
+_LEVELS = ('easy', 'moderate', 'hard')
+
+
+def ap_tables(gt_annos, dt_annos, class_ids, min_overlaps, eval_types=('bbox', 'bev', '3d'), overlap_fn=None):
+    """11-point AP tables [class, difficulty, overlap set] per requested metric: {'bbox' | 'bev' | '3d' | 'aos': array}.
+    One eval_class pass per metric; 'aos' rides on the bbox pass (orientation similarity needs the 2-D matches)."""
+    want = set(eval_types)
+    tables = {}
+    for name, metric, _, _ in _METRICS:
+        if name not in want:
+            continue
+        with_aos = name == 'bbox' and 'aos' in want
+        curves = eval_class(gt_annos, dt_annos, class_ids, [0, 1, 2], metric, min_overlaps, compute_aos=with_aos, overlap_fn=overlap_fn)
+        tables[name] = get_mAP(curves['precision'])
+        if with_aos:
+            tables['aos'] = get_mAP(curves['orientation'])
+    return tables
+
+
 def do_eval(gt_annos, dt_annos, current_classes, min_overlaps, eval_types=('bbox', 'bev', '3d'), overlap_fn=None):
-    difficultys = [0, 1, 2]
-    mAP_bbox = mAP_aos = mAP_bev = mAP_3d = None
-    if 'bbox' in eval_types:
-        ret = eval_class(gt_annos, dt_annos, current_classes, difficultys, 0, min_overlaps, compute_aos=('aos' in eval_types),
-                         overlap_fn=overlap_fn)
-        mAP_bbox = get_mAP(ret['precision'])
-        if 'aos' in eval_types:
-            mAP_aos = get_mAP(ret['orientation'])
-    if 'bev' in eval_types:
-        mAP_bev = get_mAP(eval_class(gt_annos, dt_annos, current_classes, difficultys, 1, min_overlaps, overlap_fn=overlap_fn)['precision'])
-    if '3d' in eval_types:
-        mAP_3d = get_mAP(eval_class(gt_annos, dt_annos, current_classes, difficultys, 2, min_overlaps, overlap_fn=overlap_fn)['precision'])
-    return mAP_bbox, mAP_bev, mAP_3d, mAP_aos
+    """(mAP_bbox, mAP_bev, mAP_3d, mAP_aos) in the reference's order (eval.py:578-625); None for a metric that was not asked for."""
+    t = ap_tables(gt_annos, dt_annos, current_classes, min_overlaps, eval_types, overlap_fn)
+    return t.get('bbox'), t.get('bev'), t.get('3d'), t.get('aos')
 
 
 def _class_ids(current_classes):
@@ -291,70 +302,51 @@ def _class_ids(current_classes):
     return [name_to_class[c] if isinstance(c, str) else c for c in current_classes]
 
 
+def _ap_lines(tables, pick, with_aos):
+    """The 'bbox AP:..' / 'bev  AP:..' / '3d   AP:..' [/ 'aos  AP:..'] lines of one report block; pick(table) -> the three difficulty values."""
+    lines = ['{} AP:{:.4f}, {:.4f}, {:.4f}\n'.format(label, *pick(tables[name])) for name, _, _, label in _METRICS if name in tables]
+    if with_aos:
+        lines.append('aos  AP:{:.2f}, {:.2f}, {:.2f}\n'.format(*pick(tables['aos'])))
+    return ''.join(lines)
+
+
 def kitti_eval(gt_annos, dt_annos, current_classes, eval_types=('bbox', 'bev', '3d'), overlap_fn=None):
-    """-> (report string, dict) with the reference's format and keys (eval.py:643-773).
+    """-> (report string, dict) with the reference's format and keys (eval.py:643-773): per class one block per overlap set (strict:
+    0.7 / 0.5 / 0.5 per Car / Pedestrian / Cyclist, loose: 0.5 / 0.25 / 0.25 in BEV and 3-D), then the class mean of the strict set.
     overlap_fn(a_xyxyr, b_xyxyr) -> intersection areas [N,K] replaces the device kernel (used by the CPU-only tests)."""
     eval_types = list(eval_types)
-    assert len(eval_types) > 0, 'must contain at least one evaluation type'
-    if 'aos' in eval_types:
-        assert 'bbox' in eval_types, 'must evaluate bbox when evaluating aos'
-    overlap_0_7 = np.array([[0.7, 0.5, 0.5, 0.7, 0.5]] * 3)
-    overlap_0_5 = np.array([[0.7, 0.5, 0.5, 0.7, 0.5], [0.5, 0.25, 0.25, 0.5, 0.25], [0.5, 0.25, 0.25, 0.5, 0.25]])
-    min_overlaps = np.stack([overlap_0_7, overlap_0_5], axis=0)          # [2, metric, class]
-    current_classes = _class_ids(current_classes)
-    min_overlaps = min_overlaps[:, :, current_classes]
-    pred_alpha = any(a['alpha'].shape[0] != 0 for a in dt_annos)
-    valid_alpha_gt = any(a['alpha'][0] != -10 for a in gt_annos)
-    compute_aos = pred_alpha and valid_alpha_gt
-    if compute_aos and 'aos' not in eval_types:
+    if not eval_types:
+        raise AssertionError('must contain at least one evaluation type')
+    if 'aos' in eval_types and 'bbox' not in eval_types:
+        raise AssertionError('must evaluate bbox when evaluating aos')
+    per_class = np.array([0.7, 0.5, 0.5, 0.7, 0.5])                       # strict 3-D / BEV / 2-D overlap per class id
+    loose = np.array([0.5, 0.25, 0.25, 0.5, 0.25])
+    class_ids = _class_ids(current_classes)
+    min_overlaps = np.stack([np.stack([per_class] * 3), np.stack([per_class, loose, loose])])[:, :, class_ids]    # [set, metric, class]
+    # orientation similarity is reported whenever the detections carry alpha and the ground truth has it (alpha = -10 marks "none")
+    with_aos = any(a['alpha'].shape[0] != 0 for a in dt_annos) and any(a['alpha'][0] != -10 for a in gt_annos)
+    if with_aos and 'aos' not in eval_types:
         eval_types.append('aos')
-    mAPbbox, mAPbev, mAP3d, mAPaos = do_eval(gt_annos, dt_annos, current_classes, min_overlaps, eval_types, overlap_fn)
-    result = ''
-    ret_dict = {}
-    difficulty = ['easy', 'moderate', 'hard']
-    for j, curcls in enumerate(current_classes):
-        name = CLASS_TO_NAME[curcls]
-        for i in range(min_overlaps.shape[0]):
-            result += '{} AP@{:.2f}, {:.2f}, {:.2f}:\n'.format(name, *min_overlaps[i, :, j])
-            if mAPbbox is not None:
-                result += 'bbox AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAPbbox[j, :, i])
-            if mAPbev is not None:
-                result += 'bev  AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAPbev[j, :, i])
-            if mAP3d is not None:
-                result += '3d   AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAP3d[j, :, i])
-            if compute_aos:
-                result += 'aos  AP:{:.2f}, {:.2f}, {:.2f}\n'.format(*mAPaos[j, :, i])
-            for idx in range(3):
-                postfix = f'{difficulty[idx]}_strict' if i == 0 else f'{difficulty[idx]}_loose'
-                prefix = f'KITTI/{name}'
-                if mAP3d is not None:
-                    ret_dict[f'{prefix}_3D_{postfix}'] = mAP3d[j, idx, i]
-                if mAPbev is not None:
-                    ret_dict[f'{prefix}_BEV_{postfix}'] = mAPbev[j, idx, i]
-                if mAPbbox is not None:
-                    ret_dict[f'{prefix}_2D_{postfix}'] = mAPbbox[j, idx, i]
-    if len(current_classes) > 1:
-        result += '\nOverall AP@{}, {}, {}:\n'.format(*difficulty)
-        if mAPbbox is not None:
-            mAPbbox = mAPbbox.mean(axis=0)
-            result += 'bbox AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAPbbox[:, 0])
-        if mAPbev is not None:
-            mAPbev = mAPbev.mean(axis=0)
-            result += 'bev  AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAPbev[:, 0])
-        if mAP3d is not None:
-            mAP3d = mAP3d.mean(axis=0)
-            result += '3d   AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAP3d[:, 0])
-        if compute_aos:
-            mAPaos = mAPaos.mean(axis=0)
-            result += 'aos  AP:{:.2f}, {:.2f}, {:.2f}\n'.format(*mAPaos[:, 0])
-        for idx in range(3):
-            if mAP3d is not None:
-                ret_dict[f'KITTI/Overall_3D_{difficulty[idx]}'] = mAP3d[idx, 0]
-            if mAPbev is not None:
-                ret_dict[f'KITTI/Overall_BEV_{difficulty[idx]}'] = mAPbev[idx, 0]
-            if mAPbbox is not None:
-                ret_dict[f'KITTI/Overall_2D_{difficulty[idx]}'] = mAPbbox[idx, 0]
-    return result, ret_dict
+    tables = ap_tables(gt_annos, dt_annos, class_ids, min_overlaps, eval_types, overlap_fn)
+    report, values = [], {}
+    for j, cid in enumerate(class_ids):
+        cname = CLASS_TO_NAME[cid]
+        for s_, tag in enumerate(('strict', 'loose')):
+            report.append('{} AP@{:.2f}, {:.2f}, {:.2f}:\n'.format(cname, *min_overlaps[s_, :, j]))
+            report.append(_ap_lines(tables, lambda t: t[j, :, s_], with_aos))
+            for d, level in enumerate(_LEVELS):
+                for name, _, infix, _ in reversed(_METRICS):                 # key order of the reference: 3D, BEV, 2D
+                    if name in tables:
+                        values[f'KITTI/{cname}_{infix}_{level}_{tag}'] = tables[name][j, d, s_]
+    if len(class_ids) > 1:
+        mean = {k: v.mean(axis=0) for k, v in tables.items()}
+        report.append('\nOverall AP@{}, {}, {}:\n'.format(*_LEVELS))
+        report.append(_ap_lines(mean, lambda t: t[:, 0], with_aos))
+        for d, level in enumerate(_LEVELS):
+            for name, _, infix, _ in reversed(_METRICS):
+                if name in mean:
+                    values[f'KITTI/Overall_{infix}_{level}'] = mean[name][d, 0]
+    return ''.join(report), values
 
 
 def kitti_eval_coco_style(gt_annos, dt_annos, current_classes, overlap_fn=None):
