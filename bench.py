@@ -682,7 +682,7 @@ def main():
     # from the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh -> profiles/*_bench_pmc.json;
     # FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as reported), averaged per launch; null if absent.
     traffic, traffic_src = None, None
-    for name in (('r04_bench_pmc.json', 'r03b_bench_pmc.json') if pair else ('r03_bench_pmc.json', 'r02_bench_pmc.json', 'r01_bench_pmc.json')):
+    for name in (('r05_bench_pmc.json', 'r04_bench_pmc.json', 'r03b_bench_pmc.json') if pair else ('r03_bench_pmc.json', 'r02_bench_pmc.json', 'r01_bench_pmc.json')):
         pj = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pj) and not bf16:
             try:   # the summary covers the main launch of every neck layer: HBM bytes averaged per launch

@@ -1858,7 +1858,17 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
     } else {
       lds_dma_wait_all();
     }
-    __syncthreads();                    // ... and every wave is done reading the buffer of group g - 1, which group g + D now overwrites
+    if constexpr (NBUF == 2) {
+      __syncthreads();                  // ... and every wave is done reading the buffer of group g - 1, which group g + D now overwrites
+    } else {
+      // a ring deeper than two needs a RAW barrier: the fence of __syncthreads() waits for vmcnt(0), i.e. for the whole ring (round 5; the
+      // three-buffer rings of rounds 3 - 4 were two-deep rings with a third buffer).  This wave's fragment reads of group g - 1 are complete
+      // (its MFMAs consumed them); the clobbers keep LDS accesses on their side of the barrier.
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     if (g + D < G) load_group(g + D, nxt);
     const T *Ac = smem + cur * BUF + (DI ? 1 : SW) * wr * TM * 32 * BK;
     const T *Bc = smem + cur * BUF + AROWS * BK + wc * TN * 32 * BK;
@@ -2133,6 +2143,9 @@ int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st) {
     case 24: launch_halo<1, 2, 4, 1, 2, 2, 2, 0, 2>(p, st); break;  // 127 x 64, 4 waves in M (wave tile 32 x 64): 56 KB
     // ZR: masked taps read a zero row (10 / 13 / 14 / 11 / 22 / 21 with the fragment address selected instead of the fragment zeroed)
     case 30: launch_halo<2, 1, 2, 2, 4, 2, 2, 0, 1, 1>(p, st); break;  // 125 x 64
+    // (round 5, with the raw barrier that makes a third buffer a real prefetch distance of two groups -- measured and removed, profiles/
+    // r05_fused_gemm_output.md: 125 x 64 with three / four buffers 0.535 / 0.600 ms against 0.493 (64 channels); 253 x 128 with three 0.806
+    // against 0.659 (128) and 1.314 against 1.171 (256): on these launches resident workgroups DO hide the latency better than depth)
     case 31: launch_halo<2, 2, 4, 1, 2, 2, 2, 0, 1, 1>(p, st); break;  // 253 x 64
     case 33: launch_halo<2, 2, 4, 2, 1, 2, 2, 0, 1, 1>(p, st); break;  // 253 x 128, 8 waves
     case 34: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 1, 1>(p, st); break;  // 125 x 128

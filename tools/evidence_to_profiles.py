@@ -39,7 +39,7 @@ def main():
             ('--storage bf16 (optional reduced-precision mode; NOT the headline)', 'bench_bf16.json'),
             ('IVX_BENCH_FORCE_DIST=1 under torch.distributed.run, world size 1 (RCCL all-gather in every step)', 'bench_dist1.json'),
             (f'the run under rocprofv3 --kernel-trace --stats (profiles/{pre}_bench_kernel_trace.md)', 'bench_profiled_kitti.json')]
-    out = [f'# Round 4: bench lines (one MI355X box, one session; tools/evidence_r4.sh -> {E})', '',
+    out = [f'# Round {int(pre[1:])}: bench lines (one MI355X box, one session; tools/evidence_r{int(pre[1:])}.sh -> {E})', '',
            '| run | images/s | ms/step | GEMM: products TFLOP/s (frac of its MFMA peak) | fp32-equivalent TFLOP/s | GEMM ms | neck ms | transforms ms (GB/s) | trunk ms |',
            '|---|---|---|---|---|---|---|---|---|']
     for name, f in rows:
