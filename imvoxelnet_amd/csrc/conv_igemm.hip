@@ -723,25 +723,25 @@ __device__ __forceinline__ f32x16 pair_mfma(const f32x4 a, const f32x4 b, const 
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// s_waitcnt vmcnt(n), n a runtime value in 0 .. 15 (the tail of a deep ring: fewer slabs are outstanding than in the steady state)
-__device__ __forceinline__ void lds_dma_wait_le(const int n) {
-  switch (n) {
-    case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
-    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
-    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
-    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
-    case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
-    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
-    case 7: __builtin_amdgcn_s_waitcnt(0x0f77); break;
-    case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
-    case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
-    case 10: __builtin_amdgcn_s_waitcnt(0x0f7a); break;
-    case 11: __builtin_amdgcn_s_waitcnt(0x0f7b); break;
-    case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
-    case 13: __builtin_amdgcn_s_waitcnt(0x0f7d); break;
-    case 14: __builtin_amdgcn_s_waitcnt(0x0f7e); break;
-    case 15: __builtin_amdgcn_s_waitcnt(0x0f7f); break;
-    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;      // 0 (and anything larger: waiting for more than needed is always correct)
+// s_waitcnt vmcnt(n) with n = PER * newer, newer a runtime value in 0 .. 7 (the tail of a deep ring: fewer slabs are outstanding than in the
+// steady state).  gfx9 encoding: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14; expcnt / lgkmcnt fields all ones = untouched.  A count
+// above 63 is clamped (waiting for fewer outstanding requests than needed is always correct).
+template <int N>
+__device__ __forceinline__ void lds_dma_wait_imm() {
+  constexpr int n = N > 63 ? 63 : N;
+  __builtin_amdgcn_s_waitcnt(0x0f70 | (n & 15) | ((n >> 4) << 14));
+}
+template <int PER>
+__device__ __forceinline__ void lds_dma_wait_slabs(const int newer) {
+  switch (newer) {
+    case 1: lds_dma_wait_imm<PER>(); break;
+    case 2: lds_dma_wait_imm<2 * PER>(); break;
+    case 3: lds_dma_wait_imm<3 * PER>(); break;
+    case 4: lds_dma_wait_imm<4 * PER>(); break;
+    case 5: lds_dma_wait_imm<5 * PER>(); break;
+    case 6: lds_dma_wait_imm<6 * PER>(); break;
+    case 7: lds_dma_wait_imm<7 * PER>(); break;
+    default: lds_dma_wait_imm<0>(); break;      // 0 (and anything else: waiting for everything is always correct)
   }
 }
 
@@ -766,8 +766,8 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   static_assert(BM % RP == 0 && BN % RP == 0, "tile rows");
   static_assert(WR * WC == 4 || WR * WC == 8 || WR * WC == 16, "4, 8 or 16 waves per workgroup");
   // LDS-DMA staging: rows are BK elements (128 or 64 B), unpadded
-  static_assert(NB >= 2 && NB <= 4, "ring depth");
-  static_assert(NB == 2 || (NB - 1) * (AR + BR) <= 15, "deep ring: vmcnt immediates of the tail waits");
+  static_assert(NB >= 2 && NB <= 8, "ring depth");
+  static_assert(NB == 2 || (NB - 1) * (AR + BR) <= 63, "deep ring: vmcnt immediates of the tail waits (6 bits)");
   __shared__ __attribute__((aligned(16))) T smem[NB * (BM + BN) * BK];
   T *As = smem;
   T *Bs = smem + NB * BM * BK;
@@ -973,7 +973,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
     lds_dma_wait_all();
   } else {
     const int newer = (S - 1 < NB - 1) ? S - 1 : NB - 1;      // slabs issued after slab 0
-    lds_dma_wait_le(newer * (AR + BR));
+    lds_dma_wait_slabs<AR + BR>(newer);
   }
   // (NB > 2: a RAW barrier -- the workgroup fence of __syncthreads() waits for vmcnt(0), i.e. for every request of the ring, which makes
   // any ring deeper than two a two-deep one: seen in the ISA, round 5.  The clobbers keep LDS accesses on their side of it.)
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
         } else {           // slab s + 1 has landed when only the slabs issued after it are outstanding: min(NB - 2, S - s - 2) of them
           int newer = S - s - 2;
           newer = newer < 0 ? 0 : (newer > NB - 2 ? NB - 2 : newer);
-          lds_dma_wait_le(newer * (AR + BR));
+          lds_dma_wait_slabs<AR + BR>(newer);
         }
         if constexpr (NB == 2) {
           __syncthreads();
@@ -1693,6 +1693,9 @@ static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     // most 512 tiles (plan_conv; profiles/r05_trunk_deep_ring.md)
     case 166: launch_v4<__bf16, 1, 1, 2, 2, 64, 2, PAIR, 4>(p, st); break;   // 66 (64 x 64, 128-byte rows)
     case 174: launch_v4<__bf16, 2, 2, 2, 2, 32, 2, PAIR, 4>(p, st); break;   // 74 (128 x 128, 64-byte rows)
+    // (round 5, measured and removed -- profiles/r05_trunk_deep_ring.md (e): rings of six / eight buffers (96 / 128 KB): trunk 3.40 -> 3.9 / 4.05 ms,
+    // and 3.43 / 3.47 when only launches of at most one tile per CU take them; a slab-level software pipeline of the four-buffer loop (next slab's
+    // fragments read and the next DMA issued in front of the slab's last eight MFMAs): -0.09 us per slab in a long K loop, but 3.42 -> 3.45 ms)
     // (measured and removed, profiles/r05_trunk_deep_ring.md: 74 with three buffers for launches of 513 .. 4096 tiles: trunk 3.44 -> 3.57 ms; on the
     // last neck layer's grouped GEMM 81 / 76 / 74 with three or four buffers: 0.66 / 0.67 / 0.74 / 0.62 ms against 0.57 of tile 82)
     case 85: launch_v4<__bf16, 2, 4, 2, 2, 32, 2, PAIR>(p, st); break;   // 128 x 256, 4 waves, wave tile 64 x 128: no gain over 81 / 82, so the
