@@ -85,6 +85,10 @@ struct ConvParams {
   const unsigned *amax_in, *amax_res;   // device, IVX_AMAX_SLOTS words: bits of max |in| / max |res| (true values); out_pair only
   unsigned *amax_out;            // device, IVX_AMAX_SLOTS words the epilogue accumulates max |out| into (atomic max), or NULL
   float wbound, sbound;          // |out| <= amax_in * wbound + sbound (+ amax_res): max_co |scale[co]| * sum_k |w[co][k]| and max_co |shift[co]|
+#ifdef IVX_CONV_TIMELINE
+  unsigned long long *tl;        // debug build only (tools/conv_timeline.py): 8 words per workgroup of conv_igemm_v4_kernel's pair-IO path --
+                                 // s_memrealtime (100 MHz) at entry, after the prologue barrier, after the K loop, at the end; HW_ID; XCC_ID
+#endif
 };
 
 // What a wave needs of the pair-IO state: multipliers of the accumulator / the residual (exact: powers of two) and the output scale.
@@ -368,9 +372,32 @@ __device__ __forceinline__ float conv_pio_finish4(const ConvParams &p, const Pai
 // 128 -> 512 0.41 -> 0.45, 256 -> 1024 0.27 -> 0.29): the serial load -> store chain of a wave is hidden by the other fifteen waves of
 // the CU; what bounds these layers is not the residual's latency.  (A one-block-ahead form with the request issued before the block is
 // consumed: 55 spilled registers, 0.68 -> 1.11 ms.)
+// RPF (round 5): the residual of the whole tile was requested BEFORE the K loop (conv_pio_res_prefetch: raw bits, 4 dwords per lane, block
+// and pass -- 64 registers for the 128 x 128 tile) and is decoded here; taken when p.res_mode == 1, everything else goes the path above.
 template <int TM, int TN>
+__device__ __forceinline__ void conv_pio_res_prefetch(const ConvParams &p, u32x4r (&rraw)[TM][TN][4], int m0, int n0, int wr, int wc, int lane) {
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = n0 + (wc * TN + j) * 32 + c4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + (wr * TM + i) * 32 + rrow + 8 * q;
+        rraw[i][j][q] = u32x4r{0u, 0u, 0u, 0u};
+        if (m < p.M && nb < p.Cout) rraw[i][j][q] = conv_pio_res_load(p, (size_t)m, nb);
+      }
+  }
+}
+// The maximum is committed ONCE PER WORKGROUP (round 5): every wave leaves its maximum in the first word of its own staging slice, one
+// barrier, wave 0 reduces and issues the atomic.  The 64 slots of a tensor lie in two cache lines, so atomics on different slots still
+// serialise at one memory channel; with one atomic per WAVE the 960 .. 3840 waves of a trunk launch whose slots had just been zeroed
+// queued there and the last workgroups of the launch waited 10 - 20 us in their epilogue (workgroup timelines inside the model,
+// profiles/r05_trunk_wg_timeline.md; isolated launches do not show it: their slots already hold the maximum and the read skips the atomic).
+template <int TM, int TN, int RPF = 0>
 __device__ __forceinline__ void conv_epilogue_wide_pio(const ConvParams &p, const PairIO io, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc,
-                                                       int lane, float *stage, int salt) {
+                                                       int lane, float *stage, int wid, int nw, const u32x4r (*rraw)[TN][4] = nullptr) {
   const int col_l = lane & 31, hh = lane >> 5;
   const int rrow = lane >> 3, c4 = (lane & 7) * 4;
   float omax = 0.f;
@@ -391,11 +418,20 @@ __device__ __forceinline__ void conv_epilogue_wide_pio(const ConvParams &p, cons
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + (rrow + 8 * q) * 32 + c4);
         const int m = mb + 8 * q;
-        if (m < p.M && nok) omax = fmaxf(omax, conv_pio_finish4(p, io, v, m, nb, sc, sf));
+        if (m < p.M && nok) {
+          if (RPF && p.res_mode == 1) omax = fmaxf(omax, conv_pio_finish4_rr(p, io, v, m, nb, sc, sf, conv_pio_res_decode(p, io, rraw[i][j][q])));
+          else omax = fmaxf(omax, conv_pio_finish4(p, io, v, m, nb, sc, sf));
+        }
       }
     }
   }
-  if (p.amax_out) ivx_amax_commit(p.amax_out, omax, salt);
+  if (p.amax_out) {        // (uniform over the workgroup)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+    if (lane == 0) stage[0] = omax;
+    __syncthreads();
+    if (wid == 0) ivx_amax_commit(p.amax_out, lane < nw ? stage[lane * 1024] : 0.f, (int)blockIdx.x);
+  }
 }
 
 // bf16-output variant of the wide epilogue (Cout % 8 == 0).  The one-channel-per-lane epilogue stores 2 bytes per lane --
@@ -750,7 +786,7 @@ __device__ __forceinline__ void lds_dma_wait_slabs(const int newer) {
 // has workgroup slots (every /8 .. /32 layer at KITTI's batch of 4: 240 - 480 tiles of 0.7 - 1.5 us per slab with 6 - 12 MFMAs of work in it)
 // are bound by that latency, and resident workgroups cannot hide it when there are not enough tiles to be resident.  The products are
 // accumulated in the same order: results are bit-identical to NB = 2.
-template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE, int UNI, int PAIR = 0, int NB = 2>
+template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE, int UNI, int PAIR = 0, int NB = 2, int RPF = 0>
 __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const ConvParams p, const unsigned in_bytes,
                                                                   const unsigned w_bytes) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
@@ -793,6 +829,9 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   if (mt * BM >= p.M) return;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
+#ifdef IVX_CONV_TIMELINE
+  unsigned long long tl0 = __builtin_amdgcn_s_memrealtime(), tl1 = 0, tl2 = 0;
+#endif
 
   const size_t gz = blockIdx.z;   // group of a grouped launch (strides are 0 otherwise)
   const __amdgpu_buffer_rsrc_t rs_in =
@@ -958,6 +997,14 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // RPF: the tile's residual is requested here, in front of the K loop, and consumed by the epilogue (pair IO, res_mode 1): the Cout-expanding
+  // 1x1 layers of the bottlenecks have 4 .. 32 slabs of K and twice the output's bytes to move; with the residual requested block by block
+  // in the epilogue the launch ran as K loop + (load -> store) chains, 90 us for 283 MB at 64 -> 256 / 96 x 320 x 4 against 46 without one.
+  u32x4r rraw[RPF ? TM : 1][RPF ? TN : 1][4];
+  if constexpr (RPF) {
+    static_assert(PAIR == 2, "residual prefetch: the pair-IO epilogue");
+    if (p.pio && p.res_mode == 1 && p.ksplit <= 1) conv_pio_res_prefetch<TM, TN>(p, rraw, m0, n0, wr, wc, lane);
+  }
   // Software pipeline over two LDS buffers with a prefetch distance of two slabs.  The fragments of a slab's LAST k-step
   // are read into registers before the barrier, so after the barrier the buffer of the CURRENT slab is already free:
   // the DMA of slab s+2 is issued into it right there and has the last MFMA group of slab s plus all but the last
@@ -986,6 +1033,9 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   }
 
   const int frow = (lane & 31) * BK, fsw = ((lane & 31) >> SW_SH) & SW_MSK, fh = lane >> 5;
+#ifdef IVX_CONV_TIMELINE
+  tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
   int cur = 0;
   for (int s = 0; s < S; ++s) {
     const T *Ac = As + cur * BM * BK + wr * TM * 32 * BK + frow;
@@ -1085,6 +1135,9 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
     }
     cur = cur + 1 == NB ? 0 : cur + 1;
   }
+#ifdef IVX_CONV_TIMELINE
+  tl2 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (p.ksplit > 1) {
     // raw partial sums; ivx split-K reduce kernel applies the epilogue
     float *part = p.partial + ((size_t)blockIdx.y * 8 * p.q_count + ct) * BM * p.Cout;   // rows of this tile, slice y
@@ -1108,7 +1161,15 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
       static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
       const PairIO io = conv_pair_io(p);
       if (p.out_scale_p && blockIdx.x == 0 && tid == 0) *p.out_scale_p = io.s_out;     // (workgroup 0 owns M-tile q_begin of XCD 0: never out of range)
-      conv_epilogue_wide_pio<TM, TN>(p, io, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, (int)blockIdx.x * (NT / 64) + wid_u);
+      if constexpr (RPF) conv_epilogue_wide_pio<TM, TN, 1>(p, io, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, wid_u, NT / 64, rraw);
+      else conv_epilogue_wide_pio<TM, TN>(p, io, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, wid_u, NT / 64);
+#ifdef IVX_CONV_TIMELINE
+      if (p.tl && tid == 0) {
+        unsigned long long *t = p.tl + (size_t)blockIdx.x * 8;
+        t[0] = tl0; t[1] = tl1; t[2] = tl2; t[3] = __builtin_amdgcn_s_memrealtime();
+        t[4] = __builtin_amdgcn_s_getreg(63492); t[5] = __builtin_amdgcn_s_getreg(63508);
+      }
+#endif
       return;
     }
   }
@@ -1184,7 +1245,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
     for (int z = 0; z < p.ksplit; ++z) acc += p.partial[(size_t)z * total + idx];
     omax = fmaxf(omax, conv_store_one(p, (int)m, n, acc, io));
   }
-  if (p.pio && p.amax_out) ivx_amax_commit(p.amax_out, omax, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (p.pio && p.amax_out) {        // (uniform)
+    __shared__ float red[4];
+    ivx_amax_commit_wg(p.amax_out, omax, red, (int)blockIdx.x);
+  }
 }
 
 // The same reduction for pair IO (the chained fp16-pair trunk), four channels per thread: 16-byte partial loads, the epilogue of
@@ -1209,7 +1273,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_pio_kernel(const ConvP
     sc *= io.inv_in;
     omax = fmaxf(omax, conv_pio_finish4(p, io, acc, (int)m, (int)nb, sc, sf));
   }
-  if (p.amax_out) ivx_amax_commit(p.amax_out, omax, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (p.amax_out) {        // (uniform)
+    __shared__ float red[4];
+    ivx_amax_commit_wg(p.amax_out, omax, red, (int)blockIdx.x);
+  }
 }
 
 // Validation kernel: one thread per output element, sequential fmaf over (kd,kh,kw,ci).
@@ -1272,9 +1339,16 @@ __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p)
     }
     omax = fmaxf(omax, conv_store_one(p, m, n, acc, io));
   }
-  if (p.pio && p.amax_out) ivx_amax_commit(p.amax_out, omax, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (p.pio && p.amax_out) {        // (uniform)
+    __shared__ float red[4];
+    ivx_amax_commit_wg(p.amax_out, omax, red, (int)blockIdx.x);
+  }
 }
 
+#ifdef IVX_CONV_TIMELINE
+static unsigned long long *g_timeline = nullptr;
+extern "C" int ivx_conv_set_timeline(void *buf) { g_timeline = (unsigned long long *)buf; return 0; }
+#endif
 static thread_local int g_plan_mode = 0;
 // Tuning knob (A/B; per calling thread): 1 = the round-1 tile rule of plan_conv, 0 (default) = the scored choice.
 extern "C" int ivx_conv_set_plan_mode(int mode) {
@@ -1347,6 +1421,9 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   p->ksplit = 1; p->partial = nullptr; p->q_total = 0; p->q_begin = 0; p->q_count = 0; p->bm = 0;
   p->groups = 1; p->g_in = p->g_w = p->g_out = 0;
   p->narrow_epilogue = g_narrow_epilogue;
+#ifdef IVX_CONV_TIMELINE
+  p->tl = g_timeline;
+#endif
   p->pio = 0; p->in_scale_p = nullptr; p->out_pair = 0; p->res_pair = 0; p->res_scale_p = nullptr; p->out_scale_p = nullptr;
   p->amax_in = p->amax_res = nullptr; p->amax_out = nullptr; p->wbound = 0.f; p->sbound = 0.f;
   if (io) {
@@ -1382,7 +1459,7 @@ static void launch_cfg(const ConvParams &p, hipStream_t st) {
 
 #endif   // IVX_CONV_TU == 0
 
-template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE = 1, int PAIR = 0, int NB = 2>
+template <typename T, int TM, int TN, int WR, int WC, int BK, int WPE = 1, int PAIR = 0, int NB = 2, int RPF = 0>
 static void launch_v4(ConvParams &p, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   const int64_t in_bytes = (int64_t)p.B * p.D * p.H * p.W * p.Cin * sizeof(T);
@@ -1403,10 +1480,10 @@ static void launch_v4(ConvParams &p, hipStream_t st) {
       launch_v4<T, TM, TN, WR, WC, BK, WPE, PAIR, 2>(p, st);
       return;
     }
-    auto kern = conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1, PAIR, NB>;
+    auto kern = conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1, PAIR, NB, RPF>;
     hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
   } else {
-    auto kern = uni ? conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1, PAIR> : conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 0, PAIR>;
+    auto kern = uni ? conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 1, PAIR, 2, RPF> : conv_igemm_v4_kernel<T, TM, TN, WR, WC, BK, WPE, 0, PAIR>;
     hipLaunchKernelGGL(kern, grid, dim3(64 * WR * WC), 0, st, p, (unsigned)in_bytes, (unsigned)w_bytes);
   }
 }
@@ -1480,6 +1557,12 @@ static bool tile_info(int cfg, TileInfo *t) {
     // deep-ring forms of 66 / 74 (pair operands): NB = 4 -> 64 KB of LDS, two workgroups per CU; NB = 3 -> 48 KB, three
     case 166: *t = {64, 64, 64, 2}; return true;
     case 174: *t = {128, 128, 32, 2}; return true;
+    case 474: *t = {128, 128, 32, 3}; return true;
+    case 475: *t = {128, 128, 32, 2}; return true;
+    case 574: *t = {128, 128, 32, 2}; return true;
+    case 177: *t = {128, 128, 32, 2}; return true;
+    case 179: *t = {128, 128, 64, 1}; return true;
+    case 77: *t = {128, 128, 32, 2}; return true;
     default: return false;
   }
 }
@@ -1620,6 +1703,14 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
       static const int deep_slabs = getenv("IVX_PIO_DEEP_SLABS") ? atoi(getenv("IVX_PIO_DEEP_SLABS")) : 6;
       if (!will_split && p.kmode == 1 && Sd >= deep_slabs && tl <= deep_tiles) {
         pl.cfg += 100;       // 66 -> 166, 74 -> 174
+        // ... and the 128 x 128 tile runs on MORE WAVES where the launch leaves SIMDs idle: 16 waves (179: wave tile 32 x 32, 128-byte rows, 128 KB, one
+        // workgroup per CU) up to one tile per CU, 8 waves (177: wave tile 64 x 32) up to two.  A slab's LDS-DMA requests, fragment reads, barriers
+        // and the epilogue are issued by 4x / 2x the waves (workgroup timelines, profiles/r05_trunk_wg_timeline.md: 512 -> 128 at 48 x 160 x 4
+        // 27.1 -> 23.1 -> 20.2 us, 128 -> 128 3x3 46.8 -> 41.1 -> 34.9, 512 -> 2048 + residual at 12 x 40 33.5 -> 26.9 -> 21.9).  Same products in
+        // the same order per output: bit-identical.
+        static const long long w16_tiles = getenv("IVX_PIO_W16_TILES") ? atoll(getenv("IVX_PIO_W16_TILES")) : 256;
+        static const long long w8_tiles = getenv("IVX_PIO_W8_TILES") ? atoll(getenv("IVX_PIO_W8_TILES")) : 512;
+        if (pl.cfg == 174) pl.cfg = tl <= w16_tiles ? 179 : (tl <= w8_tiles ? 177 : 174);
         small = false;
       }
     }
@@ -1693,6 +1784,14 @@ static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     // most 512 tiles (plan_conv; profiles/r05_trunk_deep_ring.md)
     case 166: launch_v4<__bf16, 1, 1, 2, 2, 64, 2, PAIR, 4>(p, st); break;   // 66 (64 x 64, 128-byte rows)
     case 174: launch_v4<__bf16, 2, 2, 2, 2, 32, 2, PAIR, 4>(p, st); break;   // 74 (128 x 128, 64-byte rows)
+    // residual prefetch (RPF; fp16 pairs only): 74 at three / two workgroups per CU, 174
+    case 474: if constexpr (PAIR == 2) { launch_v4<__bf16, 2, 2, 2, 2, 32, 3, PAIR, 2, 1>(p, st); break; } else return IVX_ERR_INVALID_ARG;
+    case 475: if constexpr (PAIR == 2) { launch_v4<__bf16, 2, 2, 2, 2, 32, 2, PAIR, 2, 1>(p, st); break; } else return IVX_ERR_INVALID_ARG;
+    case 574: if constexpr (PAIR == 2) { launch_v4<__bf16, 2, 2, 2, 2, 32, 2, PAIR, 4, 1>(p, st); break; } else return IVX_ERR_INVALID_ARG;
+    // the 128 x 128 tile of 174 on 8 / 16 waves (wave tile 64 x 32 / 32 x 32): more waves issue the slab's LDS-DMA requests and barriers in parallel
+    case 177: launch_v4<__bf16, 2, 1, 2, 4, 32, 2, PAIR, 4>(p, st); break;
+    case 179: launch_v4<__bf16, 1, 1, 4, 4, 64, 1, PAIR, 4>(p, st); break;
+    case 77: launch_v4<__bf16, 2, 1, 2, 4, 32, 2, PAIR>(p, st); break;
     // (round 5, measured and removed -- profiles/r05_trunk_deep_ring.md (e): rings of six / eight buffers (96 / 128 KB): trunk 3.40 -> 3.9 / 4.05 ms,
     // and 3.43 / 3.47 when only launches of at most one tile per CU take them; a slab-level software pipeline of the four-buffer loop (next slab's
     // fragments read and the next DMA issued in front of the slab's last eight MFMAs): -0.09 us per slab in a long K loop, but 3.42 -> 3.45 ms)
@@ -2593,7 +2692,7 @@ static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStrea
     ivx_set_error("ivx_conv_fwd: fp8 input is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;
   }
-  const bool deep_cfg = pl.cfg == 166 || pl.cfg == 174;      // deep-ring pair tiles
+  const bool deep_cfg = pl.cfg == 166 || pl.cfg == 174 || pl.cfg == 474 || pl.cfg == 475 || pl.cfg == 574 || pl.cfg == 177 || pl.cfg == 179;      // deep-ring pair tiles
   if (p.in_bf16 && (!dma_applicable(p) || !(tile_info(pl.cfg, &ti) && ((pl.cfg >= 61 && pl.cfg < 91) || (deep_cfg && p.in_pair))))) {
     ivx_set_error("ivx_conv_fwd: bf16 input is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;

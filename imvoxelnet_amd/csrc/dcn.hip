@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const _Float16 *x,
       *reinterpret_cast<f16x8 *>(op + 16) = lo;
     }
   }
-  if (amax_out) ivx_amax_commit(amax_out, omax / sx, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (amax_out) {        // (uniform)
+    __shared__ float red[16];
+    ivx_amax_commit_wg(amax_out, omax / sx, red, (int)blockIdx.x);
+  }
 }
 
 extern "C" int ivx_dcn_im2col_fwd_pair(const void *x, const float *x_scale, const float *offset_mask, int32_t B, int32_t H, int32_t W, int32_t C,

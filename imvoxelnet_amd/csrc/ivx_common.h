@@ -62,6 +62,18 @@ __device__ __forceinline__ void ivx_amax_commit(unsigned *slots, float m, int sa
     if (__float_as_uint(m) > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(s, __float_as_uint(m));
   }
 }
+// One atomic per WORKGROUP (round 5): every thread of the workgroup calls (uniformly); the waves leave their maxima in `red` (>= blockDim.x / 64
+// floats of LDS), one barrier, wave 0 commits.  The 64 slots of a tensor lie in two cache lines, so atomics on different slots still queue at
+// one memory channel: with one atomic per wave the thousands of waves that finish together behind freshly zeroed slots held up the tail of
+// their launch by 10 - 20 us (profiles/r05_trunk_wg_timeline.md).
+__device__ __forceinline__ void ivx_amax_commit_wg(unsigned *slots, float m, float *red, int salt) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
+  if (lane == 0) red[wid] = m;
+  __syncthreads();
+  if (wid == 0) ivx_amax_commit(slots, lane < nw ? red[lane] : 0.f, salt);
+}
 // the maximum the slots hold (every lane of a full wave calls; all lanes get the result)
 __device__ __forceinline__ float ivx_amax_read(const unsigned *slots) {
   float a = __uint_as_float(slots[threadIdx.x & (IVX_AMAX_SLOTS - 1)]);

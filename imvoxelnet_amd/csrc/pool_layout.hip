@@ -174,7 +174,10 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float *in, int
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = f32x4p{v[0][q], v[1][q], v[2][q], v[3][q]};
   }
-  if (AMAX) ivx_amax_commit(amax, m, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (AMAX) {
+    __shared__ float red[4];
+    ivx_amax_commit_wg(amax, m, red, (int)blockIdx.x);
+  }
 }
 static bool nchw4_applicable(const float *in, const float *out, int C, long long S, int Cpad) {
   return C <= 4 && Cpad == 4 && S % 4 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0;
@@ -424,7 +427,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_amax_kernel(const float *in,
     const int c = c0 + tx;
     if (s < S && c < Cpad) out[((size_t)b * S + s) * Cpad + c] = tile[tx][r];
   }
-  ivx_amax_commit(amax, m, (int)(blockIdx.x + blockIdx.z) * 4 + (int)(threadIdx.x >> 6));
+  __shared__ float red[4];
+  ivx_amax_commit_wg(amax, m, red, (int)(blockIdx.x + blockIdx.z));
 }
 
 extern "C" int ivx_nchw_to_nhwc_amax(const float *in, int32_t B, int32_t C, int64_t S, int32_t Cpad, float *out, uint32_t *amax,
@@ -492,7 +496,10 @@ __global__ __launch_bounds__(256) void maxpool2d_nhwc_pair_kernel(const float *i
     *reinterpret_cast<f16x4 *>(o) = hi;
     *reinterpret_cast<f16x4 *>(o + 16) = lo;
   }
-  if (amax_out) ivx_amax_commit(amax_out, omax, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (amax_out) {        // (uniform)
+    __shared__ float red[4];
+    ivx_amax_commit_wg(amax_out, omax, red, (int)blockIdx.x);
+  }
 }
 
 extern "C" int ivx_maxpool2d_fwd_pair(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p, void *out,

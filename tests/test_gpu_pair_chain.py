@@ -149,7 +149,9 @@ DEEP_CASES = [
 def test_deep_ring_tiles_are_bit_identical(ia, case):
     """Round 5: the deep-ring forms of the pair tiles (conv_igemm_v4_kernel<.., NB = 4>: 166 = 64 x 64, 174 = 128 x 128; A/B configs) issue
     the same products in the same order as the two-buffer tiles 66 / 74 -- only the DMA of slab s + NB is issued earlier -- so outputs,
-    scales and recorded maxima are equal bit for bit, for K loops shorter than the ring, odd slab counts and every residual form."""
+    scales and recorded maxima are equal bit for bit, for K loops shorter than the ring, odd slab counts and every residual form.  Likewise the
+    128 x 128 tile on 8 / 16 waves (177 / 179: the rule's choice up to two / one tile per CU) and with the residual requested in front of the K
+    loop (475)."""
     from imvoxelnet_amd import _lib, ops
     L = _lib.lib()
     B, (H, W), ci, co, k, st, res_kind, out_pair = case
@@ -180,13 +182,16 @@ def test_deep_ring_tiles_are_bit_identical(ia, case):
         finally:
             L.ivx_conv_set_tile_override(0)
 
-    for base, deep in ((66, (166,)), (74, (174,))):
+    for base, deep in ((66, (166,)), (74, (174, 177, 179, 475))):
         want = run(base)
         for cfg in deep:
             got = run(cfg)
             if out_pair:
                 assert got.scale() == want.scale() and torch.equal(got.data, want.data), (base, cfg)
-                assert torch.equal(got.slots, want.slots), (base, cfg)
+                if cfg in (177, 179):      # other workgroup shapes: the maxima land in other slots, the recorded maximum is the same
+                    assert int(got.slots.max()) == int(want.slots.max()), (base, cfg)
+                else:
+                    assert torch.equal(got.slots, want.slots), (base, cfg)
             else:
                 assert torch.equal(got, want) and torch.equal(got.ivx_slots, want.ivx_slots), (base, cfg)
     auto = run(0)                      # the library's own choice: same bits as tile 66 / 74 ...

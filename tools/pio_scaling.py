@@ -65,8 +65,29 @@ def timed(L, args, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=50)
+    ap.add_argument('--expand', action='store_true', help="only: the four Cout-expanding 1x1 layers with a residual at KITTI's sizes, by epilogue option and tile")
     a = ap.parse_args()
     L = _lib.lib()
+    if a.expand:
+        cfgs = [int(c) for c in os.environ.get("PIO_CFGS", "0,74,73,81").split(",")]
+        print('## 1x1 expansions of the bottlenecks (KITTI batch 4): us per launch (algorithmic GB/s) by epilogue option; tile configs ' + str(cfgs))
+        for (h, w, ci, co) in ((96, 320, 64, 256), (48, 160, 128, 512), (24, 80, 256, 1024), (12, 40, 512, 2048)):
+            M = 4 * h * w
+            for out_pair, amax, res in ((True, True, True), (True, True, False), (False, False, False), (False, False, True)):
+                args, keep = build(4, h, w, ci, co, 1, out_pair, amax, res)
+                nbytes = (M * ci + M * co * (2 if res else 1) + ci * co) * 4
+                row = []
+                for c in cfgs:
+                    L.ivx_conv_set_tile_override(c)
+                    try:
+                        t = timed(L, args, a.iters)
+                        row.append(f'cfg {c}: {t:.1f} ({nbytes / t / 1e3:.0f})')
+                    except Exception:
+                        row.append(f'cfg {c}: -')
+                    L.ivx_conv_set_tile_override(0)
+                print(f'{ci}->{co} at {h}x{w} out_pair={out_pair} amax={amax} residual={res} [{nbytes / 1e6:.0f} MB]: ' + ' | '.join(row), flush=True)
+                del args, keep
+        return
     B, H, W = 4, 24, 80
     print('## K sweep: 1x1, M = 7680 rows (4 x 24 x 80), Cout 256, pair out; us per launch by tile config')
     cfgs = [int(c) for c in os.environ.get("PIO_CFGS", "0,66,166,74,174,73,81").split(",")]
