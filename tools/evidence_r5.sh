@@ -29,7 +29,7 @@ IVX_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-no
 # kernel traces
 trace() {   # name, steps-profiled, bench args...
   name=$1; nst=$2; shift 2
-  (cd /tmp && IVX_BENCH_ALT=0 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace_$name -o t -- python $ROOT/bench.py --no-cpu-baseline "$@" > $ROOT/$OUT/trace_$name.log 2>&1)
+  (cd /tmp && IVX_BENCH_ALT=0 IVX_BENCH_EXTRA=0 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace_$name -o t -- python $ROOT/bench.py --no-cpu-baseline "$@" > $ROOT/$OUT/trace_$name.log 2>&1)
   grep '^{"metric' $OUT/trace_$name.log | tail -1 > $OUT/bench_profiled_$name.json
   DB=$(find $OUT/trace_$name -name "*.db" | head -1)
   [ -n "$DB" ] && python tools/rocpd_summary.py $DB $nst > $OUT/kernel_trace_$name.md

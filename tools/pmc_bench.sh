@@ -14,6 +14,6 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_
            "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $ROOT/$OUT/pass$i -o p -- \
-      env IVX_BENCH_ALT=0 python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $ARGS > $ROOT/$OUT/pass$i.log 2>&1
+      env IVX_BENCH_ALT=0 IVX_BENCH_EXTRA=0 python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $ARGS > $ROOT/$OUT/pass$i.log 2>&1
   tail -1 $ROOT/$OUT/pass$i.log | cut -c1-200
 done
