@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libimvoxel_hip.so')
+LIB_PATH = os.environ.get('IVX_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libimvoxel_hip.so')      # (IVX_LIB_PATH: A/B builds of the same ABI, tools/)
 _lib = None
 
 
