@@ -85,6 +85,10 @@ struct ConvParams {
   const unsigned *amax_in, *amax_res;   // device, IVX_AMAX_SLOTS words: bits of max |in| / max |res| (true values); out_pair only
   unsigned *amax_out;            // device, IVX_AMAX_SLOTS words the epilogue accumulates max |out| into (atomic max), or NULL
   float wbound, sbound;          // |out| <= amax_in * wbound + sbound (+ amax_res): max_co |scale[co]| * sum_k |w[co][k]| and max_co |shift[co]|
+  // one device word copied by workgroup 0 of the launch (grouped Winograd-domain GEMMs: the filter scale travels to the workspace header
+  // the output transform reads -- was a 4-byte hipMemcpyAsync, i.e. one more launch per neck layer); NULL = none
+  const unsigned *cp_src;
+  unsigned *cp_dst;
 #ifdef IVX_CONV_TIMELINE
   unsigned long long *tl;        // debug build only (tools/conv_timeline.py): 8 words per workgroup of conv_igemm_v4_kernel's pair-IO path --
                                  // s_memrealtime (100 MHz) at entry, after the prologue barrier, after the K loop, at the end; HW_ID; XCC_ID
@@ -829,6 +833,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   if (mt * BM >= p.M) return;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
+  if (p.cp_dst && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *p.cp_dst = *p.cp_src;
 #ifdef IVX_CONV_TIMELINE
   unsigned long long tl0 = __builtin_amdgcn_s_memrealtime(), tl1 = 0, tl2 = 0;
 #endif
@@ -1424,6 +1429,7 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
 #ifdef IVX_CONV_TIMELINE
   p->tl = g_timeline;
 #endif
+  p->cp_src = nullptr; p->cp_dst = nullptr;
   p->pio = 0; p->in_scale_p = nullptr; p->out_pair = 0; p->res_pair = 0; p->res_scale_p = nullptr; p->out_scale_p = nullptr;
   p->amax_in = p->amax_res = nullptr; p->amax_out = nullptr; p->wbound = 0.f; p->sbound = 0.f;
   if (io) {
@@ -1871,6 +1877,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
   if (mt * BMO >= p.M) return;
   const int m0 = mt * BMO, n0 = nt * BN;
   const size_t gz = blockIdx.z;
+  if (p.cp_dst && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) *p.cp_dst = *p.cp_src;
   const __amdgpu_buffer_rsrc_t rs_in =
       __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.in + gz * (size_t)p.g_in * sizeof(T)), 0, in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w =
@@ -2098,6 +2105,7 @@ __global__ __launch_bounds__(64 * WCOL * (Z / 3) * WN, WPE) void conv_wino_zblk_
   const int m0 = c0 * Z;                         // its first OUTPUT row (columns x Z)
   if (m0 >= p.M) return;
   const size_t gz = blockIdx.z;
+  if (p.cp_dst && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) *p.cp_dst = *p.cp_src;
   const __amdgpu_buffer_rsrc_t rs_in =
       __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.in + gz * (size_t)p.g_in * sizeof(T)), 0, in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w =
@@ -2798,10 +2806,18 @@ extern "C" float ivx_conv_winograd_issued_fraction(const ivx_conv_desc *d) {
 }
 
 int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w,
-                            float *out, long long g_out, hipStream_t st) {
+                            float *out, long long g_out, hipStream_t st, const unsigned *cp_src, unsigned *cp_dst) {
   ConvParams p;
   int rc = fill_params(d, in, wgt, nullptr, nullptr, nullptr, out, &p);
   if (rc != IVX_OK) return rc;
+  if (cp_dst && !p.in_pair) {                    // (only the pair-operand kernels carry the word; not reached by the library's own callers)
+    if (hipMemcpyAsync(cp_dst, cp_src, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      ivx_set_error("ivx_conv_grouped_launch: hipMemcpyAsync failed");
+      return IVX_ERR_HIP;
+    }
+  } else {
+    p.cp_src = cp_src; p.cp_dst = cp_dst;
+  }
   IVX_REQUIRE(groups >= 1 && groups <= 65535, "ivx_conv_grouped_launch: bad group count");
   IVX_REQUIRE((d->in_dtype == IVX_F32 || d->in_dtype == IVX_BF16_PAIR || d->in_dtype == IVX_F16_PAIR) && d->out_dtype == IVX_F32 &&
                   d->out_mode == 0 && d->res_mode == 0,

@@ -19,7 +19,7 @@
 #include "ivx_common.h"
 
 int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w,
-                            float *out, long long g_out, hipStream_t st);
+                            float *out, long long g_out, hipStream_t st, const unsigned *cp_src, unsigned *cp_dst);
 int ivx_conv_grouped_fold4(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w, const IvxWinoFold *f,
                            hipStream_t st);
 int ivx_conv_fold4_blocks(long long M, int Cout);
@@ -777,7 +777,7 @@ static int wino_input_impl(const ivx_conv_desc *d, int32_t tile, const void *in,
       ivx_set_error("ivx_conv_winograd_input: hipMemsetAsync failed");
       return IVX_ERR_HIP;
     }
-    if (partials) {   // the producer left per-workgroup maxima of this tensor (ivx_conv_winograd_output_amax): reduce those few KB
+    if (partials) {   // the producer left per-workgroup maxima of this tensor (ivx_conv_winograd_output_amax): reduce those (1 - 2 MB at KITTI size)
       const int pb = (n_partials + 255) / 256;
       hipLaunchKernelGGL(wino_amax_partials_kernel, dim3((unsigned)(pb > 64 ? 64 : pb)), dim3(256), 0, (hipStream_t)stream, partials, n_partials,
                          (unsigned *)p.hdr);
@@ -825,13 +825,12 @@ extern "C" int ivx_conv_winograd_gemm(const ivx_conv_desc *d, int32_t tile, cons
   ivx_conv_desc g = wino_group_desc(d, w);
   const long long el = d->wino_operands == IVX_F16_PAIR ? 2 : 1;   // operand strides count stored elements (two fp16 per value)
   g.in_dtype = d->wino_operands;
-  rc = ivx_conv_grouped_launch(&g, w.n2, p.V, el * w.v_stride, u, el * d->Cout * d->KW * d->Cin, p.Mw, w.m_stride, (hipStream_t)stream);
+  // the filter scale travels with the filters; the output transform reads it from the workspace header: workgroup 0 of the GEMM launch copies
+  // the word (a separate 4-byte hipMemcpyAsync was one more launch per layer)
+  const unsigned *us = p.hdr ? reinterpret_cast<const unsigned *>(u + (int64_t)w.n2 * d->Cout * d->KW * d->Cin + 1) : nullptr;
+  rc = ivx_conv_grouped_launch(&g, w.n2, p.V, el * w.v_stride, u, el * d->Cout * d->KW * d->Cin, p.Mw, w.m_stride, (hipStream_t)stream, us,
+                               p.hdr ? const_cast<unsigned *>(p.hdr) + 1 : nullptr);
   if (rc != IVX_OK) return rc;
-  if (p.hdr && hipMemcpyAsync((void *)(p.hdr + 1), u + (int64_t)w.n2 * d->Cout * d->KW * d->Cin + 1, 4, hipMemcpyDeviceToDevice,
-                              (hipStream_t)stream) != hipSuccess) {   // the filter scale travels with the filters; the output transform reads it here
-    ivx_set_error("ivx_conv_winograd_gemm: hipMemcpyAsync failed");
-    return IVX_ERR_HIP;
-  }
   IVX_CHECK_LAUNCH("ivx_conv_winograd_gemm");
   return IVX_OK;
 }
