@@ -1569,6 +1569,7 @@ static bool tile_info(int cfg, TileInfo *t) {
     case 177: *t = {128, 128, 32, 2}; return true;
     case 179: *t = {128, 128, 64, 1}; return true;
     case 77: *t = {128, 128, 32, 2}; return true;
+    case 183: *t = {256, 256, 32, 1}; return true;
     default: return false;
   }
 }
@@ -1798,6 +1799,7 @@ static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
     case 177: launch_v4<__bf16, 2, 1, 2, 4, 32, 2, PAIR, 4>(p, st); break;
     case 179: launch_v4<__bf16, 1, 1, 4, 4, 64, 1, PAIR, 4>(p, st); break;
     case 77: launch_v4<__bf16, 2, 1, 2, 4, 32, 2, PAIR>(p, st); break;
+    case 183: launch_v4<__bf16, 2, 2, 4, 4, 32, 1, PAIR, 3>(p, st); break;   // 82 (256 x 256, 16 waves) with a three-buffer ring: 96 KB
     // (round 5, measured and removed -- profiles/r05_trunk_deep_ring.md (e): rings of six / eight buffers (96 / 128 KB): trunk 3.40 -> 3.9 / 4.05 ms,
     // and 3.43 / 3.47 when only launches of at most one tile per CU take them; a slab-level software pipeline of the four-buffer loop (next slab's
     // fragments read and the next DMA issued in front of the slab's last eight MFMAs): -0.09 us per slab in a long K loop, but 3.42 -> 3.45 ms)
@@ -2700,7 +2702,7 @@ static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStrea
     ivx_set_error("ivx_conv_fwd: fp8 input is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;
   }
-  const bool deep_cfg = pl.cfg == 166 || pl.cfg == 174 || pl.cfg == 474 || pl.cfg == 475 || pl.cfg == 574 || pl.cfg == 177 || pl.cfg == 179;      // deep-ring pair tiles
+  const bool deep_cfg = pl.cfg == 166 || pl.cfg == 174 || pl.cfg == 474 || pl.cfg == 475 || pl.cfg == 574 || pl.cfg == 177 || pl.cfg == 179 || pl.cfg == 183;      // deep-ring pair tiles
   if (p.in_bf16 && (!dma_applicable(p) || !(tile_info(pl.cfg, &ti) && ((pl.cfg >= 61 && pl.cfg < 91) || (deep_cfg && p.in_pair))))) {
     ivx_set_error("ivx_conv_fwd: bf16 input is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;
@@ -2855,7 +2857,10 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     // (tools/gemm_ab.py --pair, profiles/r03_gemm_ab_pair.log)
     // measured on the KITTI neck (tools/pair_ab.py, profiles/r03_pair_ab.log): Cout 64: 256 x 64 at four per CU 0.69 ms (128 x 64: 0.74-0.84);
     // Cout 128: 256 x 128 8 waves 0.60 / 0.88 (128 x 128: 0.63 / 0.89); Cout 256: 256 x 256 16 waves 0.87 / 1.39 (8 waves: 0.91 / 1.41)
-    pl.cfg = p.Cout <= 64 ? 76 : (p.Cout <= 128 ? 81 : 82);
+    // round 5: the 256 x 256 tile with a THREE-buffer ring behind raw barriers (183; one workgroup of 16 waves per CU either way): the last KITTI
+    // neck layer (256 -> 256, z 3 -> 1: a dense GEMM with K = 3 Cin, 48 slabs of 1.9 us for 0.64 us of matrix work) 0.633 -> 0.579 ms (four
+    // buffers 0.582; tools/l9_ab.py); same products in the same order
+    pl.cfg = p.Cout <= 64 ? 76 : (p.Cout <= 128 ? 81 : (p.in_pair == 2 && p.kmode == 1 ? 183 : 82));
     // few tiles (the 2-D 3x3 layers of the trunk at KITTI size, the indoor necks): the 8- / 16-wave tiles would leave most CUs idle
     const long long nblk = (long long)groups * ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (nblk < 2500) pl.cfg = 67;
