@@ -182,7 +182,7 @@ def test_deep_ring_tiles_are_bit_identical(ia, case):
         finally:
             L.ivx_conv_set_tile_override(0)
 
-    for base, deep in ((66, (166,)), (74, (174, 177, 179, 475))):
+    for base, deep in ((66, (166,)), (74, (174, 177, 179, 475)), (82, (183,))):      # 183: the last neck layer's GEMM tile on a three-buffer ring
         want = run(base)
         for cfg in deep:
             got = run(cfg)
@@ -194,6 +194,7 @@ def test_deep_ring_tiles_are_bit_identical(ia, case):
                     assert torch.equal(got.slots, want.slots), (base, cfg)
             else:
                 assert torch.equal(got, want) and torch.equal(got.ivx_slots, want.ivx_slots), (base, cfg)
+    want = run(74)
     auto = run(0)                      # the library's own choice: same bits as tile 66 / 74 ...
     gv = auto.float() if out_pair else auto
     wv = want.float() if out_pair else want
