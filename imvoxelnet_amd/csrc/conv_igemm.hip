@@ -1880,6 +1880,10 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
   const int m0 = mt * BMO, n0 = nt * BN;
   const size_t gz = blockIdx.z;
   if (p.cp_dst && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) *p.cp_dst = *p.cp_src;
+#ifdef IVX_CONV_TIMELINE
+  const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tl1 = 0, tl2 = 0;
+#endif
   const __amdgpu_buffer_rsrc_t rs_in =
       __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.in + gz * (size_t)p.g_in * sizeof(T)), 0, in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w =
@@ -1969,6 +1973,9 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
     } else {
       lds_dma_wait_all();
     }
+#ifdef IVX_CONV_TIMELINE
+    if (g == 0) tl1 = __builtin_amdgcn_s_memrealtime();      // the first group has landed
+#endif
     if constexpr (NBUF == 2) {
       __syncthreads();                  // ... and every wave is done reading the buffer of group g - 1, which group g + D now overwrites
     } else {
@@ -2027,6 +2034,9 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
     cur = cur + 1 == NBUF ? 0 : cur + 1;
     nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
   }
+#ifdef IVX_CONV_TIMELINE
+  tl2 = __builtin_amdgcn_s_memrealtime();
+#endif
   __syncthreads();                      // the staging area of the epilogue overlaps the ring
   if constexpr (TAIL) {
     conv_epilogue_wide<TM, TN>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, gz * (size_t)p.g_out);
@@ -2054,6 +2064,13 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_wino_halo_kernel(const
       }
     }
   }
+#ifdef IVX_CONV_TIMELINE
+  if (p.tl && tid == 0) {
+    unsigned long long *t = p.tl + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    t[0] = tl0; t[1] = tl1; t[2] = tl2; t[3] = __builtin_amdgcn_s_memrealtime();
+    t[4] = __builtin_amdgcn_s_getreg(63492); t[5] = __builtin_amdgcn_s_getreg(63508);
+  }
+#endif
 }
 
 template <int TM, int TN, int WR, int WC, int WPE, int PAIR, int NBUF, int TAIL = 1, int SW = 1, int ZR = 0, int DI = 0>
@@ -2266,6 +2283,9 @@ int ivx_conv_launch_halo(ConvParams &p, int cfg, hipStream_t st) {
     case 43: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 2, 1, 1>(p, st); break;  // 42 with de-interleaved staging
     case 44: launch_halo<2, 1, 2, 2, 2, 2, 2, 0, 2, 1, 1>(p, st); break;  // 41 with de-interleaved staging
     case 45: launch_halo<2, 2, 2, 2, 2, 2, 2, 0, 2, 0, 1>(p, st); break;  // 22 with de-interleaved staging
+    // round 5 (A/B): the tile of 42 on twice the waves (wave tile 64 x 32 instead of 64 x 64) -- 0.520 / 0.807 ms against 0.519 / 0.802: unlike the
+    // trunk's one-wave-per-SIMD launches these kernels are not bound by what a single wave issues
+    case 46: launch_halo<2, 1, 2, 4, 2, 2, 2, 0, 2, 1>(p, st); break;  // stride 2: 127 x 128, 8 waves, 80 KB, two per CU
     // z-blocked tiles (conv_wino_zblk_kernel; Wo = 3 or 6 only): 50 / 51 = 8 / 16 waves at Z = 3, 60 at Z = 6.  Measured and not kept as
     // instantiations (profiles/r04_zblk_ab.md): 384 x 64 (8 waves) 1.04, 192 x 64 (4 waves) 1.07, 192 x 256 (16 waves) 1.05, 96 x 128 1.22 ms at
     // Z = 3 (50: 0.99); at Z = 6: 192 x 64 0.675, 192 x 256 1.08, 384 x 128 0.67 (60: 0.63-0.65); z stride 2: 6 -> 3 slices 64 columns 0.874, 12 -> 6 0.578
