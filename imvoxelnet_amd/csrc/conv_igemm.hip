@@ -96,13 +96,13 @@ struct ConvParams {
 };
 
 // What a wave needs of the pair-IO state: multipliers of the accumulator / the residual (exact: powers of two) and the output scale.
-struct PairIO { float inv_in, inv_res, s_out; bool sat; };
+struct PairIO { float inv_in, inv_res, s_out; bool sat; float post; };      // post = ConvParams::post_scale (carried here: see conv_igemm_v4_kernel)
 // Every wave computes the same values from the same device words (no communication): the output scale comes from a BOUND of the
 // output -- |out| <= max|in| * wbound + sbound + max|res| with the MEASURED maxima of the operands, which their producers left in the
 // amax slots -- so nothing has to pass over the output before it is written as (hi, lo) halves.  A bound that is loose by a factor L
 // costs nothing up to L = 2^18: a value's error is max(2^-22 |x|, 2^-25 / s), i.e. relative to the tensor's maximum max(2^-22, 2^-40 L).
 __device__ __forceinline__ PairIO conv_pair_io(const ConvParams &p) {
-  PairIO io = {1.0f, 1.0f, 1.0f, false};
+  PairIO io = {1.0f, 1.0f, 1.0f, false, p.post_scale};
   if (p.in_scale_p) io.inv_in = 1.0f / *p.in_scale_p;
   if (p.res_pair && p.res_scale_p) io.inv_res = 1.0f / *p.res_scale_p;
   if (p.out_pair) {
@@ -343,7 +343,7 @@ __device__ __forceinline__ float conv_pio_finish4_rr(const ConvParams &p, const 
     v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
   }
   if (p.res_mode && p.res_after_act) v += rr;
-  v *= p.post_scale;
+  v *= io.post;
   if (p.out_pair) {
     f16x4 h, l;
 #pragma unroll
@@ -1164,7 +1164,15 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
   if constexpr (PAIR == 2) {
     if (p.pio) {        // fill_params guarantees out_mode 0, Cout % 16 == 0, no grouped launch
       static_assert(sizeof(smem) >= (size_t)NT / 64 * 4096, "4 KB of staging LDS per wave for the transposed epilogue");
-      const PairIO io = conv_pair_io(p);
+      PairIO io = conv_pair_io(p);
+      // the three multipliers are the same in every lane: say so (SGPRs).  As VGPR values they were spilled at four workgroups per CU and
+      // RELOADED FROM SCRATCH in every pass of the epilogue -- two more memory round trips per pass, each behind an `s_waitcnt vmcnt(0)` that
+      // also waits for the pass's own stores (ISA, round 5)
+      io.inv_in = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, io.inv_in)));
+      io.inv_res = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, io.inv_res)));
+      io.s_out = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, io.s_out)));
+      io.post = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.post_scale)));      // (the compiler kept
+      // {post_scale, ksplit, partial} of the by-value ConvParams in a 16-byte private array and re-read post_scale from scratch in every pass)
       if (p.out_scale_p && blockIdx.x == 0 && tid == 0) *p.out_scale_p = io.s_out;     // (workgroup 0 owns M-tile q_begin of XCD 0: never out of range)
       if constexpr (RPF) conv_epilogue_wide_pio<TM, TN, 1>(p, io, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, wid_u, NT / 64, rraw);
       else conv_epilogue_wide_pio<TM, TN>(p, io, acc, m0, n0, wr, wc, lane, reinterpret_cast<float *>(smem) + wid_u * 1024, wid_u, NT / 64);
@@ -1203,7 +1211,7 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
 // kernel and the split-K reduction.
 #if IVX_CONV_TU == 0
 // (pair IO: the scales of conv_pair_io; returns |stored value| before the output scale, for the amax slots)
-__device__ __forceinline__ float conv_store_one(const ConvParams &p, int m, int n, float acc, const PairIO io = {1.0f, 1.0f, 1.0f, false}) {
+__device__ __forceinline__ float conv_store_one(const ConvParams &p, int m, int n, float acc, const PairIO io = {1.0f, 1.0f, 1.0f, false, 1.0f}) {
   if (p.pio) {
     const size_t idx = (size_t)m * p.Cout + n;
     size_t ridx = idx;
@@ -1233,7 +1241,7 @@ __device__ __forceinline__ float conv_store_one(const ConvParams &p, int m, int 
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   const size_t rows = (size_t)8 * p.q_count * p.bm;
   const size_t total = rows * p.Cout;
-  PairIO io = {1.0f, 1.0f, 1.0f, false};
+  PairIO io = {1.0f, 1.0f, 1.0f, false, p.post_scale};
   if (p.pio) {
     io = conv_pair_io(p);
     if (p.out_scale_p && blockIdx.x == 0 && threadIdx.x == 0) *p.out_scale_p = io.s_out;
@@ -1287,7 +1295,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_pio_kernel(const ConvP
 // Validation kernel: one thread per output element, sequential fmaf over (kd,kh,kw,ci).
 __global__ __launch_bounds__(256) void conv_naive_f32_kernel(const ConvParams p) {
   const size_t total = (size_t)p.M * p.Cout;
-  PairIO io = {1.0f, 1.0f, 1.0f, false};
+  PairIO io = {1.0f, 1.0f, 1.0f, false, p.post_scale};
   if (p.pio) {
     io = conv_pair_io(p);
     if (p.out_scale_p && blockIdx.x == 0 && threadIdx.x == 0) *p.out_scale_p = io.s_out;
