@@ -17,6 +17,7 @@ SOURCES = [
     ('conv_igemm.hip', ['-DIVX_CONV_TU=3'], 'conv_igemm_pair_bf16.o'),
     ('conv_igemm.hip', ['-DIVX_CONV_TU=4'], 'conv_igemm_pair_f16.o'),
     ('conv_igemm.hip', ['-DIVX_CONV_TU=5'], 'conv_igemm_halo.o'),
+    ('bottleneck.hip', []),
     ('winograd.hip', []),
     ('pool_layout.hip', []),
     ('backproject.hip', ['-ffp-contract=off']),

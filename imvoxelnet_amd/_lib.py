@@ -51,6 +51,17 @@ class PairIO(C.Structure):
                 ('amax_res', C.c_void_p), ('amax_out', C.c_void_p), ('wbound', C.c_float), ('sbound', C.c_float)]
 
 
+class BottleneckDesc(C.Structure):
+    """ivx_bottleneck_desc."""
+    _fields_ = [(n, C.c_int32) for n in ('B', 'H', 'W', 'P')]
+
+
+class BottleneckIO(C.Structure):
+    """ivx_bottleneck_io: scalar blocks of the fused bottleneck's input / output and the bound terms of its three layers."""
+    _fields_ = [('in_scale', C.c_void_p), ('amax_in', C.c_void_p), ('out_scale', C.c_void_p), ('amax_out', C.c_void_p), ('wbound', C.c_float * 3),
+                ('sbound', C.c_float * 3)]
+
+
 class SampleMeta(C.Structure):
     """ivx_sample_meta."""
     _fields_ = [('intrinsic', C.c_float * 16), ('extrinsics', C.c_void_p), ('origin', C.c_float * 3), ('img_h', C.c_int32), ('img_w', C.c_int32),
@@ -69,7 +80,7 @@ class TraceRec(C.Structure):
                 ('bytes', C.c_double), ('name', C.c_char * 48)]
 
 
-EXPORTS = ['ivx_conv_winograd_set_variant', 'ivx_ubench_mfma', 'ivx_ubench_copy', 'ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws', 'ivx_conv_set_halo_mode', 'ivx_bf16_pair_split', 'ivx_f16_pair_split', 'ivx_conv_pair_supported', 'ivx_conv_pio_workspace_bytes', 'ivx_conv_fwd_pio', 'ivx_conv_fwd_pio_naive', 'ivx_pair_pack_filters', 'ivx_nchw_to_nhwc_amax', 'ivx_maxpool2d_fwd_pair', 'ivx_f16_pair_merge', 'ivx_model_calibrate_fp8', 'ivx_amax_bf16', 'ivx_conv_winograd_output_blocks', 'ivx_conv_winograd_issued_fraction', 'ivx_conv_winograd_output_amax', 'ivx_conv_winograd_input_amax', 'ivx_conv_winograd_fused_supported', 'ivx_conv_winograd_fused_blocks', 'ivx_conv_winograd_gemm_output_amax',
+EXPORTS = ['ivx_bottleneck_supported', 'ivx_bottleneck_fwd_pio', 'ivx_conv_winograd_set_variant', 'ivx_ubench_mfma', 'ivx_ubench_copy', 'ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws', 'ivx_conv_set_halo_mode', 'ivx_bf16_pair_split', 'ivx_f16_pair_split', 'ivx_conv_pair_supported', 'ivx_conv_pio_workspace_bytes', 'ivx_conv_fwd_pio', 'ivx_conv_fwd_pio_naive', 'ivx_pair_pack_filters', 'ivx_nchw_to_nhwc_amax', 'ivx_maxpool2d_fwd_pair', 'ivx_f16_pair_merge', 'ivx_model_calibrate_fp8', 'ivx_amax_bf16', 'ivx_conv_winograd_output_blocks', 'ivx_conv_winograd_issued_fraction', 'ivx_conv_winograd_output_amax', 'ivx_conv_winograd_input_amax', 'ivx_conv_winograd_fused_supported', 'ivx_conv_winograd_fused_blocks', 'ivx_conv_winograd_gemm_output_amax',
            'ivx_conv_winograd_supported', 'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_weights', 'ivx_conv_winograd_workspace_bytes',
            'ivx_conv_winograd_input', 'ivx_conv_winograd_gemm', 'ivx_conv_winograd_output', 'ivx_conv_winograd_fwd',
            'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_maxpool2d_fwd_fp8', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_dcn_im2col_fwd_pair', 'ivx_nchw_to_nhwc', 'ivx_image_s2d_bf16', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_amax', 'ivx_backproject_amax_blocks', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
@@ -118,6 +129,8 @@ def lib():
     L.ivx_conv_pair_supported.argtypes = [C.POINTER(ConvDesc)]
     L.ivx_conv_pio_workspace_bytes.argtypes = [C.POINTER(ConvDesc), C.POINTER(PairIO)]
     L.ivx_conv_pio_workspace_bytes.restype = i64
+    L.ivx_bottleneck_supported.argtypes = [C.POINTER(BottleneckDesc)]
+    L.ivx_bottleneck_fwd_pio.argtypes = [C.POINTER(BottleneckDesc), C.POINTER(BottleneckIO)] + [vp] * 12
     L.ivx_conv_fwd_pio.argtypes = [C.POINTER(ConvDesc), C.POINTER(PairIO), vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.ivx_conv_fwd_pio_naive.argtypes = [C.POINTER(ConvDesc), C.POINTER(PairIO), vp, vp, vp, vp, vp, vp, vp]
     L.ivx_pair_pack_filters.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, C.POINTER(f32), C.POINTER(f32)]

@@ -1,0 +1,540 @@
+// One ResNet bottleneck (identity shortcut) in ONE launch on the 16-bit matrix cores: conv1 1x1 (4P -> P) + BN + ReLU, conv2 3x3 (P -> P) + BN +
+// ReLU, conv3 1x1 (P -> 4P) + BN + shortcut + ReLU, on fp16 (hi, lo) pair tensors (IVX_F16_PAIR; three fp16 MFMA products per multiply-add as
+// ivx_conv_fwd_pio).  Replaces three launches of conv_igemm_v4_kernel per block of ResNet-50's stages 1 and 2 (reference call site
+// mmdet3d/models/detectors/imvoxelnet.py:48, configs/imvoxelnet/imvoxelnet_kitti.py:4-12: the mmdet ResNet(depth=50, style='pytorch') blocks):
+// the P-channel intermediates never leave the CU -- per block HBM carries the 4P-channel input once (+ a one-pixel halo, mostly from L2) and
+// the 4P-channel output once, instead of (4P + P) + (P + P) + (P + 4P + 4P) channels per pixel.
+//
+//   Workgroup = an 8 x 16 tile of output pixels of one image; P / 16 waves (P = 64: 4 waves, two workgroups per CU; P = 128: 8 waves, one).
+//   Phase 1   conv1 over the tile + its one-pixel ring (10 x 18 = 180 pixels, 192 GEMM rows): A (pixels) and B (filters) stream global -> LDS by
+//             LDS-DMA in 32-channel slabs (128-byte XOR-swizzled rows, hardware zero fill outside the image), ring of NB1 slabs; the epilogue
+//             (BN, ReLU, zero outside the image = conv2's padding, pair split with the a-priori scale) leaves mid1 in LDS as a pair tile.
+//   Phase 2   conv2: A fragments straight from the mid1 tile (im2col by addressing: tap (dy, dx) shifts the pixel row), the 9 x P/32 filter
+//             slabs through a ring of NB2; epilogue -> mid2 (pair tile, 128 pixels) over mid1's LDS.
+//   Phase 3   conv3 in units of 128 output channels: A from mid2, filter slabs through a ring of NB3; epilogue through a per-wave transposing
+//             stage (4 consecutive channels per lane): BN + the block's input re-read as the shortcut (L2) + ReLU + max |out| + pair split,
+//             8-byte stores of hi and lo halves.
+//   Scales    powers of two from BOUNDS, as conv_pair_io (conv_igemm.hip): b1 = max|in| * wbound1 + sbound1, b2 = b1 * wbound2 + sbound2,
+//             b3 = b2 * wbound3 + sbound3 + max|in|; every wave derives them from the input's amax slots -- no pass over a tensor, no
+//             communication.  The looseness compounds over the three layers (the layer-wise chain measures max |mid|): a bound loose by L
+//             costs nothing up to L = 2^18 (ivx_common.h), ResNet-50's are ~2^10 after three layers.
+//   LDS swizzle of the pair tiles: a pixel row is 4P bytes (16-byte chunks [hi8 hi8 lo8 lo8] per 16 channels); chunk c of pixel (y, x) lies at
+//             c ^ (x & 15): the 16 lanes of one ds_read_b128 group hold 16 consecutive x (ds_read_b128 lane groups, MI355X guide), so every
+//             group reads 16 different 16-byte positions of the 256-byte bank window -- for every tap.
+#include "ivx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct BnkParams {
+  const _Float16 *in;
+  _Float16 *out;
+  const _Float16 *w1, *w2, *w3;              // pair filters of ivx_pair_pack_filters: [Cout][Cin/32][taps][hi16 lo16 hi16 lo16]
+  const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3;   // scale / s_w and shift of the three BatchNorms
+  const float *in_scale_p;                   // device: the scale the input was written with
+  const unsigned *amax_in;                   // device, IVX_AMAX_SLOTS words: bits of max |in|
+  float *out_scale_p;                        // device: receives the scale of the output
+  unsigned *amax_out;                        // device, IVX_AMAX_SLOTS words: max |out| (atomic max), or NULL
+  float wb1, sb1, wb2, sb2, wb3, sb3;
+  int B, H, W;
+  int tiles_x, tiles_y, n_tiles, q_total;    // q_total: tiles per XCD (workgroup b runs on XCD b % 8 and owns tile (b % 8) * q_total + b / 8)
+#ifdef IVX_CONV_TIMELINE
+  unsigned long long *tl;
+#endif
+};
+
+
+template <int N>
+__device__ __forceinline__ void bnk_wait_vm() {           // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] bits 3:0, vmcnt[5:4] bits 15:14)
+  constexpr int n = N > 63 ? 63 : N;
+  __builtin_amdgcn_s_waitcnt(0x0f70 | (n & 15) | ((n >> 4) << 14));
+}
+// wait until at most PER * newer of this lane's vector-memory requests are outstanding (newer: slabs issued after the one needed)
+template <int PER>
+__device__ __forceinline__ void bnk_wait_slabs(const int newer) {
+  switch (newer) {
+    case 1: bnk_wait_vm<PER>(); break;
+    case 2: bnk_wait_vm<2 * PER>(); break;
+    case 3: bnk_wait_vm<3 * PER>(); break;
+    default: bnk_wait_vm<0>(); break;
+  }
+}
+// workgroup barrier without the fence of __syncthreads() (that fence waits for vmcnt(0): every LDS-DMA request of a ring); the caller has
+// waited for what must be visible -- lgkmcnt(0) here covers this wave's own LDS writes / fragment reads
+__device__ __forceinline__ void bnk_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ f32x16 bnk_mfma(const f32x4 a, const f32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// (hi, lo) halves of y as one word: hi in the low 16 bits
+__device__ __forceinline__ unsigned bnk_split(float y, const bool sat) {
+  if (sat) y = (y > 65504.f && y < __builtin_inff()) ? 65504.f : ((y < -65504.f && y > -__builtin_inff()) ? -65504.f : y);
+  const _Float16 h = (_Float16)y;
+  const _Float16 l = (_Float16)(y - (float)h);
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+template <int P, int NB1, int NB2, int NB3>
+struct BnkCfg {
+  static constexpr int C = 4 * P, NW = P / 16, NT = 64 * NW;
+  static constexpr int NQ = P / 32;            // 32-channel chunks of a P-channel tensor (K slabs of conv2 per tap / of conv3; 128-column units of conv3)
+  static constexpr int NQ1 = C / 32;           // K slabs of conv1
+  static constexpr int NTN = P / 32;           // 32-column tiles of a P-column GEMM
+  static constexpr int PXB = 4 * P;            // bytes of one pixel of a pair tile
+  static constexpr int M1 = 180, M1P = 192;
+  static constexpr int A1 = M1P * 128, B1 = P * 128, SL1 = A1 + B1;
+  static constexpr int MID = M1 * PXB;
+  static constexpr int SL2 = P * 128, R2 = MID;
+  static constexpr int MID2 = 128 * PXB, ST3 = MID2, STG = NW * 2048, R3 = ST3 + STG, SL3 = 128 * 128;
+  static constexpr int L1 = NB1 * SL1, L2 = R2 + NB2 * SL2, L3 = R3 + NB3 * SL3;
+  static constexpr int LDS = L1 > L2 ? (L1 > L3 ? L1 : L3) : (L2 > L3 ? L2 : L3);
+  static constexpr int RP = NT / 8;            // rows of 128 bytes one pass of the workgroup's DMA covers
+  static constexpr int AR = M1P / RP, BR1 = P / RP, BR2 = P / RP, BR3 = 128 / RP;
+};
+
+
+
+template <int P, int NB1, int NB2, int NB3>
+__global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParams p, const unsigned in_bytes, const unsigned w1_bytes,
+                                                                                 const unsigned w2_bytes, const unsigned w3_bytes) {
+  typedef BnkCfg<P, NB1, NB2, NB3> G;
+  constexpr int C = G::C, NW = G::NW, NQ = G::NQ, NQ1 = G::NQ1, NTN = G::NTN, PXB = G::PXB, RP = G::RP;
+  constexpr int AR = G::AR, BR1 = G::BR1, BR2 = G::BR2, BR3 = G::BR3;      // (local: arrays with these bounds are captured by the DMA lambdas)
+  static_assert(P == 64 || P == 128, "planes");
+  static_assert(G::LDS <= (P == 64 ? 81920 : 163840), "LDS budget");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rr = lane & 31, hh = lane >> 5;
+  // tile of this workgroup
+  const int tile = (int)(blockIdx.x & 7) * p.q_total + (int)(blockIdx.x >> 3);
+  if (tile >= p.n_tiles) return;
+#ifdef IVX_CONV_TIMELINE
+  const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tl1 = 0, tl2 = 0, tl3 = 0;
+#endif
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int b = tile / tpi;
+  const int trem = tile - b * tpi;
+  const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+  const int y0 = ty * 8, x0 = tx * 16;
+
+  // ---- scales (every wave computes the same values from the same device words)
+  float inv_in, s1, s2, s_out;
+  bool sat;
+  {
+    float a = __uint_as_float(p.amax_in[lane]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o));
+    const float b1 = (a * p.wb1 + p.sb1) * 1.001f;
+    const float b2 = (b1 * p.wb2 + p.sb2) * 1.001f;
+    const float b3 = (b2 * p.wb3 + p.sb3 + a) * 1.001f;
+    sat = !(b3 < 3.0e38f);
+    s1 = sat ? 0.00390625f : ivx_pow2_scale(b1);
+    s2 = sat ? 0.00390625f : ivx_pow2_scale(b2);
+    s_out = sat ? 0.00390625f : ivx_pow2_scale(b3);
+    inv_in = 1.0f / *p.in_scale_p;
+    inv_in = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, inv_in)));
+    s1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s1)));
+    s2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s2)));
+    s_out = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_out)));
+  }
+  if (p.out_scale_p && blockIdx.x == 0 && tid == 0) *p.out_scale_p = s_out;
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void *)p.w1, 0, w1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void *)p.w2, 0, w2_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc((void *)p.w3, 0, w3_bytes, 0x00020000);
+  const unsigned OOB = 0x80000000u;
+
+  // DMA lane geometry: 8 lanes per 128-byte row; slot tid & 7 of row lr receives k-chunk slot ^ ((lr >> 1) & 7)
+  const int lr = tid >> 3;
+  const int cc = (tid & 7) ^ ((lr >> 1) & 7);
+  const int fsw = (rr >> 1) & 7;                        // fragment reads of the DMA-staged slabs undo it
+
+  // =========================================================================================== phase 1: conv1 over the haloed tile
+  {
+    unsigned a_off[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+      const int r = lr + RP * j;
+      const int hy = (r * 3641) >> 16, hx = r - hy * 18;     // r / 18, r % 18 (exact for r < 192)
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      const bool ok = r < G::M1 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      a_off[j] = ok ? (unsigned)(((b * p.H + gy) * p.W + gx) * (4 * C) + cc * 16) : OOB;
+    }
+    unsigned b_off[BR1];
+#pragma unroll
+    for (int j = 0; j < BR1; ++j) b_off[j] = (unsigned)((lr + RP * j) * NQ1 * 128 + cc * 16);
+    auto load1 = [&](const int k, const int buf) {
+      unsigned char *Ab = smem + buf * G::SL1 + w * 1024;
+      unsigned char *Bb = Ab + G::A1;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) {       // (the offset goes through a local: with the captured array element as the builtin's argument clang drops
+        const unsigned vo = a_off[j] == OOB ? OOB : a_off[j] + (unsigned)k * 128u;       //  the kernel's host stub without a diagnostic)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Ab + RP * j * 128), 16, vo, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < BR1; ++j) {
+        const unsigned vo = b_off[j] + (unsigned)k * 128u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_ptr_t)(Bb + RP * j * 128), 16, vo, 0, 0, 0);
+      }
+    };
+    const int nt = w % NTN, mg = w / NTN;                // this wave: column tile nt, row tiles mg * 3 .. + 2
+    f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB1 - 1; ++k) load1(k, k);
+    int cur = 0;
+    for (int k = 0; k < NQ1; ++k) {
+      int newer = NQ1 - 1 - k;
+      newer = newer > NB1 - 2 ? NB1 - 2 : newer;
+      bnk_wait_slabs<AR + BR1>(newer);
+      bnk_barrier();                                     // slab k visible to every wave; every wave has finished slab k - 1
+      if (k + NB1 - 1 < NQ1) load1(k + NB1 - 1, cur == 0 ? NB1 - 1 : cur - 1);
+      const unsigned char *Ac = smem + cur * G::SL1 + (mg * 96 + rr) * 128;
+      const unsigned char *Bc = smem + cur * G::SL1 + G::A1 + (nt * 32 + rr) * 128;
+      f32x4 fa[2][3], fb[2];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int sl = kk & 1;
+        const int ch = ((2 * kk + hh) ^ fsw) * 16;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fa[sl][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 4096 + ch);
+        fb[sl] = *reinterpret_cast<const f32x4 *>(Bc + ch);
+        if (sl == 0) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) acc[i] = bnk_mfma(fa[0][i], fb[0], acc[i]);          // hi * hi
+        } else {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            acc[i] = bnk_mfma(fa[0][i], fb[1], acc[i]);                                    // hi * lo
+            acc[i] = bnk_mfma(fa[1][i], fb[0], acc[i]);                                    // lo * hi
+          }
+        }
+      }
+      cur = cur + 1 == NB1 ? 0 : cur + 1;
+    }
+    __syncthreads();                                     // the conv1 ring is dead: mid1 and the conv2 ring take its place
+#ifdef IVX_CONV_TIMELINE
+    tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- epilogue: mid1 = s1 * relu(bn1(conv1)) as a pair tile, zero outside the image.  Lanes l, l ^ 1 hold channels n, n ^ 1 of the same
+    // rows: they exchange one packed (hi, lo) word per row pair, so that the even lane writes both channels of row a and the odd lane both
+    // channels of row a + 1 as 4-byte words.
+    const int n = nt * 32 + rr;
+    const float scv = p.sc1[n] * inv_in, shv = p.sh1[n];
+    const int ne = n & ~1;
+    const int chunk_hi = (ne >> 4) * 4 + ((ne & 15) >> 3);
+    const int inchunk = (ne & 7) * 2;
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        const int ra = 2 * pr;
+        const int row_a = (mg * 3 + i) * 32 + (ra & 3) + 8 * (ra >> 2) + 4 * hh;
+        const int row = row_a + (odd ? 1 : 0);
+        const int hy = (row * 3641) >> 16, hx = row - hy * 18;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        // own values of rows a and a + 1; the partner needs the one of ITS row
+        float ya = acc[i][ra] * scv + shv, yb = acc[i][ra + 1] * scv + shv;
+        ya = ya > 0.f ? ya * s1 : 0.f;
+        yb = yb > 0.f ? yb * s1 : 0.f;
+        const unsigned wa = bnk_split(ya, sat), wb = bnk_split(yb, sat);
+        const unsigned send = odd ? wa : wb, keep = odd ? wb : wa;
+        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, true);      // quad_perm [1, 0, 3, 2]
+        const unsigned e0 = odd ? recv : keep, e1 = odd ? keep : recv;     // channels ne, ne + 1
+        unsigned hi = (e0 & 0xffffu) | (e1 << 16), lo = (e0 >> 16) | (e1 & 0xffff0000u);
+        if (!ok) { hi = 0u; lo = 0u; }
+        if (row < G::M1) {
+          unsigned char *dst = smem + row * PXB + ((chunk_hi ^ (hx & 15)) * 16) + inchunk;
+          *reinterpret_cast<unsigned *>(dst) = hi;
+          *reinterpret_cast<unsigned *>(dst + 32 - 64 * (((chunk_hi ^ (hx & 15)) >> 1) & 1)) = lo;      // chunk ^ 2
+        }
+      }
+    }
+  }
+
+  // =========================================================================================== phase 2: conv2 (3x3) from the mid1 tile
+  {
+    constexpr int S2 = 9 * NQ;
+    unsigned b_off[BR2];
+#pragma unroll
+    for (int j = 0; j < BR2; ++j) b_off[j] = (unsigned)((lr + RP * j) * S2 * 128 + cc * 16);
+    auto load2 = [&](const int s, const int buf) {      // slab s = (chunk q, tap t) = s-th 128-byte block of every filter row
+      unsigned char *Bb = smem + G::R2 + buf * G::SL2 + w * 1024;
+#pragma unroll
+      for (int j = 0; j < BR2; ++j) {
+        const unsigned vo = b_off[j] + (unsigned)s * 128u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_ptr_t)(Bb + RP * j * 128), 16, vo, 0, 0, 0);
+      }
+    };
+    const int nt = w % NTN, g = w / NTN;                 // column tile nt, row tiles 2g, 2g + 1
+#pragma unroll
+    for (int s = 0; s < NB2 - 1; ++s) load2(s, s);       // (in flight while the epilogue above writes mid1)
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int ox = rr & 15;
+    int prow[2];                                          // halo-pixel index of tap (0, 0) of this lane's row in tile i
+#pragma unroll
+    for (int i = 0; i < 2; ++i) prow[i] = (2 * (2 * g + i) + (rr >> 4)) * 18 + ox;
+    int cur = 0, q = 0, t = 0;
+    for (int s = 0; s < S2; ++s) {
+      int newer = S2 - 1 - s;
+      newer = newer > NB2 - 2 ? NB2 - 2 : newer;
+      bnk_wait_slabs<BR2>(newer);
+      bnk_barrier();                                     // (first pass: also publishes mid1)
+      if (s + NB2 - 1 < S2) load2(s + NB2 - 1, cur == 0 ? NB2 - 1 : cur - 1);
+      const int dy = t / 3, dx = t - dy * 3;
+      const int key = (ox + dx) & 15;
+      const unsigned char *Bc = smem + G::R2 + cur * G::SL2 + (nt * 32 + rr) * 128;
+      const unsigned char *Ar[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) Ar[i] = smem + (prow[i] + dy * 18 + dx) * PXB;
+      f32x4 fa[2][2], fb[2];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int sl = kk & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[sl][i] = *reinterpret_cast<const f32x4 *>(Ar[i] + (((q * 8 + 2 * kk + hh) ^ key) * 16));
+        fb[sl] = *reinterpret_cast<const f32x4 *>(Bc + (((2 * kk + hh) ^ fsw) * 16));
+        if (sl == 0) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i] = bnk_mfma(fa[0][i], fb[0], acc[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            acc[i] = bnk_mfma(fa[0][i], fb[1], acc[i]);
+            acc[i] = bnk_mfma(fa[1][i], fb[0], acc[i]);
+          }
+        }
+      }
+      cur = cur + 1 == NB2 ? 0 : cur + 1;
+      if (++t == 9) { t = 0; ++q; }
+    }
+    __syncthreads();                                     // mid1 and the conv2 ring are dead
+#ifdef IVX_CONV_TIMELINE
+    tl2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- epilogue: mid2 = s2 * relu(bn2(conv2)), pixel row m = 16 * oy + ox, swizzle key ox
+    const int n = nt * 32 + rr;
+    const float scv = p.sc2[n] * (1.0f / s1), shv = p.sh2[n];
+    const int ne = n & ~1;
+    const int chunk_hi = (ne >> 4) * 4 + ((ne & 15) >> 3);
+    const int inchunk = (ne & 7) * 2;
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        const int ra = 2 * pr;
+        const int row_a = (2 * g + i) * 32 + (ra & 3) + 8 * (ra >> 2) + 4 * hh;
+        const int row = row_a + (odd ? 1 : 0);
+        float ya = acc[i][ra] * scv + shv, yb = acc[i][ra + 1] * scv + shv;
+        ya = ya > 0.f ? ya * s2 : 0.f;
+        yb = yb > 0.f ? yb * s2 : 0.f;
+        const unsigned wa = bnk_split(ya, sat), wb = bnk_split(yb, sat);
+        const unsigned send = odd ? wa : wb, keep = odd ? wb : wa;
+        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, true);
+        const unsigned e0 = odd ? recv : keep, e1 = odd ? keep : recv;
+        const unsigned hi = (e0 & 0xffffu) | (e1 << 16), lo = (e0 >> 16) | (e1 & 0xffff0000u);
+        const int ck = chunk_hi ^ (row & 15);
+        unsigned char *dst = smem + row * PXB + ck * 16 + inchunk;
+        *reinterpret_cast<unsigned *>(dst) = hi;
+        *reinterpret_cast<unsigned *>(dst + 32 - 64 * ((ck >> 1) & 1)) = lo;
+      }
+    }
+  }
+
+  // =========================================================================================== phase 3: conv3 + shortcut, 128 columns at a time
+  {
+    constexpr int S3 = NQ * NQ;                          // (unit u, chunk q)
+    constexpr int TN3 = P == 64 ? 2 : 1;
+    unsigned b_off[BR3];
+#pragma unroll
+    for (int j = 0; j < BR3; ++j) b_off[j] = (unsigned)((lr + RP * j) * NQ * 128 + cc * 16);
+    auto load3 = [&](const int s, const int buf) {
+      const int u = s / NQ, q = s - u * NQ;
+      unsigned char *Bb = smem + G::R3 + buf * G::SL3 + w * 1024;
+#pragma unroll
+      for (int j = 0; j < BR3; ++j) {
+        const unsigned vo = b_off[j] + (unsigned)((u * 128 * NQ + q) * 128);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (lds_ptr_t)(Bb + RP * j * 128), 16, vo, 0, 0, 0);
+      }
+    };
+    const int wm = P == 64 ? (w >> 1) : (w >> 2), wn = P == 64 ? (w & 1) : (w & 3);
+#pragma unroll
+    for (int s = 0; s < NB3 - 1; ++s) load3(s, s);
+    f32x16 acc[2][TN3];
+    float *stage = reinterpret_cast<float *>(smem + G::ST3 + w * 2048);
+    const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+    float omax = 0.f;
+    auto epilogue3 = [&](const int u) {
+#pragma unroll
+      for (int j = 0; j < TN3; ++j) {
+        const int nb = u * 128 + (wn * TN3 + j) * 32 + c4;
+        f32x4 sc = *reinterpret_cast<const f32x4 *>(p.sc3 + nb);
+        const f32x4 sf = *reinterpret_cast<const f32x4 *>(p.sh3 + nb);
+        sc *= (1.0f / s2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) stage[((r8 & 3) + 8 * (r8 >> 2) + 4 * hh) * 32 + rr] = acc[i][j][hf * 8 + r8];
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+              f32x4 v = *reinterpret_cast<const f32x4 *>(stage + (rrow + 8 * q2) * 32 + c4);
+              const int pr = (2 * wm + i) * 32 + hf * 16 + rrow + 8 * q2;
+              const int gy = y0 + (pr >> 4), gx = x0 + (pr & 15);
+              if (gy < p.H && gx < p.W) {
+                const size_t m = ((size_t)b * p.H + gy) * p.W + gx;
+                const size_t off = m * (size_t)(2 * C) + (size_t)((nb >> 4) * 32 + (nb & 15));
+                const u32x2 rh = *reinterpret_cast<const u32x2 *>(p.in + off), rl = *reinterpret_cast<const u32x2 *>(p.in + off + 16);
+                const f16x4 h4 = __builtin_bit_cast(f16x4, rh), l4 = __builtin_bit_cast(f16x4, rl);
+                v = v * sc + sf;
+                f16x4 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float x = v[e] + ((float)h4[e] + (float)l4[e]) * inv_in;
+                  x = x > 0.f ? x : 0.f;
+                  omax = fmaxf(omax, x);
+                  float y = x * s_out;
+                  if (sat) y = (y > 65504.f && y < __builtin_inff()) ? 65504.f : y;
+                  oh[e] = (_Float16)y;
+                  ol[e] = (_Float16)(y - (float)oh[e]);
+                }
+                *reinterpret_cast<f16x4 *>(p.out + off) = oh;
+                *reinterpret_cast<f16x4 *>(p.out + off + 16) = ol;
+              }
+            }
+          }
+        }
+      }
+    };
+    int cur = 0, u = 0, q = 0;
+    for (int s = 0; s < S3; ++s) {
+      bnk_wait_vm<0>();                                  // (stores of an earlier unit's epilogue count in vmcnt too: wait for everything)
+      bnk_barrier();                                     // (first pass: also publishes mid2)
+      if (s + NB3 - 1 < S3) load3(s + NB3 - 1, cur == 0 ? NB3 - 1 : cur - 1);
+      if (q == 0) {
+        if (u > 0) epilogue3(u - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
+      const unsigned char *Bc = smem + G::R3 + cur * G::SL3 + (wn * TN3 * 32 + rr) * 128;
+      const unsigned char *Ac = smem + ((2 * wm) * 32 + rr) * PXB;
+      const int key = rr & 15;
+      f32x4 fa[2][2], fb[2][TN3];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int sl = kk & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[sl][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * PXB + (((q * 8 + 2 * kk + hh) ^ key) * 16));
+#pragma unroll
+        for (int j = 0; j < TN3; ++j) fb[sl][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 4096 + (((2 * kk + hh) ^ fsw) * 16));
+        if (sl == 0) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN3; ++j) acc[i][j] = bnk_mfma(fa[0][i], fb[0][j], acc[i][j]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN3; ++j) {
+              acc[i][j] = bnk_mfma(fa[0][i], fb[1][j], acc[i][j]);
+              acc[i][j] = bnk_mfma(fa[1][i], fb[0][j], acc[i][j]);
+            }
+        }
+      }
+      cur = cur + 1 == NB3 ? 0 : cur + 1;
+      if (++q == NQ) { q = 0; ++u; }
+    }
+#ifdef IVX_CONV_TIMELINE
+    tl3 = __builtin_amdgcn_s_memrealtime();
+#endif
+    epilogue3(NQ - 1);
+    if (p.amax_out) {        // one atomic per workgroup (ivx_common.h); the stage slices are per wave, word 0 of each is free now
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+      __syncthreads();
+      if (lane == 0) stage[0] = omax;
+      __syncthreads();
+      if (w == 0) ivx_amax_commit(p.amax_out, lane < NW ? reinterpret_cast<const float *>(smem + G::ST3)[lane * 512] : 0.f, (int)blockIdx.x);
+    }
+  }
+#ifdef IVX_CONV_TIMELINE
+  if (p.tl && tid == 0) {
+    unsigned long long *t = p.tl + (size_t)blockIdx.x * 8;
+    t[0] = tl0; t[1] = tl1; t[2] = tl3; t[3] = __builtin_amdgcn_s_memrealtime();
+    t[4] = __builtin_amdgcn_s_getreg(63492); t[5] = __builtin_amdgcn_s_getreg(63508); t[6] = tl2;
+  }
+#endif
+}
+
+#ifdef IVX_CONV_TIMELINE
+static unsigned long long *g_bnk_timeline = nullptr;
+extern "C" int ivx_bottleneck_set_timeline(void *buf) { g_bnk_timeline = (unsigned long long *)buf; return 0; }
+#endif
+
+extern "C" int ivx_bottleneck_supported(const ivx_bottleneck_desc *d) {
+  if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
+  if (d->P != 64 && d->P != 128) return 0;
+  if ((int64_t)d->B * d->H * d->W * d->P * 16 >= (1LL << 31)) return 0;      // the 4P-channel pair tensor below 2 GiB (32-bit buffer offsets)
+  return 1;
+}
+
+extern "C" int ivx_bottleneck_fwd_pio(const ivx_bottleneck_desc *d, const ivx_bottleneck_io *io, const void *in, const void *w1, const float *scale1,
+                                      const float *shift1, const void *w2, const float *scale2, const float *shift2, const void *w3,
+                                      const float *scale3, const float *shift3, void *out, ivx_stream_t stream) {
+  IVX_REQUIRE(d && io && in && w1 && w2 && w3 && out && scale1 && shift1 && scale2 && shift2 && scale3 && shift3, "ivx_bottleneck_fwd_pio: null argument");
+  IVX_REQUIRE(ivx_bottleneck_supported(d), "ivx_bottleneck_fwd_pio: planes must be 64 or 128 and the [B, H, W, 4 * planes] pair tensor below 2 GiB "
+              "(B %d H %d W %d planes %d)", d->B, d->H, d->W, d->P);
+  IVX_REQUIRE(io->in_scale && io->amax_in && io->out_scale, "ivx_bottleneck_fwd_pio: in_scale, amax_in and out_scale are required");
+  IVX_REQUIRE(in != out, "ivx_bottleneck_fwd_pio: the block cannot run in place (the shortcut re-reads the input)");
+  BnkParams p;
+  p.in = (const _Float16 *)in; p.out = (_Float16 *)out;
+  p.w1 = (const _Float16 *)w1; p.w2 = (const _Float16 *)w2; p.w3 = (const _Float16 *)w3;
+  p.sc1 = scale1; p.sh1 = shift1; p.sc2 = scale2; p.sh2 = shift2; p.sc3 = scale3; p.sh3 = shift3;
+  p.in_scale_p = io->in_scale; p.amax_in = io->amax_in; p.out_scale_p = io->out_scale; p.amax_out = io->amax_out;
+  p.wb1 = io->wbound[0]; p.sb1 = io->sbound[0]; p.wb2 = io->wbound[1]; p.sb2 = io->sbound[1]; p.wb3 = io->wbound[2]; p.sb3 = io->sbound[2];
+  p.B = d->B; p.H = d->H; p.W = d->W;
+  p.tiles_x = (d->W + 15) / 16; p.tiles_y = (d->H + 7) / 8;
+  p.n_tiles = d->B * p.tiles_x * p.tiles_y;
+  p.q_total = (p.n_tiles + 7) / 8;
+#ifdef IVX_CONV_TIMELINE
+  p.tl = g_bnk_timeline;
+#endif
+  const int P = d->P, C = 4 * P;
+  const unsigned in_bytes = (unsigned)((int64_t)d->B * d->H * d->W * C * 4);
+  const unsigned w1_bytes = (unsigned)(P * C * 4), w2_bytes = (unsigned)(P * 9 * P * 4), w3_bytes = (unsigned)(C * P * 4);
+  const dim3 grid((unsigned)(8 * p.q_total));
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 2, 3, 2>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+  else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 3, 3, 2>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+  IVX_CHECK_LAUNCH("ivx_bottleneck_fwd_pio");
+  return IVX_OK;
+}

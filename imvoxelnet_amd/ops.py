@@ -540,6 +540,43 @@ def conv_fwd_pio(x, wgt, scale, shift, kernel, stride, padding, relu, wbound, sb
     return out
 
 
+def bottleneck_supported(B, H, W, planes):
+    """ivx_bottleneck_supported: the one-launch form of an identity bottleneck exists for this map (csrc/bottleneck.hip)."""
+    d = _lib.BottleneckDesc(int(B), int(H), int(W), int(planes))
+    return bool(_lib.lib().ivx_bottleneck_supported(C.byref(d)))
+
+
+def bottleneck_fwd_pio(x, f1, f2, f3):
+    """One identity bottleneck (1x1 -> 3x3 -> 1x1 + shortcut, every BN / ReLU) in one launch on a PairTensor [B,1,H,W,4P] (ivx_bottleneck_fwd_pio).
+    f1 / f2 / f3: the block's three layers, objects with wpair, scale_p, shift, wbound, sbound (conv.FusedConv(chain=True)).  -> PairTensor."""
+    if not isinstance(x, PairTensor):
+        raise TypeError('bottleneck_fwd_pio takes a PairTensor')
+    _chk(x.data, 'x', torch.float16)
+    B, D, H, W, Cn = x.shape
+    P = Cn // 4
+    if D != 1 or not bottleneck_supported(B, H, W, P) or Cn != 4 * P:
+        raise ValueError(f'no fused bottleneck for an input of shape {x.shape}')
+    want = ((P, Cn // 32, 1, 64), (P, P // 32, 9, 64), (Cn, P // 32, 1, 64))
+    for f, shp in zip((f1, f2, f3), want):
+        _chk(f.wpair, 'wpair', torch.float16)
+        if tuple(f.wpair.shape) != shp:
+            raise ValueError(f'pair filters {tuple(f.wpair.shape)} do not match the bottleneck ({shp})')
+        _chk(f.scale_p, 'scale_p')
+        _chk(f.shift, 'shift')
+    d = _lib.BottleneckDesc(B, H, W, P)
+    io = _lib.BottleneckIO()
+    slots = new_slots(x.device)
+    io.in_scale, io.amax_in = _scale_ptr(x.slots), _ptr(x.slots)
+    io.out_scale, io.amax_out = _scale_ptr(slots), _ptr(slots)
+    for i, f in enumerate((f1, f2, f3)):
+        io.wbound[i], io.sbound[i] = float(f.wbound), float(f.sbound)
+    out = torch.empty_like(x.data)
+    check(_lib.lib().ivx_bottleneck_fwd_pio(C.byref(d), C.byref(io), _ptr(x.data), _ptr(f1.wpair), _ptr(f1.scale_p), _ptr(f1.shift), _ptr(f2.wpair),
+                                            _ptr(f2.scale_p), _ptr(f2.shift), _ptr(f3.wpair), _ptr(f3.scale_p), _ptr(f3.shift), _ptr(out), _stream()),
+          'ivx_bottleneck_fwd_pio')
+    return PairTensor(out, slots)
+
+
 def global_avgpool(x):
     """[B,D,H,W,C] channels-last -> [B,1,1,1,C]: mean over every spatial position."""
     _chk(x, 'x')

@@ -186,6 +186,31 @@ int ivx_maxpool2d_fwd_pair(const float *in, int32_t B, int32_t H, int32_t W, int
 /* IVX_F16_PAIR [n] (scale *scale_dev or 1) -> fp32 [n] (tests / hosts that want to look at an intermediate tensor) */
 int ivx_f16_pair_merge(const void *in, int64_t n, const float *scale_dev, float *out, ivx_stream_t stream);
 
+/* One ResNet bottleneck with an identity shortcut in ONE launch (csrc/bottleneck.hip), inside the pair chain:
+ *   out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(in)))))))) + in),  conv1 1x1 4P -> P, conv2 3x3 pad 1 P -> P, conv3 1x1 P -> 4P, stride 1
+ * -- the identity blocks of mmdet's ResNet(depth=50, style='pytorch') the reference builds at mmdet3d/models/detectors/imvoxelnet.py:22 from
+ * configs/imvoxelnet/imvoxelnet_kitti.py:4-12 and runs at :48 (`self.backbone(img)`); stages 1 and 2 (P = 64, 128).  The P-channel
+ * intermediates stay in LDS as pair tiles.  in / out: IVX_F16_PAIR [B,1,H,W,4P]; w1 / w2 / w3, scale* / shift*: the pair filters, scale / s_w
+ * and shift of ivx_pair_pack_filters for the three layers (w1 [P][4P/32][1][64], w2 [P][P/32][9][64], w3 [4P][P/32][1][64] halves).
+ * Scales: powers of two from the BOUND chain b1 = max|in| * wbound[0] + sbound[0], b2 = b1 * wbound[1] + sbound[1],
+ * b3 = b2 * wbound[2] + sbound[2] + max|in| (max|in| read from amax_in); *out_scale receives the output's, amax_out max |out|.
+ * Differs from three ivx_conv_fwd_pio calls only by the scales of the two intermediates (a-priori bound instead of the measured maximum):
+ * fp32-level rounding.  ivx_bottleneck_supported: P in {64, 128} and the tensor below 2 GiB. */
+typedef struct ivx_bottleneck_desc {
+  int32_t B, H, W, P;
+} ivx_bottleneck_desc;
+typedef struct ivx_bottleneck_io {
+  const float *in_scale;       /* device [1] */
+  const uint32_t *amax_in;     /* device [IVX_AMAX_SLOTS] */
+  float *out_scale;            /* device [1] */
+  uint32_t *amax_out;          /* device [IVX_AMAX_SLOTS] or NULL */
+  float wbound[3], sbound[3];
+} ivx_bottleneck_io;
+int ivx_bottleneck_supported(const ivx_bottleneck_desc *d);
+int ivx_bottleneck_fwd_pio(const ivx_bottleneck_desc *d, const ivx_bottleneck_io *io, const void *in, const void *w1, const float *scale1,
+                           const float *shift1, const void *w2, const float *scale2, const float *shift2, const void *w3, const float *scale3,
+                           const float *shift3, void *out, ivx_stream_t stream);
+
 /* Validation kernel: same contract, one thread per output element, plain FMA loop. Used by the
  * GPU tests to cross-check the MFMA kernel at full size; never called by the product path.   */
 int ivx_conv_fwd_naive(const ivx_conv_desc *d, const void *in, const void *wgt, const float *scale,
