@@ -6,6 +6,8 @@ torchvision / mmdet so `torchvision://resnet50` and released ImVoxelNet checkpoi
 Parity status: UNPINNED (mmdet/torchvision sources are not in the reference tree); checked against the
 torch-CPU restatement in oracle/imvoxel_oracle.py.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -98,9 +100,38 @@ class _Bottleneck(nn.Module):
             y = self.f1(x)
             y = self.f2(ops.dcn_im2col(y, self.f_off(y), 3, self.stride, 1, 1))
             return self.f3(y, res=idt)
+        if self.fuses(x, out_pair):
+            return self._fused(x)
         y = self.f1(x, out_pair=self.f2.pair_ok)
         y = self.f2(y, out_pair=self.f3.pair_ok)
         return self.f3(y, res=idt, out_pair=out_pair)
+
+    # IVX_FUSE_BOTTLENECK=0: the three-launch form everywhere (A/B; csrc/model.cpp make_plan reads the same variable)
+    fuse = os.environ.get('IVX_FUSE_BOTTLENECK', '1') != '0'
+
+    def fuses(self, x, out_pair):
+        """the block runs as ONE launch (ops.bottleneck_fwd_pio, csrc/bottleneck.hip): an identity block of the pair chain with 64 or 128
+        planes whose output is a pair tensor -- the rule of csrc/model.cpp make_plan, so both hosts launch the same kernels"""
+        return (_Bottleneck.fuse and self.fd is None and not self.dcn and self.stride == 1 and bool(out_pair) and isinstance(x, ops.PairTensor)
+                and self.f1.pair_ok and self.f2.pair_ok and self.f3.pair_ok and self.f1.cin == 4 * self.f1.cout and self.f3.cout == 4 * self.f1.cout
+                and x.shape[1] == 1 and ops.bottleneck_supported(x.shape[0], x.shape[2], x.shape[3], self.f1.cout))
+
+    def _fused(self, x):
+        tr = FusedConv.trace is not None
+        if tr:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        y = ops.bottleneck_fwd_pio(x, self.f1, self.f2, self.f3)
+        P = self.f1.cout
+        fl = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * 17.0 * P * P
+        if FusedConv.count_flops:
+            FusedConv.flops += fl
+            FusedConv.exec_flops += 3.0 * fl
+        if tr:
+            e1.record()
+            FusedConv.trace.append(('direct', e0, e1, 3.0 * fl, float(4 * x.numel() + 4 * y.numel()), False,
+                                    f'bottleneck {4 * P}->{P}->{P}->{4 * P} in {tuple(x.shape[:4])} pair, one launch'))
+        return y
 
 
 def stem_s2d_weights(w):

@@ -22,6 +22,7 @@
 //             c ^ (x & 15): the 16 lanes of one ds_read_b128 group hold 16 consecutive x (ds_read_b128 lane groups, MI355X guide), so every
 //             group reads 16 different 16-byte positions of the 256-byte bank window -- for every tap.
 #include "ivx_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -73,12 +74,26 @@ __device__ __forceinline__ void bnk_barrier() {
 __device__ __forceinline__ f32x16 bnk_mfma(const f32x4 a, const f32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// (hi, lo) halves of y as one word: hi in the low 16 bits
-__device__ __forceinline__ unsigned bnk_split(float y, const bool sat) {
-  if (sat) y = (y > 65504.f && y < __builtin_inff()) ? 65504.f : ((y < -65504.f && y > -__builtin_inff()) ? -65504.f : y);
-  const _Float16 h = (_Float16)y;
-  const _Float16 l = (_Float16)(y - (float)h);
-  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// Two channels (ne, ne + 1) of one pixel of a pair tile: e0, e1 are the scaled values in [0, 65504]; hi halves go to 16-byte chunk `ck` of the
+// pixel row (byte `inchunk` inside it), lo halves to chunk ck ^ 2.  Packed conversions (v_cvt_pk_f16_f32, round to nearest even).
+__device__ __forceinline__ void bnk_put2(unsigned char *px, const int ck, const int inchunk, const float e0, const float e1, const bool ok) {
+  const f32x2 e = {e0, e1};
+  const f16x2 h = __builtin_convertvector(e, f16x2);
+  const f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, f32x2), f16x2);
+  unsigned hi = __builtin_bit_cast(unsigned, h), lo = __builtin_bit_cast(unsigned, l);
+  if (!ok) { hi = 0u; lo = 0u; }
+  *reinterpret_cast<unsigned *>(px + ck * 16 + inchunk) = hi;
+  *reinterpret_cast<unsigned *>(px + (ck ^ 2) * 16 + inchunk) = lo;
+}
+// Lanes l, l ^ 1 hold channels n, n ^ 1 of the same accumulator rows: ya / yb = this lane's values of rows a / a + 1.  After the exchange the
+// even lane owns both channels of row a, the odd lane both channels of row a + 1: (e0, e1) = channels (n & ~1, n | 1).
+__device__ __forceinline__ void bnk_swap2(const float ya, const float yb, const bool odd, float &e0, float &e1) {
+  const float pa = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ya), 0xB1, 0xf, 0xf, true));   // quad_perm [1, 0, 3, 2]
+  const float pb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, yb), 0xB1, 0xf, 0xf, true));
+  e0 = odd ? pb : ya;
+  e1 = odd ? yb : pa;
 }
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -92,18 +107,20 @@ struct BnkCfg {
   static constexpr int PXB = 4 * P;            // bytes of one pixel of a pair tile
   static constexpr int M1 = 180, M1P = 192;
   static constexpr int A1 = M1P * 128, B1 = P * 128, SL1 = A1 + B1;
-  static constexpr int MID = M1 * PXB;
+  static constexpr int MID = M1P * PXB;         // (192 rows: the epilogue writes the 12 padding rows too instead of branching around them)
   static constexpr int SL2 = P * 128, R2 = MID;
   static constexpr int MID2 = 128 * PXB, ST3 = MID2, STG = NW * 2048, R3 = ST3 + STG, SL3 = 128 * 128;
   static constexpr int L1 = NB1 * SL1, L2 = R2 + NB2 * SL2, L3 = R3 + NB3 * SL3;
-  static constexpr int LDS = L1 > L2 ? (L1 > L3 ? L1 : L3) : (L2 > L3 ? L2 : L3);
+  static constexpr int LBUF = L1 > L2 ? (L1 > L3 ? L1 : L3) : (L2 > L3 ? L2 : L3);
+  static constexpr int PRM = LBUF;             // 12 P floats: scale1 | shift1 | scale2 | shift2 | scale3 | shift3 (read by the epilogues from LDS, not L2)
+  static constexpr int LDS = LBUF + 12 * P * 4;
   static constexpr int RP = NT / 8;            // rows of 128 bytes one pass of the workgroup's DMA covers
   static constexpr int AR = M1P / RP, BR1 = P / RP, BR2 = P / RP, BR3 = 128 / RP;
 };
 
 
 
-template <int P, int NB1, int NB2, int NB3>
+template <int P, int NB1, int NB2, int NB3, int DB2 = 0>
 __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParams p, const unsigned in_bytes, const unsigned w1_bytes,
                                                                                  const unsigned w2_bytes, const unsigned w3_bytes) {
   typedef BnkCfg<P, NB1, NB2, NB3> G;
@@ -111,6 +128,7 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
   constexpr int AR = G::AR, BR1 = G::BR1, BR2 = G::BR2, BR3 = G::BR3;      // (local: arrays with these bounds are captured by the DMA lambdas)
   static_assert(P == 64 || P == 128, "planes");
   static_assert(G::LDS <= (P == 64 ? 81920 : 163840), "LDS budget");
+  static_assert(G::NT == 4 * P, "the parameter block is loaded three floats per thread");
   __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -121,7 +139,7 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
   if (tile >= p.n_tiles) return;
 #ifdef IVX_CONV_TIMELINE
   const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long tl1 = 0, tl2 = 0, tl3 = 0;
+  unsigned long long tl1 = 0, tl1b = 0, tl2 = 0, tl2b = 0, tl3 = 0;
 #endif
   const int tpi = p.tiles_x * p.tiles_y;
   const int b = tile / tpi;
@@ -150,6 +168,13 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
     s_out = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_out)));
   }
   if (p.out_scale_p && blockIdx.x == 0 && tid == 0) *p.out_scale_p = s_out;
+  float *prm = reinterpret_cast<float *>(smem + G::PRM);
+  {   // 12 P floats = 3 per thread; first read after conv1's K loop (a __syncthreads() lies between)
+    const float *src[6] = {p.sc1, p.sh1, p.sc2, p.sh2, p.sc3, p.sh3};
+    prm[tid] = tid < P ? src[0][tid] : (tid < 2 * P ? src[1][tid - P] : (tid < 3 * P ? src[2][tid - 2 * P] : src[3][tid - 3 * P]));
+    prm[4 * P + tid] = p.sc3[tid];
+    prm[8 * P + tid] = p.sh3[tid];
+  }
 
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void *)p.w1, 0, w1_bytes, 0x00020000);
@@ -232,11 +257,9 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
 #ifdef IVX_CONV_TIMELINE
     tl1 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // ---- epilogue: mid1 = s1 * relu(bn1(conv1)) as a pair tile, zero outside the image.  Lanes l, l ^ 1 hold channels n, n ^ 1 of the same
-    // rows: they exchange one packed (hi, lo) word per row pair, so that the even lane writes both channels of row a and the odd lane both
-    // channels of row a + 1 as 4-byte words.
+    // ---- epilogue: mid1 = s1 * relu(bn1(conv1)) as a pair tile, zero outside the image (conv2's padding)
     const int n = nt * 32 + rr;
-    const float scv = p.sc1[n] * inv_in, shv = p.sh1[n];
+    const float sA = prm[n] * (inv_in * s1), tA = prm[P + n] * s1;
     const int ne = n & ~1;
     const int chunk_hi = (ne >> 4) * 4 + ((ne & 15) >> 3);
     const int inchunk = (ne & 7) * 2;
@@ -246,33 +269,80 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
 #pragma unroll
       for (int pr = 0; pr < 8; ++pr) {
         const int ra = 2 * pr;
-        const int row_a = (mg * 3 + i) * 32 + (ra & 3) + 8 * (ra >> 2) + 4 * hh;
-        const int row = row_a + (odd ? 1 : 0);
+        const int row = (mg * 3 + i) * 32 + (ra & 3) + 8 * (ra >> 2) + 4 * hh + (odd ? 1 : 0);
         const int hy = (row * 3641) >> 16, hx = row - hy * 18;
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        // own values of rows a and a + 1; the partner needs the one of ITS row
-        float ya = acc[i][ra] * scv + shv, yb = acc[i][ra + 1] * scv + shv;
-        ya = ya > 0.f ? ya * s1 : 0.f;
-        yb = yb > 0.f ? yb * s1 : 0.f;
-        const unsigned wa = bnk_split(ya, sat), wb = bnk_split(yb, sat);
-        const unsigned send = odd ? wa : wb, keep = odd ? wb : wa;
-        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, true);      // quad_perm [1, 0, 3, 2]
-        const unsigned e0 = odd ? recv : keep, e1 = odd ? keep : recv;     // channels ne, ne + 1
-        unsigned hi = (e0 & 0xffffu) | (e1 << 16), lo = (e0 >> 16) | (e1 & 0xffff0000u);
-        if (!ok) { hi = 0u; lo = 0u; }
-        if (row < G::M1) {
-          unsigned char *dst = smem + row * PXB + ((chunk_hi ^ (hx & 15)) * 16) + inchunk;
-          *reinterpret_cast<unsigned *>(dst) = hi;
-          *reinterpret_cast<unsigned *>(dst + 32 - 64 * (((chunk_hi ^ (hx & 15)) >> 1) & 1)) = lo;      // chunk ^ 2
-        }
+        const float ya = __builtin_amdgcn_fmed3f(acc[i][ra] * sA + tA, 0.f, 65504.f), yb = __builtin_amdgcn_fmed3f(acc[i][ra + 1] * sA + tA, 0.f, 65504.f);
+        float e0, e1;
+        bnk_swap2(ya, yb, odd, e0, e1);
+        bnk_put2(smem + row * PXB, chunk_hi ^ (hx & 15), inchunk, e0, e1, ok);
       }
     }
   }
 
   // =========================================================================================== phase 2: conv2 (3x3) from the mid1 tile
   {
+#ifdef IVX_CONV_TIMELINE
+    tl1b = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int S2 = 9 * NQ;
+    const int nt = w % NTN, g = w / NTN;                 // column tile nt, row tiles 2g, 2g + 1
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int ox = rr & 15;
+    int prow[2];                                          // halo-pixel index of tap (0, 0) of this lane's row in tile i
+#pragma unroll
+    for (int i = 0; i < 2; ++i) prow[i] = (2 * (2 * g + i) + (rr >> 4)) * 18 + ox;
+    if constexpr (DB2) {
+      // B fragments straight from L2 into registers, three slabs deep, NO barrier in the loop: a filter slab is 16 KB (P = 128) for 12 MFMAs
+      // per wave -- staged through LDS every slab cost a workgroup barrier + a DMA round trip (0.8 us per slab for 0.16 us of matrix work,
+      // workgroup timelines).  Here the waves drift apart freely; the two waves that share a column tile read the same lines (L1).
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      // DB2 == 2: w2 in FRAGMENT-MAJOR order [column tile][slab][kk][lane][8 halves]: one load instruction = 1 KB contiguous
+      const int voff = DB2 == 2 ? lane * 16 : (nt * 32 + rr) * S2 * 128 + hh * 16;
+      u32x4 bq[3][4];
+      auto ldb = [&](const int s, u32x4 (&dst)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          dst[kk] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, voff, DB2 == 2 ? ((nt * S2 + s) * 4 + kk) * 1024 : s * 128 + kk * 32, 0));
+      };
+      ldb(0, bq[0]);
+      ldb(1, bq[1]);
+      bnk_barrier();                                     // publishes mid1
+      for (int q = 0; q < NQ; ++q)
+        for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int s = q * 9 + dy * 3 + dx;           // s % 3 == dx: static register slots
+            if (s + 2 < S2) ldb(s + 2, bq[(dx + 2) % 3]);
+            const int key = (ox + dx) & 15;
+            const unsigned char *Ar[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) Ar[i] = smem + (prow[i] + dy * 18 + dx) * PXB;
+            f32x4 fa[2][2];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int sl = kk & 1;
+#pragma unroll
+              for (int i = 0; i < 2; ++i) fa[sl][i] = *reinterpret_cast<const f32x4 *>(Ar[i] + (((q * 8 + 2 * kk + hh) ^ key) * 16));
+              if (sl == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = bnk_mfma(fa[0][i], __builtin_bit_cast(f32x4, bq[dx][kk]), acc[i]);
+              } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                  acc[i] = bnk_mfma(fa[0][i], __builtin_bit_cast(f32x4, bq[dx][kk]), acc[i]);
+                  acc[i] = bnk_mfma(fa[1][i], __builtin_bit_cast(f32x4, bq[dx][kk - 1]), acc[i]);
+                }
+              }
+            }
+          }
+        }
+    } else {
     unsigned b_off[BR2];
 #pragma unroll
     for (int j = 0; j < BR2; ++j) b_off[j] = (unsigned)((lr + RP * j) * S2 * 128 + cc * 16);
@@ -284,18 +354,8 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_ptr_t)(Bb + RP * j * 128), 16, vo, 0, 0, 0);
       }
     };
-    const int nt = w % NTN, g = w / NTN;                 // column tile nt, row tiles 2g, 2g + 1
 #pragma unroll
-    for (int s = 0; s < NB2 - 1; ++s) load2(s, s);       // (in flight while the epilogue above writes mid1)
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    const int ox = rr & 15;
-    int prow[2];                                          // halo-pixel index of tap (0, 0) of this lane's row in tile i
-#pragma unroll
-    for (int i = 0; i < 2; ++i) prow[i] = (2 * (2 * g + i) + (rr >> 4)) * 18 + ox;
+    for (int s = 0; s < NB2 - 1; ++s) load2(s, s);
     int cur = 0, q = 0, t = 0;
     for (int s = 0; s < S2; ++s) {
       int newer = S2 - 1 - s;
@@ -330,13 +390,14 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
       cur = cur + 1 == NB2 ? 0 : cur + 1;
       if (++t == 9) { t = 0; ++q; }
     }
+    }
     __syncthreads();                                     // mid1 and the conv2 ring are dead
 #ifdef IVX_CONV_TIMELINE
     tl2 = __builtin_amdgcn_s_memrealtime();
 #endif
     // ---- epilogue: mid2 = s2 * relu(bn2(conv2)), pixel row m = 16 * oy + ox, swizzle key ox
     const int n = nt * 32 + rr;
-    const float scv = p.sc2[n] * (1.0f / s1), shv = p.sh2[n];
+    const float sA = prm[2 * P + n] * (s2 / s1), tA = prm[3 * P + n] * s2;
     const int ne = n & ~1;
     const int chunk_hi = (ne >> 4) * 4 + ((ne & 15) >> 3);
     const int inchunk = (ne & 7) * 2;
@@ -346,26 +407,20 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
 #pragma unroll
       for (int pr = 0; pr < 8; ++pr) {
         const int ra = 2 * pr;
-        const int row_a = (2 * g + i) * 32 + (ra & 3) + 8 * (ra >> 2) + 4 * hh;
-        const int row = row_a + (odd ? 1 : 0);
-        float ya = acc[i][ra] * scv + shv, yb = acc[i][ra + 1] * scv + shv;
-        ya = ya > 0.f ? ya * s2 : 0.f;
-        yb = yb > 0.f ? yb * s2 : 0.f;
-        const unsigned wa = bnk_split(ya, sat), wb = bnk_split(yb, sat);
-        const unsigned send = odd ? wa : wb, keep = odd ? wb : wa;
-        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, true);
-        const unsigned e0 = odd ? recv : keep, e1 = odd ? keep : recv;
-        const unsigned hi = (e0 & 0xffffu) | (e1 << 16), lo = (e0 >> 16) | (e1 & 0xffff0000u);
-        const int ck = chunk_hi ^ (row & 15);
-        unsigned char *dst = smem + row * PXB + ck * 16 + inchunk;
-        *reinterpret_cast<unsigned *>(dst) = hi;
-        *reinterpret_cast<unsigned *>(dst + 32 - 64 * ((ck >> 1) & 1)) = lo;
+        const int row = (2 * g + i) * 32 + (ra & 3) + 8 * (ra >> 2) + 4 * hh + (odd ? 1 : 0);
+        const float ya = __builtin_amdgcn_fmed3f(acc[i][ra] * sA + tA, 0.f, 65504.f), yb = __builtin_amdgcn_fmed3f(acc[i][ra + 1] * sA + tA, 0.f, 65504.f);
+        float e0, e1;
+        bnk_swap2(ya, yb, odd, e0, e1);
+        bnk_put2(smem + row * PXB, chunk_hi ^ (row & 15), inchunk, e0, e1, true);
       }
     }
   }
 
   // =========================================================================================== phase 3: conv3 + shortcut, 128 columns at a time
   {
+#ifdef IVX_CONV_TIMELINE
+    tl2b = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int S3 = NQ * NQ;                          // (unit u, chunk q)
     constexpr int TN3 = P == 64 ? 2 : 1;
     unsigned b_off[BR3];
@@ -384,55 +439,94 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
 #pragma unroll
     for (int s = 0; s < NB3 - 1; ++s) load3(s, s);
     f32x16 acc[2][TN3];
+    // Epilogue: a wave transposes one half tile (16 rows x 32 channels) at a time through its 2 KB stage so that a lane owns 8 consecutive
+    // channels of a row: 16 bytes of hi halves and 16 bytes of lo halves -- one 16-byte load each for the shortcut, one 16-byte store each for
+    // the output.  Stage rows are 128 bytes; 16-byte slot c of row r lies at c ^ ((r >> 1) & 1) (ds_read_b128 lane groups hit 4 rows).
+    // The shortcut (the block's input at the tile's own pixels) of unit u is REQUESTED before the unit's K loop and decoded after it: with
+    // the request in the epilogue a wave ran 16 load -> store round trips in series per unit.
     float *stage = reinterpret_cast<float *>(smem + G::ST3 + w * 2048);
-    const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+    const int rrow = lane >> 2, c8 = (lane & 3) * 8;
     float omax = 0.f;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rhi[2][TN3][2], rlo[2][TN3][2];
+    size_t poff[2][2];                                  // element offset of the pixel row of (tile i, half hf) in the pair tensor
+    bool pok[2][2];                                     // ... inside the image (outside: the shortcut is requested from pixel 0 -- the NUMBER of
+                                                        // requests per unit is what the counted wait below relies on -- and nothing is stored)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int pr = (2 * wm + i) * 32 + hf * 16 + rrow;
+        const int gy = y0 + (pr >> 4), gx = x0 + (pr & 15);
+        pok[i][hf] = gy < p.H && gx < p.W;
+        poff[i][hf] = pok[i][hf] ? (((size_t)b * p.H + gy) * p.W + gx) * (size_t)(2 * C) : (size_t)0;
+      }
+    auto res_request = [&](const int u) {
+#pragma unroll
+      for (int j = 0; j < TN3; ++j) {
+        const int nb = u * 128 + (wn * TN3 + j) * 32 + c8;
+        const int coff = (nb >> 4) * 32 + (nb & 15);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            rhi[i][j][hf] = *reinterpret_cast<const u32x4 *>(p.in + poff[i][hf] + coff);
+            rlo[i][j][hf] = *reinterpret_cast<const u32x4 *>(p.in + poff[i][hf] + coff + 16);
+          }
+      }
+    };
+    const float k_acc = s_out / s2, k_res = inv_in * s_out;        // powers of two: the output scale is folded into the epilogue's multipliers
     auto epilogue3 = [&](const int u) {
 #pragma unroll
       for (int j = 0; j < TN3; ++j) {
-        const int nb = u * 128 + (wn * TN3 + j) * 32 + c4;
-        f32x4 sc = *reinterpret_cast<const f32x4 *>(p.sc3 + nb);
-        const f32x4 sf = *reinterpret_cast<const f32x4 *>(p.sh3 + nb);
-        sc *= (1.0f / s2);
+        const int nb = u * 128 + (wn * TN3 + j) * 32 + c8;
+        const int coff = (nb >> 4) * 32 + (nb & 15);
+        const f32x4 sc0 = *reinterpret_cast<const f32x4 *>(prm + 4 * P + nb) * k_acc, sc1 = *reinterpret_cast<const f32x4 *>(prm + 4 * P + nb + 4) * k_acc;
+        const f32x4 sf0 = *reinterpret_cast<const f32x4 *>(prm + 8 * P + nb) * s_out, sf1 = *reinterpret_cast<const f32x4 *>(prm + 8 * P + nb + 4) * s_out;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8) stage[((r8 & 3) + 8 * (r8 >> 2) + 4 * hh) * 32 + rr] = acc[i][j][hf * 8 + r8];
+            for (int r8 = 0; r8 < 8; ++r8) {
+              const int rowh = (r8 & 3) + 8 * (r8 >> 2) + 4 * hh;
+              stage[rowh * 32 + ((((rr >> 2) ^ ((rowh >> 1) & 1)) << 2) | (rr & 3))] = acc[i][j][hf * 8 + r8];
+            }
+            const int sw = (rrow >> 1) & 1;
+            f32x4 v0 = *reinterpret_cast<const f32x4 *>(stage + rrow * 32 + (((c8 >> 2) ^ sw) << 2));
+            f32x4 v1 = *reinterpret_cast<const f32x4 *>(stage + rrow * 32 + ((((c8 >> 2) + 1) ^ sw) << 2));
+            if (pok[i][hf]) {
+              const f16x8 h8 = __builtin_bit_cast(f16x8, rhi[i][j][hf]), l8 = __builtin_bit_cast(f16x8, rlo[i][j][hf]);
+              v0 = v0 * sc0 + sf0;
+              v1 = v1 * sc1 + sf1;
+              f16x8 oh, ol;
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-              f32x4 v = *reinterpret_cast<const f32x4 *>(stage + (rrow + 8 * q2) * 32 + c4);
-              const int pr = (2 * wm + i) * 32 + hf * 16 + rrow + 8 * q2;
-              const int gy = y0 + (pr >> 4), gx = x0 + (pr & 15);
-              if (gy < p.H && gx < p.W) {
-                const size_t m = ((size_t)b * p.H + gy) * p.W + gx;
-                const size_t off = m * (size_t)(2 * C) + (size_t)((nb >> 4) * 32 + (nb & 15));
-                const u32x2 rh = *reinterpret_cast<const u32x2 *>(p.in + off), rl = *reinterpret_cast<const u32x2 *>(p.in + off + 16);
-                const f16x4 h4 = __builtin_bit_cast(f16x4, rh), l4 = __builtin_bit_cast(f16x4, rl);
-                v = v * sc + sf;
-                f16x4 oh, ol;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  float x = v[e] + ((float)h4[e] + (float)l4[e]) * inv_in;
-                  x = x > 0.f ? x : 0.f;
-                  omax = fmaxf(omax, x);
-                  float y = x * s_out;
-                  if (sat) y = (y > 65504.f && y < __builtin_inff()) ? 65504.f : y;
-                  oh[e] = (_Float16)y;
-                  ol[e] = (_Float16)(y - (float)oh[e]);
-                }
-                *reinterpret_cast<f16x4 *>(p.out + off) = oh;
-                *reinterpret_cast<f16x4 *>(p.out + off + 16) = ol;
+              for (int e = 0; e < 8; e += 2) {
+                f32x2 x = {e < 4 ? v0[e & 3] : v1[e & 3], e < 4 ? v0[(e & 3) + 1] : v1[(e & 3) + 1]};
+                x = f32x2{(float)h8[e], (float)h8[e + 1]} * k_res + x;
+                x = f32x2{(float)l8[e], (float)l8[e + 1]} * k_res + x;
+                x[0] = __builtin_amdgcn_fmed3f(x[0], 0.f, 65504.f);
+                x[1] = __builtin_amdgcn_fmed3f(x[1], 0.f, 65504.f);
+                omax = fmaxf(omax, fmaxf(x[0], x[1]));
+                const f16x2 h = __builtin_convertvector(x, f16x2);
+                const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
+                oh[e] = h[0]; oh[e + 1] = h[1];
+                ol[e] = l[0]; ol[e + 1] = l[1];
               }
+              *reinterpret_cast<f16x8 *>(p.out + poff[i][hf] + coff) = oh;
+              *reinterpret_cast<f16x8 *>(p.out + poff[i][hf] + coff + 16) = ol;
             }
           }
         }
       }
     };
+    constexpr int NRES = 2 * TN3 * 2 * 2;                // shortcut requests of one unit per lane
     int cur = 0, u = 0, q = 0;
     for (int s = 0; s < S3; ++s) {
-      bnk_wait_vm<0>();                                  // (stores of an earlier unit's epilogue count in vmcnt too: wait for everything)
+      // slab s was requested one pass ago, right after that pass's barrier; only a unit's shortcut requests can be younger (loads return in
+      // order, so "at most NRES outstanding" implies the slab has landed whatever the epilogue's stores are doing)
+      if (NB3 == 2 && q == 1) bnk_wait_vm<NRES>();
+      else bnk_wait_vm<0>();
       bnk_barrier();                                     // (first pass: also publishes mid2)
       if (s + NB3 - 1 < S3) load3(s + NB3 - 1, cur == 0 ? NB3 - 1 : cur - 1);
       if (q == 0) {
@@ -443,6 +537,7 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
           for (int j = 0; j < TN3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        res_request(u);
       }
       const unsigned char *Bc = smem + G::R3 + cur * G::SL3 + (wn * TN3 * 32 + rr) * 128;
       const unsigned char *Ac = smem + ((2 * wm) * 32 + rr) * PXB;
@@ -483,14 +578,14 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
       __syncthreads();
       if (lane == 0) stage[0] = omax;
       __syncthreads();
-      if (w == 0) ivx_amax_commit(p.amax_out, lane < NW ? reinterpret_cast<const float *>(smem + G::ST3)[lane * 512] : 0.f, (int)blockIdx.x);
+      if (w == 0) ivx_amax_commit(p.amax_out, lane < NW ? reinterpret_cast<const float *>(smem + G::ST3)[lane * 512] * (1.0f / s_out) : 0.f, (int)blockIdx.x);
     }
   }
 #ifdef IVX_CONV_TIMELINE
   if (p.tl && tid == 0) {
     unsigned long long *t = p.tl + (size_t)blockIdx.x * 8;
-    t[0] = tl0; t[1] = tl1; t[2] = tl3; t[3] = __builtin_amdgcn_s_memrealtime();
-    t[4] = __builtin_amdgcn_s_getreg(63492); t[5] = __builtin_amdgcn_s_getreg(63508); t[6] = tl2;
+    t[0] = tl0; t[1] = tl1; t[2] = tl1b; t[3] = tl2; t[4] = tl2b; t[5] = tl3; t[6] = __builtin_amdgcn_s_memrealtime();
+    t[7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
   }
 #endif
 }
@@ -533,8 +628,17 @@ extern "C" int ivx_bottleneck_fwd_pio(const ivx_bottleneck_desc *d, const ivx_bo
   const unsigned w1_bytes = (unsigned)(P * C * 4), w2_bytes = (unsigned)(P * 9 * P * 4), w3_bytes = (unsigned)(C * P * 4);
   const dim3 grid((unsigned)(8 * p.q_total));
   hipStream_t st = (hipStream_t)stream;
-  if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 2, 3, 2>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
-  else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 3, 3, 2>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+  static const int variant = getenv("IVX_BNK_VARIANT") ? atoi(getenv("IVX_BNK_VARIANT")) : 0;      // lab knob (tools/bottleneck_ab.py)
+  if (variant == 2) {
+    if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 2, 3, 2, 2>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+    else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 3, 3, 2, 2>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+  } else if (variant == 1) {
+    if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 2, 3, 2, 1>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+    else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 3, 3, 2, 1>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+  } else {
+    if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 2, 3, 2>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+    else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 3, 3, 2>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+  }
   IVX_CHECK_LAUNCH("ivx_bottleneck_fwd_pio");
   return IVX_OK;
 }

@@ -164,6 +164,9 @@ struct PlanStep {
   int amax_n = 0, amax_in_n = 0;
   int pio = 0;            // CONV: the fp16-pair form (ivx_conv_fwd_pio); MAXPOOL: pair output (aux = the stem's layer for the bound)
   int bound_layer = -1;
+  // identity bottleneck in one launch (ivx_bottleneck_fwd_pio, csrc/bottleneck.hip): fuse 1 = conv1's step, which runs the whole block and
+  // writes conv3's output tensor (fuse_out); fuse 2 = conv2's / conv3's step, covered by it
+  int fuse = 0, fuse_out = -1;
 };
 
 struct Plan {
@@ -998,6 +1001,35 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       for (size_t l = 0; l < m->t_cb.size(); ++l)
         for (int t : {m->t_cb[l], m->t_cs[l], m->t_cc[l]}) pl->t[t].last = std::max(pl->t[t].last, i);
   }
+  // Identity bottlenecks of the pair chain that the one-launch kernel takes: conv1 1x1 (4P -> P) -> conv2 3x3 s1 p1 (P -> P) -> conv3 1x1
+  // (P -> 4P) + the block's input as the shortcut, every tensor a pair tensor, P in {64, 128} (ResNet-50's stages 1 and 2).  The block's
+  // output is written by conv1's step, so it is allocated there; the two P-channel intermediates stay unwritten.
+  // (backbones.py _Bottleneck.forward_cl applies the same rule: both hosts launch the same kernels.)
+  static const bool fuse_on = !(getenv("IVX_FUSE_BOTTLENECK") && atoi(getenv("IVX_FUSE_BOTTLENECK")) == 0);
+  if (pair_mode && fuse_on)
+    for (int i = std::max(r.s0, m->trunk0); i + 2 < std::min(r.s1, m->trunk1); ++i) {
+      const Step &s1 = m->steps[i], &s2 = m->steps[i + 1], &s3 = m->steps[i + 2];
+      if (s1.kind != ST_CONV || s2.kind != ST_CONV || s3.kind != ST_CONV) continue;
+      const ConvLayer &L1 = m->layers[s1.layer], &L2 = m->layers[s2.layer], &L3 = m->layers[s3.layer];
+      const TInfo &x = pl->t[s1.in], &y1 = pl->t[s1.out], &y2 = pl->t[s2.out], &o = pl->t[s3.out];
+      auto is1x1 = [](const ConvLayer &L) { return L.k[0] == 1 && L.k[1] == 1 && L.k[2] == 1 && L.s[1] == 1 && L.s[2] == 1 && L.p[1] == 0 && L.p[2] == 0; };
+      const int P = L1.cout;
+      if (!(pl->ps[i].pio && pl->ps[i + 1].pio && pl->ps[i + 2].pio) || s1.res >= 0 || s2.res >= 0 || s2.in != s1.out || s3.in != s2.out ||
+          s3.res != s1.in || s3.res_mode != 1 || s3.res_after_act || s3.post_scale != 1.0f)
+        continue;
+      if (!is1x1(L1) || !is1x1(L3) || !(L2.k[0] == 1 && L2.k[1] == 3 && L2.k[2] == 3 && L2.s[1] == 1 && L2.s[2] == 1 && L2.p[1] == 1 && L2.p[2] == 1) ||
+          L2.dcn_cols || !L1.relu || !L2.relu || !L3.relu || L1.cin != 4 * P || L2.cin != P || L2.cout != P || L3.cin != P || L3.cout != 4 * P)
+        continue;
+      if (x.fmt != IVX_F16_PAIR || y1.fmt != IVX_F16_PAIR || y2.fmt != IVX_F16_PAIR || o.fmt != IVX_F16_PAIR || x.D != 1 || x.slot < 0 || o.slot < 0 ||
+          y1.last != i + 1 || y2.last != i + 2)
+        continue;
+      ivx_bottleneck_desc bd = {x.B, x.H, x.W, P};
+      if (!ivx_bottleneck_supported(&bd)) continue;
+      pl->ps[i].fuse = 1; pl->ps[i].fuse_out = s3.out;
+      pl->ps[i + 1].fuse = pl->ps[i + 2].fuse = 2;
+      pl->t[s3.out].first = i;
+      i += 2;
+    }
   std::vector<int> keep = {m->t_fpn0, m->t_volume, m->t_valid, m->t_neck, m->t_head, m->t_angle, m->t_layout};
   keep.insert(keep.end(), m->t_levels.begin(), m->t_levels.end());
   for (int t : keep)
@@ -1030,7 +1062,7 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
   };
   for (int i = r.s0; i < r.s1; ++i) {
     const Step &s = m->steps[i];
-    const int extra = s.kind == ST_FCOS ? m->t_cc[s.aux] : -1;
+    const int extra = s.kind == ST_FCOS ? m->t_cc[s.aux] : pl->ps[i].fuse_out;
     for (int t : {s.out, s.out2, extra}) {
       if (t < 0 || pl->t[t].first != i) continue;
       TInfo &ti = pl->t[t];
@@ -1271,6 +1303,23 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
       case ST_CONV: {
         const ConvLayer &L = m->layers[s.layer];
         const PlanStep &ps = pl.ps[i];
+        if (ps.fuse == 2) break;               // conv2 / conv3 of a bottleneck that conv1's step ran
+        if (ps.fuse == 1) {
+          const ConvLayer &L2 = m->layers[m->steps[i + 1].layer], &L3 = m->layers[m->steps[i + 2].layer];
+          const int t_out = ps.fuse_out;
+          ivx_bottleneck_desc bd = {in.B, in.H, in.W, L.cout};
+          ivx_bottleneck_io io;
+          memset(&io, 0, sizeof(io));
+          io.in_scale = scalep(s.in); io.amax_in = slotp(s.in); io.out_scale = scalep(t_out); io.amax_out = slotp(t_out);
+          io.wbound[0] = L.wbound; io.sbound[0] = L.sbound; io.wbound[1] = L2.wbound; io.sbound[1] = L2.sbound;
+          io.wbound[2] = L3.wbound; io.sbound[2] = L3.sbound;
+          const double px = (double)in.elems() / in.C;
+          M_TRY(trace_begin(m, i, 0, 0, 3.0 * 2.0 * px * (17.0 * L.cout * L.cout), 2.0 * 4.0 * in.elems(), L.name + " .. conv3 (one launch)", st));
+          M_TRY(ivx_bottleneck_fwd_pio(&bd, &io, ptr(s.in), L.wpair, L.scale_p, L.shift, L2.wpair, L2.scale_p, L2.shift, L3.wpair, L3.scale_p, L3.shift,
+                                       ptr(t_out), st));
+          M_TRY(trace_end(m, st));
+          break;
+        }
         const void *res = s.res >= 0 ? ptr(s.res) : nullptr;
         const TInfo &o = pl.t[s.out];
         const int is3d = in.D > 1 && in.W > 1;      // a 3-D neck layer (the head conv sees [B,X',Y',1,C])

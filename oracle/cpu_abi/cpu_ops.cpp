@@ -263,6 +263,60 @@ extern "C" int ivx_conv_fwd_pio(const ivx_conv_desc *d, const ivx_pair_io *io, c
   return IVX_OK;
 }
 
+// csrc/bottleneck.hip: one identity bottleneck in one launch.  The CPU restatement runs the three pair convolutions above with the scales of the
+// device's BOUND chain for the two intermediates (slots handed to the layers hold the bound, so that each layer's own rule reproduces it).
+extern "C" int ivx_bottleneck_supported(const ivx_bottleneck_desc *d) {
+  if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
+  if (d->P != 64 && d->P != 128) return 0;
+  return (int64_t)d->B * d->H * d->W * d->P * 16 < (1LL << 31);
+}
+extern "C" int ivx_bottleneck_fwd_pio(const ivx_bottleneck_desc *d, const ivx_bottleneck_io *io, const void *in, const void *w1, const float *scale1,
+                                      const float *shift1, const void *w2, const float *scale2, const float *shift2, const void *w3,
+                                      const float *scale3, const float *shift3, void *out, ivx_stream_t stream) {
+  C_REQUIRE(d && io && in && w1 && w2 && w3 && out && io->in_scale && io->amax_in && io->out_scale, "ivx_bottleneck_fwd_pio: null argument");
+  C_REQUIRE(ivx_bottleneck_supported(d), "ivx_bottleneck_fwd_pio: planes must be 64 or 128 and the tensor below 2 GiB");
+  const int P = d->P, C4 = 4 * P;
+  const int64_t rows = (int64_t)d->B * d->H * d->W;
+  const float a = c_amax_read(io->amax_in);
+  const float b1 = (a * io->wbound[0] + io->sbound[0]) * 1.001f, b2 = (b1 * io->wbound[1] + io->sbound[1]) * 1.001f;
+  const float b3 = (b2 * io->wbound[2] + io->sbound[2] + a) * 1.001f;
+  const bool sat = !(b3 < 3.0e38f);
+  std::vector<uint16_t> m1((size_t)rows * 2 * P), m2((size_t)rows * 2 * P);
+  uint32_t sl1[IVX_AMAX_SLOTS + 1] = {0}, sl2[IVX_AMAX_SLOTS + 1] = {0}, scratch[IVX_AMAX_SLOTS] = {0};
+  ivx_conv_desc c;
+  memset(&c, 0, sizeof(c));
+  c.B = d->B; c.D = 1; c.H = d->H; c.W = d->W; c.Cin = C4; c.Cout = P; c.KD = c.KH = c.KW = 1; c.sd = c.sh = c.sw = 1;
+  c.relu = 1; c.wgt_layout = 1; c.post_scale = 1.0f; c.in_dtype = IVX_F16_PAIR; c.out_dtype = IVX_F32; c.res_scale = 1.0f;
+  std::vector<float> t((size_t)rows * C4);
+  // conv1 -> fp32, then encoded with the bound's scale (not the layer rule's: identical here, written out so that the chain is explicit)
+  ivx_pair_io p1;
+  memset(&p1, 0, sizeof(p1));
+  p1.in_scale = io->in_scale; p1.amax_in = io->amax_in; p1.amax_out = scratch;
+  int rc = ivx_conv_fwd_pio(&c, &p1, in, w1, scale1, shift1, nullptr, t.data(), nullptr, 0, stream);
+  if (rc != IVX_OK) return rc;
+  float s1 = sat ? 0.00390625f : c_pow2_scale(b1), s2 = sat ? 0.00390625f : c_pow2_scale(b2), s3 = sat ? 0.00390625f : c_pow2_scale(b3);
+  c_pair_encode(t.data(), rows, P, s1, m1.data());
+  memcpy(&sl1[IVX_AMAX_SLOTS], &s1, 4);
+  c.Cin = P; c.KH = c.KW = 3; c.ph = c.pw = 1;
+  ivx_pair_io p2;
+  memset(&p2, 0, sizeof(p2));
+  p2.in_scale = (const float *)&sl1[IVX_AMAX_SLOTS]; p2.amax_in = sl1; p2.amax_out = scratch;
+  rc = ivx_conv_fwd_pio(&c, &p2, m1.data(), w2, scale2, shift2, nullptr, t.data(), nullptr, 0, stream);
+  if (rc != IVX_OK) return rc;
+  c_pair_encode(t.data(), rows, P, s2, m2.data());
+  memcpy(&sl2[IVX_AMAX_SLOTS], &s2, 4);
+  c.KH = c.KW = 1; c.ph = c.pw = 0; c.Cout = C4; c.res_mode = 1;
+  ivx_pair_io p3;
+  memset(&p3, 0, sizeof(p3));
+  p3.in_scale = (const float *)&sl2[IVX_AMAX_SLOTS]; p3.amax_in = sl2; p3.res_dtype = IVX_F16_PAIR; p3.res_scale = io->in_scale; p3.amax_res = io->amax_in;
+  p3.amax_out = io->amax_out ? io->amax_out : scratch;
+  rc = ivx_conv_fwd_pio(&c, &p3, m2.data(), w3, scale3, shift3, in, t.data(), nullptr, 0, stream);
+  if (rc != IVX_OK) return rc;
+  *io->out_scale = s3;
+  c_pair_encode(t.data(), rows, C4, s3, (uint16_t *)out);
+  return IVX_OK;
+}
+
 extern "C" int ivx_conv_fwd_pio_naive(const ivx_conv_desc *d, const ivx_pair_io *io, const void *in, const void *wgt, const float *scale, const float *shift,
                                       const void *res, void *out, ivx_stream_t stream) {
   return ivx_conv_fwd_pio(d, io, in, wgt, scale, shift, res, out, nullptr, 0, stream);
