@@ -18,6 +18,7 @@ SOURCES = [
     ('conv_igemm.hip', ['-DIVX_CONV_TU=4'], 'conv_igemm_pair_f16.o'),
     ('conv_igemm.hip', ['-DIVX_CONV_TU=5'], 'conv_igemm_halo.o'),
     ('bottleneck.hip', []),
+    ('stem.hip', []),
     ('winograd.hip', []),
     ('pool_layout.hip', []),
     ('backproject.hip', ['-ffp-contract=off']),

@@ -200,8 +200,13 @@ class ResNet(nn.Module):
         self.stem = None
         # fp32 storage: the trunk's activations chained as fp16-pair tensors (FusedConv.trunk_operands, conv.py)
         self.chain = current_storage_dtype() == torch.float32 and FusedConv.trunk_operands == ops.IVX_F16_PAIR
+        self.stem_frag = None
         if not fp8:
             self.stem = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), stride=2, padding=3, relu=True, dims=2, chain=self.chain).to(device)
+            # the head of the pair chain in one launch (ops.stem_pool_pair; csrc/model.cpp pack_layer builds the same filters)
+            if self.chain and tuple(self.conv1.weight.shape) == (64, 3, 7, 7):
+                fr, sp = ops.stem_pool_pack_filters(self.conv1.weight, self.stem._scale_host)
+                self.stem_frag = (fr.to(device), sp.to(device))
         # bf16 mode: the 7x7 stride-2 stem as a 4x4 stride-1 convolution over 2x2 space-to-depth blocks of the image
         # (ops.image_s2d_bf16): bf16 MFMA with K = 256 instead of the fp32 kernel on 3 (padded to 4) channels
         self.stem_s2d = None
@@ -244,6 +249,22 @@ class ResNet(nn.Module):
         if self.stem is None:
             raise ValueError('the fp8 trunk takes float32 images with even height and width')
         if getattr(self, 'chain', False):
+            if self.fuses_stem(img):       # layout change + stem + max-pool in one launch (csrc/model.cpp make_plan: the same rule)
+                tr = FusedConv.trace is not None
+                if tr:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                x = ops.stem_pool_pair(img.contiguous(), self.stem_frag[0], self.stem_frag[1], self.stem.shift, self.stem.wbound, self.stem.sbound)
+                hc, wc = (img.shape[2] - 1) // 2 + 1, (img.shape[3] - 1) // 2 + 1
+                fl = 2.0 * img.shape[0] * hc * wc * 64 * 147
+                if FusedConv.count_flops:
+                    FusedConv.flops += fl
+                    FusedConv.exec_flops += 3.0 * fl
+                if tr:
+                    e1.record()
+                    FusedConv.trace.append(('direct', e0, e1, 3.0 * fl, float(4 * img.numel() + 4 * x.numel()), False,
+                                            f'stem 3->64 k7 s2 + max-pool in {tuple(img.shape)} pair, one launch'))
+                return self._stages(x, None, pooled=True)
             return self.forward_cl(ops.to_channels_last_amax(img.contiguous(), pad_to=4))
         return self.forward_cl(ops.to_channels_last(img.contiguous(), pad_to=4))
 
@@ -257,13 +278,26 @@ class ResNet(nn.Module):
     # (the FPN laterals); the detector clears the last entry when a LayoutHead pools C5 (features_2d_cl)
     stage_out_pair = (True, True, True, True)
 
-    def _stages(self, x, img_slots=None):
+    # IVX_FUSE_STEM=0: the three-launch head (layout change, fp32-MFMA stem, max-pool) -- A/B; csrc/model.cpp make_plan reads the same variable
+    fuse_stem = os.environ.get('IVX_FUSE_STEM', '1') != '0'
+
+    def fuses_stem(self, img):
+        """the chain's head runs as one launch: the conditions under which _stages would write the pooled map as a pair tensor"""
+        if not (ResNet.fuse_stem and getattr(self, 'stem_frag', None) is not None and img.dim() == 4 and img.shape[1] == 3 and img.dtype == torch.float32
+                and img.shape[2] >= 7 and img.shape[3] >= 7):
+            return False
+        hc, wc = (img.shape[2] - 1) // 2 + 1, (img.shape[3] - 1) // 2 + 1
+        return (self.layer1[0].takes_pairs() and img.shape[0] * ((hc - 1) // 2 + 1) * ((wc - 1) // 2 + 1) * 64 * 4 < 2 ** 31)
+
+    def _stages(self, x, img_slots=None, pooled=False):
         from .conv import QTensor
         blocks = [list(getattr(self, f'layer{i + 1}')) for i in range(self.num_stages)]
         chain = (getattr(self, 'chain', False) and img_slots is not None and self.stem is not None and isinstance(x, torch.Tensor)
                  and x.shape[-1] % 16 == 0 and blocks[0][0].takes_pairs()
                  and x.shape[0] * ((x.shape[2] - 1) // 2 + 1) * ((x.shape[3] - 1) // 2 + 1) * x.shape[4] * 4 < 2 ** 31)
-        if chain:      # fp32 stem output -> pair tensor, scaled by the bound of the stem's output from max |image|
+        if pooled:     # the one-launch head already wrote the pooled pair map
+            pass
+        elif chain:    # fp32 stem output -> pair tensor, scaled by the bound of the stem's output from max |image|
             x = ops.maxpool2d_pair(x, img_slots, self.stem.wbound, self.stem.sbound, 3, 2, 1)
         else:
             x = QTensor(ops.maxpool2d(x.data, 3, 2, 1), x.scale) if isinstance(x, QTensor) else ops.maxpool2d(x, 3, 2, 1)

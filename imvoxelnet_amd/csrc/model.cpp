@@ -128,6 +128,7 @@ struct ConvLayer {
   bool pair_ok = false;
   float *wpair = nullptr, *scale_p = nullptr;
   float wbound = 0.f, sbound = 0.f;
+  float *wstem = nullptr;             // the 7x7 stem in the pair chain: fragment-ordered pair filters of the one-launch stem (csrc/stem.hip); scale_p with them
 };
 
 enum StepKind { ST_IMG2CL, ST_IMG_S2D, ST_CONV, ST_MAXPOOL, ST_LIFT, ST_TAIL, ST_UPSAMPLE, ST_DCN_COL, ST_AVGPOOL, ST_LAYOUT, ST_FCOS, ST_INDOOR_TAIL };
@@ -700,6 +701,15 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
       M_TRY(dev_upload_sync(m, reinterpret_cast<const float *>(packed.data()), n_w, &L.wpair, st));
       M_TRY(dev_upload_sync(m, sp.data(), sp.size(), &L.scale_p, st));
     }
+    if (L.name == "backbone.conv1" && L.cin == 3 && L.cout == 64 && kd == 1 && kh == 7 && kw == 7 && L.s[1] == 2 && L.s[2] == 2 && L.p[1] == 3 && L.p[2] == 3 &&
+        L.w_keys.size() == 1) {        // the one-launch stem + max-pool (ivx_stem_pool_fwd_pair)
+      const HostTensor *w = find_w(m, L.w_keys[0]);
+      std::vector<uint16_t> fr((size_t)ivx_stem_pool_filter_bytes() / 2);
+      std::vector<float> sps(64);
+      M_TRY(ivx_stem_pool_pack_filters(w->data.data(), scale.data(), fr.data(), sps.data()));
+      M_TRY(dev_upload_sync(m, reinterpret_cast<const float *>(fr.data()), fr.size() / 2, &L.wstem, st));
+      M_TRY(dev_upload_sync(m, sps.data(), sps.size(), &L.scale_p, st));
+    }
   }
   return IVX_OK;
 }
@@ -1006,6 +1016,17 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
   // output is written by conv1's step, so it is allocated there; the two P-channel intermediates stay unwritten.
   // (backbones.py _Bottleneck.forward_cl applies the same rule: both hosts launch the same kernels.)
   static const bool fuse_on = !(getenv("IVX_FUSE_BOTTLENECK") && atoi(getenv("IVX_FUSE_BOTTLENECK")) == 0);
+  // The head of the chain in one launch (ivx_stem_pool_fwd_pair): image layout change + 7x7 stem + max-pool -> only max |image| is computed
+  // at the layout step, the stem's step is skipped, the max-pool's step runs the fused kernel on the caller's NCHW image.
+  static const bool fuse_stem = !(getenv("IVX_FUSE_STEM") && atoi(getenv("IVX_FUSE_STEM")) == 0);
+  if (pair_mode && fuse_stem)
+    for (int i = std::max(r.s0, m->trunk0); i + 2 < std::min(r.s1, m->trunk1); ++i) {
+      const Step &s0 = m->steps[i], &s1 = m->steps[i + 1], &s2 = m->steps[i + 2];
+      if (s0.kind != ST_IMG2CL || s1.kind != ST_CONV || s2.kind != ST_MAXPOOL || s1.in != s0.out || s2.in != s1.out) continue;
+      const ConvLayer &L = m->layers[s1.layer];
+      if (!L.wstem || !pl->ps[i + 2].pio || pl->t[s0.out].slot < 0 || pl->t[s1.out].last != i + 2 || pl->t[s0.out].last != i + 1) continue;
+      pl->ps[i].fuse = 3; pl->ps[i + 1].fuse = 2; pl->ps[i + 2].fuse = 4;
+    }
   if (pair_mode && fuse_on)
     for (int i = std::max(r.s0, m->trunk0); i + 2 < std::min(r.s1, m->trunk1); ++i) {
       const Step &s1 = m->steps[i], &s2 = m->steps[i + 1], &s3 = m->steps[i + 2];
@@ -1263,13 +1284,17 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           const double tiles = (double)o.B * ((ps.d.D + 2 * ps.d.pd - 2 + ps.tile - 1) / ps.tile) * ((ps.d.H + 2 * ps.d.ph - 2 + ps.tile - 1) / ps.tile);
           span_flops += (ps.d.wino_operands ? 3.0 : 1.0) * ivx_conv_winograd_issued_fraction(&ps.d) * 2.0 * n * n * tiles * zo * ps.d.Cout * ps.d.KW * ps.d.Cin;   // as the per-launch records count
         } else {
-          span_flops += (ps.pio ? 3.0 : 1.0) * 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2];      // pair form: three products per multiply-add
+          span_flops += ((ps.pio || (ps.fuse == 2 && L.wstem)) ? 3.0 : 1.0) * 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2];      // pair form (the one-launch stem too): three products per multiply-add
         }
       }
     }
     struct Restore { ivx_model *m; bool on; ~Restore() { m->trace_on = on; } } restore{m, was_on};   // also on an error return
     switch (s.kind) {
       case ST_IMG2CL:
+        if (pl.ps[i].fuse == 3) {              // one-launch stem: only the image's maximum is needed here
+          M_TRY(ivx_amax_f32((const float *)ptr(s.in), in.elems(), slotp(s.out), st));
+          break;
+        }
         if (slotp(s.out))
           M_TRY(ivx_nchw_to_nhwc_amax((const float *)ptr(s.in), in.B, 3, (int64_t)in.H * in.W, 4, (float *)ptr(s.out), slotp(s.out), st));
         else
@@ -1289,6 +1314,19 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           for (int j = r.s0; j < i; ++j)
             if (m->steps[j].out == s.in) t_img4 = m->steps[j].in;
           M_REQUIRE(slotp(t_img4), "internal: the pair max-pool needs the image's amax slots");
+          if (pl.ps[i].fuse == 4) {            // layout change + stem + max-pool in one launch, from the caller's NCHW image
+            int t_img = -1;
+            for (int j = r.s0; j < i; ++j)
+              if (m->steps[j].out == t_img4) t_img = m->steps[j].in;
+            M_REQUIRE(t_img >= 0, "internal: the one-launch stem needs the image");
+            const TInfo &im = pl.t[t_img];
+            const double px = (double)in.elems() / in.C;
+            M_TRY(trace_begin(m, i, 0, 0, 3.0 * 2.0 * px * 64 * 147, 0.0, Ls.name + " + max-pool (one launch)", st));
+            M_TRY(ivx_stem_pool_fwd_pair((const float *)ptr(t_img), im.B, im.H, im.W, Ls.wstem, Ls.scale_p, Ls.shift, Ls.wbound, Ls.sbound, slotp(t_img4),
+                                         ptr(s.out), scalep(s.out), slotp(s.out), st));
+            M_TRY(trace_end(m, st));
+            break;
+          }
           M_TRY(ivx_maxpool2d_fwd_pair((const float *)ptr(s.in), in.B, in.H, in.W, in.C, 3, 2, 1, ptr(s.out), slotp(t_img4), Ls.wbound, Ls.sbound,
                                        scalep(s.out), slotp(s.out), st));
         } else
@@ -2087,6 +2125,38 @@ extern "C" int ivx_pair_pack_filters(const float *w, int32_t Cout, int32_t taps,
             dst[g * 32 + 16 + e] = f32_to_f16_bits(y - f16_bits_to_f32(h));
           }
       }
+  return IVX_OK;
+}
+
+// Host-only: the pair filters of the one-launch stem (csrc/stem.hip) in the order its wave reads them: [column tile 2][step 11][hi, lo][lane 64]
+// [8 halves]; lane = h * 32 + n_l holds output channel nt * 32 + n_l, k = (c, ky) pair 2 * step + h (the 22nd: zeros), 8 filter columns
+// (the eighth: zero).  Same scale rule as ivx_pair_pack_filters: s_w puts max |w| into [2^14, 2^15); scale_out = scale / s_w.
+extern "C" int64_t ivx_stem_pool_filter_bytes(void) { return 2 * 11 * 2 * 64 * 8 * 2; }
+extern "C" int ivx_stem_pool_pack_filters(const float *w, const float *scale, void *packed, float *scale_out) {
+  M_REQUIRE(w && packed && scale_out, "ivx_stem_pool_pack_filters: null argument");
+  float amax = 0.f;
+  for (int i = 0; i < 64 * 3 * 49; ++i) amax = std::max(amax, fabsf(w[i]));
+  float sw = 1.0f;
+  if (amax > 0.f && amax < 3.0e38f) {
+    int e;
+    (void)frexpf(amax, &e);
+    int k = 15 - e;
+    k = k < -120 ? -120 : (k > 120 ? 120 : k);
+    sw = ldexpf(1.0f, k);
+  }
+  for (int co = 0; co < 64; ++co) scale_out[co] = (scale ? scale[co] : 1.0f) / sw;
+  uint16_t *o = (uint16_t *)packed;
+  for (int nt = 0; nt < 2; ++nt)
+    for (int kk = 0; kk < 11; ++kk)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int n = nt * 32 + (lane & 31), pq = 2 * kk + (lane >> 5);
+          float y = 0.f;
+          if (pq < 21 && e < 7) y = w[((n * 3 + pq / 7) * 7 + pq % 7) * 7 + e] * sw;
+          const uint16_t h = f32_to_f16_bits(y);
+          o[((((size_t)nt * 11 + kk) * 2 + 0) * 64 + lane) * 8 + e] = h;
+          o[((((size_t)nt * 11 + kk) * 2 + 1) * 64 + lane) * 8 + e] = f32_to_f16_bits(y - f16_bits_to_f32(h));
+        }
   return IVX_OK;
 }
 

@@ -540,6 +540,38 @@ def conv_fwd_pio(x, wgt, scale, shift, kernel, stride, padding, relu, wbound, sb
     return out
 
 
+def stem_pool_pack_filters(w, scale):
+    """Host: [64,3,7,7] stem filters + BN scale [64] (CPU tensors) -> (fragment-ordered pair filters as a uint8 tensor, scale / s_w [64]) through
+    ivx_stem_pool_pack_filters (the native handle packs with the same function)."""
+    w = w.detach().to(torch.float32).cpu().contiguous()
+    if tuple(w.shape) != (64, 3, 7, 7):
+        raise ValueError('the one-launch stem is built for [64, 3, 7, 7] filters')
+    sc = scale.detach().to(torch.float32).cpu().contiguous()
+    L = _lib.lib()
+    packed = torch.empty(int(L.ivx_stem_pool_filter_bytes()), dtype=torch.uint8)
+    sp = torch.empty(64, dtype=torch.float32)
+    check(L.ivx_stem_pool_pack_filters(_ptr_any(w), _ptr_any(sc), _ptr_any(packed), _ptr_any(sp)), 'ivx_stem_pool_pack_filters')
+    return packed, sp
+
+
+def stem_pool_pair(img, wfrag, scale_p, shift, wbound, sbound):
+    """fp32 NCHW image [N,3,H,W] -> PairTensor [N,1,Hp,Wp,64]: conv 7x7 s2 p3 + BN + ReLU + MaxPool2d(3,2,1) in one launch (ivx_amax_f32 +
+    ivx_stem_pool_fwd_pair, csrc/stem.hip).  wfrag / scale_p: device copies of stem_pool_pack_filters' outputs."""
+    _chk(img, 'img')
+    N, Cn, H, W = img.shape
+    if Cn != 3:
+        raise ValueError('stem_pool_pair takes a 3-channel image')
+    L = _lib.lib()
+    hp, wp = C.c_int32(), C.c_int32()
+    check(L.ivx_stem_pool_out_dims(H, W, C.byref(hp), C.byref(wp)), 'ivx_stem_pool_out_dims')
+    islots, slots = new_slots(img.device), new_slots(img.device)
+    check(L.ivx_amax_f32(_ptr(img), img.numel(), _ptr(islots), _stream()), 'ivx_amax_f32')
+    out = torch.empty((N, 1, hp.value, wp.value, 128), device=img.device, dtype=torch.float16)
+    check(L.ivx_stem_pool_fwd_pair(_ptr(img), N, H, W, _ptr(wfrag), _ptr(scale_p), _ptr(shift), float(wbound), float(sbound), _ptr(islots), _ptr(out),
+                                   _scale_ptr(slots), _ptr(slots), _stream()), 'ivx_stem_pool_fwd_pair')
+    return PairTensor(out, slots)
+
+
 def bottleneck_supported(B, H, W, planes):
     """ivx_bottleneck_supported: the one-launch form of an identity bottleneck exists for this map (csrc/bottleneck.hip)."""
     d = _lib.BottleneckDesc(int(B), int(H), int(W), int(planes))

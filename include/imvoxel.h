@@ -186,6 +186,23 @@ int ivx_maxpool2d_fwd_pair(const float *in, int32_t B, int32_t H, int32_t W, int
 /* IVX_F16_PAIR [n] (scale *scale_dev or 1) -> fp32 [n] (tests / hosts that want to look at an intermediate tensor) */
 int ivx_f16_pair_merge(const void *in, int64_t n, const float *scale_dev, float *out, ivx_stream_t stream);
 
+/* The head of the 2-D trunk in ONE launch (csrc/stem.hip), inside the pair chain: conv 7x7 stride 2 pad 3 (3 -> 64) + BatchNorm + ReLU +
+ * MaxPool2d(3, 2, 1) from the fp32 NCHW image [B,3,H,W] to the IVX_F16_PAIR map [B,1,Hp,Wp,64] (ivx_stem_pool_out_dims) -- mmdet ResNet's
+ * conv1 / bn1 / relu / maxpool (mmdet3d/models/detectors/imvoxelnet.py:22,48; configs/imvoxelnet/imvoxelnet_kitti.py:4-12).  The conv runs on
+ * fp16 (hi, lo) pair operands (image values split in registers with the power-of-two scale of amax_img; three MFMA products per multiply-add),
+ * the pool is exact, the output scale is the one of ivx_maxpool2d_fwd_pair (bound amax_img * wbound + sbound).
+ *   ivx_amax_f32                 max |x| of an fp32 buffer into IVX_AMAX_SLOTS zeroed words (the image's maximum; a NaN counts as Inf)
+ *   ivx_stem_pool_pack_filters   host-only: [64,3,7,7] fp32 filters + BN scale -> the kernel's fragment-ordered pair filters
+ *                                (ivx_stem_pool_filter_bytes() bytes) and scale / s_w
+ *   ivx_stem_pool_fwd_pair       wfrag / scale_p / shift: device copies of those and of the BN shift; out_scale / amax_out as ivx_pair_io */
+int ivx_amax_f32(const float *x, int64_t n, uint32_t *amax, ivx_stream_t stream);
+int64_t ivx_stem_pool_filter_bytes(void);
+int ivx_stem_pool_pack_filters(const float *w, const float *scale, void *packed, float *scale_out);
+int ivx_stem_pool_out_dims(int32_t H, int32_t W, int32_t *Hp, int32_t *Wp);
+int ivx_stem_pool_fwd_pair(const float *img, int32_t B, int32_t H, int32_t W, const void *wfrag, const float *scale_p, const float *shift,
+                           float wbound, float sbound, const uint32_t *amax_img, void *out, float *out_scale, uint32_t *amax_out,
+                           ivx_stream_t stream);
+
 /* One ResNet bottleneck with an identity shortcut in ONE launch (csrc/bottleneck.hip), inside the pair chain:
  *   out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(in)))))))) + in),  conv1 1x1 4P -> P, conv2 3x3 pad 1 P -> P, conv3 1x1 P -> 4P, stride 1
  * -- the identity blocks of mmdet's ResNet(depth=50, style='pytorch') the reference builds at mmdet3d/models/detectors/imvoxelnet.py:22 from

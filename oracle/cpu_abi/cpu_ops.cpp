@@ -328,6 +328,55 @@ extern "C" int ivx_f16_pair_merge(const void *in, int64_t n, const float *scale_
   return IVX_OK;
 }
 
+// csrc/stem.hip: layout change + 7x7 stem + BN + ReLU + max-pool in one launch.  CPU restatement: the image's maximum, then the fp32 direct
+// convolution on the filters the packed fragments stand for (s_w * w; scale_p carries 1 / s_w), the exact pool, the pair encoding.
+extern "C" int ivx_amax_f32(const float *x, int64_t n, uint32_t *amax, ivx_stream_t) {
+  C_REQUIRE(x && amax && n >= 0, "ivx_amax_f32: bad argument");
+  float m = 0.f;
+  for (int64_t i = 0; i < n; ++i) { const float a = x[i] != x[i] ? INFINITY : fabsf(x[i]); m = a > m ? a : m; }
+  c_amax_commit(amax, m);
+  return IVX_OK;
+}
+extern "C" int ivx_stem_pool_out_dims(int32_t H, int32_t W, int32_t *Hp, int32_t *Wp) {
+  C_REQUIRE(Hp && Wp && H > 0 && W > 0, "ivx_stem_pool_out_dims: bad argument");
+  const int Hc = (H + 6 - 7) / 2 + 1, Wc = (W + 6 - 7) / 2 + 1;
+  *Hp = (Hc + 2 - 3) / 2 + 1;
+  *Wp = (Wc + 2 - 3) / 2 + 1;
+  return IVX_OK;
+}
+extern "C" int ivx_maxpool2d_fwd_pair(const float *in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s, int32_t p, void *out,
+                                      const uint32_t *amax_in, float wbound, float sbound, float *out_scale, uint32_t *amax_out, ivx_stream_t stream);
+extern "C" int ivx_stem_pool_fwd_pair(const float *img, int32_t B, int32_t H, int32_t W, const void *wfrag, const float *scale_p, const float *shift,
+                                      float wbound, float sbound, const uint32_t *amax_img, void *out, float *out_scale, uint32_t *amax_out,
+                                      ivx_stream_t stream) {
+  C_REQUIRE(img && wfrag && scale_p && shift && amax_img && out && out_scale && B > 0 && H >= 7 && W >= 7, "ivx_stem_pool_fwd_pair: bad argument");
+  // fragments [nt 2][step 11][hi, lo][lane 64][8] -> tap-major fp32 filters [64][7][7][4] (channel 3: zero)
+  std::vector<float> wt((size_t)64 * 49 * 4, 0.f);
+  const uint16_t *f = (const uint16_t *)wfrag;
+  for (int nt = 0; nt < 2; ++nt)
+    for (int kk = 0; kk < 11; ++kk)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 7; ++e) {
+          const int n = nt * 32 + (lane & 31), pq = 2 * kk + (lane >> 5);
+          if (pq >= 21) continue;
+          const size_t o = ((((size_t)nt * 11 + kk) * 2 + 0) * 64 + lane) * 8 + e;
+          wt[(((size_t)n * 7 + pq % 7) * 7 + e) * 4 + pq / 7] = c_f16_to_f32(f[o]) + c_f16_to_f32(f[o + 64 * 8]);
+        }
+  const int64_t S = (int64_t)H * W;
+  std::vector<float> x4((size_t)B * S * 4);
+  int rc = ivx_nchw_to_nhwc(img, B, 3, S, 4, x4.data(), stream);
+  if (rc != IVX_OK) return rc;
+  ivx_conv_desc c;
+  memset(&c, 0, sizeof(c));
+  c.B = B; c.D = 1; c.H = H; c.W = W; c.Cin = 4; c.Cout = 64; c.KD = 1; c.KH = c.KW = 7; c.sd = 1; c.sh = c.sw = 2; c.ph = c.pw = 3;
+  c.relu = 1; c.post_scale = 1.0f; c.res_scale = 1.0f;
+  const int Hc = (H + 6 - 7) / 2 + 1, Wc = (W + 6 - 7) / 2 + 1;
+  std::vector<float> y((size_t)B * Hc * Wc * 64);
+  rc = ivx_conv_fwd_ws(&c, x4.data(), wt.data(), scale_p, shift, nullptr, y.data(), nullptr, 0, stream);
+  if (rc != IVX_OK) return rc;
+  return ivx_maxpool2d_fwd_pair(y.data(), B, Hc, Wc, 64, 3, 2, 1, out, amax_img, wbound, sbound, out_scale, amax_out, stream);
+}
+
 // The minimal-filtering form is a device-side optimisation: the CPU restatement reports "not supported" and the handle
 // (csrc/model.cpp plan_conv) falls back to the direct convolution, as it does for any layer the Winograd entry points refuse.
 extern "C" int ivx_conv_winograd_supported(const ivx_conv_desc *, int32_t) { return 0; }

@@ -1440,8 +1440,9 @@ def test_cpu_abi_stage_trace_levels():
     assert sum(r[0] == 4 for r in full) == 1 and sum(r[0] == 5 for r in full) == 1          # unprojection, tail
     trunk_full = [r for r in full if r[0] == 0 and not r[1]]
     # ResNet-50 convs + FPN + head conv; the five identity blocks of stages 1 and 2 run as one launch each (ivx_bottleneck_fwd_pio)
-    fused = [r for r in trunk_full if 'one launch' in r[3]]
+    fused = [r for r in trunk_full if 'one launch' in r[3] and 'conv3' in r[3]]
     assert len(fused) == 5 and all(r[3].startswith(('backbone.layer1.', 'backbone.layer2.')) for r in fused)
+    assert sum('max-pool (one launch)' in r[3] for r in trunk_full) == 1          # layout change + stem + max-pool (ivx_stem_pool_fwd_pair)
     assert len(trunk_full) >= 53 + 4 + 1 - 2 * len(fused) and any('backbone.layer3.5.conv2' in r[3] for r in trunk_full)
     assert sum(r[0] == 6 for r in coarse) == 1 and 'trunk' in [r for r in coarse if r[0] == 6][0][3]
     neck_full, neck_coarse = [r for r in full if r[1] and r[0] <= 3], [r for r in coarse if r[1] and r[0] <= 3]
