@@ -68,6 +68,21 @@ def neck_flops_per_sample(nv, c_in, c_out):
     return 2.0 * macs
 
 
+def neck_algorithmic_bytes_per_sample(nv, c_in, c_out):
+    """Bytes KittiImVoxelNeck's nine layers must move once per sample: every layer's fp32 input, output, residual (the second conv of a
+    block) and filters -- what a direct convolution per layer would read and write (the Winograd form's V / M workspaces are NOT in it)."""
+    X, Y, Z = nv
+    c1, c2, c4 = c_in, c_in * 2, c_in * 4
+    z2, z3 = (Z + 2 - 3) // 2 + 1, ((Z + 2 - 3) // 2 + 1 + 2 - 3) // 2 + 1
+    v1, v2, v3 = X * Y * Z, X * Y * z2, X * Y * z3
+    b = 0
+    for v, c in ((v1, c1), (v2, c2), (v3, c4)):          # block: conv (in + out) and conv + residual (in + res + out), 2 x 27 c^2 filters
+        b += 4 * (2 * v * c + 3 * v * c + 2 * 27 * c * c)
+    b += 4 * (v1 * c1 + v2 * c2 + 27 * c1 * c2) + 4 * (v2 * c2 + v3 * c4 + 27 * c2 * c4)        # the two z-stride-2 convs
+    b += 4 * (v3 * c4 + (X - 2) * (Y - 2) * (z3 - 2) * c_out + 27 * c4 * c_out)                 # the last, pad-0 conv
+    return float(b)
+
+
 def bench_lift(args, ia, kc, dev):
     """Unprojection-only stress (BASELINE configs 4 / 5: "HBM-bound gather stress"): the fused multi-view lift alone on
     synthetic FPN maps, timed with HIP events over `steps` launches.  Algorithmic bytes per scene =
@@ -682,7 +697,7 @@ def main():
     # from the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh -> profiles/*_bench_pmc.json;
     # FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as reported), averaged per launch; null if absent.
     traffic, traffic_src = None, None
-    for name in (('r05_bench_pmc.json', 'r04_bench_pmc.json', 'r03b_bench_pmc.json') if pair else ('r03_bench_pmc.json', 'r02_bench_pmc.json', 'r01_bench_pmc.json')):
+    for name in (('r06_bench_pmc.json', 'r05_bench_pmc.json', 'r04_bench_pmc.json', 'r03b_bench_pmc.json') if pair else ('r03_bench_pmc.json', 'r02_bench_pmc.json', 'r01_bench_pmc.json')):
         pj = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pj) and not bf16:
             try:   # the summary covers the main launch of every neck layer: HBM bytes averaged per launch
@@ -696,6 +711,35 @@ def main():
 
     trunk_pair = FusedConv.trunk_operands == 4 and not bf16
     peak2d = PEAK_BF16_MFMA_TFLOPS if (bf16 or trunk_pair) else PEAK_F32_MFMA_TFLOPS
+    # The whole step against its two floors (round-5 verdict, item 5): every matrix-core product the step issues / the dense MFMA peak of the
+    # operand type, and the bytes its launches must move once (inputs + outputs + filters of every launch as executed) / the HBM peak.
+    # counter_GB: HBM bytes per step by the PMC counters of the committed profile of this command (all kernels of the step), or null.
+    t2d_bytes = sum(t[4] for t in t2d) / nst
+    step_flops = mfma_flops + t2d_flops
+    neck_alg_bytes = neck_algorithmic_bytes_per_sample((216, 248, 12), 64, 256) * B       # activations + filters; V / M of the three-stage form excluded
+    step_alg_bytes = neck_alg_bytes + t2d_bytes + lift_bytes
+    counter_gb, counter_src = None, None
+    pj_all = os.path.join(ROOT, 'profiles', 'r06_bench_pmc_all.json')
+    if os.path.exists(pj_all) and pair and not bf16:
+        try:
+            ja = json.load(open(pj_all))
+            nsteps_prof = float(ja.get('_meta', {}).get('steps', 3))
+            skip = ('ubench', 'rocclr', 'at::native', '_meta')
+            counter_gb = round(sum(v['derived'].get('hbm_bytes', 0.0) * v['launches'] for k, v in ja.items()
+                                   if not any(q in k for q in skip) and isinstance(v, dict) and 'derived' in v) / nsteps_prof / 1e9, 2)
+            counter_src = 'profiles/r06_bench_pmc_all.json'
+        except Exception:
+            counter_gb = None
+    peak_step = PEAK_BF16_MFMA_TFLOPS if (pair or bf16) else PEAK_F32_MFMA_TFLOPS
+    ms_step = dt / args.steps * 1e3
+    t_mfma_floor = step_flops / (peak_step * 1e12) * 1e3
+    t_hbm_floor = step_alg_bytes / 8e12 * 1e3
+    whole_step = {'issued_pflop': round(step_flops / 1e15, 4), 'counter_GB': counter_gb, 'counter_source': counter_src,
+                  'algorithmic_GB': round(step_alg_bytes / 1e9, 2), 'algorithmic_GB_neck': round(neck_alg_bytes / 1e9, 2), 'algorithmic_GB_trunk': round(t2d_bytes / 1e9, 2),
+                  'moved_GB_neck_three_stage_form': round(sum(t[4] for t in tr) / nst / 1e9, 2), 't_mfma_floor_ms': round(t_mfma_floor, 3), 't_hbm_floor_ms': round(t_hbm_floor, 3),
+                  'ms_per_step': round(ms_step, 3), 'frac': round(max(t_mfma_floor, t_hbm_floor) / ms_step, 4),
+                  'note': 'floors: products issued / %.0f TFLOP/s (dense 16-bit MFMA; the pair form issues 3 per multiply-add) and algorithmic bytes / 8 TB/s; '
+                          'frac = the larger floor / the measured step' % peak_step}
     if rank == 0:
         total_images = B * world * args.steps
         rec = {
@@ -721,7 +765,7 @@ def main():
                        'all_gather_us': all_gather_us},
             'measured_ceilings': dict(ceil, note='csrc/ubench.hip at start-up: MFMA issue rate of the conv kernel\'s instruction, HBM copy rate '
                                                  '(read + written bytes) over 2 x 1 GiB') if ceil else None,
-            'exact_fp32_mfma': alt,
+            'exact_fp32_mfma': alt, 'exact_fp32_mfma_images_per_s': alt['value'] if alt else None,
             'roofline': {'bound': 'mfma', 'kernel': ('conv_wino_halo_kernel / conv_wino_zblk_kernel<fp16 pair operands> (the 8 Winograd-domain GEMMs of the stride-1 / '
                                                     'z-stride-2 neck layers; z-blocked tiles on the 3-slice columns) + conv_igemm_v4_kernel<fp16 pair operands> (the last, '
                                                     'pad-0 layer): %d launches/step' % n_launch) if pair else
@@ -743,7 +787,8 @@ def main():
                          'neck_ms_per_step': round(neck_ms_avg, 3), 'neck_direct_gflop_per_step': round(flops_step / 1e9, 1),
                          'neck_executed_tflops': round(mfma_flops / (neck_ms_avg * 1e-3) / 1e12, 2),
                          'direct_equivalent_tflops': round(flops_step / (neck_ms_avg * 1e-3) / 1e12, 2),
-                         'winograd_gemm_launches_per_step': len([t for t in tr if t[0] == 'wino_gemm']) // nst},
+                         'winograd_gemm_launches_per_step': len([t for t in tr if t[0] == 'wino_gemm']) // nst,
+                         'whole_step': whole_step},
             'roofline_winograd_transforms': None if not xf else {
                 'bound': 'hbm', 'kernel': 'wino_input_kernel + wino_output_kernel (%d launches/step, event-bracketed)' % (len(xf) // nst),
                 'achieved': round(xf_bytes / (xf_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
@@ -756,17 +801,19 @@ def main():
                                       'frac_of_measured': round(lift_bytes / (lift_ms * 1e-3) / 1e9 / hbm_meas, 4) if hbm_meas else None,
                                       'ms': round(lift_ms, 4),
                                       'algorithmic_MB': round(lift_bytes / 1e6, 1)},
-            'roofline_trunk_2d': {'bound': 'mfma', 'kernel': 'conv_igemm_v4_kernel (ResNet-50 + FPN level 0 + head conv; %s)' % (
+            'roofline_trunk_2d': {'bound': 'mfma', 'kernel': 'stem_pool_pair_kernel + bottleneck_pio_kernel (identity blocks of stages 1-2) + conv_igemm_v4_kernel (ResNet-50 + FPN level 0 + head conv; %s)' % (
                                       'one event pair around the whole trunk + one around the head conv' if native_trace else
                                       '%d launches/step, event-bracketed incl. their transform / split-K passes' % (len(t2d) // nst)),
                                   'achieved': round(t2d_flops / (t2d_ms * 1e-3) / 1e12, 2) if t2d_ms > 0 else None, 'peak': peak2d, 'unit': 'TFLOP/s',
                                   'frac': round(t2d_flops / (t2d_ms * 1e-3) / 1e12 / peak2d, 4) if t2d_ms > 0 else None,
-                                  'flops_counted': ('every fp16 MFMA product issued by the chained pair form: 3 per fp32 multiply-add (the stem alone runs on fp32 MFMA), '
+                                  'flops_counted': ('every fp16 MFMA product issued by the chained pair form: 3 per fp32 multiply-add, '
                                                     'priced against the dense 16-bit MFMA peak; these layers are bound by HBM / launch latency, not by the matrix pipe') if trunk_pair else
                                                    ('matrix-core products of the executed form: one per multiply-add on the fp32 MFMA layers, three on the 2-D 3x3 layers that run '
                                                     'as Winograd on fp16-pair operands (priced against the fp32 MFMA peak all the same: a mixed span)'),
                                   'fp32_equivalent_tflops': round(t2d_flops / 3 / (t2d_ms * 1e-3) / 1e12, 2) if (trunk_pair and t2d_ms > 0) else None,
-                                  'ms_per_step': round(t2d_ms, 3), 'executed_gflop_per_step': round(t2d_flops / 1e9, 1)},
+                                  'ms_per_step': round(t2d_ms, 3), 'executed_gflop_per_step': round(t2d_flops / 1e9, 1),
+                                  'algorithmic_GB_per_step': round(t2d_bytes / 1e9, 3) if t2d_bytes > 0 else None,
+                                  'hbm_GBps_algorithmic': round(t2d_bytes / (t2d_ms * 1e-3) / 1e9, 1) if (t2d_bytes > 0 and t2d_ms > 0) else None},
         }
         if untraced:
             for k in ('roofline', 'roofline_winograd_transforms', 'roofline_unprojection', 'roofline_trunk_2d'):
@@ -777,25 +824,33 @@ def main():
         if world == 1 and not multi and args.api == 'simple_test' and not bf16 and os.environ.get('IVX_BENCH_EXTRA', '1') != '0':
             # The other BASELINE.json workloads on the driver's line (round-4 verdict, item 4): a few timed steps each of the public call, same
             # timing method (bench_other), after the KITTI region -- parity-test configurations, NOT the headline metric.
-            import argparse as _ap
+            import subprocess
             rec['extra_configs'] = []
             for cname, views in (('nuscenes', 0), ('scannet_fast', 20), ('scannet_v1', 50), ('sunrgbd_fast', 0)):
-                a2 = _ap.Namespace(**vars(args))
-                a2.config, a2.views, a2.steps, a2.warmup, a2.batch, a2.shard = cname, views, 5, 2, BATCH_PER_GPU, 'samples'
-                try:
-                    r2 = bench_other(a2, ia, kc, dev, 0, 1, emit=False)
+                cmd = [sys.executable, os.path.abspath(__file__), '--config', cname, '--steps', '5', '--warmup', '2', '--batch', str(BATCH_PER_GPU)]
+                if views:
+                    cmd += ['--views', str(views)]
+                if not pair:
+                    cmd += ['--wino-operands', 'f32']
+                if FusedConv.trunk_operands != 4:
+                    cmd += ['--trunk-operands', 'f32']
+                try:      # its own process, bounded: a fault or a hang in an extra configuration cannot cost the headline line (round-5 advisor)
+                    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                    line = [l for l in pr.stdout.splitlines() if l.startswith('{"metric')]
+                    if pr.returncode != 0 or not line:
+                        raise RuntimeError('exit code %d: %s' % (pr.returncode, (pr.stderr or '')[-200:]))
+                    r2 = json.loads(line[-1])
                     rf = r2['roofline']
                     rec['extra_configs'].append({
-                        'workload': r2['metric'], 'value': r2['value'], 'unit': r2['unit'], 'scenes_per_s': r2['scenes_per_s'], 'ms_per_step': r2['ms_per_step'],
-                        'steps': r2['steps'], 'warmup': r2['warmup'], 'dtype': 'f32 (fp16 (hi, lo) pair MFMA operands where the layer rules take them)' if pair else r2['dtype'],
-                        'batch_per_gpu': r2['config']['batch_per_gpu'], 'views': r2['config']['views'], 'api': r2['config']['api'],
-                        'detections_last_step': r2['config']['detections_last_step'],
-                        'roofline': {'bound': rf['bound'], 'kernel': rf['kernel'], 'achieved': rf['achieved'], 'peak': rf['peak'], 'unit': rf['unit'], 'frac': rf['frac'],
-                                     'neck_ms_per_step': rf['neck_ms_per_step']},
+                        'workload': r2['metric'], 'value': r2['value'], 'unit': r2['unit'], 'ms_per_step': r2['ms_per_step'],
+                        'steps': r2['steps'], 'warmup': r2['warmup'], 'batch_per_gpu': r2['config']['batch_per_gpu'], 'views': r2['config']['views'],
+                        'api': r2['config']['api'], 'detections_last_step': r2['config']['detections_last_step'],
+                        'neck_frac_of_mfma_peak': rf['frac'], 'neck_ms_per_step': rf['neck_ms_per_step'],
                         'trunk_2d_ms_per_step': (r2['roofline_trunk_2d'] or {}).get('ms_per_step')})
-                except Exception as e:      # an extra line must never cost the headline line
-                    rec['extra_configs'].append({'workload': cname, 'error': repr(e)})
-                torch.cuda.empty_cache()
+                except Exception as e:
+                    rec['extra_configs'].append({'workload': cname, 'error': repr(e)[:300]})
+            rec['extra_configs_note'] = ('five timed steps each of the public call in a subprocess of this script (same dtype / operand modes as the headline); '
+                                         'parity-test configurations, not the headline metric')
         if world == 1 and not args.no_cpu_baseline:
             from oracle import imvoxel_oracle as orc
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}

@@ -22,7 +22,6 @@
 //             c ^ (x & 15): the 16 lanes of one ds_read_b128 group hold 16 consecutive x (ds_read_b128 lane groups, MI355X guide), so every
 //             group reads 16 different 16-byte positions of the 256-byte bank window -- for every tap.
 #include "ivx_common.h"
-#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -120,7 +119,7 @@ struct BnkCfg {
 
 
 
-template <int P, int NB1, int NB2, int NB3, int DB2 = 0>
+template <int P, int NB1, int NB2, int NB3>
 __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParams p, const unsigned in_bytes, const unsigned w1_bytes,
                                                                                  const unsigned w2_bytes, const unsigned w3_bytes) {
   typedef BnkCfg<P, NB1, NB2, NB3> G;
@@ -297,52 +296,7 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
     int prow[2];                                          // halo-pixel index of tap (0, 0) of this lane's row in tile i
 #pragma unroll
     for (int i = 0; i < 2; ++i) prow[i] = (2 * (2 * g + i) + (rr >> 4)) * 18 + ox;
-    if constexpr (DB2) {
-      // B fragments straight from L2 into registers, three slabs deep, NO barrier in the loop: a filter slab is 16 KB (P = 128) for 12 MFMAs
-      // per wave -- staged through LDS every slab cost a workgroup barrier + a DMA round trip (0.8 us per slab for 0.16 us of matrix work,
-      // workgroup timelines).  Here the waves drift apart freely; the two waves that share a column tile read the same lines (L1).
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      // DB2 == 2: w2 in FRAGMENT-MAJOR order [column tile][slab][kk][lane][8 halves]: one load instruction = 1 KB contiguous
-      const int voff = DB2 == 2 ? lane * 16 : (nt * 32 + rr) * S2 * 128 + hh * 16;
-      u32x4 bq[3][4];
-      auto ldb = [&](const int s, u32x4 (&dst)[4]) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-          dst[kk] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, voff, DB2 == 2 ? ((nt * S2 + s) * 4 + kk) * 1024 : s * 128 + kk * 32, 0));
-      };
-      ldb(0, bq[0]);
-      ldb(1, bq[1]);
-      bnk_barrier();                                     // publishes mid1
-      for (int q = 0; q < NQ; ++q)
-        for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const int s = q * 9 + dy * 3 + dx;           // s % 3 == dx: static register slots
-            if (s + 2 < S2) ldb(s + 2, bq[(dx + 2) % 3]);
-            const int key = (ox + dx) & 15;
-            const unsigned char *Ar[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) Ar[i] = smem + (prow[i] + dy * 18 + dx) * PXB;
-            f32x4 fa[2][2];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              const int sl = kk & 1;
-#pragma unroll
-              for (int i = 0; i < 2; ++i) fa[sl][i] = *reinterpret_cast<const f32x4 *>(Ar[i] + (((q * 8 + 2 * kk + hh) ^ key) * 16));
-              if (sl == 0) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = bnk_mfma(fa[0][i], __builtin_bit_cast(f32x4, bq[dx][kk]), acc[i]);
-              } else {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                  acc[i] = bnk_mfma(fa[0][i], __builtin_bit_cast(f32x4, bq[dx][kk]), acc[i]);
-                  acc[i] = bnk_mfma(fa[1][i], __builtin_bit_cast(f32x4, bq[dx][kk - 1]), acc[i]);
-                }
-              }
-            }
-          }
-        }
-    } else {
+    {
     unsigned b_off[BR2];
 #pragma unroll
     for (int j = 0; j < BR2; ++j) b_off[j] = (unsigned)((lr + RP * j) * S2 * 128 + cc * 16);
@@ -628,17 +582,10 @@ extern "C" int ivx_bottleneck_fwd_pio(const ivx_bottleneck_desc *d, const ivx_bo
   const unsigned w1_bytes = (unsigned)(P * C * 4), w2_bytes = (unsigned)(P * 9 * P * 4), w3_bytes = (unsigned)(C * P * 4);
   const dim3 grid((unsigned)(8 * p.q_total));
   hipStream_t st = (hipStream_t)stream;
-  static const int variant = getenv("IVX_BNK_VARIANT") ? atoi(getenv("IVX_BNK_VARIANT")) : 0;      // lab knob (tools/bottleneck_ab.py)
-  if (variant == 2) {
-    if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 2, 3, 2, 2>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
-    else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 3, 3, 2, 2>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
-  } else if (variant == 1) {
-    if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 2, 3, 2, 1>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
-    else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 3, 3, 2, 1>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
-  } else {
-    if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 2, 3, 2>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
-    else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 3, 3, 2>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
-  }
+  // (measured and removed, profiles/r06_fused_bottleneck.md (c): conv2's filters straight from L2 into registers, in the chain's layout and in
+  // fragment order -- no gain over the LDS ring)
+  if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 2, 3, 2>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+  else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 3, 3, 2>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
   IVX_CHECK_LAUNCH("ivx_bottleneck_fwd_pio");
   return IVX_OK;
 }

@@ -1716,7 +1716,7 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
       const bool will_split = small && allow_ws && Sd >= 16 && tl <= split_tiles && (tl <= 100 || Sd >= 48);      // (the rule of the split-K block below)
       static const long long deep_tiles = getenv("IVX_PIO_DEEP_TILES") ? atoll(getenv("IVX_PIO_DEEP_TILES")) : 512;
       static const int deep_slabs = getenv("IVX_PIO_DEEP_SLABS") ? atoi(getenv("IVX_PIO_DEEP_SLABS")) : 6;
-      if (!will_split && p.kmode == 1 && Sd >= deep_slabs && tl <= deep_tiles) {
+      if (!will_split && p.kmode == 1 && Sd >= deep_slabs && tl <= deep_tiles && (pl.cfg == 66 || pl.cfg == 74)) {      // (only these two have a deep-ring form)
         pl.cfg += 100;       // 66 -> 166, 74 -> 174
         // ... and the 128 x 128 tile runs on MORE WAVES where the launch leaves SIMDs idle: 16 waves (179: wave tile 32 x 32, 128-byte rows, 128 KB, one
         // workgroup per CU) up to one tile per CU, 8 waves (177: wave tile 64 x 32) up to two.  A slab's LDS-DMA requests, fragment reads, barriers
@@ -1817,7 +1817,7 @@ static int launch_pair(ConvParams &p, const ConvPlan &pl, hipStream_t st) {
                                                                          // fragment reads are not what limits the loop (TM = 4 variants: the
                                                                          // compiler keeps the accumulators in scratch, 10x slower; removed)
     default:
-      ivx_set_error("ivx_conv_fwd: tile %d has no pair-operand instantiation (61, 63, 66, 67, 73 .. 76, 81 .. 83, 85, 166, 174)", pl.cfg);
+      ivx_set_error("ivx_conv_fwd: tile %d has no pair-operand instantiation (61, 63, 66, 67, 73 .. 77, 81 .. 83, 85, 166, 174, 177, 179, 183; fp16 pairs also 474, 475, 574)", pl.cfg);
       return IVX_ERR_INVALID_ARG;
   }
   return IVX_OK;
@@ -2840,14 +2840,6 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
   ConvParams p;
   int rc = fill_params(d, in, wgt, nullptr, nullptr, nullptr, out, &p);
   if (rc != IVX_OK) return rc;
-  if (cp_dst && !p.in_pair) {                    // (only the pair-operand kernels carry the word; not reached by the library's own callers)
-    if (hipMemcpyAsync(cp_dst, cp_src, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-      ivx_set_error("ivx_conv_grouped_launch: hipMemcpyAsync failed");
-      return IVX_ERR_HIP;
-    }
-  } else {
-    p.cp_src = cp_src; p.cp_dst = cp_dst;
-  }
   IVX_REQUIRE(groups >= 1 && groups <= 65535, "ivx_conv_grouped_launch: bad group count");
   IVX_REQUIRE((d->in_dtype == IVX_F32 || d->in_dtype == IVX_BF16_PAIR || d->in_dtype == IVX_F16_PAIR) && d->out_dtype == IVX_F32 &&
                   d->out_mode == 0 && d->res_mode == 0,
@@ -2855,6 +2847,15 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
   if (!dma_applicable(p)) {
     ivx_set_error("ivx_conv_grouped_launch: one group must stay below 2 GiB");
     return IVX_ERR_UNSUPPORTED;
+  }
+  // (after the argument checks: a rejected call has no side effect -- round-5 advisor)
+  if (cp_dst && !p.in_pair) {                    // (only the pair-operand kernels carry the word; not reached by the library's own callers)
+    if (hipMemcpyAsync(cp_dst, cp_src, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      ivx_set_error("ivx_conv_grouped_launch: hipMemcpyAsync failed");
+      return IVX_ERR_HIP;
+    }
+  } else {
+    p.cp_src = cp_src; p.cp_dst = cp_dst;
   }
   p.groups = groups; p.g_in = g_in; p.g_w = g_w; p.g_out = g_out;
   // z-halo kernel (TU 5): 1x1x3 along z, stride 1, pad 1, chunk-major fp16 pairs -- the ResModule layers of the stack necks

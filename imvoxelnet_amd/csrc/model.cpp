@@ -1264,7 +1264,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
   if (pl.scal_bytes > 0 && r.s0 <= m->trunk0 && r.s1 > m->trunk0)
     M_HIP(hipMemsetAsync(base + pl.scal_off, 0, (size_t)pl.scal_bytes, st), "hipMemsetAsync (amax slots)");
   const bool span2d = m->trace_on && m->trace_level == 1 && m->cfg.with_trunk;     // coarse tracing: the trunk is one span
-  double span_flops = 0.0;
+  double span_flops = 0.0, span_bytes = 0.0;     // products issued / bytes every launch of the span must move (inputs + outputs + filters, as executed)
   for (int i = r.s0; i < r.s1; ++i) {
     const Step &s = m->steps[i];
     const TInfo &in = pl.t[s.in];
@@ -1273,6 +1273,25 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
     const bool was_on = m->trace_on;
     if (in_span) {
       m->trace_on = false;                       // no per-launch events inside the span
+      {   // algorithmic bytes of the launch this step issues (a step covered by a one-launch kernel issues none)
+        const PlanStep &ps = pl.ps[i];
+        auto tb = [&](int t) { return t >= 0 ? (double)pl.t[t].elems() * pl.t[t].esz : 0.0; };
+        if (s.kind == ST_CONV && ps.fuse != 2) {
+          const ConvLayer &L = m->layers[s.layer];
+          if (ps.fuse == 1) {
+            const ConvLayer &L2 = m->layers[m->steps[i + 1].layer], &L3 = m->layers[m->steps[i + 2].layer];
+            span_bytes += tb(s.in) + tb(ps.fuse_out) + 4.0 * ((double)L.cout * L.cin + 9.0 * L2.cout * L2.cin + (double)L3.cout * L3.cin);
+          } else {
+            span_bytes += tb(s.in) + tb(s.out) + tb(s.res) + (double)pl.t[s.in].esz * L.cout * L.cin_pad * L.k[0] * L.k[1] * L.k[2];
+          }
+        } else if (s.kind == ST_MAXPOOL && ps.fuse == 4) {
+          span_bytes += tb(s.out) + tb(m->t_img);      // the one-launch head reads the image, writes the pooled map
+        } else if (s.kind == ST_IMG2CL && ps.fuse == 3) {
+          span_bytes += tb(s.in);                      // the amax pass
+        } else if (s.kind != ST_CONV && s.kind != ST_LAYOUT) {
+          span_bytes += tb(s.in) + tb(s.out) + tb(s.res);
+        }
+      }
       if (s.kind == ST_CONV) {
         const PlanStep &ps = pl.ps[i];
         const TInfo &o = pl.t[s.out];
@@ -1507,6 +1526,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
       for (auto it = m->trace.rbegin(); it != m->trace.rend(); ++it)
         if (it->stage == 6) {
           it->flops = span_flops;
+          it->bytes = span_bytes;
           M_HIP(hipEventRecord(it->e1, st), "hipEventRecord");
           break;
         }

@@ -132,7 +132,7 @@ class ImVoxelNet(nn.Module):
             if residual == 'bf16' and stages is None and self._native.cfg.with_trunk:
                 try:
                     self._native.calibrate_fp8(x, margin)     # the same mode inside the native handle (its own calibration pass: same maxima)
-                except Exception as e:
+                except ValueError as e:      # the library's invalid-argument status only; a HIP error / OOM (IvxError) propagates (round-5 advisor)
                     # (e.g. calibration images whose H / W are not multiples of 32: ivx_model_calibrate_fp8 refuses them.)  The Python
                     # modules are e4m3 already; a handle left in bf16 would make simple_test run ANOTHER mode than extract_feat without a
                     # word, so the handle goes and the layer-by-layer composition (the calibrated one) serves every call.
@@ -233,12 +233,13 @@ class ImVoxelNet(nn.Module):
         levels = self.neck_3d.forward_cl(volume)
         return self.bbox_head.get_bboxes_cl(self.bbox_head.forward_cl(levels), valid, img_metas)
 
-    def simple_test(self, img, img_metas, gather=False):
+    def simple_test(self, img, img_metas, gather=False, global_batch=None):
         """detectors/imvoxelnet.py:93-106.  gather (native-handle families, torch.distributed initialised): every rank passes
         its slice of the batch; ONE all-gather of the fixed-size padded device tensors (dist.all_gather_detections) replaces
         mmdet's pickle-based collect_results after the loop (tools/test.py:131-136), and -- as there -- the collected result list
         (whole batch, rank order) is built and returned on rank 0 only; the other ranks return None, so the host work of a step
-        does not grow with the number of ranks."""
+        does not grow with the number of ranks.  global_batch (with gather): the size of the batch dist.shard_batch() partitioned, needed when
+        it does not divide by the world size (shards that differ by one sample are padded for the fixed-size all-gather)."""
         if self._prepared_device is None and self._native is None and img.is_cuda:
             self.prepare(img.device)                             # first call: pack the weights (and build the native handle)
         H, W = img.shape[-2:]
@@ -261,7 +262,7 @@ class ImVoxelNet(nn.Module):
                               'outside the padded detection block; every rank returns its own results', RuntimeWarning, stacklevel=2)
             if gather and self.head_2d is None:      # sample-sharded ranks: one all-gather of the padded detections, result list on rank 0
                 from .dist import all_gather_detections, is_collecting_rank
-                boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)
+                boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count, global_batch=global_batch)
                 if not is_collecting_rank():
                     return None
                 img_metas = [img_metas[i % len(img_metas)] for i in range(boxes.shape[0])]
@@ -287,7 +288,7 @@ class ImVoxelNet(nn.Module):
             boxes, scores, labels, count = self._native.detect(img.contiguous(), img_metas)
             if gather:
                 from .dist import all_gather_detections, is_collecting_rank
-                boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)
+                boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count, global_batch=global_batch)
                 if not is_collecting_rank():
                     return None                  # as collect_results (tools/test.py:131-136): the collected list exists on rank 0 only
                 img_metas = [img_metas[i % len(img_metas)] for i in range(boxes.shape[0])]
@@ -298,7 +299,7 @@ class ImVoxelNet(nn.Module):
             boxes, scores, labels, count = self.detect_cl(volume, img_metas)
             if gather:
                 from .dist import all_gather_detections, is_collecting_rank
-                boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count)
+                boxes, scores, labels, count = all_gather_detections(boxes, scores, labels, count, global_batch=global_batch)
                 if not is_collecting_rank():
                     return None
                 img_metas = [img_metas[i % len(img_metas)] for i in range(boxes.shape[0])]     # box type of the other ranks' samples

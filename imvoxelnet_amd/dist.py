@@ -32,7 +32,11 @@ def _rank_world(rank, world, group=None):
     """Defaults from the process group (`group`: a sub-group, whose ranks are numbered 0 .. size-1; None: the default group);
     (0, 1) when torch.distributed is not initialised (single process)."""
     on = dist.is_available() and dist.is_initialized()
-    return ((dist.get_rank(group) if on else 0) if rank is None else rank, (dist.get_world_size(group) if on else 1) if world is None else world)
+    if rank is None:
+        rank = dist.get_rank(group) if on else 0
+        if rank < 0:       # torch returns -1 for a process outside `group`: indexing shard plans with it would silently pick the last one
+            raise RuntimeError('this process is not a member of the process group passed as `group`; call the sharded entry points from member ranks only')
+    return (rank, (dist.get_world_size(group) if on else 1) if world is None else world)
 
 
 def _peer(group, r):

@@ -131,9 +131,6 @@ int ivx_conv_fwd_ws(const ivx_conv_desc *d, const void *in, const void *wgt, con
 int ivx_bf16_pair_split(const float *in, int64_t n, void *out, ivx_stream_t stream);
 int ivx_f16_pair_split(const float *in, int64_t n, float scale, void *out, ivx_stream_t stream);   /* IVX_F16_PAIR of scale * in, saturating */
 int ivx_conv_pair_supported(const ivx_conv_desc *d);
-/* A/B knob (per calling thread) of the Winograd-domain GEMMs on fp16 pairs: -1 (default) = the z-halo kernel where it applies (1x1x3 along z,
- * stride 1, pad 1, Cin % 32 == 0: one staged tile serves the three z-taps), 0 = the generic LDS-DMA kernel always, 1 .. 4 = force a config. */
-int ivx_conv_set_halo_mode(int mode);
 
 /* ---------------------------------------------------------------------------------------
  * Chained fp16-pair activations (0.4.0): the 2-D trunk on the 16-bit matrix cores without split passes.
@@ -289,23 +286,6 @@ int ivx_conv_winograd_gemm_output_amax(const ivx_conv_desc *d, int32_t tile, con
                                        const void *res, void *out, void *workspace, int64_t workspace_bytes, float *partials,
                                        ivx_stream_t stream);
 
-/* Tuning knob for A/B experiments only (per calling thread): 0 = automatic tile choice (default); 1..7 force a tile
- * of the generic kernel, 41..53 of the LDS-DMA fp32 kernel, 61..73 of its bf16 instantiation. */
-int ivx_conv_set_tile_override(int cfg);
-/* Per calling thread, A/B only (tools/wino_ab.py): kernel of the F(6x6,3x3) output transform.  -1 = the library's rule (2 with a
- * residual, 1 without); 0 whole 8x8 tile per thread, 2 channels per lane (the round-2 kernel); 1 the same with 1 channel per lane;
- * 2 buffer addressing + column accumulation, 2 channels per lane; 3 the same with 1 channel per lane.  input_variant: -1 / 0 two
- * channels per lane, 1 one channel per lane. */
-int ivx_conv_winograd_set_variant(int32_t output_variant, int32_t input_variant);
-/* Per calling thread, A/B only: 1 = one-channel-per-lane epilogue stores in the LDS-DMA conv kernel; 0 (default) = the
- * LDS-transposed epilogue (a lane stores 4 consecutive channels as one 16-byte word) wherever it applies. */
-int ivx_conv_set_epilogue_mode(int narrow);
-/* Per calling thread, A/B only: 1 = the round-1 tile rule of the direct convolution planner, 0 (default) = scored choice. */
-int ivx_conv_set_plan_mode(int mode);
-/* Per calling thread, A/B and tests only: 1 = the candidate top-k of the detection tails (ivx_anchor_head_get_bboxes,
- * ivx_fcos_head_level_candidates) always runs as the one-workgroup radix select; 0 (default) = lists of >= 16 384 scores take
- * the chip-wide histogram / compaction form.  Both return the same indices in the same order. */
-int ivx_topk_set_mode(int32_t single_workgroup);
 
 /* Modulated deformable convolution (DCNv2; mmcv ModulatedDeformConv2dPack, deform_groups = 1) -- nuScenes reference
  * backbone, configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14.  Builds the modulated, bilinearly sampled columns
@@ -745,14 +725,25 @@ int ivx_voxel_new_origin(const float *origin, const int32_t *n_voxels, const flo
 int ivx_fold_batchnorm(const float *gamma, const float *beta, const float *mean, const float *var, const float *bias, float eps,
                        int32_t n, float *scale, float *shift);
 
+
 /* ---------------------------------------------------------------------------------------
- * Device ceilings measured on the box (measurement only; bench.py prices its roofline fractions against the data-sheet
- * peaks AND these): the dense issue rate of the MFMA form the conv kernel uses for `dtype` (IVX_F32:
- * v_mfma_f32_32x32x2_f32, IVX_BF16: v_mfma_f32_32x32x16_bf16; scratch >= 512 KiB of device memory), and the streaming
- * copy rate of HBM (read + written bytes per second over `bytes` from src to dst; use buffers well past the 256 MiB
- * Infinity Cache).  Both synchronise the stream and return the best of a few repetitions. */
-int ivx_ubench_mfma(int32_t dtype, void *scratch, int64_t scratch_bytes, double *tflops, ivx_stream_t stream);
-int ivx_ubench_copy(const void *src, void *dst, int64_t bytes, double *gbps, ivx_stream_t stream);
+ * The export names of SURVEY.md section 8(b)'s minimum set that this header spells differently -- the same entry points under the survey's
+ * names (csrc/api_common.cpp forwards; INTEGRATION.md B has the table):
+ *   ivx_anchor_head_decode  = ivx_anchor_head_get_bboxes       (Anchor3DHead.get_bboxes_single, dense_heads/anchor3d_head.py)
+ *   ivx_fcos3d_head_decode  = ivx_fcos_head_level_candidates   (ImVoxelHead / V2 per-level decode, dense_heads/imvoxel_head*.py)
+ *   ivx_nms_rotated_bev     = ivx_nms_bev with rotated = 1     (nms_gpu, ops/iou3d/src/iou3d.cpp:95-147)
+ *   ivx_nms_aligned3d       = ivx_aligned_3d_nms               (core/post_processing/box3d_nms.py:91-138)                              */
+int ivx_anchor_head_decode(const ivx_anchor_head_desc *d, const float *head_out, const float *anchors, void *workspace, int64_t workspace_bytes,
+                           float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_count, int64_t *cand_idx, float *cand_boxes,
+                           float *cand_scores, ivx_stream_t stream);
+int ivx_fcos3d_head_decode(const float *head_out, const uint8_t *valid0, const float *level_vs, const float *level_new_origin, float scale, int32_t B,
+                           int32_t nx, int32_t ny, int32_t nz, int32_t CH, int32_t n_classes, int32_t n_reg, int32_t level, int32_t X, int32_t Y,
+                           int32_t Z, int32_t nms_pre, void *workspace, int64_t workspace_bytes, float *cand_boxes, float *cand_scores,
+                           int32_t *cand_count, ivx_stream_t stream);
+int ivx_nms_rotated_bev(const float *boxes_sorted, int32_t n, float thresh, void *workspace, int64_t workspace_bytes, int64_t *keep, int32_t *num_out,
+                        ivx_stream_t stream);
+int ivx_nms_aligned3d(const float *boxes, const float *scores, const int64_t *classes, int32_t n, float thresh, int64_t *pick, int32_t *num_out,
+                      ivx_stream_t stream);
 
 #ifdef __cplusplus
 }

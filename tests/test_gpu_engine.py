@@ -459,6 +459,7 @@ def test_rccl_two_gpus_gather_and_slab_exchange(ia):
     rec = json.loads(lines[0])
     assert rec['world'] == n and rec['rccl_ranks'] == n
     assert rec['gather_len'] == 2 * n and rec['gather_same'] and rec['gather_detections'] > 0
+    assert rec['ragged_gather_len'] == 2 * n + 1 and rec['ragged_gather_same']           # shards that differ by one sample
     assert rec['view_sharded_same']
 
 

@@ -34,9 +34,6 @@ def main():
                              ('scannet x50 s2', 128, 50, 60, 80), ('nuscenes s1', 64, 6, 232, 400), ('nuscenes s2', 128, 6, 116, 200),
                              ('scannet x20 s1', 64, 20, 120, 160), ('scannet x20 s2', 128, 20, 60, 80)]:
         (f1, f2, f3), _, _ = _block(P, 1)
-        if os.environ.get('IVX_BNK_VARIANT') == '2':      # lab: conv2's filters in fragment-major order
-            wp = f2.wpair
-            f2.wpair = wp.view(P // 32, 32, (P // 32) * 9, 4, 2, 8).permute(0, 2, 3, 4, 1, 5).contiguous().view(wp.shape)
         x = torch.relu(torch.randn(B, 1, H, W, 4 * P, generator=torch.Generator().manual_seed(1))).cuda()
         xp = make_pair(x)
         t_f = timed(lambda: ops.bottleneck_fwd_pio(xp, f1, f2, f3))

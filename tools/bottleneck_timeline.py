@@ -33,9 +33,6 @@ def main():
     lines = ['| map | workgroups | span us | conv1 K loop p50 / p90 | conv1 epilogue | conv2 K loop | conv2 epilogue | conv3 K loop (+ epilogues of earlier units) | last epilogue | whole p50 / p90 |', '|---|---|---|---|---|---|---|---|---|---|']
     for name, P, B, H, W in [('kitti s1', 64, 4, 96, 320), ('kitti s2', 128, 4, 48, 160), ('scannet x50 s1', 64, 50, 120, 160), ('scannet x50 s2', 128, 50, 60, 80)]:
         (f1, f2, f3), _, _ = _block(P, 1)
-        if os.environ.get('IVX_BNK_VARIANT') == '2':
-            wp = f2.wpair
-            f2.wpair = wp.view(P // 32, 32, (P // 32) * 9, 4, 2, 8).permute(0, 2, 3, 4, 1, 5).contiguous().view(wp.shape)
         x = torch.relu(torch.randn(B, 1, H, W, 4 * P, generator=torch.Generator().manual_seed(1))).cuda()
         xp = make_pair(x)
         for _ in range(3):

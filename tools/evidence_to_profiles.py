@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 COPIES = (('kernel_trace_kitti.md', 'bench_kernel_trace.md'), ('kernel_trace_scannet_v1.md', 'kernel_trace_scannet_v1.md'),
           ('kernel_trace_nuscenes.md', 'kernel_trace_nuscenes.md'), ('pmc.md', 'bench_pmc.md'), ('pmc.json', 'bench_pmc.json'),
-          ('pmc_wino.md', 'bench_pmc_wino.md'), ('pmc_wino.json', 'bench_pmc_wino.json'), ('pmc_trunk.md', 'bench_pmc_trunk.md'),
+          ('pmc_wino.md', 'bench_pmc_wino.md'), ('pmc_wino.json', 'bench_pmc_wino.json'), ('pmc_trunk.md', 'bench_pmc_trunk.md'), ('pmc_all.md', 'bench_pmc_all.md'), ('pmc_all.json', 'bench_pmc_all.json'),
+          ('bottleneck_ab.md', 'bottleneck_ab.md'), ('stem_ab.md', 'stem_ab.md'), ('other_no_fusion.jsonl', 'bench_other_configs_no_fusion.jsonl'),
           ('pmc_scannet_v1.md', 'pmc_scannet_v1.md'), ('pmc_scannet_v1.json', 'pmc_scannet_v1.json'),
           ('pmc_nuscenes.md', 'pmc_nuscenes.md'), ('pmc_nuscenes.json', 'pmc_nuscenes.json'),
           ('other.jsonl', 'bench_other_configs.jsonl'), ('other_f32_operands.jsonl', 'bench_other_configs_f32_operands.jsonl'),
@@ -36,6 +37,9 @@ def main():
             ('`--trunk-operands f32` (round 3: the 2-D trunk on fp32 MFMA, the neck GEMMs on pairs)', 'bench_trunk_f32.json'),
             ('`--wino-operands f32 --trunk-operands f32` (fp32 MFMA everywhere: the round-2 arithmetic)', 'bench_f32_operands.json'),
             ('--api composed (layer by layer over the op-level ABI)', 'bench_composed.json'),
+            ('`IVX_FUSE_BOTTLENECK=0` (the five identity blocks of stages 1-2 as three launches each)', 'bench_no_fused_bottleneck.json'),
+            ('`IVX_FUSE_STEM=0` (layout change, fp32-MFMA stem, max-pool as three launches)', 'bench_no_fused_stem.json'),
+            ('`IVX_FUSE_STEM=0 IVX_FUSE_BOTTLENECK=0` (the round-5 trunk)', 'bench_no_fusion.json'),
             ('--storage bf16 (optional reduced-precision mode; NOT the headline)', 'bench_bf16.json'),
             ('IVX_BENCH_FORCE_DIST=1 under torch.distributed.run, world size 1 (RCCL all-gather in every step)', 'bench_dist1.json'),
             (f'the run under rocprofv3 --kernel-trace --stats (profiles/{pre}_bench_kernel_trace.md)', 'bench_profiled_kitti.json')]
@@ -65,6 +69,11 @@ def main():
         m = [q for q in b if q['config']['workload'] == r['config']['workload'] and q['config'].get('views') == r['config'].get('views')]
         out.append(f"| {r['config']['workload']} x{r['config'].get('views')} views | {r['value']} | {r['ms_per_step']} | {(r.get('roofline_trunk_2d') or {}).get('ms_per_step')} | "
                    f"{(r.get('roofline') or {}).get('neck_ms_per_step')} | {m[0]['value'] if m else '-'} |")
+    if os.path.exists(os.path.join(E, 'other_no_fusion.jsonl')):
+        out += ['', '| workload, `IVX_FUSE_STEM=0 IVX_FUSE_BOTTLENECK=0` (the round-5 trunk) | images/s | ms/scene | trunk ms |', '|---|---|---|---|']
+        for l in open(os.path.join(E, 'other_no_fusion.jsonl')):
+            r = json.loads(l)
+            out.append(f"| {r['config']['workload']} x{r['config'].get('views')} views | {r['value']} | {r['ms_per_step']} | {(r.get('roofline_trunk_2d') or {}).get('ms_per_step')} |")
     if os.path.exists(os.path.join(E, 'other_bf16.jsonl')):
         out += ['', '| optional storage mode | images/s | ms/scene |', '|---|---|---|']
         for l in open(os.path.join(E, 'other_bf16.jsonl')):

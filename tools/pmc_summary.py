@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--min-ms', type=float, default=0.0)
     ap.add_argument('--match', default='conv_igemm,conv_wino_halo,conv_wino_zblk', help='comma-separated substrings of the kernel names to keep')
     ap.add_argument('--json', default=None)
+    ap.add_argument('--steps', type=int, default=0, help='model steps the profiled command ran (written to the JSON as _meta.steps: per-step sums)')
     a = ap.parse_args()
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
@@ -78,6 +79,8 @@ def main():
             print(f'| {k} | {v:.4g} |')
         print()
         out[key] = dict(counters=m, derived=der, launches=max(n.values()))
+    if a.steps:
+        out['_meta'] = {'steps': a.steps}
     if a.json:
         json.dump(out, open(a.json, 'w'), indent=1)
 
