@@ -19,6 +19,7 @@ SOURCES = [
     ('conv_igemm.hip', ['-DIVX_CONV_TU=5'], 'conv_igemm_halo.o'),
     ('bottleneck.hip', []),
     ('stem.hip', []),
+    ('fold4w.hip', []),
     ('winograd.hip', []),
     ('pool_layout.hip', []),
     ('backproject.hip', ['-ffp-contract=off']),

@@ -2131,6 +2131,10 @@ __global__ __launch_bounds__(64 * WCOL * (Z / 3) * WN, WPE) void conv_wino_zblk_
   const int c0 = mt * CT, n0 = nt * BN;          // first column of the tile
   const int m0 = c0 * Z;                         // its first OUTPUT row (columns x Z)
   if (m0 >= p.M) return;
+#ifdef IVX_CONV_TIMELINE
+  const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tl1 = 0, tl2 = 0;
+#endif
   const size_t gz = blockIdx.z;
   if (p.cp_dst && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) *p.cp_dst = *p.cp_src;
   const __amdgpu_buffer_rsrc_t rs_in =
@@ -2186,6 +2190,9 @@ __global__ __launch_bounds__(64 * WCOL * (Z / 3) * WN, WPE) void conv_wino_zblk_
   int cur = 0;
   for (int g = 0; g < G; ++g) {
     lds_dma_wait_all();                 // this wave's loads of group g have landed; the barrier publishes all waves'
+#ifdef IVX_CONV_TIMELINE
+    if (g == 0) tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();                    // ... and every wave is done reading the other buffer (group g - 1)
     if (g + 1 < G) load_group(g + 1, cur ^ 1);
     const T *A0 = smem + cur * BUF + (cg * 32 + rl) * BK;
@@ -2217,6 +2224,9 @@ __global__ __launch_bounds__(64 * WCOL * (Z / 3) * WN, WPE) void conv_wino_zblk_
     }
     cur ^= 1;
   }
+#ifdef IVX_CONV_TIMELINE
+  tl2 = __builtin_amdgcn_s_memrealtime();
+#endif
   __syncthreads();                      // the staging area of the epilogue overlaps the ring
   float *stage = reinterpret_cast<float *>(smem) + wid_u * 1024;
   float *outp = p.out + gz * (size_t)p.g_out;
@@ -2234,6 +2244,13 @@ __global__ __launch_bounds__(64 * WCOL * (Z / 3) * WN, WPE) void conv_wino_zblk_
       if (m < p.M && nok) *reinterpret_cast<f32x4 *>(outp + (size_t)m * p.Cout + nbc) = v;
     }
   }
+#ifdef IVX_CONV_TIMELINE
+  if (p.tl && tid == 0) {
+    unsigned long long *t = p.tl + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    t[0] = tl0; t[1] = tl1; t[2] = tl2; t[3] = __builtin_amdgcn_s_memrealtime();
+    t[4] = __builtin_amdgcn_s_getreg(63492); t[5] = __builtin_amdgcn_s_getreg(63508);
+  }
+#endif
 }
 
 template <int Z, int WCOL, int WN, int WPE, int SW = 1>

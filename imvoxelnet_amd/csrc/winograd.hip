@@ -17,6 +17,9 @@
 // by fp32 rounding only: measured max deviation from the direct MFMA kernel on the KITTI neck layers, as a fraction of the
 // output range: m = 2 up to 4e-6, m = 4 up to 2.4e-5, m = 6 up to 4e-5 (profiles/r01_conv_layers.log).
 #include "ivx_common.h"
+#include <stdlib.h>
+int ivx_conv_launch_fold4w(const _Float16 *V, long long vs, const _Float16 *U, long long us, int M, int Cin_stored, int Cout, int Z, const IvxWinoFold &f,
+                           hipStream_t st);
 
 int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in, long long g_in, const float *wgt, long long g_w,
                             float *out, long long g_out, hipStream_t st, const unsigned *cp_src, unsigned *cp_dst);
@@ -39,7 +42,22 @@ struct WinoP {
   float post_scale;
   float *pmax;              // output transform: per-workgroup max |out| goes to pmax[blockIdx.x] (the next layer's input scale), or NULL
   const unsigned *hdr;      // pair operands: {bits of max |input|, bits of the filter scale} (device; see wino_pair_vscale), else NULL
+#ifdef IVX_CONV_TIMELINE
+  unsigned long long *tl;   // debug build (tools/neck_timeline.py): 8 words per workgroup -- s_memrealtime at entry and at the end, HW_ID, XCC_ID
+#endif
 };
+#ifdef IVX_CONV_TIMELINE
+#define WINO_TL_BEGIN const unsigned long long wtl0 = __builtin_amdgcn_s_memrealtime();
+#define WINO_TL_END(p)                                                                                              \
+  if ((p).tl && threadIdx.x == 0) {                                                                                \
+    unsigned long long *t_ = (p).tl + (size_t)blockIdx.x * 8;                                                       \
+    t_[0] = wtl0; t_[1] = wtl0; t_[2] = wtl0; t_[3] = __builtin_amdgcn_s_memrealtime();                             \
+    t_[4] = __builtin_amdgcn_s_getreg(63492); t_[5] = __builtin_amdgcn_s_getreg(63508);                             \
+  }
+#else
+#define WINO_TL_BEGIN
+#define WINO_TL_END(p)
+#endif
 
 // Power-of-two scales of the fp16-pair operands (ivx_conv_desc.wino_operands = IVX_F16_PAIR), chosen on the device from the data so
 // that the largest value lands in [2^14, 2^15) -- below fp16's 65504 with room for the transform's growth -- and everything down to
@@ -272,6 +290,7 @@ __device__ __forceinline__ void wino_pair2(const float2 v, const float s, unsign
 // fabric traffic suggests; a tile order or an LDS exchange that removes it has nothing to win.)
 template <int MT, int VW, int PAIR = 0>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
+  WINO_TL_BEGIN
   typedef typename VecT<VW>::T V;
   constexpr int N = MT + 2;
   static_assert(!PAIR || VW == 2, "pair operands: two channels per lane (one dword of hi, one of lo)");
@@ -336,6 +355,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
       }
     }
   }
+  WINO_TL_END(p)
 }
 
 __device__ __forceinline__ float wino_finish(const WinoP &p, float acc, float sc, float sf, float r) {
@@ -357,6 +377,7 @@ __device__ __forceinline__ float2 wino_finish_v(const WinoP &p, float2 a, float2
 // out = epilogue(At M A).  One thread: VW channels of one (b, tx, ty, zo) -> m x m outputs.
 template <int MT, int VW>
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
+  WINO_TL_BEGIN
   typedef typename VecT<VW>::T V;
   constexpr int N = MT + 2;
   const int CV = p.Co / VW;
@@ -408,6 +429,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
     }
   }
   if (p.pmax) wino_block_max_store(omax, p.pmax);
+  WINO_TL_END(p)
 }
 
 // Coefficients of At for the column-accumulate form of the output transform (wino_output_buf_kernel below).
@@ -513,6 +535,7 @@ template <int VW> struct Wino6Columns<8, VW> {
 // SIMD instead of three at VW = 2).
 template <int VW, int WPE, int RPF = 0>
 __global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p, const unsigned m_bytes, const unsigned out_bytes) {
+  WINO_TL_BEGIN
   typedef typename VecT<VW>::T V;
   constexpr int MT = 6, N = 8, EB = VW * 4;     // bytes per lane item
   const int CV = p.Co / VW;
@@ -573,6 +596,7 @@ __global__ __launch_bounds__(256, WPE) void wino_output_buf_kernel(const WinoP p
     }
   }
   if (p.pmax) wino_block_max_store(omax, p.pmax);
+  WINO_TL_END(p)
 }
 
 // U = G g Gt.  wgt is layout 0 [Co,3,3,KW,Ci]; U is [n*n][Co][K] with the K order of `kmode` (0: k = kz*Ci + ci;
@@ -729,6 +753,9 @@ extern "C" int64_t ivx_conv_winograd_workspace_bytes(const ivx_conv_desc *d, int
 }
 
 namespace {
+#ifdef IVX_CONV_TIMELINE
+unsigned long long *g_wino_timeline = nullptr;
+#endif
 int wino_setup(const ivx_conv_desc *d, int tile, const void *in, const float *scale, const float *shift, const void *res, void *out,
                void *workspace, int64_t workspace_bytes, WinoDims *w, WinoP *p, const char *who) {
   int rc = wino_dims(d, tile, w, who);
@@ -755,6 +782,9 @@ int wino_setup(const ivx_conv_desc *d, int tile, const void *in, const float *sc
   p->relu = d->relu; p->res_mode = d->res_mode; p->res_after_act = d->res_after_act;
   p->post_scale = d->post_scale == 0.f ? 1.0f : d->post_scale;
   p->pmax = nullptr;
+#ifdef IVX_CONV_TIMELINE
+  p->tl = g_wino_timeline;
+#endif
   p->hdr = d->wino_operands == IVX_F16_PAIR
                ? (const unsigned *)((char *)workspace + ivx_align_up(w->n2 * w->v_stride * 4, 256) + ivx_align_up(w->n2 * w->m_stride * 4, 256))
                : nullptr;
@@ -877,7 +907,14 @@ extern "C" int ivx_conv_winograd_gemm_output_amax(const ivx_conv_desc *d, int32_
   f.pmax = partials;
   f.B = d->B; f.TX = w.TX; f.TY = w.TY; f.Z = w.Zo; f.Xo = w.Xo; f.Yo = w.Yo; f.Co = d->Cout;
   f.relu = p.relu; f.res_mode = p.res_mode; f.res_after_act = p.res_after_act; f.post_scale = p.post_scale;
-  rc = ivx_conv_grouped_fold4(&g, w.n2, p.V, 2 * w.v_stride, u, 2LL * d->Cout * d->KW * d->Cin, &f, (hipStream_t)stream);
+  // IVX_FOLD4_WAVES=2: the two-waves-per-SIMD form on v_mfma_f32_16x16x32_f16 (csrc/fold4w.hip, round 6: measured slower, profiles/r06_fused_two_wave.md); default 1: the round-5 one-wave kernel
+  // (conv_wino_fold4_kernel) -- same tile geometry, same partial-maximum entries
+  static const int fold_waves = getenv("IVX_FOLD4_WAVES") ? atoi(getenv("IVX_FOLD4_WAVES")) : 1;
+  if (fold_waves == 2 && d->Cout % 8 == 0)
+    rc = ivx_conv_launch_fold4w(reinterpret_cast<const _Float16 *>(p.V), 2 * w.v_stride, reinterpret_cast<const _Float16 *>(u), 2LL * d->Cout * d->KW * d->Cin,
+                                d->B * w.TX * w.TY * w.Zo, 2 * d->Cin, d->Cout, w.Zo, f, (hipStream_t)stream);
+  else
+    rc = ivx_conv_grouped_fold4(&g, w.n2, p.V, 2 * w.v_stride, u, 2LL * d->Cout * d->KW * d->Cin, &f, (hipStream_t)stream);
   if (rc != IVX_OK) return rc;
   IVX_CHECK_LAUNCH("ivx_conv_winograd_gemm_output");
   return IVX_OK;
@@ -962,3 +999,7 @@ extern "C" int ivx_conv_winograd_fwd(const ivx_conv_desc *d, int32_t tile, const
   if (rc != IVX_OK) return rc;
   return ivx_conv_winograd_output(d, tile, scale, shift, res, out, workspace, workspace_bytes, stream);
 }
+
+#ifdef IVX_CONV_TIMELINE
+extern "C" int ivx_wino_set_timeline(void *buf) { g_wino_timeline = (unsigned long long *)buf; return 0; }
+#endif

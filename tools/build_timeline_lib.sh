@@ -13,8 +13,9 @@ for tu in 0 4 5; do
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$CSRC/bottleneck.hip" -o "$TMP/bottleneck.o" -DIVX_CONV_TIMELINE &
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$CSRC/stem.hip" -o "$TMP/stem.o" -DIVX_CONV_TIMELINE &
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$CSRC/winograd.hip" -o "$TMP/winograd.o" -DIVX_CONV_TIMELINE &
 wait
 cd "$CSRC"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/bin/libimvoxel_hip_tl.so" "$TMP/tu0.o" conv_igemm_f32.o conv_igemm_lowp.o \
-  conv_igemm_pair_bf16.o "$TMP/tu4.o" "$TMP/tu5.o" "$TMP/bottleneck.o" "$TMP/stem.o" winograd.o pool_layout.o backproject.o anchor_tail.o dcn.o ubench.o api_common.o kitti_eval.o model.o
+  conv_igemm_pair_bf16.o "$TMP/tu4.o" "$TMP/tu5.o" "$TMP/bottleneck.o" "$TMP/stem.o" "$TMP/winograd.o" pool_layout.o backproject.o anchor_tail.o dcn.o ubench.o api_common.o kitti_eval.o model.o
 echo "$ROOT/tools/bin/libimvoxel_hip_tl.so"
