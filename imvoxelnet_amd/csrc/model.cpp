@@ -168,6 +168,9 @@ struct PlanStep {
   // identity bottleneck in one launch (ivx_bottleneck_fwd_pio, csrc/bottleneck.hip): fuse 1 = conv1's step, which runs the whole block and
   // writes conv3's output tensor (fuse_out); fuse 2 = conv2's / conv3's step, covered by it
   int fuse = 0, fuse_out = -1;
+  // the shortcut conv of a block with a downsample runs on the handle's SIDE stream next to conv1 / conv2 (independent: both read the block's
+  // input): side = site index + 1 on the shortcut conv's step, join = site index + 1 on the step that reads its output as the residual
+  int side = 0, join = 0;
 };
 
 struct Plan {
@@ -181,6 +184,8 @@ struct Plan {
   ivx_indoor_tail_desc itail;          // indoor families with a head
   int max_det = 0;                     // rows per sample of the detection outputs
   int64_t scal_off = 0, scal_bytes = 0;   // scalar blocks of the pair-chained tensors (zeroed at the start of every forward)
+  int64_t ws2_off = 0;                    // second split-K workspace (launches on the side stream), 0: none
+  int n_sides = 0;
 };
 
 }  // namespace
@@ -221,6 +226,9 @@ struct ivx_model {
   std::vector<TraceRec> trace;
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
+  hipStream_t side = nullptr;          // side stream (created on first use) + fork / join events per site
+  hipEvent_t ev_fork = nullptr;
+  std::vector<hipEvent_t> ev_join;
 };
 
 namespace {
@@ -1051,6 +1059,25 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       pl->t[s3.out].first = i;
       i += 2;
     }
+  // Shortcut convs on the side stream: step i = the downsample conv, steps i + 1 .. j - 1 read the same block input / each other, step j takes
+  // the shortcut as its residual.  The block input stays allocated until the join (the side launch may still be reading it).
+  static const bool side_on = !(getenv("IVX_SIDE_STREAM") && atoi(getenv("IVX_SIDE_STREAM")) == 0);
+  if (side_on && c.with_trunk)
+    for (int i = std::max(r.s0, m->trunk0); i + 2 < std::min(r.s1, m->trunk1); ++i) {
+      const Step &s0 = m->steps[i];
+      if (s0.kind != ST_CONV || pl->ps[i].tile != 0 || pl->ps[i].fuse != 0 || s0.res >= 0) continue;
+      const std::string &nm = m->layers[s0.layer].name;
+      if (nm.size() < 10 || nm.compare(nm.size() - 10, 10, "downsample") != 0) continue;
+      int j = -1;
+      for (int k = i + 1; k < std::min(r.s1, m->trunk1) && k <= i + 6; ++k)
+        if (m->steps[k].res == s0.out) { j = k; break; }
+      if (j < 0 || j < i + 2) continue;
+      bool ok = true;
+      for (int k = i + 1; k < j && ok; ++k) ok = m->steps[k].in != s0.out && m->steps[k].res != s0.out && pl->ps[k].side == 0 && pl->ps[k].join == 0;
+      if (!ok) continue;
+      pl->ps[i].side = pl->ps[j].join = ++pl->n_sides;
+      pl->t[s0.in].last = std::max(pl->t[s0.in].last, j);
+    }
   std::vector<int> keep = {m->t_fpn0, m->t_volume, m->t_valid, m->t_neck, m->t_head, m->t_angle, m->t_layout};
   keep.insert(keep.end(), m->t_levels.begin(), m->t_levels.end());
   for (int t : keep)
@@ -1146,6 +1173,7 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
   pl->ws_off = pl->arena;
   pl->ws_bytes = align256(pl->ws_bytes);
   pl->total = pl->arena + pl->ws_bytes;
+  if (pl->n_sides > 0) { pl->ws2_off = pl->total; pl->total += pl->ws_bytes; }      // the side stream's own split-K workspace
   return IVX_OK;
 }
 
@@ -1264,6 +1292,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
   if (pl.scal_bytes > 0 && r.s0 <= m->trunk0 && r.s1 > m->trunk0)
     M_HIP(hipMemsetAsync(base + pl.scal_off, 0, (size_t)pl.scal_bytes, st), "hipMemsetAsync (amax slots)");
   const bool span2d = m->trace_on && m->trace_level == 1 && m->cfg.with_trunk;     // coarse tracing: the trunk is one span
+  std::vector<char> forked((size_t)std::max(pl.n_sides, 1), 0);      // sites whose shortcut conv went to the side stream in this run
   double span_flops = 0.0, span_bytes = 0.0;     // products issued / bytes every launch of the span must move (inputs + outputs + filters, as executed)
   for (int i = r.s0; i < r.s1; ++i) {
     const Step &s = m->steps[i];
@@ -1380,6 +1409,29 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         const void *res = s.res >= 0 ? ptr(s.res) : nullptr;
         const TInfo &o = pl.t[s.out];
         const int is3d = in.D > 1 && in.W > 1;      // a 3-D neck layer (the head conv sees [B,X',Y',1,C])
+        // the shortcut conv of a block runs on the side stream next to conv1 / conv2 (with per-launch tracing everything stays on `st`)
+        hipStream_t cst = st;
+        void *cws = ws;
+        if (ps.side > 0 && !m->trace_on && pl.ws2_off > 0) {
+          if (!m->side) {
+            M_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+            M_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming), "hipEventCreateWithFlags");
+          }
+          while ((int)m->ev_join.size() < pl.n_sides) {
+            hipEvent_t e;
+            M_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreateWithFlags");
+            m->ev_join.push_back(e);
+          }
+          M_HIP(hipEventRecord(m->ev_fork, st), "hipEventRecord");
+          M_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0), "hipStreamWaitEvent");
+          cst = m->side;
+          cws = base + pl.ws2_off;
+          forked[ps.side - 1] = 1;
+        }
+        if (ps.join > 0 && forked[ps.join - 1]) {
+          M_HIP(hipStreamWaitEvent(st, m->ev_join[ps.join - 1], 0), "hipStreamWaitEvent");
+          forked[ps.join - 1] = 0;
+        }
         if (ps.tile && m->trace_on) {   // the three stages as separate launches so each gets its own pair of events
           const int n = ps.tile + 2, tiles = o.B * ((ps.d.D + 2 * ps.d.pd - 2 + ps.tile - 1) / ps.tile) * ((ps.d.H + 2 * ps.d.ph - 2 + ps.tile - 1) / ps.tile);
           int32_t zo_d, zo_h, zo;
@@ -1410,7 +1462,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           io.out_scale = scalep(s.out);
           io.amax_in = slotp(s.in); io.amax_res = slotp(s.res); io.amax_out = slotp(s.out);
           io.wbound = L.wbound; io.sbound = L.sbound;
-          M_TRY(ivx_conv_fwd_pio(&ps.d, &io, ptr(s.in), L.wpair, L.scale_p, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
+          M_TRY(ivx_conv_fwd_pio(&ps.d, &io, ptr(s.in), L.wpair, L.scale_p, L.shift, res, ptr(s.out), cws, pl.ws_bytes, cst));
         } else if (ps.tile) {
           M_TRY(ivx_conv_winograd_input_amax(&ps.d, ps.tile, ptr(s.in), ws, pl.ws_bytes, ps.amax_in >= 0 ? (const float *)(base + ps.amax_in) : nullptr,
                                              ps.amax_in_n, st));
@@ -1418,13 +1470,14 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           M_TRY(ivx_conv_winograd_output_amax(&ps.d, ps.tile, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes,
                                               ps.amax_out >= 0 ? (float *)(base + ps.amax_out) : nullptr, st));
         } else if (m->fp8_on && L.fp8_role) {
-          M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.fp8_role >= 2 ? L.wq : L.w, L.scale_q, L.shift_q, res, ptr(s.out), ws, pl.ws_bytes, st));
+          M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.fp8_role >= 2 ? L.wq : L.w, L.scale_q, L.shift_q, res, ptr(s.out), cws, pl.ws_bytes, cst));
         } else {
-          M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.w, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes, st));
+          M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.w, L.scale, L.shift, res, ptr(s.out), cws, pl.ws_bytes, cst));
           if (m->calib_dev && (L.fp8_role == 1 || L.fp8_role == 2))       // calibration pass: max |output| of the tensors that will be e4m3
             M_TRY(ivx_amax_bf16(ptr(s.out), o.elems(), m->calib_dev + s.layer, st));
         }
         M_TRY(trace_end(m, st));
+        if (cst != st) M_HIP(hipEventRecord(m->ev_join[ps.side - 1], cst), "hipEventRecord");
         break;
       }
       case ST_LIFT: {
@@ -1584,6 +1637,9 @@ extern "C" int ivx_destroy(ivx_model *m) {
   if (!m) return IVX_OK;
   for (void *p : m->owned) (void)hipFree(p);
   for (hipEvent_t e : m->event_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : m->ev_join) (void)hipEventDestroy(e);
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  if (m->side) (void)hipStreamDestroy(m->side);
   delete m;
   return IVX_OK;
 }

@@ -323,8 +323,18 @@ class ImVoxelNet(nn.Module):
         on the host from it."""
         from .boxes import LiDARInstance3DBoxes, DepthInstance3DBoxes
         from .dist import pack_detections, unpack_detections
-        packed = pack_detections(boxes, scores, labels, count).cpu()         # the one sync of the step
-        b, s, l, c = unpack_detections(packed, scores.shape[1])
+        blk = getattr(boxes, 'ivx_block', None)
+        if blk is not None:          # the native handle wrote the four tensors into one allocation (engine.NativeModel.detect): one copy, no packing kernels
+            block, M, o_s, o_l, o_c = blk
+            B = boxes.shape[0]
+            h = block.cpu()                                                  # the one sync of the step
+            b = h[:o_s].view(torch.float32).view(B, M, 7)
+            s = h[o_s:o_s + B * M * 4].view(torch.float32).view(B, M)
+            l = h[o_l:o_l + B * M * 8].view(torch.int64).view(B, M)
+            c = h[o_c:o_c + B * 4].view(torch.int32)
+        else:
+            packed = pack_detections(boxes, scores, labels, count).cpu()     # the one sync of the step
+            b, s, l, c = unpack_detections(packed, scores.shape[1])
         res = []
         for i, meta in enumerate(img_metas):
             n = int(c[i])

@@ -254,8 +254,15 @@ class NativeModel:
             check(-1, 'ivx_model_detect_workspace_bytes')
         ws = self._workspace('fwd', n)
         dev = x.device
-        out = (torch.empty((B, M, 7), device=dev, dtype=torch.float32), torch.empty((B, M), device=dev, dtype=torch.float32),
-               torch.empty((B, M), device=dev, dtype=torch.int64), torch.empty((B,), device=dev, dtype=torch.int32))
+        # the four caller-owned detection buffers as views of ONE allocation: the host side of simple_test copies that block back in one
+        # D2H transfer without packing kernels (detector._results_one_copy; round 6: the torch.cat / cast launches were ~40 us of a 15 ms step)
+        n_b, n_s, n_l = B * M * 7 * 4, B * M * 4, B * M * 8
+        o_s, o_l, o_c = n_b, (n_b + n_s + 7) // 8 * 8, 0
+        o_c = o_l + n_l
+        block = torch.empty((o_c + B * 4,), device=dev, dtype=torch.uint8)
+        out = (block[:n_b].view(torch.float32).view(B, M, 7), block[o_s:o_s + n_s].view(torch.float32).view(B, M),
+               block[o_l:o_l + n_l].view(torch.int64).view(B, M), block[o_c:o_c + B * 4].view(torch.int32).view(B))
+        out[0].ivx_block = (block, M, o_s, o_l, o_c)
         valid = torch.empty((B,) + self.n_voxels, device=dev, dtype=torch.uint8) if want_valid else None
         ang = torch.empty((B, 2), dtype=torch.float32) if self.layout else None
         lay = torch.empty((B, 7), dtype=torch.float32) if self.layout else None

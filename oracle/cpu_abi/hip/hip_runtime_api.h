@@ -41,6 +41,13 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t st) {
   return hipSuccess;
 }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
+/* side streams of the step interpreter (csrc/model.cpp: the shortcut convs overlap conv1 / conv2): on the host everything runs in program order */
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags) { (void)flags; *st = (hipStream_t)1; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t st) { (void)st; return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned flags) { (void)st; (void)e; (void)flags; return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags) { (void)flags; return hipEventCreate(e); }
 static inline hipError_t hipStreamBeginCapture(hipStream_t st, hipStreamCaptureMode m) { (void)st; (void)m; return hipErrorNotSupported; }
 static inline hipError_t hipStreamEndCapture(hipStream_t st, hipGraph_t *g) { (void)st; *g = NULL; return hipErrorNotSupported; }
 static inline hipError_t hipGraphInstantiate(hipGraphExec_t *x, hipGraph_t g, void *a, void *b, size_t n) { (void)g; (void)a; (void)b; (void)n; *x = NULL; return hipErrorNotSupported; }
