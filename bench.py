@@ -156,7 +156,7 @@ def bench_other(args, ia, kc, dev, rank, world, emit=True):
     if args.trunk_fp8:
         if args.storage != 'bf16':
             raise SystemExit('--trunk-fp8 goes on top of --storage bf16 (BASELINE config 5: "bf16 with fp8 2D-conv MFMA")')
-        model.calibrate_fp8(img, stages=args.fp8_stages, residual=args.fp8_residual)   # one bf16 pass over the batch: per-tensor activation scales
+        model.calibrate_fp8(img, stages=args.fp8_stages, residual=args.fp8_residual, variant=args.fp8_variant)   # one bf16 pass over the batch: per-tensor activation scales
         fp8_note = ('ResNet-50 %s stored as e4m3 (calibrated per-tensor / per-channel scales; stages: %s; residual stream: %s), v_mfma_f32_32x32x16_fp8_fp8'
                     % ('activations and weights' if args.fp8_residual == 'fp8' else 'bottleneck interiors (conv1 / conv2 outputs, conv2 / conv3 weights)',
                        'all' if args.fp8_stages is None else args.fp8_stages, args.fp8_residual))
@@ -434,6 +434,7 @@ def main():
                          "configs: the views of each scene are split over the ranks, one RCCL all-reduce of the partial volume; strong scaling)")
     ap.add_argument('--fp8-stages', type=int, default=None, help='--trunk-fp8: how many leading ResNet stages store e4m3 (default: all four)')
     ap.add_argument('--fp8-residual', default='bf16', choices=['bf16', 'fp8'], help="--trunk-fp8: 'bf16' (default) keeps the residual stream in bf16 and stores the bottleneck interiors as e4m3; 'fp8' stores every trunk activation as e4m3 (bandwidth stress mode, ~10 %% feature noise)")
+    ap.add_argument('--fp8-variant', default='conv3', choices=['conv3', 'full'], help="--trunk-fp8: 'conv3' (default) = e4m3 on conv3 of ResNet stages 3 - 4 only (FPN within ~2.2 %% of fp32); 'full' = every bottleneck interior e4m3 (3.6 %%)")
     ap.add_argument('--trunk-fp8', action='store_true', help='with --storage bf16 and an indoor --config: e4m3 storage of the 2-D trunk (calibrated on the bench batch)')
     ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
                     help='f32 (default) = the reference precision and the headline metric; bf16 = optional reduced-precision '

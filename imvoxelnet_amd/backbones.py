@@ -36,7 +36,7 @@ class _Bottleneck(nn.Module):
         else:
             self.downsample = None
 
-    def prepare(self, device, in_dtype=None, stream_dtype=None, chain=False):
+    def prepare(self, device, in_dtype=None, stream_dtype=None, chain=False, conv2_bf16=False):
         """in_dtype: storage type of the block's INPUT when it differs from the block's own (the first bf16 block after the e4m3
         stages of the fp8 trunk): conv1 and the shortcut conv read it.
         stream_dtype (fp8 trunk, residual='bf16'): storage type of the RESIDUAL STREAM -- the block's input, its shortcut and its
@@ -49,7 +49,11 @@ class _Bottleneck(nn.Module):
         # style='pytorch': the stride sits on the 3x3 conv
         # chain (fp32 storage with FusedConv.trunk_operands == 4): the block's activations as fp16-pair tensors (ops.PairTensor)
         chain = bool(chain) and sd == torch.float32 and xd == torch.float32 and od == torch.float32
-        self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2, dtype=xd, out_dtype=sd, chain=chain).to(device)
+        # conv2_bf16 (fp8 trunk with a bf16 residual stream, detector.calibrate_fp8(variant='conv3')): conv1 and conv2 stay bf16 convolutions, conv2
+        # WRITES e4m3 and only conv3 reads e4m3 activations and filters (csrc/model.cpp ivx_model_calibrate_fp8_ex, conv2_bf16 = 1)
+        c3_only = bool(conv2_bf16) and stream_dtype is not None and sd != stream_dtype and not self.dcn
+        mid = stream_dtype if c3_only else sd          # storage type of conv1's output and of conv2's input / filters
+        self.f1 = FusedConv(self.conv1.weight, bn=self.bn1.tensors(), relu=True, dims=2, dtype=xd, out_dtype=mid, chain=chain).to(device)
         if self.dcn:
             if sd != torch.float32:
                 raise NotImplementedError('the DCNv2 stages are built for float32 storage only')
@@ -63,7 +67,8 @@ class _Bottleneck(nn.Module):
             w_col = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1, 1, 1)
             self.f2 = FusedConv(w_col, bn=self.bn2.tensors(), relu=True, dims=2, chain=chain).to(device)
         else:
-            self.f2 = FusedConv(self.conv2.weight, bn=self.bn2.tensors(), stride=self.stride, padding=1, relu=True, dims=2, chain=chain).to(device)
+            self.f2 = FusedConv(self.conv2.weight, bn=self.bn2.tensors(), stride=self.stride, padding=1, relu=True, dims=2, chain=chain,
+                                dtype=mid if c3_only else None, out_dtype=sd if c3_only else None).to(device)
         self.f3 = FusedConv(self.conv3.weight, bn=self.bn3.tensors(), relu=True, dims=2, dtype=sd, out_dtype=od, chain=chain).to(device)  # relu after the add
         self.fd = None
         if self.downsample is not None:
@@ -227,12 +232,14 @@ class ResNet(nn.Module):
         n8 = 0 if not fp8 else (self.num_stages if n_req is None else max(0, min(int(n_req), self.num_stages)))
         self.stage_dtypes = []
         prev = torch.bfloat16 if res_bf16 else current_storage_dtype()
+        first8 = int(getattr(self, 'fp8_first_stage', 0) or 0) if res_bf16 else 0      # stages below it keep plain bf16 bottlenecks
+        c3_only = res_bf16 and getattr(self, 'fp8_variant', 'full') == 'conv3'
         for i in range(self.num_stages):
-            sd = current_storage_dtype() if not fp8 else (FP8 if i < n8 else torch.bfloat16)
+            sd = current_storage_dtype() if not fp8 else (FP8 if (i < n8 and i >= first8) else torch.bfloat16)
             with storage_dtype(sd):
                 for j, blk in enumerate(getattr(self, f'layer{i + 1}')):
                     if res_bf16:
-                        blk.prepare(device, stream_dtype=torch.bfloat16 if sd == FP8 else None)
+                        blk.prepare(device, stream_dtype=torch.bfloat16 if sd == FP8 else None, conv2_bf16=c3_only)
                     else:
                         blk.prepare(device, in_dtype=prev if (j == 0 and prev != sd) else None, chain=self.chain)
             self.stage_dtypes.append(torch.bfloat16 if res_bf16 else sd)

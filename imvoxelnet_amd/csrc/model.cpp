@@ -121,6 +121,8 @@ struct ConvLayer {
   // e4m3 interior of the bottlenecks (ivx_model_calibrate_fp8 on a bf16 handle): 1 conv1 (bf16 in, e4m3 out), 2 conv2 (e4m3 in / filters /
   // out), 3 conv3 (e4m3 in / filters, bf16 out + bf16 shortcut); 0: not part of it
   int fp8_role = 0;
+  int stage = -1;                     // ResNet stage (0 .. 3) of a bottleneck conv, else -1
+  int fp8_eff = 0;                    // the role in effect after ivx_model_calibrate_fp8[_ex] (variant / first stage applied to fp8_role)
   std::vector<float> w_tap, scale_h, shift_h;   // roles 2 / 3: the fp32 filters (tap-major) kept for the quantisation; the epilogue vectors of every role
   float *wq = nullptr, *scale_q = nullptr, *shift_q = nullptr;
   int layout_q = 0;
@@ -295,6 +297,7 @@ void build_trunk(ivx_model *m) {
         idt = add_conv(m, conv2d(pre + "downsample", cin, planes * 4, 1, stride, 0, false, pre + "downsample.0.weight", "", pre + "downsample.1"), x);
       ConvLayer c1 = conv2d(pre + "conv1", cin, planes, 1, 1, 0, true, pre + "conv1.weight", "", pre + "bn1");
       c1.fp8_role = (bf16 && !m->cfg.dcn_stages[i]) ? 1 : 0;
+      c1.stage = i;
       int y = add_conv(m, c1, x);
       if (m->cfg.dcn_stages[i]) {
         // ModulatedDeformConv2dPack (mmcv; configs/imvoxelnet/imvoxelnet_nuscenes.py:13-14): conv_offset (3x3, bias) -> 27 raw channels,
@@ -311,10 +314,12 @@ void build_trunk(ivx_model *m) {
       } else {
         ConvLayer c2 = conv2d(pre + "conv2", planes, planes, 3, stride, 1, true, pre + "conv2.weight", "", pre + "bn2");
         c2.fp8_role = bf16 ? 2 : 0;
+        c2.stage = i;
         y = add_conv(m, c2, y);
       }
       ConvLayer c3 = conv2d(pre + "conv3", planes, planes * 4, 1, 1, 0, true, pre + "conv3.weight", "", pre + "bn3");
       c3.fp8_role = (bf16 && !m->cfg.dcn_stages[i]) ? 3 : 0;
+      c3.stage = i;
       x = add_conv(m, c3, y, idt, 1);
       cin = planes * 4;
     }
@@ -780,10 +785,10 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
   if (m->cfg.storage == IVX_BF16) {   // bf16 storage: the direct kernel on bf16 operands, fp32 accumulate; the head convs write fp32
     d.in_dtype = IVX_BF16;
     d.out_dtype = L.out_f32 ? IVX_F32 : IVX_BF16;
-    if (m->fp8_on && L.fp8_role) {    // e4m3 interior of a bottleneck: tensor scales are folded into scale_q / shift_q
-      d.in_dtype = L.fp8_role == 1 ? IVX_BF16 : IVX_FP8;
-      d.out_dtype = L.fp8_role == 3 ? IVX_BF16 : IVX_FP8;
-      if (L.fp8_role >= 2) d.wgt_layout = L.layout_q;
+    if (m->fp8_on && L.fp8_eff) {     // e4m3 interior of a bottleneck: tensor scales are folded into scale_q / shift_q
+      d.in_dtype = L.fp8_eff == 1 ? IVX_BF16 : IVX_FP8;
+      d.out_dtype = L.fp8_eff == 3 ? IVX_BF16 : IVX_FP8;
+      if (L.fp8_eff >= 2) d.wgt_layout = L.layout_q;
       d.res_scale = 1.0f;
     }
   }
@@ -1005,7 +1010,7 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
     }
     if (s.kind != ST_CONV && s.kind != ST_MAXPOOL && s.kind != ST_IMG2CL && s.kind != ST_DCN_COL) { o.fmt = 0; o.slot = -1; }   // (`o = in` above copies the input's)
     o.esz = (s.kind == ST_CONV && m->layers[s.layer].out_f32) ? 4 : esz;
-    if (s.kind == ST_CONV && m->fp8_on && (m->layers[s.layer].fp8_role == 1 || m->layers[s.layer].fp8_role == 2)) o.esz = 1;
+    if (s.kind == ST_CONV && m->fp8_on && (m->layers[s.layer].fp8_eff == 1 || m->layers[s.layer].fp8_eff == 2)) o.esz = 1;
     o.bytes = align256(o.elems() * o.esz);
     o.first = i;
     pl->t[s.out] = o;
@@ -1469,11 +1474,11 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           M_TRY(ivx_conv_winograd_gemm(&ps.d, ps.tile, L.u.at(ps.tile * 8 + ps.d.wino_operands), ws, pl.ws_bytes, st));
           M_TRY(ivx_conv_winograd_output_amax(&ps.d, ps.tile, L.scale, L.shift, res, ptr(s.out), ws, pl.ws_bytes,
                                               ps.amax_out >= 0 ? (float *)(base + ps.amax_out) : nullptr, st));
-        } else if (m->fp8_on && L.fp8_role) {
-          M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.fp8_role >= 2 ? L.wq : L.w, L.scale_q, L.shift_q, res, ptr(s.out), cws, pl.ws_bytes, cst));
+        } else if (m->fp8_on && L.fp8_eff) {
+          M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.fp8_eff >= 2 ? L.wq : L.w, L.scale_q, L.shift_q, res, ptr(s.out), cws, pl.ws_bytes, cst));
         } else {
           M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.w, L.scale, L.shift, res, ptr(s.out), cws, pl.ws_bytes, cst));
-          if (m->calib_dev && (L.fp8_role == 1 || L.fp8_role == 2))       // calibration pass: max |output| of the tensors that will be e4m3
+          if (m->calib_dev && (L.fp8_eff == 1 || L.fp8_eff == 2))       // calibration pass: max |output| of the tensors that will be e4m3
             M_TRY(ivx_amax_bf16(ptr(s.out), o.elems(), m->calib_dev + s.layer, st));
         }
         M_TRY(trace_end(m, st));
@@ -1800,11 +1805,24 @@ inline uint8_t f32_to_e4m3_bits(float f) {
 
 extern "C" int ivx_model_calibrate_fp8(ivx_model *m, const float *img, int32_t BV, int32_t H, int32_t W, float margin, void *workspace,
                                        int64_t workspace_bytes, ivx_stream_t stream) {
+  return ivx_model_calibrate_fp8_ex(m, img, BV, H, W, margin, 0, 0, workspace, workspace_bytes, stream);
+}
+
+// first_stage: ResNet stages below it keep plain bf16 bottlenecks; conv2_bf16: conv1 and conv2 stay bf16 convolutions, conv2 WRITES e4m3 and only
+// conv3 runs on the fp8 matrix cores (e4m3 input + e4m3 filters).  (2, 1) is the variant the noise budget prices at ~2.1 % of FPN level 0
+// (tools/fp8_noise_budget.py, profiles/r06_config5.md); (0, 0) the round-3 mode (every interior tensor and both filter banks e4m3: 3.6 %).
+extern "C" int ivx_model_calibrate_fp8_ex(ivx_model *m, const float *img, int32_t BV, int32_t H, int32_t W, float margin, int32_t first_stage,
+                                          int32_t conv2_bf16, void *workspace, int64_t workspace_bytes, ivx_stream_t stream) {
   M_TRY(check_img(m, BV, 1, H, W, "ivx_model_calibrate_fp8"));
-  M_REQUIRE(img && margin > 0.f, "ivx_model_calibrate_fp8: bad argument");
+  M_REQUIRE(img && margin > 0.f && first_stage >= 0 && first_stage <= 4, "ivx_model_calibrate_fp8: bad argument");
   M_REQUIRE(m->cfg.storage == IVX_BF16 && m->cfg.with_trunk, "ivx_model_calibrate_fp8: needs a handle with storage = IVX_BF16 and the 2-D trunk");
   hipStream_t st = (hipStream_t)stream;
   m->fp8_on = false;                         // a second calibration starts from the bf16 trunk again
+  for (ConvLayer &L : m->layers) {
+    L.fp8_eff = 0;
+    if (!L.fp8_role || L.stage < first_stage) continue;
+    L.fp8_eff = !conv2_bf16 ? L.fp8_role : (L.fp8_role == 1 ? 0 : (L.fp8_role == 2 ? 1 : 3));
+  }
   m->plans.clear();
   Plan *pl;
   M_TRY(plan_trunk(m, BV, H, W, &pl, st));
@@ -1827,13 +1845,13 @@ extern "C" int ivx_model_calibrate_fp8(ivx_model *m, const float *img, int32_t B
   double s_prev = 1.0;                       // scale of the e4m3 tensor the next layer of the block reads
   for (size_t li = 0; li < nl; ++li) {
     ConvLayer &L = m->layers[li];
-    if (!L.fp8_role) continue;
-    const double s_in = L.fp8_role == 1 ? 1.0 : s_prev;
-    const double s_out = L.fp8_role == 3 ? 1.0 : std::max((double)amax[li], 1e-12) * (double)margin / 448.0;
+    if (!L.fp8_eff) continue;
+    const double s_in = L.fp8_eff == 1 ? 1.0 : s_prev;
+    const double s_out = L.fp8_eff == 3 ? 1.0 : std::max((double)amax[li], 1e-12) * (double)margin / 448.0;
     L.out_scale_q = s_out;
     const int taps = L.k[0] * L.k[1] * L.k[2];
     std::vector<float> ws_(L.cout, 1.0f);
-    if (L.fp8_role >= 2) {
+    if (L.fp8_eff >= 2) {
       M_REQUIRE(L.cin_pad % 16 == 0 && !L.w_tap.empty(), "ivx_model_calibrate_fp8: layer %s: e4m3 filters need Cin %% 16 == 0", L.name.c_str());
       const size_t per = (size_t)taps * L.cin_pad, n_w = per * L.cout;
       L.layout_q = L.cin_pad % 128 == 0 ? 1 : 0;

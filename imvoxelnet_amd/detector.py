@@ -91,7 +91,7 @@ class ImVoxelNet(nn.Module):
             self._native = engine.NativeModel(self, device)
         return self
 
-    def calibrate_fp8(self, img, margin=1.0, stages=None, residual='bf16'):
+    def calibrate_fp8(self, img, margin=1.0, stages=None, residual='bf16', variant='conv3'):
         """Optional, on top of prepare(device, dtype=torch.bfloat16) (BASELINE config 5: "bf16 with fp8 2D-conv MFMA"): store
         the 2-D trunk's activations and weights as OCP e4m3 bytes.  One bf16 pass over `img` ([B,V,3,H,W] or [N,3,H,W], a
         representative batch) records max |output| of every trunk layer; the layers are then rebuilt with per-tensor activation
@@ -101,6 +101,10 @@ class ImVoxelNet(nn.Module):
         bf16 and stores only the inside of each bottleneck (conv1 / conv2 outputs, all conv weights of conv2 / conv3) as e4m3, so
         the rounding noise of a block does not ride on through the later ones (FPN level 0 within a few % rms of fp32);
         'fp8' stores every trunk activation as e4m3 (half the bf16 traffic; FPN level 0 ~10 % rms away: a bandwidth stress mode).
+        variant (residual='bf16' only): 'conv3' (default since round 6) = e4m3 only where the noise budget allows it -- in ResNet stages 3 and 4
+        conv2 writes e4m3 and conv3 runs on the fp8 matrix cores (e4m3 input and filters), everything else stays bf16: FPN level 0 within
+        ~2.2 % rms of the fp32 oracle (tools/fp8_noise_budget.py, profiles/r06_config5.md); 'full' = the round-3 mode, every bottleneck's
+        conv1 / conv2 outputs and conv2 / conv3 filters e4m3 in all four stages (3.6 %).
         Weights loaded afterwards need a new calibration.  Returns {layer key: amax}."""
         from .conv import FusedConv, storage_dtype, FP8
         if self._prepared_device is None or self.storage_dtype != torch.bfloat16:
@@ -120,6 +124,11 @@ class ImVoxelNet(nn.Module):
             if residual not in ('bf16', 'fp8'):
                 raise ValueError("residual must be 'bf16' or 'fp8'")
             self.backbone.fp8_residual = residual
+            if variant not in ('conv3', 'full'):
+                raise ValueError("variant must be 'conv3' or 'full'")
+            c3 = variant == 'conv3' and residual == 'bf16' and stages is None
+            self.backbone.fp8_variant = 'conv3' if c3 else 'full'
+            self.backbone.fp8_first_stage = 2 if c3 else 0
             with storage_dtype(FP8):
                 self.backbone.prepare(dev)
             with storage_dtype(torch.bfloat16):
@@ -131,7 +140,7 @@ class ImVoxelNet(nn.Module):
         if self._native is not None:
             if residual == 'bf16' and stages is None and self._native.cfg.with_trunk:
                 try:
-                    self._native.calibrate_fp8(x, margin)     # the same mode inside the native handle (its own calibration pass: same maxima)
+                    self._native.calibrate_fp8(x, margin, first_stage=2 if c3 else 0, conv2_bf16=c3)     # the same mode inside the native handle (its own calibration pass: same maxima)
                 except ValueError as e:      # the library's invalid-argument status only; a HIP error / OOM (IvxError) propagates (round-5 advisor)
                     # (e.g. calibration images whose H / W are not multiples of 32: ivx_model_calibrate_fp8 refuses them.)  The Python
                     # modules are e4m3 already; a handle left in bf16 would make simple_test run ANOTHER mode than extract_feat without a

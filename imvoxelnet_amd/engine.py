@@ -306,7 +306,7 @@ class NativeModel:
         check(fn(self.h, C.c_void_p(volume.data_ptr()), B, ptrs, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), 'ivx_neck3d_levels_fwd')
         return outs
 
-    def calibrate_fp8(self, img, margin=1.0):
+    def calibrate_fp8(self, img, margin=1.0, first_stage=0, conv2_bf16=False):
         """bf16 handle: one bf16 pass of the trunk over img [BV,3,H,W] fp32 records the maxima of the bottleneck interiors, which are
         stored as e4m3 from then on (ivx_model_calibrate_fp8: BASELINE config 5's "bf16 with fp8 2-D conv MFMA" inside the C-ABI)."""
         BV, _, H, W = img.shape
@@ -314,8 +314,8 @@ class NativeModel:
         if n < 0:
             check(-1, 'ivx_backbone_fpn_workspace_bytes')
         ws = self._workspace('trunk', n)
-        check(self.L.ivx_model_calibrate_fp8(self.h, C.c_void_p(img.data_ptr()), BV, H, W, float(margin), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
-              'ivx_model_calibrate_fp8')
+        check(self.L.ivx_model_calibrate_fp8_ex(self.h, C.c_void_p(img.data_ptr()), BV, H, W, C.c_float(float(margin)), int(first_stage), int(bool(conv2_bf16)),
+                                                C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), _stream()), 'ivx_model_calibrate_fp8_ex')
         self._ws = {}            # plans (and workspace sizes) are rebuilt on the next call
 
     # ------------------------------------------------------------------ sub-paths

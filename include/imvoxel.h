@@ -689,6 +689,11 @@ int ivx_model_detect(ivx_model *m, const float *img, int32_t B, int32_t V, int32
  * reduction it uses (out: device float, zeroed by the caller). */
 int ivx_model_calibrate_fp8(ivx_model *m, const float *img, int32_t BV, int32_t H, int32_t W, float margin, void *workspace,
                             int64_t workspace_bytes, ivx_stream_t stream);
+/* The same with the variant chosen: ResNet stages below first_stage (0 .. 4) keep plain bf16 bottlenecks; conv2_bf16 != 0: conv1 / conv2 stay bf16
+ * convolutions, conv2 writes e4m3 and only conv3 (e4m3 input and filters) runs on the fp8 matrix cores.  (2, 1): FPN level 0 within ~2.2 % rms of the fp32
+ * oracle (BASELINE config 5 "bf16 with fp8 2D-conv MFMA" at a usable accuracy); (0, 0) = ivx_model_calibrate_fp8 (3.6 %). */
+int ivx_model_calibrate_fp8_ex(ivx_model *m, const float *img, int32_t BV, int32_t H, int32_t W, float margin, int32_t first_stage, int32_t conv2_bf16,
+                               void *workspace, int64_t workspace_bytes, ivx_stream_t stream);
 int ivx_amax_bf16(const void *x, int64_t n, float *out, ivx_stream_t stream);
 
 /* Host-only LayoutHead arithmetic in a fixed fp32 order (both hosts of the library use it): angle = limit_period(raw) and layout =

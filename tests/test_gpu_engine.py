@@ -517,8 +517,8 @@ def test_c_program_e2e_indoor_bf16_storage_without_python(ia):
     assert 'C e2e_indoor OK (bf16 storage)' in out.stdout
 
 
-@pytest.mark.parametrize('cfg_name,views', [('scannet_v1', 6), ('scannet_fast', 4)])
-def test_native_config5_named_mode_equals_layerwise(ia, cfg_name, views):
+@pytest.mark.parametrize('cfg_name,views,variant', [('scannet_v1', 6, 'conv3'), ('scannet_fast', 4, 'conv3'), ('scannet_v1', 6, 'full')])
+def test_native_config5_named_mode_equals_layerwise(ia, cfg_name, views, variant):
     """BASELINE config 5's named mode -- bf16 storage with the fp8 2-D conv trunk (e4m3 bottleneck interiors, bf16 residual stream) --
     behind the C-ABI (ivx_model_cfg.storage = IVX_BF16 + ivx_model_calibrate_fp8): one native call against the layer-by-layer
     composition of ImVoxelNet.calibrate_fp8(residual='bf16'): the same calibration maxima, the same e4m3 filters and epilogue vectors,
@@ -536,12 +536,12 @@ def test_native_config5_named_mode_equals_layerwise(ia, cfg_name, views):
         model.bbox_head.reg_conv.weight.normal_(0, 0.002, generator=g)
     img = torch.randn(1, views, 3, *hw, generator=torch.Generator().manual_seed(9)).cuda()
     model.prepare(torch.device('cuda'), dtype=torch.bfloat16, native=False)
-    model.calibrate_fp8(img)
+    model.calibrate_fp8(img, variant=variant)      # 'conv3': e4m3 on conv3 of stages 3 - 4 only (round 6, the default); 'full': the round-3 mode
     assert model._native is None
     ref = model.simple_test(img, metas)
     fpn_ref = model.features_2d_cl(img).float()
     model.prepare(torch.device('cuda'), dtype=torch.bfloat16)
-    model.calibrate_fp8(img)
+    model.calibrate_fp8(img, variant=variant)
     assert model._native is not None and model._native.cfg.storage == 1
     fpn_nat = model._native.backbone_fpn(img.reshape(views, 3, *hw)).float()
     res = model.simple_test(img, metas)

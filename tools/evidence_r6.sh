@@ -25,6 +25,7 @@ for c in nuscenes scannet_v1; do IVX_FUSE_STEM=0 IVX_FUSE_BOTTLENECK=0 python be
 for c in nuscenes sunrgbd_fast scannet_fast scannet_v1; do python bench.py --config $c --steps 10 --warmup 3 --wino-operands f32 --trunk-operands f32 2>/dev/null | tail -1 >> $OUT/other_f32_operands.jsonl; done
 python bench.py --config scannet_v1 --steps 10 --warmup 3 --storage bf16 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl
 python bench.py --config scannet_v1 --steps 10 --warmup 3 --storage bf16 --trunk-fp8 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl
+python bench.py --config scannet_v1 --steps 10 --warmup 3 --storage bf16 --trunk-fp8 --fp8-variant full 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl
 # kernel traces
 trace() {   # name, steps-profiled, bench args...
   name=$1; nst=$2; shift 2

@@ -97,7 +97,14 @@ def main():
                 ('as built, stages 2-4 only', dict(base, x1=True, x2=True, w2=1, w3=1, stages={1, 2, 3})),
                 ('as built, stages 3-4 only', dict(base, x1=True, x2=True, w2=1, w3=1, stages={2, 3})),
                 ('two-term filters, stages 2-4 only', dict(base, x1=True, x2=True, w2=2, w3=2, stages={1, 2, 3})),
-                ('two-term filters, stages 3-4 only', dict(base, x1=True, x2=True, w2=2, w3=2, stages={2, 3}))]
+                ('two-term filters, stages 3-4 only', dict(base, x1=True, x2=True, w2=2, w3=2, stages={2, 3})),
+                # round 6: one-term candidates that need no second MFMA chain
+                ('as built, stage 4 only', dict(base, x1=True, x2=True, w2=1, w3=1, stages={3})),
+                ('x2, w3 (conv2 stays bf16), stages 2-4 only', dict(base, x2=True, w3=1, stages={1, 2, 3})),
+                ('x2, w3 (conv2 stays bf16), stages 3-4 only', dict(base, x2=True, w3=1, stages={2, 3})),
+                ('x1, w2 (conv3 stays bf16), stages 3-4 only', dict(base, x1=True, w2=1, stages={2, 3})),
+                ('x2 + two-term w3 (conv2 stays bf16), stages 2-4 only', dict(base, x2=True, w3=2, stages={1, 2, 3})),
+                ('x2 + two-term w3 (conv2 stays bf16), stages 3-4 only', dict(base, x2=True, w3=2, stages={2, 3}))]
         print(f'# e4m3 noise budget of the bottleneck interiors: FPN level-0 error / signal rms ({a.views} views 480x640, seed {a.seed}; torch-CPU fp32 emulation)')
         print('| e4m3 tensors | rms error / rms | max error / max |')
         print('|---|---|---|')
