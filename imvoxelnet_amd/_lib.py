@@ -80,7 +80,7 @@ class TraceRec(C.Structure):
                 ('bytes', C.c_double), ('name', C.c_char * 48)]
 
 
-EXPORTS = ['ivx_anchor_head_decode', 'ivx_fcos3d_head_decode', 'ivx_nms_rotated_bev', 'ivx_nms_aligned3d', 'ivx_bottleneck_supported', 'ivx_bottleneck_fwd_pio', 'ivx_amax_f32', 'ivx_stem_pool_filter_bytes', 'ivx_stem_pool_pack_filters', 'ivx_stem_pool_out_dims', 'ivx_stem_pool_fwd_pair', 'ivx_conv_winograd_set_variant', 'ivx_ubench_mfma', 'ivx_ubench_copy', 'ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws', 'ivx_conv_set_halo_mode', 'ivx_bf16_pair_split', 'ivx_f16_pair_split', 'ivx_conv_pair_supported', 'ivx_conv_pio_workspace_bytes', 'ivx_conv_fwd_pio', 'ivx_conv_fwd_pio_naive', 'ivx_pair_pack_filters', 'ivx_nchw_to_nhwc_amax', 'ivx_maxpool2d_fwd_pair', 'ivx_f16_pair_merge', 'ivx_model_calibrate_fp8', 'ivx_model_calibrate_fp8_ex', 'ivx_amax_bf16', 'ivx_conv_winograd_output_blocks', 'ivx_conv_winograd_issued_fraction', 'ivx_conv_winograd_output_amax', 'ivx_conv_winograd_input_amax', 'ivx_conv_winograd_fused_supported', 'ivx_conv_winograd_fused_blocks', 'ivx_conv_winograd_gemm_output_amax',
+EXPORTS = ['ivx_bottleneck_proj_supported', 'ivx_bottleneck_proj_pack', 'ivx_bottleneck_proj_fwd_pio', 'ivx_anchor_head_decode', 'ivx_fcos3d_head_decode', 'ivx_nms_rotated_bev', 'ivx_nms_aligned3d', 'ivx_bottleneck_supported', 'ivx_bottleneck_fwd_pio', 'ivx_amax_f32', 'ivx_stem_pool_filter_bytes', 'ivx_stem_pool_pack_filters', 'ivx_stem_pool_out_dims', 'ivx_stem_pool_fwd_pair', 'ivx_conv_winograd_set_variant', 'ivx_ubench_mfma', 'ivx_ubench_copy', 'ivx_version', 'ivx_last_error', 'ivx_conv_out_dims', 'ivx_conv_fwd', 'ivx_conv_fwd_naive', 'ivx_conv_set_tile_override', 'ivx_conv_set_epilogue_mode', 'ivx_conv_set_plan_mode', 'ivx_topk_set_mode', 'ivx_conv_workspace_bytes', 'ivx_conv_fwd_ws', 'ivx_conv_set_halo_mode', 'ivx_bf16_pair_split', 'ivx_f16_pair_split', 'ivx_conv_pair_supported', 'ivx_conv_pio_workspace_bytes', 'ivx_conv_fwd_pio', 'ivx_conv_fwd_pio_naive', 'ivx_pair_pack_filters', 'ivx_nchw_to_nhwc_amax', 'ivx_maxpool2d_fwd_pair', 'ivx_f16_pair_merge', 'ivx_model_calibrate_fp8', 'ivx_model_calibrate_fp8_ex', 'ivx_amax_bf16', 'ivx_conv_winograd_output_blocks', 'ivx_conv_winograd_issued_fraction', 'ivx_conv_winograd_output_amax', 'ivx_conv_winograd_input_amax', 'ivx_conv_winograd_fused_supported', 'ivx_conv_winograd_fused_blocks', 'ivx_conv_winograd_gemm_output_amax',
            'ivx_conv_winograd_supported', 'ivx_conv_winograd_weight_elems', 'ivx_conv_winograd_weights', 'ivx_conv_winograd_workspace_bytes',
            'ivx_conv_winograd_input', 'ivx_conv_winograd_gemm', 'ivx_conv_winograd_output', 'ivx_conv_winograd_fwd',
            'ivx_maxpool2d_fwd', 'ivx_maxpool2d_fwd_bf16', 'ivx_maxpool2d_fwd_fp8', 'ivx_global_avgpool_fwd', 'ivx_upsample_trilinear2x_fwd', 'ivx_dcn_im2col_fwd', 'ivx_dcn_im2col_fwd_pair', 'ivx_nchw_to_nhwc', 'ivx_image_s2d_bf16', 'ivx_nhwc_to_nchw', 'ivx_backproject_mean_fwd', 'ivx_backproject_mean_fwd_amax', 'ivx_backproject_amax_blocks', 'ivx_backproject_mean_fwd_bf16', 'ivx_upsample_trilinear2x_fwd_bf16', 'ivx_backproject_sum_fwd', 'ivx_volume_normalize_fwd',
@@ -137,6 +137,9 @@ def lib():
     L.ivx_stem_pool_fwd_pair.argtypes = [vp, i32, i32, i32, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
     L.ivx_bottleneck_supported.argtypes = [C.POINTER(BottleneckDesc)]
     L.ivx_bottleneck_fwd_pio.argtypes = [C.POINTER(BottleneckDesc), C.POINTER(BottleneckIO)] + [vp] * 12
+    L.ivx_bottleneck_proj_supported.argtypes = [C.POINTER(BottleneckDesc), i32]
+    L.ivx_bottleneck_proj_pack.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]
+    L.ivx_bottleneck_proj_fwd_pio.argtypes = [C.POINTER(BottleneckDesc), i32, C.POINTER(BottleneckIO), f32] + [vp] * 12
     L.ivx_conv_fwd_pio.argtypes = [C.POINTER(ConvDesc), C.POINTER(PairIO), vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.ivx_conv_fwd_pio_naive.argtypes = [C.POINTER(ConvDesc), C.POINTER(PairIO), vp, vp, vp, vp, vp, vp, vp]
     L.ivx_pair_pack_filters.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, C.POINTER(f32), C.POINTER(f32)]

@@ -76,6 +76,12 @@ class _Bottleneck(nn.Module):
                                 dtype=xd, out_dtype=od, chain=chain).to(device)
         elif in_dtype is not None and in_dtype != sd and stream_dtype is None:
             raise ValueError('a block without a shortcut conv keeps the storage type of its input')
+        # the first block of stage 1 in one launch (ops.bottleneck_proj_fwd_pio): conv3 + shortcut conv as one filter bank (csrc/model.cpp
+        # ivx_weights_finalize packs the same bank with the same function)
+        self.bank = None
+        if (chain and self.fd is not None and self.stride == 1 and not self.dcn and self.f3.pair_ok and self.fd.pair_ok and self.f3._w_tap_host is not None
+                and self.fd._w_tap_host is not None and self.f3.cin == 64 and self.fd.cin == 64):
+            self.bank = ops.ProjBank(self.f3, self.fd).to(device)
 
     def takes_pairs(self):
         """every layer that reads the block's INPUT has pair filters (csrc/model.cpp make_plan: wants_pair)"""
@@ -93,6 +99,8 @@ class _Bottleneck(nn.Module):
             else:
                 y = self.f2(y)
             return self.f3(y, res=idt)
+        if self.fuses_proj(x, out_pair):
+            return self._fused_proj(x)
         idt = x if self.fd is None else self.fd(x)                 # shortcut conv: fp32 out (only read as a residual), max |out| recorded
         if self.dcn:
             # conv1 feeds conv_offset and the column kernel: pairs when both can read them and the columns can be pairs too (wants_pair of
@@ -120,6 +128,30 @@ class _Bottleneck(nn.Module):
         return (_Bottleneck.fuse and self.fd is None and not self.dcn and self.stride == 1 and bool(out_pair) and isinstance(x, ops.PairTensor)
                 and self.f1.pair_ok and self.f2.pair_ok and self.f3.pair_ok and self.f1.cin == 4 * self.f1.cout and self.f3.cout == 4 * self.f1.cout
                 and x.shape[1] == 1 and ops.bottleneck_supported(x.shape[0], x.shape[2], x.shape[3], self.f1.cout))
+
+    def fuses_proj(self, x, out_pair):
+        """the first block of stage 1 (shortcut conv, stride 1, 64 -> 64 -> 64 -> 256) runs as ONE launch (ops.bottleneck_proj_fwd_pio) -- the rule of
+        csrc/model.cpp make_plan (fuse 5)"""
+        return (_Bottleneck.fuse and getattr(self, 'bank', None) is not None and bool(out_pair) and isinstance(x, ops.PairTensor)
+                and self.f1.pair_ok and self.f2.pair_ok and x.shape[1] == 1 and x.shape[4] == self.bank.cin
+                and ops.bottleneck_proj_supported(x.shape[0], x.shape[2], x.shape[3], self.f1.cout, x.shape[4]))
+
+    def _fused_proj(self, x):
+        tr = FusedConv.trace is not None
+        if tr:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        y = ops.bottleneck_proj_fwd_pio(x, self.f1, self.f2, self.bank)
+        P, ci = self.f1.cout, self.bank.cin
+        fl = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * (ci * P + 9.0 * P * P + 4.0 * P * P + 4.0 * P * ci)
+        if FusedConv.count_flops:
+            FusedConv.flops += fl
+            FusedConv.exec_flops += 3.0 * fl
+        if tr:
+            e1.record()
+            FusedConv.trace.append(('direct', e0, e1, 3.0 * fl, float(4 * x.numel() + 4 * y.numel()), False,
+                                    f'bottleneck {ci}->{P}->{P}->{4 * P} + shortcut conv in {tuple(x.shape[:4])} pair, one launch'))
+        return y
 
     def _fused(self, x):
         tr = FusedConv.trace is not None

@@ -236,11 +236,14 @@ class FusedConv:
         self.pair_ok = False
         self.wbound = self.sbound = None
         self._wpair_host = self._scale_p_host = self.wpair = self.scale_p = None
+        self._w_tap_host = None
         if chain and dtype == torch.float32 and out_dtype == torch.float32 and dims == 2 and type(self) is FusedConv:
             self.pair_ok = self.cin_pad == self.cin and self.cin % 32 == 0 and self.cout % 4 == 0
             taps = self.kernel[0] * self.kernel[1] * self.kernel[2]
             self._wpair_host, self._scale_p_host, self.wbound, self.sbound = ops.pair_pack_filters(
                 wp_tap.reshape(self.cout, taps, self.cin_pad), self._scale_host, self._shift_host, pack=self.pair_ok)
+            # 1x1 layers keep their fp32 filters on the host: conv3 + shortcut conv of a stage's first block are packed jointly (ops.bottleneck_proj_pack)
+            self._w_tap_host = wp_tap.reshape(self.cout, taps, self.cin_pad).contiguous() if taps == 1 else None
 
     def to(self, device):
         self.w = self._w_host.to(device)

@@ -21,6 +21,13 @@
 //   LDS swizzle of the pair tiles: a pixel row is 4P bytes (16-byte chunks [hi8 hi8 lo8 lo8] per 16 channels); chunk c of pixel (y, x) lies at
 //             c ^ (x & 15): the 16 lanes of one ds_read_b128 group hold 16 consecutive x (ds_read_b128 lane groups, MI355X guide), so every
 //             group reads 16 different 16-byte positions of the 256-byte bank window -- for every tap.
+//
+// CIN != 4P (round 6, second form): the FIRST block of ResNet stage 1 (layer1.0: CIN = P = 64, stride 1) whose shortcut is a 1x1 convolution + BN of the
+// block's input.  conv3 and the shortcut conv are ONE GEMM over K = CIN + P: the filter bank is [4P][x channels | mid2 channels] with both
+// BatchNorm scales folded into the filters on the host (ivx_bottleneck_proj_pack; the epilogue's multiplier is 1 / s_w, its shift shift3 + shiftd).
+// The A operand of the x part are the block's input at the tile's own pixels, read into registers from conv1's staged slabs at the end of phase 1
+// (K = 64: both slabs are resident); the two operand scales differ by a power of two: the accumulator is multiplied by rho = s2 / s_in between the
+// x slabs and the mid2 slabs.  No shortcut tensor exists: HBM carries the CIN-channel input (+ halo) and the 4P-channel output, once.
 #include "ivx_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,6 +46,7 @@ struct BnkParams {
   float *out_scale_p;                        // device: receives the scale of the output
   unsigned *amax_out;                        // device, IVX_AMAX_SLOTS words: max |out| (atomic max), or NULL
   float wb1, sb1, wb2, sb2, wb3, sb3;
+  float wbd;                                 // bound factor of the shortcut: 1 (identity) or max_n sum_k |scaled w_d| (projection)
   int B, H, W;
   int tiles_x, tiles_y, n_tiles, q_total;    // q_total: tiles per XCD (workgroup b runs on XCD b % 8 and owns tile (b % 8) * q_total + b / 8)
 #ifdef IVX_CONV_TIMELINE
@@ -97,11 +105,13 @@ __device__ __forceinline__ void bnk_swap2(const float ya, const float yb, const 
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
-template <int P, int NB1, int NB2, int NB3>
+template <int P, int CIN, int NB1, int NB2, int NB3>
 struct BnkCfg {
   static constexpr int C = 4 * P, NW = P / 16, NT = 64 * NW;
+  static constexpr bool PROJ = CIN != C;       // the shortcut is a 1x1 conv of the CIN-channel input (folded into conv3's filter bank)
   static constexpr int NQ = P / 32;            // 32-channel chunks of a P-channel tensor (K slabs of conv2 per tap / of conv3; 128-column units of conv3)
-  static constexpr int NQ1 = C / 32;           // K slabs of conv1
+  static constexpr int NQ1 = CIN / 32;         // K slabs of conv1
+  static constexpr int NQX = PROJ ? CIN / 32 : 0;   // K slabs of the shortcut conv in front of conv3's
   static constexpr int NTN = P / 32;           // 32-column tiles of a P-column GEMM
   static constexpr int PXB = 4 * P;            // bytes of one pixel of a pair tile
   static constexpr int M1 = 180, M1P = 192;
@@ -119,11 +129,14 @@ struct BnkCfg {
 
 
 
-template <int P, int NB1, int NB2, int NB3>
+template <int P, int CIN, int NB1, int NB2, int NB3>
 __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParams p, const unsigned in_bytes, const unsigned w1_bytes,
                                                                                  const unsigned w2_bytes, const unsigned w3_bytes) {
-  typedef BnkCfg<P, NB1, NB2, NB3> G;
+  typedef BnkCfg<P, CIN, NB1, NB2, NB3> G;
   constexpr int C = G::C, NW = G::NW, NQ = G::NQ, NQ1 = G::NQ1, NTN = G::NTN, PXB = G::PXB, RP = G::RP;
+  constexpr bool PROJ = G::PROJ;
+  constexpr int NQX = G::NQX;
+  static_assert(!PROJ || (P == 64 && NQ1 == NB1 && NB3 == 2), "projection form: P = 64, both conv1 slabs resident, two-slot conv3 ring");
   constexpr int AR = G::AR, BR1 = G::BR1, BR2 = G::BR2, BR3 = G::BR3;      // (local: arrays with these bounds are captured by the DMA lambdas)
   static_assert(P == 64 || P == 128, "planes");
   static_assert(G::LDS <= (P == 64 ? 81920 : 163840), "LDS budget");
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
     for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o));
     const float b1 = (a * p.wb1 + p.sb1) * 1.001f;
     const float b2 = (b1 * p.wb2 + p.sb2) * 1.001f;
-    const float b3 = (b2 * p.wb3 + p.sb3 + a) * 1.001f;
+    const float b3 = (b2 * p.wb3 + p.sb3 + a * p.wbd) * 1.001f;
     sat = !(b3 < 3.0e38f);
     s1 = sat ? 0.00390625f : ivx_pow2_scale(b1);
     s2 = sat ? 0.00390625f : ivx_pow2_scale(b2);
@@ -186,6 +199,8 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
   const int cc = (tid & 7) ^ ((lr >> 1) & 7);
   const int fsw = (rr >> 1) & 7;                        // fragment reads of the DMA-staged slabs undo it
 
+  // projection form: A fragments of the block's input at the tile's own pixels (row tiles 2 wm, 2 wm + 1 of phase 3), all K = CIN
+  f32x4 xf[PROJ ? 2 : 1][PROJ ? NQX : 1][4];
   // =========================================================================================== phase 1: conv1 over the haloed tile
   {
     unsigned a_off[AR];
@@ -195,7 +210,7 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
       const int hy = (r * 3641) >> 16, hx = r - hy * 18;     // r / 18, r % 18 (exact for r < 192)
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
       const bool ok = r < G::M1 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      a_off[j] = ok ? (unsigned)(((b * p.H + gy) * p.W + gx) * (4 * C) + cc * 16) : OOB;
+      a_off[j] = ok ? (unsigned)(((b * p.H + gy) * p.W + gx) * (4 * CIN) + cc * 16) : OOB;
     }
     unsigned b_off[BR1];
 #pragma unroll
@@ -251,6 +266,20 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
         }
       }
       cur = cur + 1 == NB1 ? 0 : cur + 1;
+    }
+    if constexpr (PROJ) {                                // slab q still lies in ring slot q (NQ1 == NB1: nothing was loaded over it)
+      const int wm3 = w >> 1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = (2 * wm3 + i) * 32 + rr;           // tile pixel (m >> 4, m & 15) = halo row ((m >> 4) + 1) * 18 + (m & 15) + 1
+        const int hr = ((m >> 4) + 1) * 18 + (m & 15) + 1;
+        const int key = (hr >> 1) & 7;
+#pragma unroll
+        for (int q = 0; q < NQX; ++q)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            xf[i][q][kk] = *reinterpret_cast<const f32x4 *>(smem + q * G::SL1 + hr * 128 + (((2 * kk + hh) ^ key) * 16));
+      }
     }
     __syncthreads();                                     // the conv1 ring is dead: mid1 and the conv2 ring take its place
 #ifdef IVX_CONV_TIMELINE
@@ -371,6 +400,152 @@ __global__ __launch_bounds__(P * 4, 2) void bottleneck_pio_kernel(const BnkParam
   }
 
   // =========================================================================================== phase 3: conv3 + shortcut, 128 columns at a time
+  if constexpr (PROJ) {
+    // conv3 and the shortcut conv as one GEMM: per unit of 128 output columns the slabs (x chunk 0 .. NQX - 1, mid2 chunk 0 .. NQ - 1) of the joint
+    // filter bank go through the two-slot ring; the x part's A fragments are registers (xf), the mid2 part's come from the LDS tile.
+#ifdef IVX_CONV_TIMELINE
+    tl2b = __builtin_amdgcn_s_memrealtime();
+#endif
+    constexpr int NQ3 = NQX + NQ, NU = C / 128, S3 = NU * NQ3, TN3 = 2;
+    static_assert(NQ3 % 2 == 0, "a unit's first slab lies in ring slot 0");
+    unsigned b_off[BR3];
+#pragma unroll
+    for (int j = 0; j < BR3; ++j) b_off[j] = (unsigned)((lr + RP * j) * NQ3 * 128 + cc * 16);
+    auto load3 = [&](const int s, const int buf) {
+      const int u = s / NQ3, q = s - u * NQ3;
+      unsigned char *Bb = smem + G::R3 + buf * G::SL3 + w * 1024;
+#pragma unroll
+      for (int j = 0; j < BR3; ++j) {
+        const unsigned vo = b_off[j] + (unsigned)((u * 128 * NQ3 + q) * 128);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (lds_ptr_t)(Bb + RP * j * 128), 16, vo, 0, 0, 0);
+      }
+    };
+    const int wm = w >> 1, wn = w & 1;
+    load3(0, 0);
+    f32x16 acc[2][TN3];
+    float *stage = reinterpret_cast<float *>(smem + G::ST3 + w * 2048);
+    const int rrow = lane >> 2, c8 = (lane & 3) * 8;
+    float omax = 0.f;
+    size_t poff[2][2];
+    bool pok[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int pr = (2 * wm + i) * 32 + hf * 16 + rrow;
+        const int gy = y0 + (pr >> 4), gx = x0 + (pr & 15);
+        pok[i][hf] = gy < p.H && gx < p.W;
+        poff[i][hf] = pok[i][hf] ? (((size_t)b * p.H + gy) * p.W + gx) * (size_t)(2 * C) : (size_t)0;
+      }
+    const float rho = s2 * inv_in;                       // x slabs accumulate in units of s_in s_w, mid2 slabs in units of s2 s_w
+    const float k_acc = s_out / s2;
+    auto epilogue3 = [&](const int u) {
+#pragma unroll
+      for (int j = 0; j < TN3; ++j) {
+        const int nb = u * 128 + (wn * TN3 + j) * 32 + c8;
+        const int coff = (nb >> 4) * 32 + (nb & 15);
+        const f32x4 sc0 = *reinterpret_cast<const f32x4 *>(prm + 4 * P + nb) * k_acc, sc1 = *reinterpret_cast<const f32x4 *>(prm + 4 * P + nb + 4) * k_acc;
+        const f32x4 sf0 = *reinterpret_cast<const f32x4 *>(prm + 8 * P + nb) * s_out, sf1 = *reinterpret_cast<const f32x4 *>(prm + 8 * P + nb + 4) * s_out;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+              const int rowh = (r8 & 3) + 8 * (r8 >> 2) + 4 * hh;
+              stage[rowh * 32 + ((((rr >> 2) ^ ((rowh >> 1) & 1)) << 2) | (rr & 3))] = acc[i][j][hf * 8 + r8];
+            }
+            const int sw = (rrow >> 1) & 1;
+            f32x4 v0 = *reinterpret_cast<const f32x4 *>(stage + rrow * 32 + (((c8 >> 2) ^ sw) << 2));
+            f32x4 v1 = *reinterpret_cast<const f32x4 *>(stage + rrow * 32 + ((((c8 >> 2) + 1) ^ sw) << 2));
+            if (pok[i][hf]) {
+              v0 = v0 * sc0 + sf0;
+              v1 = v1 * sc1 + sf1;
+              f16x8 oh, ol;
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) {
+                f32x2 x = {e < 4 ? v0[e & 3] : v1[e & 3], e < 4 ? v0[(e & 3) + 1] : v1[(e & 3) + 1]};
+                x[0] = __builtin_amdgcn_fmed3f(x[0], 0.f, 65504.f);
+                x[1] = __builtin_amdgcn_fmed3f(x[1], 0.f, 65504.f);
+                omax = fmaxf(omax, fmaxf(x[0], x[1]));
+                const f16x2 h = __builtin_convertvector(x, f16x2);
+                const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
+                oh[e] = h[0]; oh[e + 1] = h[1];
+                ol[e] = l[0]; ol[e + 1] = l[1];
+              }
+              *reinterpret_cast<f16x8 *>(p.out + poff[i][hf] + coff) = oh;
+              *reinterpret_cast<f16x8 *>(p.out + poff[i][hf] + coff + 16) = ol;
+            }
+          }
+        }
+      }
+    };
+    int s = 0;
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+      for (int q = 0; q < NQ3; ++q, ++s) {
+        bnk_wait_vm<0>();                                // slab s (and the stores of the previous unit's epilogue)
+        bnk_barrier();                                   // (first pass: also publishes mid2)
+        if (s + 1 < S3) load3(s + 1, (q & 1) ^ 1);
+        if (q == 0) {
+          if (u > 0) epilogue3(u - 1);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN3; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        if (q == NQX) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN3; ++j) acc[i][j] = acc[i][j] * rho;
+        }
+        const unsigned char *Bc = smem + G::R3 + (q & 1) * G::SL3 + (wn * TN3 * 32 + rr) * 128;
+        const unsigned char *Ac = smem + ((2 * wm) * 32 + rr) * PXB;
+        const int key = rr & 15;
+        f32x4 fa[2][2], fb[2][TN3];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int sl = kk & 1;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if (q < NQX) fa[sl][i] = xf[i][q < NQX ? q : 0][kk];
+            else fa[sl][i] = *reinterpret_cast<const f32x4 *>(Ac + i * 32 * PXB + ((((q - NQX) * 8 + 2 * kk + hh) ^ key) * 16));
+          }
+#pragma unroll
+          for (int j = 0; j < TN3; ++j) fb[sl][j] = *reinterpret_cast<const f32x4 *>(Bc + j * 4096 + (((2 * kk + hh) ^ fsw) * 16));
+          if (sl == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < TN3; ++j) acc[i][j] = bnk_mfma(fa[0][i], fb[0][j], acc[i][j]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < TN3; ++j) {
+                acc[i][j] = bnk_mfma(fa[0][i], fb[1][j], acc[i][j]);
+                acc[i][j] = bnk_mfma(fa[1][i], fb[0][j], acc[i][j]);
+              }
+          }
+        }
+      }
+    }
+#ifdef IVX_CONV_TIMELINE
+    tl3 = __builtin_amdgcn_s_memrealtime();
+#endif
+    epilogue3(NU - 1);
+    if (p.amax_out) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+      __syncthreads();
+      if (lane == 0) stage[0] = omax;
+      __syncthreads();
+      if (w == 0) ivx_amax_commit(p.amax_out, lane < NW ? reinterpret_cast<const float *>(smem + G::ST3)[lane * 512] * (1.0f / s_out) : 0.f, (int)blockIdx.x);
+    }
+  } else
   {
 #ifdef IVX_CONV_TIMELINE
     tl2b = __builtin_amdgcn_s_memrealtime();
@@ -570,6 +745,7 @@ extern "C" int ivx_bottleneck_fwd_pio(const ivx_bottleneck_desc *d, const ivx_bo
   p.sc1 = scale1; p.sh1 = shift1; p.sc2 = scale2; p.sh2 = shift2; p.sc3 = scale3; p.sh3 = shift3;
   p.in_scale_p = io->in_scale; p.amax_in = io->amax_in; p.out_scale_p = io->out_scale; p.amax_out = io->amax_out;
   p.wb1 = io->wbound[0]; p.sb1 = io->sbound[0]; p.wb2 = io->wbound[1]; p.sb2 = io->sbound[1]; p.wb3 = io->wbound[2]; p.sb3 = io->sbound[2];
+  p.wbd = 1.0f;
   p.B = d->B; p.H = d->H; p.W = d->W;
   p.tiles_x = (d->W + 15) / 16; p.tiles_y = (d->H + 7) / 8;
   p.n_tiles = d->B * p.tiles_x * p.tiles_y;
@@ -584,8 +760,48 @@ extern "C" int ivx_bottleneck_fwd_pio(const ivx_bottleneck_desc *d, const ivx_bo
   hipStream_t st = (hipStream_t)stream;
   // (measured and removed, profiles/r06_fused_bottleneck.md (c): conv2's filters straight from L2 into registers, in the chain's layout and in
   // fragment order -- no gain over the LDS ring)
-  if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 2, 3, 2>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
-  else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 3, 3, 2>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+  if (P == 64) hipLaunchKernelGGL((bottleneck_pio_kernel<64, 256, 2, 3, 2>), grid, dim3(256), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+  else hipLaunchKernelGGL((bottleneck_pio_kernel<128, 512, 3, 3, 2>), grid, dim3(512), 0, st, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
   IVX_CHECK_LAUNCH("ivx_bottleneck_fwd_pio");
+  return IVX_OK;
+}
+
+// ---- the first block of stage 1 (shortcut = 1x1 conv + BN of the input, stride 1): Cin = P = 64 -> 4P
+extern "C" int ivx_bottleneck_proj_supported(const ivx_bottleneck_desc *d, int32_t Cin) {
+  if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
+  if (d->P != 64 || Cin != 64) return 0;
+  if ((int64_t)d->B * d->H * d->W * d->P * 16 >= (1LL << 31)) return 0;      // the 4P-channel pair output below 2 GiB
+  return 1;
+}
+
+extern "C" int ivx_bottleneck_proj_fwd_pio(const ivx_bottleneck_desc *d, int32_t Cin, const ivx_bottleneck_io *io, float wbound_shortcut, const void *in,
+                                           const void *w1, const float *scale1, const float *shift1, const void *w2, const float *scale2,
+                                           const float *shift2, const void *w3d, const float *scale3d, const float *shift3d, void *out,
+                                           ivx_stream_t stream) {
+  IVX_REQUIRE(d && io && in && w1 && w2 && w3d && out && scale1 && shift1 && scale2 && shift2 && scale3d && shift3d, "ivx_bottleneck_proj_fwd_pio: null argument");
+  IVX_REQUIRE(ivx_bottleneck_proj_supported(d, Cin), "ivx_bottleneck_proj_fwd_pio: built for planes = Cin = 64 and a [B, H, W, 256] pair output below 2 GiB "
+              "(B %d H %d W %d planes %d Cin %d)", d->B, d->H, d->W, d->P, Cin);
+  IVX_REQUIRE(io->in_scale && io->amax_in && io->out_scale, "ivx_bottleneck_proj_fwd_pio: in_scale, amax_in and out_scale are required");
+  IVX_REQUIRE(wbound_shortcut >= 0.f, "ivx_bottleneck_proj_fwd_pio: negative shortcut bound");
+  BnkParams p;
+  p.in = (const _Float16 *)in; p.out = (_Float16 *)out;
+  p.w1 = (const _Float16 *)w1; p.w2 = (const _Float16 *)w2; p.w3 = (const _Float16 *)w3d;
+  p.sc1 = scale1; p.sh1 = shift1; p.sc2 = scale2; p.sh2 = shift2; p.sc3 = scale3d; p.sh3 = shift3d;
+  p.in_scale_p = io->in_scale; p.amax_in = io->amax_in; p.out_scale_p = io->out_scale; p.amax_out = io->amax_out;
+  p.wb1 = io->wbound[0]; p.sb1 = io->sbound[0]; p.wb2 = io->wbound[1]; p.sb2 = io->sbound[1]; p.wb3 = io->wbound[2]; p.sb3 = io->sbound[2];
+  p.wbd = wbound_shortcut;
+  p.B = d->B; p.H = d->H; p.W = d->W;
+  p.tiles_x = (d->W + 15) / 16; p.tiles_y = (d->H + 7) / 8;
+  p.n_tiles = d->B * p.tiles_x * p.tiles_y;
+  p.q_total = (p.n_tiles + 7) / 8;
+#ifdef IVX_CONV_TIMELINE
+  p.tl = g_bnk_timeline;
+#endif
+  const int P = d->P, C = 4 * P;
+  const unsigned in_bytes = (unsigned)((int64_t)d->B * d->H * d->W * Cin * 4);
+  const unsigned w1_bytes = (unsigned)(P * Cin * 4), w2_bytes = (unsigned)(P * 9 * P * 4), w3_bytes = (unsigned)(C * (Cin + P) * 4);
+  const dim3 grid((unsigned)(8 * p.q_total));
+  hipLaunchKernelGGL((bottleneck_pio_kernel<64, 64, 2, 3, 2>), grid, dim3(256), 0, (hipStream_t)stream, p, in_bytes, w1_bytes, w2_bytes, w3_bytes);
+  IVX_CHECK_LAUNCH("ivx_bottleneck_proj_fwd_pio");
   return IVX_OK;
 }

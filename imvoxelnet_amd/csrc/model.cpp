@@ -130,6 +130,12 @@ struct ConvLayer {
   bool pair_ok = false;
   float *wpair = nullptr, *scale_p = nullptr;
   float wbound = 0.f, sbound = 0.f;
+  // the first block of stage 1 in one launch (ivx_bottleneck_proj_fwd_pio): on conv3, the layer index of the block's shortcut conv and the joint filter
+  // bank of the two (ivx_bottleneck_proj_pack: BN scales folded into the filters, scale_proj = 1 / s_w, shift_proj = shift3 + shiftd) with its bound terms
+  int proj_peer = -1;
+  bool proj_keep = false;             // pack_layer keeps w_tap / scale_h / shift_h of this layer for the joint bank
+  float *wproj = nullptr, *scale_proj = nullptr, *shift_proj = nullptr;
+  float proj_wb3 = 0.f, proj_sb = 0.f, proj_wbd = 0.f;
   float *wstem = nullptr;             // the 7x7 stem in the pair chain: fragment-ordered pair filters of the one-launch stem (csrc/stem.hip); scale_p with them
 };
 
@@ -293,8 +299,14 @@ void build_trunk(ivx_model *m) {
       const std::string pre = "backbone.layer" + std::to_string(i + 1) + "." + std::to_string(j) + ".";
       const int stride = (j == 0 && i > 0) ? 2 : 1;
       int idt = x;
-      if (j == 0)
+      int ds_layer = -1;
+      if (j == 0) {
         idt = add_conv(m, conv2d(pre + "downsample", cin, planes * 4, 1, stride, 0, false, pre + "downsample.0.weight", "", pre + "downsample.1"), x);
+        ds_layer = (int)m->layers.size() - 1;
+      }
+      // candidate of the one-launch projection block (make_plan decides per shape): stride 1, Cin = planes = 64, no DCN, fp32 storage + pair chain
+      const bool proj_cand = j == 0 && stride == 1 && cin == 64 && planes == 64 && !bf16 && !m->cfg.dcn_stages[i] && m->cfg.trunk_operands == IVX_F16_PAIR;
+      if (proj_cand) m->layers[ds_layer].proj_keep = true;
       ConvLayer c1 = conv2d(pre + "conv1", cin, planes, 1, 1, 0, true, pre + "conv1.weight", "", pre + "bn1");
       c1.fp8_role = (bf16 && !m->cfg.dcn_stages[i]) ? 1 : 0;
       c1.stage = i;
@@ -320,6 +332,7 @@ void build_trunk(ivx_model *m) {
       ConvLayer c3 = conv2d(pre + "conv3", planes, planes * 4, 1, 1, 0, true, pre + "conv3.weight", "", pre + "bn3");
       c3.fp8_role = (bf16 && !m->cfg.dcn_stages[i]) ? 3 : 0;
       c3.stage = i;
+      if (proj_cand) { c3.proj_keep = true; c3.proj_peer = ds_layer; }
       x = add_conv(m, c3, y, idt, 1);
       cin = planes * 4;
     }
@@ -691,6 +704,11 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
     M_TRY(ivx_fold_batchnorm(g->data.data(), b->data.data(), mu->data.data(), var->data.data(), bias_in.data(), 1e-5f, n_aff, scale.data(),
                              shift.data()));
   }
+  if (L.proj_keep) {                 // kept for ivx_bottleneck_proj_pack (ivx_weights_finalize, after every layer is packed)
+    L.w_tap.assign(wp.begin(), wp.begin() + n_w);
+    L.scale_h = scale;
+    L.shift_h = shift;
+  }
   if (L.fp8_role) {                  // kept for ivx_model_calibrate_fp8
     if (L.fp8_role >= 2) L.w_tap.assign(wp.begin(), wp.begin() + n_w);
     L.scale_h = scale;
@@ -1040,9 +1058,40 @@ int make_plan(ivx_model *m, Range r, const std::map<int, TInfo> &inputs, int n_v
       if (!L.wstem || !pl->ps[i + 2].pio || pl->t[s0.out].slot < 0 || pl->t[s1.out].last != i + 2 || pl->t[s0.out].last != i + 1) continue;
       pl->ps[i].fuse = 3; pl->ps[i + 1].fuse = 2; pl->ps[i + 2].fuse = 4;
     }
+  // The first block of stage 1 (steps: shortcut conv, conv1, conv2, conv3 + shortcut) in one launch (ivx_bottleneck_proj_fwd_pio; backbones.py
+  // _Bottleneck.fuses_proj applies the same rule): the shortcut conv's step and conv2 / conv3 are skipped, conv1's step (fuse 5) runs the block; the
+  // shortcut tensor and the two intermediates stay unwritten.
+  if (pair_mode && fuse_on)
+    for (int i = std::max(r.s0, m->trunk0); i + 3 < std::min(r.s1, m->trunk1); ++i) {
+      const Step &sd = m->steps[i], &s1 = m->steps[i + 1], &s2 = m->steps[i + 2], &s3 = m->steps[i + 3];
+      if (sd.kind != ST_CONV || s1.kind != ST_CONV || s2.kind != ST_CONV || s3.kind != ST_CONV) continue;
+      const ConvLayer &Ld = m->layers[sd.layer], &L1 = m->layers[s1.layer], &L2 = m->layers[s2.layer], &L3 = m->layers[s3.layer];
+      if (!L3.wproj || L3.proj_peer != sd.layer) continue;
+      const TInfo &x = pl->t[sd.in], &yd = pl->t[sd.out], &y1 = pl->t[s1.out], &y2 = pl->t[s2.out], &o = pl->t[s3.out];
+      auto is1x1 = [](const ConvLayer &L) { return L.k[0] == 1 && L.k[1] == 1 && L.k[2] == 1 && L.s[1] == 1 && L.s[2] == 1 && L.p[1] == 0 && L.p[2] == 0; };
+      const int P = L1.cout;
+      if (!(pl->ps[i + 1].pio && pl->ps[i + 2].pio && pl->ps[i + 3].pio) || sd.res >= 0 || s1.res >= 0 || s2.res >= 0 || s1.in != sd.in || s2.in != s1.out ||
+          s3.in != s2.out || s3.res != sd.out || s3.res_mode != 1 || s3.res_after_act || s3.post_scale != 1.0f)
+        continue;
+      if (!is1x1(Ld) || !is1x1(L1) || !is1x1(L3) || !(L2.k[0] == 1 && L2.k[1] == 3 && L2.k[2] == 3 && L2.s[1] == 1 && L2.s[2] == 1 && L2.p[1] == 1 && L2.p[2] == 1) ||
+          L2.dcn_cols || Ld.relu || !L1.relu || !L2.relu || !L3.relu || L1.cin != Ld.cin || L2.cin != P || L2.cout != P || L3.cin != P || L3.cout != 4 * P ||
+          Ld.cout != 4 * P)
+        continue;
+      if (x.fmt != IVX_F16_PAIR || y1.fmt != IVX_F16_PAIR || y2.fmt != IVX_F16_PAIR || o.fmt != IVX_F16_PAIR || x.D != 1 || x.slot < 0 || o.slot < 0 ||
+          yd.last != i + 3 || y1.last != i + 2 || y2.last != i + 3)
+        continue;
+      ivx_bottleneck_desc bd = {x.B, x.H, x.W, P};
+      if (!ivx_bottleneck_proj_supported(&bd, L1.cin)) continue;
+      pl->ps[i].fuse = 2;
+      pl->ps[i + 1].fuse = 5; pl->ps[i + 1].fuse_out = s3.out;
+      pl->ps[i + 2].fuse = pl->ps[i + 3].fuse = 2;
+      pl->t[s3.out].first = i + 1;
+      i += 3;
+    }
   if (pair_mode && fuse_on)
     for (int i = std::max(r.s0, m->trunk0); i + 2 < std::min(r.s1, m->trunk1); ++i) {
       const Step &s1 = m->steps[i], &s2 = m->steps[i + 1], &s3 = m->steps[i + 2];
+      if (pl->ps[i].fuse || pl->ps[i + 1].fuse || pl->ps[i + 2].fuse) continue;
       if (s1.kind != ST_CONV || s2.kind != ST_CONV || s3.kind != ST_CONV) continue;
       const ConvLayer &L1 = m->layers[s1.layer], &L2 = m->layers[s2.layer], &L3 = m->layers[s3.layer];
       const TInfo &x = pl->t[s1.in], &y1 = pl->t[s1.out], &y2 = pl->t[s2.out], &o = pl->t[s3.out];
@@ -1315,6 +1364,9 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           if (ps.fuse == 1) {
             const ConvLayer &L2 = m->layers[m->steps[i + 1].layer], &L3 = m->layers[m->steps[i + 2].layer];
             span_bytes += tb(s.in) + tb(ps.fuse_out) + 4.0 * ((double)L.cout * L.cin + 9.0 * L2.cout * L2.cin + (double)L3.cout * L3.cin);
+          } else if (ps.fuse == 5) {
+            const ConvLayer &L2 = m->layers[m->steps[i + 1].layer], &L3 = m->layers[m->steps[i + 2].layer];
+            span_bytes += tb(s.in) + tb(ps.fuse_out) + 4.0 * ((double)L.cout * L.cin + 9.0 * L2.cout * L2.cin + (double)L3.cout * (L3.cin + L.cin));
           } else {
             span_bytes += tb(s.in) + tb(s.out) + tb(s.res) + (double)pl.t[s.in].esz * L.cout * L.cin_pad * L.k[0] * L.k[1] * L.k[2];
           }
@@ -1395,6 +1447,23 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         const ConvLayer &L = m->layers[s.layer];
         const PlanStep &ps = pl.ps[i];
         if (ps.fuse == 2) break;               // conv2 / conv3 of a bottleneck that conv1's step ran
+        if (ps.fuse == 5) {                    // conv1's step of the one-launch projection block (the shortcut conv's step i - 1 was skipped)
+          const ConvLayer &L2 = m->layers[m->steps[i + 1].layer], &L3 = m->layers[m->steps[i + 2].layer];
+          const int t_out = ps.fuse_out;
+          ivx_bottleneck_desc bd = {in.B, in.H, in.W, L.cout};
+          ivx_bottleneck_io io;
+          memset(&io, 0, sizeof(io));
+          io.in_scale = scalep(s.in); io.amax_in = slotp(s.in); io.out_scale = scalep(t_out); io.amax_out = slotp(t_out);
+          io.wbound[0] = L.wbound; io.sbound[0] = L.sbound; io.wbound[1] = L2.wbound; io.sbound[1] = L2.sbound;
+          io.wbound[2] = L3.proj_wb3; io.sbound[2] = L3.proj_sb;
+          const double px = (double)in.elems() / in.C;
+          M_TRY(trace_begin(m, i, 0, 0, 3.0 * 2.0 * px * ((double)L.cin * L.cout + 13.0 * L.cout * L.cout + 4.0 * L.cout * L.cin),
+                            4.0 * in.elems() + 4.0 * px * 4.0 * L.cout, L.name + " ..conv3+ds (one launch)", st));
+          M_TRY(ivx_bottleneck_proj_fwd_pio(&bd, L.cin, &io, L3.proj_wbd, ptr(s.in), L.wpair, L.scale_p, L.shift, L2.wpair, L2.scale_p, L2.shift, L3.wproj,
+                                            L3.scale_proj, L3.shift_proj, ptr(t_out), st));
+          M_TRY(trace_end(m, st));
+          break;
+        }
         if (ps.fuse == 1) {
           const ConvLayer &L2 = m->layers[m->steps[i + 1].layer], &L3 = m->layers[m->steps[i + 2].layer];
           const int t_out = ps.fuse_out;
@@ -1690,6 +1759,21 @@ extern "C" int ivx_weights_finalize(ivx_model *m, ivx_stream_t stream) {
   if (!missing.empty()) {
     ivx_set_error("ivx_weights_finalize: missing state-dict keys: %.400s", missing.c_str());
     return IVX_ERR_INVALID_ARG;
+  }
+  for (ConvLayer &L3 : m->layers) {               // joint filter bank of conv3 + shortcut conv of the one-launch projection block
+    if (L3.proj_peer < 0) continue;
+    ConvLayer &Ld = m->layers[L3.proj_peer];
+    if (L3.pair_ok && Ld.pair_ok && L3.cout == Ld.cout && L3.cout == 4 * L3.cin && !L3.w_tap.empty() && !Ld.w_tap.empty()) {
+      const int P = L3.cin, Cin = Ld.cin;
+      std::vector<uint16_t> packed((size_t)2 * 4 * P * (Cin + P));
+      std::vector<float> sc(4 * P), sf(4 * P);
+      M_TRY(ivx_bottleneck_proj_pack(L3.w_tap.data(), L3.scale_h.data(), L3.shift_h.data(), Ld.w_tap.data(), Ld.scale_h.data(), Ld.shift_h.data(), P, Cin,
+                                     packed.data(), sc.data(), sf.data(), &L3.proj_wb3, &L3.proj_sb, &L3.proj_wbd));
+      M_TRY(dev_upload_sync(m, reinterpret_cast<const float *>(packed.data()), packed.size() / 2, &L3.wproj, (hipStream_t)stream));
+      M_TRY(dev_upload_sync(m, sc.data(), sc.size(), &L3.scale_proj, (hipStream_t)stream));
+      M_TRY(dev_upload_sync(m, sf.data(), sf.size(), &L3.shift_proj, (hipStream_t)stream));
+    }
+    for (ConvLayer *L : {&L3, &Ld}) { std::vector<float>().swap(L->w_tap); std::vector<float>().swap(L->scale_h); std::vector<float>().swap(L->shift_h); }
   }
   for (size_t l = 0; l < m->t_headout.size() && l < 3; ++l) {     // mmcv Scale of the anchor-free heads (imvoxel_head_v2.py:78-80): exp(scale * reg)
     const HostTensor *sc = find_w(m, "bbox_head.scales." + std::to_string(l) + ".scale");
@@ -2220,6 +2304,38 @@ extern "C" int ivx_pair_pack_filters(const float *w, int32_t Cout, int32_t taps,
           }
       }
   return IVX_OK;
+}
+
+// Host-only: the joint filter bank of conv3 and the shortcut conv of a stage's first block (include/imvoxel.h, csrc/bottleneck.hip projection form)
+extern "C" int ivx_bottleneck_proj_pack(const float *w3, const float *scale3, const float *shift3, const float *wd, const float *scaled, const float *shiftd,
+                                        int32_t P, int32_t Cin, void *packed, float *scale_out, float *shift_out, float *wbound3, float *sbound,
+                                        float *wboundd) {
+  M_REQUIRE(w3 && scale3 && shift3 && wd && scaled && shiftd && packed && scale_out && shift_out && wbound3 && sbound && wboundd,
+            "ivx_bottleneck_proj_pack: null argument");
+  M_REQUIRE(P > 0 && Cin > 0 && P % 32 == 0 && Cin % 32 == 0, "ivx_bottleneck_proj_pack: P and Cin must be multiples of 32");
+  const int C = 4 * P, K = Cin + P;
+  std::vector<float> bank((size_t)C * K);
+  double b3 = 0.0, bd = 0.0;
+  for (int n = 0; n < C; ++n) {
+    double l3 = 0.0, ld = 0.0;
+    for (int k = 0; k < Cin; ++k) {
+      const float v = (float)((double)scaled[n] * (double)wd[(size_t)n * Cin + k]);
+      bank[(size_t)n * K + k] = v;
+      ld += fabs((double)v);
+    }
+    for (int k = 0; k < P; ++k) {
+      const float v = (float)((double)scale3[n] * (double)w3[(size_t)n * P + k]);
+      bank[(size_t)n * K + Cin + k] = v;
+      l3 += fabs((double)v);
+    }
+    b3 = std::max(b3, l3);
+    bd = std::max(bd, ld);
+    shift_out[n] = shift3[n] + shiftd[n];
+  }
+  *wbound3 = nextafterf((float)b3, INFINITY);
+  *wboundd = nextafterf((float)bd, INFINITY);
+  float wb_all;
+  return ivx_pair_pack_filters(bank.data(), C, 1, K, nullptr, shift_out, packed, scale_out, &wb_all, sbound);
 }
 
 // Host-only: the pair filters of the one-launch stem (csrc/stem.hip) in the order its wave reads them: [column tile 2][step 11][hi, lo][lane 64]

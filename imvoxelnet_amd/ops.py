@@ -609,6 +609,68 @@ def bottleneck_fwd_pio(x, f1, f2, f3):
     return PairTensor(out, slots)
 
 
+def bottleneck_proj_supported(B, H, W, planes, cin):
+    """ivx_bottleneck_proj_supported: the one-launch form of a stage's first block (shortcut conv, stride 1) exists for this map."""
+    d = _lib.BottleneckDesc(int(B), int(H), int(W), int(planes))
+    return bool(_lib.lib().ivx_bottleneck_proj_supported(C.byref(d), int(cin)))
+
+
+class ProjBank:
+    """the joint pair filter bank of conv3 and the shortcut conv (ivx_bottleneck_proj_pack) + its epilogue vectors and bound terms"""
+
+    def __init__(self, f3, fd):
+        P, cin = f3.cin, fd.cin
+        if f3._w_tap_host is None or fd._w_tap_host is None or f3.cout != 4 * P or fd.cout != 4 * P:
+            raise ValueError('bottleneck_proj_pack takes the 1x1 conv3 (P -> 4P) and the 1x1 shortcut conv (Cin -> 4P) of one block, built with chain=True')
+        self.planes, self.cin = P, cin
+        packed = torch.empty((4 * P, (cin + P) // 32, 1, 64), dtype=torch.float16)
+        sc, sf = torch.empty(4 * P, dtype=torch.float32), torch.empty(4 * P, dtype=torch.float32)
+        wb3, sb, wbd = C.c_float(), C.c_float(), C.c_float()
+        check(_lib.lib().ivx_bottleneck_proj_pack(_ptr_any(f3._w_tap_host), _ptr_any(f3._scale_host), _ptr_any(f3._shift_host), _ptr_any(fd._w_tap_host),
+                                                  _ptr_any(fd._scale_host), _ptr_any(fd._shift_host), P, cin, _ptr_any(packed), _ptr_any(sc), _ptr_any(sf),
+                                                  C.byref(wb3), C.byref(sb), C.byref(wbd)), 'ivx_bottleneck_proj_pack')
+        self._host = (packed, sc, sf)
+        self.wbound3, self.sbound, self.wboundd = wb3.value, sb.value, wbd.value
+        self.wpair = self.scale_p = self.shift = None
+
+    def to(self, device):
+        self.wpair, self.scale_p, self.shift = (t.to(device) for t in self._host)
+        return self
+
+
+def bottleneck_proj_fwd_pio(x, f1, f2, bank):
+    """The first block of ResNet stage 1 (1x1 -> 3x3 -> 1x1 + the 1x1 shortcut conv of the input, every BN / ReLU) in one launch on a PairTensor
+    [B,1,H,W,Cin] (ivx_bottleneck_proj_fwd_pio).  f1 / f2: conv.FusedConv(chain=True) of conv1 / conv2, bank: ProjBank(conv3, shortcut conv).to(device)
+    -> PairTensor [B,1,H,W,4P]."""
+    if not isinstance(x, PairTensor):
+        raise TypeError('bottleneck_proj_fwd_pio takes a PairTensor')
+    _chk(x.data, 'x', torch.float16)
+    B, D, H, W, Cn = x.shape
+    P = bank.planes
+    if D != 1 or Cn != bank.cin or not bottleneck_proj_supported(B, H, W, P, Cn):
+        raise ValueError(f'no fused projection bottleneck for an input of shape {x.shape} (planes {P})')
+    want = ((P, Cn // 32, 1, 64), (P, P // 32, 9, 64), (4 * P, (Cn + P) // 32, 1, 64))
+    for f, shp in zip((f1, f2, bank), want):
+        _chk(f.wpair, 'wpair', torch.float16)
+        if tuple(f.wpair.shape) != shp:
+            raise ValueError(f'pair filters {tuple(f.wpair.shape)} do not match the bottleneck ({shp})')
+        _chk(f.scale_p, 'scale_p')
+        _chk(f.shift, 'shift')
+    d = _lib.BottleneckDesc(B, H, W, P)
+    io = _lib.BottleneckIO()
+    slots = new_slots(x.device)
+    io.in_scale, io.amax_in = _scale_ptr(x.slots), _ptr(x.slots)
+    io.out_scale, io.amax_out = _scale_ptr(slots), _ptr(slots)
+    for i, f in enumerate((f1, f2)):
+        io.wbound[i], io.sbound[i] = float(f.wbound), float(f.sbound)
+    io.wbound[2], io.sbound[2] = float(bank.wbound3), float(bank.sbound)
+    out = torch.empty((B, 1, H, W, 8 * P), device=x.data.device, dtype=torch.float16)
+    check(_lib.lib().ivx_bottleneck_proj_fwd_pio(C.byref(d), Cn, C.byref(io), float(bank.wboundd), _ptr(x.data), _ptr(f1.wpair), _ptr(f1.scale_p),
+                                                 _ptr(f1.shift), _ptr(f2.wpair), _ptr(f2.scale_p), _ptr(f2.shift), _ptr(bank.wpair), _ptr(bank.scale_p),
+                                                 _ptr(bank.shift), _ptr(out), _stream()), 'ivx_bottleneck_proj_fwd_pio')
+    return PairTensor(out, slots)
+
+
 def global_avgpool(x):
     """[B,D,H,W,C] channels-last -> [B,1,1,1,C]: mean over every spatial position."""
     _chk(x, 'x')

@@ -224,6 +224,22 @@ int ivx_bottleneck_supported(const ivx_bottleneck_desc *d);
 int ivx_bottleneck_fwd_pio(const ivx_bottleneck_desc *d, const ivx_bottleneck_io *io, const void *in, const void *w1, const float *scale1,
                            const float *shift1, const void *w2, const float *scale2, const float *shift2, const void *w3, const float *scale3,
                            const float *shift3, void *out, ivx_stream_t stream);
+/* The FIRST block of ResNet stage 1 in one launch (layer1.0 of mmdet's ResNet-50: stride 1, shortcut = 1x1 conv + BN of the block's input; same
+ * reference lines as above):  out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(in)))))))) + bnd(convd(in))),  in: IVX_F16_PAIR [B,1,H,W,Cin],
+ * out: [B,1,H,W,4P]; built for Cin = P = 64 (ivx_bottleneck_proj_supported).  conv3 and the shortcut conv run as ONE GEMM over K = Cin + P:
+ *   ivx_bottleneck_proj_pack   host-only (both hosts call it): w3 [4P][P], wd [4P][Cin] fp32 + the two BatchNorms' scale / shift -> the joint pair
+ *                              filter bank `packed` [4P][(Cin + P) / 32][1][64] halves of s_w * [scaled * wd | scale3 * w3] (the BN scales folded
+ *                              into the filters), scale_out[n] = 1 / s_w, shift_out = shift3 + shiftd; *wbound3 = max_n sum_k |scale3 w3|,
+ *                              *wboundd = max_n sum_k |scaled wd|, *sbound = max_n |shift_out|
+ *   ivx_bottleneck_proj_fwd_pio  w1 / w2 and their vectors as ivx_bottleneck_fwd_pio; w3d / scale3d / shift3d: the packed bank and its vectors;
+ *                              io->wbound[2] = wbound3, io->sbound[2] = sbound, wbound_shortcut = wboundd: b3 = b2 * wbound3 + sbound + max|in| * wboundd.
+ * Differs from the four-launch chain by fp32-level rounding (scales from bounds; BN scales folded into the filters; one accumulation). */
+int ivx_bottleneck_proj_supported(const ivx_bottleneck_desc *d, int32_t Cin);
+int ivx_bottleneck_proj_pack(const float *w3, const float *scale3, const float *shift3, const float *wd, const float *scaled, const float *shiftd,
+                             int32_t P, int32_t Cin, void *packed, float *scale_out, float *shift_out, float *wbound3, float *sbound, float *wboundd);
+int ivx_bottleneck_proj_fwd_pio(const ivx_bottleneck_desc *d, int32_t Cin, const ivx_bottleneck_io *io, float wbound_shortcut, const void *in,
+                                const void *w1, const float *scale1, const float *shift1, const void *w2, const float *scale2, const float *shift2,
+                                const void *w3d, const float *scale3d, const float *shift3d, void *out, ivx_stream_t stream);
 
 /* Validation kernel: same contract, one thread per output element, plain FMA loop. Used by the
  * GPU tests to cross-check the MFMA kernel at full size; never called by the product path.   */

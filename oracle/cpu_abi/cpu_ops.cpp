@@ -317,6 +317,71 @@ extern "C" int ivx_bottleneck_fwd_pio(const ivx_bottleneck_desc *d, const ivx_bo
   return IVX_OK;
 }
 
+// csrc/bottleneck.hip, projection form: the first block of stage 1 in one launch.  CPU restatement: conv1 and conv2 as above (scales of the bound chain),
+// then ONE 1x1 convolution over the concatenation [x | mid2] with the joint filter bank (BN scales folded in, scale3d = 1 / s_w, shift3d = shift3 + shiftd).
+extern "C" int ivx_bottleneck_proj_supported(const ivx_bottleneck_desc *d, int32_t Cin) {
+  if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
+  if (d->P != 64 || Cin != 64) return 0;
+  return (int64_t)d->B * d->H * d->W * d->P * 16 < (1LL << 31);
+}
+extern "C" int ivx_bottleneck_proj_fwd_pio(const ivx_bottleneck_desc *d, int32_t Cin, const ivx_bottleneck_io *io, float wbound_shortcut, const void *in,
+                                           const void *w1, const float *scale1, const float *shift1, const void *w2, const float *scale2,
+                                           const float *shift2, const void *w3d, const float *scale3d, const float *shift3d, void *out,
+                                           ivx_stream_t stream) {
+  C_REQUIRE(d && io && in && w1 && w2 && w3d && out && io->in_scale && io->amax_in && io->out_scale, "ivx_bottleneck_proj_fwd_pio: null argument");
+  C_REQUIRE(ivx_bottleneck_proj_supported(d, Cin), "ivx_bottleneck_proj_fwd_pio: built for planes = Cin = 64 and the output below 2 GiB");
+  const int P = d->P, C4 = 4 * P, K = Cin + P;
+  const int64_t rows = (int64_t)d->B * d->H * d->W;
+  const float a = c_amax_read(io->amax_in);
+  const float b1 = (a * io->wbound[0] + io->sbound[0]) * 1.001f, b2 = (b1 * io->wbound[1] + io->sbound[1]) * 1.001f;
+  const float b3 = (b2 * io->wbound[2] + io->sbound[2] + a * wbound_shortcut) * 1.001f;
+  const bool sat = !(b3 < 3.0e38f);
+  const float s1 = sat ? 0.00390625f : c_pow2_scale(b1), s2 = sat ? 0.00390625f : c_pow2_scale(b2), s3 = sat ? 0.00390625f : c_pow2_scale(b3);
+  std::vector<uint16_t> m1((size_t)rows * 2 * P), m2((size_t)rows * 2 * P);
+  uint32_t sl1[IVX_AMAX_SLOTS + 1] = {0}, scratch[IVX_AMAX_SLOTS] = {0};
+  ivx_conv_desc c;
+  memset(&c, 0, sizeof(c));
+  c.B = d->B; c.D = 1; c.H = d->H; c.W = d->W; c.Cin = Cin; c.Cout = P; c.KD = c.KH = c.KW = 1; c.sd = c.sh = c.sw = 1;
+  c.relu = 1; c.wgt_layout = 1; c.post_scale = 1.0f; c.in_dtype = IVX_F16_PAIR; c.out_dtype = IVX_F32; c.res_scale = 1.0f;
+  std::vector<float> t((size_t)rows * C4);
+  ivx_pair_io p1;
+  memset(&p1, 0, sizeof(p1));
+  p1.in_scale = io->in_scale; p1.amax_in = io->amax_in; p1.amax_out = scratch;
+  int rc = ivx_conv_fwd_pio(&c, &p1, in, w1, scale1, shift1, nullptr, t.data(), nullptr, 0, stream);
+  if (rc != IVX_OK) return rc;
+  c_pair_encode(t.data(), rows, P, s1, m1.data());
+  memcpy(&sl1[IVX_AMAX_SLOTS], &s1, 4);
+  c.Cin = P; c.KH = c.KW = 3; c.ph = c.pw = 1;
+  ivx_pair_io p2;
+  memset(&p2, 0, sizeof(p2));
+  p2.in_scale = (const float *)&sl1[IVX_AMAX_SLOTS]; p2.amax_in = sl1; p2.amax_out = scratch;
+  rc = ivx_conv_fwd_pio(&c, &p2, m1.data(), w2, scale2, shift2, nullptr, t.data(), nullptr, 0, stream);
+  if (rc != IVX_OK) return rc;
+  c_pair_encode(t.data(), rows, P, s2, m2.data());
+  // [x | mid2] as fp32 values, the joint bank as fp32 chunk-major filters of s_w * w'
+  std::vector<float> xin((size_t)rows * Cin), mid((size_t)rows * P), cat((size_t)rows * K), w((size_t)C4 * K);
+  c_pair_decode((const uint16_t *)in, rows, Cin, 1.0f / *io->in_scale, xin.data());
+  c_pair_decode(m2.data(), rows, P, 1.0f / s2, mid.data());
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < rows; ++r) {
+    memcpy(&cat[(size_t)r * K], &xin[(size_t)r * Cin], (size_t)Cin * 4);
+    memcpy(&cat[(size_t)r * K + Cin], &mid[(size_t)r * P], (size_t)P * 4);
+  }
+  c_pair_decode((const uint16_t *)w3d, (int64_t)C4 * (K / 32), 32, 1.0f, w.data());
+  ivx_conv_desc f;
+  memset(&f, 0, sizeof(f));
+  f.B = d->B; f.D = 1; f.H = d->H; f.W = d->W; f.Cin = K; f.Cout = C4; f.KD = f.KH = f.KW = 1; f.sd = f.sh = f.sw = 1;
+  f.relu = 1; f.wgt_layout = 1; f.post_scale = 1.0f; f.in_dtype = IVX_F32; f.out_dtype = IVX_F32; f.res_scale = 1.0f;
+  rc = ivx_conv_fwd_ws(&f, cat.data(), w.data(), scale3d, shift3d, nullptr, t.data(), nullptr, 0, stream);
+  if (rc != IVX_OK) return rc;
+  float omax = 0.f;
+  for (int64_t i = 0; i < rows * C4; ++i) omax = fabsf(t[i]) > omax ? fabsf(t[i]) : omax;
+  if (io->amax_out) c_amax_commit(io->amax_out, omax);
+  *io->out_scale = s3;
+  c_pair_encode(t.data(), rows, C4, s3, (uint16_t *)out);
+  return IVX_OK;
+}
+
 extern "C" int ivx_conv_fwd_pio_naive(const ivx_conv_desc *d, const ivx_pair_io *io, const void *in, const void *wgt, const float *scale, const float *shift,
                                       const void *res, void *out, ivx_stream_t stream) {
   return ivx_conv_fwd_pio(d, io, in, wgt, scale, shift, res, out, nullptr, 0, stream);

@@ -128,3 +128,109 @@ def test_fused_bottleneck_full_size_vs_chain(ia, name, P, B, H, W):
     y = ops.bottleneck_fwd_pio(xp, f1, f2, f3).float()
     yc = f3(f2(f1(xp, out_pair=True), out_pair=True), res=xp, out_pair=True).float()
     assert_close(f'{name}: fused vs chain', y, yc, rtol=0, atol=2e-5 * float(yc.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------- the first block of stage 1 (shortcut conv), one launch
+def _proj_block(seed, P=64, cin=64, device='cuda'):
+    """layer1.0 of ResNet-50: conv1 (cin -> P), conv2 3x3, conv3 (P -> 4P) + the 1x1 shortcut conv (cin -> 4P), each with its BatchNorm"""
+    from imvoxelnet_amd import ops
+    from imvoxelnet_amd.conv import FusedConv
+    g = torch.Generator().manual_seed(seed)
+    C4 = 4 * P
+
+    def bn(c):
+        return (0.5 + torch.rand(c, generator=g), 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g), 0.5 + torch.rand(c, generator=g))
+    w1 = torch.randn(P, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    w2 = torch.randn(P, P, 3, 3, generator=g) * (2.0 / (9 * P)) ** 0.5
+    w3 = torch.randn(C4, P, 1, 1, generator=g) * (2.0 / P) ** 0.5
+    wd = torch.randn(C4, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    bns = [bn(P), bn(P), bn(C4), bn(C4)]
+    f1 = FusedConv(w1, bn=bns[0], relu=True, dims=2, chain=True).to(device)
+    f2 = FusedConv(w2, bn=bns[1], padding=1, relu=True, dims=2, chain=True).to(device)
+    f3 = FusedConv(w3, bn=bns[2], relu=True, dims=2, chain=True).to(device)
+    fd = FusedConv(wd, bn=bns[3], relu=False, dims=2, chain=True).to(device)
+    bank = ops.ProjBank(f3, fd).to(device)
+    return (f1, f2, f3, fd, bank), (w1, w2, w3, wd), bns
+
+
+def _proj_ref64(x_cl, ws, bns):
+    import torch.nn.functional as F
+    x = x_cl[:, 0].permute(0, 3, 1, 2).double()
+
+    def bn(y, t):
+        gmm, beta, mean, var = (v.double().to(y.device) for v in t)
+        return (y - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5) * gmm[None, :, None, None] + beta[None, :, None, None]
+    y = F.relu(bn(F.conv2d(x, ws[0].double()), bns[0]))
+    y = F.relu(bn(F.conv2d(y, ws[1].double(), padding=1), bns[1]))
+    y = F.relu(bn(F.conv2d(y, ws[2].double()), bns[2]) + bn(F.conv2d(x, ws[3].double()), bns[3]))
+    return y.permute(0, 2, 3, 1)[:, None]
+
+
+def _proj_chain(xp, f1, f2, f3, fd):
+    """the four-launch form of the pair chain (backbones._Bottleneck.forward_cl): the shortcut conv writes fp32, conv3 adds it in its epilogue"""
+    return f3(f2(f1(xp, out_pair=True), out_pair=True), res=fd(xp), out_pair=True)
+
+
+@pytest.mark.parametrize('B,H,W', [(1, 8, 16), (2, 13, 37), (1, 5, 9), (2, 24, 80), (3, 17, 48)])
+def test_fused_proj_bottleneck_vs_chain_and_fp64(ia, B, H, W):
+    from imvoxelnet_amd import ops
+    (f1, f2, f3, fd, bank), ws, bns = _proj_block(300 + H)
+    g = torch.Generator().manual_seed(H * W + 1)
+    x = torch.relu(torch.randn(B, 1, H, W, 64, generator=g) * torch.logspace(-1.5, 0.5, 64)).cuda()
+    xp = make_pair(x)
+    xv = xp.float()
+    got = ops.bottleneck_proj_fwd_pio(xp, f1, f2, bank)
+    torch.cuda.synchronize()
+    assert isinstance(got, ops.PairTensor) and got.shape == (B, 1, H, W, 256)
+    y = got.float()
+    yc = _proj_chain(xp, f1, f2, f3, fd).float()
+    ref = _proj_ref64(xv.cpu(), ws, bns)
+    rng = float(ref.abs().max())
+    assert_close(f'fused projection block vs four-launch chain {B}x{H}x{W}', y, yc, rtol=0, atol=2e-5 * rng)
+    assert_close(f'fused projection block vs fp64 {B}x{H}x{W}', y.double().cpu(), ref, rtol=0, atol=2e-5 * rng)
+    e_f = float((y.double().cpu() - ref).abs().max())
+    e_c = float((yc.double().cpu() - ref).abs().max())
+    print(f'max error vs fp64: fused {e_f:.3e}  chain {e_c:.3e}  (range {rng:.3e})')
+    assert e_f <= 2.0 * e_c + 1e-6 * rng, 'the fused block must be as accurate as the layer-wise chain'
+    amax = got.amax()
+    assert abs(amax - float(y.abs().max())) <= 1e-6 * rng + 2.0 ** -20 * amax
+    s = got.scale()
+    assert s > 0 and (s * amax) < 32768.0 and float(torch.tensor(s).log2()) == round(float(torch.tensor(s).log2()))
+
+
+def test_fused_proj_then_identity_blocks(ia):
+    """layer1.0 -> layer1.1 as two launches: the identity block reads the projection block's output, scale and maximum from the device"""
+    from imvoxelnet_amd import ops
+    (f1, f2, f3, fd, bank), ws_a, bns_a = _proj_block(11)
+    blk_b, ws_b, bns_b = _block(64, 12)
+    x = torch.relu(torch.randn(2, 1, 19, 33, 64, generator=torch.Generator().manual_seed(13))).cuda()
+    xp = make_pair(x)
+    y2 = ops.bottleneck_fwd_pio(ops.bottleneck_proj_fwd_pio(xp, f1, f2, bank), *blk_b)
+    ref = _ref64(_proj_ref64(xp.float().cpu(), ws_a, bns_a).float(), ws_b, bns_b)
+    assert_close('projection + identity block vs fp64', y2.float().double().cpu(), ref, rtol=0, atol=4e-5 * float(ref.abs().max()))
+
+
+def test_fused_proj_bottleneck_nonfinite_and_rejects(ia):
+    from imvoxelnet_amd import ops
+    (f1, f2, f3, fd, bank), ws, bns = _proj_block(14)
+    x = torch.relu(torch.randn(1, 1, 16, 32, 64, generator=torch.Generator().manual_seed(15))).cuda()
+    xp = make_pair(x)
+    xp.slots[:ops.AMAX_SLOTS].view(torch.float32)[3] = float('inf')
+    y = ops.bottleneck_proj_fwd_pio(xp, f1, f2, bank).float()
+    assert bool(torch.isfinite(y).all())
+    ref = _proj_ref64(xp.float().cpu(), ws, bns)
+    assert_close('fixed-scale path', y.double().cpu(), ref, rtol=0, atol=2e-3 * float(ref.abs().max()))
+    assert ops.bottleneck_proj_supported(4, 96, 320, 64, 64) and not ops.bottleneck_proj_supported(4, 48, 160, 128, 256)
+    with pytest.raises(ValueError):
+        ops.bottleneck_proj_fwd_pio(make_pair(torch.randn(1, 1, 8, 16, 128).cuda()), f1, f2, bank)
+
+
+@pytest.mark.parametrize('name,B,H,W', [('kitti', 4, 96, 320), ('scannet x20', 20, 120, 160)])
+def test_fused_proj_bottleneck_full_size_vs_chain(ia, name, B, H, W):
+    from imvoxelnet_amd import ops
+    (f1, f2, f3, fd, bank), ws, bns = _proj_block(16)
+    x = torch.relu(torch.randn(B, 1, H, W, 64, generator=torch.Generator().manual_seed(17))).cuda()
+    xp = make_pair(x)
+    y = ops.bottleneck_proj_fwd_pio(xp, f1, f2, bank).float()
+    yc = _proj_chain(xp, f1, f2, f3, fd).float()
+    assert_close(f'{name}: fused projection block vs chain', y, yc, rtol=0, atol=2e-5 * float(yc.abs().max()))

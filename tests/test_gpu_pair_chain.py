@@ -250,9 +250,10 @@ def test_trunk_pair_chain_vs_fp32_mfma(ia, monkeypatch):
         n_fused = sum(k.startswith('bottleneck ') and k.endswith(' pair, one launch') for k in kinds)
         n_stem = sum(k.startswith('stem ') and k.endswith(' pair, one launch') for k in kinds)
         # every bottleneck conv, shortcut conv, FPN lateral and the FPN output conv run on pairs.  The five identity blocks of stages 1 and 2
-        # are one launch each (ops.bottleneck_fwd_pio) instead of three, and so is the head (layout change + stem + max-pool: ops.stem_pool_pair)
-        assert (n_fused, n_stem) == ((0, 0) if mode == 0 else (5, 1)), (mode, n_fused, n_stem)
-        assert n_pair == (0 if mode == 0 else 3 * (16 - n_fused) + 4 + 4 + 1), (mode, n_pair, len(kinds))
+        # are one launch each (ops.bottleneck_fwd_pio) instead of three, the first block of stage 1 one (ops.bottleneck_proj_fwd_pio: its shortcut
+        # conv included) instead of four, and so is the head (layout change + stem + max-pool: ops.stem_pool_pair)
+        assert (n_fused, n_stem) == ((0, 0) if mode == 0 else (6, 1)), (mode, n_fused, n_stem)
+        assert n_pair == (0 if mode == 0 else 3 * (16 - n_fused) + 3 + 4 + 1), (mode, n_pair, len(kinds))
     torch.cuda.synchronize()
     rng = float(outs[0].abs().max())
     assert_close('FPN level 0: pair chain vs fp32 MFMA', outs[4], outs[0], 0, 2e-5 * rng)

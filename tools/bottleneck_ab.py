@@ -43,8 +43,26 @@ def main():
         by = px * 4 * P * 4 * 2
         rows.append((name, P, px, t_c * 1e3, t_f * 1e3, fl / t_f / 1e9, by / t_f / 1e6))
         print(f'{name}: chain {t_c * 1e3:.1f} us  fused {t_f * 1e3:.1f} us  ({fl / t_f / 1e9:.0f} TFLOP/s of fp16 products, {by / t_f / 1e6:.0f} GB/s in + out)', flush=True)
+    # the first block of stage 1 (shortcut conv): one launch against the four-launch chain (the shortcut conv on the same stream)
+    from test_gpu_bottleneck import _proj_block, _proj_chain
+    prow = []
+    for name, B, H, W in [('kitti layer1.0', 4, 96, 320), ('scannet x50 layer1.0', 50, 120, 160), ('nuscenes layer1.0', 6, 232, 400),
+                          ('scannet x20 layer1.0', 20, 120, 160)]:
+        (f1, f2, f3, fd, bank), _, _ = _proj_block(1)
+        xp = make_pair(torch.relu(torch.randn(B, 1, H, W, 64, generator=torch.Generator().manual_seed(1))).cuda())
+        t_f = timed(lambda: ops.bottleneck_proj_fwd_pio(xp, f1, f2, bank))
+        t_c = timed(lambda: _proj_chain(xp, f1, f2, f3, fd))
+        px = B * H * W
+        fl = 2.0 * px * (64 * 64 + 9 * 64 * 64 + 2 * 64 * 256) * 3
+        by = px * (64 + 256) * 4
+        prow.append((name, px, t_c * 1e3, t_f * 1e3, fl / t_f / 1e9, by / t_f / 1e6))
+        print(f'{name}: chain {t_c * 1e3:.1f} us  fused {t_f * 1e3:.1f} us  ({fl / t_f / 1e9:.0f} TFLOP/s of fp16 products, {by / t_f / 1e6:.0f} GB/s in + out)', flush=True)
     if a.md:
         with open(a.md, 'w') as f:
+            f.write('| map (projection block 64 -> 64 -> 64 -> 256 + shortcut conv) | pixels | four launches (us) | one launch (us) | TFLOP/s (fp16 products) | GB/s (input + output once) |\n|---|---|---|---|---|---|\n')
+            for r in prow:
+                f.write(f'| {r[0]} | {r[1]} | {r[2]:.1f} | {r[3]:.1f} | {r[4]:.0f} | {r[5]:.0f} |\n')
+            f.write('\n')
             f.write('| map | planes | pixels | three launches (us) | one launch (us) | TFLOP/s (fp16 products, no halo recompute) | GB/s (input + output once) |\n|---|---|---|---|---|---|---|\n')
             for r in rows:
                 f.write(f'| {r[0]} | {r[1]} | {r[2]} | {r[3]:.1f} | {r[4]:.1f} | {r[5]:.0f} | {r[6]:.0f} |\n')
