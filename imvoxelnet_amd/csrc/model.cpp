@@ -228,6 +228,7 @@ struct ivx_model {
   float *calib_dev = nullptr;          // during the calibration pass: one max |output| per layer (device)
   // optional stage timing (ivx_model_trace): one record per launch group, events recorded on the caller's stream
   bool trace_on = false;
+  bool trace_skip = false;             // the open trace_begin recorded nothing (level 3, a stage other than the GEMM)
   int trace_level = 2;                 // 2: every launch group; 1: the 3-D neck stages, the unprojection and the tail individually,
                                        //    the 2-D trunk (image layout change .. FPN level 0) as ONE span (stage 6)
   struct TraceRec { int step, stage, is3d; double flops, bytes; hipEvent_t e0, e1; std::string name; };
@@ -1275,6 +1276,8 @@ struct Bind {               // caller-owned buffers by tensor id
 
 int trace_begin(ivx_model *m, int step, int stage, int is3d, double flops, double bytes, const std::string &name, hipStream_t st) {
   if (!m->trace_on) return IVX_OK;
+  m->trace_skip = m->trace_level == 3 && stage != 2;      // level 3: only the grouped Winograd-domain GEMM launches carry events
+  if (m->trace_skip) return IVX_OK;
   while (m->event_pool.size() < m->events_used + 2) {
     hipEvent_t e;
     M_HIP(hipEventCreate(&e), "hipEventCreate");
@@ -1288,7 +1291,7 @@ int trace_begin(ivx_model *m, int step, int stage, int is3d, double flops, doubl
 }
 
 int trace_end(ivx_model *m, hipStream_t st) {
-  if (!m->trace_on) return IVX_OK;
+  if (!m->trace_on || m->trace_skip) return IVX_OK;
   M_HIP(hipEventRecord(m->trace.back().e1, st), "hipEventRecord");
   return IVX_OK;
 }
@@ -1486,7 +1489,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
         // the shortcut conv of a block runs on the side stream next to conv1 / conv2 (with per-launch tracing everything stays on `st`)
         hipStream_t cst = st;
         void *cws = ws;
-        if (ps.side > 0 && !m->trace_on && pl.ws2_off > 0) {
+        if (ps.side > 0 && !(m->trace_on && m->trace_level != 3) && pl.ws2_off > 0) {
           if (!m->side) {
             M_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking), "hipStreamCreateWithFlags");
             M_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming), "hipEventCreateWithFlags");
@@ -2239,7 +2242,7 @@ extern "C" int ivx_model_trace(ivx_model *m, int32_t enable) {
   m->trace.clear();
   m->events_used = 0;
   m->trace_on = enable != 0;
-  if (enable == 1 || enable == 2) m->trace_level = enable;
+  if (enable >= 1 && enable <= 3) m->trace_level = enable;
   return IVX_OK;
 }
 

@@ -347,7 +347,8 @@ class NativeModel:
     # ------------------------------------------------------------------ stage timing
     def trace(self, level=2):
         """0 / False: off; 2 / True: an event pair around every launch group; 1: coarse -- the neck stages, the unprojection and
-        the tail individually, the 2-D trunk as one span (stage 6): a third of the events, for timed runs."""
+        the tail individually, the 2-D trunk as one span (stage 6): a third of the events; 3: only the grouped Winograd-domain GEMM launches
+        (stage 2) -- what bench.py keeps inside its timed region."""
         level = 2 if level is True else int(level)
         check(self.L.ivx_model_trace(self.h, level), 'ivx_model_trace')
 

@@ -729,7 +729,8 @@ typedef struct ivx_trace_rec {
   char name[48];
 } ivx_trace_rec;
 int ivx_model_trace(ivx_model *m, int32_t level);   /* 0 off | 2 every launch group | 1 coarse: the 3-D neck stages, the
-                                                       unprojection and the tail individually, the 2-D trunk as one span (stage 6) */
+                                                       unprojection and the tail individually, the 2-D trunk as one span (stage 6) |
+                                                       3 only the grouped Winograd-domain GEMM launches (stage 2): nine event pairs per KITTI step */
 int32_t ivx_model_trace_count(ivx_model *m);
 int ivx_model_trace_read(ivx_model *m, int32_t i, ivx_trace_rec *rec);
 
