@@ -134,9 +134,16 @@ class FusedConv:
     # fp32 activations and filters as (hi, lo) bf16 pairs, three bf16 MFMA products per pair with fp32 accumulation -- 16x the fp32 MFMA
     # rate at 2^-17 operand precision, one split pass over the input.  Measured on the KITTI neck it loses to the Winograd form
     # (1.9 / 2.9 / 5.2 ms vs 1.8 / 2.7 / 4.5 for the 64 / 128 / 256-channel layers: the minimal-filtering form needs 5x fewer products).
-    # 0: off;  1: 3-D layers with Cin % 32 == 0;  2: 2-D layers as well
-    pair_mode = int(os.environ.get('IVX_CONV_PAIR', '0'))
+    # -1 (default): the rule -- 3x3x3 layers with Cin % 32 == 0 and Cout >= 64 that the Winograd form does not take (the strided convolutions of
+    #     NuScenesImVoxelNeck / FastIndoorImVoxelNeck / the Atlas encoder, and the layers of the coarsest levels: fewer than winograd_min_pos
+    #     positions under a K loop of 13824 .. 27648), from SPLIT_MIN_POS input positions on, when the Winograd-domain GEMMs run on 16-bit operands
+    #     too (wino_operands = 4; with 0 every product of the neck stays on fp32 MFMA).  Measured (tools/neck_layers.py, profiles/r06_split_form.md):
+    #     64 -> 128 stride 2 at 312 x 312 x 12 0.616 -> 0.369 ms, 256 -> 512 stride 2 at 40 x 40 x 16 0.239 -> 0.126, 512 -> 512 at 10 x 10 x 4
+    #     0.084 -> 0.065; 1x1x1 layers and the Cout = 25 head convs gain nothing (HBM / latency-bound) and stay fp32.  csrc/model.cpp plan_conv mirrors it.
+    # 0: off;  1: every 3-D layer with Cin % 32 == 0 from pair_min_pos positions on;  2: 2-D layers as well
+    pair_mode = int(os.environ.get('IVX_CONV_PAIR', '-1'))
     pair_min_pos = 2000
+    SPLIT_MIN_POS = 256
     # Operands of the Winograd-domain GEMMs (ivx_conv_desc.wino_operands): 4 = fp16 (hi, lo) pairs, three fp16 MFMA products per pair
     # (~3.3x the fp32 MFMA rate at 22-bit operands: the error stays at the level of the fp32 form's own rounding);
     # 0 = fp32 MFMA (exact fp32 products)
@@ -214,8 +221,11 @@ class FusedConv:
         # candidate for the split-operand form: pair-packed filters (made on the host once)
         self._wp_host = None
         self._dims = dims
-        if (dtype == torch.float32 and out_dtype == torch.float32 and self.cin_pad == self.cin and self.cin % 32 == 0 and type(self) is FusedConv
-                and FusedConv.pair_mode >= (1 if dims == 3 else 2)):
+        self._split_cand = (dims == 3 and self.kernel == (3, 3, 3) and self.cout >= 64 and dtype == torch.float32 and out_dtype == torch.float32
+                            and self.cin_pad == self.cin and self.cin % 32 == 0 and type(self) is FusedConv)
+        if ((self._split_cand and FusedConv.pair_mode < 0) or
+                (dtype == torch.float32 and out_dtype == torch.float32 and self.cin_pad == self.cin and self.cin % 32 == 0 and type(self) is FusedConv
+                 and FusedConv.pair_mode >= (1 if dims == 3 else 2))):
             self._wp_host = pack_pair_weights(w.permute(0, 2, 3, 4, 1).contiguous(), 1)
         self.wp = None
         self.u = None          # {tile: transformed filters}, filled by to() / on first use of a tile
@@ -365,9 +375,14 @@ class FusedConv:
         return y
 
     def takes_pair_form(self, x_shape, dtype=torch.float32, naive=False):
-        return (self.wp is not None and not naive and dtype == torch.float32 and FusedConv.pair_mode >= (1 if self._dims == 3 else 2)
-                and x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3] >= FusedConv.pair_min_pos
-                and ops.conv_pair_supported(x_shape, self.cout, self.kernel, self.stride, self.padding, 1))
+        if self.wp is None or naive or dtype != torch.float32:
+            return False
+        npos = x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3]
+        if FusedConv.pair_mode < 0:       # the default rule (class comment; csrc/model.cpp plan_conv)
+            ok = self._split_cand and FusedConv.wino_operands == ops.IVX_F16_PAIR and npos >= FusedConv.SPLIT_MIN_POS
+        else:
+            ok = FusedConv.pair_mode >= (1 if self._dims == 3 else 2) and npos >= FusedConv.pair_min_pos
+        return ok and ops.conv_pair_supported(x_shape, self.cout, self.kernel, self.stride, self.padding, 1)
 
     def _pair(self, x, res, res_mode, relu, res_after_act, post_scale):
         """split pass (fp32 -> bf16 pairs) + the three-product bf16 MFMA kernel with the usual fused fp32 epilogue"""

@@ -1601,6 +1601,10 @@ static bool dma_applicable(const ConvParams &p) {
 //    launch with K split so that it fills every slot once (needs the caller's workspace: ivx_conv_fwd_ws).
 //  * The LDS-DMA kernel (cfg 4x/5x fp32, 6x/7x bf16) is used whenever its preconditions hold, else the same tile on
 //    the generic kernel (cfg 1..7).
+static int conv_skinny_rule() {
+  static const int v = getenv("IVX_CONV_SKINNY") ? atoi(getenv("IVX_CONV_SKINNY")) : 1;
+  return v;
+}
 static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
   ConvPlan pl = {g_tile_override, 1, 1, 0, 0, 0, 0};
   const bool dma_ok = dma_applicable(p);
@@ -1631,11 +1635,18 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
       if (score > best) { best = score; pl.cfg = cand[i]; }
     }
     small = pl.cfg == c64;
+    // (Round 6, measured and not adopted -- profiles/r06_skinny_convs.md: 128 x 128 / 256 x 128 tiles + split K for the layers of a few hundred rows
+    // under a K loop of 13824 .. 27648 (512 -> 512 at 10 x 10 x 4): 0.084 -> 0.140 / 0.243 ms per launch.  These launches are bound by the number of
+    // slabs a workgroup runs one after the other, not by L2 -> LDS bytes: 64 x 64 tiles with K split 27 ways stay.)
   }
   if (pl.cfg == 0) {
     const long long nblk = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (p.Cout <= 32) {
       pl.cfg = dma_ok ? 44 : 4;
+      // the head convs of the indoor configs (Cout = 25) on the coarse levels: 4 .. 25 row tiles under a K loop of 54 .. 108 slabs ran as that
+      // many workgroups, one slab after the other (89 us for 69 MFLOP at 10 x 10 x 4); K is split as for every other small layer
+      // (IVX_CONV_SKINNY=0: the round-5 rule, for A/B)
+      small = dma_ok && !p.in_bf16 && !p.in_fp8 && conv_skinny_rule() != 0;
     } else if (nblk >= 2500) {
       pl.cfg = p.Cout > 64 ? (dma_ok ? 54 : 1) : (dma_ok ? (p.K <= 640 ? 49 : 56) : 3);   // 49: the stem
     } else {

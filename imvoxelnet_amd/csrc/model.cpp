@@ -129,6 +129,10 @@ struct ConvLayer {
   double out_scale_q = 1.0;
   bool pair_ok = false;
   float *wpair = nullptr, *scale_p = nullptr;
+  // split-operand (IVX_BF16_PAIR) form of the 3x3x3 neck layers the Winograd form does not take (strided; fewer than 2000 positions): filters as
+  // conv.py pack_pair_weights(layout 1); the layer's input goes through ivx_bf16_pair_split into the step's workspace (conv.py FusedConv._pair)
+  bool split_cand = false;
+  float *wsplit = nullptr;
   float wbound = 0.f, sbound = 0.f;
   // the first block of stage 1 in one launch (ivx_bottleneck_proj_fwd_pio): on conv3, the layer index of the block's shortcut conv and the joint filter
   // bank of the two (ivx_bottleneck_proj_pack: BN scales folded into the filters, scale_proj = 1 / s_w, shift_proj = shift3 + shiftd) with its bound terms
@@ -172,6 +176,7 @@ struct PlanStep {
   int64_t amax_out = -1, amax_in = -1;
   int amax_n = 0, amax_in_n = 0;
   int pio = 0;            // CONV: the fp16-pair form (ivx_conv_fwd_pio); MAXPOOL: pair output (aux = the stem's layer for the bound)
+  int64_t split = 0;      // CONV: > 0 = the split-operand form: bytes of the (hi, lo) bf16 copy of the input at the start of the workspace (d.in_dtype = IVX_BF16_PAIR)
   int bound_layer = -1;
   // identity bottleneck in one launch (ivx_bottleneck_fwd_pio, csrc/bottleneck.hip): fuse 1 = conv1's step, which runs the whole block and
   // writes conv3's output tensor (fuse_out); fuse 2 = conv2's / conv3's step, covered by it
@@ -720,6 +725,31 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
     M_TRY(dev_upload(m, scale, &L.scale, st));
     M_TRY(dev_upload(m, shift, &L.shift, st));
   }
+  // Split-operand form (conv.py FusedConv: _split_cand / pack_pair_weights): every fp32 filter as hi = bf16(w), lo = bf16(w - hi), per 16 channels
+  // [hi x16 | lo x16], chunk-major [Cout, 2 Cin / 64, taps, 64]
+  L.split_cand = !bf16 && m->cfg.wino_operands == IVX_F16_PAIR && L.dims == 3 && kd == 3 && kh == 3 && kw == 3 && !L.conv_t && !L.linear && !L.dcn_cols &&
+                 L.cin_pad == L.cin && L.cin % 32 == 0 && L.cout >= 64;
+  if (L.split_cand) {
+    std::vector<uint16_t> wb(2 * n_w);
+    const int nch = L.cin / 32;
+    for (int co = 0; co < L.cout; ++co)
+      for (int ch = 0; ch < nch; ++ch)
+        for (int t = 0; t < taps; ++t) {
+          const float *src = &wp[((size_t)co * taps + t) * L.cin + ch * 32];
+          uint16_t *dst = &wb[(((size_t)co * nch + ch) * taps + t) * 64];
+          for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < 16; ++j) {
+              const float w = src[g * 16 + j];
+              const uint16_t hi = f32_to_bf16_bits(w);
+              uint32_t hb = (uint32_t)hi << 16;
+              float hf;
+              memcpy(&hf, &hb, 4);
+              dst[g * 32 + j] = hi;
+              dst[g * 32 + 16 + j] = f32_to_bf16_bits(w - hf);
+            }
+        }
+    M_TRY(dev_upload_sync(m, reinterpret_cast<const float *>(wb.data()), n_w, &L.wsplit, st));
+  }
   // fp16-pair form of the 2-D trunk (cfg.trunk_operands): pair filters + scale / s_w, and the bound terms (also for the layers that
   // stay fp32: the stem's bound scales the max-pool's pair output)
   const bool trunk_layer = L.name.rfind("backbone.", 0) == 0 || L.name.rfind("neck.", 0) == 0;
@@ -786,6 +816,7 @@ int conv_out(const ConvLayer &L, const TInfo &in, TInfo *o) {
   return IVX_OK;
 }
 
+constexpr int64_t SPLIT_MIN_POS = 256;      // conv.py FusedConv.SPLIT_MIN_POS
 // The Winograd decision of FusedConv.wino_tile (conv.py): returns the tile (0 = direct) and the descriptor to run.
 int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const TInfo *res, PlanStep *ps, hipStream_t stream, int out_fmt = 0) {
   ivx_conv_desc d;
@@ -870,9 +901,17 @@ int plan_conv(ivx_model *m, ConvLayer &L, const TInfo &in, const Step &st, const
       L.u[ukey] = (float *)u;
     }
   } else {
+    // the split-operand form for the 3x3x3 layers the Winograd form did not take (conv.py FusedConv.takes_pair_form, the default rule): the
+    // strided convolutions of the necks and the layers of their coarsest levels; fp32 tensors on both sides, 16-bit matrix cores in between
+    if (L.split_cand && L.wsplit && m->cfg.storage == IVX_F32 && (int64_t)in.B * in.D * in.H * in.W >= SPLIT_MIN_POS && ivx_conv_pair_supported(&d) == 1) {
+      ps->split = align256((int64_t)in.elems() * 4);
+      d.in_dtype = IVX_BF16_PAIR;
+      d.wgt_layout = 1;
+    }
     ps->d = d;
     ps->ws = ivx_conv_workspace_bytes(&d);
     M_REQUIRE(ps->ws >= 0, "layer %s: %s", L.name.c_str(), ivx_last_error());
+    ps->ws += ps->split;
   }
   ps->tile = tile;
   return IVX_OK;
@@ -1529,7 +1568,7 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
           M_TRY(trace_end(m, st));
           break;
         }
-        M_TRY(trace_begin(m, i, 0, is3d, (ps.pio ? 3.0 : 1.0) * 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2], 0.0, L.name, st));
+        M_TRY(trace_begin(m, i, 0, is3d, ((ps.pio || ps.split) ? 3.0 : 1.0) * 2.0 * o.elems() * L.cin * L.k[0] * L.k[1] * L.k[2], 0.0, L.name, st));
         if (ps.pio) {
           ivx_pair_io io;
           memset(&io, 0, sizeof(io));
@@ -1548,6 +1587,9 @@ int run_steps(ivx_model *m, const Plan &pl, Range r, const Bind &bd, void *works
                                               ps.amax_out >= 0 ? (float *)(base + ps.amax_out) : nullptr, st));
         } else if (m->fp8_on && L.fp8_eff) {
           M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.fp8_eff >= 2 ? L.wq : L.w, L.scale_q, L.shift_q, res, ptr(s.out), cws, pl.ws_bytes, cst));
+        } else if (ps.split) {     // (hi, lo) bf16 copy of the input at the start of the workspace, then the three-product kernel
+          M_TRY(ivx_bf16_pair_split((const float *)ptr(s.in), in.elems(), cws, cst));
+          M_TRY(ivx_conv_fwd_ws(&ps.d, cws, L.wsplit, L.scale, L.shift, res, ptr(s.out), (char *)cws + ps.split, pl.ws_bytes - ps.split, cst));
         } else {
           M_TRY(ivx_conv_fwd_ws(&ps.d, ptr(s.in), L.w, L.scale, L.shift, res, ptr(s.out), cws, pl.ws_bytes, cst));
           if (m->calib_dev && (L.fp8_eff == 1 || L.fp8_eff == 2))       // calibration pass: max |output| of the tensors that will be e4m3

@@ -618,7 +618,9 @@ typedef struct ivx_model_cfg {
                                       its predicted angles replace the extrinsics of the metas at test time; keys head_2d.{angle,layout}_mlp.* */
   int32_t layout_linear_size;
   int32_t wino_operands;           /* (0.3.1) ivx_conv_desc.wino_operands of the layers that run in the Winograd form: IVX_F32 (0) = fp32 MFMA,
-                                      IVX_F16_PAIR = fp16 (hi, lo) operand pairs where the layer allows it (tile 4 / 6, Cin % 32 == 0) */
+                                      IVX_F16_PAIR = fp16 (hi, lo) operand pairs where the layer allows it (tile 4 / 6, Cin % 32 == 0); with it the
+                                      3x3x3 neck layers the Winograd form does not take (stride 2 in x / y; under 2000 positions) run in the
+                                      IVX_BF16_PAIR form above (split pass + three-product kernel; Cin % 32 == 0, Cout >= 64, >= 256 positions) */
   int32_t trunk_operands;          /* (0.4.0) IVX_F32 (0): the 2-D trunk (ResNet-50 + FPN) on fp32 MFMA.  IVX_F16_PAIR: its activations chained as
                                       fp16 (hi, lo) pair tensors on the 16-bit matrix cores (ivx_conv_fwd_pio: three fp16 MFMA products per
                                       multiply-add, fp32 accumulate, device-side power-of-two scales, no conversion passes) wherever a tensor's

@@ -448,6 +448,12 @@ extern "C" int ivx_conv_winograd_supported(const ivx_conv_desc *, int32_t) { ret
 extern "C" float ivx_conv_winograd_issued_fraction(const ivx_conv_desc *) { return 1.0f; }
 extern "C" int64_t ivx_conv_winograd_weight_elems(const ivx_conv_desc *, int32_t) { return -1; }
 extern "C" int64_t ivx_conv_winograd_workspace_bytes(const ivx_conv_desc *, int32_t) { return -1; }
+// The split-operand (IVX_BF16_PAIR) form is a device-side optimisation too: "not supported" keeps the handle's 3x3x3 layers on the direct fp32 convolution.
+extern "C" int ivx_conv_pair_supported(const ivx_conv_desc *) { return 0; }
+extern "C" int ivx_bf16_pair_split(const float *, int64_t, void *, ivx_stream_t) {
+  ivx_set_error("ivx_bf16_pair_split: the CPU restatement has no split-operand form (ivx_conv_pair_supported returns 0)");
+  return IVX_ERR_UNSUPPORTED;
+}
 static int no_wino(const char *who) {
   ivx_set_error("%s: the CPU restatement has no Winograd form (ivx_conv_winograd_supported returns 0)", who);
   return IVX_ERR_UNSUPPORTED;

@@ -95,6 +95,52 @@ def test_conv_bf16_pair_operands(ia, case):
     assert_close('pair MFMA vs torch fp64', got, tref.float(), 0, 2e-5 * rng)
 
 
+@pytest.mark.parametrize('case', [
+    # B, (D,H,W), Cin, Cout, stride, residual: the layers the default rule sends to the split-operand form
+    (1, (24, 26, 12), 64, 128, (2, 2, 2), False),      # NuScenesImVoxelNeck's first _get_conv (necks/imvoxelnet.py:133), reduced
+    (1, (20, 20, 8), 256, 512, (2, 2, 2), False),      # FastIndoorImVoxelNeck BasicBlock3dV2.conv1 of a down layer (necks/imvoxelnet.py:237)
+    (1, (10, 10, 4), 512, 512, (1, 1, 1), True),       # Atlas encoder, coarsest level: 400 positions, below the Winograd form's minimum
+])
+def test_fusedconv_split_operand_rule(ia, case, monkeypatch):
+    """FusedConv's default rule (conv.py pair_mode = -1; csrc/model.cpp plan_conv): 3x3x3 layers the Winograd form does not take run as split pass +
+    three-product bf16 MFMA kernel when the neck's GEMMs use 16-bit operands, and on fp32 MFMA otherwise; both against torch fp64."""
+    from imvoxelnet_amd.conv import FusedConv
+    B, (D, H, W), ci, co, st, use_res = case
+    g = torch.Generator().manual_seed(ci + co)
+    x = torch.randn(B, D, H, W, ci, generator=g).abs_()
+    w = torch.randn(co, ci, 3, 3, 3, generator=g) * (2.0 / (ci * 27)) ** 0.5
+    bn = (torch.rand(co, generator=g) + .5, torch.randn(co, generator=g) * .1, torch.randn(co, generator=g) * .1, torch.rand(co, generator=g) + .5)
+    monkeypatch.setattr(FusedConv, 'pair_mode', -1)
+    f = FusedConv(w, bn=bn, stride=st, padding=1, relu=True, dims=3).to('cuda')
+    sc = bn[0] / torch.sqrt(bn[3] + 1e-5)
+    tref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).double(), w.double(), stride=st, padding=1).permute(0, 2, 3, 4, 1)
+    tref = tref * sc.double() + (bn[1] - bn[2] * sc).double()
+    res = torch.randn(tref.shape, generator=g) if use_res else None
+    if use_res:
+        tref = tref + res.double()
+    tref = tref.clamp_min(0)
+    rng = float(tref.abs().max())
+    out = {}
+    for opnd in (4, 0):
+        monkeypatch.setattr(FusedConv, 'wino_operands', opnd)
+        assert f.wino_tile(tuple(x.shape))[0] == 0
+        assert f.takes_pair_form(tuple(x.shape)) == (opnd == 4)
+        FusedConv.trace = []
+        y = f(x.cuda(), res.cuda() if use_res else None)
+        torch.cuda.synchronize()
+        kinds, FusedConv.trace = [t[0] for t in FusedConv.trace], None
+        assert kinds == (['pair_split', 'pair_gemm'] if opnd == 4 else ['direct'])
+        assert_close('FusedConv (%s) vs torch fp64' % ('split-operand form' if opnd else 'fp32 MFMA'), y, tref.float(), 0, (2e-5 if opnd else 2e-6) * rng)
+        out[opnd] = y
+    assert not torch.equal(out[4], out[0])
+    # what the rule leaves alone: 1x1x1 layers, narrow outputs (the Cout = 25 head convs), 2-D layers, tensors under SPLIT_MIN_POS positions
+    monkeypatch.setattr(FusedConv, 'wino_operands', 4)
+    assert not FusedConv(torch.zeros(128, 64, 1, 1, 1), dims=3).to('cuda').takes_pair_form((1, 40, 40, 16, 64))
+    assert not FusedConv(torch.zeros(25, 64, 3, 3, 3), padding=1, dims=3).to('cuda').takes_pair_form((1, 40, 40, 16, 64))
+    assert not FusedConv(torch.zeros(64, 64, 3, 3), padding=1, dims=2).to('cuda').takes_pair_form((1, 1, 40, 40, 64))
+    assert not f.takes_pair_form((1, 5, 5, 4, ci))
+
+
 def test_conv_pair_refusals(ia):
     from imvoxelnet_amd import ops
     assert not ops.conv_pair_supported((1, 4, 4, 4, 24), 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), 0)      # Cin % 16

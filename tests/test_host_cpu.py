@@ -1504,6 +1504,18 @@ def test_pair_operand_host_side_without_gpu(monkeypatch):
         assert FusedConv(torch.zeros(40, 40, 3, 3, 3), padding=1)._wino_operands(6) == 0
         FusedConv.wino_operands = 0
         assert f._wino_operands(6) == 0
+        # ... and which layers the split-operand (bf16 pair) form takes by default (conv.py pair_mode = -1; csrc/model.cpp plan_conv): 3x3x3, Cin % 32 == 0,
+        # Cout >= 64, from SPLIT_MIN_POS positions on, only next to 16-bit Winograd-domain operands (the caller asks after the Winograd form refused)
+        assert FusedConv.pair_mode == -1 and FusedConv.SPLIT_MIN_POS == 256
+        s2 = FusedConv(torch.zeros(128, 64, 3, 3, 3), stride=2, padding=1).to('cpu')
+        assert s2._split_cand and s2.wp is not None and s2.wp.dtype == torch.bfloat16 and tuple(s2.wp.shape) == (128, 2, 3, 3, 3, 64)
+        assert not s2.takes_pair_form((1, 40, 40, 16, 64))            # fp32 operands in the Winograd domain: fp32 MFMA here too
+        FusedConv.wino_operands = ops.IVX_F16_PAIR
+        assert s2.takes_pair_form((1, 40, 40, 16, 64)) and not s2.takes_pair_form((1, 6, 6, 4, 64)) and not s2.takes_pair_form((1, 40, 40, 16, 64), naive=True)
+        for wz, kw in ((torch.zeros(128, 64, 1, 1, 1), {}), (torch.zeros(25, 64, 3, 3, 3), dict(padding=1)), (torch.zeros(64, 48, 3, 3, 3), dict(padding=1)),
+                       (torch.zeros(64, 64, 3, 3), dict(padding=1, dims=2))):
+            fz = FusedConv(wz, **kw).to('cpu')
+            assert not fz._split_cand and fz.wp is None and not fz.takes_pair_form((1, 1 if wz.dim() == 4 else 40, 40, 16, wz.shape[1]))
     finally:
         FusedConv.wino_operands = old
     # the operand-type fields of the handle's configuration are validated
