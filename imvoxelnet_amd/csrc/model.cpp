@@ -727,7 +727,8 @@ int pack_layer(ivx_model *m, ConvLayer &L, hipStream_t st, std::string *missing)
   }
   // Split-operand form (conv.py FusedConv: _split_cand / pack_pair_weights): every fp32 filter as hi = bf16(w), lo = bf16(w - hi), per 16 channels
   // [hi x16 | lo x16], chunk-major [Cout, 2 Cin / 64, taps, 64]
-  L.split_cand = !bf16 && m->cfg.wino_operands == IVX_F16_PAIR && L.dims == 3 && kd == 3 && kh == 3 && kw == 3 && !L.conv_t && !L.linear && !L.dcn_cols &&
+  static const bool split_rule = !(getenv("IVX_CONV_PAIR") && atoi(getenv("IVX_CONV_PAIR")) == 0);      // IVX_CONV_PAIR=0: off in both hosts (A/B)
+  L.split_cand = split_rule && !bf16 && m->cfg.wino_operands == IVX_F16_PAIR && L.dims == 3 && kd == 3 && kh == 3 && kw == 3 && !L.conv_t && !L.linear && !L.dcn_cols &&
                  L.cin_pad == L.cin && L.cin % 32 == 0 && L.cout >= 64;
   if (L.split_cand) {
     std::vector<uint16_t> wb(2 * n_w);

@@ -26,6 +26,11 @@ for c in nuscenes sunrgbd_fast scannet_fast scannet_v1; do python bench.py --con
 python bench.py --config scannet_v1 --steps 10 --warmup 3 --storage bf16 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl
 python bench.py --config scannet_v1 --steps 10 --warmup 3 --storage bf16 --trunk-fp8 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl
 python bench.py --config scannet_v1 --steps 10 --warmup 3 --storage bf16 --trunk-fp8 --fp8-variant full 2>/dev/null | tail -1 >> $OUT/other_bf16.jsonl
+# A/B of the split-operand form of the non-Winograd 3x3x3 neck layers + K split of the narrow head convs (round 6, last change) inside the whole step
+for c in nuscenes sunrgbd_fast scannet_fast scannet_v1; do IVX_CONV_PAIR=0 IVX_CONV_SKINNY=0 python bench.py --config $c --steps 10 --warmup 3 2>/dev/null | tail -1 >> $OUT/other_no_split_form.jsonl; done
+for c in scannet_v1 scannet_fast sunrgbd_fast nuscenes; do python tools/neck_layers.py --config $c --min-pos 256 > $OUT/neck_layers_$c.md 2>/dev/null; done
+# the round-5 placement of the stage events (an event pair around every launch group of the timed steps)
+IVX_BENCH_TRACE_TIMED=1 $NOX python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_events_in_timed_region.json
 # kernel traces
 trace() {   # name, steps-profiled, bench args...
   name=$1; nst=$2; shift 2

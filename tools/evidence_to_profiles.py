@@ -16,7 +16,10 @@ COPIES = (('kernel_trace_kitti.md', 'bench_kernel_trace.md'), ('kernel_trace_sca
           ('pmc_nuscenes.md', 'pmc_nuscenes.md'), ('pmc_nuscenes.json', 'pmc_nuscenes.json'),
           ('other.jsonl', 'bench_other_configs.jsonl'), ('other_f32_operands.jsonl', 'bench_other_configs_f32_operands.jsonl'),
           ('other_bf16.jsonl', 'bench_other_configs_bf16.jsonl'), ('trunk_layers_kitti.md', 'trunk_layers_kitti.md'),
-          ('trunk_layers_scannet_v1.md', 'trunk_layers_scannet_v1.md'), ('host.txt', 'host.txt'))
+          ('trunk_layers_scannet_v1.md', 'trunk_layers_scannet_v1.md'), ('host.txt', 'host.txt'),
+          ('other_no_split_form.jsonl', 'bench_other_configs_no_split_form.jsonl'), ('neck_layers_scannet_v1.md', 'neck_layers_scannet_v1.md'),
+          ('neck_layers_scannet_fast.md', 'neck_layers_scannet_fast.md'), ('neck_layers_sunrgbd_fast.md', 'neck_layers_sunrgbd_fast.md'),
+          ('neck_layers_nuscenes.md', 'neck_layers_nuscenes.md'))
 
 
 def load(E, f):
@@ -40,6 +43,7 @@ def main():
             ('`IVX_FUSE_BOTTLENECK=0` (the five identity blocks of stages 1-2 as three launches each)', 'bench_no_fused_bottleneck.json'),
             ('`IVX_FUSE_STEM=0` (layout change, fp32-MFMA stem, max-pool as three launches)', 'bench_no_fused_stem.json'),
             ('`IVX_FUSE_STEM=0 IVX_FUSE_BOTTLENECK=0` (the round-5 trunk)', 'bench_no_fusion.json'),
+            ('`IVX_BENCH_TRACE_TIMED=1` (round-5 placement of the stage events: a pair around every launch group of the TIMED steps)', 'bench_events_in_timed_region.json'),
             ('--storage bf16 (optional reduced-precision mode; NOT the headline)', 'bench_bf16.json'),
             ('IVX_BENCH_FORCE_DIST=1 under torch.distributed.run, world size 1 (RCCL all-gather in every step)', 'bench_dist1.json'),
             (f'the run under rocprofv3 --kernel-trace --stats (profiles/{pre}_bench_kernel_trace.md)', 'bench_profiled_kitti.json')]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-launch table of the 3-D neck + head convolutions as the layer-by-layer host runs them (FusedConv.trace events), with the split-operand
-form of the layers the Winograd form does not take (strided, 1x1x1, head convs) switched off and on:
+form of the layers the Winograd form does not take switched off and on (default rule of conv.py; --all: every 3-D layer, the round-3 opt-in):
   python tools/neck_layers.py [--config scannet_v1|scannet_fast|sunrgbd_fast|nuscenes|kitti] [--top 40]"""
 import argparse
 import collections
@@ -49,7 +49,8 @@ def table(config, pair_mode, top, reps=5):
     rows = [(k, v[0] / reps, v[1] / reps, v[2] / reps, v[3] / reps) for k, v in agg.items()]
     total = sum(r[2] for r in rows)
     other = sum(r[2] for r in rows if not r[0][1].startswith('wino_'))
-    print(f'\n# {config}, split-operand form {"on" if pair_mode else "off"}: {total:.3f} ms of conv-stage time per step, {other:.3f} ms outside the Winograd form')
+    form = {0: 'off', 1: 'on (every 3-D layer with Cin % 32 == 0)', -1: 'by the default rule'}[pair_mode]
+    print(f'\n# {config}, split-operand form {form}: {total:.3f} ms of conv-stage time per step, {other:.3f} ms outside the Winograd form')
     print('| layer shape | stage | launches | ms/step | TFLOP/s executed | GB/s algorithmic |')
     print('|---|---|---|---|---|---|')
     for (desc, kind), n, ms, fl, by in sorted(rows, key=lambda r: -r[2])[:top]:
@@ -63,11 +64,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', default='scannet_v1')
     ap.add_argument('--top', type=int, default=40)
-    ap.add_argument('--min-pos', type=int, default=2000, help='FusedConv.pair_min_pos: fewest output positions the split-operand form takes')
+    ap.add_argument('--min-pos', type=int, default=2000, help='FusedConv.pair_min_pos: fewest positions the split-operand form takes with --all')
+    ap.add_argument('--all', action='store_true', help='second table with IVX_CONV_PAIR=1 (every 3-D layer with Cin %% 32 == 0) instead of the default rule')
     a = ap.parse_args()
     FusedConv.pair_min_pos = a.min_pos
     o0 = table(a.config, 0, a.top)
-    o1 = table(a.config, 1, a.top)
+    o1 = table(a.config, 1 if a.all else -1, a.top)
     f0 = o0 if isinstance(o0, (list, tuple)) else [o0]
     f1 = o1 if isinstance(o1, (list, tuple)) else [o1]
 
