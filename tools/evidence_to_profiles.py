@@ -78,6 +78,11 @@ def main():
         for l in open(os.path.join(E, 'other_no_fusion.jsonl')):
             r = json.loads(l)
             out.append(f"| {r['config']['workload']} x{r['config'].get('views')} views | {r['value']} | {r['ms_per_step']} | {(r.get('roofline_trunk_2d') or {}).get('ms_per_step')} |")
+    if os.path.exists(os.path.join(E, 'other_no_split_form.jsonl')):
+        out += ['', '| workload, `IVX_CONV_PAIR=0 IVX_CONV_SKINNY=0` (the 3x3x3 neck layers outside the Winograd form on fp32 MFMA, no K split for the Cout <= 32 head convs: before the last change of round 6) | images/s | ms/scene | neck ms |', '|---|---|---|---|']
+        for l in open(os.path.join(E, 'other_no_split_form.jsonl')):
+            r = json.loads(l)
+            out.append(f"| {r['config']['workload']} x{r['config'].get('views')} views | {r['value']} | {r['ms_per_step']} | {(r.get('roofline') or {}).get('neck_ms_per_step')} |")
     if os.path.exists(os.path.join(E, 'other_bf16.jsonl')):
         out += ['', '| optional storage mode | images/s | ms/scene |', '|---|---|---|']
         for l in open(os.path.join(E, 'other_bf16.jsonl')):
