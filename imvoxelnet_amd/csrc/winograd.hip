@@ -102,6 +102,24 @@ __global__ __launch_bounds__(256) void wino_amax_partials_kernel(const float *__
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// The same reduction by ONE workgroup that WRITES hdr[0]: no zeroing launch in front of it (round 6: the 4-byte hipMemsetAsync + the 64-block
+// reduction were two ~5 us launches in front of every input transform of the chained neck; up to 65536 maxima = 256 KB, a few us from L2).
+__global__ __launch_bounds__(1024) void wino_amax_partials_write_kernel(const float *__restrict__ part, int n, unsigned *out) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (int t = threadIdx.x; t < n; t += 1024) m = fmaxf(m, part[t]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    m = threadIdx.x < 16 ? red[threadIdx.x] : 0.f;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (threadIdx.x == 0) *out = __float_as_uint(m);
+  }
+}
+
 // max |x| over a tensor into hdr[0] (zeroed by the caller): non-negative floats order like their bit patterns.  A read-only stream:
 // four independent 16-byte loads per lane and iteration keep enough bytes in flight for HBM (one load per iteration ran at 2.6 TB/s).
 typedef float wf32x4 __attribute__((ext_vector_type(4)));
@@ -803,11 +821,15 @@ static int wino_input_impl(const ivx_conv_desc *d, int32_t tile, const void *in,
   if (rc != IVX_OK) return rc;
   if (d->wino_operands == IVX_F16_PAIR) {
     // max |input| -> header word 0 (the scale of V is derived from it on the device: no host round trip)
-    if (hipMemsetAsync((void *)p.hdr, 0, 4, (hipStream_t)stream) != hipSuccess) {
+    static const bool one_wg = !(getenv("IVX_WINO_AMAX_ONE_WG") && atoi(getenv("IVX_WINO_AMAX_ONE_WG")) == 0);      // =0: the round-5 pair of launches (A/B)
+    const bool write_form = partials && n_partials <= 65536 && one_wg;
+    if (!write_form && hipMemsetAsync((void *)p.hdr, 0, 4, (hipStream_t)stream) != hipSuccess) {
       ivx_set_error("ivx_conv_winograd_input: hipMemsetAsync failed");
       return IVX_ERR_HIP;
     }
-    if (partials) {   // the producer left per-workgroup maxima of this tensor (ivx_conv_winograd_output_amax): reduce those (1 - 2 MB at KITTI size)
+    if (write_form) {   // the producer's per-workgroup maxima, reduced by one workgroup that writes the word
+      hipLaunchKernelGGL(wino_amax_partials_write_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, n_partials, (unsigned *)p.hdr);
+    } else if (partials) {   // the producer left per-workgroup maxima of this tensor (ivx_conv_winograd_output_amax): reduce those (1 - 2 MB at KITTI size)
       const int pb = (n_partials + 255) / 256;
       hipLaunchKernelGGL(wino_amax_partials_kernel, dim3((unsigned)(pb > 64 ? 64 : pb)), dim3(256), 0, (hipStream_t)stream, partials, n_partials,
                          (unsigned *)p.hdr);

@@ -44,11 +44,13 @@ class direct_conv_only:
     def __enter__(self):
         from imvoxelnet_amd.conv import FusedConv
         self._old, FusedConv.winograd = FusedConv.winograd, False
+        self._old_pair, FusedConv.pair_mode = FusedConv.pair_mode, 0      # ... and not the split-operand form of the 3x3x3 layers (conv.py pair_mode)
         return self
 
     def __exit__(self, *exc):
         from imvoxelnet_amd.conv import FusedConv
         FusedConv.winograd = self._old
+        FusedConv.pair_mode = self._old_pair
         return False
 
 
