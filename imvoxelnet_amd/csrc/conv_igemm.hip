@@ -89,6 +89,10 @@ struct ConvParams {
   // the output transform reads -- was a 4-byte hipMemcpyAsync, i.e. one more launch per neck layer); NULL = none
   const unsigned *cp_src;
   unsigned *cp_dst;
+  // Phase stagger of the first round of workgroups (pair-IO launches with a residual epilogue, run_conv): workgroups whose XCD-local index q has bit
+  // stagger_shift set and q < stagger_first wait stagger_ticks (100 MHz) before their first request, so that the K loops of one half of the resident
+  // workgroups overlap the epilogues of the other half for the rest of the launch.  0 ticks = off.
+  int stagger_ticks, stagger_shift, stagger_first;
 #ifdef IVX_CONV_TIMELINE
   unsigned long long *tl;        // debug build only (tools/conv_timeline.py): 8 words per workgroup of conv_igemm_v4_kernel's pair-IO path --
                                  // s_memrealtime (100 MHz) at entry, after the prologue barrier, after the K loop, at the end; HW_ID; XCC_ID
@@ -837,6 +841,15 @@ __global__ __launch_bounds__(64 * WR * WC, WPE) void conv_igemm_v4_kernel(const 
 #ifdef IVX_CONV_TIMELINE
   unsigned long long tl0 = __builtin_amdgcn_s_memrealtime(), tl1 = 0, tl2 = 0;
 #endif
+  if constexpr (PAIR == 2) {
+    if (p.stagger_ticks > 0) {      // (uniform per workgroup)
+      const unsigned q = blockIdx.x >> 3;
+      if (q < (unsigned)p.stagger_first && ((q >> p.stagger_shift) & 1u)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+      }
+    }
+  }
 
   const size_t gz = blockIdx.z;   // group of a grouped launch (strides are 0 otherwise)
   const __amdgpu_buffer_rsrc_t rs_in =
@@ -1432,6 +1445,7 @@ static int fill_params(const ivx_conv_desc *d, const void *in, const void *wgt, 
   p->out_mode = d->out_mode; p->Cr = d->out_mode == 1 ? d->Cout / 8 : d->Cout; p->res_after_act = d->res_after_act;
   p->post_scale = d->post_scale == 0.f ? 1.0f : d->post_scale;
   p->ksplit = 1; p->partial = nullptr; p->q_total = 0; p->q_begin = 0; p->q_count = 0; p->bm = 0;
+  p->stagger_ticks = 0; p->stagger_shift = 0; p->stagger_first = 0;
   p->groups = 1; p->g_in = p->g_w = p->g_out = 0;
   p->narrow_epilogue = g_narrow_epilogue;
 #ifdef IVX_CONV_TIMELINE
@@ -1737,6 +1751,21 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
         static const long long w16_tiles = getenv("IVX_PIO_W16_TILES") ? atoll(getenv("IVX_PIO_W16_TILES")) : 256;
         static const long long w8_tiles = getenv("IVX_PIO_W8_TILES") ? atoll(getenv("IVX_PIO_W8_TILES")) : 512;
         if (pl.cfg == 174) pl.cfg = tl <= w16_tiles ? 179 : (tl <= w8_tiles ? 177 : 174);
+        small = false;
+      }
+    }
+    // Round 6: the 256 x 256 tile on 16 waves (183: three-buffer ring, one workgroup per CU; built for the neck's last layer) for the wide layers of the
+    // multi-view maps -- half the L2 -> LDS bytes per product of the 128 x 128 tile.  It wins where its tiles fill the 256 CUs in whole rounds: interleaved
+    // A/B over the trunk's layers at 50 / 20 ScanNet views, nuScenes and KITTI (tools/pio_ab.py --cfgs 0,74,81,82,183; profiles/r06_tile183_trunk.md):
+    // 235 - 1876 tiles at 50 views -5 .. -19 % per launch (1024 -> 256 0.141 -> 0.114 ms, 256 -> 256 3x3 0.239 -> 0.202, 256 -> 1024 + residual 0.225 -> 0.215),
+    // 272 tiles (1.06 rounds) +4 .. +10 %, 94 - 136 tiles +30 %; the nearest-upsampled FPN laterals lose 4 %.  Rule: last-round fill of the 256 x 256 grid
+    // >= 0.7.  Same products in the same order per output: bit-identical.  IVX_PIO_T183=0 turns it off (A/B).
+    static const int pio_t183 = getenv("IVX_PIO_T183") ? atoi(getenv("IVX_PIO_T183")) : 1;
+    if (pio_t183 && pl.cfg == 74 && p.in_pair == 2 && p.kmode == 1 && p.res_mode != 2 && p.Cout >= 256 && p.Cout % 256 == 0) {
+      const long long t256 = (long long)((p.M + 255) / 256) * (p.Cout / 256);
+      const long long rounds = (t256 + 255) / 256;
+      if (t256 * 10 >= rounds * 256 * 7) {
+        pl.cfg = 183;
         small = false;
       }
     }
@@ -2766,6 +2795,18 @@ static int run_conv(ConvParams &p, const ConvPlan &pl, void *workspace, hipStrea
   if (p.kmode == 1 && (!dma_applicable(p) || pl.cfg < 40)) {
     ivx_set_error("ivx_conv_fwd: wgt_layout 1 is only implemented by the LDS-DMA kernel (tensor < 2 GiB, kernel extents <= 8)");
     return IVX_ERR_UNSUPPORTED;
+  }
+  p.stagger_ticks = 0;
+  if (p.pio && p.res_mode == 1 && pl.ksplit <= 1 && pl.tail_ks <= 1 && tile_info(pl.cfg, &ti)) {
+    // (experiment, default off: IVX_PIO_STAGGER_US = delay in us, IVX_PIO_STAGGER_SHIFT = which bit of the XCD-local workgroup index picks the late half)
+    static const int st_us = getenv("IVX_PIO_STAGGER_US") ? atoi(getenv("IVX_PIO_STAGGER_US")) : 0;
+    static const int st_sh = getenv("IVX_PIO_STAGGER_SHIFT") ? atoi(getenv("IVX_PIO_STAGGER_SHIFT")) : 0;
+    const long long tiles = (long long)((p.M + ti.bm - 1) / ti.bm) * ((p.Cout + ti.bn - 1) / ti.bn);
+    if (st_us > 0 && tiles >= 2LL * 256 * ti.wg_per_cu) {
+      p.stagger_ticks = st_us * 100;
+      p.stagger_shift = st_sh;
+      p.stagger_first = 32 * ti.wg_per_cu;
+    }
   }
   int rc;
   if (pl.tail_ks > 1) {

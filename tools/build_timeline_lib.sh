@@ -17,5 +17,5 @@ done
 wait
 cd "$CSRC"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/bin/libimvoxel_hip_tl.so" "$TMP/tu0.o" conv_igemm_f32.o conv_igemm_lowp.o \
-  conv_igemm_pair_bf16.o "$TMP/tu4.o" "$TMP/tu5.o" "$TMP/bottleneck.o" "$TMP/stem.o" "$TMP/winograd.o" pool_layout.o backproject.o anchor_tail.o dcn.o ubench.o api_common.o kitti_eval.o model.o
+  conv_igemm_pair_bf16.o "$TMP/tu4.o" "$TMP/tu5.o" "$TMP/bottleneck.o" "$TMP/stem.o" "$TMP/winograd.o" pool_layout.o backproject.o anchor_tail.o dcn.o fold4w.o ubench.o api_common.o kitti_eval.o model.o
 echo "$ROOT/tools/bin/libimvoxel_hip_tl.so"

@@ -25,6 +25,7 @@ def q(t, f):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cfgs', default='0,74')
+    ap.add_argument('--views50', action='store_true', help='the expanding 1x1 + residual layers and their neighbours at 50 ScanNet views (batch 50, 480 x 640 image)')
     a = ap.parse_args()
     L = _lib.lib()
     L.ivx_conv_set_timeline.argtypes = [C.c_void_p]
@@ -32,11 +33,15 @@ def main():
               (48, 160, 128, 512, 1, True), (48, 160, 512, 128, 1, False), (48, 160, 128, 128, 3, False),
               (24, 80, 256, 1024, 1, True), (24, 80, 1024, 256, 1, False), (24, 80, 256, 256, 3, False),
               (12, 40, 512, 2048, 1, True), (12, 40, 2048, 512, 1, False), (12, 40, 512, 512, 3, False)]
+    batch = 4
+    if a.views50:
+        batch = 50
+        shapes = [(60, 80, 128, 512, 1, True), (30, 40, 256, 1024, 1, True), (30, 40, 1024, 256, 1, False), (30, 40, 256, 256, 3, False), (15, 20, 512, 2048, 1, True)]
     for (h, w, ci, co, k, res) in shapes:
-        args, keep = ps.build(4, h, w, ci, co, k, True, True, res)
+        args, keep = ps.build(batch, h, w, ci, co, k, True, True, res)
         for cfg in [int(c) for c in a.cfgs.split(',')]:
             L.ivx_conv_set_tile_override(cfg)
-            buf = torch.zeros(1 << 16, 8, dtype=torch.int64, device='cuda')
+            buf = torch.zeros(1 << 17, 8, dtype=torch.int64, device='cuda')
             try:
                 for _ in range(3):
                     L.ivx_conv_fwd_pio(*args)
