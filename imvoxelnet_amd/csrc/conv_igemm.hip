@@ -1799,6 +1799,11 @@ static ConvPlan plan_conv(const ConvParams &p, bool allow_ws) {
     return pl;
   }
   // tail plan
+  // (Round 6: not for pair IO.  At 16-bit MFMA rates a tile is short: the second launch + the partial sums' round trip + the reduction cost more than
+  // the idle slots of the last round -- the same layers run 5 - 12 % faster as ONE launch (tools/pio_ab.py, cfg 0 vs the same tile forced:
+  // nuScenes 512 -> 1024 s2 0.177 -> 0.156 ms, 256 -> 512 s2 0.215 -> 0.195, 256 -> 128 0.257 -> 0.235; profiles/r06_tile183_trunk.md (c)).  IVX_PIO_TAIL=1 restores it.)
+  static const int pio_tail = getenv("IVX_PIO_TAIL") ? atoi(getenv("IVX_PIO_TAIL")) : 0;
+  if (p.pio && !pio_tail) return pl;
   const long long spx = 32LL * t.wg_per_cu;              // workgroup slots per XCD
   const long long bpx = (long long)pl.q_total * Nt;      // workgroups per XCD
   const long long fr = bpx / spx, rem = bpx - fr * spx;
