@@ -6,6 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 mkdir -p $ROOT/$OUT
 cd $ROOT
+if [ "$EVIDENCE_PROFILES_ONLY" != "1" ]; then
 nproc > $OUT/host.txt; lscpu | grep -E "Model name|Socket|Core|Thread" >> $OUT/host.txt
 python bench.py --steps 20 --warmup 5 2>$OUT/bench.err | tail -1 > $OUT/bench_default.json
 NOX="env IVX_BENCH_EXTRA=0"
@@ -31,10 +32,11 @@ for c in nuscenes sunrgbd_fast scannet_fast scannet_v1; do IVX_CONV_PAIR=0 IVX_C
 for c in scannet_v1 scannet_fast sunrgbd_fast nuscenes; do python tools/neck_layers.py --config $c --min-pos 256 > $OUT/neck_layers_$c.md 2>/dev/null; done
 # the round-5 placement of the stage events (an event pair around every launch group of the timed steps)
 IVX_BENCH_TRACE_TIMED=1 $NOX python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_events_in_timed_region.json
-# kernel traces
+fi   # EVIDENCE_PROFILES_ONLY
+# kernel traces (IVX_BENCH_TRACE_TIMED=1: the profiled process runs exactly warmup + steps model steps, no traced steps after the timed region)
 trace() {   # name, steps-profiled, bench args...
   name=$1; nst=$2; shift 2
-  (cd /tmp && IVX_BENCH_ALT=0 IVX_BENCH_EXTRA=0 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace_$name -o t -- python $ROOT/bench.py --no-cpu-baseline "$@" > $ROOT/$OUT/trace_$name.log 2>&1)
+  (cd /tmp && IVX_BENCH_ALT=0 IVX_BENCH_EXTRA=0 IVX_BENCH_TRACE_TIMED=1 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace_$name -o t -- python $ROOT/bench.py --no-cpu-baseline "$@" > $ROOT/$OUT/trace_$name.log 2>&1)
   grep '^{"metric' $OUT/trace_$name.log | tail -1 > $OUT/bench_profiled_$name.json
   DB=$(find $OUT/trace_$name -name "*.db" | head -1)
   [ -n "$DB" ] && python tools/rocpd_summary.py $DB $nst > $OUT/kernel_trace_$name.md
