@@ -2951,7 +2951,13 @@ int ivx_conv_grouped_launch(const ivx_conv_desc *d, int groups, const float *in,
     // 125 x 64 0.487 / 0.756 / 1.410 (= 10), 253 x 128 0.597 / 0.644 / 1.144 (13: 0.607 / 0.653 / 1.167); bit-identical results
     // round 4, z-blocked tiles for 3-slice columns (50: a tap outside the column is skipped instead of multiplied by zeros: 7 of 9
     // tap-slices): 256 -> 256 at 216 x 248 x 3 0.99 vs 1.135-1.15 ms, bit-identical; at 6 slices (60) 0.626-0.651 vs 0.637-0.650: a wash
-    const int cfg = g_halo_mode > 0 ? g_halo_mode : (p.Cout <= 64 ? 30 : (zblk_rule(p) ? 50 : 33));
+    // round 6: small volumes (the indoor necks: 200 .. 1600 rows per Winograd position).  The 253 x 128 tile on 8 waves leaves most CUs idle there --
+    // 72 workgroups for 256 -> 256 at 20 x 20 x 8 -- and the 125 x 64 tile at four per CU wins for every Cout: 0.073 -> 0.050 ms (12 launches per ScanNet v1
+    // step), 512 -> 512 0.208 -> 0.163, 128 -> 128 at 40 x 40 x 16 0.037 -> 0.033 (tools/neck_halo_ab.py, profiles/r06_halo_small_volumes.md); bit-identical
+    // results.  Rule: fewer workgroups of the 253 x 128 tile than the chip has slots for them (512).  IVX_HALO_SMALL=0 turns it off (A/B).
+    static const int halo_small = getenv("IVX_HALO_SMALL") ? atoi(getenv("IVX_HALO_SMALL")) : 1;
+    const bool few = halo_small && p.Cout > 64 && !zblk_rule(p) && (long long)((p.M + 252) / 253) * ((p.Cout + 127) / 128) * groups < 512;
+    const int cfg = g_halo_mode > 0 ? g_halo_mode : ((p.Cout <= 64 || few) ? 30 : (zblk_rule(p) ? 50 : 33));
     return ivx_conv_launch_halo(p, cfg, st);
   }
   ConvPlan pl = {g_tile_override, 1, 1, 0, 0, 0, 0};
